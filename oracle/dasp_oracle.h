@@ -1,0 +1,109 @@
+/*
+ * oracle/dasp_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of the DASP SpMV hot path of the reference
+ * (/root/reference, SuperScientificSoftwareLaboratory/DASP), used as the parity
+ * checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ * Nothing under dasp_amd/ may include, link or call this.
+ *
+ * PINNING STATUS: "parity unpinned" for the classifier / packers / y.
+ *   - The reference holds no tests, fixtures or golden vectors (test/ only has
+ *     two run scripts whose input .mtx is not in the tree).
+ *   - Its hot path cannot be compiled here: src/common.h:15-16 includes
+ *     <cusparse.h> and <cublas_v2.h>, which this image lacks, and writing
+ *     stand-ins is not allowed.  Only src/mmio.h is self-contained; it is built
+ *     by oracle/Makefile into oracle/_ref/libref_mmio.so and pins the banner and
+ *     size-line parsing of this file (tests/test_oracle_ref.py).
+ *   - radix_sort is pinned by the known-answer vector the survey recorded from a
+ *     run of the real code.
+ *   - Everything else is pinned only through the reference's own identities:
+ *     y[i] == nnz(row order_rid[i]) when A == 1 and x == 1 (src/utils.h:93-100,
+ *     src/main_f64.cu:131-132) and
+ *     nnz_short + nnz_long + origin_nnz_reg + nnz_irreg == nnzA (dasp_f64.h:1091).
+ */
+#ifndef DASP_ORACLE_H
+#define DASP_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- loader: src/mmio_highlevel.h:608-774, src/mmio.h:398-624 ------------- */
+/* typecode[4] as in mmio.h (M, C|A, R|C|P|I, G|S|H|K). returns mmio.h codes:
+ * 0 ok, 12 premature EOF, 14 no header, 15 unsupported type. */
+int oracle_mm_read_banner(const char *path, char typecode[4]);
+/* reads banner then size line; returns 0 or mmio.h code. */
+int oracle_mm_read_size(const char *path, int *M, int *N, int *nz);
+/* returns 0, -1 (open), -2 (banner), -4 (size line) like mmio_allinone.
+ * arrays are malloc'd; free with oracle_free. values as double. */
+int oracle_mmio_allinone(const char *path, int *m, int *n, int *nnz, int *is_symmetric,
+                         int **row_ptr, int **col_idx, double **val);
+void oracle_free(void *p);
+
+/* ---- utilities ----------------------------------------------------------- */
+void oracle_exclusive_scan(int *a, int len);           /* mmio_highlevel.h:10-25 */
+void oracle_radix_sort_desc(int *key, int *idx, int len); /* utils.h:118-160,196-203 */
+void oracle_init_vec_f64(double *v, int len);           /* utils.h:93-100 */
+
+/* ---- CSR SpMV (the reference has none; canonical row loop dasp_f64.h:189-192) */
+void oracle_csr_spmv_f64(int m, const int *row_ptr, const int *col_idx, const double *val,
+                         const double *x, double *y);
+/* sum_j |a_ij x_j| per row: scale for the relative-error bound */
+void oracle_csr_absrow_f64(int m, const int *row_ptr, const int *col_idx, const double *val,
+                           const double *x, double *s);
+/* rounds a double to the nearest IEEE binary16 value (ties to even), returned as double */
+double oracle_round_f16(double v);
+
+/* ---- DASP packed format in the REFERENCE geometry ------------------------- */
+typedef struct oracle_dasp {
+    int precision;              /* 64 or 16 */
+    int rowA, colA, nnzA;
+    /* classifier (dasp_f64.h:499-607 / dasp_f16.h:1029-1137); short_row_1/3 are AFTER pairing */
+    int row_long, row_block, row_zero, rowloop;
+    int short_row_1, short_row_2, short_row_3, short_row_4, common_13;
+    int short_row_34;
+    int nnz_short, nnz_long, origin_nnz_reg, nnz_irreg;
+    /* padded sizes */
+    int fill0_nnz_short13, fill0_nnz_short34, fill0_nnz_short22, fill0_nnz_short;
+    int fill0_nnz_long, fill0_nnz_reg;
+    int threadblock13, threadblock34, threadblock22;
+    int blocknum, warp_number, BlockNum_long;
+    int offset_short1;          /* element offset of the len-1 segment inside short_* (0 for f64) */
+    long long data_X;           /* dasp_f64.h:1162-1166 / dasp_f16.h (sizeof(val) = 8 or 2) */
+    double rate_fill0;
+    /* arrays (malloc'd) */
+    int *order_rid;             /* [rowA]            dasp_f64.h:960-976 / dasp_f16.h:1253-1270 */
+    double *short_val; int *short_cid;   /* [fill0_nnz_short] */
+    double *long_val;  int *long_cid;    /* [fill0_nnz_long] */
+    int *long_rpt_new;          /* [row_long+1] in units of one warp's work */
+    double *reg_val;   int *reg_cid;     /* [fill0_nnz_reg] chunk-major tiles */
+    int *block_ptr;             /* [blocknum+1] */
+    double *irreg_val; int *irreg_cid;   /* [nnz_irreg] */
+    int *irreg_rpt;             /* [row_block+1] */
+} oracle_dasp_t;
+
+/* host preprocessing of spmv_all up to (not including) the first CUDA call.
+ * precision 64: dasp_f64.h:499-713,914,954-976,1000-1166; 16: dasp_f16.h:1029-1449.
+ * returns 0, or -1 on bad arguments. */
+int oracle_dasp_pack(int precision, int rowA, int colA, int nnzA,
+                     const int *row_ptr, const int *col_idx, const double *val,
+                     double threshold, int block_longest, oracle_dasp_t *out);
+void oracle_dasp_free(oracle_dasp_t *d);
+
+/* evaluates y (permuted order) from the packed arrays, following what the fused
+ * kernel + longPart_sum compute per category (dasp_f64.h:53-484, dasp_f16.h:106-590);
+ * all arithmetic in double (the f16 reference accumulates in half: not restated). */
+void oracle_dasp_eval(const oracle_dasp_t *d, const double *x, double *y_perm);
+
+/* accessors so ctypes users need not mirror the struct layout */
+int         oracle_dasp_int(const oracle_dasp_t *d, const char *name);
+const void *oracle_dasp_arr(const oracle_dasp_t *d, const char *name, int *len);
+oracle_dasp_t *oracle_dasp_new(void);
+
+/* FNV-1a 64 over an int array (fixture hashing) */
+unsigned long long oracle_fnv1a_i32(const int *a, long long len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
