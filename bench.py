@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py -- DASP SpMV on MI355X: GFLOP/s and achieved fraction of the HBM roofline.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N == 1 : one process, one GPU.
+  N  > 1 : launched by torch.distributed.run, one rank per GPU (RCCL).  The matrix is
+           partitioned by contiguous row ranges of equal nonzero count; every rank builds the
+           DASP plan of its slice (column ids remapped so that the all-gather buffer IS the next
+           x), one step = local SpMV + all-gather of y over xGMI.  Fixed total work => "strong".
+A step is one y = A*x over the whole matrix.  Input: the seeded synthetic stand-in of the
+SuiteSparse matrix named by --workload (no .mtx files / network on the bench machines), values
+and x all ones as in the reference's driver (src/main_f64.cu:131-132), so y[i] == nnz(row) is
+checked exactly after the timed region.
+Prints ONE JSON line on rank 0.  The GPU path has no CPU fallback: without a GPU this exits non-zero.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def algorithmic_bytes(m, n, nnz, vbytes):
+    """CSR read once + x read once + y written once: the reference's data_origin1 (main_f64.cu:143)."""
+    return (nnz + n + m) * vbytes + nnz * 4 + (m + 1) * 4
+
+
+def build_slice(D, name, scale, precision, r0, r1, lengths, bounds=None, stride=0, natural=False, threads=0):
+    rp, ci = D.synth_csr(name, scale, r0, r1, lengths=lengths[r0:r1])
+    rows, cols = D.synth_dims(name, scale)
+    dt = np.float64 if precision == 64 else np.float16
+    val = np.ones(ci.size, dt)                                  # initVec(csrValA): utils.h:93-100
+    t0 = time.time()
+    plan = D.Plan(rp, ci, val, cols, precision=precision, y_order=D.Y_NATURAL if natural else D.Y_PERMUTED,
+                  part_bounds=bounds, part_stride=stride, host_threads=threads)
+    pre_s = time.time() - t0
+    return plan, rp, ci, val, pre_s
+
+
+def time_plan(torch, plan, x, y, iters, warmup):
+    s = torch.cuda.current_stream().cuda_stream
+    return plan.time(x.data_ptr(), y.data_ptr(), s, warmup=warmup, iters=iters)
+
+
+def suite_entry(torch, D, name, precision, scale, budget_s=2.0):
+    """Reference protocol (100 warm-up + up to 1000 timed launches, dasp_f64.h:1285-1286) on one stand-in."""
+    rows, cols = D.synth_dims(name, scale)
+    lengths = D.synth_row_lengths(name, scale)
+    plan, rp, ci, val, pre_s = build_slice(D, name, scale, precision, 0, rows, lengths)
+    nnz = int(rp[-1])
+    del ci, val
+    plan.upload()
+    plan.drop_host()
+    tdt = torch.float64 if precision == 64 else torch.float16
+    x = torch.ones(cols, dtype=tdt, device="cuda")
+    y = torch.zeros(rows, dtype=tdt, device="cuda")
+    w, e = time_plan(torch, plan, x, y, 20, 10)
+    iters = int(max(20, min(1000, budget_s * 1e3 / max(e, 1e-4))))
+    w, e = time_plan(torch, plan, x, y, iters, min(100, iters))
+    order = torch.from_numpy(plan.order_rid.astype(np.int64)).cuda()
+    want = torch.from_numpy(np.diff(rp).astype(np.float64)).cuda()[order]
+    ok = bool((y.double() == want).all().item()) if precision == 64 or int(np.diff(rp).max()) <= 2048 else \
+        bool(((y.double() - want).abs() <= 1e-2 * want.clamp(min=1)).all().item())
+    st = plan.stats
+    b_alg = algorithmic_bytes(rows, cols, nnz, precision // 8)
+    out = {"workload": name, "dtype": "f64" if precision == 64 else "f16", "rows": rows, "nnz": nnz,
+           "ms": round(w, 6), "event_ms": round(e, 6), "iters": iters, "gflops": round(2.0 * nnz / (w * 1e6), 2),
+           "achieved_GBps": round(b_alg / (e * 1e6), 1), "frac_hbm_roofline": round(b_alg / (e * 1e6) / HBM_PEAK_GBPS, 4),
+           "rate_fill0": round(st["rate_fill0"], 4), "pre_ms": round(st["pre_ms"], 1), "verified": ok,
+           "row_long": st["row_long"], "row_block": st["row_block"],
+           "row_short": rows - st["row_long"] - st["row_block"] - st["row_zero"]}
+    plan.close()
+    del x, y
+    torch.cuda.empty_cache()
+    return out
+
+
+def cpu_baseline(O, rp, ci, n_cols, budget_s=20.0):
+    """Serial CSR SpMV (oracle/dasp_oracle.c, 1 thread) on the same CSR and x: a reported baseline."""
+    nnz = int(rp[-1])
+    val = np.ones(nnz, np.float64)
+    x = np.ones(n_cols, np.float64)
+    t = []
+    O.csr_spmv(rp, ci, val, x)
+    t0 = time.time()
+    while len(t) < 3 or (time.time() - t0 < budget_s and len(t) < 15):
+        a = time.perf_counter()
+        y = O.csr_spmv(rp, ci, val, x)
+        t.append(time.perf_counter() - a)
+    assert (y == np.diff(rp)).all()
+    med = float(np.median(t))
+    return {"value": round(2.0 * nnz / med / 1e9, 3), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "sample": "serial CSR loop over the full %d-row / %d-nnz workload matrix, median of %d passes" % (rp.size - 1, nnz, len(t)),
+            "ms": round(med * 1e3, 3), "host_cores_available": os.cpu_count(),
+            "achieved_GBps": round(algorithmic_bytes(rp.size - 1, n_cols, nnz, 8) / med / 1e9, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="HV15R")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--precision", type=int, default=64, choices=[64, 16])
+    ap.add_argument("--no-suite", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--suite-scale", type=float, default=1.0)
+    args = ap.parse_args()
+
+    import torch
+    import dasp_amd as D
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible; the DASP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    name, scale, prec = args.workload, args.scale, args.precision
+    vb = prec // 8
+    rows, cols = D.synth_dims(name, scale)
+    lengths = D.synth_row_lengths(name, scale)                      # every rank: cheap, deterministic
+    rp_full = np.zeros(rows + 1, np.int64)
+    np.cumsum(lengths, out=rp_full[1:])
+    nnz_total = int(rp_full[-1])
+    if world > 1:
+        # same rule as dasp_partition_rows (first row whose start >= g/world of the nonzeros), on int64 prefix sums
+        bounds = np.searchsorted(rp_full, nnz_total * np.arange(world + 1) // world, side="left").astype(np.int32)
+        bounds[0], bounds[-1] = 0, rows
+        bounds = np.maximum.accumulate(bounds)
+        stride = int(np.diff(bounds).max())
+        stride = (stride + 63) // 64 * 64
+    else:
+        bounds, stride = None, 0
+    r0, r1 = (0, rows) if world == 1 else (int(bounds[rank]), int(bounds[rank + 1]))
+    threads = max(1, (os.cpu_count() or 8) // max(1, world))
+    plan, rp, ci, val, pre_s = build_slice(D, name, scale, prec, r0, r1, lengths, bounds, stride, natural=world > 1, threads=threads)
+    del val
+    plan.upload()
+    plan.drop_host()
+    st = plan.stats
+    tdt = torch.float64 if prec == 64 else torch.float16
+    x = torch.ones(plan.x_len, dtype=tdt, device="cuda")
+    y = torch.zeros(max(stride, r1 - r0), dtype=tdt, device="cuda")
+    gathered = torch.zeros(world * stride, dtype=tdt, device="cuda") if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        plan.spmv(x.data_ptr(), y.data_ptr(), stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, y[:stride])   # RCCL over xGMI; `gathered` has the layout x is read in
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    region_event_ms = ev0.elapsed_time(ev1) / args.steps
+
+    # ---- exact check: values and x all ones => y == row length
+    want = torch.from_numpy(lengths[r0:r1].astype(np.float64)).cuda()
+    got = y[: r1 - r0].double()
+    if world == 1:
+        got_nat = torch.empty_like(got)
+        got_nat[torch.from_numpy(plan.order_rid.astype(np.int64)).cuda()] = got
+        got = got_nat
+    ok = bool((got == want).all().item()) if prec == 64 else bool(((got - want).abs() <= 1e-2 * want.clamp(min=1)).all().item())
+    if world > 1:
+        full = torch.cat([gathered[g * stride: g * stride + int(bounds[g + 1] - bounds[g])] for g in range(world)]).double()
+        ok = ok and bool((full == torch.from_numpy(lengths.astype(np.float64)).cuda()).all().item())
+        okt = torch.tensor([1 if ok else 0], device="cuda")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
+
+    # ---- dominant kernel alone: HIP events on the launch stream around back-to-back launches
+    k_iters = max(20, min(args.steps, 1000))
+    kw, ke = plan.time(x.data_ptr(), y.data_ptr(), stream, warmup=5, iters=k_iters)
+    nnz_local = int(rp[-1])
+    b_alg_local = algorithmic_bytes(r1 - r0, cols, nnz_local, vb)
+    b_alg_total = algorithmic_bytes(rows, cols, nnz_total, vb)
+    achieved = b_alg_local / (ke * 1e6)
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = 2.0 * nnz_total / (ms_per_step * 1e6)
+
+    out = {
+        "metric": "SpMV GFLOP/s (f64)" if prec == 64 else "SpMV GFLOP/s (f16)", "value": round(value, 2), "unit": "GFLOP/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 6),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64" if prec == 64 else "f16 (f32 accumulate)", "data": "synthetic",
+        "config": {"workload": "%s synthetic stand-in (seeded; SuiteSparse dims/row statistics), A=1, x=1" % name,
+                   "rows": rows, "cols": cols, "nnz": nnz_total, "scale": scale,
+                   "partition": "single GPU" if world == 1 else "row ranges by nnz + RCCL all_gather(y)",
+                   "row_long": st["row_long"], "row_block": st["row_block"], "rate_fill0": round(st["rate_fill0"], 4)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "kernel": "dasp_spmv_kernel<%s>" % ("double" if prec == 64 else "_Float16"),
+                     "algorithmic_bytes_per_launch": b_alg_local, "kernel_ms": round(ke, 6),
+                     "method": "hipEvent pair on the launch stream around %d back-to-back launches (rank 0 slice)" % k_iters},
+        "achieved_GBps_whole_job": round(b_alg_total / (ms_per_step * 1e6), 1),
+        "frac_hbm_roofline_whole_job": round(b_alg_total / (ms_per_step * 1e6) / (HBM_PEAK_GBPS * world), 4),
+        "region_event_ms_per_step": round(region_event_ms, 6), "verified": ok, "preprocess_s": round(pre_s, 3),
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O      # checker / baseline only; never on the measured path
+        out["cpu_baseline"] = cpu_baseline(O, rp, ci, cols)
+    del ci
+    plan.close()
+    del x, y
+    torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_suite:
+        suite = []
+        for nm, pr in (("cop20k_A", 64), ("nlpkkt160", 64), ("powerlaw_1M", 64), ("Queen_4147", 64),
+                       ("webbase-1M", 16), ("ljournal-2008", 16)):
+            try:
+                suite.append(suite_entry(torch, D, nm, pr, args.suite_scale))
+            except Exception as exc:   # a failing extra must not hide the headline line
+                suite.append({"workload": nm, "error": repr(exc)})
+        out["suite"] = suite
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+    if not ok:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,100 @@
+"""ctypes binding of libdasp_amd.so (include/dasp_amd.h).
+
+The library is the product: hand-written HIP kernels + C++ host preprocessing behind a C ABI.
+There is no Python or CPU fallback for the compute path; if the shared object is missing the
+import fails loudly, and device entry points return DASP_ERR_NO_DEVICE without a GPU.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libdasp_amd.so")
+
+
+class DaspError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("dasp status %d: %s" % (status, msg))
+        self.status = status
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("threshold", C.c_double), ("block_longest", C.c_int), ("y_order", C.c_int), ("long_piece", C.c_int),
+        ("host_threads", C.c_int), ("n_parts", C.c_int), ("part_bounds", C.POINTER(C.c_int)), ("part_stride", C.c_int),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "precision rowA colA nnzA short_row_1 common_13 short_row_3 short_row_4 short_row_2 row_long row_block "
+        "row_zero nnz_short nnz_long origin_nnz_reg nnz_irreg rowloop").split()] + [
+        ("fill0_nnz_short", C.c_longlong), ("fill0_nnz_long", C.c_longlong), ("fill0_nnz_reg", C.c_longlong),
+        ("rate_fill0", C.c_double), ("data_X", C.c_longlong), ("data_origin1", C.c_longlong),
+        ("n_med_blocks", C.c_int), ("n_long_pieces", C.c_int), ("n_long_multi", C.c_int), ("n_short_tiles", C.c_int),
+        ("n_workgroups", C.c_int), ("pre_ms", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def build(force=False):
+    """Compile libdasp_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src, "-s", "clean"])
+    subprocess.check_call(["make", "-C", src, "-s", "-j8", "all"])
+    return SO_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            "dasp_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no fallback implementation." % SO_PATH)
+    L = C.CDLL(SO_PATH)
+    ip, vp = C.POINTER(C.c_int), C.c_void_p
+    L.dasp_last_error.restype = C.c_char_p
+    L.dasp_version.restype = C.c_char_p
+    L.dasp_free.argtypes = [vp]
+    L.dasp_options_default.argtypes = [C.POINTER(Options)]
+    L.dasp_mmio_allinone_f64.argtypes = [ip, ip, ip, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(C.POINTER(C.c_double)), C.c_char_p]
+    L.dasp_mmio_allinone_f16.argtypes = [ip, ip, ip, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(C.POINTER(C.c_uint16)), C.c_char_p]
+    L.dasp_plan_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.POINTER(Options)]
+    L.dasp_plan_destroy.argtypes = [vp]
+    L.dasp_plan_order.argtypes = [vp]
+    L.dasp_plan_order.restype = ip
+    L.dasp_plan_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.dasp_plan_host_array.argtypes = [vp, C.c_char_p, C.POINTER(vp), ip]
+    L.dasp_plan_host_array.restype = C.c_longlong
+    L.dasp_plan_upload.argtypes = [vp]
+    L.dasp_plan_drop_host.argtypes = [vp]
+    L.dasp_plan_spmv.argtypes = [vp, vp, vp, vp]
+    L.dasp_plan_time.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.dasp_spmv_all_f64.argtypes = [C.c_char_p, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+    L.dasp_spmv_all_f16.argtypes = L.dasp_spmv_all_f64.argtypes
+    L.dasp_partition_rows.argtypes = [C.c_int, vp, C.c_int, vp]
+    L.dasp_selftest_mfma.argtypes = []
+    L.dasp_synth_dims.argtypes = [C.c_char_p, C.c_double, ip, ip]
+    L.dasp_synth_row_lengths.argtypes = [C.c_char_p, C.c_double, C.c_int, C.c_int, vp]
+    L.dasp_synth_rows.argtypes = [C.c_char_p, C.c_double, C.c_int, C.c_int, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise DaspError(rc, lib().dasp_last_error().decode("utf-8", "replace"))
+
+
+EXPORTS = (
+    "dasp_last_error dasp_version dasp_mmio_allinone_f64 dasp_mmio_allinone_f16 dasp_free dasp_options_default "
+    "dasp_plan_create dasp_plan_destroy dasp_plan_order dasp_plan_stats dasp_plan_host_array dasp_plan_upload "
+    "dasp_plan_drop_host dasp_plan_spmv dasp_plan_time dasp_spmv_all_f64 dasp_spmv_all_f16 dasp_partition_rows "
+    "dasp_selftest_mfma dasp_synth_dims dasp_synth_row_lengths dasp_synth_rows").split()

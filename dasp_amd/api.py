@@ -1,0 +1,204 @@
+"""Host-side mirror of the reference's interface for the DASP SpMV path, on top of the C ABI.
+
+Names and argument meaning follow the reference (paths relative to the reference tree):
+  mmio_allinone(filename)            src/mmio_highlevel.h:608-610
+  spmv_all(filename, csrValA, csrRowPtrA, csrColIdxA, X_val, rowA, colA, nnzA, NUM, threshold,
+           block_longest)            src/dasp_f64.h:486-487 / src/dasp_f16.h:1015-1016
+  Plan                               the same work split into create / upload / spmv
+numpy carries host arrays; torch (if used by the caller) only supplies device pointers and
+streams.  Half precision crosses as numpy.float16.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import DaspError, Options, Stats
+
+Y_PERMUTED, Y_NATURAL = 0, 1
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _dtype(precision):
+    if precision == 64:
+        return np.float64
+    if precision == 16:
+        return np.float16
+    raise ValueError("precision must be 64 or 16")
+
+
+def mmio_allinone(filename, precision=64):
+    """MatrixMarket -> CSR.  Returns (m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, csrVal).
+    Raises DaspError with the reference's codes: -1 open, -2 banner, -4 size line (-5 bad entry)."""
+    L = _lib.lib()
+    ip = C.POINTER(C.c_int)
+    m, n, nnz, sym = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rp, ci = ip(), ip()
+    if precision == 64:
+        v = C.POINTER(C.c_double)()
+        rc = L.dasp_mmio_allinone_f64(C.byref(m), C.byref(n), C.byref(nnz), C.byref(sym), C.byref(rp), C.byref(ci), C.byref(v), os.fsencode(filename))
+    else:
+        v = C.POINTER(C.c_uint16)()
+        rc = L.dasp_mmio_allinone_f16(C.byref(m), C.byref(n), C.byref(nnz), C.byref(sym), C.byref(rp), C.byref(ci), C.byref(v), os.fsencode(filename))
+    _lib.check(rc)
+    k = nnz.value
+    row_ptr = np.ctypeslib.as_array(rp, (m.value + 1,)).copy()
+    col_idx = np.ctypeslib.as_array(ci, (max(k, 1),))[:k].copy()
+    raw = np.ctypeslib.as_array(v, (max(k, 1),))[:k].copy()
+    val = raw if precision == 64 else raw.view(np.float16)
+    for q in (rp, ci, v):
+        L.dasp_free(C.cast(q, C.c_void_p))
+    return m.value, n.value, k, sym.value, row_ptr, col_idx, val
+
+
+class Plan:
+    """DASP plan: classifier + packers on the host, kernels on the current HIP device."""
+
+    def __init__(self, csrRowPtr, csrColIdx, csrVal, colA, precision=64, threshold=0.75, block_longest=256,
+                 y_order=Y_PERMUTED, long_piece=0, host_threads=0, part_bounds=None, part_stride=0):
+        L = _lib.lib()
+        self.precision = precision
+        dt = _dtype(precision)
+        rp = np.ascontiguousarray(csrRowPtr, np.int32)
+        ci = np.ascontiguousarray(csrColIdx, np.int32)
+        v = np.ascontiguousarray(csrVal, dt)
+        self.rowA, self.colA, self.nnzA = rp.size - 1, int(colA), int(ci.size)
+        opt = Options()
+        L.dasp_options_default(C.byref(opt))
+        opt.threshold, opt.block_longest, opt.y_order = threshold, block_longest, y_order
+        opt.long_piece, opt.host_threads = long_piece, host_threads
+        self._pb = None
+        if part_bounds is not None:
+            self._pb = np.ascontiguousarray(part_bounds, np.int32)
+            opt.n_parts = self._pb.size - 1
+            opt.part_bounds = self._pb.ctypes.data_as(C.POINTER(C.c_int))
+            opt.part_stride = int(part_stride)
+        self._h = C.c_void_p()
+        _lib.check(L.dasp_plan_create(C.byref(self._h), precision, self.rowA, self.colA, self.nnzA, _vp(rp), _vp(ci), _vp(v), C.byref(opt)))
+        self.y_order = y_order
+        self.x_len = self.colA if part_bounds is None else (self._pb.size - 1) * int(part_stride)
+
+    # -- host side -------------------------------------------------------------------
+    @property
+    def order_rid(self):
+        if self.rowA == 0:
+            return np.zeros(0, np.int32)
+        p = _lib.lib().dasp_plan_order(self._h)
+        return np.ctypeslib.as_array(p, (max(self.rowA, 1),))[: self.rowA].copy()
+
+    @property
+    def stats(self):
+        s = Stats()
+        _lib.check(_lib.lib().dasp_plan_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def host_array(self, name):
+        ptr, eb = C.c_void_p(), C.c_int()
+        n = _lib.lib().dasp_plan_host_array(self._h, name.encode(), C.byref(ptr), C.byref(eb))
+        if n < 0:
+            _lib.check(int(n))
+        if eb.value == 4:
+            dt = np.int32
+        else:
+            dt = np.float64 if eb.value == 8 else np.float16
+        if n == 0:
+            return np.zeros(0, dt)
+        buf = (C.c_char * (n * eb.value)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dt).copy()
+
+    # -- device side -----------------------------------------------------------------
+    def upload(self):
+        _lib.check(_lib.lib().dasp_plan_upload(self._h))
+        return self
+
+    def drop_host(self):
+        _lib.check(_lib.lib().dasp_plan_drop_host(self._h))
+
+    def spmv(self, dX, dY, stream=0):
+        """dX, dY: integer device addresses (e.g. torch_tensor.data_ptr()); stream: hipStream_t as int."""
+        _lib.check(_lib.lib().dasp_plan_spmv(self._h, C.c_void_p(dX), C.c_void_p(dY), C.c_void_p(stream)))
+
+    def time(self, dX, dY, stream=0, warmup=100, iters=1000):
+        """The reference's protocol (dasp_f64.h:1285-1320): returns (wall_ms, event_ms) per SpMV."""
+        w, e = C.c_double(), C.c_double()
+        _lib.check(_lib.lib().dasp_plan_time(self._h, C.c_void_p(dX), C.c_void_p(dY), C.c_void_p(stream), warmup, iters, C.byref(w), C.byref(e)))
+        return w.value, e.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().dasp_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def spmv_all(filename, csrValA, csrRowPtrA, csrColIdxA, X_val, rowA, colA, nnzA, NUM=4, threshold=0.75, block_longest=256,
+             precision=64):
+    """One-shot entry with the reference's argument list; returns (Y_val, order_rid):
+    Y_val[i] is the product for row order_rid[i].  Runs the reference's 100 + 1000 launches and
+    prints its result line."""
+    L = _lib.lib()
+    dt = _dtype(precision)
+    v = np.ascontiguousarray(csrValA, dt)
+    rp = np.ascontiguousarray(csrRowPtrA, np.int32)
+    ci = np.ascontiguousarray(csrColIdxA, np.int32)
+    x = np.ascontiguousarray(X_val, dt)
+    y = np.zeros(rowA, dt)
+    order = np.zeros(rowA, np.int32)
+    fn = L.dasp_spmv_all_f64 if precision == 64 else L.dasp_spmv_all_f16
+    _lib.check(fn(os.fsencode(filename or ""), _vp(v), _vp(rp), _vp(ci), _vp(x), _vp(y), _vp(order), rowA, colA, nnzA, NUM, threshold, block_longest))
+    return y, order
+
+
+def partition_rows(csrRowPtr, n_parts):
+    """Contiguous row ranges with equal nonzero counts -> int32[n_parts+1]."""
+    rp = np.ascontiguousarray(csrRowPtr, np.int32)
+    b = np.zeros(n_parts + 1, np.int32)
+    _lib.check(_lib.lib().dasp_partition_rows(rp.size - 1, _vp(rp), n_parts, _vp(b)))
+    return b
+
+
+def selftest_mfma():
+    _lib.check(_lib.lib().dasp_selftest_mfma())
+
+
+# ---- synthetic stand-ins for the SuiteSparse inputs (dasp_amd/csrc/gen.cpp) -----------------
+SYNTH_NAMES = ("cop20k_A", "nlpkkt160", "powerlaw_1M", "webbase-1M", "ljournal-2008", "HV15R", "Queen_4147")
+
+
+def synth_dims(name, scale=1.0):
+    r, c = C.c_int(), C.c_int()
+    _lib.check(_lib.lib().dasp_synth_dims(name.encode(), scale, C.byref(r), C.byref(c)))
+    return r.value, c.value
+
+
+def synth_row_lengths(name, scale=1.0, row_begin=0, row_end=None):
+    rows, _ = synth_dims(name, scale)
+    row_end = rows if row_end is None else row_end
+    out = np.zeros(row_end - row_begin, np.int32)
+    _lib.check(_lib.lib().dasp_synth_row_lengths(name.encode(), scale, row_begin, row_end, _vp(out)))
+    return out
+
+
+def synth_csr(name, scale=1.0, row_begin=0, row_end=None, lengths=None):
+    """CSR pattern (global column ids) of rows [row_begin,row_end): (row_ptr_local, col_idx)."""
+    rows, _ = synth_dims(name, scale)
+    row_end = rows if row_end is None else row_end
+    if lengths is None:
+        lengths = synth_row_lengths(name, scale, row_begin, row_end)
+    rp = np.zeros(row_end - row_begin + 1, np.int64)
+    np.cumsum(lengths, out=rp[1:])
+    if rp[-1] >= 2 ** 31:
+        raise ValueError("slice has more than 2^31 nonzeros")
+    rp = rp.astype(np.int32)
+    ci = np.empty(int(rp[-1]), np.int32)
+    _lib.check(_lib.lib().dasp_synth_rows(name.encode(), scale, row_begin, row_end, _vp(rp), _vp(ci)))
+    return rp, ci

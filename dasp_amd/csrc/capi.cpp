@@ -1,0 +1,274 @@
+// capi.cpp -- extern "C" surface of libdasp_amd.so (include/dasp_amd.h).
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <sys/stat.h>
+
+#include "plan.hpp"
+
+struct dasp_plan {
+    dasp::Plan impl;
+};
+
+namespace dasp {
+const char *last_error_cstr();
+int upload_plan(Plan &p);
+int launch_spmv(Plan &p, const void *dX, void *dY, void *stream);
+int time_spmv(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, double *wall_ms, double *event_ms);
+int selftest_mfma();
+}  // namespace dasp
+
+using namespace dasp;
+
+extern "C" {
+
+const char *dasp_last_error(void) { return last_error_cstr(); }
+const char *dasp_version(void) { return "dasp_amd 0.1 gfx950"; }
+void dasp_free(void *p) { std::free(p); }
+
+void dasp_options_default(dasp_options_t *o)
+{
+    if (!o) return;
+    std::memset(o, 0, sizeof *o);
+    o->threshold = 0.75;      // src/main_f64.cu:125
+    o->block_longest = 256;   // src/main_f64.cu:124
+    o->y_order = DASP_Y_PERMUTED;
+}
+
+int dasp_mmio_allinone_f64(int *m, int *n, int *nnz, int *isSymmetric, int **csrRowPtr, int **csrColIdx,
+                           double **csrVal, const char *filename)
+{
+    void *v = nullptr;
+    int rc = load_mtx(filename, 64, m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, &v);
+    if (rc == DASP_OK) *csrVal = static_cast<double *>(v);
+    return rc;
+}
+
+int dasp_mmio_allinone_f16(int *m, int *n, int *nnz, int *isSymmetric, int **csrRowPtr, int **csrColIdx,
+                           uint16_t **csrVal, const char *filename)
+{
+    void *v = nullptr;
+    int rc = load_mtx(filename, 16, m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, &v);
+    if (rc == DASP_OK) *csrVal = static_cast<uint16_t *>(v);
+    return rc;
+}
+
+int dasp_plan_create(dasp_plan_t **out, int precision, int rowA, int colA, int nnzA, const int *rp, const int *ci,
+                     const void *val, const dasp_options_t *opt)
+{
+    if (!out) return DASP_ERR_ARG;
+    *out = nullptr;
+    if ((precision != 64 && precision != 16) || rowA < 0 || colA < 0 || nnzA < 0 || !rp || (nnzA > 0 && (!ci || !val))) {
+        set_error("dasp_plan_create: bad arguments");
+        return DASP_ERR_ARG;
+    }
+    dasp_plan *h = new (std::nothrow) dasp_plan();
+    if (!h) return DASP_ERR_NOMEM;
+    Plan &p = h->impl;
+    p.precision = precision; p.m = rowA; p.n = colA; p.nnz = nnzA;
+    if (opt) p.opt = *opt; else dasp_options_default(&p.opt);
+    if (!(p.opt.threshold > 0)) p.opt.threshold = 0.75;
+    if (p.opt.block_longest < 6) p.opt.block_longest = 256;
+    if (p.opt.n_parts > 0) {
+        if (!p.opt.part_bounds || p.opt.part_stride <= 0) { delete h; set_error("bad column partition"); return DASP_ERR_ARG; }
+        p.part_bounds.assign(p.opt.part_bounds, p.opt.part_bounds + p.opt.n_parts + 1);
+        if (p.part_bounds.front() != 0 || p.part_bounds.back() != colA) { delete h; set_error("part_bounds must span [0,colA]"); return DASP_ERR_ARG; }
+        for (int g = 0; g < p.opt.n_parts; ++g)
+            if (p.part_bounds[g + 1] < p.part_bounds[g] || p.part_bounds[g + 1] - p.part_bounds[g] > p.opt.part_stride) {
+                delete h; set_error("part_bounds not monotone or wider than part_stride"); return DASP_ERR_ARG;
+            }
+        p.opt.part_bounds = p.part_bounds.data();
+    } else { p.opt.n_parts = 0; p.opt.part_bounds = nullptr; }
+    int rc;
+    try { rc = build_plan(p, rp, ci, val); }
+    catch (const std::bad_alloc &) { rc = DASP_ERR_NOMEM; set_error("out of host memory"); }
+    if (rc != DASP_OK) { delete h; return rc; }
+    *out = h;
+    return DASP_OK;
+}
+
+void dasp_plan_destroy(dasp_plan_t *plan) { delete plan; }
+
+const int *dasp_plan_order(const dasp_plan_t *plan) { return plan ? plan->impl.order.data() : nullptr; }
+
+int dasp_plan_stats(const dasp_plan_t *plan, dasp_stats_t *out)
+{
+    if (!plan || !out) return DASP_ERR_ARG;
+    *out = plan->impl.stats;
+    return DASP_OK;
+}
+
+long long dasp_plan_host_array(const dasp_plan_t *plan, const char *name, const void **ptr, int *elem_bytes)
+{
+    if (!plan || !name || !ptr || !elem_bytes) return DASP_ERR_ARG;
+    const Plan &p = plan->impl;
+    if (p.host_dropped && std::strcmp(name, "order") != 0) { set_error("host arrays were dropped"); return DASP_ERR_STATE; }
+    const int vb = p.geo.vbytes;
+    auto ints = [&](const std::vector<int> &v) { *ptr = v.data(); *elem_bytes = 4; return (long long)v.size(); };
+    auto vals = [&](const std::vector<char> &v) { *ptr = v.data(); *elem_bytes = vb; return (long long)(v.size() / vb); };
+    const std::string n(name);
+    if (n == "order") return ints(p.order);
+    if (n == "long_val") return vals(p.long_val);
+    if (n == "long_cid") return ints(p.long_cid);
+    if (n == "piece_ptr") return ints(p.piece_ptr);
+    if (n == "piece_dst") return ints(p.piece_dst);
+    if (n == "multi_ptr") return ints(p.multi_ptr);
+    if (n == "multi_dst") return ints(p.multi_dst);
+    if (n == "med_ptr") return ints(p.med_ptr);
+    if (n == "med_val") return vals(p.med_val);
+    if (n == "med_cid") return ints(p.med_cid);
+    if (n == "irr_ptr") return ints(p.irr_ptr);
+    if (n == "irr_val") return vals(p.irr_val);
+    if (n == "irr_cid") return ints(p.irr_cid);
+    if (n == "short_val") return vals(p.short_val);
+    if (n == "short_cid") return ints(p.short_cid);
+    if (n == "short_groups") {   // kNumShortGroups x {len,count,tiles,tile0,elem_off_lo,elem_off_hi,split,base0,base1,grp0,grp1,off0,off1}
+        static thread_local std::vector<int> flat;
+        flat.clear();
+        for (int g = 0; g < kNumShortGroups; ++g) {
+            const ShortGroup &G = p.grp[g];
+            const int row[13] = {G.len, G.count, G.tiles, G.tile0, (int)(G.elem_off & 0xffffffffll), (int)(G.elem_off >> 32),
+                                 G.map.split, G.map.base[0], G.map.base[1], G.map.grp[0], G.map.grp[1], G.map.off[0], G.map.off[1]};
+            flat.insert(flat.end(), row, row + 13);
+        }
+        return ints(flat);
+    }
+    set_error("unknown host array: " + n);
+    return DASP_ERR_ARG;
+}
+
+int dasp_plan_upload(dasp_plan_t *plan)
+{
+    if (!plan) return DASP_ERR_ARG;
+    return upload_plan(plan->impl);
+}
+
+int dasp_plan_drop_host(dasp_plan_t *plan)
+{
+    if (!plan) return DASP_ERR_ARG;
+    Plan &p = plan->impl;
+    if (!p.dev) { set_error("upload the plan before dropping its host arrays"); return DASP_ERR_STATE; }
+    auto dropc = [](std::vector<char> &v) { std::vector<char>().swap(v); };
+    auto dropi = [](std::vector<int> &v) { std::vector<int>().swap(v); };
+    dropc(p.long_val); dropi(p.long_cid); dropc(p.med_val); dropi(p.med_cid);
+    dropc(p.irr_val); dropi(p.irr_cid); dropc(p.short_val); dropi(p.short_cid);
+    p.host_dropped = true;
+    return DASP_OK;
+}
+
+int dasp_plan_spmv(dasp_plan_t *plan, const void *dX, void *dY, void *stream)
+{
+    if (!plan) return DASP_ERR_ARG;
+    return launch_spmv(plan->impl, dX, dY, stream);
+}
+
+int dasp_plan_time(dasp_plan_t *plan, const void *dX, void *dY, void *stream, int warmup, int iters, double *wall_ms,
+                   double *event_ms)
+{
+    if (!plan || iters <= 0 || warmup < 0) return DASP_ERR_ARG;
+    return time_spmv(plan->impl, dX, dY, stream, warmup, iters, wall_ms, event_ms);
+}
+
+int dasp_selftest_mfma(void) { return selftest_mfma(); }
+
+int dasp_partition_rows(int rowA, const int *rp, int n_parts, int *bounds)
+{
+    if (rowA < 0 || !rp || n_parts <= 0 || !bounds) return DASP_ERR_ARG;
+    const long long total = rp[rowA];
+    bounds[0] = 0;
+    for (int g = 1; g < n_parts; ++g) {
+        const long long target = total * g / n_parts;
+        // first row whose start is >= target, never going backwards
+        const int *it = std::lower_bound(rp, rp + rowA + 1, (int)std::min<long long>(target, 2147483647LL));
+        int b = (int)(it - rp);
+        b = std::max(b, bounds[g - 1]);
+        bounds[g] = std::min(b, rowA);
+    }
+    bounds[n_parts] = rowA;
+    return DASP_OK;
+}
+
+// ---- one-shot spmv_all (src/dasp_f64.h:486-1483): host buffers in/out, reference stdout + CSV
+static int spmv_all_impl(int precision, const char *filename, const void *val, const int *rp, const int *ci, const void *X,
+                         void *Y, int *order_rid, int rowA, int colA, int nnzA, double threshold, int block_longest)
+{
+    if (!X || !Y || !order_rid) { set_error("spmv_all: null X/Y/order_rid"); return DASP_ERR_ARG; }
+    dasp_options_t opt;
+    dasp_options_default(&opt);
+    opt.threshold = threshold; opt.block_longest = block_longest;
+    dasp_plan_t *plan = nullptr;
+    int rc = dasp_plan_create(&plan, precision, rowA, colA, nnzA, rp, ci, val, &opt);
+    if (rc) return rc;
+    rc = dasp_plan_upload(plan);
+    if (rc) { dasp_plan_destroy(plan); return rc; }
+    const size_t vb = precision == 64 ? 8 : 2;
+    void *dX = nullptr, *dY = nullptr;
+    auto fail = [&](int code, const char *what) {
+        set_error(what);
+        if (dX) (void)hipFree(dX);
+        if (dY) (void)hipFree(dY);
+        dasp_plan_destroy(plan);
+        return code;
+    };
+    if (hipMalloc(&dX, std::max<size_t>(vb * (size_t)colA, 8)) != hipSuccess) return fail(DASP_ERR_HIP, "hipMalloc X");
+    if (hipMalloc(&dY, std::max<size_t>(vb * (size_t)rowA, 8)) != hipSuccess) return fail(DASP_ERR_HIP, "hipMalloc Y");
+    if (hipMemcpy(dX, X, vb * (size_t)colA, hipMemcpyHostToDevice) != hipSuccess) return fail(DASP_ERR_HIP, "hipMemcpy X");
+    if (hipMemset(dY, 0, vb * (size_t)rowA) != hipSuccess) return fail(DASP_ERR_HIP, "hipMemset Y");
+    double wall = 0, ev = 0;
+    rc = dasp_plan_time(plan, dX, dY, nullptr, 100, 1000, &wall, &ev);   // dasp_f64.h:1285-1286
+    if (rc) { std::string keep = dasp_last_error(); return fail(rc, keep.c_str()); }
+    if (hipMemcpy(Y, dY, vb * (size_t)rowA, hipMemcpyDeviceToHost) != hipSuccess) return fail(DASP_ERR_HIP, "hipMemcpy Y");
+    std::memcpy(order_rid, dasp_plan_order(plan), sizeof(int) * (size_t)rowA);
+
+    dasp_stats_t s;
+    dasp_plan_stats(plan, &s);
+    const double t = wall;                                                  // ms per SpMV, dasp_f64.h:1394
+    const double gflops = (double)((long long)nnzA * 2) / (t * 1e6);        // :1395
+    const long long data_X2 = s.data_X + (long long)(nnzA - colA) * (long long)vb;  // x counted per gather, :1168-1172
+    const double bw1 = (double)s.data_X / (t * 1e6), bw2 = (double)data_X2 / (t * 1e6);
+    std::printf("SpMV_X:  %8.4lf ms, %8.4lf GFlop/s, %9.4lf GB/s, %9.4lf GB/s\n\n", t, gflops, bw1, bw2);   // :1398
+    struct stat st;
+    if (stat("data", &st) == 0 && S_ISDIR(st.st_mode)) {
+        FILE *fo = std::fopen(precision == 64 ? "data/spmv_f64_record.csv" : "data/spmv_f16_record.csv", "a");
+        if (fo) {   // column order of dasp_f64.h:1439-1441 (f16 adds dasp_pre after rate_fill0.. see dasp_f16.h:1756-1758)
+            std::fprintf(fo, "%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%lld,%d,%lld,%d,%lld,%d,", filename ? filename : "", rowA, colA,
+                         nnzA, s.short_row_1, s.common_13, s.short_row_3, s.short_row_4, s.short_row_2, s.row_long, s.row_block,
+                         s.nnz_short, s.fill0_nnz_short, s.nnz_long, s.fill0_nnz_long, s.origin_nnz_reg, s.fill0_nnz_reg, s.nnz_irreg);
+            if (precision == 64)
+                std::fprintf(fo, "%lf,%d,%lld,%lf,%lf,%lf,%lf,", s.rate_fill0, block_longest, s.data_X, t, gflops, bw1, bw2);
+            else
+                std::fprintf(fo, "%lf,%d,%lld,%lf,%lf,%lf,%lf,%lf,%lf,%lf,", s.rate_fill0, block_longest, s.data_X, s.pre_ms, t, gflops,
+                             bw1, bw2, t, gflops);
+            std::fclose(fo);
+        }
+    }
+    (void)hipFree(dX);
+    (void)hipFree(dY);
+    dasp_plan_destroy(plan);
+    return DASP_OK;
+}
+
+int dasp_spmv_all_f64(const char *filename, const double *csrValA, const int *csrRowPtrA, const int *csrColIdxA,
+                      const double *X_val, double *Y_val, int *order_rid, int rowA, int colA, int nnzA, int NUM,
+                      double threshold, int block_longest)
+{
+    (void)NUM;
+    return spmv_all_impl(64, filename, csrValA, csrRowPtrA, csrColIdxA, X_val, Y_val, order_rid, rowA, colA, nnzA, threshold,
+                         block_longest);
+}
+
+int dasp_spmv_all_f16(const char *filename, const uint16_t *csrValA, const int *csrRowPtrA, const int *csrColIdxA,
+                      const uint16_t *X_val, uint16_t *Y_val, int *order_rid, int rowA, int colA, int nnzA, int NUM,
+                      double threshold, int block_longest)
+{
+    (void)NUM;
+    return spmv_all_impl(16, filename, csrValA, csrRowPtrA, csrColIdxA, X_val, Y_val, order_rid, rowA, colA, nnzA, threshold,
+                         block_longest);
+}
+
+}  // extern "C"

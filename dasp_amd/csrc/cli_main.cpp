@@ -1,0 +1,69 @@
+// cli_main.cpp -- the two drivers of the reference, `spmv_double <matrix.mtx>` and
+// `spmv_half <matrix.mtx>` (src/main_f64.cu:102-168, src/main_f16.cu:102-164), on top of the C ABI:
+// load -> all-ones values and x (initVec, src/utils.h:93-100) -> spmv_all -> verify.
+// The reference's comparator is cuSPARSE and its verify call is commented out (main_f64.cu:157);
+// here the comparator is a serial CSR loop on the host and the check is on, through order_rid,
+// with the reference's absolute tolerances (1e-5 f64, 1.0 f16: main_f64.cu:8, main_f16.cu:10).
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/dasp_amd.h"
+
+#ifdef DASP_CLI_F64
+typedef double val_t;
+#define LOAD dasp_mmio_allinone_f64
+#define SPMV dasp_spmv_all_f64
+static const char *kName = "dasp_f64";
+static inline double to_d(val_t v) { return v; }
+static inline val_t one() { return 1.0; }
+static const double kTol = 1e-5;
+#else
+typedef uint16_t val_t;
+#define LOAD dasp_mmio_allinone_f16
+#define SPMV dasp_spmv_all_f16
+static const char *kName = "dasp_f16";
+static inline double to_d(val_t h)
+{
+    const int s = h >> 15, e = (h >> 10) & 31, f = h & 1023;
+    double v = e == 0 ? std::ldexp((double)f, -24) : (e == 31 ? (f ? NAN : INFINITY) : std::ldexp((double)(f | 1024), e - 25));
+    return s ? -v : v;
+}
+static inline val_t one() { return 0x3C00; }
+static const double kTol = 1.0;
+#endif
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { std::printf("Run the code by './%s matrix.mtx'. \n", kName); return 0; }
+    const char *filename = argv[1];
+    std::printf("\n===%s===\n\n", filename);
+    int rowA, colA, nnzA, sym, *rpt, *cid;
+    val_t *val;
+    int rc = LOAD(&rowA, &colA, &nnzA, &sym, &rpt, &cid, &val, filename);
+    if (rc != 0) { std::fprintf(stderr, "%s: cannot load %s (status %d: %s)\n", kName, filename, rc, dasp_last_error()); return 1; }
+    std::vector<val_t> X((size_t)colA + 1, one()), Y((size_t)rowA);
+    for (int i = 0; i < nnzA; ++i) val[i] = one();
+    std::vector<int> order((size_t)rowA);
+    std::printf("INIT DONE\n");
+    const long long data_origin1 = (long long)(nnzA + colA + rowA) * (long long)sizeof(val_t) + (long long)nnzA * 4 + (long long)(rowA + 1) * 4;
+    rc = SPMV(filename, val, rpt, cid, X.data(), Y.data(), order.data(), rowA, colA, nnzA, 4, 0.75, 256);
+    if (rc != 0) { std::fprintf(stderr, "%s: spmv_all failed (status %d: %s)\n", kName, rc, dasp_last_error()); return 2; }
+    // host CSR comparator (the reference has cuSPARSE here)
+    int bad = 0;
+    for (int i = 0; i < rowA && !bad; ++i) {
+        const int r = order[i];
+        double s = 0;
+        for (int j = rpt[r]; j < rpt[r + 1]; ++j) s += to_d(val[j]) * to_d(X[cid[j]]);
+        if (std::fabs(s - to_d(Y[i])) > kTol) {
+            std::printf("error in (%d), csr(%4.2f), dasp(%4.2f),please check your code!\n", i, s, to_d(Y[i]));
+            bad = 1;
+        }
+    }
+    if (!bad) std::printf("Y(%d), compute succeed!\n", rowA);
+    std::printf("data_origin1 = %lld bytes\n", data_origin1);
+    dasp_free(val); dasp_free(cid); dasp_free(rpt);
+    return bad ? 3 : 0;
+}

@@ -1,0 +1,272 @@
+// gen.cpp -- seeded synthetic stand-ins for the SuiteSparse matrices BASELINE.json names.
+// Neither the build container nor the GPU box has .mtx files or a network, so the benchmark
+// inputs are generated: each named stand-in follows the collection's dimensions, row-length
+// statistics and structure class.  Row r of a matrix depends only on
+// (name, scale, r), so any row range can be produced independently (multi-GPU ranks build
+// only their slice) and reproducibly.
+//
+//   cop20k_A      121192 rows, symmetric, avg 21.7 / max ~81 per row, empty rows, +-4000 band
+//   nlpkkt160     8345600 = 2 dof x 160x160x163 grid, symmetric, <= 28 per row (19-pt + 9-pt coupling)
+//   Queen_4147    4147110 rows, 3 dof x 27-point stencil (<= 81 per row), symmetric
+//   HV15R         2017169 rows, 5 dof x 27-point stencil (135) with 2% / 0.2% extended rows (375 / 484)
+//   webbase-1M    1000005 rows, power-law lengths (mean ~3.1, max 4700), 70% near / 30% uniform columns
+//   ljournal-2008 5363260 rows, power-law lengths (mean ~14.7, max 2469), uniform columns
+//   powerlaw_1M   2^20 rows, Zipf(1.8) lengths clipped at 200000 (mean ~48), uniform columns
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "plan.hpp"
+
+namespace dasp {
+namespace {
+
+inline uint64_t mix(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline uint64_t h2(uint64_t seed, uint64_t a, uint64_t b) { return mix(mix(seed ^ mix(a)) ^ (b * 0xD6E8FEB86659FD93ull)); }
+inline double u01(uint64_t h) { return ((h >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+
+struct Synth {
+    enum Kind { GRID, BAND, POWER } kind;
+    int rows = 0, cols = 0;
+    uint64_t seed = 0;
+    // GRID
+    int nx = 0, ny = 0, nz = 0, dof = 1;
+    int variant = 0;   // 0 = full 27-pt coupling, 1 = nlpkkt (19-pt same dof, 9-pt cross), 2 = HV15R extended rows
+    // BAND
+    int band = 0; double deg_mean = 0, deg_sd = 0; int deg_max = 0; double tbar = 1;
+    // POWER
+    double alpha = 2, xmin = 1, p_zero = 0, near_frac = 0; int len_max = 0, near_w = 0;
+};
+
+int scaled(int full, double s) { return std::max(64, (int)std::llround(full * s)); }
+
+bool make(const char *name, double scale, Synth &g)
+{
+    const std::string n(name ? name : "");
+    if (!(scale > 0)) return false;
+    const double c = std::cbrt(scale);
+    auto grid = [&](int nx, int ny, int nz, int dof, int rows_full, int variant, uint64_t seed) {
+        g.kind = Synth::GRID; g.dof = dof; g.variant = variant; g.seed = seed;
+        g.nx = std::max(4, (int)std::llround(nx * c)); g.ny = std::max(4, (int)std::llround(ny * c));
+        g.nz = std::max(4, (int)std::llround(nz * c));
+        const long long cap = (long long)g.nx * g.ny * g.nz * dof;
+        g.rows = g.cols = (int)std::min<long long>(cap, scale == 1.0 ? rows_full : (long long)scaled(rows_full, scale));
+    };
+    if (n == "Queen_4147") { grid(113, 111, 111, 3, 4147110, 0, 20007); return true; }
+    if (n == "HV15R") { grid(74, 74, 74, 5, 2017169, 2, 20006); return true; }
+    if (n == "nlpkkt160") { grid(160, 160, 163, 2, 8345600, 1, 20002); return true; }
+    if (n == "cop20k_A") {
+        g.kind = Synth::BAND; g.seed = 20001; g.rows = g.cols = scaled(121192, scale);
+        g.band = std::min(4000, std::max(8, g.rows / 4)); g.deg_mean = 21.7; g.deg_sd = 14; g.deg_max = 81;
+        // E[clip(N(21.7,14),0,81)] ~ 21.95 ; t_i / sqrt(tbar) propensities give E[deg_i] ~ t_i
+        g.tbar = 21.95;
+        return true;
+    }
+    auto power = [&](int rows_full, double alpha, double xmin, double pz, int lmax, double nearf, int nearw, uint64_t seed) {
+        g.kind = Synth::POWER; g.seed = seed; g.rows = g.cols = scaled(rows_full, scale);
+        g.alpha = alpha; g.xmin = xmin; g.p_zero = pz; g.len_max = std::min(lmax, std::max(8, g.cols / 2));
+        g.near_frac = nearf; g.near_w = nearw;
+    };
+    if (n == "webbase-1M") { power(1000005, 2.45, 1.32, 0.02, 4700, 0.7, 1000, 20004); return true; }
+    if (n == "ljournal-2008") { power(5363260, 2.35, 4.6, 0.01, 2469, 0.0, 0, 20005); return true; }
+    if (n == "powerlaw_1M") { power(1 << 20, 1.8, 2.05, 0.0, 200000, 0.0, 0, 20003); return true; }
+    return false;
+}
+
+// ---- GRID rows ------------------------------------------------------------------------
+// neighbourhood class of a node for the HV15R stand-in: 0 = 27-pt, 1 = 5x5x3 (75 nodes), 2 = 5x5x4 (100 nodes)
+inline int hv_class(const Synth &g, long long node)
+{
+    const uint64_t h = h2(g.seed, (uint64_t)node, 77) % 1000;
+    return h < 2 ? 2 : (h < 22 ? 1 : 0);
+}
+
+int grid_row(const Synth &g, int row, int *out)
+{
+    const int dof = g.dof;
+    const long long node = row / dof;
+    const int da = row % dof;
+    const int x = (int)(node % g.nx), y = (int)((node / g.nx) % g.ny), z = (int)(node / ((long long)g.nx * g.ny));
+    int rx = 1, ry = 1, rz0 = -1, rz1 = 1, cap = 1 << 30;
+    if (g.variant == 2) {
+        const int cls = hv_class(g, node);
+        if (cls >= 1) { rx = 2; ry = 2; }
+        if (cls == 2) { rz1 = 2; cap = 484; }
+    } else if (g.variant == 1) {
+        rx = 2;   // the +-2x cross-dof coupling
+    }
+    int len = 0;
+    for (int dz = rz0; dz <= rz1; ++dz) {
+        const int zz = z + dz;
+        if (zz < 0 || zz >= g.nz) continue;
+        for (int dy = -ry; dy <= ry; ++dy) {
+            const int yy = y + dy;
+            if (yy < 0 || yy >= g.ny) continue;
+            for (int dx = -rx; dx <= rx; ++dx) {
+                const int xx = x + dx;
+                if (xx < 0 || xx >= g.nx) continue;
+                const long long nb = ((long long)zz * g.ny + yy) * g.nx + xx;
+                for (int db = 0; db < dof; ++db) {
+                    if (g.variant == 1) {
+                        const int nzc = (dx != 0) + (dy != 0) + (dz != 0);
+                        const int l1 = std::abs(dx) + std::abs(dy) + std::abs(dz);
+                        bool ok;
+                        if (da == db) ok = std::abs(dx) <= 1 && nzc <= 2;                 // 19-point
+                        else ok = l1 <= 1 || (std::abs(dx) == 2 && dy == 0 && dz == 0);    // 7-point + (+-2,0,0)
+                        if (!ok) continue;
+                    }
+                    const long long col = nb * dof + db;
+                    if (col >= g.cols) continue;
+                    if (len >= cap) continue;
+                    if (out) out[len] = (int)col;
+                    ++len;
+                }
+            }
+        }
+    }
+    return len;
+}
+
+// ---- BAND rows (cop20k_A stand-in): symmetric by construction -------------------------
+inline double band_target(const Synth &g, int i)
+{
+    // Box-Muller from two hashes of the row
+    const double u1 = u01(h2(g.seed, (uint64_t)i, 1)), u2 = u01(h2(g.seed, (uint64_t)i, 2));
+    const double nrm = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+    double t = g.deg_mean + g.deg_sd * nrm;
+    return std::min((double)g.deg_max, std::max(0.0, t));
+}
+
+// tg[j - tg0] caches band_target(j) for the rows a call can touch (the Box-Muller draw is the
+// expensive part; the window test itself is one hash per candidate)
+int band_row(const Synth &g, int i, int *out, const float *tg, int tg0)
+{
+    const double ti = tg[i - tg0];
+    if (ti <= 0) return 0;
+    const int lo = std::max(0, i - g.band), hi = std::min(g.rows - 1, i + g.band);
+    // window actually available to row i (rows near the ends see a one-sided band)
+    const double si = ti / std::sqrt(g.tbar);
+    int len = 0;
+    for (int j = lo; j <= hi; ++j) {
+        bool take;
+        if (j == i) take = true;
+        else {
+            const double tj = tg[j - tg0];
+            if (tj <= 0) continue;
+            const double p = si * (tj / std::sqrt(g.tbar)) / (2.0 * g.band);
+            const int a = std::max(i, j), b = std::min(i, j);
+            take = u01(h2(g.seed ^ 0xABCDEFull, (uint64_t)a, (uint64_t)b)) < p;
+        }
+        if (take) { if (out) out[len] = j; ++len; }
+    }
+    return len;
+}
+
+// ---- POWER rows ------------------------------------------------------------------------
+inline int power_len(const Synth &g, int i)
+{
+    const double u = u01(h2(g.seed, (uint64_t)i, 11));
+    if (u < g.p_zero) return 0;
+    const double v = u01(h2(g.seed, (uint64_t)i, 12));
+    const double xlen = g.xmin * std::pow(v, -1.0 / (g.alpha - 1.0));
+    return (int)std::min<double>(g.len_max, std::floor(xlen));
+}
+
+int power_row(const Synth &g, int i, int *out)
+{
+    const int len = power_len(g, i);
+    if (!out) return len;
+    for (int k = 0; k < len; ++k) {
+        const uint64_t h = h2(g.seed ^ 0x5151ull, (uint64_t)i, (uint64_t)k);
+        int col;
+        if (u01(h) < g.near_frac) {
+            const int w = std::min(g.near_w, g.cols / 2);
+            col = i + (int)(mix(h) % (uint64_t)(2 * w + 1)) - w;
+            if (col < 0) col += g.cols;
+            if (col >= g.cols) col -= g.cols;
+        } else col = (int)(mix(h ^ 0x77ull) % (uint64_t)g.cols);
+        out[k] = col;
+    }
+    return len;
+}
+
+inline int any_row(const Synth &g, int row, int *out, const float *tg, int tg0)
+{
+    switch (g.kind) {
+        case Synth::GRID: return grid_row(g, row, out);
+        case Synth::BAND: return band_row(g, row, out, tg, tg0);
+        default: return power_row(g, row, out);
+    }
+}
+
+// per-call cache of band targets for rows [r0 - band, r1 + band)
+void band_cache(const Synth &g, int r0, int r1, std::vector<float> &tg, int &tg0)
+{
+    tg0 = 0;
+    if (g.kind != Synth::BAND) return;
+    const int lo = std::max(0, r0 - g.band), hi = std::min(g.rows, r1 + g.band);
+    tg0 = lo;
+    tg.resize((size_t)std::max(0, hi - lo));
+    for (int j = lo; j < hi; ++j) tg[(size_t)(j - lo)] = (float)band_target(g, j);
+}
+
+template <class F>
+void par_rows(int r0, int r1, F f)
+{
+    const int nt = resolve_threads(0);
+    const long long n = (long long)r1 - r0;
+    if (n <= 0) return;
+    const int parts = (int)std::min<long long>(nt, std::max<long long>(1, n / 256));
+    std::vector<std::thread> th;
+    for (int t = 0; t < parts; ++t) {
+        const int b = r0 + (int)(n * t / parts), e = r0 + (int)(n * (t + 1) / parts);
+        th.emplace_back([=] { for (int r = b; r < e; ++r) f(r); });
+    }
+    for (auto &x : th) x.join();
+}
+
+}  // namespace
+}  // namespace dasp
+
+using namespace dasp;
+
+extern "C" int dasp_synth_dims(const char *name, double scale, int *rows, int *cols)
+{
+    Synth g;
+    if (!make(name, scale, g) || !rows || !cols) { set_error("unknown synthetic matrix name"); return DASP_ERR_ARG; }
+    *rows = g.rows; *cols = g.cols;
+    return DASP_OK;
+}
+
+extern "C" int dasp_synth_row_lengths(const char *name, double scale, int row_begin, int row_end, int *len_out)
+{
+    Synth g;
+    if (!make(name, scale, g) || !len_out || row_begin < 0 || row_end > g.rows || row_begin > row_end) {
+        set_error("bad arguments to dasp_synth_row_lengths"); return DASP_ERR_ARG;
+    }
+    std::vector<float> tg; int tg0;
+    band_cache(g, row_begin, row_end, tg, tg0);
+    par_rows(row_begin, row_end, [&](int r) { len_out[r - row_begin] = any_row(g, r, nullptr, tg.data(), tg0); });
+    return DASP_OK;
+}
+
+extern "C" int dasp_synth_rows(const char *name, double scale, int row_begin, int row_end, const int *rp, int *col_idx_out)
+{
+    Synth g;
+    if (!make(name, scale, g) || !rp || !col_idx_out || row_begin < 0 || row_end > g.rows || row_begin > row_end) {
+        set_error("bad arguments to dasp_synth_rows"); return DASP_ERR_ARG;
+    }
+    std::vector<float> tg; int tg0;
+    band_cache(g, row_begin, row_end, tg, tg0);
+    par_rows(row_begin, row_end, [&](int r) { any_row(g, r, col_idx_out + rp[r - row_begin], tg.data(), tg0); });
+    return DASP_OK;
+}

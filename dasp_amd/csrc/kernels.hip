@@ -1,0 +1,576 @@
+// kernels.hip -- gfx950 (CDNA4, wave64) SpMV kernels for the DASP plan + device plumbing.
+//
+// One fused launch covers the three row categories by workgroup-index range, as the
+// reference's dasp_spmv2 does (src/dasp_f64.h:77-484, src/dasp_f16.h:133-590):
+//   [ long pieces | medium blocks | short tiles ]      256 threads = 4 waves, one unit per wave
+// followed by long_reduce only when some long row was cut into several pieces
+// (the reference's longPart_sum, src/dasp_f64.h:53-75).
+//
+// Medium / long rows use the DASP diagonal trick on the CDNA4 matrix cores: a chunk of
+// 16 rows x K columns is fed as A = values, B = x[column ids] with the same element index on
+// both operands, so D[i][i] accumulates row i's dot product (reference: m8n8k4 PTX MMA,
+// src/utils.h:102-115; here v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x16_f16).
+// Lane maps (pinned on the device by dasp_selftest_mfma):
+//   f64 16x16x4 : lane l holds A[l&15][l>>4], B[l>>4][l&15]; D reg r = D[(l>>4)+4r][l&15]
+//   f16 16x16x16: lane l holds A[l&15][4(l>>4)+j], B[4(l>>4)+j][l&15], j<4; D reg r = D[4(l>>4)+r][l&15]
+// Short rows (1..4 nonzeros) are uniform-length slabs: a lane owns whole rows, so the
+// segmented dot product needs no cross-lane step; cross-lane sums (long rows, stage 2)
+// use DPP row rotations + readlane.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "plan.hpp"
+
+namespace dasp {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+struct ShortDev {
+    int len, count, tiles, tile0;
+    long long elem_off;
+    SlotMap map;
+};
+
+struct DevArgs {
+    const void *x;
+    void *y;
+    // long
+    const void *long_val; const int *long_cid; const int *piece_ptr; const int *piece_dst; void *partial;
+    const int *multi_ptr; const int *multi_dst;
+    int n_pieces, n_multi;
+    // medium
+    const int *med_ptr; const void *med_val; const int *med_cid;
+    const int *irr_ptr; const void *irr_val; const int *irr_cid;
+    int n_blocks, row_block, row_long;
+    // short
+    const void *short_val; const int *short_cid; const ShortDev *groups;
+    int n_short_tiles;
+    // permutation (DASP_Y_NATURAL only)
+    const int *order;
+    // workgroup ranges
+    int wg_long, wg_med, wg_short;
+};
+
+struct DevicePlan {
+    void *arena = nullptr;
+    size_t arena_bytes = 0;
+    DevArgs args{};
+    bool nt = false;
+    int device = -1;
+};
+
+// ------------------------------------------------------------------ device helpers
+
+template <bool NT, class U>
+__device__ __forceinline__ U ldg(const U *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes of a wave, result uniform.  DPP row_ror:8,4,2,1 (0x120+n) make every lane of
+// a 16-lane row hold that row's sum; the four rows are combined on the scalar side.
+__device__ __forceinline__ double wave_sum(double v)
+{
+    v += dpp_mov_f64<0x128>(v);
+    v += dpp_mov_f64<0x124>(v);
+    v += dpp_mov_f64<0x122>(v);
+    v += dpp_mov_f64<0x121>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += dpp_mov_f32<0x128>(v);
+    v += dpp_mov_f32<0x124>(v);
+    v += dpp_mov_f32<0x122>(v);
+    v += dpp_mov_f32<0x121>(v);
+    float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (a + b) + (c + d);
+}
+
+__device__ __forceinline__ int slot_of(const SlotMap &m, int t)
+{
+    const int p = t < m.split ? 0 : 1;
+    const int u = p ? t - m.split : t;
+    const int g = m.grp[p];
+    return g ? m.base[p] + (u / g) * 2 * g + m.off[p] + u % g : m.base[p] + u;
+}
+
+template <class T> struct Tr;
+template <> struct Tr<double> {
+    using acc_t = f64x4; using part_t = double;
+    static constexpr int CHUNK = 64, SHORT_ROWS = 128;
+};
+template <> struct Tr<_Float16> {
+    using acc_t = f32x4; using part_t = float;
+    static constexpr int CHUNK = 256, SHORT_ROWS = 256;
+};
+
+// ---- one MFMA step on `chunk` elements starting at element offset `e` (lane-linear layout)
+template <bool NT>
+__device__ __forceinline__ void mfma_chunk(f64x4 &acc, const double *val, const int *cid, size_t e, int lane, const double *x)
+{
+    const double a = ldg<NT>(val + e + lane);
+    const int c = ldg<NT>(cid + e + lane);
+    const double b = c >= 0 ? x[c] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+}
+template <bool NT>
+__device__ __forceinline__ void mfma_chunk(f32x4 &acc, const _Float16 *val, const int *cid, size_t e, int lane, const _Float16 *x)
+{
+    const f16x4 a = ldg<NT>(reinterpret_cast<const f16x4 *>(val + e) + lane);
+    const i32x4 c = ldg<NT>(reinterpret_cast<const i32x4 *>(cid + e) + lane);
+    f16x4 b;
+    b[0] = c[0] >= 0 ? x[c[0]] : (_Float16)0;
+    b[1] = c[1] >= 0 ? x[c[1]] : (_Float16)0;
+    b[2] = c[2] >= 0 ? x[c[2]] : (_Float16)0;
+    b[3] = c[3] >= 0 ? x[c[3]] : (_Float16)0;
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, acc, 0, 0, 0);
+}
+
+// diagonal element D[row][row] held by this lane (valid only on the 16 "diagonal lanes")
+__device__ __forceinline__ bool diag_of(const f64x4 &acc, int lane, double &d)
+{
+    const int r = (lane & 15) >> 2;            // D reg r = row (l>>4)+4r, col l&15
+    d = r == 0 ? acc[0] : r == 1 ? acc[1] : r == 2 ? acc[2] : acc[3];
+    return (lane & 3) == (lane >> 4);
+}
+__device__ __forceinline__ bool diag_of(const f32x4 &acc, int lane, float &d)
+{
+    const int r = lane & 3;                    // D reg r = row 4(l>>4)+r, col l&15
+    d = r == 0 ? acc[0] : r == 1 ? acc[1] : r == 2 ? acc[2] : acc[3];
+    return ((lane & 15) >> 2) == (lane >> 4);
+}
+
+// ---- medium: one wave = one block of 16 sorted rows (reference: dasp_f64.h:145-279)
+template <class T, bool NT, bool NATURAL>
+__device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane)
+{
+    using acc_t = typename Tr<T>::acc_t;
+    constexpr int CH = Tr<T>::CHUNK;
+    const T *x = static_cast<const T *>(a.x);
+    const T *val = static_cast<const T *>(a.med_val);
+    const int c0 = a.med_ptr[b], c1 = a.med_ptr[b + 1];
+    acc_t acc = {0, 0, 0, 0};
+    size_t e = (size_t)c0 * CH;
+    int c = c0;
+    for (; c + 4 <= c1; c += 4, e += 4 * CH) {
+        mfma_chunk<NT>(acc, val, a.med_cid, e, lane, x);
+        mfma_chunk<NT>(acc, val, a.med_cid, e + CH, lane, x);
+        mfma_chunk<NT>(acc, val, a.med_cid, e + 2 * CH, lane, x);
+        mfma_chunk<NT>(acc, val, a.med_cid, e + 3 * CH, lane, x);
+    }
+    for (; c < c1; ++c, e += CH) mfma_chunk<NT>(acc, val, a.med_cid, e, lane, x);
+
+    // irregular tail: lane (row = l&15, kq = l>>4) walks its row's leftover entries; the block's
+    // first row is its longest (rows are sorted), so its tail length bounds the loop.
+    const int row = lane & 15, kq = lane >> 4;
+    const int r = b * kMedRows + row;
+    int t0 = 0, t1 = 0;
+    if (r < a.row_block) { t0 = a.irr_ptr[r]; t1 = a.irr_ptr[r + 1]; }
+    const int tmax = __builtin_amdgcn_readfirstlane(t1 - t0);
+    const T *ival = static_cast<const T *>(a.irr_val);
+    if constexpr (sizeof(T) == 8) {
+        for (int j = 0; j < tmax; j += 4) {
+            const int i = t0 + j + kq;
+            const bool ok = i < t1;
+            const double av = ok ? ldg<NT>(ival + i) : 0.0;
+            const double bv = ok ? x[ldg<NT>(a.irr_cid + i)] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+    } else {
+        for (int j = 0; j < tmax; j += 16) {
+            f16x4 av, bv;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = t0 + j + 4 * kq + q;
+                const bool ok = i < t1;
+                av[q] = ok ? ival[i] : (_Float16)0;
+                bv[q] = ok ? x[a.irr_cid[i]] : (_Float16)0;
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, acc, 0, 0, 0);
+        }
+    }
+    typename Tr<T>::part_t d;
+    if (diag_of(acc, lane, d) && r < a.row_block) {
+        const int slot = a.row_long + r;
+        const int yi = NATURAL ? a.order[slot] : slot;
+        static_cast<T *>(a.y)[yi] = (T)d;
+    }
+}
+
+// ---- long: one wave = one piece (<= long_piece elements) of one long row (reference: dasp_f64.h:90-144)
+template <class T, bool NT>
+__device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
+{
+    using acc_t = typename Tr<T>::acc_t;
+    using part_t = typename Tr<T>::part_t;
+    constexpr int CH = Tr<T>::CHUNK;
+    constexpr int VPL = CH / kWave;          // values per lane per MFMA: 1 (f64) / 4 (f16)
+    const T *x = static_cast<const T *>(a.x);
+    const T *val = static_cast<const T *>(a.long_val);
+    const int p0 = a.piece_ptr[p], p1 = a.piece_ptr[p + 1];
+    acc_t acc = {0, 0, 0, 0};
+    int e = p0;
+    for (; e + CH <= p1; e += CH) mfma_chunk<NT>(acc, val, a.long_cid, (size_t)e, lane, x);
+    if (e < p1) {   // last, partial chunk: rows are padded to kLongAlign so a lane's group is all-in or all-out
+        if constexpr (VPL == 1) {
+            const int i = e + lane;
+            const bool ok = i < p1;
+            const double av = ok ? ldg<NT>(val + i) : 0.0;
+            const int c = ok ? ldg<NT>(a.long_cid + i) : -1;
+            const double bv = c >= 0 ? x[c] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        } else {
+            const int i = e + 4 * lane;
+            const bool ok = i < p1;
+            f16x4 av = {0, 0, 0, 0}, bv = {0, 0, 0, 0};
+            if (ok) {
+                av = ldg<NT>(reinterpret_cast<const f16x4 *>(val + i));
+                const i32x4 c = ldg<NT>(reinterpret_cast<const i32x4 *>(a.long_cid + i));
+                bv[0] = c[0] >= 0 ? x[c[0]] : (_Float16)0;
+                bv[1] = c[1] >= 0 ? x[c[1]] : (_Float16)0;
+                bv[2] = c[2] >= 0 ? x[c[2]] : (_Float16)0;
+                bv[3] = c[3] >= 0 ? x[c[3]] : (_Float16)0;
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, acc, 0, 0, 0);
+        }
+    }
+    part_t d;
+    const bool on_diag = diag_of(acc, lane, d);
+    const part_t total = wave_sum(on_diag ? d : (part_t)0);
+    if (lane == 0) {
+        const int dst = a.piece_dst[p];
+        if (dst >= 0) static_cast<T *>(a.y)[dst] = (T)total;
+        else static_cast<part_t *>(a.partial)[~dst] = total;
+    }
+}
+
+// ---- short: one wave = one tile of SHORT_ROWS rows of equal length L; lane owns V consecutive rows
+template <class T, int L, bool NT, bool NATURAL>
+__device__ __forceinline__ void short_rows(const DevArgs &a, const ShortDev &g, int local_tile, int lane)
+{
+    constexpr int SR = Tr<T>::SHORT_ROWS;
+    constexpr int V = SR / kWave;            // 2 (f64) / 4 (f16)
+    const T *x = static_cast<const T *>(a.x);
+    const T *val = static_cast<const T *>(a.short_val);
+    using part_t = typename Tr<T>::part_t;
+    part_t s[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) s[v] = 0;
+    const size_t base = (size_t)g.elem_off + (size_t)local_tile * L * SR + (size_t)V * lane;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        if constexpr (V == 2) {
+            const f64x2 av = ldg<NT>(reinterpret_cast<const f64x2 *>(val + base + (size_t)k * SR));
+            const i32x2 c = ldg<NT>(reinterpret_cast<const i32x2 *>(a.short_cid + base + (size_t)k * SR));
+            s[0] += av[0] * (c[0] >= 0 ? x[c[0]] : 0.0);
+            s[1] += av[1] * (c[1] >= 0 ? x[c[1]] : 0.0);
+        } else {
+            const f16x4 av = ldg<NT>(reinterpret_cast<const f16x4 *>(val + base + (size_t)k * SR));
+            const i32x4 c = ldg<NT>(reinterpret_cast<const i32x4 *>(a.short_cid + base + (size_t)k * SR));
+#pragma unroll
+            for (int v = 0; v < 4; ++v) s[v] += (float)av[v] * (float)(c[v] >= 0 ? x[c[v]] : (_Float16)0);
+        }
+    }
+    const int t0 = local_tile * SR + V * lane;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int t = t0 + v;
+        if (t < g.count) {
+            const int slot = slot_of(g.map, t);
+            const int yi = NATURAL ? a.order[slot] : slot;
+            static_cast<T *>(a.y)[yi] = (T)s[v];
+        }
+    }
+}
+
+template <class T, bool NT, bool NATURAL>
+__device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
+{
+    int gi = 0;
+#pragma unroll
+    for (int g = 1; g < kNumShortGroups; ++g) if (tile >= a.groups[g].tile0) gi = g;
+    const ShortDev g = a.groups[gi];
+    const int local = tile - g.tile0;
+    switch (g.len) {
+        case 1: short_rows<T, 1, NT, NATURAL>(a, g, local, lane); break;
+        case 2: short_rows<T, 2, NT, NATURAL>(a, g, local, lane); break;
+        case 3: short_rows<T, 3, NT, NATURAL>(a, g, local, lane); break;
+        case 4: short_rows<T, 4, NT, NATURAL>(a, g, local, lane); break;
+        default: short_rows<T, 0, NT, NATURAL>(a, g, local, lane); break;   // empty rows: y = 0
+    }
+}
+
+template <class T, bool NT, bool NATURAL>
+__global__ __launch_bounds__(256) void dasp_spmv_kernel(DevArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wg = blockIdx.x;
+    if (wg < a.wg_long) {
+        const int p = wg * kWavesPerWG + wave;
+        if (p < a.n_pieces) long_piece<T, NT>(a, p, lane);
+    } else if (wg < a.wg_long + a.wg_med) {
+        const int b = (wg - a.wg_long) * kWavesPerWG + wave;
+        if (b < a.n_blocks) medium_block<T, NT, NATURAL>(a, b, lane);
+    } else {
+        const int t = (wg - a.wg_long - a.wg_med) * kWavesPerWG + wave;
+        if (t < a.n_short_tiles) short_tile<T, NT, NATURAL>(a, t, lane);
+    }
+}
+
+// stage 2 for long rows cut into several pieces (reference: longPart_sum, dasp_f64.h:53-75)
+template <class T>
+__global__ __launch_bounds__(256) void dasp_long_reduce_kernel(DevArgs a)
+{
+    using part_t = typename Tr<T>::part_t;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kWavesPerWG + (threadIdx.x >> 6);
+    if (i >= a.n_multi) return;
+    const int q0 = a.multi_ptr[i], q1 = a.multi_ptr[i + 1];
+    const part_t *part = static_cast<const part_t *>(a.partial);
+    part_t s = 0;
+    for (int q = q0 + lane; q < q1; q += kWave) s += part[q];
+    s = wave_sum(s);
+    if (lane == 0) static_cast<T *>(a.y)[a.multi_dst[i]] = (T)s;
+}
+
+// ------------------------------------------------------------------ MFMA lane-map self test
+__global__ void selftest_f64_kernel(double *D)
+{
+    const int l = threadIdx.x;
+    const double A = (double)((l & 15) * 4 + (l >> 4) + 1);        // A[i][k] = 4i + k + 1
+    const double B = (double)(((l >> 4) + 1) * 100 + (l & 15));     // B[k][j] = 100(k+1) + j
+    f64x4 acc = {0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A, B, acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) D[((l >> 4) + 4 * r) * 16 + (l & 15)] = acc[r];
+}
+__global__ void selftest_f16_kernel(float *D)
+{
+    const int l = threadIdx.x;
+    f16x4 A, B;
+    for (int j = 0; j < 4; ++j) {
+        const int k = 4 * (l >> 4) + j;
+        A[j] = (_Float16)(float)(((l & 15) + 2 * k) % 7 + 1);       // A[i][k]
+        B[j] = (_Float16)(float)((3 * k + (l & 15)) % 5 + 1);       // B[k][j]
+    }
+    f32x4 acc = {0, 0, 0, 0};
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(A, B, acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) D[(4 * (l >> 4) + r) * 16 + (l & 15)] = acc[r];
+}
+
+// ------------------------------------------------------------------ host side
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+            return e_ == hipErrorNoDevice ? DASP_ERR_NO_DEVICE : DASP_ERR_HIP;                 \
+        }                                                                                      \
+    } while (0)
+
+Plan::~Plan()
+{
+    if (dev) {
+        if (dev->arena) (void)hipFree(dev->arena);
+        delete dev;
+    }
+}
+
+static int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device visible (the DASP GPU path has no CPU fallback)");
+        return DASP_ERR_NO_DEVICE;
+    }
+    return DASP_OK;
+}
+
+int upload_plan(Plan &p)
+{
+    if (int rc = require_device()) return rc;
+    if (p.host_dropped) { set_error("host arrays were dropped"); return DASP_ERR_STATE; }
+    if (p.dev) { if (p.dev->arena) (void)hipFree(p.dev->arena); delete p.dev; p.dev = nullptr; }
+    auto *d = new DevicePlan();
+    p.dev = d;
+    HIP_TRY(hipGetDevice(&d->device));
+
+    std::vector<ShortDev> groups(kNumShortGroups);
+    for (int g = 0; g < kNumShortGroups; ++g) {
+        groups[g].len = p.grp[g].len; groups[g].count = p.grp[g].count; groups[g].tiles = p.grp[g].tiles;
+        groups[g].tile0 = p.grp[g].tile0; groups[g].elem_off = p.grp[g].elem_off; groups[g].map = p.grp[g].map;
+    }
+    const bool natural = p.opt.y_order == DASP_Y_NATURAL;
+    const size_t part_bytes = (size_t)std::max<size_t>(1, p.multi_ptr.empty() ? 0 : (size_t)p.multi_ptr.back()) * 8;
+
+    struct Item { const void *src; size_t bytes; size_t off; };
+    std::vector<Item> items;
+    size_t total = 0;
+    auto add = [&](const void *src, size_t bytes) {
+        size_t off = total;
+        items.push_back({src, bytes, off});
+        total += (bytes + 255) & ~size_t(255);
+        if (bytes == 0) total += 256;
+        return off;
+    };
+    const size_t o_lv = add(p.long_val.data(), p.long_val.size());
+    const size_t o_lc = add(p.long_cid.data(), p.long_cid.size() * 4);
+    const size_t o_pp = add(p.piece_ptr.data(), p.piece_ptr.size() * 4);
+    const size_t o_pd = add(p.piece_dst.data(), p.piece_dst.size() * 4);
+    const size_t o_mp = add(p.multi_ptr.data(), p.multi_ptr.size() * 4);
+    const size_t o_md = add(p.multi_dst.data(), p.multi_dst.size() * 4);
+    const size_t o_part = add(nullptr, part_bytes);
+    const size_t o_mptr = add(p.med_ptr.data(), p.med_ptr.size() * 4);
+    const size_t o_mv = add(p.med_val.data(), p.med_val.size());
+    const size_t o_mc = add(p.med_cid.data(), p.med_cid.size() * 4);
+    const size_t o_ip = add(p.irr_ptr.data(), p.irr_ptr.size() * 4);
+    const size_t o_iv = add(p.irr_val.data(), p.irr_val.size());
+    const size_t o_ic = add(p.irr_cid.data(), p.irr_cid.size() * 4);
+    const size_t o_sv = add(p.short_val.data(), p.short_val.size());
+    const size_t o_sc = add(p.short_cid.data(), p.short_cid.size() * 4);
+    const size_t o_g = add(groups.data(), groups.size() * sizeof(ShortDev));
+    const size_t o_ord = add(natural ? p.order.data() : nullptr, natural ? p.order.size() * 4 : 0);
+
+    HIP_TRY(hipMalloc(&d->arena, total));
+    d->arena_bytes = total;
+    char *base = static_cast<char *>(d->arena);
+    for (const Item &it : items)
+        if (it.src && it.bytes) HIP_TRY(hipMemcpy(base + it.off, it.src, it.bytes, hipMemcpyHostToDevice));
+
+    DevArgs &a = d->args;
+    a.long_val = base + o_lv; a.long_cid = (const int *)(base + o_lc);
+    a.piece_ptr = (const int *)(base + o_pp); a.piece_dst = (const int *)(base + o_pd);
+    a.multi_ptr = (const int *)(base + o_mp); a.multi_dst = (const int *)(base + o_md);
+    a.partial = base + o_part;
+    a.n_pieces = (int)p.piece_dst.size(); a.n_multi = (int)p.multi_dst.size();
+    a.med_ptr = (const int *)(base + o_mptr); a.med_val = base + o_mv; a.med_cid = (const int *)(base + o_mc);
+    a.irr_ptr = (const int *)(base + o_ip); a.irr_val = base + o_iv; a.irr_cid = (const int *)(base + o_ic);
+    a.n_blocks = p.stats.n_med_blocks; a.row_block = p.stats.row_block; a.row_long = p.stats.row_long;
+    a.short_val = base + o_sv; a.short_cid = (const int *)(base + o_sc); a.groups = (const ShortDev *)(base + o_g);
+    a.n_short_tiles = p.stats.n_short_tiles;
+    a.order = natural ? (const int *)(base + o_ord) : nullptr;
+    a.wg_long = (a.n_pieces + kWavesPerWG - 1) / kWavesPerWG;
+    a.wg_med = (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG;
+    a.wg_short = (a.n_short_tiles + kWavesPerWG - 1) / kWavesPerWG;
+    // streamed-once matrix data bypasses the caches (the reference's ld.global.cs, dasp_f64.h:34-51)
+    // only when it cannot stay resident in the 256 MiB Infinity Cache between two SpMVs anyway.
+    d->nt = p.stats.data_X > (200ll << 20);
+    return DASP_OK;
+}
+
+template <class T>
+static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
+{
+    const int grid = a.wg_long + a.wg_med + a.wg_short;
+    const bool nt = p.dev->nt, natural = p.opt.y_order == DASP_Y_NATURAL;
+    if (grid > 0) {
+        if (nt && natural) hipLaunchKernelGGL((dasp_spmv_kernel<T, true, true>), dim3(grid), dim3(256), 0, s, a);
+        else if (nt) hipLaunchKernelGGL((dasp_spmv_kernel<T, true, false>), dim3(grid), dim3(256), 0, s, a);
+        else if (natural) hipLaunchKernelGGL((dasp_spmv_kernel<T, false, true>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((dasp_spmv_kernel<T, false, false>), dim3(grid), dim3(256), 0, s, a);
+    }
+    if (a.n_multi > 0)
+        hipLaunchKernelGGL((dasp_long_reduce_kernel<T>), dim3((a.n_multi + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, s, a);
+    HIP_TRY(hipGetLastError());
+    return DASP_OK;
+}
+
+int launch_spmv(Plan &p, const void *dX, void *dY, void *stream)
+{
+    if (!p.dev || !p.dev->arena) { set_error("plan not uploaded"); return DASP_ERR_STATE; }
+    if (!dX || !dY) { set_error("null device pointer"); return DASP_ERR_ARG; }
+    DevArgs a = p.dev->args;
+    a.x = dX; a.y = dY;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return p.precision == 64 ? launch_typed<double>(p, a, s) : launch_typed<_Float16>(p, a, s);
+}
+
+int time_spmv(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, double *wall_ms, double *event_ms)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int i = 0; i < warmup; ++i) if (int rc = launch_spmv(p, dX, dY, stream)) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) if (int rc = launch_spmv(p, dX, dY, stream)) return rc;
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const auto t1 = std::chrono::steady_clock::now();
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (iters > 0) {
+        if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / iters;
+        if (event_ms) *event_ms = (double)ms / iters;
+    }
+    return DASP_OK;
+}
+
+int selftest_mfma()
+{
+    if (int rc = require_device()) return rc;
+    double *dD = nullptr; float *dF = nullptr;
+    HIP_TRY(hipMalloc(&dD, 256 * sizeof(double)));
+    HIP_TRY(hipMalloc(&dF, 256 * sizeof(float)));
+    hipLaunchKernelGGL(selftest_f64_kernel, dim3(1), dim3(64), 0, 0, dD);
+    hipLaunchKernelGGL(selftest_f16_kernel, dim3(1), dim3(64), 0, 0, dF);
+    HIP_TRY(hipGetLastError());
+    double hD[256]; float hF[256];
+    HIP_TRY(hipMemcpy(hD, dD, sizeof hD, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hF, dF, sizeof hF, hipMemcpyDeviceToHost));
+    (void)hipFree(dD); (void)hipFree(dF);
+    int bad = 0;
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            double e = 0;
+            for (int k = 0; k < 4; ++k) e += (double)(4 * i + k + 1) * (double)(100 * (k + 1) + j);
+            if (hD[i * 16 + j] != e) bad |= 1;
+            float f = 0;
+            for (int k = 0; k < 16; ++k) f += (float)((i + 2 * k) % 7 + 1) * (float)((3 * k + j) % 5 + 1);
+            if (hF[i * 16 + j] != f) bad |= 2;
+        }
+    if (bad) { set_error("MFMA lane map mismatch: mask " + std::to_string(bad)); return DASP_ERR_HIP; }
+    return DASP_OK;
+}
+
+}  // namespace dasp

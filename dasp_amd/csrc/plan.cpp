@@ -1,0 +1,329 @@
+// plan.cpp -- row classifier and the long / medium / short packers (host, multi-threaded).
+// Mirrors the host half of the reference's spmv_all (src/dasp_f64.h:499-1157,
+// src/dasp_f16.h:1029-1443) in the gfx950 geometry described in plan.hpp / DESIGN.md.
+#include "plan.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <functional>
+#include <thread>
+
+namespace dasp {
+
+static thread_local std::string g_err;
+void set_error(const std::string &s) { g_err = s; }
+const char *last_error_cstr() { return g_err.c_str(); }
+
+int resolve_threads(int requested)
+{
+    if (requested > 0) return requested;
+    unsigned hc = std::thread::hardware_concurrency();
+    if (hc == 0) hc = 1;
+    return (int)std::min(hc, 32u);
+}
+
+// f(begin, end) over [0, n) in contiguous ranges
+template <class F>
+static void parallel_for(long long n, int threads, long long grain, F f)
+{
+    if (n <= 0) return;
+    long long parts = std::min<long long>(threads, (n + grain - 1) / grain);
+    if (parts <= 1) { f(0LL, n); return; }
+    std::vector<std::thread> th;
+    th.reserve((size_t)parts);
+    for (long long t = 0; t < parts; ++t) {
+        long long b = n * t / parts, e = n * (t + 1) / parts;
+        th.emplace_back([=] { f(b, e); });
+    }
+    for (auto &x : th) x.join();
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+namespace {
+struct Remap {
+    int n_parts = 0, stride = 0;
+    const int *b = nullptr;
+    inline int operator()(int c) const
+    {
+        if (n_parts <= 0) return c;
+        const int *it = std::upper_bound(b, b + n_parts + 1, c);  // first bound > c
+        int g = (int)(it - b) - 1;
+        return g * stride + (c - b[g]);
+    }
+};
+}  // namespace
+
+template <class T>
+static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
+{
+    using clk = std::chrono::steady_clock;
+    const auto t_begin = clk::now();
+    const Geometry geo = p.geo;
+    const int m = p.m, nnz = p.nnz;
+    const int threads = resolve_threads(p.opt.host_threads);
+    const bool f16 = p.precision == 16;
+    const int block_longest = p.opt.block_longest;
+    const double threshold = p.opt.threshold;
+    Remap remap;
+    remap.n_parts = p.opt.n_parts; remap.stride = p.opt.part_stride; remap.b = p.part_bounds.data();
+
+    // ---- validate CSR (the reference trusts its input; an out-of-range column here would be a
+    // wild device read, so it is an argument error instead)
+    if (rp[0] != 0 || rp[m] != nnz) { set_error("csrRowPtr[0] != 0 or csrRowPtr[rowA] != nnzA"); return DASP_ERR_ARG; }
+    {
+        std::atomic<int> bad{0};
+        parallel_for(m, threads, 1 << 16, [&](long long b, long long e) {
+            for (long long i = b; i < e; ++i) if (rp[i + 1] < rp[i]) { bad = 1; return; }
+        });
+        const int ncol = p.n;
+        parallel_for(nnz, threads, 1 << 18, [&](long long b, long long e) {
+            for (long long i = b; i < e; ++i) if ((unsigned)ci[i] >= (unsigned)ncol) { bad = 2; return; }
+        });
+        if (bad) { set_error(bad == 1 ? "csrRowPtr not monotone" : "column index out of range"); return DASP_ERR_ARG; }
+    }
+
+    // ---- classifier: same tests in the same order as dasp_f64.h:499-531
+    int n1 = 0, n2 = 0, n3 = 0, n4 = 0, nz0 = 0, nlong = 0, nmed = 0;
+    for (int i = 0; i < m; ++i) {
+        const int len = rp[i + 1] - rp[i];
+        if (len == 1) n1++; else if (len == 3) n3++; else if (len == 2) n2++;
+        else if (len == 0) nz0++; else if (len == 4) n4++;
+        else if (len >= block_longest) nlong++; else nmed++;
+    }
+    std::vector<int> rid1(n1), rid2(n2), rid3(n3), rid4(n4), rid0(nz0), ridL(nlong), ridM_in(nmed);
+    {
+        int a = 0, b = 0, c = 0, d = 0, z = 0, e = 0, g = 0;
+        for (int i = 0; i < m; ++i) {
+            const int len = rp[i + 1] - rp[i];
+            if (len == 1) rid1[a++] = i; else if (len == 3) rid3[c++] = i; else if (len == 2) rid2[b++] = i;
+            else if (len == 0) rid0[z++] = i; else if (len == 4) rid4[d++] = i;
+            else if (len >= block_longest) ridL[e++] = i; else ridM_in[g++] = i;
+        }
+    }
+    const int n1_all = n1, n3_all = n3;
+    const int nnz_short = n1 + 3 * n3 + 2 * n2 + 4 * n4;
+    long long nnz_long = 0;
+    for (int r : ridL) nnz_long += rp[r + 1] - rp[r];
+
+    // 1&3 pairing count: dasp_f64.h:597-607 (multiple of 8) / dasp_f16.h:1127-1137 (multiple of 32).
+    // Kept only because it fixes which slots of the output permutation those rows occupy.
+    int c13 = std::min(n1, n3);
+    if (c13 / 8 >= 16) { c13 = f16 ? 32 * (c13 / 32) : 8 * (c13 / 8); n1 -= c13; n3 -= c13; }
+    else c13 = 0;
+
+    // ---- medium rows sorted by length, descending and stable (what utils.h:118-160,196-203 produce);
+    // lengths are < block_longest, so one counting pass does it.
+    std::vector<int> ridM(nmed), lenM(nmed);
+    {
+        std::vector<int> bucket((size_t)std::max(block_longest, 6) + 1, 0);
+        for (int r : ridM_in) bucket[rp[r + 1] - rp[r]]++;
+        int run = 0;
+        for (int L = block_longest; L >= 0; --L) { int c = bucket[L]; bucket[L] = run; run += c; }
+        for (int r : ridM_in) { int L = rp[r + 1] - rp[r]; int at = bucket[L]++; ridM[at] = r; lenM[at] = L; }
+    }
+    std::vector<int>().swap(ridM_in);
+
+    // ---- output permutation (order_rid): dasp_f64.h:960-976 / dasp_f16.h:1253-1270
+    const int base_s = nlong + nmed;
+    const int pg = f16 ? 32 : 8;
+    {
+        SlotMap lin{};  // helper
+        auto linear = [](int count, int base) { SlotMap s{}; s.split = count; s.base[0] = base; s.base[1] = base; return s; };
+        SlotMap m1{}, m3{};
+        int b1, b13, b3, b4, b2, b0;
+        if (!f16) { b1 = base_s; b13 = b1 + n1; b3 = b13 + 2 * c13; b4 = b3 + n3; b2 = b4 + n4; b0 = b2 + n2; }
+        else { b13 = base_s; b3 = b13 + 2 * c13; b4 = b3 + n3; b2 = b4 + n4; b1 = b2 + n2; b0 = b1 + n1; }
+        // len-1 list = rows in row order: first n1 unpaired, last c13 paired
+        m1.split = n1; m1.base[0] = b1; m1.grp[0] = 0; m1.off[0] = 0;
+        m1.base[1] = b13; m1.grp[1] = pg; m1.off[1] = 0;
+        // len-3 list: first c13 paired, rest unpaired
+        m3.split = c13; m3.base[0] = b13; m3.grp[0] = pg; m3.off[0] = pg;
+        m3.base[1] = b3; m3.grp[1] = 0; m3.off[1] = 0;
+        (void)lin;
+        p.grp[0].len = 1; p.grp[0].count = n1_all; p.grp[0].map = m1;
+        p.grp[1].len = 2; p.grp[1].count = n2; p.grp[1].map = linear(n2, b2);
+        p.grp[2].len = 3; p.grp[2].count = n3_all; p.grp[2].map = m3;
+        p.grp[3].len = 4; p.grp[3].count = n4; p.grp[3].map = linear(n4, b4);
+        p.grp[4].len = 0; p.grp[4].count = nz0; p.grp[4].map = linear(nz0, b0);
+    }
+    const std::vector<int> *glist[kNumShortGroups] = {&rid1, &rid2, &rid3, &rid4, &rid0};
+    p.order.assign((size_t)m, -1);
+    for (int i = 0; i < nlong; ++i) p.order[i] = ridL[i];
+    for (int i = 0; i < nmed; ++i) p.order[nlong + i] = ridM[i];
+    for (int g = 0; g < kNumShortGroups; ++g)
+        for (int t = 0; t < p.grp[g].count; ++t) p.order[p.grp[g].map.slot(t)] = (*glist[g])[t];
+    const bool natural = p.opt.y_order == DASP_Y_NATURAL;
+    auto ydst = [&](int slot) { return natural ? p.order[slot] : slot; };
+
+    // ---- long rows: compact, padded to kLongAlign; one wave per piece
+    int piece = p.opt.long_piece > 0 ? p.opt.long_piece : 1024;
+    piece = std::max(geo.chunk, (piece / geo.chunk) * geo.chunk);
+    {
+        std::vector<long long> start((size_t)nlong + 1, 0);
+        for (int i = 0; i < nlong; ++i) {
+            const int len = rp[ridL[i] + 1] - rp[ridL[i]];
+            start[i + 1] = start[i] + (long long)ceil_div(len, kLongAlign) * kLongAlign;
+        }
+        const long long total = start[nlong];
+        if (total >= (1LL << 31)) { set_error("long-row segment exceeds 2^31 elements"); return DASP_ERR_ARG; }
+        p.long_val.assign((size_t)total * sizeof(T), 0);
+        p.long_cid.assign((size_t)total, -1);
+        p.piece_ptr.clear(); p.piece_dst.clear(); p.multi_ptr.assign(1, 0); p.multi_dst.clear();
+        int n_partial = 0;
+        for (int i = 0; i < nlong; ++i) {
+            const long long lp = start[i + 1] - start[i];
+            const int np = (int)((lp + piece - 1) / piece);
+            for (int q = 0; q < np; ++q) {
+                p.piece_ptr.push_back((int)(start[i] + (long long)q * piece));
+                p.piece_dst.push_back(np == 1 ? ydst(i) : ~(n_partial++));
+            }
+            if (np > 1) { p.multi_ptr.push_back(n_partial); p.multi_dst.push_back(ydst(i)); }
+        }
+        p.piece_ptr.push_back((int)total);
+        T *lv = reinterpret_cast<T *>(p.long_val.data());
+        parallel_for(nlong, threads, 64, [&](long long b, long long e) {
+            for (long long i = b; i < e; ++i) {
+                const int r = ridL[i], len = rp[r + 1] - rp[r];
+                const size_t at = (size_t)start[i];
+                for (int j = 0; j < len; ++j) { lv[at + j] = val[rp[r] + j]; p.long_cid[at + j] = remap(ci[rp[r] + j]); }
+            }
+        });
+    }
+
+    // ---- medium rows: regular tiles kept while a 16 x K chunk is >= threshold full
+    // (the reference's rule, dasp_f64.h:1044-1091, on this geometry's tile), rest = irregular tail
+    const int K = geo.med_k, CH = geo.chunk;
+    const int nb = ceil_div(nmed, kMedRows);
+    std::vector<int> nchunks((size_t)nb + 1, 0);
+    p.irr_ptr.assign((size_t)nmed + 1, 0);
+    parallel_for(nb, threads, 256, [&](long long b0, long long b1) {
+        for (long long b = b0; b < b1; ++b) {
+            const int r0 = (int)b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
+            int k = 0;
+            for (;; ++k) {
+                int fill = 0;
+                for (int r = r0; r < r1; ++r) fill += std::min(K, std::max(0, lenM[r] - K * k));
+                if (!(fill >= threshold * CH) || fill == 0) break;
+            }
+            nchunks[b] = k;
+            for (int r = r0; r < r1; ++r) p.irr_ptr[r] = std::max(0, lenM[r] - K * k);
+        }
+    });
+    p.med_ptr.assign((size_t)nb + 1, 0);
+    {
+        long long run = 0;
+        for (int b = 0; b < nb; ++b) { p.med_ptr[b] = (int)run; run += nchunks[b]; }
+        if (run >= (1LL << 31) / 1) { set_error("too many medium chunks"); return DASP_ERR_ARG; }
+        p.med_ptr[nb] = (int)run;
+        long long t = 0;
+        for (int r = 0; r < nmed; ++r) { int v = p.irr_ptr[r]; p.irr_ptr[r] = (int)t; t += v; }
+        p.irr_ptr[nmed] = (int)t;
+    }
+    const long long n_reg = (long long)p.med_ptr[nb] * CH;
+    const int nnz_irreg = p.irr_ptr[nmed];
+    p.med_val.assign((size_t)n_reg * sizeof(T), 0);
+    p.med_cid.assign((size_t)n_reg, -1);
+    p.irr_val.assign((size_t)nnz_irreg * sizeof(T), 0);
+    p.irr_cid.assign((size_t)nnz_irreg, -1);
+    {
+        T *mv = reinterpret_cast<T *>(p.med_val.data());
+        T *iv = reinterpret_cast<T *>(p.irr_val.data());
+        parallel_for(nb, threads, 64, [&](long long b0, long long b1) {
+            for (long long b = b0; b < b1; ++b) {
+                const int nc = p.med_ptr[b + 1] - p.med_ptr[b];
+                const size_t base = (size_t)p.med_ptr[b] * CH;
+                const int r0 = (int)b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
+                for (int r = r0; r < r1; ++r) {
+                    const int rr = r - r0, row = ridM[r], len = lenM[r], a0 = rp[row];
+                    const int nreg = std::min(len, nc * K);
+                    for (int i = 0; i < nreg; ++i) {
+                        const int c = i / K, kk = i % K;
+                        // f64: lane = kk*16 + rr holds A[rr][kk]            (one value per lane)
+                        // f16: lane = (kk/4)*16 + rr holds A[rr][4*(kk/4)..+3] (four values per lane)
+                        const size_t at = f16 ? base + (size_t)c * CH + (size_t)(kk / 4) * 64 + rr * 4 + kk % 4
+                                              : base + (size_t)c * CH + (size_t)kk * kMedRows + rr;
+                        mv[at] = val[a0 + i];
+                        p.med_cid[at] = remap(ci[a0 + i]);
+                    }
+                    const int t0 = p.irr_ptr[r], tl = p.irr_ptr[r + 1] - t0;
+                    for (int j = 0; j < tl; ++j) {   // the LAST tl entries of the row (dasp_f64.h:1094-1106)
+                        iv[t0 + j] = val[a0 + len - tl + j];
+                        p.irr_cid[t0 + j] = remap(ci[a0 + len - tl + j]);
+                    }
+                }
+            }
+        });
+    }
+
+    // ---- short rows: one slab per length, tile-major [tile][k][short_rows]
+    {
+        const int SR = geo.short_rows;
+        long long off = 0; int tile0 = 0;
+        for (int g = 0; g < kNumShortGroups; ++g) {
+            ShortGroup &G = p.grp[g];
+            G.tiles = ceil_div(G.count, SR);
+            G.tile0 = tile0; G.elem_off = off;
+            tile0 += G.tiles;
+            off += (long long)G.tiles * SR * G.len;
+        }
+        if (off >= (1LL << 40)) { set_error("short segment too large"); return DASP_ERR_ARG; }
+        p.short_val.assign((size_t)off * sizeof(T), 0);
+        p.short_cid.assign((size_t)off, -1);
+        T *sv = reinterpret_cast<T *>(p.short_val.data());
+        for (int g = 0; g < 4; ++g) {
+            const ShortGroup &G = p.grp[g];
+            const std::vector<int> &list = *glist[g];
+            parallel_for(G.count, threads, 1 << 14, [&](long long b, long long e) {
+                for (long long t = b; t < e; ++t) {
+                    const int row = list[t], a0 = rp[row];
+                    const size_t tile = (size_t)(t / SR), lr = (size_t)(t % SR);
+                    for (int k = 0; k < G.len; ++k) {
+                        const size_t at = (size_t)G.elem_off + (tile * G.len + k) * SR + lr;
+                        sv[at] = val[a0 + k];
+                        p.short_cid[at] = remap(ci[a0 + k]);
+                    }
+                }
+            });
+        }
+    }
+
+    // ---- stats: the reference's CSV counters (dasp_f64.h:1439-1441) + native sizes
+    dasp_stats_t &s = p.stats;
+    std::memset(&s, 0, sizeof s);
+    s.precision = p.precision; s.rowA = m; s.colA = p.n; s.nnzA = nnz;
+    s.short_row_1 = n1; s.common_13 = c13; s.short_row_3 = n3; s.short_row_4 = n4; s.short_row_2 = n2;
+    s.row_long = nlong; s.row_block = nmed; s.row_zero = nz0;
+    s.nnz_short = nnz_short; s.nnz_long = (int)nnz_long; s.nnz_irreg = nnz_irreg;
+    s.origin_nnz_reg = nnz - nnz_irreg - (int)nnz_long - nnz_short;
+    s.rowloop = nmed < 59990 ? 1 : (nmed < 400000 ? 2 : 4);
+    s.fill0_nnz_short = (long long)p.short_cid.size();
+    s.fill0_nnz_long = (long long)p.long_cid.size();
+    s.fill0_nnz_reg = n_reg;
+    const long long stored = s.fill0_nnz_short + s.fill0_nnz_long + s.fill0_nnz_reg + nnz_irreg;
+    s.rate_fill0 = nnz > 0 ? (double)(stored - nnz) / nnz : 0.0;
+    const long long sv = geo.vbytes;
+    s.data_X = (long long)(m + p.n) * sv + stored * (sv + 4) +
+               (long long)(p.piece_ptr.size() + p.piece_dst.size() + p.multi_ptr.size() + p.multi_dst.size()) * 4 +
+               (long long)(p.med_ptr.size() + p.irr_ptr.size()) * 4 + (natural ? (long long)m * 4 : 0);
+    s.data_origin1 = (long long)(nnz + p.n + m) * sv + (long long)nnz * 4 + (long long)(m + 1) * 4;  // main_f64.cu:143
+    s.n_med_blocks = nb;
+    s.n_long_pieces = (int)p.piece_dst.size();
+    s.n_long_multi = (int)p.multi_dst.size();
+    s.n_short_tiles = 0;
+    for (int g = 0; g < kNumShortGroups; ++g) s.n_short_tiles += p.grp[g].tiles;
+    s.n_workgroups = ceil_div(s.n_long_pieces, kWavesPerWG) + ceil_div(nb, kWavesPerWG) + ceil_div(s.n_short_tiles, kWavesPerWG);
+    s.pre_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
+    return DASP_OK;
+}
+
+int build_plan(Plan &p, const int *rp, const int *ci, const void *val)
+{
+    p.geo = geometry_for(p.precision);
+    if (p.precision == 64) return build_impl<double>(p, rp, ci, static_cast<const double *>(val));
+    return build_impl<_Float16>(p, rp, ci, static_cast<const _Float16 *>(val));
+}
+
+}  // namespace dasp

@@ -1,0 +1,109 @@
+// plan.hpp -- host-side DASP plan in the gfx950-native geometry.
+//
+// What the reference calls "preprocessing" (the host half of spmv_all,
+// src/dasp_f64.h:499-1157 / src/dasp_f16.h:1029-1443) lives here: classify rows by
+// length, sort the medium rows, split them into regular MFMA tiles + irregular tails,
+// lay the long rows out for wave-sized pieces and the short rows as uniform-length slabs.
+// The categories, the 1&3 pairing count and the output permutation (order_rid) are the
+// reference's; the tile geometry is this build's own (DESIGN.md "Data layout in HBM").
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/dasp_amd.h"
+
+namespace dasp {
+
+constexpr int kWave = 64;         // gfx950 wavefront
+constexpr int kWavesPerWG = 4;    // 256-thread workgroups
+constexpr int kMedRows = 16;      // rows of one MFMA tile (v_mfma_*_16x16x*)
+constexpr int kLongAlign = 4;     // long rows start on a multiple of 4 elements
+constexpr int kNumShortGroups = 5;  // row lengths 1,2,3,4 and 0 (zero rows only get y=0)
+
+struct Geometry {
+    int vbytes;      // 8 / 2
+    int med_k;       // K extent of one MFMA tile: 4 (f64 16x16x4) / 16 (f16 16x16x16)
+    int chunk;       // kMedRows * med_k elements = one MFMA = one coalesced wave load
+    int short_rows;  // rows one wave handles in a short slab: 128 (2 per lane) / 256 (4 per lane)
+};
+inline Geometry geometry_for(int precision)
+{
+    return precision == 64 ? Geometry{8, 4, 64, 128} : Geometry{2, 16, 256, 256};
+}
+
+// slot(t) for the t-th row of a short group: two pieces, each linear or "paired"
+// (the reference interleaves 8 (f64) / 32 (f16) len-1 rows with as many len-3 rows).
+struct SlotMap {
+    int split;                 // t <  split -> piece 0 with u = t ; else piece 1 with u = t - split
+    int base[2], grp[2], off[2];   // grp == 0: base + u ; else base + (u / grp) * 2 * grp + off + u % grp
+    int slot(int t) const
+    {
+        const int p = t < split ? 0 : 1;
+        const int u = p ? t - split : t;
+        return grp[p] ? base[p] + (u / grp[p]) * 2 * grp[p] + off[p] + u % grp[p] : base[p] + u;
+    }
+};
+
+struct ShortGroup {
+    int len = 0;            // nonzeros per row (0..4)
+    int count = 0;          // rows
+    int tiles = 0;          // ceil(count / short_rows)
+    int tile0 = 0;          // index of this group's first tile among all short tiles
+    long long elem_off = 0; // first element in short_val / short_cid
+    SlotMap map{};
+};
+
+struct DevicePlan;  // kernels.hip
+
+struct Plan {
+    int precision = 64;
+    Geometry geo{};
+    int m = 0, n = 0, nnz = 0;
+    dasp_options_t opt{};
+    std::vector<int> part_bounds;   // copy of opt.part_bounds
+    dasp_stats_t stats{};
+
+    std::vector<int> order;         // [m]   order_rid
+
+    // long rows: CSR-ordered, each row padded to kLongAlign (val 0, cid -1); pieces of <= long_piece
+    std::vector<char> long_val;     // vbytes per element
+    std::vector<int> long_cid;
+    std::vector<int> piece_ptr;     // [P+1] element offsets
+    std::vector<int> piece_dst;     // [P]   >= 0: y index ; < 0: partial sum ~dst
+    std::vector<int> multi_ptr;     // [R2+1] ranges of partial sums of rows cut into several pieces
+    std::vector<int> multi_dst;     // [R2]  y index
+
+    // medium rows: sorted by length (desc, stable); blocks of 16 rows
+    std::vector<int> med_ptr;       // [nb+1] in chunks
+    std::vector<char> med_val;      // chunk-major, lane-linear inside a chunk
+    std::vector<int> med_cid;
+    std::vector<int> irr_ptr;       // [row_block+1]
+    std::vector<char> irr_val;
+    std::vector<int> irr_cid;
+
+    // short rows: per length one slab, tile-major [tile][k][short_rows]
+    ShortGroup grp[kNumShortGroups];
+    std::vector<char> short_val;
+    std::vector<int> short_cid;
+
+    bool host_dropped = false;
+    DevicePlan *dev = nullptr;
+
+    ~Plan();
+};
+
+// builds every host array of `p` from CSR.  T = double or _Float16.
+int build_plan(Plan &p, const int *rp, const int *ci, const void *val);
+
+// loader (mmio.cpp).  val_out: malloc'd array of double or binary16.
+int load_mtx(const char *path, int precision, int *m, int *n, int *nnz, int *sym, int **rp, int **ci, void **val);
+
+void set_error(const std::string &s);
+
+// threads helper
+int resolve_threads(int requested);
+
+}  // namespace dasp

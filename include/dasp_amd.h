@@ -1,0 +1,183 @@
+/*
+ * dasp_amd.h -- C ABI of libdasp_amd.so: MI355X (gfx950) implementation of the DASP SpMV
+ * hot path.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to the
+ * reference tree, SuperScientificSoftwareLaboratory/DASP).  The reference has no FFI layer:
+ * its boundary is two C++ free functions (mmio_allinone, spmv_all) called from main()
+ * (src/main_f64.cu:129,149; src/main_f16.cu:131,146) -- those are what a maintainer would
+ * re-bind (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - all functions return 0 on success or a negative dasp_status (never abort, never print
+ *     on error); the loader keeps the reference's -1/-2/-4 codes.
+ *   - half precision values cross the boundary as IEEE binary16 bit patterns (uint16_t).
+ *   - device pointers are HIP device pointers of the current process; `stream` is a
+ *     hipStream_t passed as void* (NULL = the null stream).
+ *   - the GPU path has NO CPU fallback: without a usable HIP device the device entry points
+ *     return DASP_ERR_NO_DEVICE / DASP_ERR_HIP.
+ */
+#ifndef DASP_AMD_H
+#define DASP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum dasp_status {
+    DASP_OK = 0,
+    DASP_ERR_OPEN = -1,       /* mmio_allinone: fopen failed        (mmio_highlevel.h:623-624) */
+    DASP_ERR_BANNER = -2,     /* mmio_allinone: bad banner          (mmio_highlevel.h:626-630) */
+    DASP_ERR_SIZE = -4,       /* mmio_allinone: bad size line       (mmio_highlevel.h:638-640) */
+    DASP_ERR_ENTRY = -5,      /* malformed / missing entry, index out of range (reference: undefined) */
+    DASP_ERR_ARG = -10,
+    DASP_ERR_NOMEM = -11,
+    DASP_ERR_NO_DEVICE = -20, /* no HIP device visible */
+    DASP_ERR_HIP = -21,       /* a HIP runtime call failed; see dasp_last_error() */
+    DASP_ERR_STATE = -22      /* e.g. spmv before upload */
+} dasp_status;
+
+/* thread-local text of the last failure ("" if none) */
+const char *dasp_last_error(void);
+/* "dasp_amd <version> gfx950" */
+const char *dasp_version(void);
+
+/* ------------------------------------------------------------------ loader
+ * Replaces  int mmio_allinone(int *m, int *n, MAT_PTR_TYPE *nnz, int *isSymmetric,
+ *                             MAT_PTR_TYPE **csrRowPtr, int **csrColIdx,
+ *                             MAT_VAL_TYPE **csrVal, char *filename)
+ * (src/mmio_highlevel.h:608-610; banner/size rules src/mmio.h:398-624).
+ * Same out-parameters, same CSR (file order inside a row, symmetric/hermitian mirrored
+ * right after the source entry, duplicates kept, columns not sorted), same return codes.
+ * The three arrays are malloc'd; release each with dasp_free (the reference's caller uses
+ * free(): src/main_f64.cu:162-164). */
+int dasp_mmio_allinone_f64(int *m, int *n, int *nnz, int *isSymmetric,
+                           int **csrRowPtr, int **csrColIdx, double **csrVal, const char *filename);
+int dasp_mmio_allinone_f16(int *m, int *n, int *nnz, int *isSymmetric,
+                           int **csrRowPtr, int **csrColIdx, uint16_t **csrVal, const char *filename);
+void dasp_free(void *p);
+
+/* --------------------------------------------------------------- plan API
+ * The reference fuses preprocessing, upload, 1100 launches and download in spmv_all
+ * (src/dasp_f64.h:486-1483).  The plan API is the same work split into reusable steps. */
+typedef struct dasp_plan dasp_plan_t;
+
+typedef enum { DASP_F64 = 64, DASP_F16 = 16 } dasp_precision;
+typedef enum {
+    DASP_Y_PERMUTED = 0, /* y[i] belongs to row order_rid[i]: the reference's output (dasp_f64.h:1402) */
+    DASP_Y_NATURAL = 1   /* y[r] belongs to row r: un-permute fused into the kernel's stores */
+} dasp_y_order;
+
+typedef struct dasp_options {
+    double threshold;      /* regular/irregular fill threshold; reference: 0.75 (main_f64.cu:125) */
+    int block_longest;     /* rows with >= this many nonzeros are "long"; reference: 256 (main_f64.cu:124) */
+    int y_order;           /* dasp_y_order */
+    int long_piece;        /* nonzeros of a long row given to one wave; 0 = default (1024) */
+    int host_threads;      /* preprocessing threads; 0 = hardware concurrency */
+    /* column remap for the row-partitioned multi-GPU layout (0/NULL = identity):
+     * column c owned by part g (part_bounds[g] <= c < part_bounds[g+1]) is read from
+     * x[g * part_stride + (c - part_bounds[g])], i.e. straight out of an all-gather buffer
+     * of equal-size padded slices. */
+    int n_parts;
+    const int *part_bounds; /* [n_parts+1] */
+    int part_stride;
+} dasp_options_t;
+
+void dasp_options_default(dasp_options_t *opt);
+
+/* the reference's CSV counters (src/dasp_f64.h:1439-1441) + this build's own layout sizes */
+typedef struct dasp_stats {
+    int precision, rowA, colA, nnzA;
+    /* classifier -- identical to the reference's columns (short_row_1/3 after pairing) */
+    int short_row_1, common_13, short_row_3, short_row_4, short_row_2, row_long, row_block, row_zero;
+    int nnz_short, nnz_long, origin_nnz_reg, nnz_irreg;
+    int rowloop;               /* reference's 59990/400000 rule, reported only (dasp_f64.h:533-536) */
+    /* native (gfx950 geometry) padded sizes, the analogue of fill0_nnz_* */
+    long long fill0_nnz_short, fill0_nnz_long, fill0_nnz_reg;
+    double rate_fill0;         /* (stored slots - nnzA) / nnzA, as dasp_f64.h:1159-1160 */
+    long long data_X;          /* bytes of the packed format + x + y, as dasp_f64.h:1162-1166 */
+    long long data_origin1;    /* CSR algorithmic bytes, main_f64.cu:143 */
+    int n_med_blocks, n_long_pieces, n_long_multi, n_short_tiles, n_workgroups;
+    double pre_ms;             /* host preprocessing wall time (dasp_f16.h:1444-1445 "dasp_pre") */
+} dasp_stats_t;
+
+/* classifier + packers on the host (no GPU needed).  CSR arrays are read-only and may be
+ * freed afterwards.  csrVal: double* for DASP_F64, uint16_t* (binary16) for DASP_F16.
+ * Mirrors the host part of spmv_all: dasp_f64.h:499-1157 / dasp_f16.h:1029-1443. */
+int dasp_plan_create(dasp_plan_t **plan, int precision, int rowA, int colA, int nnzA,
+                     const int *csrRowPtr, const int *csrColIdx, const void *csrVal,
+                     const dasp_options_t *opt /* NULL = defaults */);
+void dasp_plan_destroy(dasp_plan_t *plan);
+
+/* order_rid[i] = original row of permuted slot i (dasp_f64.h:960-976 / dasp_f16.h:1253-1270);
+ * identical to the reference's array.  Owned by the plan. */
+const int *dasp_plan_order(const dasp_plan_t *plan);
+int dasp_plan_stats(const dasp_plan_t *plan, dasp_stats_t *out);
+
+/* read-only view of a packed host array, for format tests and serialisation.
+ * returns element count, or a negative dasp_status for an unknown name. */
+long long dasp_plan_host_array(const dasp_plan_t *plan, const char *name, const void **ptr, int *elem_bytes);
+
+/* hipMalloc + H2D of the packed arrays on the CURRENT device (dasp_f64.h:1239-1278) */
+int dasp_plan_upload(dasp_plan_t *plan);
+/* release the host copies of the packed arrays once uploaded (order_rid and stats stay) */
+int dasp_plan_drop_host(dasp_plan_t *plan);
+
+/* one SpMV, y = A*x, asynchronous on `stream`.  dX: colA values (or the part_stride layout),
+ * dY: rowA values, both device pointers of the plan's precision.
+ * Replaces the launches dasp_spmv2<rowloop><<<>>> + longPart_sum<<<>>>
+ * (dasp_f64.h:1291-1319 / dasp_f16.h:1548-1704). */
+int dasp_plan_spmv(dasp_plan_t *plan, const void *dX, void *dY, void *stream);
+
+/* the reference's timing protocol (dasp_f64.h:1285-1320,1394): `warmup` untimed + `iters`
+ * timed back-to-back SpMVs on `stream`, one sync at the end.
+ * wall_ms_per_iter: host clock; event_ms_per_iter: hipEvent pair recorded on `stream`. */
+int dasp_plan_time(dasp_plan_t *plan, const void *dX, void *dY, void *stream, int warmup, int iters,
+                   double *wall_ms_per_iter, double *event_ms_per_iter);
+
+/* ---------------------------------------------------------------- one-shot
+ * Replaces  void spmv_all(char *filename, MAT_VAL_TYPE *csrValA, MAT_PTR_TYPE *csrRowPtrA,
+ *                         int *csrColIdxA, MAT_VAL_TYPE *X_val, MAT_VAL_TYPE *Y_val,
+ *                         int *order_rid, int rowA, int colA, MAT_PTR_TYPE nnzA, int NUM,
+ *                         double threshold, int block_longest)
+ * (src/dasp_f64.h:486-487, src/dasp_f16.h:1015-1016).  Host buffers in, Y_val (permuted) and
+ * order_rid out; prints the reference's "SpMV_X: ms, GFlop/s, GB/s, GB/s" line and appends
+ * the reference's CSV row to data/spmv_f64_record.csv / data/spmv_f16_record.csv when the
+ * data/ directory exists.  NUM is accepted and ignored, as in the reference. */
+int dasp_spmv_all_f64(const char *filename, const double *csrValA, const int *csrRowPtrA,
+                      const int *csrColIdxA, const double *X_val, double *Y_val, int *order_rid,
+                      int rowA, int colA, int nnzA, int NUM, double threshold, int block_longest);
+int dasp_spmv_all_f16(const char *filename, const uint16_t *csrValA, const int *csrRowPtrA,
+                      const int *csrColIdxA, const uint16_t *X_val, uint16_t *Y_val, int *order_rid,
+                      int rowA, int colA, int nnzA, int NUM, double threshold, int block_longest);
+
+/* ---------------------------------------------------------------- multi-GPU helper
+ * (no reference counterpart: the reference is single-GPU).  Contiguous row ranges with
+ * equal nonzero counts: bounds[0]=0 <= ... <= bounds[n_parts]=rowA. */
+int dasp_partition_rows(int rowA, const int *csrRowPtr, int n_parts, int *bounds);
+
+/* ---------------------------------------------------------------- device self-test
+ * known-answer check of the MFMA operand / accumulator lane maps this library relies on
+ * (v_mfma_f64_16x16x4_f64, v_mfma_f32_16x16x16_f16).  0 = maps as assumed. */
+int dasp_selftest_mfma(void);
+
+/* ---------------------------------------------------------------- synthetic inputs
+ * Seeded stand-ins for the SuiteSparse matrices BASELINE.json names (no .mtx files and no
+ * network on the build/bench machines).  Rows [row_begin,row_end) of the named matrix are
+ * generated as CSR (global column ids, file-like order inside a row); every row can be
+ * generated independently, so ranks of a multi-GPU run build only their slice.
+ *   names: "cop20k_A" "nlpkkt160" "powerlaw_1M" "webbase-1M" "ljournal-2008" "HV15R" "Queen_4147"
+ *   scale: 1.0 = the collection's size; <1 shrinks the row count (tests). */
+int dasp_synth_dims(const char *name, double scale, int *rows, int *cols);
+int dasp_synth_row_lengths(const char *name, double scale, int row_begin, int row_end, int *len_out);
+int dasp_synth_rows(const char *name, double scale, int row_begin, int row_end,
+                    const int *row_ptr_local /* [row_end-row_begin+1], exclusive scan of lengths */,
+                    int *col_idx_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DASP_AMD_H */

@@ -1,0 +1,192 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs.
+  f64: |y - y_csr| <= 1e-12 * sum_j |a_ij x_j|   (BASELINE.json north_star: 1e-12 relative)
+  f16: |y - y_csr| <= 1e-2  * sum_j |a_ij x_j|   (north_star: 1e-2; f16 inputs, f32 accumulate, f16 store)
+  A == 1, x == 1 (the reference driver's mode): y[i] == nnz(row order_rid[i]) EXACTLY.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = {64: 1e-12, 16: 1e-2}
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU; there is no CPU fallback to hide behind"
+    torch.cuda.set_device(0)
+    return torch
+
+
+def tdtype(torch, prec):
+    return torch.float64 if prec == 64 else torch.float16
+
+
+def run_spmv(torch, plan, xh, rows, prec):
+    x = torch.from_numpy(np.ascontiguousarray(xh)).cuda()
+    y = torch.full((max(rows, 1),), float("nan"), dtype=tdtype(torch, prec), device="cuda")   # every slot must be written
+    plan.spmv(x.data_ptr(), y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return y[:rows].double().cpu().numpy()
+
+
+def check(oracle, dasp, torch, rp, ci, v, n, prec, **kw):
+    dt = np.float64 if prec == 64 else np.float16
+    v = v.astype(dt)
+    rng = np.random.default_rng(99)
+    xh = (rng.uniform(-1, 1, n) if prec == 64 else rng.uniform(0.5, 1.5, n)).astype(dt)
+    m = rp.size - 1
+    ref = oracle.csr_spmv(rp, ci, v.astype(np.float64), xh.astype(np.float64))
+    scale = np.maximum(oracle.csr_absrow(rp, ci, v.astype(np.float64), xh.astype(np.float64)), 1e-300)
+    for y_order in (dasp.Y_PERMUTED, dasp.Y_NATURAL):
+        plan = dasp.Plan(rp, ci, v, n, precision=prec, y_order=y_order, **kw).upload()
+        got = run_spmv(torch, plan, xh, m, prec)
+        perm = plan.order_rid if y_order == dasp.Y_PERMUTED else np.arange(m)
+        err = np.abs(got - ref[perm]) / scale[perm]
+        assert np.isfinite(got).all()
+        assert err.max() <= TOL[prec], (prec, y_order, err.max(), int(err.argmax()))
+        plan.close()
+    # the reference driver's mode: all-ones values and x -> exact row lengths
+    lens = np.diff(rp)
+    plan = dasp.Plan(rp, ci, np.ones(ci.size, dt), n, precision=prec, **kw).upload()
+    got = run_spmv(torch, plan, np.ones(n, dt), m, prec)
+    want = lens[plan.order_rid].astype(np.float64)
+    if prec == 16:
+        want = want.astype(np.float16).astype(np.float64)       # rows longer than 2048 round on the f16 store
+    assert (got == want).all()
+    plan.close()
+
+
+def test_mfma_lane_maps(dasp, torch_cuda):
+    dasp.selftest_mfma()
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("tag,builder,m,n,seed", [
+    ("mixed", util.mixed_matrix, 3000, 2500, 7),
+    ("pairs", util.pair_heavy_matrix, 4000, 3000, 11),
+    ("tiny", util.mixed_matrix, 37, 50, 3),
+    ("one_row", util.mixed_matrix, 1, 10, 5),
+])
+def test_parity_seeded(oracle, dasp, torch_cuda, prec, tag, builder, m, n, seed):
+    rp, ci, v = builder(m, n, seed, values="f16" if prec == 16 else "uniform")
+    check(oracle, dasp, torch_cuda, rp, ci, v, n, prec)
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+def test_long_rows_cut_into_pieces(oracle, dasp, torch_cuda, prec):
+    """rows longer than long_piece exercise the partial sums + dasp_long_reduce_kernel"""
+    lens = [5000, 256, 1023, 1024, 1025, 4096, 300, 7, 2, 20000, 0, 700]
+    rp, ci, v = util.csr_from_lengths(lens, 30000, 4, values="f16" if prec == 16 else "uniform")
+    check(oracle, dasp, torch_cuda, rp, ci, v, 30000, prec)
+    check(oracle, dasp, torch_cuda, rp, ci, v, 30000, prec, long_piece=256)
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("lens", [[5] * 100, [255] * 33, [17, 16, 16, 5], [4] * 1000, [1] * 300 + [3] * 300, [0] * 70,
+                                   [2] * 129, [3] * 257, [6, 0, 6, 0, 1]])
+def test_single_category_edges(oracle, dasp, torch_cuda, prec, lens):
+    rp, ci, v = util.csr_from_lengths(lens, 997, 13, values="f16" if prec == 16 else "uniform")
+    check(oracle, dasp, torch_cuda, rp, ci, v, 997, prec)
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+def test_empty_matrix(dasp, torch_cuda, prec):
+    rp = np.zeros(9, np.int32)
+    plan = dasp.Plan(rp, np.zeros(0, np.int32), np.zeros(0), 4, precision=prec).upload()
+    got = run_spmv(torch_cuda, plan, np.ones(4, np.float64 if prec == 64 else np.float16), 8, prec)
+    assert (got == 0).all()
+
+
+@pytest.mark.parametrize("name,prec,scale", [
+    ("cop20k_A", 64, 0.1), ("nlpkkt160", 64, 0.004), ("powerlaw_1M", 64, 0.05), ("HV15R", 64, 0.01),
+    ("Queen_4147", 64, 0.005), ("webbase-1M", 16, 0.1), ("ljournal-2008", 16, 0.01),
+])
+def test_parity_synthetic_standins(oracle, dasp, torch_cuda, name, prec, scale):
+    rows, cols = dasp.synth_dims(name, scale)
+    rp, ci = dasp.synth_csr(name, scale)
+    rng = np.random.default_rng(1)
+    v = rng.uniform(0.5, 1.5, ci.size) if prec == 16 else rng.uniform(-1, 1, ci.size)
+    check(oracle, dasp, torch_cuda, rp, ci, v, cols, prec)
+
+
+def test_padded_slots_do_not_read_x0(oracle, dasp, torch_cuda):
+    """the reference's padded slots multiply 0 by x[0] (dasp_f64.h:1127-1128): x[0] = inf poisons
+    unrelated rows there.  Here pads never touch x."""
+    rp, ci, v = util.mixed_matrix(2000, 1500, 17)
+    ci = np.where(ci == 0, 1, ci).astype(np.int32)            # no row references column 0
+    x = np.random.default_rng(1).uniform(-1, 1, 1500)
+    x[0] = np.inf
+    plan = dasp.Plan(rp, ci, v, 1500).upload()
+    got = run_spmv(torch_cuda, plan, x, 2000, 64)
+    assert np.isfinite(got).all()
+
+
+def test_one_shot_spmv_all(oracle, dasp, torch_cuda, capfd):
+    """spmv_all with the reference's argument list: Y in permuted order + order_rid, result line on stdout"""
+    for prec in (64, 16):
+        dt = np.float64 if prec == 64 else np.float16
+        rp, ci, v = util.mixed_matrix(1500, 1200, 23, values="ones")
+        y, order = dasp.spmv_all("mixed.mtx", v.astype(dt), rp, ci, np.ones(1200, dt), 1500, 1200, int(rp[-1]), 4, 0.75, 256, precision=prec)
+        P = oracle.Packed(prec, rp, ci, v, 1200)
+        assert (order == P.order_rid).all()
+        want = np.diff(rp)[order].astype(dt).astype(np.float64)
+        assert (y.astype(np.float64) == want).all()
+    assert "SpMV_X:" in capfd.readouterr().out          # dasp_f64.h:1398
+
+
+def test_partitioned_x_layout(oracle, dasp, torch_cuda):
+    """row slice + column remap: x is read from an all-gather-shaped buffer of padded slices"""
+    torch = torch_cuda
+    rp, ci, v = util.mixed_matrix(900, 900, 31)
+    bounds = dasp.partition_rows(rp, 3)
+    stride = int(np.diff(bounds).max()) + 5
+    x = np.random.default_rng(2).uniform(-1, 1, 900)
+    xg = np.zeros(3 * stride)
+    for g in range(3):
+        xg[g * stride: g * stride + bounds[g + 1] - bounds[g]] = x[bounds[g]:bounds[g + 1]]
+    ref = oracle.csr_spmv(rp, ci, v, x)
+    scale = np.maximum(oracle.csr_absrow(rp, ci, v, x), 1e-300)
+    for g in range(3):
+        r0, r1 = bounds[g], bounds[g + 1]
+        sl = slice(rp[r0], rp[r1])
+        plan = dasp.Plan(rp[r0:r1 + 1] - rp[r0], ci[sl], v[sl], 900, y_order=dasp.Y_NATURAL, part_bounds=bounds, part_stride=stride).upload()
+        got = run_spmv(torch, plan, xg, r1 - r0, 64)
+        assert (np.abs(got - ref[r0:r1]) / scale[r0:r1]).max() <= 1e-12
+
+
+def test_timing_protocol(dasp, torch_cuda):
+    torch = torch_cuda
+    rp, ci, v = util.mixed_matrix(20000, 20000, 41)
+    plan = dasp.Plan(rp, ci, v, 20000).upload()
+    x = torch.ones(20000, dtype=torch.float64, device="cuda")
+    y = torch.zeros(20000, dtype=torch.float64, device="cuda")
+    wall, ev = plan.time(x.data_ptr(), y.data_ptr(), torch.cuda.current_stream().cuda_stream, warmup=10, iters=50)
+    assert 0 < ev < 50 and 0 < wall < 50
+
+
+def test_spmv_before_upload_is_an_error(dasp, torch_cuda):
+    rp, ci, v = util.mixed_matrix(10, 10, 1)
+    plan = dasp.Plan(rp, ci, v, 10)
+    with pytest.raises(dasp.DaspError) as e:
+        plan.spmv(1, 1)
+    assert e.value.status == -22
+
+
+@pytest.mark.parametrize("exe,fixture", [("dasp_f64", "sym_real.mtx"), ("dasp_f16", "gen_real.mtx")])
+def test_cli_drivers(torch_cuda, exe, fixture, tmp_path):
+    """spmv_double / spmv_half equivalents: load .mtx, all-ones, spmv_all, verify through order_rid"""
+    (tmp_path / "data").mkdir()
+    r = subprocess.run([os.path.join(ROOT, "dasp_amd", "bin", exe), os.path.join(ROOT, "tests", "golden", fixture)],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "compute succeed" in r.stdout and "SpMV_X:" in r.stdout
+    csv = (tmp_path / "data" / ("spmv_f64_record.csv" if exe == "dasp_f64" else "spmv_f16_record.csv")).read_text()
+    assert csv.startswith(os.path.join(ROOT, "tests", "golden", fixture) + ",")

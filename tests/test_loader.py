@@ -1,0 +1,78 @@
+"""Product loader (dasp_amd/csrc/mmio.cpp through the C ABI) == oracle restatement of
+mmio_allinone, on the committed fixtures and on generated files (all field types, symmetry,
+duplicates, empty rows); f16 values are the correctly rounded binary16 of the parsed double."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+EXP = json.load(open(os.path.join(GOLD, "expected.json")))
+MTX = sorted(k for k in EXP if k.endswith(".mtx"))
+
+
+@pytest.mark.parametrize("name", MTX)
+def test_fixture(dasp, name):
+    e = EXP[name]
+    path = os.path.join(GOLD, name)
+    if e["rc"] != 0:
+        with pytest.raises(dasp.DaspError) as err:
+            dasp.mmio_allinone(path)
+        assert err.value.status == e["rc"]       # -2 banner / -4 size, as mmio_highlevel.h:626-640
+        return
+    m, n, nnz, sym, rp, ci, v = dasp.mmio_allinone(path, 64)
+    assert (m, n, nnz, sym) == (e["m"], e["n"], e["nnz"], e["sym"])
+    assert rp.tolist() == e["row_ptr"] and ci.tolist() == e["col_idx"] and v.tolist() == e["val"]
+    m, n, nnz, sym, rp, ci, h = dasp.mmio_allinone(path, 16)
+    assert h.dtype == np.float16 and (h == np.asarray(e["val"]).astype(np.float16)).all()
+
+
+def write_mtx(path, m, n, rows, cols, vals, field, symm, rng):
+    with open(path, "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate %s %s\n%% generated\n%d %d %d\n" % (field, symm, m, n, len(rows)))
+        for i, j, v in zip(rows, cols, vals):
+            if field == "pattern":
+                f.write("%d %d\n" % (i + 1, j + 1))
+            elif field == "integer":
+                f.write("%d %d %d\n" % (i + 1, j + 1, int(v)))
+            elif field == "complex":
+                f.write("%d %d %.17g %.17g\n" % (i + 1, j + 1, v, rng.uniform()))
+            else:
+                f.write("%d %d %s\n" % (i + 1, j + 1, rng.choice(["%.17g", "%.6e", "%+.3f", "%g"]) % v))
+
+
+@pytest.mark.parametrize("field", ["real", "pattern", "integer", "complex"])
+@pytest.mark.parametrize("symm", ["general", "symmetric", "hermitian", "skew-symmetric"])
+def test_random_files_match_oracle(dasp, oracle, tmp_path, field, symm):
+    rng = np.random.default_rng(hash((field, symm)) % 2 ** 32)
+    m = n = 300
+    k = 4000
+    rows = rng.integers(0, m, k)
+    cols = rng.integers(0, n, k)
+    if symm != "general":
+        lo = np.minimum(rows, cols)
+        rows, cols = np.maximum(rows, cols), lo          # lower triangle, diagonal and duplicates included
+    vals = rng.uniform(-50, 50, k)
+    p = str(tmp_path / "r.mtx")
+    write_mtx(p, m, n, rows, cols, vals, field, symm, rng)
+    rc, om, on, onnz, osym, orp, oci, ov = oracle.mmio_allinone(p)
+    assert rc == 0
+    gm, gn, gnnz, gsym, grp, gci, gv = dasp.mmio_allinone(p, 64)
+    assert (gm, gn, gnnz, gsym) == (om, on, onnz, osym)
+    assert (grp == orp).all() and (gci == oci).all()
+    assert (gv == ov).all()                               # bit-exact doubles
+    *_, hv = dasp.mmio_allinone(p, 16)
+    assert (hv == ov.astype(np.float16)).all()
+
+
+def test_entry_errors(dasp, tmp_path):
+    p = tmp_path / "short.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real general\n3 3 3\n1 1 1.0\n2 2 2.0\n")
+    with pytest.raises(dasp.DaspError) as e:
+        dasp.mmio_allinone(str(p))
+    assert e.value.status == -5
+    p.write_text("%%MatrixMarket matrix coordinate real general\n3 3 1\n4 1 1.0\n")
+    with pytest.raises(dasp.DaspError) as e:
+        dasp.mmio_allinone(str(p))
+    assert e.value.status == -5

@@ -1,0 +1,78 @@
+"""N > 1 path on CPU (gloo, world_size 2): row partition by nonzeros, per-rank plans with the
+column remap, all-gather of padded y slices into the layout x is read from.  The local SpMV is
+done by the CPU oracle here (tests may use it; the product path has no CPU fallback) -- what is
+under test is the sharding / exchange logic bench.py uses with RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import dasp_amd as D
+    from oracle import oracle as O
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = n = 1200
+        rp, ci, v = util.mixed_matrix(m, n, 77)
+        bounds = D.partition_rows(rp, world)
+        stride = (int(np.diff(bounds).max()) + 63) // 64 * 64
+        r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+        sl = slice(rp[r0], rp[r1])
+        plan = D.Plan(rp[r0:r1 + 1] - rp[r0], ci[sl], v[sl], n, y_order=D.Y_NATURAL, part_bounds=bounds, part_stride=stride)
+        # x in the gathered layout; every rank starts from the same x
+        x = np.random.default_rng(5).uniform(-1, 1, n)
+        xg = np.zeros(world * stride)
+        for g in range(world):
+            xg[g * stride: g * stride + bounds[g + 1] - bounds[g]] = x[bounds[g]:bounds[g + 1]]
+        # the plan's remapped columns index xg exactly where the global column's x lives
+        rows = util.decode_plan(plan)
+        order = plan.order_rid
+        y_local = np.zeros(stride)
+        for slot, (cs, vs) in rows.items():
+            y_local[order[slot]] = float(np.dot(np.asarray(vs, np.float64), xg[np.asarray(cs, np.int64)])) if cs else 0.0
+        gathered = torch.zeros(world * stride, dtype=torch.float64)
+        dist.all_gather_into_tensor(gathered, torch.from_numpy(y_local))
+        full = np.concatenate([gathered.numpy()[g * stride: g * stride + bounds[g + 1] - bounds[g]] for g in range(world)])
+        ref = O.csr_spmv(rp, ci, v, x)
+        scale = np.maximum(O.csr_absrow(rp, ci, v, x), 1e-300)
+        err = float((np.abs(full - ref) / scale).max())
+        q.put((rank, err, int(np.diff(rp[bounds]).max()), int(rp[-1])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_partition_and_allgather():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, max_part, nnz in res:
+        assert err <= 1e-12
+        assert max_part <= nnz / 2 + 2500          # balanced by nonzeros up to one row

@@ -1,0 +1,110 @@
+"""The oracle against its pins: the reference's own mmio.h (oracle/_ref), the radix-sort
+known-answer vector recorded from the real code, the committed fixtures,
+and the reference's accounting / all-ones identities."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import util
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+EXP = json.load(open(os.path.join(GOLD, "expected.json")))
+MTX = sorted(k for k in EXP if k.endswith(".mtx"))
+
+
+def test_radix_known_answer(oracle):
+    ka = EXP["radix_known_answer"]
+    k, i = oracle.radix_sort_desc(ka["key"], ka["idx"])
+    assert k.tolist() == ka["key_sorted"] and i.tolist() == ka["idx_sorted"]
+
+
+def test_radix_is_stable_descending(oracle):
+    rng = np.random.default_rng(3)
+    key = rng.integers(5, 256, 5000)
+    k, i = oracle.radix_sort_desc(key, np.arange(key.size))
+    ref = np.argsort(-key, kind="stable")
+    assert (i == ref).all() and (k == key[ref]).all()
+
+
+def test_exclusive_scan(oracle):
+    assert oracle.exclusive_scan([3, 1, 4, 1, 5]).tolist() == [0, 3, 4, 8, 9]
+    assert oracle.exclusive_scan([7]).tolist() == [7]      # len 1 is left untouched (mmio_highlevel.h:12-13)
+    assert oracle.exclusive_scan([]).tolist() == []
+
+
+@pytest.mark.parametrize("name", MTX)
+def test_banner_and_size_match_reference_mmio(oracle, name):
+    """oracle restatement == the reference's own mmio.h compiled into oracle/_ref"""
+    R = oracle.ref_mmio()
+    if R is None:
+        pytest.skip("oracle/_ref not built (reference tree absent and no prebuilt copy)")
+    p = os.path.join(GOLD, name).encode()
+    tc = C.create_string_buffer(4)
+    rc = R.ref_mm_read_banner_path(p, tc)
+    assert (rc, tc.raw.decode("latin1")) == oracle.mm_read_banner(p.decode())
+    M, N, nz = C.c_int(), C.c_int(), C.c_int()
+    rc2 = R.ref_mm_read_size_path(p, C.byref(M), C.byref(N), C.byref(nz))
+    assert (rc2, M.value, N.value, nz.value) == oracle.mm_read_size(p.decode())
+
+
+@pytest.mark.parametrize("name", MTX)
+def test_loader_fixtures(oracle, name):
+    e = EXP[name]
+    rc, m, n, nnz, sym, rp, ci, v = oracle.mmio_allinone(os.path.join(GOLD, name))
+    assert rc == e["rc"]
+    assert oracle.mm_read_banner(os.path.join(GOLD, name)) == (e["banner_rc"], e["typecode"])
+    if rc == 0:
+        assert (m, n, nnz, sym) == (e["m"], e["n"], e["nnz"], e["sym"])
+        assert rp.tolist() == e["row_ptr"] and ci.tolist() == e["col_idx"] and v.tolist() == e["val"]
+
+
+def test_symmetric_4x4_matches_survey_run(oracle):
+    """CSR the surveyor obtained from the real loader on a 4x4 symmetric file"""
+    s = EXP["sym4_survey"]
+    rc, m, n, nnz, sym, rp, ci, v = oracle.mmio_allinone(os.path.join(GOLD, s["file"]))
+    assert rc == 0 and rp.tolist() == s["row_ptr"] and ci.tolist() == s["col_idx"]
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("builder,m,n,seed", [(util.mixed_matrix, 3000, 2500, 7), (util.pair_heavy_matrix, 4000, 3000, 11)])
+def test_pack_identities_and_eval(oracle, prec, builder, m, n, seed):
+    rp, ci, v = builder(m, n, seed)
+    P = oracle.Packed(prec, rp, ci, v, n)
+    lens = np.diff(rp)
+    # the reference's accounting identity (dasp_f64.h:1091)
+    assert P.nnz_short + P.nnz_long + P.origin_nnz_reg + P.nnz_irreg == P.nnzA
+    # order_rid is a permutation, categories in the documented order
+    assert sorted(P.order_rid.tolist()) == list(range(m))
+    assert (lens[P.order_rid[: P.row_long]] >= 256).all()
+    ml = lens[P.order_rid[P.row_long: P.row_long + P.row_block]]
+    assert ((ml >= 5) & (ml < 256)).all() and (np.diff(ml) <= 0).all()
+    assert (lens[P.order_rid[m - P.row_zero:]] == 0).all()
+    # evaluation of the packed format == CSR product
+    x = np.random.default_rng(5).uniform(-1, 1, n)
+    y = P.eval(x)
+    yref = oracle.csr_spmv(rp, ci, v, x)
+    scale = oracle.csr_absrow(rp, ci, v, x)
+    assert (np.abs(y - yref[P.order_rid]) <= 1e-12 * np.maximum(scale[P.order_rid], 1e-300)).all()
+    # all-ones identity of the reference's driver: y[i] == nnz(row order_rid[i]) exactly
+    P1 = oracle.Packed(prec, rp, ci, np.ones_like(v), n)
+    assert (P1.eval(np.ones(n)) == lens[P1.order_rid]).all()
+
+
+def test_packer_regression_values(oracle):
+    for tag, e in EXP["packer_cases"].items():
+        builder = {"mixed": util.mixed_matrix, "pairs": util.pair_heavy_matrix}[e["builder"]]
+        rp, ci, v = builder(e["m"], e["n"], e["seed"])
+        P = oracle.Packed(int(tag[-2:]), rp, ci, v, e["n"])
+        for f, want in e.items():
+            if f in ("builder", "m", "n", "seed"):
+                continue
+            got = "%016x" % oracle.fnv1a_i32(P.order_rid) if f == "order_fnv" else int(getattr(P, f))
+            assert got == want, (tag, f)
+
+
+def test_round_f16(oracle):
+    a = np.array([0.0, 1.0, 1.0009765625, 1.00048828125, 65504.0, 1e-8, 3.14159, -2.71828])
+    assert (oracle.round_f16(a) == a.astype(np.float16).astype(np.float64)).all()

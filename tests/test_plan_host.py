@@ -1,0 +1,106 @@
+"""Host half of the plan (classifier + packers, no GPU): category counts and the output
+permutation are bit-identical to the oracle's restatement of the reference; the native packed
+arrays decode back to exactly the CSR rows (every nonzero once, in row order, pads only at row ends)."""
+import numpy as np
+import pytest
+
+import util
+
+CASES = [
+    ("mixed", util.mixed_matrix, 3000, 2500, 7),
+    ("pairs", util.pair_heavy_matrix, 4000, 3000, 11),
+    ("tiny", util.mixed_matrix, 37, 50, 3),
+]
+COUNT_FIELDS = "row_long row_block row_zero rowloop short_row_1 short_row_2 short_row_3 short_row_4 common_13 nnz_short nnz_long".split()   # nnz_irreg / origin_nnz_reg depend on the tile geometry
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("tag,builder,m,n,seed", CASES)
+def test_counts_and_order_match_oracle(dasp, oracle, prec, tag, builder, m, n, seed):
+    dt = np.float64 if prec == 64 else np.float16
+    rp, ci, v = builder(m, n, seed, values="f16" if prec == 16 else "uniform", dtype=dt)
+    plan = dasp.Plan(rp, ci, v, n, precision=prec)
+    P = oracle.Packed(prec, rp, ci, v.astype(np.float64), n)
+    st = plan.stats
+    for f in COUNT_FIELDS:
+        assert st[f] == getattr(P, f), f
+    assert (plan.order_rid == P.order_rid).all()          # identical output permutation
+    assert st["data_origin1"] == (rp[-1] + n + m) * (prec // 8) + rp[-1] * 4 + (m + 1) * 4   # main_f64.cu:143
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("tag,builder,m,n,seed", CASES)
+@pytest.mark.parametrize("piece", [0, 256])
+def test_native_format_decodes_to_csr(dasp, prec, tag, builder, m, n, seed, piece):
+    dt = np.float64 if prec == 64 else np.float16
+    rp, ci, v = builder(m, n, seed, values="f16" if prec == 16 else "uniform", dtype=dt)
+    plan = dasp.Plan(rp, ci, v, n, precision=prec, long_piece=piece)
+    rows = util.decode_plan(plan)
+    order = plan.order_rid
+    assert sorted(rows) == list(range(m))
+    for slot in range(m):
+        r = order[slot]
+        cs, vs = rows[slot]
+        assert cs == ci[rp[r]:rp[r + 1]].tolist(), (slot, r)
+        assert np.array_equal(np.asarray(vs, dt), v[rp[r]:rp[r + 1]]), (slot, r)
+    st = plan.stats
+    stored = st["fill0_nnz_short"] + st["fill0_nnz_long"] + st["fill0_nnz_reg"] + st["nnz_irreg"]
+    assert stored >= st["nnzA"] and abs(st["rate_fill0"] - (stored - st["nnzA"]) / max(st["nnzA"], 1)) < 1e-12
+
+
+def test_threshold_and_block_longest_change_the_split(dasp):
+    rp, ci, v = util.mixed_matrix(2000, 1500, 9)
+    a = dasp.Plan(rp, ci, v, 1500, threshold=0.75).stats
+    b = dasp.Plan(rp, ci, v, 1500, threshold=0.25).stats
+    assert b["nnz_irreg"] <= a["nnz_irreg"] and b["fill0_nnz_reg"] >= a["fill0_nnz_reg"]
+    c = dasp.Plan(rp, ci, v, 1500, block_longest=64).stats
+    assert c["row_long"] > a["row_long"] and c["row_block"] < a["row_block"]
+
+
+def test_empty_and_degenerate(dasp):
+    for m, n in [(0, 0), (5, 3)]:
+        rp = np.zeros(m + 1, np.int32)
+        plan = dasp.Plan(rp, np.zeros(0, np.int32), np.zeros(0), n)
+        assert plan.stats["row_zero"] == m and plan.order_rid.tolist() == list(range(m))
+
+
+def test_column_remap_for_partitioned_x(dasp):
+    rp, ci, v = util.mixed_matrix(500, 1000, 21)
+    bounds = np.array([0, 300, 650, 1000], np.int32)
+    stride = 384
+    plan = dasp.Plan(rp, ci, v, 1000, part_bounds=bounds, part_stride=stride)
+    rows = util.decode_plan(plan)
+    g = np.searchsorted(bounds, ci, side="right") - 1
+    want = g * stride + (ci - bounds[g])
+    order = plan.order_rid
+    for slot in range(500):
+        r = order[slot]
+        assert rows[slot][0] == want[rp[r]:rp[r + 1]].tolist()
+    assert plan.x_len == 3 * stride
+
+
+def test_partition_rows(dasp):
+    rp, _, _ = util.mixed_matrix(1000, 100, 2)
+    for g in (1, 2, 3, 8):
+        b = dasp.partition_rows(rp, g)
+        assert b[0] == 0 and b[-1] == 1000 and (np.diff(b) >= 0).all()
+        per = np.diff(rp[b])
+        assert per.max() - rp[-1] / g <= np.diff(rp).max()
+
+
+def test_synthetic_generators_are_sliceable_and_seeded(dasp):
+    for name in dasp.SYNTH_NAMES:
+        sc = 0.002 if name != "cop20k_A" else 0.05
+        rows, cols = dasp.synth_dims(name, sc)
+        rp, ci = dasp.synth_csr(name, sc)
+        assert rp.size == rows + 1 and (ci >= 0).all() and (ci < cols).all()
+        a, b = rows // 3, 2 * rows // 3
+        rp2, ci2 = dasp.synth_csr(name, sc, a, b)
+        assert (ci2 == ci[rp[a]:rp[b]]).all() and (np.diff(rp2) == np.diff(rp)[a:b]).all()
+    # the symmetric stand-ins really are symmetric
+    import scipy.sparse as sp
+    for name, sc in (("cop20k_A", 0.05), ("nlpkkt160", 0.001), ("Queen_4147", 0.002)):
+        rows, cols = dasp.synth_dims(name, sc)
+        rp, ci = dasp.synth_csr(name, sc)
+        A = sp.csr_matrix((np.ones(ci.size), ci, rp), shape=(rows, cols))
+        assert (A != A.T).nnz == 0, name

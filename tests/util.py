@@ -1,0 +1,115 @@
+"""Shared helpers for the test-suite: seeded CSR builders and the decoder of the native
+packed format (the format specification of DESIGN.md, restated independently of the C++ packer)."""
+import numpy as np
+
+ALL_LENGTHS = [0, 1, 2, 3, 4, 5, 6, 7, 9, 12, 16, 17, 20, 33, 60, 64, 100, 255, 256, 257, 300, 700, 1024, 1030, 2500]
+
+
+def csr_from_lengths(lens, n_cols, seed, values="uniform", dtype=np.float64):
+    rng = np.random.default_rng(seed)
+    lens = np.asarray(lens, np.int64)
+    rp = np.zeros(lens.size + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    nnz = int(rp[-1])
+    ci = rng.integers(0, n_cols, nnz).astype(np.int32)
+    if values == "ones":
+        v = np.ones(nnz)
+    elif values == "f16":
+        v = rng.uniform(0.5, 1.5, nnz)
+    else:
+        v = rng.uniform(-1, 1, nnz)
+    return rp.astype(np.int32), ci, v.astype(dtype)
+
+
+def mixed_matrix(m, n_cols, seed, lengths=None, p=None, values="uniform", dtype=np.float64):
+    rng = np.random.default_rng(seed + 1000)
+    lengths = ALL_LENGTHS if lengths is None else lengths
+    lens = rng.choice(lengths, size=m, p=p)
+    lens = np.minimum(lens, n_cols * 4)
+    return csr_from_lengths(lens, n_cols, seed, values, dtype)
+
+
+def pair_heavy_matrix(m, n_cols, seed, values="uniform", dtype=np.float64):
+    """many len-1 and len-3 rows so that common_13 > 0 (needs >= 128 of each)"""
+    rng = np.random.default_rng(seed + 7)
+    lens = rng.choice([1, 3, 1, 3, 2, 4, 0, 8, 30], size=m)
+    return csr_from_lengths(lens, n_cols, seed, values, dtype)
+
+
+def slot_of(g, t):
+    """g = 13-int row of Plan.host_array('short_groups')"""
+    split, base, grp, off = g[6], (g[7], g[8]), (g[9], g[10]), (g[11], g[12])
+    p = 0 if t < split else 1
+    u = t - split if p else t
+    return base[p] + (u // grp[p]) * 2 * grp[p] + off[p] + u % grp[p] if grp[p] else base[p] + u
+
+
+def decode_plan(plan):
+    """Rebuild, from the native packed arrays alone, the list of (col, val) per permuted slot.
+    Returns dict slot -> (cols[], vals[]) in stored order (pads removed)."""
+    prec = plan.precision
+    K, CH, SR = (4, 64, 128) if prec == 64 else (16, 256, 256)
+    st = plan.stats
+    out = {}
+    # long rows
+    lv, lc = plan.host_array("long_val"), plan.host_array("long_cid")
+    pp, pd = plan.host_array("piece_ptr"), plan.host_array("piece_dst")
+    mp, md = plan.host_array("multi_ptr"), plan.host_array("multi_dst")
+    # piece_dst / multi_dst hold final y indices: slots (Y_PERMUTED) or natural row ids (Y_NATURAL)
+    natural = getattr(plan, "y_order", 0) == 1
+    inv = np.argsort(plan.order_rid) if natural else None
+    part_owner = {}
+    for i in range(md.size):
+        for q in range(mp[i], mp[i + 1]):
+            part_owner[q] = int(md[i])
+    for p in range(pd.size):
+        dst = int(pd[p])
+        slot = dst if dst >= 0 else part_owner[~dst]
+        if natural:
+            slot = int(inv[slot])
+        c = lc[pp[p]:pp[p + 1]]
+        v = lv[pp[p]:pp[p + 1]]
+        keep = c >= 0
+        cs, vs = out.setdefault(slot, ([], []))
+        cs.extend(c[keep].tolist())
+        vs.extend(v[keep].tolist())
+    # medium rows
+    mptr, mv, mc = plan.host_array("med_ptr"), plan.host_array("med_val"), plan.host_array("med_cid")
+    ip_, iv, ic = plan.host_array("irr_ptr"), plan.host_array("irr_val"), plan.host_array("irr_cid")
+    nb = mptr.size - 1
+    row_block, row_long = st["row_block"], st["row_long"]
+    for b in range(nb):
+        nc = mptr[b + 1] - mptr[b]
+        blk_c = mc[mptr[b] * CH: mptr[b + 1] * CH].reshape(nc, CH)
+        blk_v = mv[mptr[b] * CH: mptr[b + 1] * CH].reshape(nc, CH)
+        for rr in range(16):
+            r = b * 16 + rr
+            if prec == 64:      # element (k, row) at k*16 + row
+                idx = np.arange(K) * 16 + rr
+            else:               # element (kq, row, j) at kq*64 + row*4 + j ; k = 4*kq + j
+                idx = (np.arange(K) // 4) * 64 + rr * 4 + np.arange(K) % 4
+            c = blk_c[:, idx].reshape(-1)
+            v = blk_v[:, idx].reshape(-1)
+            if r >= row_block:
+                assert (c == -1).all() and (v == 0).all()
+                continue
+            keep = c >= 0
+            # pads only after the row's last regular entry
+            if keep.any():
+                assert keep[: keep.sum()].all(), "pad before a real entry"
+            cs = c[keep].tolist() + ic[ip_[r]:ip_[r + 1]].tolist()
+            vs = v[keep].tolist() + iv[ip_[r]:ip_[r + 1]].tolist()
+            out[row_long + r] = (cs, vs)
+    # short rows
+    sg = plan.host_array("short_groups").reshape(5, 13)
+    sv, sc = plan.host_array("short_val"), plan.host_array("short_cid")
+    for g in sg:
+        L, count, tiles, tile0 = int(g[0]), int(g[1]), int(g[2]), int(g[3])
+        eoff = int(g[4]) & 0xFFFFFFFF | (int(g[5]) << 32)
+        for t in range(count):
+            tile, lr = divmod(t, SR)
+            at = [eoff + (tile * L + k) * SR + lr for k in range(L)]
+            slot = slot_of(g, t)
+            assert slot not in out
+            out[slot] = ([int(sc[a]) for a in at], [sv[a] for a in at])
+    return out
