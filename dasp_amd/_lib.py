@@ -50,6 +50,31 @@ def build(force=False):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same
+    soname as /opt/rocm's).  If libdasp_amd.so pulled in the system copy first and torch its own
+    later, the process would hold two ROCr instances and the second one sees no device.  So when a
+    torch wheel is installed, its runtime is mapped first (by path, RTLD_GLOBAL): libdasp_amd.so's
+    NEEDED libamdhip64.so.7 then binds to it by soname, and a later `import torch` finds the very
+    same file already loaded.  Without torch the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -58,6 +83,7 @@ def lib():
         raise ImportError(
             "dasp_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no fallback implementation." % SO_PATH)
+    _preload_hip_runtime()
     L = C.CDLL(SO_PATH)
     ip, vp = C.POINTER(C.c_int), C.c_void_p
     L.dasp_last_error.restype = C.c_char_p

@@ -138,26 +138,77 @@ template <> struct Tr<_Float16> {
     static constexpr int CHUNK = 256, SHORT_ROWS = 256;
 };
 
-// ---- one MFMA step on `chunk` elements starting at element offset `e` (lane-linear layout)
+// ---- chunk = one MFMA worth of elements in lane-linear order.  Loads, gathers and MFMAs are kept
+// as separate branch-free stages so that a batch of chunks has all its streaming loads, then all
+// its x gathers, in flight together.  Padded slots carry column id -1: the gather address is
+// clamped to x[0] (always readable) and the gathered value replaced by 0, so a pad contributes an
+// exact 0 whatever x holds (the reference multiplies 0 by x[0]: dasp_f64.h:1127-1128).
+template <class T> struct Frag;
+template <> struct Frag<double> { double a; int c; double b; };
+template <> struct Frag<_Float16> { f16x4 a; i32x4 c; f16x4 b; };
+
+// `at` = this lane's first element (f64: one element, f16: four consecutive ones)
 template <bool NT>
-__device__ __forceinline__ void mfma_chunk(f64x4 &acc, const double *val, const int *cid, size_t e, int lane, const double *x)
+__device__ __forceinline__ void frag_load_at(Frag<double> &f, const double *val, const int *cid, size_t at)
 {
-    const double a = ldg<NT>(val + e + lane);
-    const int c = ldg<NT>(cid + e + lane);
-    const double b = c >= 0 ? x[c] : 0.0;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    f.a = ldg<NT>(val + at);
+    f.c = ldg<NT>(cid + at);
 }
 template <bool NT>
-__device__ __forceinline__ void mfma_chunk(f32x4 &acc, const _Float16 *val, const int *cid, size_t e, int lane, const _Float16 *x)
+__device__ __forceinline__ void frag_load_at(Frag<_Float16> &f, const _Float16 *val, const int *cid, size_t at)
 {
-    const f16x4 a = ldg<NT>(reinterpret_cast<const f16x4 *>(val + e) + lane);
-    const i32x4 c = ldg<NT>(reinterpret_cast<const i32x4 *>(cid + e) + lane);
-    f16x4 b;
-    b[0] = c[0] >= 0 ? x[c[0]] : (_Float16)0;
-    b[1] = c[1] >= 0 ? x[c[1]] : (_Float16)0;
-    b[2] = c[2] >= 0 ? x[c[2]] : (_Float16)0;
-    b[3] = c[3] >= 0 ? x[c[3]] : (_Float16)0;
-    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, acc, 0, 0, 0);
+    f.a = ldg<NT>(reinterpret_cast<const f16x4 *>(val + at));
+    f.c = ldg<NT>(reinterpret_cast<const i32x4 *>(cid + at));
+}
+template <bool NT, class T>
+__device__ __forceinline__ void frag_load(Frag<T> &f, const T *val, const int *cid, size_t e, int lane)
+{
+    frag_load_at<NT>(f, val, cid, e + (size_t)(Tr<T>::CHUNK / kWave) * lane);
+}
+__device__ __forceinline__ void frag_gather(Frag<double> &f, const double *x)
+{
+    const double xv = x[f.c < 0 ? 0 : f.c];
+    f.b = f.c < 0 ? 0.0 : xv;
+}
+__device__ __forceinline__ void frag_gather(Frag<_Float16> &f, const _Float16 *x)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const _Float16 xv = x[f.c[j] < 0 ? 0 : f.c[j]];
+        f.b[j] = f.c[j] < 0 ? (_Float16)0 : xv;
+    }
+}
+__device__ __forceinline__ void frag_mfma(f64x4 &acc, const Frag<double> &f)
+{
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a, f.b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void frag_mfma(f32x4 &acc, const Frag<_Float16> &f)
+{
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(f.a, f.b, acc, 0, 0, 0);
+}
+
+// all full chunks in [e0, e1) (element offsets, multiples of CHUNK apart), batches of UNROLL
+template <class T, bool NT, class ACC>
+__device__ __forceinline__ void mfma_stream(ACC &acc, const T *val, const int *cid, size_t e0, size_t e1, int lane, const T *x)
+{
+    constexpr int CH = Tr<T>::CHUNK;
+    constexpr int U = 4;
+    size_t e = e0;
+    for (; e + U * CH <= e1; e += U * CH) {
+        Frag<T> f[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) frag_load<NT>(f[u], val, cid, e + (size_t)u * CH, lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) frag_gather(f[u], x);
+#pragma unroll
+        for (int u = 0; u < U; ++u) frag_mfma(acc, f[u]);
+    }
+    for (; e + CH <= e1; e += CH) {
+        Frag<T> f;
+        frag_load<NT>(f, val, cid, e, lane);
+        frag_gather(f, x);
+        frag_mfma(acc, f);
+    }
 }
 
 // diagonal element D[row][row] held by this lane (valid only on the 16 "diagonal lanes")
@@ -184,15 +235,7 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane)
     const T *val = static_cast<const T *>(a.med_val);
     const int c0 = a.med_ptr[b], c1 = a.med_ptr[b + 1];
     acc_t acc = {0, 0, 0, 0};
-    size_t e = (size_t)c0 * CH;
-    int c = c0;
-    for (; c + 4 <= c1; c += 4, e += 4 * CH) {
-        mfma_chunk<NT>(acc, val, a.med_cid, e, lane, x);
-        mfma_chunk<NT>(acc, val, a.med_cid, e + CH, lane, x);
-        mfma_chunk<NT>(acc, val, a.med_cid, e + 2 * CH, lane, x);
-        mfma_chunk<NT>(acc, val, a.med_cid, e + 3 * CH, lane, x);
-    }
-    for (; c < c1; ++c, e += CH) mfma_chunk<NT>(acc, val, a.med_cid, e, lane, x);
+    mfma_stream<T, NT>(acc, val, a.med_cid, (size_t)c0 * CH, (size_t)c1 * CH, lane, x);
 
     // irregular tail: lane (row = l&15, kq = l>>4) walks its row's leftover entries; the block's
     // first row is its longest (rows are sorted), so its tail length bounds the loop.
@@ -202,13 +245,16 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane)
     if (r < a.row_block) { t0 = a.irr_ptr[r]; t1 = a.irr_ptr[r + 1]; }
     const int tmax = __builtin_amdgcn_readfirstlane(t1 - t0);
     const T *ival = static_cast<const T *>(a.irr_val);
+    // out-of-range lanes read element 0 of the (never empty: the arena pads it) tail arrays and are
+    // zeroed afterwards, so the loop body has no divergent branch
     if constexpr (sizeof(T) == 8) {
         for (int j = 0; j < tmax; j += 4) {
             const int i = t0 + j + kq;
             const bool ok = i < t1;
-            const double av = ok ? ldg<NT>(ival + i) : 0.0;
-            const double bv = ok ? x[ldg<NT>(a.irr_cid + i)] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            const int ii = ok ? i : 0;
+            const double av = ldg<NT>(ival + ii);
+            const double xv = x[ldg<NT>(a.irr_cid + ii)];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? av : 0.0, ok ? xv : 0.0, acc, 0, 0, 0);
         }
     } else {
         for (int j = 0; j < tmax; j += 16) {
@@ -217,8 +263,11 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane)
             for (int q = 0; q < 4; ++q) {
                 const int i = t0 + j + 4 * kq + q;
                 const bool ok = i < t1;
-                av[q] = ok ? ival[i] : (_Float16)0;
-                bv[q] = ok ? x[a.irr_cid[i]] : (_Float16)0;
+                const int ii = ok ? i : 0;
+                const _Float16 v = ival[ii];
+                const _Float16 xv = x[a.irr_cid[ii]];
+                av[q] = ok ? v : (_Float16)0;
+                bv[q] = ok ? xv : (_Float16)0;
             }
             acc = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, acc, 0, 0, 0);
         }
@@ -243,30 +292,21 @@ __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
     const T *val = static_cast<const T *>(a.long_val);
     const int p0 = a.piece_ptr[p], p1 = a.piece_ptr[p + 1];
     acc_t acc = {0, 0, 0, 0};
-    int e = p0;
-    for (; e + CH <= p1; e += CH) mfma_chunk<NT>(acc, val, a.long_cid, (size_t)e, lane, x);
-    if (e < p1) {   // last, partial chunk: rows are padded to kLongAlign so a lane's group is all-in or all-out
-        if constexpr (VPL == 1) {
-            const int i = e + lane;
-            const bool ok = i < p1;
-            const double av = ok ? ldg<NT>(val + i) : 0.0;
-            const int c = ok ? ldg<NT>(a.long_cid + i) : -1;
-            const double bv = c >= 0 ? x[c] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-        } else {
-            const int i = e + 4 * lane;
-            const bool ok = i < p1;
-            f16x4 av = {0, 0, 0, 0}, bv = {0, 0, 0, 0};
-            if (ok) {
-                av = ldg<NT>(reinterpret_cast<const f16x4 *>(val + i));
-                const i32x4 c = ldg<NT>(reinterpret_cast<const i32x4 *>(a.long_cid + i));
-                bv[0] = c[0] >= 0 ? x[c[0]] : (_Float16)0;
-                bv[1] = c[1] >= 0 ? x[c[1]] : (_Float16)0;
-                bv[2] = c[2] >= 0 ? x[c[2]] : (_Float16)0;
-                bv[3] = c[3] >= 0 ? x[c[3]] : (_Float16)0;
-            }
-            acc = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, acc, 0, 0, 0);
+    const int full = p0 + (p1 - p0) / CH * CH;
+    mfma_stream<T, NT>(acc, val, a.long_cid, (size_t)p0, (size_t)full, lane, x);
+    if (full < p1) {   // last, partial chunk: rows are padded to kLongAlign, so a lane's group is all-in or all-out;
+                       // out-of-range lanes re-read the piece's first group (in bounds) and are zeroed
+        const int i = full + VPL * lane;
+        const bool ok = i < p1;
+        Frag<T> f;
+        frag_load_at<NT>(f, val, a.long_cid, (size_t)(ok ? i : p0));
+        frag_gather(f, x);
+        if constexpr (VPL == 1) { f.a = ok ? f.a : 0.0; f.b = ok ? f.b : 0.0; }
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f.a[j] = ok ? f.a[j] : (_Float16)0; f.b[j] = ok ? f.b[j] : (_Float16)0; }
         }
+        frag_mfma(acc, f);
     }
     part_t d;
     const bool on_diag = diag_of(acc, lane, d);
@@ -296,13 +336,17 @@ __device__ __forceinline__ void short_rows(const DevArgs &a, const ShortDev &g, 
         if constexpr (V == 2) {
             const f64x2 av = ldg<NT>(reinterpret_cast<const f64x2 *>(val + base + (size_t)k * SR));
             const i32x2 c = ldg<NT>(reinterpret_cast<const i32x2 *>(a.short_cid + base + (size_t)k * SR));
-            s[0] += av[0] * (c[0] >= 0 ? x[c[0]] : 0.0);
-            s[1] += av[1] * (c[1] >= 0 ? x[c[1]] : 0.0);
+            const double x0 = x[c[0] < 0 ? 0 : c[0]], x1 = x[c[1] < 0 ? 0 : c[1]];   // pads: clamped gather, value dropped
+            s[0] += av[0] * (c[0] < 0 ? 0.0 : x0);
+            s[1] += av[1] * (c[1] < 0 ? 0.0 : x1);
         } else {
             const f16x4 av = ldg<NT>(reinterpret_cast<const f16x4 *>(val + base + (size_t)k * SR));
             const i32x4 c = ldg<NT>(reinterpret_cast<const i32x4 *>(a.short_cid + base + (size_t)k * SR));
 #pragma unroll
-            for (int v = 0; v < 4; ++v) s[v] += (float)av[v] * (float)(c[v] >= 0 ? x[c[v]] : (_Float16)0);
+            for (int v = 0; v < 4; ++v) {
+                const _Float16 xv = x[c[v] < 0 ? 0 : c[v]];
+                s[v] += (float)av[v] * (c[v] < 0 ? 0.0f : (float)xv);
+            }
         }
     }
     const int t0 = local_tile * SR + V * lane;
