@@ -232,6 +232,7 @@ static int spmv_all_impl(int precision, const char *filename, const void *val, c
     const long long data_X2 = s.data_X + (long long)(nnzA - colA) * (long long)vb;  // x counted per gather, :1168-1172
     const double bw1 = (double)s.data_X / (t * 1e6), bw2 = (double)data_X2 / (t * 1e6);
     std::printf("SpMV_X:  %8.4lf ms, %8.4lf GFlop/s, %9.4lf GB/s, %9.4lf GB/s\n\n", t, gflops, bw1, bw2);   // :1398
+    std::fflush(stdout);
     struct stat st;
     if (stat("data", &st) == 0 && S_ISDIR(st.st_mode)) {
         FILE *fo = std::fopen(precision == 64 ? "data/spmv_f64_record.csv" : "data/spmv_f16_record.csv", "a");
