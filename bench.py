@@ -234,6 +234,16 @@ def main():
         "region_event_ms_per_step": round(region_event_ms, 6), "verified": ok, "preprocess_s": round(pre_s, 3),
     }
 
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/prof.sh;
+    # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), when there is one; PMC cannot be read from inside the run
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if world == 1 and os.path.exists(tpath):
+        for t in json.load(open(tpath)):
+            if t["workload"] == name and t["precision"] == prec and abs(t["scale"] - scale) < 1e-12:
+                out["roofline"]["traffic"] = int(t["traffic_bytes"])
+                out["roofline"]["traffic_source"] = t["source"]
+                out["roofline"]["traffic_over_algorithmic"] = round(t["traffic_bytes"] / b_alg_local, 4)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O      # checker / baseline only; never on the measured path
         out["cpu_baseline"] = cpu_baseline(O, rp, ci, cols)
