@@ -103,6 +103,7 @@ def lib():
     L.dasp_plan_drop_host.argtypes = [vp]
     L.dasp_plan_spmv.argtypes = [vp, vp, vp, vp]
     L.dasp_plan_time.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.dasp_plan_time_graph.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dasp_spmv_all_f64.argtypes = [C.c_char_p, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
     L.dasp_spmv_all_f16.argtypes = L.dasp_spmv_all_f64.argtypes
     L.dasp_partition_rows.argtypes = [C.c_int, vp, C.c_int, vp]
@@ -122,5 +123,5 @@ def check(rc):
 EXPORTS = (
     "dasp_last_error dasp_version dasp_mmio_allinone_f64 dasp_mmio_allinone_f16 dasp_free dasp_options_default "
     "dasp_plan_create dasp_plan_destroy dasp_plan_order dasp_plan_stats dasp_plan_host_array dasp_plan_upload "
-    "dasp_plan_drop_host dasp_plan_spmv dasp_plan_time dasp_spmv_all_f64 dasp_spmv_all_f16 dasp_partition_rows "
+    "dasp_plan_drop_host dasp_plan_spmv dasp_plan_time dasp_plan_time_graph dasp_spmv_all_f64 dasp_spmv_all_f16 dasp_partition_rows "
     "dasp_selftest_mfma dasp_synth_dims dasp_synth_row_lengths dasp_synth_rows").split()

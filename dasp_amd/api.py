@@ -128,6 +128,12 @@ class Plan:
         _lib.check(_lib.lib().dasp_plan_time(self._h, C.c_void_p(dX), C.c_void_p(dY), C.c_void_p(stream), warmup, iters, C.byref(w), C.byref(e)))
         return w.value, e.value
 
+    def time_graph(self, dX, dY, stream=0, warmup=100, iters=1000, batch=100):
+        """Same protocol, `batch` SpMVs captured into one hipGraph and replayed: (wall_ms, event_ms) per SpMV."""
+        w, e = C.c_double(), C.c_double()
+        _lib.check(_lib.lib().dasp_plan_time_graph(self._h, C.c_void_p(dX), C.c_void_p(dY), C.c_void_p(stream), warmup, iters, batch, C.byref(w), C.byref(e)))
+        return w.value, e.value
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.lib().dasp_plan_destroy(self._h)

@@ -20,6 +20,7 @@ const char *last_error_cstr();
 int upload_plan(Plan &p);
 int launch_spmv(Plan &p, const void *dX, void *dY, void *stream);
 int time_spmv(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, double *wall_ms, double *event_ms);
+int time_spmv_graph(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, int batch, double *wall_ms, double *event_ms);
 int selftest_mfma();
 }  // namespace dasp
 
@@ -172,6 +173,13 @@ int dasp_plan_time(dasp_plan_t *plan, const void *dX, void *dY, void *stream, in
 {
     if (!plan || iters <= 0 || warmup < 0) return DASP_ERR_ARG;
     return time_spmv(plan->impl, dX, dY, stream, warmup, iters, wall_ms, event_ms);
+}
+
+int dasp_plan_time_graph(dasp_plan_t *plan, const void *dX, void *dY, void *stream, int warmup, int iters, int batch,
+                         double *wall_ms, double *event_ms)
+{
+    if (!plan || iters <= 0 || warmup < 0 || batch <= 0) return DASP_ERR_ARG;
+    return time_spmv_graph(plan->impl, dX, dY, stream, warmup, iters, batch, wall_ms, event_ms);
 }
 
 int dasp_selftest_mfma(void) { return selftest_mfma(); }

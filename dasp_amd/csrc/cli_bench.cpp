@@ -50,6 +50,8 @@ int main(int argc, char **argv)
     if (hipMemcpy(dX, ones.data(), ones.size(), hipMemcpyHostToDevice) != hipSuccess) return 2;
     double wall = 0, ev = 0;
     CHECK(dasp_plan_time(plan, dX, dY, nullptr, warmup, iters, &wall, &ev));
+    double gwall = 0, gev = 0;
+    CHECK(dasp_plan_time_graph(plan, dX, dY, nullptr, warmup, iters, iters < 50 ? iters : 50, &gwall, &gev));
     // exact check: y[i] == nnz(row order[i])
     std::vector<char> y((size_t)rows * vb);
     if (hipMemcpy(y.data(), dY, y.size(), hipMemcpyDeviceToHost) != hipSuccess) return 2;
@@ -60,9 +62,9 @@ int main(int argc, char **argv)
     dasp_stats_t s;
     dasp_plan_stats(plan, &s);
     const double balg = (double)s.data_origin1;
-    std::printf("%s scale=%g f%d rows=%d nnz=%d long=%d med=%d fill0=%.4f pre=%.1fms | %.4f ms (event %.4f) %.1f GFLOP/s %.1f GB/s alg = %.3f of 8 TB/s | mismatches=%lld\n",
+    std::printf("%s scale=%g f%d rows=%d nnz=%d long=%d med=%d fill0=%.4f pre=%.1fms | %.4f ms (event %.4f) %.1f GFLOP/s %.1f GB/s alg = %.3f of 8 TB/s | graph: %.4f ms %.3f | mismatches=%lld\n",
                 name, scale, prec, rows, nnz, s.row_long, s.row_block, s.rate_fill0, s.pre_ms, wall, ev, 2.0 * nnz / (wall * 1e6),
-                balg / (ev * 1e6), balg / (ev * 1e6) / 8000.0, bad);
+                balg / (ev * 1e6), balg / (ev * 1e6) / 8000.0, gev, balg / (gev * 1e6) / 8000.0, bad);
     (void)hipFree(dX); (void)hipFree(dY);
     dasp_plan_destroy(plan);
     return bad ? 3 : 0;

@@ -131,11 +131,11 @@ __device__ __forceinline__ int slot_of(const SlotMap &m, int t)
 template <class T> struct Tr;
 template <> struct Tr<double> {
     using acc_t = f64x4; using part_t = double;
-    static constexpr int CHUNK = 64, SHORT_ROWS = 128;
+    static constexpr int CHUNK = 64, SHORT_ROWS = 128, BATCH = 4;
 };
 template <> struct Tr<_Float16> {
     using acc_t = f32x4; using part_t = float;
-    static constexpr int CHUNK = 256, SHORT_ROWS = 256;
+    static constexpr int CHUNK = 256, SHORT_ROWS = 256, BATCH = 2;
 };
 
 // ---- chunk = one MFMA worth of elements in lane-linear order.  Loads, gathers and MFMAs are kept
@@ -187,27 +187,78 @@ __device__ __forceinline__ void frag_mfma(f32x4 &acc, const Frag<_Float16> &f)
     acc = __builtin_amdgcn_mfma_f32_16x16x16f16(f.a, f.b, acc, 0, 0, 0);
 }
 
-// all full chunks in [e0, e1) (element offsets, multiples of CHUNK apart), batches of UNROLL
-template <class T, bool NT, class ACC>
+template <bool NT, class T, int N>
+__device__ __forceinline__ void batch_load(Frag<T> (&f)[N], const T *val, const int *cid, size_t e, int lane)
+{
+#pragma unroll
+    for (int u = 0; u < N; ++u) frag_load<NT>(f[u], val, cid, e + (size_t)u * Tr<T>::CHUNK, lane);
+}
+template <class T, int N>
+__device__ __forceinline__ void batch_gather(Frag<T> (&f)[N], const T *x)
+{
+#pragma unroll
+    for (int u = 0; u < N; ++u) frag_gather(f[u], x);
+}
+template <class T, int N, class ACC>
+__device__ __forceinline__ void batch_mfma(ACC &acc, const Frag<T> (&f)[N])
+{
+#pragma unroll
+    for (int u = 0; u < N; ++u) frag_mfma(acc, f[u]);
+}
+
+// last step of the pipeline: `cur` (a full batch whose loads are in flight, if have_cur) and R leftover chunks at e
+template <class T, bool NT, int U, int R, class ACC>
+__device__ __forceinline__ void stream_finish(ACC &acc, bool have_cur, Frag<T> (&cur)[U], const T *val, const int *cid,
+                                              size_t e, int lane, const T *x)
+{
+    if constexpr (R == 0) {
+        if (have_cur) { batch_gather(cur, x); batch_mfma(acc, cur); }
+    } else {
+        Frag<T> r[R];
+        if (have_cur) batch_gather(cur, x);
+        batch_load<NT>(r, val, cid, e, lane);
+        if (have_cur) batch_mfma(acc, cur);
+        batch_gather(r, x);
+        batch_mfma(acc, r);
+    }
+}
+
+// All full chunks in [e0, e1) (element offsets a multiple of CHUNK apart), software-pipelined in batches of U:
+// while batch i's x gathers are in flight the streaming loads of batch i+1 are already issued, so a wave's
+// critical path per batch is max(stream latency, gather latency) instead of their sum.
+template <class T, bool NT, int U, class ACC>
 __device__ __forceinline__ void mfma_stream(ACC &acc, const T *val, const int *cid, size_t e0, size_t e1, int lane, const T *x)
 {
     constexpr int CH = Tr<T>::CHUNK;
-    constexpr int U = 4;
+    const int nchunk = (int)((e1 - e0) / CH);
+    const int nfull = nchunk / U, rem = nchunk % U;
     size_t e = e0;
-    for (; e + U * CH <= e1; e += U * CH) {
-        Frag<T> f[U];
+    Frag<T> cur[U];
+    if (nfull > 0) {
+        batch_load<NT>(cur, val, cid, e, lane);
+        e += (size_t)U * CH;
+        for (int i = 1; i < nfull; ++i) {
+            Frag<T> nxt[U];
+            batch_gather(cur, x);
+            batch_load<NT>(nxt, val, cid, e, lane);
+            e += (size_t)U * CH;
+            batch_mfma(acc, cur);
 #pragma unroll
-        for (int u = 0; u < U; ++u) frag_load<NT>(f[u], val, cid, e + (size_t)u * CH, lane);
-#pragma unroll
-        for (int u = 0; u < U; ++u) frag_gather(f[u], x);
-#pragma unroll
-        for (int u = 0; u < U; ++u) frag_mfma(acc, f[u]);
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        }
     }
-    for (; e + CH <= e1; e += CH) {
-        Frag<T> f;
-        frag_load<NT>(f, val, cid, e, lane);
-        frag_gather(f, x);
-        frag_mfma(acc, f);
+    const bool have = nfull > 0;
+    if constexpr (U == 4) {
+        switch (rem) {
+            case 0: stream_finish<T, NT, U, 0>(acc, have, cur, val, cid, e, lane, x); break;
+            case 1: stream_finish<T, NT, U, 1>(acc, have, cur, val, cid, e, lane, x); break;
+            case 2: stream_finish<T, NT, U, 2>(acc, have, cur, val, cid, e, lane, x); break;
+            default: stream_finish<T, NT, U, 3>(acc, have, cur, val, cid, e, lane, x); break;
+        }
+    } else {
+        static_assert(U == 2, "batch size");
+        if (rem == 0) stream_finish<T, NT, U, 0>(acc, have, cur, val, cid, e, lane, x);
+        else stream_finish<T, NT, U, 1>(acc, have, cur, val, cid, e, lane, x);
     }
 }
 
@@ -235,14 +286,15 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane)
     const T *val = static_cast<const T *>(a.med_val);
     const int c0 = a.med_ptr[b], c1 = a.med_ptr[b + 1];
     acc_t acc = {0, 0, 0, 0};
-    mfma_stream<T, NT>(acc, val, a.med_cid, (size_t)c0 * CH, (size_t)c1 * CH, lane, x);
-
-    // irregular tail: lane (row = l&15, kq = l>>4) walks its row's leftover entries; the block's
-    // first row is its longest (rows are sorted), so its tail length bounds the loop.
+    // tail bounds first: their latency hides under the chunk stream.  lane (row = l&15, kq = l>>4) walks its
+    // row's leftover entries; the block's first row is its longest (rows are sorted), so its tail bounds the loop.
     const int row = lane & 15, kq = lane >> 4;
     const int r = b * kMedRows + row;
     int t0 = 0, t1 = 0;
     if (r < a.row_block) { t0 = a.irr_ptr[r]; t1 = a.irr_ptr[r + 1]; }
+
+    mfma_stream<T, NT, Tr<T>::BATCH>(acc, val, a.med_cid, (size_t)c0 * CH, (size_t)c1 * CH, lane, x);
+
     const int tmax = __builtin_amdgcn_readfirstlane(t1 - t0);
     const T *ival = static_cast<const T *>(a.irr_val);
     // out-of-range lanes read element 0 of the (never empty: the arena pads it) tail arrays and are
@@ -293,7 +345,7 @@ __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
     const int p0 = a.piece_ptr[p], p1 = a.piece_ptr[p + 1];
     acc_t acc = {0, 0, 0, 0};
     const int full = p0 + (p1 - p0) / CH * CH;
-    mfma_stream<T, NT>(acc, val, a.long_cid, (size_t)p0, (size_t)full, lane, x);
+    mfma_stream<T, NT, Tr<T>::BATCH>(acc, val, a.long_cid, (size_t)p0, (size_t)full, lane, x);
     if (full < p1) {   // last, partial chunk: rows are padded to kLongAlign, so a lane's group is all-in or all-out;
                        // out-of-range lanes re-read the piece's first group (in bounds) and are zeroed
         const int i = full + VPL * lane;
@@ -587,6 +639,47 @@ int time_spmv(Plan &p, const void *dX, void *dY, void *stream, int warmup, int i
         if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / iters;
         if (event_ms) *event_ms = (double)ms / iters;
     }
+    return DASP_OK;
+}
+
+// same protocol with the launches captured once into a hipGraph of `batch` SpMVs and replayed: removes the
+// per-launch host cost (3-4 us) that bounds back-to-back launches of small matrices; the kernels are unchanged.
+int time_spmv_graph(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, int batch, double *wall_ms, double *event_ms)
+{
+    if (batch <= 0) batch = 1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipStream_t cap = nullptr;
+    const bool own = (s == nullptr);            // the legacy null stream cannot be captured
+    if (own) { HIP_TRY(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking)); } else cap = s;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_TRY(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+    int rc = DASP_OK;
+    for (int i = 0; i < batch && rc == DASP_OK; ++i) rc = launch_spmv(p, dX, dY, cap);
+    hipError_t ee = hipStreamEndCapture(cap, &graph);
+    if (rc != DASP_OK) return rc;
+    HIP_TRY(ee);
+    HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    const int reps = (iters + batch - 1) / batch, wreps = (warmup + batch - 1) / batch;
+    for (int i = 0; i < wreps; ++i) HIP_TRY(hipGraphLaunch(exec, cap));
+    HIP_TRY(hipStreamSynchronize(cap));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipEventRecord(e0, cap));
+    for (int i = 0; i < reps; ++i) HIP_TRY(hipGraphLaunch(exec, cap));
+    HIP_TRY(hipEventRecord(e1, cap));
+    HIP_TRY(hipStreamSynchronize(cap));
+    const auto t1 = std::chrono::steady_clock::now();
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
+    if (own) (void)hipStreamDestroy(cap);
+    const double n = (double)reps * batch;
+    if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / n;
+    if (event_ms) *event_ms = (double)ms / n;
     return DASP_OK;
 }
 

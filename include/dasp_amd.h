@@ -138,6 +138,12 @@ int dasp_plan_spmv(dasp_plan_t *plan, const void *dX, void *dY, void *stream);
 int dasp_plan_time(dasp_plan_t *plan, const void *dX, void *dY, void *stream, int warmup, int iters,
                    double *wall_ms_per_iter, double *event_ms_per_iter);
 
+/* the same protocol with `batch` SpMVs captured once into a hipGraph and replayed ceil(iters/batch) times:
+ * removes the per-launch host cost that bounds back-to-back launches on small matrices (kernels unchanged).
+ * stream NULL = a private capture stream. */
+int dasp_plan_time_graph(dasp_plan_t *plan, const void *dX, void *dY, void *stream, int warmup, int iters, int batch,
+                         double *wall_ms_per_iter, double *event_ms_per_iter);
+
 /* ---------------------------------------------------------------- one-shot
  * Replaces  void spmv_all(char *filename, MAT_VAL_TYPE *csrValA, MAT_PTR_TYPE *csrRowPtrA,
  *                         int *csrColIdxA, MAT_VAL_TYPE *X_val, MAT_VAL_TYPE *Y_val,
