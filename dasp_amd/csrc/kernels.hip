@@ -131,11 +131,11 @@ __device__ __forceinline__ int slot_of(const SlotMap &m, int t)
 template <class T> struct Tr;
 template <> struct Tr<double> {
     using acc_t = f64x4; using part_t = double;
-    static constexpr int CHUNK = 64, SHORT_ROWS = 128, BATCH = 4;
+    static constexpr int CHUNK = 64, SHORT_ROWS = 128, BATCH = 4, SHOT = 4;
 };
 template <> struct Tr<_Float16> {
     using acc_t = f32x4; using part_t = float;
-    static constexpr int CHUNK = 256, SHORT_ROWS = 256, BATCH = 2;
+    static constexpr int CHUNK = 256, SHORT_ROWS = 256, BATCH = 2, SHOT = 2;
 };
 
 // ---- chunk = one MFMA worth of elements in lane-linear order.  Loads, gathers and MFMAs are kept
@@ -165,16 +165,31 @@ __device__ __forceinline__ void frag_load(Frag<T> &f, const T *val, const int *c
 {
     frag_load_at<NT>(f, val, cid, e + (size_t)(Tr<T>::CHUNK / kWave) * lane);
 }
+// x gather cache policy, compile-time experiment knob (-DDASP_XG=n): 0 plain, 1 non-temporal, 2 agent-scope (sc1)
+#ifndef DASP_XG
+#define DASP_XG 0
+#endif
+template <class U>
+__device__ __forceinline__ U ldx(const U *p)
+{
+#if DASP_XG == 1
+    return __builtin_nontemporal_load(p);
+#elif DASP_XG == 2
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *p;
+#endif
+}
 __device__ __forceinline__ void frag_gather(Frag<double> &f, const double *x)
 {
-    const double xv = x[f.c < 0 ? 0 : f.c];
+    const double xv = ldx(x + (f.c < 0 ? 0 : f.c));
     f.b = f.c < 0 ? 0.0 : xv;
 }
 __device__ __forceinline__ void frag_gather(Frag<_Float16> &f, const _Float16 *x)
 {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const _Float16 xv = x[f.c[j] < 0 ? 0 : f.c[j]];
+        const _Float16 xv = ldx(x + (f.c[j] < 0 ? 0 : f.c[j]));
         f.b[j] = f.c[j] < 0 ? (_Float16)0 : xv;
     }
 }
@@ -187,79 +202,135 @@ __device__ __forceinline__ void frag_mfma(f32x4 &acc, const Frag<_Float16> &f)
     acc = __builtin_amdgcn_mfma_f32_16x16x16f16(f.a, f.b, acc, 0, 0, 0);
 }
 
-template <bool NT, class T, int N>
-__device__ __forceinline__ void batch_load(Frag<T> (&f)[N], const T *val, const int *cid, size_t e, int lane)
-{
+// ---- frag sources: src.load(f, i) issues the loads of the i-th MFMA step of a unit (i wave-uniform),
+// src.gather(f, i, x) turns its column ids into x values once they have arrived.
+
+// lane-linear chunks only (long pieces)
+template <class T, bool NT>
+struct ChunkSrc {
+    const T *val; const int *cid; size_t e0; int lane;
+    __device__ __forceinline__ void load(Frag<T> &f, int i) const { frag_load<NT>(f, val, cid, e0 + (size_t)i * Tr<T>::CHUNK, lane); }
+    __device__ __forceinline__ void gather(Frag<T> &f, int, const T *x) const { frag_gather(f, x); }
+};
+
+// a medium block: nc lane-linear chunks, then the irregular tail as extra steps in which lane (row = l&15, kq = l>>4)
+// takes the next entries of its own row.  Out-of-range lanes read element 0 of the tail arrays (never empty: the
+// arena pads them) and are zeroed in gather(), so neither stage has a divergent branch.
+template <class T, bool NT>
+struct BlockSrc {
+    ChunkSrc<T, NT> reg; int nc;
+    const T *ival; const int *icid; int t0, t1, kq;
+    __device__ __forceinline__ void load(Frag<T> &f, int i) const
+    {
+        if (i < nc) { reg.load(f, i); return; }
+        const int j = i - nc;
+        if constexpr (sizeof(T) == 8) {
+            const int e = t0 + 4 * j + kq;
+            const int ee = e < t1 ? e : 0;
+            f.a = ldg<NT>(ival + ee);
+            f.c = ldg<NT>(icid + ee);
+        } else {
 #pragma unroll
-    for (int u = 0; u < N; ++u) frag_load<NT>(f[u], val, cid, e + (size_t)u * Tr<T>::CHUNK, lane);
-}
-template <class T, int N>
-__device__ __forceinline__ void batch_gather(Frag<T> (&f)[N], const T *x)
-{
+            for (int q = 0; q < 4; ++q) {
+                const int e = t0 + 16 * j + 4 * kq + q;
+                const int ee = e < t1 ? e : 0;
+                f.a[q] = ival[ee];
+                f.c[q] = icid[ee];
+            }
+        }
+    }
+    __device__ __forceinline__ void gather(Frag<T> &f, int i, const T *x) const
+    {
+        if (i >= nc) {
+            const int j = i - nc;
+            if constexpr (sizeof(T) == 8) {
+                const bool ok = t0 + 4 * j + kq < t1;
+                f.a = ok ? f.a : 0.0;
+                f.c = ok ? f.c : -1;
+            } else {
 #pragma unroll
-    for (int u = 0; u < N; ++u) frag_gather(f[u], x);
-}
-template <class T, int N, class ACC>
-__device__ __forceinline__ void batch_mfma(ACC &acc, const Frag<T> (&f)[N])
+                for (int q = 0; q < 4; ++q) {
+                    const bool ok = t0 + 16 * j + 4 * kq + q < t1;
+                    f.a[q] = ok ? f.a[q] : (_Float16)0;
+                    f.c[q] = ok ? f.c[q] : -1;
+                }
+            }
+        }
+        frag_gather(f, x);
+    }
+};
+
+// N steps starting at step i0, everything in flight at once: all loads, then all gathers, then the MFMAs
+template <class T, int N, class SRC, class ACC>
+__device__ __forceinline__ void shot(ACC &acc, const SRC &src, int i0, const T *x)
 {
+    Frag<T> f[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) src.load(f[u], i0 + u);
+#pragma unroll
+    for (int u = 0; u < N; ++u) src.gather(f[u], i0 + u, x);
 #pragma unroll
     for (int u = 0; u < N; ++u) frag_mfma(acc, f[u]);
 }
-
-// last step of the pipeline: `cur` (a full batch whose loads are in flight, if have_cur) and R leftover chunks at e
-template <class T, bool NT, int U, int R, class ACC>
-__device__ __forceinline__ void stream_finish(ACC &acc, bool have_cur, Frag<T> (&cur)[U], const T *val, const int *cid,
-                                              size_t e, int lane, const T *x)
-{
-    if constexpr (R == 0) {
-        if (have_cur) { batch_gather(cur, x); batch_mfma(acc, cur); }
-    } else {
-        Frag<T> r[R];
-        if (have_cur) batch_gather(cur, x);
-        batch_load<NT>(r, val, cid, e, lane);
-        if (have_cur) batch_mfma(acc, cur);
-        batch_gather(r, x);
-        batch_mfma(acc, r);
+template <class T, int N, class SRC, class ACC>
+struct ShotDispatch {
+    static __device__ __forceinline__ void run(ACC &acc, const SRC &src, int i0, int n, const T *x)
+    {
+        if (n == N) shot<T, N>(acc, src, i0, x);
+        else ShotDispatch<T, N - 1, SRC, ACC>::run(acc, src, i0, n, x);
     }
-}
+};
+template <class T, class SRC, class ACC>
+struct ShotDispatch<T, 0, SRC, ACC> {
+    static __device__ __forceinline__ void run(ACC &, const SRC &, int, int, const T *) {}
+};
 
-// All full chunks in [e0, e1) (element offsets a multiple of CHUNK apart), software-pipelined in batches of U:
-// while batch i's x gathers are in flight the streaming loads of batch i+1 are already issued, so a wave's
-// critical path per batch is max(stream latency, gather latency) instead of their sum.
-template <class T, bool NT, int U, class ACC>
-__device__ __forceinline__ void mfma_stream(ACC &acc, const T *val, const int *cid, size_t e0, size_t e1, int lane, const T *x)
-{
-    constexpr int CH = Tr<T>::CHUNK;
-    const int nchunk = (int)((e1 - e0) / CH);
-    const int nfull = nchunk / U, rem = nchunk % U;
-    size_t e = e0;
-    Frag<T> cur[U];
-    if (nfull > 0) {
-        batch_load<NT>(cur, val, cid, e, lane);
-        e += (size_t)U * CH;
-        for (int i = 1; i < nfull; ++i) {
-            Frag<T> nxt[U];
-            batch_gather(cur, x);
-            batch_load<NT>(nxt, val, cid, e, lane);
-            e += (size_t)U * CH;
-            batch_mfma(acc, cur);
+// last step of the pipeline: `cur` (a full batch whose loads are in flight) and R leftover steps from i
+template <class T, int U, int R, class SRC, class ACC>
+struct FinishDispatch {
+    static __device__ __forceinline__ void run(ACC &acc, const SRC &src, Frag<T> (&cur)[U], int ibase, int i, int rem, const T *x)
+    {
+        if (rem == R) {
+            Frag<T> r[R > 0 ? R : 1];
 #pragma unroll
-            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-        }
+            for (int u = 0; u < U; ++u) src.gather(cur[u], ibase + u, x);
+#pragma unroll
+            for (int u = 0; u < R; ++u) src.load(r[u], i + u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) frag_mfma(acc, cur[u]);
+#pragma unroll
+            for (int u = 0; u < R; ++u) src.gather(r[u], i + u, x);
+#pragma unroll
+            for (int u = 0; u < R; ++u) frag_mfma(acc, r[u]);
+        } else if constexpr (R > 0) FinishDispatch<T, U, R - 1, SRC, ACC>::run(acc, src, cur, ibase, i, rem, x);
     }
-    const bool have = nfull > 0;
-    if constexpr (U == 4) {
-        switch (rem) {
-            case 0: stream_finish<T, NT, U, 0>(acc, have, cur, val, cid, e, lane, x); break;
-            case 1: stream_finish<T, NT, U, 1>(acc, have, cur, val, cid, e, lane, x); break;
-            case 2: stream_finish<T, NT, U, 2>(acc, have, cur, val, cid, e, lane, x); break;
-            default: stream_finish<T, NT, U, 3>(acc, have, cur, val, cid, e, lane, x); break;
-        }
-    } else {
-        static_assert(U == 2, "batch size");
-        if (rem == 0) stream_finish<T, NT, U, 0>(acc, have, cur, val, cid, e, lane, x);
-        else stream_finish<T, NT, U, 1>(acc, have, cur, val, cid, e, lane, x);
+};
+
+// All N MFMA steps of a unit.  N <= S: one shot (short blocks: a wave's whole dependent chain is
+// pointers -> loads -> gathers -> MFMAs).  Longer: software-pipelined batches of U -- while batch i's x gathers are in
+// flight the streaming loads of batch i+1 are already issued, so the critical path per batch is
+// max(stream latency, gather latency) instead of their sum.
+template <class T, int U, int S, class SRC, class ACC>
+__device__ __forceinline__ void run_stream(ACC &acc, const SRC &src, int N, const T *x)
+{
+    if (N <= S) { ShotDispatch<T, S, SRC, ACC>::run(acc, src, 0, N, x); return; }
+    const int nfull = N / U, rem = N % U;
+    Frag<T> cur[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) src.load(cur[u], u);
+    int i = U;
+    for (int it = 1; it < nfull; ++it, i += U) {
+        Frag<T> nxt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) src.gather(cur[u], i - U + u, x);
+#pragma unroll
+        for (int u = 0; u < U; ++u) src.load(nxt[u], i + u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) frag_mfma(acc, cur[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
+    FinishDispatch<T, U, U - 1, SRC, ACC>::run(acc, src, cur, i - U, i, rem, x);
 }
 
 // diagonal element D[row][row] held by this lane (valid only on the 16 "diagonal lanes")
@@ -286,44 +357,19 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane)
     const T *val = static_cast<const T *>(a.med_val);
     const int c0 = a.med_ptr[b], c1 = a.med_ptr[b + 1];
     acc_t acc = {0, 0, 0, 0};
-    // tail bounds first: their latency hides under the chunk stream.  lane (row = l&15, kq = l>>4) walks its
-    // row's leftover entries; the block's first row is its longest (rows are sorted), so its tail bounds the loop.
+    // the block's first row is its longest (rows are sorted), so its tail length bounds the number of tail steps
     const int row = lane & 15, kq = lane >> 4;
     const int r = b * kMedRows + row;
     int t0 = 0, t1 = 0;
     if (r < a.row_block) { t0 = a.irr_ptr[r]; t1 = a.irr_ptr[r + 1]; }
+    constexpr int TK = sizeof(T) == 8 ? 4 : 16;                      // tail entries of one row per MFMA step
+    const int nt = (__builtin_amdgcn_readfirstlane(t1 - t0) + TK - 1) / TK;
+    BlockSrc<T, NT> src;
+    src.reg.val = val; src.reg.cid = a.med_cid; src.reg.e0 = (size_t)c0 * CH; src.reg.lane = lane;
+    src.nc = c1 - c0;
+    src.ival = static_cast<const T *>(a.irr_val); src.icid = a.irr_cid; src.t0 = t0; src.t1 = t1; src.kq = kq;
+    run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, src.nc + nt, x);
 
-    mfma_stream<T, NT, Tr<T>::BATCH>(acc, val, a.med_cid, (size_t)c0 * CH, (size_t)c1 * CH, lane, x);
-
-    const int tmax = __builtin_amdgcn_readfirstlane(t1 - t0);
-    const T *ival = static_cast<const T *>(a.irr_val);
-    // out-of-range lanes read element 0 of the (never empty: the arena pads it) tail arrays and are
-    // zeroed afterwards, so the loop body has no divergent branch
-    if constexpr (sizeof(T) == 8) {
-        for (int j = 0; j < tmax; j += 4) {
-            const int i = t0 + j + kq;
-            const bool ok = i < t1;
-            const int ii = ok ? i : 0;
-            const double av = ldg<NT>(ival + ii);
-            const double xv = x[ldg<NT>(a.irr_cid + ii)];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? av : 0.0, ok ? xv : 0.0, acc, 0, 0, 0);
-        }
-    } else {
-        for (int j = 0; j < tmax; j += 16) {
-            f16x4 av, bv;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = t0 + j + 4 * kq + q;
-                const bool ok = i < t1;
-                const int ii = ok ? i : 0;
-                const _Float16 v = ival[ii];
-                const _Float16 xv = x[a.irr_cid[ii]];
-                av[q] = ok ? v : (_Float16)0;
-                bv[q] = ok ? xv : (_Float16)0;
-            }
-            acc = __builtin_amdgcn_mfma_f32_16x16x16f16(av, bv, acc, 0, 0, 0);
-        }
-    }
     typename Tr<T>::part_t d;
     if (diag_of(acc, lane, d) && r < a.row_block) {
         const int slot = a.row_long + r;
@@ -345,7 +391,8 @@ __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
     const int p0 = a.piece_ptr[p], p1 = a.piece_ptr[p + 1];
     acc_t acc = {0, 0, 0, 0};
     const int full = p0 + (p1 - p0) / CH * CH;
-    mfma_stream<T, NT, Tr<T>::BATCH>(acc, val, a.long_cid, (size_t)p0, (size_t)full, lane, x);
+    ChunkSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane};
+    run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, (full - p0) / CH, x);
     if (full < p1) {   // last, partial chunk: rows are padded to kLongAlign, so a lane's group is all-in or all-out;
                        // out-of-range lanes re-read the piece's first group (in bounds) and are zeroed
         const int i = full + VPL * lane;
@@ -430,8 +477,11 @@ __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
     }
 }
 
+#ifndef DASP_LB
+#define DASP_LB 1
+#endif
 template <class T, bool NT, bool NATURAL>
-__global__ __launch_bounds__(256) void dasp_spmv_kernel(DevArgs a)
+__global__ __launch_bounds__(256, DASP_LB) void dasp_spmv_kernel(DevArgs a)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
