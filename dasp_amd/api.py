@@ -55,6 +55,32 @@ def mmio_allinone(filename, precision=64):
     return m.value, n.value, k, sym.value, row_ptr, col_idx, val
 
 
+def csr_save(path, row_ptr, col_idx, val, n_cols, is_symmetric=0, precision=64):
+    """Binary cache of a loaded CSR (dasp_csr_save)."""
+    rp = np.ascontiguousarray(row_ptr, np.int32)
+    ci = np.ascontiguousarray(col_idx, np.int32)
+    v = np.ascontiguousarray(val, _dtype(precision))
+    _lib.check(_lib.lib().dasp_csr_save(os.fsencode(path), precision, rp.size - 1, int(n_cols), int(ci.size), int(is_symmetric), _vp(rp), _vp(ci), _vp(v)))
+
+
+def csr_load(path, precision=64):
+    """-> (m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, csrVal), as mmio_allinone returned them."""
+    L = _lib.lib()
+    ip = C.POINTER(C.c_int)
+    m, n, nnz, sym = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rp, ci, v = ip(), ip(), C.c_void_p()
+    _lib.check(L.dasp_csr_load(os.fsencode(path), precision, C.byref(m), C.byref(n), C.byref(nnz), C.byref(sym), C.byref(rp), C.byref(ci), C.byref(v)))
+    k = nnz.value
+    row_ptr = np.ctypeslib.as_array(rp, (m.value + 1,)).copy()
+    col_idx = np.ctypeslib.as_array(ci, (max(k, 1),))[:k].copy()
+    ct = C.c_double if precision == 64 else C.c_uint16
+    raw = np.ctypeslib.as_array(C.cast(v, C.POINTER(ct)), (max(k, 1),))[:k].copy()
+    val = raw if precision == 64 else raw.view(np.float16)
+    for q in (C.cast(rp, C.c_void_p), C.cast(ci, C.c_void_p), v):
+        L.dasp_free(q)
+    return m.value, n.value, k, sym.value, row_ptr, col_idx, val
+
+
 class Plan:
     """DASP plan: classifier + packers on the host, kernels on the current HIP device."""
 

@@ -59,6 +59,18 @@ int dasp_mmio_allinone_f16(int *m, int *n, int *nnz, int *isSymmetric, int **csr
     return rc;
 }
 
+int dasp_csr_save(const char *path, int precision, int m, int n, int nnz, int isSymmetric, const int *csrRowPtr,
+                  const int *csrColIdx, const void *csrVal)
+{
+    return save_csr_bin(path, precision, m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, csrVal);
+}
+
+int dasp_csr_load(const char *path, int precision, int *m, int *n, int *nnz, int *isSymmetric, int **csrRowPtr,
+                  int **csrColIdx, void **csrVal)
+{
+    return load_csr_bin(path, precision, m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, csrVal);
+}
+
 int dasp_plan_create(dasp_plan_t **out, int precision, int rowA, int colA, int nnzA, const int *rp, const int *ci,
                      const void *val, const dasp_options_t *opt)
 {

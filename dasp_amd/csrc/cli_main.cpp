@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "../../include/dasp_amd.h"
@@ -42,7 +43,15 @@ int main(int argc, char **argv)
     std::printf("\n===%s===\n\n", filename);
     int rowA, colA, nnzA, sym, *rpt, *cid;
     val_t *val;
-    int rc = LOAD(&rowA, &colA, &nnzA, &sym, &rpt, &cid, &val, filename);
+    // DASP_CSR_CACHE=1: keep / reuse a binary copy of the parsed CSR next to the .mtx
+    const bool use_cache = std::getenv("DASP_CSR_CACHE") != nullptr;
+    const std::string cache = std::string(filename) + (sizeof(val_t) == 8 ? ".f64.csrbin" : ".f16.csrbin");
+    int rc = -1;
+    if (use_cache) { void *v = nullptr; rc = dasp_csr_load(cache.c_str(), (int)sizeof(val_t) * 8, &rowA, &colA, &nnzA, &sym, &rpt, &cid, &v); val = (val_t *)v; }
+    if (rc != 0) {
+        rc = LOAD(&rowA, &colA, &nnzA, &sym, &rpt, &cid, &val, filename);
+        if (rc == 0 && use_cache) (void)dasp_csr_save(cache.c_str(), (int)sizeof(val_t) * 8, rowA, colA, nnzA, sym, rpt, cid, val);
+    }
     if (rc != 0) { std::fprintf(stderr, "%s: cannot load %s (status %d: %s)\n", kName, filename, rc, dasp_last_error()); return 1; }
     std::vector<val_t> X((size_t)colA + 1, one()), Y((size_t)rowA);
     for (int i = 0; i < nnzA; ++i) val[i] = one();

@@ -10,13 +10,18 @@
 //   * return codes 0 / -1 (open) / -2 (banner) / -4 (size line)
 // The whole file is read once and tokenised in memory instead of one fscanf per entry
 // (the reference's loader is serial text parsing: minutes on 3e8-entry files).
+#include <algorithm>
 #include <cctype>
 #include <cerrno>
 #include <charconv>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "plan.hpp"
@@ -25,9 +30,12 @@ namespace dasp {
 
 namespace {
 
+// C-locale isspace without the libc call
+static inline bool is_ws(char ch) { return ch == ' ' || (unsigned)(ch - '\t') <= 4u; }
+
 struct Cursor {
     const char *p, *end;
-    void skip_ws() { while (p < end && std::isspace((unsigned char)*p)) ++p; }
+    void skip_ws() { while (p < end && is_ws(*p)) ++p; }
     bool at_end() { skip_ws(); return p >= end; }
 };
 
@@ -83,13 +91,31 @@ bool next_line(Cursor &c, std::string &line)
 
 void lower(std::string &s) { for (auto &ch : s) ch = (char)std::tolower((unsigned char)ch); }
 
+// COO (file order) -> CSR exactly as the reference's counting pass + scatter pass do it
+// (mmio_highlevel.h:702-756), parallel over row ranges: every thread streams over all entries but only
+// counts / places those whose row -- or mirrored row -- it owns, so the order inside a row stays file order.
 template <class T>
 int finish(int M, int N, int nz, bool sym, const std::vector<int> &ri, const std::vector<int> &cj,
            const std::vector<double> &vv, int *m, int *n, int *nnz, int *symflag, int **rp_out, int **ci_out, void **val_out)
 {
+    int nthreads = nz < (1 << 20) ? 1 : resolve_threads(0);
+    nthreads = std::min(nthreads, std::max(1, M));
+    auto lo_of = [&](int t) { return (int)((long long)M * t / nthreads); };
     std::vector<int> cnt((size_t)M + 1, 0);
-    for (int e = 0; e < nz; ++e) cnt[ri[e]]++;
-    if (sym) for (int e = 0; e < nz; ++e) if (ri[e] != cj[e]) cnt[cj[e]]++;
+    auto run_par = [&](auto fn) {
+        if (nthreads == 1) { fn(0); return; }
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t) th.emplace_back(fn, t);
+        for (auto &x : th) x.join();
+    };
+    run_par([&](int t) {
+        const int lo = lo_of(t), hi = lo_of(t + 1);
+        for (int e = 0; e < nz; ++e) {
+            const int r = ri[e], c = cj[e];
+            if (r >= lo && r < hi) cnt[r]++;
+            if (sym && r != c && c >= lo && c < hi) cnt[c]++;
+        }
+    });
     int *rp = (int *)std::malloc(sizeof(int) * ((size_t)M + 1));
     if (!rp) return DASP_ERR_NOMEM;
     long long run = 0;
@@ -100,13 +126,15 @@ int finish(int M, int N, int nz, bool sym, const std::vector<int> &ri, const std
     int *ci = (int *)std::malloc(sizeof(int) * (total ? total : 1));
     T *v = (T *)std::malloc(sizeof(T) * (total ? total : 1));
     if (!ci || !v) { std::free(rp); std::free(ci); std::free(v); return DASP_ERR_NOMEM; }
-    std::fill(cnt.begin(), cnt.end(), 0);
-    for (int e = 0; e < nz; ++e) {
-        const int r = ri[e], c = cj[e];
-        size_t at = (size_t)rp[r] + cnt[r]++;
-        ci[at] = c; v[at] = (T)vv[e];
-        if (sym && r != c) { at = (size_t)rp[c] + cnt[c]++; ci[at] = r; v[at] = (T)vv[e]; }
-    }
+    run_par([&](int t) {
+        const int lo = lo_of(t), hi = lo_of(t + 1);
+        for (int i = lo; i < hi; ++i) cnt[i] = 0;
+        for (int e = 0; e < nz; ++e) {
+            const int r = ri[e], c = cj[e];
+            if (r >= lo && r < hi) { const size_t at = (size_t)rp[r] + cnt[r]++; ci[at] = c; v[at] = (T)vv[e]; }
+            if (sym && r != c && c >= lo && c < hi) { const size_t at = (size_t)rp[c] + cnt[c]++; ci[at] = r; v[at] = (T)vv[e]; }
+        }
+    });
     *m = M; *n = N; *nnz = (int)total; *symflag = sym ? 1 : 0;
     *rp_out = rp; *ci_out = ci; *val_out = v;
     return DASP_OK;
@@ -117,21 +145,26 @@ int finish(int M, int N, int nz, bool sym, const std::vector<int> &ri, const std
 int load_mtx(const char *path, int precision, int *m, int *n, int *nnz, int *symflag, int **rp_out, int **ci_out, void **val_out)
 {
     if (!path || !m || !n || !nnz || !symflag || !rp_out || !ci_out || !val_out) return DASP_ERR_ARG;
+    const bool verbose = std::getenv("DASP_VERBOSE") != nullptr;
+    auto tick = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { if (verbose) { auto now = std::chrono::steady_clock::now(); std::fprintf(stderr, "[dasp loader] %s: %.3f s\n", what, std::chrono::duration<double>(now - tick).count()); tick = now; } };
     FILE *f = std::fopen(path, "rb");
     if (!f) { set_error(std::string("cannot open ") + path); return DASP_ERR_OPEN; }
-    std::vector<char> buf;
+    std::unique_ptr<char[]> buf;
+    size_t got = 0;
     {
         std::fseek(f, 0, SEEK_END);
         long sz = std::ftell(f);
         std::fseek(f, 0, SEEK_SET);
         if (sz < 0) sz = 0;
-        buf.resize((size_t)sz + 1);
-        size_t got = sz ? std::fread(buf.data(), 1, (size_t)sz, f) : 0;
-        buf.resize(got + 1);
-        buf[got] = '\0';
+        buf.reset(new (std::nothrow) char[(size_t)sz + 1]);     // not zero-filled
+        if (!buf) { std::fclose(f); set_error("out of host memory"); return DASP_ERR_NOMEM; }
+        got = sz ? std::fread(buf.get(), 1, (size_t)sz, f) : 0;
+        buf[got] = '\0';                                        // strtod slow path needs a terminator
         std::fclose(f);
     }
-    Cursor c{buf.data(), buf.data() + buf.size() - 1};
+    Cursor c{buf.get(), buf.get() + got};
+    lap("read file");
 
     // ---- banner (mmio.h:398-564)
     std::string line;
@@ -167,26 +200,130 @@ int load_mtx(const char *path, int precision, int *m, int *n, int *nnz, int *sym
     }
     if (M < 0 || N < 0 || nz < 0) { set_error("negative dimension"); return DASP_ERR_SIZE; }
 
-    // ---- entries (mmio_highlevel.h:663-697)
+    // ---- entries (mmio_highlevel.h:663-697).  The entry section is a stream of whitespace-separated tokens
+    // (fscanf semantics: an entry may span lines), tpe tokens per entry.  Parsed in parallel: the buffer is cut at
+    // token boundaries, tokens are counted per piece, and with the prefix sums every piece knows which
+    // (entry, field) each of its tokens is.
     std::vector<int> ri((size_t)nz), cj((size_t)nz);
     std::vector<double> vv((size_t)nz);
-    for (int e = 0; e < nz; ++e) {
-        int i, j, iv = 0;
-        double re = 1.0, im = 0.0;
-        bool ok = parse_int(c, i) && parse_int(c, j);
-        if (ok && is_real) ok = parse_double(c, re);
-        else if (ok && is_complex) ok = parse_double(c, re) && parse_double(c, im);
-        else if (ok && is_integer) { ok = parse_int(c, iv); re = iv; }
-        if (!ok) { set_error("entry " + std::to_string(e + 1) + ": malformed or missing"); return DASP_ERR_ENTRY; }
-        --i; --j;
-        if (i < 0 || i >= M || j < 0 || j >= N || (sym && j >= M) ) {
-            set_error("entry " + std::to_string(e + 1) + ": index out of range"); return DASP_ERR_ENTRY;
-        }
-        ri[e] = i; cj[e] = j; vv[e] = re;
+    const int tpe = is_pattern ? 2 : (is_complex ? 4 : 3);
+    const long long need = (long long)nz * tpe;
+    c.skip_ws();
+    const char *const b0 = c.p, *const b1 = c.end;
+    int nthreads = resolve_threads(0);
+    if (b1 - b0 < (1 << 20)) nthreads = 1;
+    std::vector<const char *> cut((size_t)nthreads + 1);
+    cut[0] = b0; cut[nthreads] = b1;
+    for (int t = 1; t < nthreads; ++t) {
+        const char *q = b0 + (b1 - b0) * t / nthreads;
+        while (q < b1 && !is_ws(*q)) ++q;   // finish the token we landed in
+        cut[t] = q;
     }
-    if (precision == 64)
-        return finish<double>(M, N, nz, sym, ri, cj, vv, m, n, nnz, symflag, rp_out, ci_out, val_out);
-    return finish<_Float16>(M, N, nz, sym, ri, cj, vv, m, n, nnz, symflag, rp_out, ci_out, val_out);
+    for (int t = 1; t <= nthreads; ++t) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    std::vector<long long> ntok((size_t)nthreads + 1, 0);
+    auto count_tokens = [&](int t) {
+        const char *q = cut[t], *e = cut[t + 1];
+        long long k = 0;
+        while (q < e) {
+            while (q < e && is_ws(*q)) ++q;
+            if (q >= e) break;
+            ++k;
+            while (q < e && !is_ws(*q)) ++q;
+        }
+        ntok[t + 1] = k;
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t) th.emplace_back(count_tokens, t);
+        for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < nthreads; ++t) ntok[t + 1] += ntok[t];
+    lap("count tokens");
+    if (ntok[nthreads] < need) {
+        set_error("entry " + std::to_string(ntok[nthreads] / tpe + 1) + ": malformed or missing"); return DASP_ERR_ENTRY;
+    }
+    std::vector<long long> bad_entry((size_t)nthreads, -1);
+    std::vector<int> bad_kind((size_t)nthreads, 0);
+    auto parse_piece = [&](int t) {
+        Cursor cc{cut[t], cut[t + 1]};
+        long long g = ntok[t];
+        while (g < need) {
+            cc.skip_ws();
+            if (cc.p >= cc.end) break;
+            const long long e = g / tpe;
+            const int field = (int)(g % tpe);
+            bool ok = true;
+            const char *tok = cc.p;
+            if (field == 0) { int i; ok = parse_int(cc, i); if (ok) { if (i < 1 || i > M) { bad_entry[t] = e; bad_kind[t] = 2; return; } ri[e] = i - 1; } }
+            else if (field == 1) {
+                int j; ok = parse_int(cc, j);
+                if (ok) { if (j < 1 || j > N || (sym && j > M)) { bad_entry[t] = e; bad_kind[t] = 2; return; } cj[e] = j - 1; }
+                if (ok && is_pattern) vv[e] = 1.0;
+            } else if (field == 2) {
+                if (is_integer) { int iv; ok = parse_int(cc, iv); if (ok) vv[e] = iv; }
+                else { double re; ok = parse_double(cc, re); if (ok) vv[e] = re; }
+            } else { double im; ok = parse_double(cc, im); }
+            // a token must be consumed entirely (fscanf would leave the rest for the next conversion and derail)
+            if (ok && cc.p < cc.end && !is_ws(*cc.p)) ok = false;
+            if (!ok) { bad_entry[t] = e; bad_kind[t] = 1; (void)tok; return; }
+            ++g;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthreads; ++t) th.emplace_back(parse_piece, t);
+        for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < nthreads; ++t)
+        if (bad_entry[t] >= 0) {
+            set_error("entry " + std::to_string(bad_entry[t] + 1) + (bad_kind[t] == 2 ? ": index out of range" : ": malformed or missing"));
+            return DASP_ERR_ENTRY;
+        }
+    lap("parse tokens");
+    const int rc = precision == 64 ? finish<double>(M, N, nz, sym, ri, cj, vv, m, n, nnz, symflag, rp_out, ci_out, val_out)
+                                   : finish<_Float16>(M, N, nz, sym, ri, cj, vv, m, n, nnz, symflag, rp_out, ci_out, val_out);
+    lap("coo -> csr");
+    return rc;
+}
+
+// ---- binary CSR cache: the CSR exactly as the loader returns it, so a second run skips text parsing.
+// layout: "DASPCSR1" | int32 precision, m, n, nnz, is_symmetric, 0,0,0 | rowptr[m+1] | colidx[nnz] | val[nnz]
+static const char kMagic[8] = {'D', 'A', 'S', 'P', 'C', 'S', 'R', '1'};
+
+int save_csr_bin(const char *path, int precision, int m, int n, int nnz, int sym, const int *rp, const int *ci, const void *val)
+{
+    if (!path || !rp || (nnz > 0 && (!ci || !val)) || (precision != 64 && precision != 16)) return DASP_ERR_ARG;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) { set_error(std::string("cannot create ") + path); return DASP_ERR_OPEN; }
+    const int hdr[8] = {precision, m, n, nnz, sym, 0, 0, 0};
+    const size_t vb = precision == 64 ? 8 : 2;
+    bool ok = std::fwrite(kMagic, 1, 8, f) == 8 && std::fwrite(hdr, 4, 8, f) == 8 &&
+              std::fwrite(rp, 4, (size_t)m + 1, f) == (size_t)m + 1 &&
+              (nnz == 0 || (std::fwrite(ci, 4, (size_t)nnz, f) == (size_t)nnz && std::fwrite(val, vb, (size_t)nnz, f) == (size_t)nnz));
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok) { set_error(std::string("short write to ") + path); return DASP_ERR_OPEN; }
+    return DASP_OK;
+}
+
+int load_csr_bin(const char *path, int precision, int *m, int *n, int *nnz, int *sym, int **rp_out, int **ci_out, void **val_out)
+{
+    if (!path || !m || !n || !nnz || !sym || !rp_out || !ci_out || !val_out) return DASP_ERR_ARG;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) { set_error(std::string("cannot open ") + path); return DASP_ERR_OPEN; }
+    char magic[8]; int hdr[8];
+    if (std::fread(magic, 1, 8, f) != 8 || std::memcmp(magic, kMagic, 8) != 0 || std::fread(hdr, 4, 8, f) != 8 || hdr[0] != precision ||
+        hdr[1] < 0 || hdr[2] < 0 || hdr[3] < 0) {
+        std::fclose(f); set_error("not a DASPCSR1 file of this precision"); return DASP_ERR_BANNER;
+    }
+    const size_t M = (size_t)hdr[1], K = (size_t)hdr[3], vb = precision == 64 ? 8 : 2;
+    int *rp = (int *)std::malloc(4 * (M + 1)), *ci = (int *)std::malloc(4 * (K ? K : 1));
+    void *v = std::malloc(vb * (K ? K : 1));
+    bool ok = rp && ci && v && std::fread(rp, 4, M + 1, f) == M + 1 && (K == 0 || (std::fread(ci, 4, K, f) == K && std::fread(v, vb, K, f) == K));
+    std::fclose(f);
+    if (!ok || rp[0] != 0 || rp[M] != hdr[3]) { std::free(rp); std::free(ci); std::free(v); set_error("truncated or corrupt DASPCSR1 file"); return DASP_ERR_ENTRY; }
+    *m = hdr[1]; *n = hdr[2]; *nnz = hdr[3]; *sym = hdr[4];
+    *rp_out = rp; *ci_out = ci; *val_out = v;
+    return DASP_OK;
 }
 
 }  // namespace dasp

@@ -101,6 +101,9 @@ int build_plan(Plan &p, const int *rp, const int *ci, const void *val);
 // loader (mmio.cpp).  val_out: malloc'd array of double or binary16.
 int load_mtx(const char *path, int precision, int *m, int *n, int *nnz, int *sym, int **rp, int **ci, void **val);
 
+int save_csr_bin(const char *path, int precision, int m, int n, int nnz, int sym, const int *rp, const int *ci, const void *val);
+int load_csr_bin(const char *path, int precision, int *m, int *n, int *nnz, int *sym, int **rp, int **ci, void **val);
+
 void set_error(const std::string &s);
 
 // threads helper

@@ -60,6 +60,14 @@ int dasp_mmio_allinone_f16(int *m, int *n, int *nnz, int *isSymmetric,
                            int **csrRowPtr, int **csrColIdx, uint16_t **csrVal, const char *filename);
 void dasp_free(void *p);
 
+/* binary cache of the loader's CSR (the reference re-parses the text file on every run).
+ * dasp_csr_load returns exactly what dasp_mmio_allinone_* returned when the file was saved; csrVal is double* or
+ * uint16_t* (binary16) according to `precision`; arrays are malloc'd (dasp_free). */
+int dasp_csr_save(const char *path, int precision, int m, int n, int nnz, int isSymmetric,
+                  const int *csrRowPtr, const int *csrColIdx, const void *csrVal);
+int dasp_csr_load(const char *path, int precision, int *m, int *n, int *nnz, int *isSymmetric,
+                  int **csrRowPtr, int **csrColIdx, void **csrVal);
+
 /* --------------------------------------------------------------- plan API
  * The reference fuses preprocessing, upload, 1100 launches and download in spmv_all
  * (src/dasp_f64.h:486-1483).  The plan API is the same work split into reusable steps. */

@@ -76,3 +76,19 @@ def test_entry_errors(dasp, tmp_path):
     with pytest.raises(dasp.DaspError) as e:
         dasp.mmio_allinone(str(p))
     assert e.value.status == -5
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+def test_binary_csr_cache_round_trip(dasp, tmp_path, prec):
+    m, n, nnz, sym, rp, ci, v = dasp.mmio_allinone(os.path.join(GOLD, "sym_real.mtx"), prec)
+    p = str(tmp_path / "a.csrbin")
+    dasp.csr_save(p, rp, ci, v, n, sym, prec)
+    m2, n2, nnz2, sym2, rp2, ci2, v2 = dasp.csr_load(p, prec)
+    assert (m2, n2, nnz2, sym2) == (m, n, nnz, sym)
+    assert (rp2 == rp).all() and (ci2 == ci).all() and v2.dtype == v.dtype and (v2 == v).all()
+    with pytest.raises(dasp.DaspError):
+        dasp.csr_load(p, 16 if prec == 64 else 64)          # wrong precision is refused
+    with open(p, "r+b") as f:
+        f.truncate(40)
+    with pytest.raises(dasp.DaspError):
+        dasp.csr_load(p, prec)
