@@ -138,6 +138,9 @@ long long dasp_plan_host_array(const dasp_plan_t *plan, const char *name, const 
     if (n == "irr_ptr") return ints(p.irr_ptr);
     if (n == "irr_val") return vals(p.irr_val);
     if (n == "irr_cid") return ints(p.irr_cid);
+    if (n == "med_dst") return ints(p.med_dst);
+    if (n == "win_cmin") return ints(p.win_cmin);
+    if (n == "win_len") return ints(p.win_len);
     if (n == "short_val") return vals(p.short_val);
     if (n == "short_cid") return ints(p.short_cid);
     if (n == "short_groups") {   // kNumShortGroups x {len,count,tiles,tile0,elem_off_lo,elem_off_hi,split,base0,base1,grp0,grp1,off0,off1}

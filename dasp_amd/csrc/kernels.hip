@@ -52,6 +52,9 @@ struct DevArgs {
     const int *med_ptr; const void *med_val; const int *med_cid;
     const int *irr_ptr; const void *irr_val; const int *irr_cid;
     int n_blocks, row_block, row_long;
+    // windowed mode (LDS-staged x)
+    const int *med_dst; const int *win_cmin; const int *win_len;
+    int n_windows, blocks_per_win;
     // short
     const void *short_val; const int *short_cid; const ShortDev *groups;
     int n_short_tiles;
@@ -180,17 +183,30 @@ __device__ __forceinline__ U ldx(const U *p)
     return *p;
 #endif
 }
-__device__ __forceinline__ void frag_gather(Frag<double> &f, const double *x)
+// where x values come from: global memory, or the workgroup's window of x staged in LDS
+template <class T>
+struct XGlobal {
+    const T *x;
+    __device__ __forceinline__ T at(int c) const { return ldx(x + (c < 0 ? 0 : c)); }       // pads read x[0], dropped below
+};
+template <class T>
+struct XLds {
+    const T *xw; int cmin;
+    __device__ __forceinline__ T at(int c) const { return xw[c < 0 ? 0 : c - cmin]; }
+};
+template <class XV>
+__device__ __forceinline__ void frag_gather(Frag<double> &f, const XV &xv)
 {
-    const double xv = ldx(x + (f.c < 0 ? 0 : f.c));
-    f.b = f.c < 0 ? 0.0 : xv;
+    const double v = xv.at(f.c);
+    f.b = f.c < 0 ? 0.0 : v;
 }
-__device__ __forceinline__ void frag_gather(Frag<_Float16> &f, const _Float16 *x)
+template <class XV>
+__device__ __forceinline__ void frag_gather(Frag<_Float16> &f, const XV &xv)
 {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const _Float16 xv = ldx(x + (f.c[j] < 0 ? 0 : f.c[j]));
-        f.b[j] = f.c[j] < 0 ? (_Float16)0 : xv;
+        const _Float16 v = xv.at(f.c[j]);
+        f.b[j] = f.c[j] < 0 ? (_Float16)0 : v;
     }
 }
 __device__ __forceinline__ void frag_mfma(f64x4 &acc, const Frag<double> &f)
@@ -210,7 +226,7 @@ template <class T, bool NT>
 struct ChunkSrc {
     const T *val; const int *cid; size_t e0; int lane;
     __device__ __forceinline__ void load(Frag<T> &f, int i) const { frag_load<NT>(f, val, cid, e0 + (size_t)i * Tr<T>::CHUNK, lane); }
-    __device__ __forceinline__ void gather(Frag<T> &f, int, const T *x) const { frag_gather(f, x); }
+    template <class XV> __device__ __forceinline__ void gather(Frag<T> &f, int, const XV &x) const { frag_gather(f, x); }
 };
 
 // a medium block: nc lane-linear chunks, then the irregular tail as extra steps in which lane (row = l&15, kq = l>>4)
@@ -239,7 +255,7 @@ struct BlockSrc {
             }
         }
     }
-    __device__ __forceinline__ void gather(Frag<T> &f, int i, const T *x) const
+    template <class XV> __device__ __forceinline__ void gather(Frag<T> &f, int i, const XV &x) const
     {
         if (i >= nc) {
             const int j = i - nc;
@@ -261,8 +277,8 @@ struct BlockSrc {
 };
 
 // N steps starting at step i0, everything in flight at once: all loads, then all gathers, then the MFMAs
-template <class T, int N, class SRC, class ACC>
-__device__ __forceinline__ void shot(ACC &acc, const SRC &src, int i0, const T *x)
+template <class T, int N, class SRC, class ACC, class XV>
+__device__ __forceinline__ void shot(ACC &acc, const SRC &src, int i0, const XV &x)
 {
     Frag<T> f[N];
 #pragma unroll
@@ -272,23 +288,23 @@ __device__ __forceinline__ void shot(ACC &acc, const SRC &src, int i0, const T *
 #pragma unroll
     for (int u = 0; u < N; ++u) frag_mfma(acc, f[u]);
 }
-template <class T, int N, class SRC, class ACC>
+template <class T, int N, class SRC, class ACC, class XV>
 struct ShotDispatch {
-    static __device__ __forceinline__ void run(ACC &acc, const SRC &src, int i0, int n, const T *x)
+    static __device__ __forceinline__ void run(ACC &acc, const SRC &src, int i0, int n, const XV &x)
     {
         if (n == N) shot<T, N>(acc, src, i0, x);
-        else ShotDispatch<T, N - 1, SRC, ACC>::run(acc, src, i0, n, x);
+        else ShotDispatch<T, N - 1, SRC, ACC, XV>::run(acc, src, i0, n, x);
     }
 };
-template <class T, class SRC, class ACC>
-struct ShotDispatch<T, 0, SRC, ACC> {
-    static __device__ __forceinline__ void run(ACC &, const SRC &, int, int, const T *) {}
+template <class T, class SRC, class ACC, class XV>
+struct ShotDispatch<T, 0, SRC, ACC, XV> {
+    static __device__ __forceinline__ void run(ACC &, const SRC &, int, int, const XV &) {}
 };
 
 // last step of the pipeline: `cur` (a full batch whose loads are in flight) and R leftover steps from i
-template <class T, int U, int R, class SRC, class ACC>
+template <class T, int U, int R, class SRC, class ACC, class XV>
 struct FinishDispatch {
-    static __device__ __forceinline__ void run(ACC &acc, const SRC &src, Frag<T> (&cur)[U], int ibase, int i, int rem, const T *x)
+    static __device__ __forceinline__ void run(ACC &acc, const SRC &src, Frag<T> (&cur)[U], int ibase, int i, int rem, const XV &x)
     {
         if (rem == R) {
             Frag<T> r[R > 0 ? R : 1];
@@ -302,7 +318,7 @@ struct FinishDispatch {
             for (int u = 0; u < R; ++u) src.gather(r[u], i + u, x);
 #pragma unroll
             for (int u = 0; u < R; ++u) frag_mfma(acc, r[u]);
-        } else if constexpr (R > 0) FinishDispatch<T, U, R - 1, SRC, ACC>::run(acc, src, cur, ibase, i, rem, x);
+        } else if constexpr (R > 0) FinishDispatch<T, U, R - 1, SRC, ACC, XV>::run(acc, src, cur, ibase, i, rem, x);
     }
 };
 
@@ -310,10 +326,10 @@ struct FinishDispatch {
 // pointers -> loads -> gathers -> MFMAs).  Longer: software-pipelined batches of U -- while batch i's x gathers are in
 // flight the streaming loads of batch i+1 are already issued, so the critical path per batch is
 // max(stream latency, gather latency) instead of their sum.
-template <class T, int U, int S, class SRC, class ACC>
-__device__ __forceinline__ void run_stream(ACC &acc, const SRC &src, int N, const T *x)
+template <class T, int U, int S, class SRC, class ACC, class XV>
+__device__ __forceinline__ void run_stream(ACC &acc, const SRC &src, int N, const XV &x)
 {
-    if (N <= S) { ShotDispatch<T, S, SRC, ACC>::run(acc, src, 0, N, x); return; }
+    if (N <= S) { ShotDispatch<T, S, SRC, ACC, XV>::run(acc, src, 0, N, x); return; }
     const int nfull = N / U, rem = N % U;
     Frag<T> cur[U];
 #pragma unroll
@@ -330,7 +346,7 @@ __device__ __forceinline__ void run_stream(ACC &acc, const SRC &src, int N, cons
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
-    FinishDispatch<T, U, U - 1, SRC, ACC>::run(acc, src, cur, i - U, i, rem, x);
+    FinishDispatch<T, U, U - 1, SRC, ACC, XV>::run(acc, src, cur, i - U, i, rem, x);
 }
 
 // diagonal element D[row][row] held by this lane (valid only on the 16 "diagonal lanes")
@@ -348,12 +364,13 @@ __device__ __forceinline__ bool diag_of(const f32x4 &acc, int lane, float &d)
 }
 
 // ---- medium: one wave = one block of 16 sorted rows (reference: dasp_f64.h:145-279)
-template <class T, bool NT, bool NATURAL>
-__device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane)
+// YM: where the 16 results go -- 0 the block's own slots (reference permutation), 1 order[slot] (natural),
+// 2 med_dst[position] (windowed mode)
+template <class T, bool NT, int YM, class XV>
+__device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, const XV &x)
 {
     using acc_t = typename Tr<T>::acc_t;
     constexpr int CH = Tr<T>::CHUNK;
-    const T *x = static_cast<const T *>(a.x);
     const T *val = static_cast<const T *>(a.med_val);
     const int c0 = a.med_ptr[b], c1 = a.med_ptr[b + 1];
     acc_t acc = {0, 0, 0, 0};
@@ -373,7 +390,7 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane)
     typename Tr<T>::part_t d;
     if (diag_of(acc, lane, d) && r < a.row_block) {
         const int slot = a.row_long + r;
-        const int yi = NATURAL ? a.order[slot] : slot;
+        const int yi = YM == 2 ? a.med_dst[r] : (YM == 1 ? a.order[slot] : slot);
         static_cast<T *>(a.y)[yi] = (T)d;
     }
 }
@@ -386,7 +403,7 @@ __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
     using part_t = typename Tr<T>::part_t;
     constexpr int CH = Tr<T>::CHUNK;
     constexpr int VPL = CH / kWave;          // values per lane per MFMA: 1 (f64) / 4 (f16)
-    const T *x = static_cast<const T *>(a.x);
+    const XGlobal<T> x{static_cast<const T *>(a.x)};
     const T *val = static_cast<const T *>(a.long_val);
     const int p0 = a.piece_ptr[p], p1 = a.piece_ptr[p + 1];
     acc_t acc = {0, 0, 0, 0};
@@ -480,9 +497,13 @@ __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
 #ifndef DASP_LB
 #define DASP_LB 1
 #endif
-template <class T, bool NT, bool NATURAL>
+// WIN: windowed mode.  A medium workgroup owns one window of row_window rows (blocks_per_win blocks, strided over its
+// 4 waves); if the window's x span fits, it is copied once into LDS with coalesced 16-byte loads and every gather of
+// the window reads LDS; otherwise that workgroup gathers from global memory like the non-windowed kernel.
+template <class T, bool NT, bool NATURAL, bool WIN>
 __global__ __launch_bounds__(256, DASP_LB) void dasp_spmv_kernel(DevArgs a)
 {
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wg = blockIdx.x;
@@ -490,8 +511,36 @@ __global__ __launch_bounds__(256, DASP_LB) void dasp_spmv_kernel(DevArgs a)
         const int p = wg * kWavesPerWG + wave;
         if (p < a.n_pieces) long_piece<T, NT>(a, p, lane);
     } else if (wg < a.wg_long + a.wg_med) {
-        const int b = (wg - a.wg_long) * kWavesPerWG + wave;
-        if (b < a.n_blocks) medium_block<T, NT, NATURAL>(a, b, lane);
+        if constexpr (!WIN) {
+            const int b = (wg - a.wg_long) * kWavesPerWG + wave;
+            const XGlobal<T> x{static_cast<const T *>(a.x)};
+            if (b < a.n_blocks) medium_block<T, NT, NATURAL ? 1 : 0>(a, b, lane, x);
+        } else {
+            const int w = wg - a.wg_long;
+            const int len = a.win_len[w], cmin = a.win_cmin[w];
+            const T *xg = static_cast<const T *>(a.x);
+            T *xw = reinterpret_cast<T *>(lds_raw);
+            if (len > 0) {
+                constexpr int A = 16 / (int)sizeof(T);
+                const i32x4 *src = reinterpret_cast<const i32x4 *>(xg + cmin);
+                i32x4 *dst = reinterpret_cast<i32x4 *>(xw);
+                const int nvec = len / A;
+                for (int i = threadIdx.x; i < nvec; i += 256) dst[i] = src[i];
+                for (int i = nvec * A + threadIdx.x; i < len; i += 256) xw[i] = xg[cmin + i];
+                __syncthreads();
+                const XLds<T> x{xw, cmin};
+                for (int q = wave; q < a.blocks_per_win; q += kWavesPerWG) {
+                    const int b = w * a.blocks_per_win + q;
+                    if (b < a.n_blocks) medium_block<T, NT, 2>(a, b, lane, x);
+                }
+            } else {
+                const XGlobal<T> x{xg};
+                for (int q = wave; q < a.blocks_per_win; q += kWavesPerWG) {
+                    const int b = w * a.blocks_per_win + q;
+                    if (b < a.n_blocks) medium_block<T, NT, 2>(a, b, lane, x);
+                }
+            }
+        }
     } else {
         const int t = (wg - a.wg_long - a.wg_med) * kWavesPerWG + wave;
         if (t < a.n_short_tiles) short_tile<T, NT, NATURAL>(a, t, lane);
@@ -608,6 +657,9 @@ int upload_plan(Plan &p)
     const size_t o_ip = add(p.irr_ptr.data(), p.irr_ptr.size() * 4);
     const size_t o_iv = add(p.irr_val.data(), p.irr_val.size());
     const size_t o_ic = add(p.irr_cid.data(), p.irr_cid.size() * 4);
+    const size_t o_mdst = add(p.med_dst.data(), p.med_dst.size() * 4);
+    const size_t o_wc = add(p.win_cmin.data(), p.win_cmin.size() * 4);
+    const size_t o_wl = add(p.win_len.data(), p.win_len.size() * 4);
     const size_t o_sv = add(p.short_val.data(), p.short_val.size());
     const size_t o_sc = add(p.short_cid.data(), p.short_cid.size() * 4);
     const size_t o_g = add(groups.data(), groups.size() * sizeof(ShortDev));
@@ -632,7 +684,9 @@ int upload_plan(Plan &p)
     a.n_short_tiles = p.stats.n_short_tiles;
     a.order = natural ? (const int *)(base + o_ord) : nullptr;
     a.wg_long = (a.n_pieces + kWavesPerWG - 1) / kWavesPerWG;
-    a.wg_med = (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG;
+    a.med_dst = (const int *)(base + o_mdst); a.win_cmin = (const int *)(base + o_wc); a.win_len = (const int *)(base + o_wl);
+    a.n_windows = (int)p.win_len.size(); a.blocks_per_win = p.windowed ? p.row_window / kMedRows : 0;
+    a.wg_med = p.windowed ? a.n_windows : (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG;
     a.wg_short = (a.n_short_tiles + kWavesPerWG - 1) / kWavesPerWG;
     // streamed-once matrix data bypasses the caches (the reference's ld.global.cs, dasp_f64.h:34-51)
     // only when it cannot stay resident in the 256 MiB Infinity Cache between two SpMVs anyway.
@@ -646,10 +700,20 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
     const int grid = a.wg_long + a.wg_med + a.wg_short;
     const bool nt = p.dev->nt, natural = p.opt.y_order == DASP_Y_NATURAL;
     if (grid > 0) {
-        if (nt && natural) hipLaunchKernelGGL((dasp_spmv_kernel<T, true, true>), dim3(grid), dim3(256), 0, s, a);
-        else if (nt) hipLaunchKernelGGL((dasp_spmv_kernel<T, true, false>), dim3(grid), dim3(256), 0, s, a);
-        else if (natural) hipLaunchKernelGGL((dasp_spmv_kernel<T, false, true>), dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((dasp_spmv_kernel<T, false, false>), dim3(grid), dim3(256), 0, s, a);
+        const size_t lds = p.windowed ? (size_t)p.lds_bytes : 0;
+#define DASP_LAUNCH(NTV, NATV, WINV) hipLaunchKernelGGL((dasp_spmv_kernel<T, NTV, NATV, WINV>), dim3(grid), dim3(256), lds, s, a)
+        if (p.windowed) {
+            if (nt && natural) DASP_LAUNCH(true, true, true);
+            else if (nt) DASP_LAUNCH(true, false, true);
+            else if (natural) DASP_LAUNCH(false, true, true);
+            else DASP_LAUNCH(false, false, true);
+        } else {
+            if (nt && natural) DASP_LAUNCH(true, true, false);
+            else if (nt) DASP_LAUNCH(true, false, false);
+            else if (natural) DASP_LAUNCH(false, true, false);
+            else DASP_LAUNCH(false, false, false);
+        }
+#undef DASP_LAUNCH
     }
     if (a.n_multi > 0)
         hipLaunchKernelGGL((dasp_long_reduce_kernel<T>), dim3((a.n_multi + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, s, a);

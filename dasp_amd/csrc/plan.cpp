@@ -193,6 +193,72 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
         });
     }
 
+    // ---- optional windowed order for the medium rows (LDS-staged x).  The reference sorts all
+    // medium rows globally by length, which scatters the 16 rows of a block over the matrix; here rows are sorted inside
+    // windows of `row_window` consecutive medium rows only, one window per workgroup, so a workgroup's rows share a narrow
+    // span of x that is staged once in LDS.  Output slots stay the reference's (order_rid untouched): y goes through med_dst.
+    p.windowed = false; p.row_window = 0; p.lds_bytes = 0;
+    p.med_dst.clear(); p.win_cmin.clear(); p.win_len.clear();
+    double window_frac = 0.0;
+    if (p.opt.x_window >= 0 && nmed > 0) {
+        int R = p.opt.row_window > 0 ? p.opt.row_window : 256;
+        R = std::max(64, (R / 64) * 64);
+        const int cap_bytes = p.opt.x_window > 0 ? std::min(p.opt.x_window, 65536) : 65536;
+        const int A = 16 / geo.vbytes;                         // window base aligned for 16-byte copies
+        // medium rows in row order, then a stable descending length sort inside each window
+        std::vector<int> ridW(nmed), lenW(nmed);
+        {
+            std::vector<int> rows(ridM);                       // ridM is length-sorted; recover row order
+            std::sort(rows.begin(), rows.end());
+            const int nW = ceil_div(nmed, R);
+            parallel_for(nW, threads, 8, [&](long long w0, long long w1) {
+                std::vector<int> bucket;
+                for (long long w = w0; w < w1; ++w) {
+                    const int a0 = (int)w * R, a1 = std::min(nmed, a0 + R);
+                    bucket.assign((size_t)block_longest + 1, 0);
+                    for (int i = a0; i < a1; ++i) bucket[rp[rows[i] + 1] - rp[rows[i]]]++;
+                    int run = a0;
+                    for (int L = block_longest; L >= 0; --L) { int c = bucket[L]; bucket[L] = run; run += c; }
+                    for (int i = a0; i < a1; ++i) { const int L = rp[rows[i] + 1] - rp[rows[i]]; const int at = bucket[L]++; ridW[at] = rows[i]; lenW[at] = L; }
+                }
+            });
+        }
+        const int nW = ceil_div(nmed, R);
+        std::vector<int> cmin(nW), wlen(nW);
+        std::vector<long long> wnnz(nW);
+        parallel_for(nW, threads, 8, [&](long long w0, long long w1) {
+            for (long long w = w0; w < w1; ++w) {
+                const int a0 = (int)w * R, a1 = std::min(nmed, a0 + R);
+                int lo = 2147483647, hi = -1; long long k = 0;
+                for (int i = a0; i < a1; ++i) {
+                    const int r = ridW[i];
+                    for (int j = rp[r]; j < rp[r + 1]; ++j) { const int c = remap(ci[j]); lo = std::min(lo, c); hi = std::max(hi, c); }
+                    k += rp[r + 1] - rp[r];
+                }
+                lo = (lo / A) * A;
+                const long long span = (long long)hi - lo + 1;
+                wnnz[w] = k;
+                if (hi >= 0 && span * geo.vbytes <= cap_bytes) { cmin[w] = lo; wlen[w] = (int)span; }
+                else { cmin[w] = 0; wlen[w] = 0; }
+            }
+        });
+        long long fit = 0, all = 0; int maxlen = 0;
+        for (int w = 0; w < nW; ++w) { all += wnnz[w]; if (wlen[w] > 0) { fit += wnnz[w]; maxlen = std::max(maxlen, wlen[w]); } }
+        window_frac = all > 0 ? (double)fit / (double)all : 0.0;
+        const bool force = p.opt.x_window > 0;
+        const bool worth = window_frac >= 0.5 && (double)all >= 0.5 * (double)nnz;
+        if ((force || worth) && fit > 0) {
+            p.windowed = true; p.row_window = R;
+            p.lds_bytes = ((maxlen * geo.vbytes + 255) / 256) * 256;
+            p.win_cmin.swap(cmin); p.win_len.swap(wlen);
+            std::vector<int> slot_of_row((size_t)m, -1);
+            for (int i = 0; i < nmed; ++i) slot_of_row[ridM[i]] = nlong + i;       // reference slot of each medium row
+            p.med_dst.resize(nmed);
+            for (int i = 0; i < nmed; ++i) p.med_dst[i] = natural ? ridW[i] : slot_of_row[ridW[i]];
+            ridM.swap(ridW); lenM.swap(lenW);                                      // the packers below follow the windowed order
+        }
+    }
+
     // ---- medium rows: regular tiles kept while a 16 x K chunk is >= threshold full
     // (the reference's rule, dasp_f64.h:1044-1091, on this geometry's tile), rest = irregular tail
     const int K = geo.med_k, CH = geo.chunk;
@@ -307,7 +373,8 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
     const long long sv = geo.vbytes;
     s.data_X = (long long)(m + p.n) * sv + stored * (sv + 4) +
                (long long)(p.piece_ptr.size() + p.piece_dst.size() + p.multi_ptr.size() + p.multi_dst.size()) * 4 +
-               (long long)(p.med_ptr.size() + p.irr_ptr.size()) * 4 + (natural ? (long long)m * 4 : 0);
+               (long long)(p.med_ptr.size() + p.irr_ptr.size()) * 4 + (natural ? (long long)m * 4 : 0) +
+               (long long)(p.med_dst.size() + 2 * p.win_len.size()) * 4;
     s.data_origin1 = (long long)(nnz + p.n + m) * sv + (long long)nnz * 4 + (long long)(m + 1) * 4;  // main_f64.cu:143
     s.n_med_blocks = nb;
     s.n_long_pieces = (int)p.piece_dst.size();
@@ -315,6 +382,11 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
     s.n_short_tiles = 0;
     for (int g = 0; g < kNumShortGroups; ++g) s.n_short_tiles += p.grp[g].tiles;
     s.n_workgroups = ceil_div(s.n_long_pieces, kWavesPerWG) + ceil_div(nb, kWavesPerWG) + ceil_div(s.n_short_tiles, kWavesPerWG);
+    s.x_window_on = p.windowed ? 1 : 0; s.n_windows = (int)p.win_len.size(); s.row_window = p.row_window; s.lds_bytes = p.lds_bytes;
+    s.n_windows_lds = 0;
+    for (int v : p.win_len) s.n_windows_lds += v > 0;
+    s.window_nnz_frac = window_frac;
+    if (p.windowed) s.n_workgroups = ceil_div(s.n_long_pieces, kWavesPerWG) + s.n_windows + ceil_div(s.n_short_tiles, kWavesPerWG);
     s.pre_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
     return DASP_OK;
 }

@@ -83,6 +83,11 @@ struct Plan {
     std::vector<int> irr_ptr;       // [row_block+1]
     std::vector<char> irr_val;
     std::vector<int> irr_cid;
+    // windowed mode (LDS-staged x): medium positions follow the windowed order; med_dst[pos] = y index,
+    // win_cmin/win_len = the x span of window w (len 0: span too wide, that window gathers from global memory)
+    bool windowed = false;
+    int row_window = 0, lds_bytes = 0;
+    std::vector<int> med_dst, win_cmin, win_len;
 
     // short rows: per length one slab, tile-major [tile][k][short_rows]
     ShortGroup grp[kNumShortGroups];

@@ -92,6 +92,15 @@ typedef struct dasp_options {
     int n_parts;
     const int *part_bounds; /* [n_parts+1] */
     int part_stride;
+    /* LDS-staged x gathers.  Medium rows are blocked inside windows of `row_window` consecutive rows (sorted by
+     * length inside the window only) so that one workgroup's rows share a narrow span of x; that span is copied
+     * once into LDS (coalesced) and every gather of the window is served from LDS.  y still goes to the slots
+     * of the reference permutation (order_rid is unchanged), through a per-row destination table.
+     *   x_window: 0 = auto (on when the windows of >= half of the medium nonzeros fit), -1 = off,
+     *             > 0 = force on with this many bytes of LDS per workgroup as the cap (<= 65536)
+     *   row_window: rows per window / workgroup, multiple of 64; 0 = default (256) */
+    int x_window;
+    int row_window;
 } dasp_options_t;
 
 void dasp_options_default(dasp_options_t *opt);
@@ -110,6 +119,9 @@ typedef struct dasp_stats {
     long long data_origin1;    /* CSR algorithmic bytes, main_f64.cu:143 */
     int n_med_blocks, n_long_pieces, n_long_multi, n_short_tiles, n_workgroups;
     double pre_ms;             /* host preprocessing wall time (dasp_f16.h:1444-1445 "dasp_pre") */
+    /* LDS-staged x windows (0 everywhere when the mode is off) */
+    int x_window_on, n_windows, n_windows_lds, lds_bytes, row_window;
+    double window_nnz_frac;    /* share of the medium nonzeros whose window fits in LDS */
 } dasp_stats_t;
 
 /* classifier + packers on the host (no GPU needed).  CSR arrays are read-only and may be

@@ -190,3 +190,28 @@ def test_cli_drivers(torch_cuda, exe, fixture, tmp_path):
     assert "compute succeed" in r.stdout and "SpMV_X:" in r.stdout
     csv = (tmp_path / "data" / ("spmv_f64_record.csv" if exe == "dasp_f64" else "spmv_f16_record.csv")).read_text()
     assert csv.startswith(os.path.join(ROOT, "tests", "golden", fixture) + ",")
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("kw", [dict(), dict(x_window=8192, row_window=64), dict(x_window=65536, row_window=512), dict(x_window=-1)])
+def test_lds_staged_x_windows(oracle, dasp, torch_cuda, prec, kw):
+    """narrow-band matrix: windows of rows share a span of x that is staged in LDS (auto on); small caps mix LDS and
+    global-gather windows in one launch; results and the output permutation are the same in every mode"""
+    from test_plan_host import banded_matrix
+    rp, ci, v = banded_matrix(6000, 1200, 8)
+    if prec == 16:
+        v = np.abs(v) + 0.5
+    n = 6000
+    st = dasp.Plan(rp, ci, v.astype(np.float64 if prec == 64 else np.float16), n, precision=prec, **kw).stats
+    assert st["x_window_on"] == (0 if kw.get("x_window") == -1 else 1)
+    check(oracle, dasp, torch_cuda, rp, ci, v, n, prec, **kw)
+    # with short / long / empty rows mixed in
+    rp2, ci2, v2 = util.mixed_matrix(3000, 3000, 19, values="f16" if prec == 16 else "uniform")
+    check(oracle, dasp, torch_cuda, rp2, ci2, v2, 3000, prec, x_window=65536)
+
+
+def test_cop20k_standin_uses_windows(dasp, torch_cuda):
+    rows, cols = dasp.synth_dims("cop20k_A", 0.25)
+    rp, ci = dasp.synth_csr("cop20k_A", 0.25)
+    st = dasp.Plan(rp, ci, np.ones(ci.size), cols).stats
+    assert st["x_window_on"] == 1 and st["window_nnz_frac"] > 0.9

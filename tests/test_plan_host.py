@@ -104,3 +104,52 @@ def test_synthetic_generators_are_sliceable_and_seeded(dasp):
         rp, ci = dasp.synth_csr(name, sc)
         A = sp.csr_matrix((np.ones(ci.size), ci, rp), shape=(rows, cols))
         assert (A != A.T).nnz == 0, name
+
+
+def banded_matrix(m, band, seed, mean_len=20):
+    rng = np.random.default_rng(seed)
+    lens = np.clip(rng.normal(mean_len, mean_len * 0.6, m), 0, 4 * mean_len).astype(np.int64)
+    rp = np.zeros(m + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    rows = np.repeat(np.arange(m), lens)
+    ci = np.clip(rows + rng.integers(-band, band + 1, rows.size), 0, m - 1).astype(np.int32)
+    return rp.astype(np.int32), ci, rng.uniform(-1, 1, rows.size)
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("y_order", [0, 1])
+def test_windowed_mode_keeps_reference_slots_and_decodes(dasp, oracle, prec, y_order):
+    dt = np.float64 if prec == 64 else np.float16
+    rp, ci, v = banded_matrix(5000, 1500, 3)
+    v = v.astype(dt)
+    plan = dasp.Plan(rp, ci, v, 5000, precision=prec, y_order=y_order)          # auto: narrow band -> windows on
+    st = plan.stats
+    assert st["x_window_on"] == 1 and st["n_windows_lds"] == st["n_windows"] > 0 and st["lds_bytes"] <= 65536
+    assert st["window_nnz_frac"] == 1.0
+    P = oracle.Packed(prec, rp, ci, v.astype(np.float64), 5000)
+    assert (plan.order_rid == P.order_rid).all()                                  # output permutation unchanged
+    rows = util.decode_plan(plan)
+    order = plan.order_rid
+    assert sorted(rows) == list(range(5000))
+    for slot in range(5000):
+        r = order[slot]
+        assert rows[slot][0] == ci[rp[r]:rp[r + 1]].tolist()
+    # every window's LDS span covers all columns of its rows
+    cmin, wlen = plan.host_array("win_cmin"), plan.host_array("win_len")
+    dst = plan.host_array("med_dst")
+    R = st["row_window"]
+    for w in range(st["n_windows"]):
+        for pos in range(w * R, min((w + 1) * R, st["row_block"])):
+            r = dst[pos] if y_order == 1 else order[dst[pos]]
+            cols = ci[rp[r]:rp[r + 1]]
+            assert cols.min() >= cmin[w] and cols.max() < cmin[w] + wlen[w]
+
+
+def test_windowed_mode_auto_off_and_forced(dasp):
+    rp, ci, v = util.mixed_matrix(3000, 2_000_000, 7)          # columns all over a wide matrix: windows do not fit
+    assert dasp.Plan(rp, ci, v, 2_000_000).stats["x_window_on"] == 0
+    assert dasp.Plan(rp, ci, v, 2_000_000, x_window=-1).stats["x_window_on"] == 0
+    rp, ci, v = banded_matrix(3000, 200, 5)
+    assert dasp.Plan(rp, ci, v, 3000, x_window=-1).stats["x_window_on"] == 0
+    st = dasp.Plan(rp, ci, v, 3000, x_window=4096, row_window=64).stats            # tiny cap: only some windows fit
+    assert st["x_window_on"] == 1 and st["row_window"] == 64 and st["lds_bytes"] <= 4096

@@ -78,6 +78,10 @@ def decode_plan(plan):
     ip_, iv, ic = plan.host_array("irr_ptr"), plan.host_array("irr_val"), plan.host_array("irr_cid")
     nb = mptr.size - 1
     row_block, row_long = st["row_block"], st["row_long"]
+    # windowed mode: medium position -> y index through med_dst (a slot, or a row id when Y_NATURAL)
+    med_dst = plan.host_array("med_dst") if st.get("x_window_on") else None
+    if med_dst is not None and natural and inv is None:
+        inv = np.argsort(plan.order_rid)
     for b in range(nb):
         nc = mptr[b + 1] - mptr[b]
         blk_c = mc[mptr[b] * CH: mptr[b + 1] * CH].reshape(nc, CH)
@@ -99,7 +103,12 @@ def decode_plan(plan):
                 assert keep[: keep.sum()].all(), "pad before a real entry"
             cs = c[keep].tolist() + ic[ip_[r]:ip_[r + 1]].tolist()
             vs = v[keep].tolist() + iv[ip_[r]:ip_[r + 1]].tolist()
-            out[row_long + r] = (cs, vs)
+            if med_dst is None:
+                slot = row_long + r
+            else:
+                slot = int(inv[med_dst[r]]) if natural else int(med_dst[r])
+            assert slot not in out
+            out[slot] = (cs, vs)
     # short rows
     sg = plan.host_array("short_groups").reshape(5, 13)
     sv, sc = plan.host_array("short_val"), plan.host_array("short_cid")
