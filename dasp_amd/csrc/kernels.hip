@@ -69,6 +69,7 @@ struct DevicePlan {
     size_t arena_bytes = 0;
     DevArgs args{};
     bool nt = false;
+    bool lds_attr_set = false;
     int device = -1;
 };
 
@@ -701,6 +702,14 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
     const bool nt = p.dev->nt, natural = p.opt.y_order == DASP_Y_NATURAL;
     if (grid > 0) {
         const size_t lds = p.windowed ? (size_t)p.lds_bytes : 0;
+        if (lds > 65536 && !p.dev->lds_attr_set) {   // more than the default 64 KiB of dynamic LDS must be requested per kernel
+            const int bytes = (int)lds;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<T, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<T, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<T, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<T, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            p.dev->lds_attr_set = true;
+        }
 #define DASP_LAUNCH(NTV, NATV, WINV) hipLaunchKernelGGL((dasp_spmv_kernel<T, NTV, NATV, WINV>), dim3(grid), dim3(256), lds, s, a)
         if (p.windowed) {
             if (nt && natural) DASP_LAUNCH(true, true, true);

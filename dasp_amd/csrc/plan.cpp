@@ -203,7 +203,8 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
     if (p.opt.x_window >= 0 && nmed > 0) {
         int R = p.opt.row_window > 0 ? p.opt.row_window : 256;
         R = std::max(64, (R / 64) * 64);
-        const int cap_bytes = p.opt.x_window > 0 ? std::min(p.opt.x_window, 65536) : 65536;
+        // default cap: 80 KiB = two workgroups per CU out of gfx950's 160 KiB of LDS
+        const int cap_bytes = p.opt.x_window > 0 ? std::min(p.opt.x_window, 160 * 1024) : 80 * 1024;
         const int A = 16 / geo.vbytes;                         // window base aligned for 16-byte copies
         // medium rows in row order, then a stable descending length sort inside each window
         std::vector<int> ridW(nmed), lenW(nmed);

@@ -97,7 +97,8 @@ typedef struct dasp_options {
      * once into LDS (coalesced) and every gather of the window is served from LDS.  y still goes to the slots
      * of the reference permutation (order_rid is unchanged), through a per-row destination table.
      *   x_window: 0 = auto (on when the windows of >= half of the medium nonzeros fit), -1 = off,
-     *             > 0 = force on with this many bytes of LDS per workgroup as the cap (<= 65536)
+     *             > 0 = force on with this many bytes of LDS per workgroup as the cap (<= 163840; auto uses 81920,
+     *                   i.e. two workgroups per CU)
      *   row_window: rows per window / workgroup, multiple of 64; 0 = default (256) */
     int x_window;
     int row_window;

@@ -193,7 +193,7 @@ def test_cli_drivers(torch_cuda, exe, fixture, tmp_path):
 
 
 @pytest.mark.parametrize("prec", [64, 16])
-@pytest.mark.parametrize("kw", [dict(), dict(x_window=8192, row_window=64), dict(x_window=65536, row_window=512), dict(x_window=-1)])
+@pytest.mark.parametrize("kw", [dict(), dict(x_window=21000, row_window=64), dict(x_window=100000, row_window=512), dict(x_window=-1)])
 def test_lds_staged_x_windows(oracle, dasp, torch_cuda, prec, kw):
     """narrow-band matrix: windows of rows share a span of x that is staged in LDS (auto on); small caps mix LDS and
     global-gather windows in one launch; results and the output permutation are the same in every mode"""
@@ -203,7 +203,10 @@ def test_lds_staged_x_windows(oracle, dasp, torch_cuda, prec, kw):
         v = np.abs(v) + 0.5
     n = 6000
     st = dasp.Plan(rp, ci, v.astype(np.float64 if prec == 64 else np.float16), n, precision=prec, **kw).stats
-    assert st["x_window_on"] == (0 if kw.get("x_window") == -1 else 1)
+    if not kw:
+        assert st["x_window_on"] == 1 and st["n_windows_lds"] == st["n_windows"]
+    if kw.get("x_window") == -1:
+        assert st["x_window_on"] == 0
     check(oracle, dasp, torch_cuda, rp, ci, v, n, prec, **kw)
     # with short / long / empty rows mixed in
     rp2, ci2, v2 = util.mixed_matrix(3000, 3000, 19, values="f16" if prec == 16 else "uniform")
