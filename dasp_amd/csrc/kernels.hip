@@ -55,6 +55,7 @@ struct DevArgs {
     // windowed mode (LDS-staged x)
     const int *med_dst; const int *win_cmin; const int *win_len;
     int n_windows, blocks_per_win;
+    int wpw;   // waves per workgroup of this launch (4, or blocks_per_win in windowed mode)
     // short
     const void *short_val; const int *short_cid; const ShortDev *groups;
     int n_short_tiles;
@@ -498,18 +499,22 @@ __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
 #ifndef DASP_LB
 #define DASP_LB 1
 #endif
+#ifndef DASP_LB_WIN
+#define DASP_LB_WIN 8   // 64 registers: two 1024-thread window workgroups per CU (A/B: 12.9 vs 15.0 us on cop20k_A)
+#endif
 // WIN: windowed mode.  A medium workgroup owns one window of row_window rows (blocks_per_win blocks, strided over its
 // 4 waves); if the window's x span fits, it is copied once into LDS with coalesced 16-byte loads and every gather of
 // the window reads LDS; otherwise that workgroup gathers from global memory like the non-windowed kernel.
 template <class T, bool NT, bool NATURAL, bool WIN>
-__global__ __launch_bounds__(256, DASP_LB) void dasp_spmv_kernel(DevArgs a)
+__global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? DASP_LB_WIN : DASP_LB) void dasp_spmv_kernel(DevArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wg = blockIdx.x;
+    const int wpw = WIN ? a.wpw : kWavesPerWG;
     if (wg < a.wg_long) {
-        const int p = wg * kWavesPerWG + wave;
+        const int p = wg * wpw + wave;
         if (p < a.n_pieces) long_piece<T, NT>(a, p, lane);
     } else if (wg < a.wg_long + a.wg_med) {
         if constexpr (!WIN) {
@@ -517,6 +522,7 @@ __global__ __launch_bounds__(256, DASP_LB) void dasp_spmv_kernel(DevArgs a)
             const XGlobal<T> x{static_cast<const T *>(a.x)};
             if (b < a.n_blocks) medium_block<T, NT, NATURAL ? 1 : 0>(a, b, lane, x);
         } else {
+            // one window per workgroup; its blocks_per_win blocks are dealt round-robin to the wpw waves
             const int w = wg - a.wg_long;
             const int len = a.win_len[w], cmin = a.win_cmin[w];
             const T *xg = static_cast<const T *>(a.x);
@@ -525,25 +531,33 @@ __global__ __launch_bounds__(256, DASP_LB) void dasp_spmv_kernel(DevArgs a)
                 constexpr int A = 16 / (int)sizeof(T);
                 const i32x4 *src = reinterpret_cast<const i32x4 *>(xg + cmin);
                 i32x4 *dst = reinterpret_cast<i32x4 *>(xw);
-                const int nvec = len / A;
-                for (int i = threadIdx.x; i < nvec; i += 256) dst[i] = src[i];
-                for (int i = nvec * A + threadIdx.x; i < len; i += 256) xw[i] = xg[cmin + i];
+                const int nvec = len / A, nth = wpw * kWave;
+                for (int i0 = threadIdx.x; i0 < nvec; i0 += 4 * nth) {       // four 16-byte loads in flight per lane
+                    const int i1 = i0 + nth, i2 = i0 + 2 * nth, i3 = i0 + 3 * nth;
+                    const i32x4 v0 = src[i0];
+                    const i32x4 v1 = src[i1 < nvec ? i1 : i0], v2 = src[i2 < nvec ? i2 : i0], v3 = src[i3 < nvec ? i3 : i0];
+                    dst[i0] = v0;
+                    if (i1 < nvec) dst[i1] = v1;
+                    if (i2 < nvec) dst[i2] = v2;
+                    if (i3 < nvec) dst[i3] = v3;
+                }
+                for (int i = nvec * A + threadIdx.x; i < len; i += nth) xw[i] = xg[cmin + i];
                 __syncthreads();
                 const XLds<T> x{xw, cmin};
-                for (int q = wave; q < a.blocks_per_win; q += kWavesPerWG) {
+                for (int q = wave; q < a.blocks_per_win; q += wpw) {
                     const int b = w * a.blocks_per_win + q;
                     if (b < a.n_blocks) medium_block<T, NT, 2>(a, b, lane, x);
                 }
             } else {
                 const XGlobal<T> x{xg};
-                for (int q = wave; q < a.blocks_per_win; q += kWavesPerWG) {
+                for (int q = wave; q < a.blocks_per_win; q += wpw) {
                     const int b = w * a.blocks_per_win + q;
                     if (b < a.n_blocks) medium_block<T, NT, 2>(a, b, lane, x);
                 }
             }
         }
     } else {
-        const int t = (wg - a.wg_long - a.wg_med) * kWavesPerWG + wave;
+        const int t = (wg - a.wg_long - a.wg_med) * wpw + wave;
         if (t < a.n_short_tiles) short_tile<T, NT, NATURAL>(a, t, lane);
     }
 }
@@ -684,11 +698,12 @@ int upload_plan(Plan &p)
     a.short_val = base + o_sv; a.short_cid = (const int *)(base + o_sc); a.groups = (const ShortDev *)(base + o_g);
     a.n_short_tiles = p.stats.n_short_tiles;
     a.order = natural ? (const int *)(base + o_ord) : nullptr;
-    a.wg_long = (a.n_pieces + kWavesPerWG - 1) / kWavesPerWG;
+    a.wpw = p.windowed ? std::min(16, p.row_window / kMedRows) : kWavesPerWG;
+    a.wg_long = (a.n_pieces + a.wpw - 1) / a.wpw;
     a.med_dst = (const int *)(base + o_mdst); a.win_cmin = (const int *)(base + o_wc); a.win_len = (const int *)(base + o_wl);
     a.n_windows = (int)p.win_len.size(); a.blocks_per_win = p.windowed ? p.row_window / kMedRows : 0;
     a.wg_med = p.windowed ? a.n_windows : (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG;
-    a.wg_short = (a.n_short_tiles + kWavesPerWG - 1) / kWavesPerWG;
+    a.wg_short = (a.n_short_tiles + a.wpw - 1) / a.wpw;
     // streamed-once matrix data bypasses the caches (the reference's ld.global.cs, dasp_f64.h:34-51)
     // only when it cannot stay resident in the 256 MiB Infinity Cache between two SpMVs anyway.
     d->nt = p.stats.data_X > (200ll << 20);
@@ -710,7 +725,7 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<T, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             p.dev->lds_attr_set = true;
         }
-#define DASP_LAUNCH(NTV, NATV, WINV) hipLaunchKernelGGL((dasp_spmv_kernel<T, NTV, NATV, WINV>), dim3(grid), dim3(256), lds, s, a)
+#define DASP_LAUNCH(NTV, NATV, WINV) hipLaunchKernelGGL((dasp_spmv_kernel<T, NTV, NATV, WINV>), dim3(grid), dim3(kWave * a.wpw), lds, s, a)
         if (p.windowed) {
             if (nt && natural) DASP_LAUNCH(true, true, true);
             else if (nt) DASP_LAUNCH(true, false, true);

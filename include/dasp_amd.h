@@ -99,7 +99,8 @@ typedef struct dasp_options {
      *   x_window: 0 = auto (on when the windows of >= half of the medium nonzeros fit), -1 = off,
      *             > 0 = force on with this many bytes of LDS per workgroup as the cap (<= 163840; auto uses 81920,
      *                   i.e. two workgroups per CU)
-     *   row_window: rows per window / workgroup, multiple of 64; 0 = default (256) */
+     *   row_window: rows per window, multiple of 64 up to 1024 (16 rows per block, up to 16 waves per workgroup);
+     *               0 = by size (256 / 512 / 1024 for < 50 k / < 400 k / more medium rows) */
     int x_window;
     int row_window;
 } dasp_options_t;

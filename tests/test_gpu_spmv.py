@@ -193,7 +193,7 @@ def test_cli_drivers(torch_cuda, exe, fixture, tmp_path):
 
 
 @pytest.mark.parametrize("prec", [64, 16])
-@pytest.mark.parametrize("kw", [dict(), dict(x_window=21000, row_window=64), dict(x_window=100000, row_window=512), dict(x_window=-1)])
+@pytest.mark.parametrize("kw", [dict(), dict(x_window=21000, row_window=64), dict(x_window=100000, row_window=128), dict(row_window=512), dict(row_window=1024), dict(x_window=-1)])
 def test_lds_staged_x_windows(oracle, dasp, torch_cuda, prec, kw):
     """narrow-band matrix: windows of rows share a span of x that is staged in LDS (auto on); small caps mix LDS and
     global-gather windows in one launch; results and the output permutation are the same in every mode"""
