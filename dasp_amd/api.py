@@ -85,7 +85,7 @@ class Plan:
     """DASP plan: classifier + packers on the host, kernels on the current HIP device."""
 
     def __init__(self, csrRowPtr, csrColIdx, csrVal, colA, precision=64, threshold=0.75, block_longest=256,
-                 y_order=Y_PERMUTED, long_piece=0, host_threads=0, part_bounds=None, part_stride=0, x_window=0, row_window=0):
+                 y_order=Y_PERMUTED, long_piece=0, host_threads=0, part_bounds=None, part_stride=0, x_window=0, row_window=0, cid16=0):
         L = _lib.lib()
         self.precision = precision
         dt = _dtype(precision)
@@ -97,7 +97,7 @@ class Plan:
         L.dasp_options_default(C.byref(opt))
         opt.threshold, opt.block_longest, opt.y_order = threshold, block_longest, y_order
         opt.long_piece, opt.host_threads = long_piece, host_threads
-        opt.x_window, opt.row_window = x_window, row_window
+        opt.x_window, opt.row_window, opt.cid16 = x_window, row_window, cid16
         self._pb = None
         if part_bounds is not None:
             self._pb = np.ascontiguousarray(part_bounds, np.int32)
@@ -128,7 +128,9 @@ class Plan:
         n = _lib.lib().dasp_plan_host_array(self._h, name.encode(), C.byref(ptr), C.byref(eb))
         if n < 0:
             _lib.check(int(n))
-        if eb.value == 4:
+        if name == "med_cid16":
+            dt = np.uint16
+        elif eb.value == 4:
             dt = np.int32
         else:
             dt = np.float64 if eb.value == 8 else np.float16

@@ -138,6 +138,8 @@ long long dasp_plan_host_array(const dasp_plan_t *plan, const char *name, const 
     if (n == "irr_ptr") return ints(p.irr_ptr);
     if (n == "irr_val") return vals(p.irr_val);
     if (n == "irr_cid") return ints(p.irr_cid);
+    if (n == "med_cid16") { *ptr = p.med_cid16.data(); *elem_bytes = 2; return (long long)p.med_cid16.size(); }
+    if (n == "med_base") return ints(p.med_base);
     if (n == "med_dst") return ints(p.med_dst);
     if (n == "win_cmin") return ints(p.win_cmin);
     if (n == "win_len") return ints(p.win_len);
@@ -171,7 +173,7 @@ int dasp_plan_drop_host(dasp_plan_t *plan)
     if (!p.dev) { set_error("upload the plan before dropping its host arrays"); return DASP_ERR_STATE; }
     auto dropc = [](std::vector<char> &v) { std::vector<char>().swap(v); };
     auto dropi = [](std::vector<int> &v) { std::vector<int>().swap(v); };
-    dropc(p.long_val); dropi(p.long_cid); dropc(p.med_val); dropi(p.med_cid);
+    dropc(p.long_val); dropi(p.long_cid); dropc(p.med_val); dropi(p.med_cid); std::vector<uint16_t>().swap(p.med_cid16);
     dropc(p.irr_val); dropi(p.irr_cid); dropc(p.short_val); dropi(p.short_cid);
     p.host_dropped = true;
     return DASP_OK;

@@ -1,6 +1,6 @@
 // cli_bench.cpp -- torch-free driver of the C ABI for profiling (rocprofv3 -- dasp_bench ...):
 // builds the synthetic stand-in, runs the reference's timing protocol, prints one result line.
-//   dasp_bench <workload> [scale=1] [precision=64] [iters=200] [warmup=20] [threshold=0.75] [long_piece=0] [x_window=0] [row_window=0]
+//   dasp_bench <workload> [scale=1] [precision=64] [iters=200] [warmup=20] [threshold=0.75] [long_piece=0] [x_window=0] [row_window=0] [cid16=0]
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
@@ -25,6 +25,7 @@ int main(int argc, char **argv)
     const int long_piece = argc > 7 ? std::atoi(argv[7]) : 0;
     const int x_window = argc > 8 ? std::atoi(argv[8]) : 0;
     const int row_window = argc > 9 ? std::atoi(argv[9]) : 0;
+    const int cid16 = argc > 10 ? std::atoi(argv[10]) : 0;
     int rows, cols;
     CHECK(dasp_synth_dims(name, scale, &rows, &cols));
     std::vector<int> rp((size_t)rows + 1, 0);
@@ -40,7 +41,7 @@ int main(int argc, char **argv)
     else for (int i = 0; i < nnz; ++i) reinterpret_cast<uint16_t *>(val.data())[i] = 0x3C00;
     dasp_options_t opt;
     dasp_options_default(&opt);
-    opt.threshold = threshold; opt.long_piece = long_piece; opt.x_window = x_window; opt.row_window = row_window;
+    opt.threshold = threshold; opt.long_piece = long_piece; opt.x_window = x_window; opt.row_window = row_window; opt.cid16 = cid16;
     dasp_plan_t *plan = nullptr;
     CHECK(dasp_plan_create(&plan, prec, rows, cols, nnz, rp.data(), ci.data(), val.data(), &opt));
     CHECK(dasp_plan_upload(plan));
@@ -64,8 +65,8 @@ int main(int argc, char **argv)
     dasp_stats_t s;
     dasp_plan_stats(plan, &s);
     const double balg = (double)s.data_origin1;
-    std::printf("%s scale=%g f%d rows=%d nnz=%d long=%d med=%d fill0=%.4f pre=%.1fms win=%d/%d lds=%dB | %.4f ms (event %.4f) %.1f GFLOP/s %.1f GB/s alg = %.3f of 8 TB/s | graph: %.4f ms %.3f | mismatches=%lld\n",
-                name, scale, prec, rows, nnz, s.row_long, s.row_block, s.rate_fill0, s.pre_ms, s.n_windows_lds, s.n_windows, s.lds_bytes, wall, ev, 2.0 * nnz / (wall * 1e6),
+    std::printf("%s scale=%g f%d rows=%d nnz=%d long=%d med=%d fill0=%.4f pre=%.1fms win=%d/%d lds=%dB c16=%d | %.4f ms (event %.4f) %.1f GFLOP/s %.1f GB/s alg = %.3f of 8 TB/s | graph: %.4f ms %.3f | mismatches=%lld\n",
+                name, scale, prec, rows, nnz, s.row_long, s.row_block, s.rate_fill0, s.pre_ms, s.n_windows_lds, s.n_windows, s.lds_bytes, s.cid16_on, wall, ev, 2.0 * nnz / (wall * 1e6),
                 balg / (ev * 1e6), balg / (ev * 1e6) / 8000.0, gev, balg / (gev * 1e6) / 8000.0, bad);
     (void)hipFree(dX); (void)hipFree(dY);
     dasp_plan_destroy(plan);

@@ -34,6 +34,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
 struct ShortDev {
     int len, count, tiles, tile0;
@@ -50,6 +51,7 @@ struct DevArgs {
     int n_pieces, n_multi;
     // medium
     const int *med_ptr; const void *med_val; const int *med_cid;
+    const unsigned short *med_cid16; const int *med_base;   // cid16 mode: u16 offsets + per-chunk base column
     const int *irr_ptr; const void *irr_val; const int *irr_cid;
     int n_blocks, row_block, row_long;
     // windowed mode (LDS-staged x)
@@ -234,13 +236,29 @@ struct ChunkSrc {
 // a medium block: nc lane-linear chunks, then the irregular tail as extra steps in which lane (row = l&15, kq = l>>4)
 // takes the next entries of its own row.  Out-of-range lanes read element 0 of the tail arrays (never empty: the
 // arena pads them) and are zeroed in gather(), so neither stage has a divergent branch.
-template <class T, bool NT>
+template <class T, bool NT, bool C16>
 struct BlockSrc {
     ChunkSrc<T, NT> reg; int nc;
+    const unsigned short *cid16; const int *base; int c0;      // C16: ids of the regular chunks as u16 offsets from base[chunk]
     const T *ival; const int *icid; int t0, t1, kq;
     __device__ __forceinline__ void load(Frag<T> &f, int i) const
     {
-        if (i < nc) { reg.load(f, i); return; }
+        if (i < nc) {
+            if constexpr (!C16) reg.load(f, i);
+            else {
+                constexpr int CH = Tr<T>::CHUNK;
+                const size_t at = reg.e0 + (size_t)i * CH + (size_t)(CH / kWave) * reg.lane;
+                if constexpr (sizeof(T) == 8) {
+                    f.a = ldg<NT>(reg.val + at);
+                    f.c = (int)ldg<NT>(cid16 + at);             // raw offset; rebased in gather()
+                } else {
+                    f.a = ldg<NT>(reinterpret_cast<const f16x4 *>(reg.val + at));
+                    const u16x4 o = ldg<NT>(reinterpret_cast<const u16x4 *>(cid16 + at));
+                    f.c[0] = o[0]; f.c[1] = o[1]; f.c[2] = o[2]; f.c[3] = o[3];
+                }
+            }
+            return;
+        }
         const int j = i - nc;
         if constexpr (sizeof(T) == 8) {
             const int e = t0 + 4 * j + kq;
@@ -272,6 +290,13 @@ struct BlockSrc {
                     f.a[q] = ok ? f.a[q] : (_Float16)0;
                     f.c[q] = ok ? f.c[q] : -1;
                 }
+            }
+        } else if constexpr (C16) {
+            const int b = base[c0 + i];                         // wave-uniform: one scalar load per chunk
+            if constexpr (sizeof(T) == 8) f.c = f.c == 0xFFFF ? -1 : b + f.c;
+            else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f.c[q] = f.c[q] == 0xFFFF ? -1 : b + f.c[q];
             }
         }
         frag_gather(f, x);
@@ -366,9 +391,9 @@ __device__ __forceinline__ bool diag_of(const f32x4 &acc, int lane, float &d)
 }
 
 // ---- medium: one wave = one block of 16 sorted rows (reference: dasp_f64.h:145-279)
-// YM: where the 16 results go -- 0 the block's own slots (reference permutation), 1 order[slot] (natural),
-// 2 med_dst[position] (windowed mode)
-template <class T, bool NT, int YM, class XV>
+// YM: where the 16 results go -- 0: the block's own slots (reference permutation), or order[slot] when the plan is
+// DASP_Y_NATURAL (a.order set); 2: med_dst[position] (windowed mode)
+template <class T, bool NT, bool C16, int YM, class XV>
 __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, const XV &x)
 {
     using acc_t = typename Tr<T>::acc_t;
@@ -383,16 +408,16 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     if (r < a.row_block) { t0 = a.irr_ptr[r]; t1 = a.irr_ptr[r + 1]; }
     constexpr int TK = sizeof(T) == 8 ? 4 : 16;                      // tail entries of one row per MFMA step
     const int nt = (__builtin_amdgcn_readfirstlane(t1 - t0) + TK - 1) / TK;
-    BlockSrc<T, NT> src;
+    BlockSrc<T, NT, C16> src;
     src.reg.val = val; src.reg.cid = a.med_cid; src.reg.e0 = (size_t)c0 * CH; src.reg.lane = lane;
-    src.nc = c1 - c0;
+    src.nc = c1 - c0; src.cid16 = a.med_cid16; src.base = a.med_base; src.c0 = c0;
     src.ival = static_cast<const T *>(a.irr_val); src.icid = a.irr_cid; src.t0 = t0; src.t1 = t1; src.kq = kq;
     run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, src.nc + nt, x);
 
     typename Tr<T>::part_t d;
     if (diag_of(acc, lane, d) && r < a.row_block) {
         const int slot = a.row_long + r;
-        const int yi = YM == 2 ? a.med_dst[r] : (YM == 1 ? a.order[slot] : slot);
+        const int yi = YM == 2 ? a.med_dst[r] : (a.order ? a.order[slot] : slot);
         static_cast<T *>(a.y)[yi] = (T)d;
     }
 }
@@ -437,7 +462,7 @@ __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
 }
 
 // ---- short: one wave = one tile of SHORT_ROWS rows of equal length L; lane owns V consecutive rows
-template <class T, int L, bool NT, bool NATURAL>
+template <class T, int L, bool NT>
 __device__ __forceinline__ void short_rows(const DevArgs &a, const ShortDev &g, int local_tile, int lane)
 {
     constexpr int SR = Tr<T>::SHORT_ROWS;
@@ -473,13 +498,13 @@ __device__ __forceinline__ void short_rows(const DevArgs &a, const ShortDev &g, 
         const int t = t0 + v;
         if (t < g.count) {
             const int slot = slot_of(g.map, t);
-            const int yi = NATURAL ? a.order[slot] : slot;
+            const int yi = a.order ? a.order[slot] : slot;
             static_cast<T *>(a.y)[yi] = (T)s[v];
         }
     }
 }
 
-template <class T, bool NT, bool NATURAL>
+template <class T, bool NT>
 __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
 {
     int gi = 0;
@@ -488,11 +513,11 @@ __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
     const ShortDev g = a.groups[gi];
     const int local = tile - g.tile0;
     switch (g.len) {
-        case 1: short_rows<T, 1, NT, NATURAL>(a, g, local, lane); break;
-        case 2: short_rows<T, 2, NT, NATURAL>(a, g, local, lane); break;
-        case 3: short_rows<T, 3, NT, NATURAL>(a, g, local, lane); break;
-        case 4: short_rows<T, 4, NT, NATURAL>(a, g, local, lane); break;
-        default: short_rows<T, 0, NT, NATURAL>(a, g, local, lane); break;   // empty rows: y = 0
+        case 1: short_rows<T, 1, NT>(a, g, local, lane); break;
+        case 2: short_rows<T, 2, NT>(a, g, local, lane); break;
+        case 3: short_rows<T, 3, NT>(a, g, local, lane); break;
+        case 4: short_rows<T, 4, NT>(a, g, local, lane); break;
+        default: short_rows<T, 0, NT>(a, g, local, lane); break;   // empty rows: y = 0
     }
 }
 
@@ -505,7 +530,7 @@ __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
 // WIN: windowed mode.  A medium workgroup owns one window of row_window rows (blocks_per_win blocks, strided over its
 // 4 waves); if the window's x span fits, it is copied once into LDS with coalesced 16-byte loads and every gather of
 // the window reads LDS; otherwise that workgroup gathers from global memory like the non-windowed kernel.
-template <class T, bool NT, bool NATURAL, bool WIN>
+template <class T, bool NT, bool C16, bool WIN>
 __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? DASP_LB_WIN : DASP_LB) void dasp_spmv_kernel(DevArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -520,7 +545,7 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? DASP_LB_WIN : DASP_LB) void
         if constexpr (!WIN) {
             const int b = (wg - a.wg_long) * kWavesPerWG + wave;
             const XGlobal<T> x{static_cast<const T *>(a.x)};
-            if (b < a.n_blocks) medium_block<T, NT, NATURAL ? 1 : 0>(a, b, lane, x);
+            if (b < a.n_blocks) medium_block<T, NT, C16, 0>(a, b, lane, x);
         } else {
             // one window per workgroup; its blocks_per_win blocks are dealt round-robin to the wpw waves
             const int w = wg - a.wg_long;
@@ -546,19 +571,19 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? DASP_LB_WIN : DASP_LB) void
                 const XLds<T> x{xw, cmin};
                 for (int q = wave; q < a.blocks_per_win; q += wpw) {
                     const int b = w * a.blocks_per_win + q;
-                    if (b < a.n_blocks) medium_block<T, NT, 2>(a, b, lane, x);
+                    if (b < a.n_blocks) medium_block<T, NT, C16, 2>(a, b, lane, x);
                 }
             } else {
                 const XGlobal<T> x{xg};
                 for (int q = wave; q < a.blocks_per_win; q += wpw) {
                     const int b = w * a.blocks_per_win + q;
-                    if (b < a.n_blocks) medium_block<T, NT, 2>(a, b, lane, x);
+                    if (b < a.n_blocks) medium_block<T, NT, C16, 2>(a, b, lane, x);
                 }
             }
         }
     } else {
         const int t = (wg - a.wg_long - a.wg_med) * wpw + wave;
-        if (t < a.n_short_tiles) short_tile<T, NT, NATURAL>(a, t, lane);
+        if (t < a.n_short_tiles) short_tile<T, NT>(a, t, lane);
     }
 }
 
@@ -669,6 +694,8 @@ int upload_plan(Plan &p)
     const size_t o_mptr = add(p.med_ptr.data(), p.med_ptr.size() * 4);
     const size_t o_mv = add(p.med_val.data(), p.med_val.size());
     const size_t o_mc = add(p.med_cid.data(), p.med_cid.size() * 4);
+    const size_t o_mc16 = add(p.med_cid16.data(), p.med_cid16.size() * 2);
+    const size_t o_mb = add(p.med_base.data(), p.med_base.size() * 4);
     const size_t o_ip = add(p.irr_ptr.data(), p.irr_ptr.size() * 4);
     const size_t o_iv = add(p.irr_val.data(), p.irr_val.size());
     const size_t o_ic = add(p.irr_cid.data(), p.irr_cid.size() * 4);
@@ -700,6 +727,7 @@ int upload_plan(Plan &p)
     a.order = natural ? (const int *)(base + o_ord) : nullptr;
     a.wpw = p.windowed ? std::min(16, p.row_window / kMedRows) : kWavesPerWG;
     a.wg_long = (a.n_pieces + a.wpw - 1) / a.wpw;
+    a.med_cid16 = (const unsigned short *)(base + o_mc16); a.med_base = (const int *)(base + o_mb);
     a.med_dst = (const int *)(base + o_mdst); a.win_cmin = (const int *)(base + o_wc); a.win_len = (const int *)(base + o_wl);
     a.n_windows = (int)p.win_len.size(); a.blocks_per_win = p.windowed ? p.row_window / kMedRows : 0;
     a.wg_med = p.windowed ? a.n_windows : (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG;
@@ -714,30 +742,25 @@ template <class T>
 static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
 {
     const int grid = a.wg_long + a.wg_med + a.wg_short;
-    const bool nt = p.dev->nt, natural = p.opt.y_order == DASP_Y_NATURAL;
+    const bool nt = p.dev->nt;
     if (grid > 0) {
         const size_t lds = p.windowed ? (size_t)p.lds_bytes : 0;
+        const bool c16 = p.cid16;
+#define DASP_FOR_EACH(M) \
+        if (nt && c16 && p.windowed) { M(true, true, true); } else if (nt && c16) { M(true, true, false); } \
+        else if (nt && p.windowed) { M(true, false, true); } else if (nt) { M(true, false, false); } \
+        else if (c16 && p.windowed) { M(false, true, true); } else if (c16) { M(false, true, false); } \
+        else if (p.windowed) { M(false, false, true); } else { M(false, false, false); }
         if (lds > 65536 && !p.dev->lds_attr_set) {   // more than the default 64 KiB of dynamic LDS must be requested per kernel
-            const int bytes = (int)lds;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<T, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<T, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<T, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<T, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+#define DASP_ATTR(NTV, CV, WINV) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<T, NTV, CV, WINV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+            DASP_FOR_EACH(DASP_ATTR)
+#undef DASP_ATTR
             p.dev->lds_attr_set = true;
         }
-#define DASP_LAUNCH(NTV, NATV, WINV) hipLaunchKernelGGL((dasp_spmv_kernel<T, NTV, NATV, WINV>), dim3(grid), dim3(kWave * a.wpw), lds, s, a)
-        if (p.windowed) {
-            if (nt && natural) DASP_LAUNCH(true, true, true);
-            else if (nt) DASP_LAUNCH(true, false, true);
-            else if (natural) DASP_LAUNCH(false, true, true);
-            else DASP_LAUNCH(false, false, true);
-        } else {
-            if (nt && natural) DASP_LAUNCH(true, true, false);
-            else if (nt) DASP_LAUNCH(true, false, false);
-            else if (natural) DASP_LAUNCH(false, true, false);
-            else DASP_LAUNCH(false, false, false);
-        }
+#define DASP_LAUNCH(NTV, CV, WINV) hipLaunchKernelGGL((dasp_spmv_kernel<T, NTV, CV, WINV>), dim3(grid), dim3(kWave * a.wpw), lds, s, a)
+        DASP_FOR_EACH(DASP_LAUNCH)
 #undef DASP_LAUNCH
+#undef DASP_FOR_EACH
     }
     if (a.n_multi > 0)
         hipLaunchKernelGGL((dasp_long_reduce_kernel<T>), dim3((a.n_multi + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, s, a);

@@ -268,6 +268,12 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
     const int nb = ceil_div(nmed, kMedRows);
     std::vector<int> nchunks((size_t)nb + 1, 0);
     p.irr_ptr.assign((size_t)nmed + 1, 0);
+    // 16-bit column ids: a chunk's ids are stored as u16 offsets from the chunk's smallest column (one int32 base per
+    // chunk), 10 instead of 12 bytes per f64 nonzero (4 instead of 6 for f16).  A chunk whose columns span more than
+    // 65534 cannot be stored that way; in cid16 mode the regular part of its block ends there and the rest of those rows
+    // joins the irregular tail (32-bit ids).  opt.cid16: 0 = auto (on when that costs < 3 % of the regular elements).
+    std::vector<int> nchunks16((size_t)nb + 1, 0);
+    const bool try16 = p.opt.cid16 >= 0;
     parallel_for(nb, threads, 256, [&](long long b0, long long b1) {
         for (long long b = b0; b < b1; ++b) {
             const int r0 = (int)b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
@@ -278,9 +284,30 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
                 if (!(fill >= threshold * CH) || fill == 0) break;
             }
             nchunks[b] = k;
-            for (int r = r0; r < r1; ++r) p.irr_ptr[r] = std::max(0, lenM[r] - K * k);
+            int k16 = k;
+            if (try16) {
+                for (int c = 0; c < k; ++c) {
+                    int lo = 2147483647, hi = -1;
+                    for (int r = r0; r < r1; ++r) {
+                        const int a0 = rp[ridM[r]], i0 = c * K, i1 = std::min(lenM[r], i0 + K);
+                        for (int i = i0; i < i1; ++i) { const int col = remap(ci[a0 + i]); lo = std::min(lo, col); hi = std::max(hi, col); }
+                    }
+                    if (hi >= 0 && (long long)hi - lo > 65534) { k16 = c; break; }
+                }
+            }
+            nchunks16[b] = k16;
         }
     });
+    {
+        long long e32 = 0, e16 = 0;
+        for (int b = 0; b < nb; ++b) { e32 += nchunks[b]; e16 += nchunks16[b]; }
+        p.cid16 = try16 && e32 > 0 && (p.opt.cid16 > 0 || (double)e16 >= 0.97 * (double)e32);
+        if (p.cid16) nchunks.swap(nchunks16);
+    }
+    for (int b = 0; b < nb; ++b) {
+        const int r0 = b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
+        for (int r = r0; r < r1; ++r) p.irr_ptr[r] = std::max(0, lenM[r] - K * nchunks[b]);
+    }
     p.med_ptr.assign((size_t)nb + 1, 0);
     {
         long long run = 0;
@@ -294,7 +321,9 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
     const long long n_reg = (long long)p.med_ptr[nb] * CH;
     const int nnz_irreg = p.irr_ptr[nmed];
     p.med_val.assign((size_t)n_reg * sizeof(T), 0);
-    p.med_cid.assign((size_t)n_reg, -1);
+    p.med_cid.assign(p.cid16 ? 0 : (size_t)n_reg, -1);
+    p.med_cid16.assign(p.cid16 ? (size_t)n_reg : 0, (uint16_t)0xFFFF);
+    p.med_base.assign(p.cid16 ? (size_t)p.med_ptr[nb] : 0, 0);
     p.irr_val.assign((size_t)nnz_irreg * sizeof(T), 0);
     p.irr_cid.assign((size_t)nnz_irreg, -1);
     {
@@ -305,6 +334,15 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
                 const int nc = p.med_ptr[b + 1] - p.med_ptr[b];
                 const size_t base = (size_t)p.med_ptr[b] * CH;
                 const int r0 = (int)b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
+                if (p.cid16)   // per-chunk base = smallest column of the chunk
+                    for (int c = 0; c < nc; ++c) {
+                        int lo = 2147483647;
+                        for (int r = r0; r < r1; ++r) {
+                            const int a0 = rp[ridM[r]], i0 = c * K, i1 = std::min(lenM[r], i0 + K);
+                            for (int i = i0; i < i1; ++i) lo = std::min(lo, remap(ci[a0 + i]));
+                        }
+                        p.med_base[(size_t)p.med_ptr[b] + c] = lo == 2147483647 ? 0 : lo;
+                    }
                 for (int r = r0; r < r1; ++r) {
                     const int rr = r - r0, row = ridM[r], len = lenM[r], a0 = rp[row];
                     const int nreg = std::min(len, nc * K);
@@ -315,7 +353,9 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
                         const size_t at = f16 ? base + (size_t)c * CH + (size_t)(kk / 4) * 64 + rr * 4 + kk % 4
                                               : base + (size_t)c * CH + (size_t)kk * kMedRows + rr;
                         mv[at] = val[a0 + i];
-                        p.med_cid[at] = remap(ci[a0 + i]);
+                        const int col = remap(ci[a0 + i]);
+                        if (p.cid16) p.med_cid16[at] = (uint16_t)(col - p.med_base[(size_t)p.med_ptr[b] + c]);
+                        else p.med_cid[at] = col;
                     }
                     const int t0 = p.irr_ptr[r], tl = p.irr_ptr[r + 1] - t0;
                     for (int j = 0; j < tl; ++j) {   // the LAST tl entries of the row (dasp_f64.h:1094-1106)
@@ -374,7 +414,8 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
     const long long stored = s.fill0_nnz_short + s.fill0_nnz_long + s.fill0_nnz_reg + nnz_irreg;
     s.rate_fill0 = nnz > 0 ? (double)(stored - nnz) / nnz : 0.0;
     const long long sv = geo.vbytes;
-    s.data_X = (long long)(m + p.n) * sv + stored * (sv + 4) +
+    s.cid16_on = p.cid16 ? 1 : 0;
+    s.data_X = (long long)(m + p.n) * sv + stored * (sv + 4) - (p.cid16 ? 2 * n_reg - 4ll * p.med_ptr[nb] : 0) +
                (long long)(p.piece_ptr.size() + p.piece_dst.size() + p.multi_ptr.size() + p.multi_dst.size()) * 4 +
                (long long)(p.med_ptr.size() + p.irr_ptr.size()) * 4 + (natural ? (long long)m * 4 : 0) +
                (long long)(p.med_dst.size() + 2 * p.win_len.size()) * 4;

@@ -79,7 +79,10 @@ struct Plan {
     // medium rows: sorted by length (desc, stable); blocks of 16 rows
     std::vector<int> med_ptr;       // [nb+1] in chunks
     std::vector<char> med_val;      // chunk-major, lane-linear inside a chunk
-    std::vector<int> med_cid;
+    std::vector<int> med_cid;       // 32-bit ids (cid16 off)
+    bool cid16 = false;
+    std::vector<uint16_t> med_cid16;  // u16 offsets from med_base[chunk], 0xFFFF = pad (cid16 on)
+    std::vector<int> med_base;        // [chunks]
     std::vector<int> irr_ptr;       // [row_block+1]
     std::vector<char> irr_val;
     std::vector<int> irr_cid;

@@ -103,6 +103,11 @@ typedef struct dasp_options {
      *               0 = by size (256 / 512 / 1024 for < 50 k / < 400 k / more medium rows) */
     int x_window;
     int row_window;
+    /* 16-bit column ids for the regular medium tiles: u16 offsets from a per-chunk base column (10 instead of 12 bytes
+     * per f64 nonzero, 4 instead of 6 for f16).  Chunks spanning more than 65534 columns end their block's regular
+     * part (the rest goes to the 32-bit irregular tail).  0 = auto (on when that loses < 3 % of the regular elements),
+     * -1 = off, 1 = force on. */
+    int cid16;
 } dasp_options_t;
 
 void dasp_options_default(dasp_options_t *opt);
@@ -124,6 +129,7 @@ typedef struct dasp_stats {
     /* LDS-staged x windows (0 everywhere when the mode is off) */
     int x_window_on, n_windows, n_windows_lds, lds_bytes, row_window;
     double window_nnz_frac;    /* share of the medium nonzeros whose window fits in LDS */
+    int cid16_on;              /* regular medium tiles carry 16-bit column ids */
 } dasp_stats_t;
 
 /* classifier + packers on the host (no GPU needed).  CSR arrays are read-only and may be

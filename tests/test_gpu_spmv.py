@@ -218,3 +218,13 @@ def test_cop20k_standin_uses_windows(dasp, torch_cuda):
     rp, ci = dasp.synth_csr("cop20k_A", 0.25)
     st = dasp.Plan(rp, ci, np.ones(ci.size), cols).stats
     assert st["x_window_on"] == 1 and st["window_nnz_frac"] > 0.9
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("cid16", [-1, 1])
+@pytest.mark.parametrize("tag,builder,m,n,seed", [("mixed", util.mixed_matrix, 3000, 2500, 7), ("wide", util.mixed_matrix, 2000, 3_000_000, 9)])
+def test_cid16_modes_agree(oracle, dasp, torch_cuda, prec, cid16, tag, builder, m, n, seed):
+    """16-bit column ids on / off (forced on a 3M-column matrix most chunks fall back to the 32-bit tails)"""
+    rp, ci, v = builder(m, n, seed, values="f16" if prec == 16 else "uniform")
+    check(oracle, dasp, torch_cuda, rp, ci, v, n, prec, cid16=cid16)
+    check(oracle, dasp, torch_cuda, rp, ci, v, n, prec, cid16=cid16, x_window=100000 if n < 10000 else 0)

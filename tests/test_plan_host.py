@@ -153,3 +153,43 @@ def test_windowed_mode_auto_off_and_forced(dasp):
     assert dasp.Plan(rp, ci, v, 3000, x_window=-1).stats["x_window_on"] == 0
     st = dasp.Plan(rp, ci, v, 3000, x_window=4096, row_window=64).stats            # tiny cap: only some windows fit
     assert st["x_window_on"] == 1 and st["row_window"] == 64 and st["lds_bytes"] <= 4096
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+def test_cid16_mode_decodes_and_auto_rule(dasp, prec):
+    dt = np.float64 if prec == 64 else np.float16
+    # narrow columns: every chunk spans < 65535 -> auto on
+    rp, ci, v = banded_matrix(4000, 900, 12)
+    plan = dasp.Plan(rp, ci, v.astype(dt), 4000, precision=prec, x_window=-1)
+    assert plan.stats["cid16_on"] == 1 and plan.host_array("med_cid").size == 0
+    rows = util.decode_plan(plan)
+    order = plan.order_rid
+    for slot in range(4000):
+        r = order[slot]
+        assert rows[slot][0] == ci[rp[r]:rp[r + 1]].tolist()
+    # columns all over a 2M-wide matrix: chunks do not compress -> auto off, forcing moves them to the tails
+    rp, ci, v = util.mixed_matrix(3000, 2_000_000, 7)
+    off = dasp.Plan(rp, ci, v.astype(dt), 2_000_000, precision=prec)
+    assert off.stats["cid16_on"] == 0
+    forced = dasp.Plan(rp, ci, v.astype(dt), 2_000_000, precision=prec, cid16=1)
+    assert forced.stats["cid16_on"] == 1 and forced.stats["nnz_irreg"] > off.stats["nnz_irreg"]
+    rows = util.decode_plan(forced)
+    order = forced.order_rid
+    for slot in range(3000):
+        r = order[slot]
+        assert rows[slot][0] == ci[rp[r]:rp[r + 1]].tolist()
+    assert dasp.Plan(rp, ci, v.astype(dt), 2_000_000, precision=prec, cid16=-1).stats["cid16_on"] == 0
+
+
+def test_cid16_span_boundary(dasp):
+    """a chunk spanning exactly 65534 columns compresses, 65535 does not"""
+    for span, want in ((65534, 1), (65535, 0)):
+        lens = [8] * 16
+        rp = np.arange(0, 8 * 17, 8, dtype=np.int32)
+        ci = np.tile(np.array([0, 1, 2, span, 70000, 70001, 70002, 70003], np.int32), 16)
+        plan = dasp.Plan(rp, ci, np.ones(ci.size), 80000, x_window=-1)
+        st = plan.stats
+        assert st["cid16_on"] == want, span
+        rows = util.decode_plan(plan)
+        for slot in range(16):
+            assert rows[slot][0] == ci[:8].tolist()

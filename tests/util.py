@@ -75,6 +75,11 @@ def decode_plan(plan):
         vs.extend(v[keep].tolist())
     # medium rows
     mptr, mv, mc = plan.host_array("med_ptr"), plan.host_array("med_val"), plan.host_array("med_cid")
+    if st.get("cid16_on"):       # u16 offsets from a per-chunk base column, 0xFFFF = pad
+        off = plan.host_array("med_cid16").astype(np.int64)
+        base = np.repeat(plan.host_array("med_base").astype(np.int64), CH)
+        assert mc.size == 0 and off.size == base.size
+        mc = np.where(off == 0xFFFF, -1, base + off)
     ip_, iv, ic = plan.host_array("irr_ptr"), plan.host_array("irr_val"), plan.host_array("irr_cid")
     nb = mptr.size - 1
     row_block, row_long = st["row_block"], st["row_long"]
