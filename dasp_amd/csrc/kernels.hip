@@ -521,6 +521,12 @@ __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
     }
 }
 
+// XCD-contiguous block ranges: measured and rejected (A/B, same device: ljournal 0.94 -> 2.21 ms, powerlaw 0.99 -> 1.25 ms,
+// Queen/nlpkkt 1-3 % slower, HV15R equal).  Blocks are sorted by length, so a contiguous range per XCD puts all the long
+// blocks on one XCD; the default round-robin dispatch is what balances them.  Kept as a knob (-DDASP_XCD=1).
+#ifndef DASP_XCD
+#define DASP_XCD 0
+#endif
 #ifndef DASP_LB
 #define DASP_LB 1
 #endif
@@ -543,7 +549,15 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? DASP_LB_WIN : DASP_LB) void
         if (p < a.n_pieces) long_piece<T, NT>(a, p, lane);
     } else if (wg < a.wg_long + a.wg_med) {
         if constexpr (!WIN) {
-            const int b = (wg - a.wg_long) * kWavesPerWG + wave;
+            // optional XCD-contiguous order (see DASP_XCD above): workgroup i and i+8 share an XCD; bijective (q, r) split
+            int m = wg - a.wg_long;
+#if DASP_XCD
+            {
+                const int nwg = a.wg_med, xcd = m & 7, idx = m >> 3, q = nwg >> 3, r = nwg & 7;
+                m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+            }
+#endif
+            const int b = m * kWavesPerWG + wave;
             const XGlobal<T> x{static_cast<const T *>(a.x)};
             if (b < a.n_blocks) medium_block<T, NT, C16, 0>(a, b, lane, x);
         } else {
