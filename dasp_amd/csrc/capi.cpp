@@ -123,28 +123,29 @@ long long dasp_plan_host_array(const dasp_plan_t *plan, const char *name, const 
     if (p.host_dropped && std::strcmp(name, "order") != 0) { set_error("host arrays were dropped"); return DASP_ERR_STATE; }
     const int vb = p.geo.vbytes;
     auto ints = [&](const std::vector<int> &v) { *ptr = v.data(); *elem_bytes = 4; return (long long)v.size(); };
-    auto vals = [&](const std::vector<char> &v) { *ptr = v.data(); *elem_bytes = vb; return (long long)(v.size() / vb); };
+    auto vals = [&](const raw_vector<char> &v) { *ptr = v.data(); *elem_bytes = vb; return (long long)(v.size() / vb); };
+    auto rints = [&](const raw_vector<int> &v) { *ptr = v.data(); *elem_bytes = 4; return (long long)v.size(); };
     const std::string n(name);
     if (n == "order") return ints(p.order);
     if (n == "long_val") return vals(p.long_val);
-    if (n == "long_cid") return ints(p.long_cid);
+    if (n == "long_cid") return rints(p.long_cid);
     if (n == "piece_ptr") return ints(p.piece_ptr);
     if (n == "piece_dst") return ints(p.piece_dst);
     if (n == "multi_ptr") return ints(p.multi_ptr);
     if (n == "multi_dst") return ints(p.multi_dst);
     if (n == "med_ptr") return ints(p.med_ptr);
     if (n == "med_val") return vals(p.med_val);
-    if (n == "med_cid") return ints(p.med_cid);
+    if (n == "med_cid") return rints(p.med_cid);
     if (n == "irr_ptr") return ints(p.irr_ptr);
     if (n == "irr_val") return vals(p.irr_val);
-    if (n == "irr_cid") return ints(p.irr_cid);
+    if (n == "irr_cid") return rints(p.irr_cid);
     if (n == "med_cid16") { *ptr = p.med_cid16.data(); *elem_bytes = 2; return (long long)p.med_cid16.size(); }
     if (n == "med_base") return ints(p.med_base);
     if (n == "med_dst") return ints(p.med_dst);
     if (n == "win_cmin") return ints(p.win_cmin);
     if (n == "win_len") return ints(p.win_len);
     if (n == "short_val") return vals(p.short_val);
-    if (n == "short_cid") return ints(p.short_cid);
+    if (n == "short_cid") return rints(p.short_cid);
     if (n == "short_groups") {   // kNumShortGroups x {len,count,tiles,tile0,elem_off_lo,elem_off_hi,split,base0,base1,grp0,grp1,off0,off1}
         static thread_local std::vector<int> flat;
         flat.clear();
@@ -171,9 +172,9 @@ int dasp_plan_drop_host(dasp_plan_t *plan)
     if (!plan) return DASP_ERR_ARG;
     Plan &p = plan->impl;
     if (!p.dev) { set_error("upload the plan before dropping its host arrays"); return DASP_ERR_STATE; }
-    auto dropc = [](std::vector<char> &v) { std::vector<char>().swap(v); };
-    auto dropi = [](std::vector<int> &v) { std::vector<int>().swap(v); };
-    dropc(p.long_val); dropi(p.long_cid); dropc(p.med_val); dropi(p.med_cid); std::vector<uint16_t>().swap(p.med_cid16);
+    auto dropc = [](raw_vector<char> &v) { raw_vector<char>().swap(v); };
+    auto dropi = [](raw_vector<int> &v) { raw_vector<int>().swap(v); };
+    dropc(p.long_val); dropi(p.long_cid); dropc(p.med_val); dropi(p.med_cid); raw_vector<uint16_t>().swap(p.med_cid16);
     dropc(p.irr_val); dropi(p.irr_cid); dropc(p.short_val); dropi(p.short_cid);
     p.host_dropped = true;
     return DASP_OK;

@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <thread>
@@ -61,6 +63,9 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
 {
     using clk = std::chrono::steady_clock;
     const auto t_begin = clk::now();
+    const bool verbose = std::getenv("DASP_VERBOSE") != nullptr;
+    auto tick = t_begin;
+    auto lap = [&](const char *what) { if (verbose) { auto now = clk::now(); std::fprintf(stderr, "[dasp plan] %-28s %.3f s\n", what, std::chrono::duration<double>(now - tick).count()); tick = now; } };
     const Geometry geo = p.geo;
     const int m = p.m, nnz = p.nnz;
     const int threads = resolve_threads(p.opt.host_threads);
@@ -85,6 +90,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
         if (bad) { set_error(bad == 1 ? "csrRowPtr not monotone" : "column index out of range"); return DASP_ERR_ARG; }
     }
 
+    lap("validate");
     // ---- classifier: same tests in the same order as dasp_f64.h:499-531
     int n1 = 0, n2 = 0, n3 = 0, n4 = 0, nz0 = 0, nlong = 0, nmed = 0;
     for (int i = 0; i < m; ++i) {
@@ -114,6 +120,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
     if (c13 / 8 >= 16) { c13 = f16 ? 32 * (c13 / 32) : 8 * (c13 / 8); n1 -= c13; n3 -= c13; }
     else c13 = 0;
 
+    lap("classify");
     // ---- medium rows sorted by length, descending and stable (what utils.h:118-160,196-203 produce);
     // lengths are < block_longest, so one counting pass does it.
     std::vector<int> ridM(nmed), lenM(nmed);
@@ -126,6 +133,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
     }
     std::vector<int>().swap(ridM_in);
 
+    lap("sort medium");
     // ---- output permutation (order_rid): dasp_f64.h:960-976 / dasp_f16.h:1253-1270
     const int base_s = nlong + nmed;
     const int pg = f16 ? 32 : 8;
@@ -158,6 +166,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
     const bool natural = p.opt.y_order == DASP_Y_NATURAL;
     auto ydst = [&](int slot) { return natural ? p.order[slot] : slot; };
 
+    lap("order_rid");
     // ---- long rows: compact, padded to kLongAlign; one wave per piece
     int piece = p.opt.long_piece > 0 ? p.opt.long_piece : 1024;
     piece = std::max(geo.chunk, (piece / geo.chunk) * geo.chunk);
@@ -169,8 +178,8 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
         }
         const long long total = start[nlong];
         if (total >= (1LL << 31)) { set_error("long-row segment exceeds 2^31 elements"); return DASP_ERR_ARG; }
-        p.long_val.assign((size_t)total * sizeof(T), 0);
-        p.long_cid.assign((size_t)total, -1);
+        p.long_val.resize((size_t)total * sizeof(T));          // not zero-filled: rows + their pads are written below
+        p.long_cid.resize((size_t)total);
         p.piece_ptr.clear(); p.piece_dst.clear(); p.multi_ptr.assign(1, 0); p.multi_dst.clear();
         int n_partial = 0;
         for (int i = 0; i < nlong; ++i) {
@@ -189,10 +198,12 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
                 const int r = ridL[i], len = rp[r + 1] - rp[r];
                 const size_t at = (size_t)start[i];
                 for (int j = 0; j < len; ++j) { lv[at + j] = val[rp[r] + j]; p.long_cid[at + j] = remap(ci[rp[r] + j]); }
+                for (size_t j = at + len; j < (size_t)start[i + 1]; ++j) { lv[j] = (T)0; p.long_cid[j] = -1; }   // pad to kLongAlign
             }
         });
     }
 
+    lap("long rows");
     // ---- optional windowed order for the medium rows (LDS-staged x).  The reference sorts all
     // medium rows globally by length, which scatters the 16 rows of a block over the matrix; here rows are sorted inside
     // windows of `row_window` consecutive medium rows only, one window per workgroup, so a workgroup's rows share a narrow
@@ -262,6 +273,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
         }
     }
 
+    lap("window decision");
     // ---- medium rows: regular tiles kept while a 16 x K chunk is >= threshold full
     // (the reference's rule, dasp_f64.h:1044-1091, on this geometry's tile), rest = irregular tail
     const int K = geo.med_k, CH = geo.chunk;
@@ -311,6 +323,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
         const int r0 = b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
         for (int r = r0; r < r1; ++r) p.irr_ptr[r] = std::max(0, lenM[r] - K * nchunks[b]);
     }
+    lap("chunk split (+cid16 spans)");
     p.med_ptr.assign((size_t)nb + 1, 0);
     {
         long long run = 0;
@@ -323,12 +336,12 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
     }
     const long long n_reg = (long long)p.med_ptr[nb] * CH;
     const int nnz_irreg = p.irr_ptr[nmed];
-    p.med_val.assign((size_t)n_reg * sizeof(T), 0);
-    p.med_cid.assign(p.cid16 ? 0 : (size_t)n_reg, -1);
-    p.med_cid16.assign(p.cid16 ? (size_t)n_reg : 0, (uint16_t)0xFFFF);
+    p.med_val.resize((size_t)n_reg * sizeof(T));               // not zero-filled: each block pads its own region first
+    p.med_cid.resize(p.cid16 ? 0 : (size_t)n_reg);
+    p.med_cid16.resize(p.cid16 ? (size_t)n_reg : 0);
     p.med_base.assign(p.cid16 ? (size_t)p.med_ptr[nb] : 0, 0);
-    p.irr_val.assign((size_t)nnz_irreg * sizeof(T), 0);
-    p.irr_cid.assign((size_t)nnz_irreg, -1);
+    p.irr_val.resize((size_t)nnz_irreg * sizeof(T));           // fully covered by the rows' tails
+    p.irr_cid.resize((size_t)nnz_irreg);
     {
         T *mv = reinterpret_cast<T *>(p.med_val.data());
         T *iv = reinterpret_cast<T *>(p.irr_val.data());
@@ -337,6 +350,12 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
                 const int nc = p.med_ptr[b + 1] - p.med_ptr[b];
                 const size_t base = (size_t)p.med_ptr[b] * CH;
                 const int r0 = (int)b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
+                {   // pad the block's region (value 0, id -1 / 0xFFFF); real entries overwrite below
+                    const size_t n = (size_t)nc * CH;
+                    std::fill(mv + base, mv + base + n, (T)0);
+                    if (p.cid16) std::fill(p.med_cid16.begin() + base, p.med_cid16.begin() + base + n, (uint16_t)0xFFFF);
+                    else std::fill(p.med_cid.begin() + base, p.med_cid.begin() + base + n, -1);
+                }
                 if (p.cid16)   // per-chunk base = smallest column of the chunk
                     for (int c = 0; c < nc; ++c) {
                         int lo = 2147483647;
@@ -370,6 +389,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
         });
     }
 
+    lap("pack medium");
     // ---- short rows: one slab per length, tile-major [tile][k][short_rows]
     {
         const int SR = geo.short_rows;
@@ -382,9 +402,16 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
             off += (long long)G.tiles * SR * G.len;
         }
         if (off >= (1LL << 40)) { set_error("short segment too large"); return DASP_ERR_ARG; }
-        p.short_val.assign((size_t)off * sizeof(T), 0);
-        p.short_cid.assign((size_t)off, -1);
+        p.short_val.resize((size_t)off * sizeof(T));           // not zero-filled: only a slab's last tile has pads
+        p.short_cid.resize((size_t)off);
         T *sv = reinterpret_cast<T *>(p.short_val.data());
+        for (int g = 0; g < 4; ++g) {
+            const ShortGroup &G = p.grp[g];
+            if (G.tiles == 0) continue;
+            const size_t t0 = (size_t)G.elem_off + (size_t)(G.tiles - 1) * G.len * SR, t1 = t0 + (size_t)G.len * SR;
+            std::fill(sv + t0, sv + t1, (T)0);
+            std::fill(p.short_cid.begin() + t0, p.short_cid.begin() + t1, -1);
+        }
         for (int g = 0; g < 4; ++g) {
             const ShortGroup &G = p.grp[g];
             const std::vector<int> &list = *glist[g];
@@ -402,6 +429,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
         }
     }
 
+    lap("pack short");
     // ---- stats: the reference's CSV counters (dasp_f64.h:1439-1441) + native sizes
     dasp_stats_t &s = p.stats;
     std::memset(&s, 0, sizeof s);

@@ -10,12 +10,26 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/dasp_amd.h"
 
 namespace dasp {
+
+// std::vector that does not zero-fill on resize(): the packed arrays are gigabytes, and a serial fill
+// costs more than the (parallel) packing itself; every element is written by the packers.
+template <class T>
+struct NoInit : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInit<U>; };
+    NoInit() = default;
+    template <class U> NoInit(const NoInit<U> &) {}
+    template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using raw_vector = std::vector<T, NoInit<T>>;
 
 constexpr int kWave = 64;         // gfx950 wavefront
 constexpr int kWavesPerWG = 4;    // 256-thread workgroups
@@ -69,8 +83,8 @@ struct Plan {
     std::vector<int> order;         // [m]   order_rid
 
     // long rows: CSR-ordered, each row padded to kLongAlign (val 0, cid -1); pieces of <= long_piece
-    std::vector<char> long_val;     // vbytes per element
-    std::vector<int> long_cid;
+    raw_vector<char> long_val;      // vbytes per element
+    raw_vector<int> long_cid;
     std::vector<int> piece_ptr;     // [P+1] element offsets
     std::vector<int> piece_dst;     // [P]   >= 0: y index ; < 0: partial sum ~dst
     std::vector<int> multi_ptr;     // [R2+1] ranges of partial sums of rows cut into several pieces
@@ -78,14 +92,14 @@ struct Plan {
 
     // medium rows: sorted by length (desc, stable); blocks of 16 rows
     std::vector<int> med_ptr;       // [nb+1] in chunks
-    std::vector<char> med_val;      // chunk-major, lane-linear inside a chunk
-    std::vector<int> med_cid;       // 32-bit ids (cid16 off)
+    raw_vector<char> med_val;       // chunk-major, lane-linear inside a chunk
+    raw_vector<int> med_cid;        // 32-bit ids (cid16 off)
     bool cid16 = false;
-    std::vector<uint16_t> med_cid16;  // u16 offsets from med_base[chunk], 0xFFFF = pad (cid16 on)
+    raw_vector<uint16_t> med_cid16;  // u16 offsets from med_base[chunk], 0xFFFF = pad (cid16 on)
     std::vector<int> med_base;        // [chunks]
     std::vector<int> irr_ptr;       // [row_block+1]
-    std::vector<char> irr_val;
-    std::vector<int> irr_cid;
+    raw_vector<char> irr_val;
+    raw_vector<int> irr_cid;
     // windowed mode (LDS-staged x): medium positions follow the windowed order; med_dst[pos] = y index,
     // win_cmin/win_len = the x span of window w (len 0: span too wide, that window gathers from global memory)
     bool windowed = false;
@@ -94,8 +108,8 @@ struct Plan {
 
     // short rows: per length one slab, tile-major [tile][k][short_rows]
     ShortGroup grp[kNumShortGroups];
-    std::vector<char> short_val;
-    std::vector<int> short_cid;
+    raw_vector<char> short_val;
+    raw_vector<int> short_cid;
 
     bool host_dropped = false;
     DevicePlan *dev = nullptr;
