@@ -109,6 +109,23 @@ class Plan:
         self.y_order = y_order
         self.x_len = self.colA if part_bounds is None else (self._pb.size - 1) * int(part_stride)
 
+    def save(self, path):
+        """Write the packed plan to `path` (dasp_plan_save)."""
+        _lib.check(_lib.lib().dasp_plan_save(self._h, os.fsencode(path)))
+
+    @classmethod
+    def load(cls, path):
+        """Plan from a file written by save(): ready for upload(), no re-packing."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        self._pb = None
+        _lib.check(_lib.lib().dasp_plan_load(C.byref(self._h), os.fsencode(path)))
+        st = self.stats
+        self.precision, self.rowA, self.colA, self.nnzA = st["precision"], st["rowA"], st["colA"], st["nnzA"]
+        self.y_order = _lib.lib().dasp_plan_y_order(self._h)
+        self.x_len = int(_lib.lib().dasp_plan_x_len(self._h))
+        return self
+
     # -- host side -------------------------------------------------------------------
     @property
     def order_rid(self):

@@ -107,7 +107,36 @@ int dasp_plan_create(dasp_plan_t **out, int precision, int rowA, int colA, int n
 
 void dasp_plan_destroy(dasp_plan_t *plan) { delete plan; }
 
+int dasp_plan_save(dasp_plan_t *plan, const char *path)
+{
+    if (!plan) return DASP_ERR_ARG;
+    return save_plan(plan->impl, path);
+}
+
+int dasp_plan_load(dasp_plan_t **out, const char *path)
+{
+    if (!out) return DASP_ERR_ARG;
+    *out = nullptr;
+    dasp_plan *h = new (std::nothrow) dasp_plan();
+    if (!h) return DASP_ERR_NOMEM;
+    int rc;
+    try { rc = load_plan(h->impl, path); }
+    catch (const std::bad_alloc &) { rc = DASP_ERR_NOMEM; set_error("out of host memory"); }
+    if (rc != DASP_OK) { delete h; return rc; }
+    *out = h;
+    return DASP_OK;
+}
+
 const int *dasp_plan_order(const dasp_plan_t *plan) { return plan ? plan->impl.order.data() : nullptr; }
+
+int dasp_plan_y_order(const dasp_plan_t *plan) { return plan ? plan->impl.opt.y_order : DASP_ERR_ARG; }
+
+long long dasp_plan_x_len(const dasp_plan_t *plan)
+{
+    if (!plan) return DASP_ERR_ARG;
+    const Plan &p = plan->impl;
+    return p.opt.n_parts > 0 ? (long long)p.opt.n_parts * p.opt.part_stride : (long long)p.n;
+}
 
 int dasp_plan_stats(const dasp_plan_t *plan, dasp_stats_t *out)
 {

@@ -126,6 +126,9 @@ int load_mtx(const char *path, int precision, int *m, int *n, int *nnz, int *sym
 int save_csr_bin(const char *path, int precision, int m, int n, int nnz, int sym, const int *rp, const int *ci, const void *val);
 int load_csr_bin(const char *path, int precision, int *m, int *n, int *nnz, int *sym, int **rp, int **ci, void **val);
 
+int save_plan(Plan &p, const char *path);
+int load_plan(Plan &p, const char *path);
+
 void set_error(const std::string &s);
 
 // threads helper

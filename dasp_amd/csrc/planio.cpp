@@ -1,0 +1,91 @@
+// planio.cpp -- serialised plans (the reference never stores its packed format).
+// A plan file holds every host array of a Plan, so a later run (or every rank of a multi-GPU job)
+// skips classification and packing: load -> upload -> spmv.
+// layout: "DASPPLN2" | int32 precision, m, n, nnz, y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride |
+//         dasp_stats_t | ShortGroup[5] | then for each array, in a fixed order: int64 byte count + bytes
+#include <cstdio>
+#include <cstring>
+
+#include "plan.hpp"
+
+namespace dasp {
+
+namespace {
+const char kPlanMagic[8] = {'D', 'A', 'S', 'P', 'P', 'L', 'N', '2'};
+
+struct Writer {
+    FILE *f; bool ok = true;
+    void raw(const void *p, size_t n) { if (ok && n && std::fwrite(p, 1, n, f) != n) ok = false; }
+    template <class V> void vec(const V &v) { long long b = (long long)(v.size() * sizeof(typename V::value_type)); raw(&b, 8); raw(v.data(), (size_t)b); }
+};
+struct Reader {
+    FILE *f; bool ok = true;
+    void raw(void *p, size_t n) { if (ok && n && std::fread(p, 1, n, f) != n) ok = false; }
+    template <class V> void vec(V &v)
+    {
+        long long b = -1; raw(&b, 8);
+        if (!ok || b < 0 || b % (long long)sizeof(typename V::value_type)) { ok = false; return; }
+        v.resize((size_t)b / sizeof(typename V::value_type));
+        raw(v.data(), (size_t)b);
+    }
+};
+
+template <class IO> void arrays(IO &io, Plan &p)
+{
+    io.vec(p.part_bounds); io.vec(p.order);
+    io.vec(p.long_val); io.vec(p.long_cid); io.vec(p.piece_ptr); io.vec(p.piece_dst); io.vec(p.multi_ptr); io.vec(p.multi_dst);
+    io.vec(p.med_ptr); io.vec(p.med_val); io.vec(p.med_cid); io.vec(p.med_cid16); io.vec(p.med_base);
+    io.vec(p.irr_ptr); io.vec(p.irr_val); io.vec(p.irr_cid);
+    io.vec(p.med_dst); io.vec(p.win_cmin); io.vec(p.win_len);
+    io.vec(p.short_val); io.vec(p.short_cid);
+}
+}  // namespace
+
+int save_plan(Plan &p, const char *path)
+{
+    if (!path) return DASP_ERR_ARG;
+    if (p.host_dropped) { set_error("host arrays were dropped: nothing to save"); return DASP_ERR_STATE; }
+    FILE *f = std::fopen(path, "wb");
+    if (!f) { set_error(std::string("cannot create ") + path); return DASP_ERR_OPEN; }
+    Writer w{f};
+    const int hdr[11] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
+                         p.opt.n_parts, p.opt.part_stride};
+    w.raw(kPlanMagic, 8); w.raw(hdr, sizeof hdr); w.raw(&p.stats, sizeof p.stats); w.raw(p.grp, sizeof p.grp);
+    arrays(w, p);
+    const bool ok = (std::fclose(f) == 0) && w.ok;
+    if (!ok) { set_error(std::string("short write to ") + path); return DASP_ERR_OPEN; }
+    return DASP_OK;
+}
+
+int load_plan(Plan &p, const char *path)
+{
+    if (!path) return DASP_ERR_ARG;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) { set_error(std::string("cannot open ") + path); return DASP_ERR_OPEN; }
+    Reader r{f};
+    char magic[8]; int hdr[11];
+    r.raw(magic, 8); r.raw(hdr, sizeof hdr);
+    if (!r.ok || std::memcmp(magic, kPlanMagic, 8) != 0 || (hdr[0] != 64 && hdr[0] != 16)) {
+        std::fclose(f); set_error("not a DASPPLN2 plan file"); return DASP_ERR_BANNER;
+    }
+    p.precision = hdr[0]; p.geo = geometry_for(p.precision);
+    p.m = hdr[1]; p.n = hdr[2]; p.nnz = hdr[3];
+    dasp_options_default(&p.opt);
+    p.opt.y_order = hdr[4]; p.windowed = hdr[5] != 0; p.row_window = hdr[6]; p.lds_bytes = hdr[7]; p.cid16 = hdr[8] != 0;
+    p.opt.n_parts = hdr[9]; p.opt.part_stride = hdr[10];
+    r.raw(&p.stats, sizeof p.stats); r.raw(p.grp, sizeof p.grp);
+    arrays(r, p);
+    std::fclose(f);
+    p.opt.part_bounds = p.part_bounds.empty() ? nullptr : p.part_bounds.data();
+    const size_t vb = (size_t)p.geo.vbytes;
+    const bool sane = r.ok && p.m >= 0 && p.order.size() == (size_t)p.m && p.stats.rowA == p.m && p.stats.precision == p.precision &&
+                      p.long_val.size() == p.long_cid.size() * vb && p.irr_val.size() == p.irr_cid.size() * vb &&
+                      p.short_val.size() == p.short_cid.size() * vb && p.piece_ptr.size() == p.piece_dst.size() + 1 &&
+                      (p.cid16 ? p.med_val.size() == p.med_cid16.size() * vb : p.med_val.size() == p.med_cid.size() * vb) &&
+                      p.irr_ptr.size() == (size_t)p.stats.row_block + 1 && (!p.windowed || p.med_dst.size() == (size_t)p.stats.row_block);
+    if (!sane) { set_error("truncated or inconsistent plan file"); return DASP_ERR_ENTRY; }
+    p.host_dropped = false;
+    return DASP_OK;
+}
+
+}  // namespace dasp

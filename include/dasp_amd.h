@@ -140,10 +140,19 @@ int dasp_plan_create(dasp_plan_t **plan, int precision, int rowA, int colA, int 
                      const dasp_options_t *opt /* NULL = defaults */);
 void dasp_plan_destroy(dasp_plan_t *plan);
 
+/* serialised plan (no reference counterpart): every packed host array + order_rid + stats, so that a later
+ * run or another rank goes load -> upload -> spmv without re-packing.  Saving needs the host arrays (before
+ * dasp_plan_drop_host). */
+int dasp_plan_save(dasp_plan_t *plan, const char *path);
+int dasp_plan_load(dasp_plan_t **plan, const char *path);
+
 /* order_rid[i] = original row of permuted slot i (dasp_f64.h:960-976 / dasp_f16.h:1253-1270);
  * identical to the reference's array.  Owned by the plan. */
 const int *dasp_plan_order(const dasp_plan_t *plan);
 int dasp_plan_stats(const dasp_plan_t *plan, dasp_stats_t *out);
+/* dasp_y_order of the plan; number of x elements a SpMV reads (colA, or n_parts * part_stride in the partitioned layout) */
+int dasp_plan_y_order(const dasp_plan_t *plan);
+long long dasp_plan_x_len(const dasp_plan_t *plan);
 
 /* read-only view of a packed host array, for format tests and serialisation.
  * returns element count, or a negative dasp_status for an unknown name. */

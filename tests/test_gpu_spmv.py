@@ -228,3 +228,47 @@ def test_cid16_modes_agree(oracle, dasp, torch_cuda, prec, cid16, tag, builder, 
     rp, ci, v = builder(m, n, seed, values="f16" if prec == 16 else "uniform")
     check(oracle, dasp, torch_cuda, rp, ci, v, n, prec, cid16=cid16)
     check(oracle, dasp, torch_cuda, rp, ci, v, n, prec, cid16=cid16, x_window=100000 if n < 10000 else 0)
+
+
+def test_loaded_plan_runs(oracle, dasp, torch_cuda, tmp_path):
+    """a plan read back from disk gives the same y as the plan that was saved"""
+    rp, ci, v = util.mixed_matrix(3000, 2500, 7)
+    x = np.random.default_rng(4).uniform(-1, 1, 2500)
+    plan = dasp.Plan(rp, ci, v, 2500)
+    plan.save(str(tmp_path / "a.plan"))
+    y0 = run_spmv(torch_cuda, plan.upload(), x, 3000, 64)
+    y1 = run_spmv(torch_cuda, dasp.Plan.load(str(tmp_path / "a.plan")).upload(), x, 3000, 64)
+    assert np.array_equal(y0, y1)
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("kw", [dict(threshold=0.01), dict(threshold=1.0), dict(block_longest=64), dict(block_longest=1000),
+                                dict(long_piece=64), dict(threshold=0.5, block_longest=32, long_piece=256, x_window=40000, cid16=1)])
+def test_option_corners(oracle, dasp, torch_cuda, prec, kw):
+    """the reference's two tunables (threshold, block_longest: main_f64.cu:124-125) and this build's own, at their corners"""
+    rp, ci, v = util.mixed_matrix(2500, 2000, 29, values="f16" if prec == 16 else "uniform")
+    check(oracle, dasp, torch_cuda, rp, ci, v, 2000, prec, **kw)
+
+
+def test_single_column_and_duplicates(oracle, dasp, torch_cuda):
+    lens = [0, 1, 2, 3, 4, 5, 17, 64, 300, 1100]
+    rp, ci, v = util.csr_from_lengths(lens, 1, 3)                   # every entry in column 0: all duplicates
+    check(oracle, dasp, torch_cuda, rp, ci, v, 1, 64)
+    rp, ci, v = util.csr_from_lengths([40] * 50, 3, 5)
+    check(oracle, dasp, torch_cuda, rp, ci, v, 3, 16)
+
+
+def test_nonfinite_values_stay_in_their_rows(dasp, torch_cuda):
+    rp, ci, v = util.mixed_matrix(1500, 1200, 31)
+    lens = np.diff(rp)
+    bad_rows = [int(np.argmax(lens >= 256)), int(np.argmax((lens >= 5) & (lens < 256))), int(np.argmax(lens == 3))]
+    v = v.copy()
+    for r, val in zip(bad_rows, (np.nan, np.inf, -np.inf)):
+        v[rp[r]] = val
+    x = np.random.default_rng(6).uniform(0.5, 1.5, 1200)
+    plan = dasp.Plan(rp, ci, v, 1200, y_order=dasp.Y_NATURAL).upload()
+    y = run_spmv(torch_cuda, plan, x, 1500, 64)
+    assert np.isnan(y[bad_rows[0]]) and y[bad_rows[1]] == np.inf and y[bad_rows[2]] == -np.inf
+    ok = np.ones(1500, bool)
+    ok[bad_rows] = False
+    assert np.isfinite(y[ok]).all()

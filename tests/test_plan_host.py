@@ -194,3 +194,24 @@ def test_cid16_span_boundary(dasp):
         rows = util.decode_plan(plan)
         for slot in range(16):
             assert rows[slot][0] == ci[:8].tolist()
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+def test_serialised_plan_round_trip(dasp, tmp_path, prec):
+    dt = np.float64 if prec == 64 else np.float16
+    rp, ci, v = banded_matrix(3000, 400, 4)
+    for kw in (dict(), dict(x_window=-1, cid16=1, y_order=1), dict(part_bounds=np.array([0, 1000, 3000], np.int32), part_stride=2048)):
+        plan = dasp.Plan(rp, ci, v.astype(dt), 3000, precision=prec, **kw)
+        path = str(tmp_path / "p.daspplan")
+        plan.save(path)
+        back = dasp.Plan.load(path)
+        assert back.stats == plan.stats and (back.order_rid == plan.order_rid).all()
+        assert (back.y_order, back.x_len, back.precision) == (plan.y_order, plan.x_len, prec)
+        for name in ("long_val long_cid piece_ptr piece_dst multi_ptr multi_dst med_ptr med_val med_cid med_cid16 med_base "
+                     "irr_ptr irr_val irr_cid med_dst win_cmin win_len short_val short_cid short_groups").split():
+            a, b = plan.host_array(name), back.host_array(name)
+            assert a.dtype == b.dtype and np.array_equal(a, b), name
+    with open(path, "r+b") as f:
+        f.truncate(200)
+    with pytest.raises(dasp.DaspError):
+        dasp.Plan.load(path)
