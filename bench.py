@@ -82,6 +82,36 @@ def suite_entry(torch, D, name, precision, scale, budget_s=2.0):
     return out
 
 
+def setup_rank(torch, D, name, scale, prec, rank, world):
+    """Everything one rank owns: its row range (equal nonzeros), the DASP plan of that slice with column ids remapped
+    into the all-gather layout, x in that layout, the padded y slice and the gather buffer."""
+    rows, cols = D.synth_dims(name, scale)
+    lengths = D.synth_row_lengths(name, scale)                      # every rank: cheap, deterministic
+    rp_full = np.zeros(rows + 1, np.int64)
+    np.cumsum(lengths, out=rp_full[1:])
+    nnz_total = int(rp_full[-1])
+    if world > 1:
+        # same rule as dasp_partition_rows (first row whose start >= g/world of the nonzeros), on int64 prefix sums
+        bounds = np.searchsorted(rp_full, nnz_total * np.arange(world + 1) // world, side="left").astype(np.int32)
+        bounds[0], bounds[-1] = 0, rows
+        bounds = np.maximum.accumulate(bounds)
+        stride = (int(np.diff(bounds).max()) + 63) // 64 * 64
+    else:
+        bounds, stride = None, 0
+    r0, r1 = (0, rows) if world == 1 else (int(bounds[rank]), int(bounds[rank + 1]))
+    threads = max(1, (os.cpu_count() or 8) // max(1, world))
+    plan, rp, ci, val, pre_s = build_slice(D, name, scale, prec, r0, r1, lengths, bounds, stride, natural=world > 1, threads=threads)
+    del val
+    plan.upload()
+    plan.drop_host()
+    tdt = torch.float64 if prec == 64 else torch.float16
+    x = torch.ones(plan.x_len, dtype=tdt, device="cuda")
+    y = torch.zeros(max(stride, r1 - r0), dtype=tdt, device="cuda")
+    gathered = torch.zeros(world * stride, dtype=tdt, device="cuda") if world > 1 else None
+    return dict(plan=plan, rp=rp, ci=ci, stats=plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total, lengths=lengths,
+                bounds=bounds, stride=stride, r0=r0, r1=r1, x=x, y=y, gathered=gathered)
+
+
 def cpu_baseline(O, rp, ci, n_cols, budget_s=20.0):
     """Serial CSR SpMV (oracle/dasp_oracle.c, 1 thread) on the same CSR and x: a reported baseline."""
     nnz = int(rp[-1])
@@ -112,6 +142,7 @@ def main():
     ap.add_argument("--precision", type=int, default=64, choices=[64, 16])
     ap.add_argument("--no-suite", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vendor", action="store_true")
     ap.add_argument("--suite-scale", type=float, default=1.0)
     args = ap.parse_args()
 
@@ -135,31 +166,10 @@ def main():
 
     name, scale, prec = args.workload, args.scale, args.precision
     vb = prec // 8
-    rows, cols = D.synth_dims(name, scale)
-    lengths = D.synth_row_lengths(name, scale)                      # every rank: cheap, deterministic
-    rp_full = np.zeros(rows + 1, np.int64)
-    np.cumsum(lengths, out=rp_full[1:])
-    nnz_total = int(rp_full[-1])
-    if world > 1:
-        # same rule as dasp_partition_rows (first row whose start >= g/world of the nonzeros), on int64 prefix sums
-        bounds = np.searchsorted(rp_full, nnz_total * np.arange(world + 1) // world, side="left").astype(np.int32)
-        bounds[0], bounds[-1] = 0, rows
-        bounds = np.maximum.accumulate(bounds)
-        stride = int(np.diff(bounds).max())
-        stride = (stride + 63) // 64 * 64
-    else:
-        bounds, stride = None, 0
-    r0, r1 = (0, rows) if world == 1 else (int(bounds[rank]), int(bounds[rank + 1]))
-    threads = max(1, (os.cpu_count() or 8) // max(1, world))
-    plan, rp, ci, val, pre_s = build_slice(D, name, scale, prec, r0, r1, lengths, bounds, stride, natural=world > 1, threads=threads)
-    del val
-    plan.upload()
-    plan.drop_host()
-    st = plan.stats
-    tdt = torch.float64 if prec == 64 else torch.float16
-    x = torch.ones(plan.x_len, dtype=tdt, device="cuda")
-    y = torch.zeros(max(stride, r1 - r0), dtype=tdt, device="cuda")
-    gathered = torch.zeros(world * stride, dtype=tdt, device="cuda") if world > 1 else None
+    R = setup_rank(torch, D, name, scale, prec, rank, world)
+    plan, rp, ci, st, pre_s = R["plan"], R["rp"], R["ci"], R["stats"], R["pre_s"]
+    rows, cols, nnz_total, lengths = R["rows"], R["cols"], R["nnz_total"], R["lengths"]
+    bounds, stride, r0, r1, x, y, gathered = R["bounds"], R["stride"], R["r0"], R["r1"], R["x"], R["y"], R["gathered"]
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -251,6 +261,21 @@ def main():
     plan.close()
     del x, y
     torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_vendor:
+        # vendor comparator on the same box and matrix: rocSPARSE CSR SpMV (the reference's cuSPARSE column, main_f64.cu:18-100)
+        exe = os.path.join(ROOT, "dasp_amd", "bin", "dasp_rocsparse")
+        if prec == 64 and os.path.exists(exe):
+            import re
+            import subprocess
+            try:
+                r = subprocess.run([exe, name, repr(scale), "100", "10"], capture_output=True, text=True, timeout=600)
+                mt = re.search(r"\| ([0-9.]+) ms ([0-9.]+) GFLOP/s", r.stdout)
+                if mt:
+                    out["rocsparse_csr"] = {"ms": float(mt.group(1)), "gflops": float(mt.group(2)),
+                                            "speedup_of_dasp": round(float(mt.group(1)) / ms_per_step, 3)}
+            except Exception as exc:
+                out["rocsparse_csr"] = {"error": repr(exc)}
 
     if rank == 0 and world == 1 and not args.no_suite:
         suite = []

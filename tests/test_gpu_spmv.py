@@ -272,3 +272,34 @@ def test_nonfinite_values_stay_in_their_rows(dasp, torch_cuda):
     ok = np.ones(1500, bool)
     ok[bad_rows] = False
     assert np.isfinite(y[ok]).all()
+
+
+def test_bench_rank_setup_assembles_full_y(dasp, torch_cuda):
+    """bench.py's multi-GPU preparation, every rank's part run in turn on one GPU with the all-gather done by hand:
+    partition by nonzeros, per-rank plans with remapped columns, padded slices -> the full y, exactly"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    torch = torch_cuda
+    world = 3
+    parts = [bench.setup_rank(torch, dasp, "HV15R", 0.02, 64, r, world) for r in range(world)]
+    stride, bounds = parts[0]["stride"], parts[0]["bounds"]
+    gathered = torch.zeros(world * stride, dtype=torch.float64, device="cuda")
+    for r, P in enumerate(parts):
+        assert P["plan"].x_len == world * stride and P["plan"].y_order == dasp.Y_NATURAL
+        P["plan"].spmv(P["x"].data_ptr(), P["y"].data_ptr(), torch.cuda.current_stream().cuda_stream)
+        gathered[r * stride:(r + 1) * stride] = P["y"][:stride]              # what all_gather_into_tensor does
+    torch.cuda.synchronize()
+    full = torch.cat([gathered[g * stride: g * stride + int(bounds[g + 1] - bounds[g])] for g in range(world)]).cpu().numpy()
+    assert (full == parts[0]["lengths"]).all()
+    nnz = [int(P["rp"][-1]) for P in parts]
+    assert max(nnz) - min(nnz) <= 2 * 484                                    # balanced to within a row or two
+    # second iteration with x := gathered y (the layout IS the next x): y2 = A (A 1)
+    for r, P in enumerate(parts):
+        P["plan"].spmv(gathered.data_ptr(), P["y"].data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    rp_all, ci_all = dasp.synth_csr("HV15R", 0.02)
+    want = np.add.reduceat(parts[0]["lengths"][ci_all].astype(np.float64), rp_all[:-1].astype(np.int64))
+    got = np.concatenate([P["y"][: P["r1"] - P["r0"]].cpu().numpy() for P in parts])
+    assert (got == want).all()
