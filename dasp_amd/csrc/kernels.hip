@@ -792,24 +792,39 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream)
     return p.precision == 64 ? launch_typed<double>(p, a, s) : launch_typed<_Float16>(p, a, s);
 }
 
+namespace {
+// event pair / capture objects released on every return path
+struct EventPair {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+};
+struct GraphHolder {
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; hipStream_t own = nullptr;
+    ~GraphHolder()
+    {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (own) (void)hipStreamDestroy(own);
+    }
+};
+}  // namespace
+
 int time_spmv(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, double *wall_ms, double *event_ms)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     for (int i = 0; i < warmup; ++i) if (int rc = launch_spmv(p, dX, dY, stream)) return rc;
     HIP_TRY(hipStreamSynchronize(s));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    EventPair ev;
+    HIP_TRY(hipEventCreate(&ev.e0));
+    HIP_TRY(hipEventCreate(&ev.e1));
     const auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY(hipEventRecord(e0, s));
+    HIP_TRY(hipEventRecord(ev.e0, s));
     for (int i = 0; i < iters; ++i) if (int rc = launch_spmv(p, dX, dY, stream)) return rc;
-    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipEventRecord(ev.e1, s));
     HIP_TRY(hipStreamSynchronize(s));
     const auto t1 = std::chrono::steady_clock::now();
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
     if (iters > 0) {
         if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / iters;
         if (event_ms) *event_ms = (double)ms / iters;
@@ -822,36 +837,33 @@ int time_spmv(Plan &p, const void *dX, void *dY, void *stream, int warmup, int i
 int time_spmv_graph(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, int batch, double *wall_ms, double *event_ms)
 {
     if (batch <= 0) batch = 1;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    hipStream_t cap = nullptr;
-    const bool own = (s == nullptr);            // the legacy null stream cannot be captured
-    if (own) { HIP_TRY(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking)); } else cap = s;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
+    hipStream_t cap = static_cast<hipStream_t>(stream);
+    GraphHolder g;
+    if (cap == nullptr) {                       // the legacy null stream cannot be captured
+        HIP_TRY(hipStreamCreateWithFlags(&g.own, hipStreamNonBlocking));
+        cap = g.own;
+    }
     HIP_TRY(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
     int rc = DASP_OK;
     for (int i = 0; i < batch && rc == DASP_OK; ++i) rc = launch_spmv(p, dX, dY, cap);
-    hipError_t ee = hipStreamEndCapture(cap, &graph);
+    const hipError_t ee = hipStreamEndCapture(cap, &g.graph);      // always end the capture, even after a failed launch
     if (rc != DASP_OK) return rc;
     HIP_TRY(ee);
-    HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HIP_TRY(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
     const int reps = (iters + batch - 1) / batch, wreps = (warmup + batch - 1) / batch;
-    for (int i = 0; i < wreps; ++i) HIP_TRY(hipGraphLaunch(exec, cap));
+    for (int i = 0; i < wreps; ++i) HIP_TRY(hipGraphLaunch(g.exec, cap));
     HIP_TRY(hipStreamSynchronize(cap));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
+    EventPair ev;
+    HIP_TRY(hipEventCreate(&ev.e0));
+    HIP_TRY(hipEventCreate(&ev.e1));
     const auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY(hipEventRecord(e0, cap));
-    for (int i = 0; i < reps; ++i) HIP_TRY(hipGraphLaunch(exec, cap));
-    HIP_TRY(hipEventRecord(e1, cap));
+    HIP_TRY(hipEventRecord(ev.e0, cap));
+    for (int i = 0; i < reps; ++i) HIP_TRY(hipGraphLaunch(g.exec, cap));
+    HIP_TRY(hipEventRecord(ev.e1, cap));
     HIP_TRY(hipStreamSynchronize(cap));
     const auto t1 = std::chrono::steady_clock::now();
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
-    if (own) (void)hipStreamDestroy(cap);
+    HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
     const double n = (double)reps * batch;
     if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / n;
     if (event_ms) *event_ms = (double)ms / n;
