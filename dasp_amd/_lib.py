@@ -98,6 +98,8 @@ def lib():
     L.dasp_csr_save.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.dasp_csr_load.argtypes = [C.c_char_p, C.c_int, ip, ip, ip, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(vp)]
     L.dasp_plan_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.POINTER(Options)]
+    L.dasp_plan_create_device.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.POINTER(Options)]
+    L.dasp_plan_download_array.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     L.dasp_plan_destroy.argtypes = [vp]
     L.dasp_plan_save.argtypes = [vp, C.c_char_p]
     L.dasp_plan_load.argtypes = [C.POINTER(vp), C.c_char_p]
@@ -132,6 +134,6 @@ def check(rc):
 
 EXPORTS = (
     "dasp_last_error dasp_version dasp_mmio_allinone_f64 dasp_mmio_allinone_f16 dasp_free dasp_csr_save dasp_csr_load dasp_options_default "
-    "dasp_plan_create dasp_plan_destroy dasp_plan_save dasp_plan_load dasp_plan_order dasp_plan_stats dasp_plan_y_order dasp_plan_x_len dasp_plan_host_array dasp_plan_upload "
+    "dasp_plan_create dasp_plan_create_device dasp_plan_download_array dasp_plan_destroy dasp_plan_save dasp_plan_load dasp_plan_order dasp_plan_stats dasp_plan_y_order dasp_plan_x_len dasp_plan_host_array dasp_plan_upload "
     "dasp_plan_drop_host dasp_plan_spmv dasp_plan_time dasp_plan_time_graph dasp_spmv_all_f64 dasp_spmv_all_f16 dasp_partition_rows "
     "dasp_selftest_mfma dasp_synth_dims dasp_synth_row_lengths dasp_synth_rows").split()

@@ -109,6 +109,35 @@ class Plan:
         self.y_order = y_order
         self.x_len = self.colA if part_bounds is None else (self._pb.size - 1) * int(part_stride)
 
+    @classmethod
+    def from_device(cls, d_row_ptr, d_col_idx, d_val, rowA, colA, nnzA, precision=64, threshold=0.75, block_longest=256,
+                    y_order=Y_PERMUTED, long_piece=0, part_bounds=None, part_stride=0, x_window=0, row_window=0, cid16=0):
+        """Plan from a CSR that already lives on the GPU (integer device addresses): packed by kernels, comes back uploaded."""
+        L = _lib.lib()
+        self = cls.__new__(cls)
+        self.precision, self.rowA, self.colA, self.nnzA = precision, int(rowA), int(colA), int(nnzA)
+        opt = Options()
+        L.dasp_options_default(C.byref(opt))
+        opt.threshold, opt.block_longest, opt.y_order, opt.long_piece = threshold, block_longest, y_order, long_piece
+        opt.x_window, opt.row_window, opt.cid16 = x_window, row_window, cid16
+        self._pb = None
+        if part_bounds is not None:
+            self._pb = np.ascontiguousarray(part_bounds, np.int32)
+            opt.n_parts, opt.part_stride = self._pb.size - 1, int(part_stride)
+            opt.part_bounds = self._pb.ctypes.data_as(C.POINTER(C.c_int))
+        self._h = C.c_void_p()
+        _lib.check(L.dasp_plan_create_device(C.byref(self._h), precision, self.rowA, self.colA, self.nnzA, C.c_void_p(d_row_ptr),
+                                             C.c_void_p(d_col_idx), C.c_void_p(d_val), C.byref(opt)))
+        self.y_order = y_order
+        self.x_len = int(L.dasp_plan_x_len(self._h))
+        return self
+
+    def device_array(self, name, count, dtype):
+        """Download one nnz-sized packed array from the device arena (dasp_plan_download_array)."""
+        out = np.empty(count, dtype)
+        _lib.check(_lib.lib().dasp_plan_download_array(self._h, name.encode(), _vp(out), out.nbytes))
+        return out
+
     def save(self, path):
         """Write the packed plan to `path` (dasp_plan_save)."""
         _lib.check(_lib.lib().dasp_plan_save(self._h, os.fsencode(path)))

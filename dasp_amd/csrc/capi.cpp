@@ -8,6 +8,7 @@
 #include <new>
 #include <string>
 #include <sys/stat.h>
+#include <vector>
 
 #include "plan.hpp"
 
@@ -22,6 +23,7 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream);
 int time_spmv(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, double *wall_ms, double *event_ms);
 int time_spmv_graph(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, int batch, double *wall_ms, double *event_ms);
 int selftest_mfma();
+int download_array(Plan &p, const char *name, void *dst, size_t bytes);
 }  // namespace dasp
 
 using namespace dasp;
@@ -103,6 +105,48 @@ int dasp_plan_create(dasp_plan_t **out, int precision, int rowA, int colA, int n
     if (rc != DASP_OK) { delete h; return rc; }
     *out = h;
     return DASP_OK;
+}
+
+// CSR already on the GPU: row pointer to the host (4(m+1) bytes), every O(rows) decision there, the nonzeros never leave the device
+int dasp_plan_create_device(dasp_plan_t **out, int precision, int rowA, int colA, int nnzA, const int *dRowPtr, const int *dColIdx,
+                            const void *dVal, const dasp_options_t *opt)
+{
+    if (!out) return DASP_ERR_ARG;
+    *out = nullptr;
+    if ((precision != 64 && precision != 16) || rowA < 0 || colA < 0 || nnzA < 0 || !dRowPtr || (nnzA > 0 && (!dColIdx || !dVal))) {
+        set_error("dasp_plan_create_device: bad arguments");
+        return DASP_ERR_ARG;
+    }
+    std::vector<int> rp((size_t)rowA + 1);
+    if (hipMemcpy(rp.data(), dRowPtr, sizeof(int) * ((size_t)rowA + 1), hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("cannot read the device row pointer (no HIP device, or not a device pointer)");
+        return DASP_ERR_HIP;
+    }
+    dasp_plan *h = new (std::nothrow) dasp_plan();
+    if (!h) return DASP_ERR_NOMEM;
+    Plan &p = h->impl;
+    p.precision = precision; p.m = rowA; p.n = colA; p.nnz = nnzA;
+    if (opt) p.opt = *opt; else dasp_options_default(&p.opt);
+    if (!(p.opt.threshold > 0)) p.opt.threshold = 0.75;
+    if (p.opt.block_longest < 6) p.opt.block_longest = 256;
+    if (p.opt.n_parts > 0) {
+        if (!p.opt.part_bounds || p.opt.part_stride <= 0) { delete h; set_error("bad column partition"); return DASP_ERR_ARG; }
+        p.part_bounds.assign(p.opt.part_bounds, p.opt.part_bounds + p.opt.n_parts + 1);
+        p.opt.part_bounds = p.part_bounds.data();
+    } else { p.opt.n_parts = 0; p.opt.part_bounds = nullptr; }
+    const DevCsr dev{dRowPtr, dColIdx, dVal};
+    int rc;
+    try { rc = build_plan(p, rp.data(), nullptr, nullptr, &dev); }
+    catch (const std::bad_alloc &) { rc = DASP_ERR_NOMEM; set_error("out of host memory"); }
+    if (rc != DASP_OK) { delete h; return rc; }
+    *out = h;
+    return DASP_OK;
+}
+
+int dasp_plan_download_array(dasp_plan_t *plan, const char *name, void *dst, size_t bytes)
+{
+    if (!plan || !name || (!dst && bytes)) return DASP_ERR_ARG;
+    return download_array(plan->impl, name, dst, bytes);
 }
 
 void dasp_plan_destroy(dasp_plan_t *plan) { delete plan; }

@@ -1,0 +1,329 @@
+// devpack.hip -- the O(nnz) half of plan creation on the GPU (dasp_plan_create_device).
+// The reference's preprocessing is serial host code (src/dasp_f64.h:499-1157; f16 times it as "dasp_pre",
+// dasp_f16.h:1444-1445).  Here, when the CSR already lives on the device, the host still takes every O(rows) decision
+// from the row pointer alone (plan.cpp) and these kernels do the O(nnz) work in place: range check of the column ids,
+// column spans of windows / chunks, and the copy of every nonzero into the packed arrays of the plan's arena --
+// the same bytes plan.cpp's host packers produce (tests compare them bit for bit).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device.hpp"
+
+namespace dasp {
+
+#define HIP_TRYP(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+            return e_ == hipErrorNoDevice ? DASP_ERR_NO_DEVICE : DASP_ERR_HIP;                 \
+        }                                                                                      \
+    } while (0)
+
+namespace {
+
+struct RemapDev {            // column remap of the row-partitioned layout (plan.cpp Remap), bounds on the device
+    const int *bounds; int n_parts, stride;
+    __device__ __forceinline__ int operator()(int c) const
+    {
+        if (n_parts <= 0) return c;
+        int lo = 0, hi = n_parts;              // last g with bounds[g] <= c
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bounds[mid] <= c) lo = mid; else hi = mid; }
+        return lo * stride + (c - bounds[lo]);
+    }
+};
+
+__device__ __forceinline__ int wave_min(int v) { for (int o = 32; o; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ int wave_max(int v) { for (int o = 32; o; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
+
+__global__ void k_validate(const int *ci, long long nnz, int ncol, int *bad)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    int any = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride) any |= (unsigned)ci[i] >= (unsigned)ncol;
+    if (any) atomicOr(bad, 1);
+}
+
+// one wave per window of R consecutive positions of ridW: min / max remapped column, nonzero count
+__global__ void k_window_spans(const int *rp, const int *ci, const int *ridW, int nmed, int R, RemapDev remap, int *lo_out, int *hi_out,
+                               long long *nnz_out, int n_windows)
+{
+    const int lane = threadIdx.x & 63, w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= n_windows) return;
+    const int a0 = w * R, a1 = min(nmed, a0 + R);
+    int lo = 2147483647, hi = -1; long long k = 0;
+    for (int i = a0; i < a1; ++i) {
+        const int r = ridW[i], b = rp[r], e = rp[r + 1];
+        for (int j = b + lane; j < e; j += 64) { const int c = remap(ci[j]); lo = min(lo, c); hi = max(hi, c); }
+        k += e - b;
+    }
+    lo = wave_min(lo); hi = wave_max(hi);
+    if (lane == 0) { lo_out[w] = lo; hi_out[w] = hi; nnz_out[w] = k; }
+}
+
+// one wave per medium block: first chunk (of the nchunks[b] the fill rule keeps) whose columns span more than 65534
+template <int K>
+__global__ void k_chunk_spans(const int *rp, const int *ci, const int *ridM, const int *lenM, const int *nchunks, int nmed, int nb,
+                              RemapDev remap, int *k16)
+{
+    const int lane = threadIdx.x & 63, b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= nb) return;
+    const int r0 = b * kMedRows, k = nchunks[b];
+    int out = k;
+    for (int c = 0; c < k; ++c) {
+        int lo = 2147483647, hi = -1;
+        // K columns x 16 rows = 16*K elements of the chunk, strided over the wave
+        for (int e = lane; e < kMedRows * K; e += 64) {
+            const int rr = e % kMedRows, kk = e / kMedRows, r = r0 + rr, i = c * K + kk;
+            if (r < nmed && i < lenM[r]) { const int col = remap(ci[rp[ridM[r]] + i]); lo = min(lo, col); hi = max(hi, col); }
+        }
+        lo = wave_min(lo); hi = wave_max(hi);
+        if (hi >= 0 && (long long)hi - lo > 65534) { out = c; break; }
+    }
+    if (lane == 0) k16[b] = out;
+}
+
+template <class T>
+__global__ void k_pack_long(const int *rp, const int *ci, const T *val, const int *ridL, const long long *startL, int nlong, RemapDev remap,
+                            T *lv, int *lc)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= nlong) return;
+    const int r = ridL[i], a0 = rp[r], len = rp[r + 1] - a0;
+    const long long at = startL[i], padded = startL[i + 1] - at;
+    for (long long j = lane; j < padded; j += 64) {
+        const bool in = j < len;
+        lv[at + j] = in ? val[a0 + j] : (T)0;
+        lc[at + j] = in ? remap(ci[a0 + j]) : -1;
+    }
+}
+
+// one wave per medium block: regular chunks in lane-linear order (+ per-chunk base and u16 offsets in cid16 mode), then tails
+template <class T, bool C16>
+__global__ void k_pack_medium(const int *rp, const int *ci, const T *val, const int *ridM, const int *lenM, const int *med_ptr,
+                              const int *irr_ptr, int nmed, int nb, RemapDev remap, T *mv, int *mc, unsigned short *mc16, int *mbase,
+                              T *iv, int *ic)
+{
+    constexpr int K = sizeof(T) == 8 ? 4 : 16, CH = kMedRows * K, VPL = CH / 64;
+    const int lane = threadIdx.x & 63, b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= nb) return;
+    const int c0 = med_ptr[b], nc = med_ptr[b + 1] - c0;
+    const int r0 = b * kMedRows;
+    const int rr = lane & 15, kq = lane >> 4, r = r0 + rr;
+    const bool row_ok = r < nmed;
+    const int a0 = row_ok ? rp[ridM[r]] : 0, len = row_ok ? lenM[r] : 0;
+    for (int c = 0; c < nc; ++c) {
+        int col[VPL]; T v[VPL];
+        int lo = 2147483647;
+#pragma unroll
+        for (int q = 0; q < VPL; ++q) {
+            // f64: lane = kk*16 + rr holds entry kk of the chunk ; f16: lane = kq*16 + rr holds entries 4kq .. 4kq+3
+            const int i = c * K + (VPL == 1 ? kq : 4 * kq + q);
+            const bool in = row_ok && i < len;
+            v[q] = in ? val[a0 + i] : (T)0;
+            col[q] = in ? remap(ci[a0 + i]) : -1;
+            if (in) lo = min(lo, col[q]);
+        }
+        const size_t at = (size_t)(c0 + c) * CH + (size_t)lane * VPL;
+        if constexpr (C16) {
+            lo = wave_min(lo);
+            if (lo == 2147483647) lo = 0;
+            if (lane == 0) mbase[c0 + c] = lo;
+#pragma unroll
+            for (int q = 0; q < VPL; ++q) { mv[at + q] = v[q]; mc16[at + q] = col[q] < 0 ? (unsigned short)0xFFFF : (unsigned short)(col[q] - lo); }
+        } else {
+#pragma unroll
+            for (int q = 0; q < VPL; ++q) { mv[at + q] = v[q]; mc[at + q] = col[q]; }
+        }
+    }
+    // irregular tail = the LAST tl entries of the row (dasp_f64.h:1094-1106); lanes kq = 0..3 of a row share the copy
+    if (row_ok) {
+        const int t0 = irr_ptr[r], tl = irr_ptr[r + 1] - t0;
+        for (int j = kq; j < tl; j += 4) { iv[t0 + j] = val[a0 + len - tl + j]; ic[t0 + j] = remap(ci[a0 + len - tl + j]); }
+    }
+}
+
+// short slabs: one thread per (slab position, k); positions past the slab's row count are pads
+template <class T>
+__global__ void k_pack_short(const int *rp, const int *ci, const T *val, const int *list, int count, int tiles, int L, long long elem_off,
+                             int SR, RemapDev remap, T *sv, int *sc)
+{
+    const long long n = (long long)tiles * SR * L;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const long long tile = e / ((long long)L * SR);
+        const int k = (int)((e / SR) % L), lr = (int)(e % SR);
+        const long long t = tile * SR + lr;
+        const bool in = t < count;
+        const int a0 = in ? rp[list[t]] : 0;
+        sv[elem_off + e] = in ? val[a0 + k] : (T)0;
+        sc[elem_off + e] = in ? remap(ci[a0 + k]) : -1;
+    }
+}
+
+// small helper: a device copy of a host vector, freed on scope exit
+template <class U>
+struct DevVec {
+    U *d = nullptr;
+    int init(const std::vector<U> &h)
+    {
+        if (h.empty()) return DASP_OK;
+        if (hipMalloc(&d, h.size() * sizeof(U)) != hipSuccess) { set_error("hipMalloc (device packing scratch)"); return DASP_ERR_HIP; }
+        if (hipMemcpy(d, h.data(), h.size() * sizeof(U), hipMemcpyHostToDevice) != hipSuccess) { set_error("hipMemcpy (device packing scratch)"); return DASP_ERR_HIP; }
+        return DASP_OK;
+    }
+    ~DevVec() { if (d) (void)hipFree(d); }
+};
+
+struct RemapHolder {
+    DevVec<int> bounds;
+    RemapDev r{nullptr, 0, 0};
+    int init(const Plan &p)
+    {
+        if (p.opt.n_parts <= 0) return DASP_OK;
+        if (int rc = bounds.init(p.part_bounds)) return rc;
+        r = RemapDev{bounds.d, p.opt.n_parts, p.opt.part_stride};
+        return DASP_OK;
+    }
+};
+
+inline int waves_grid(int units) { return (units + 3) / 4; }   // 4 waves per 256-thread workgroup
+
+}  // namespace
+
+int devpack_validate(const Plan &p, const DevCsr &d)
+{
+    if (p.nnz == 0) return DASP_OK;
+    int *bad = nullptr, h = 0;
+    HIP_TRYP(hipMalloc(&bad, sizeof(int)));
+    HIP_TRYP(hipMemset(bad, 0, sizeof(int)));
+    hipLaunchKernelGGL(k_validate, dim3(2048), dim3(256), 0, 0, d.ci, (long long)p.nnz, p.n, bad);
+    hipError_t e = hipMemcpy(&h, bad, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(bad);
+    HIP_TRYP(e);
+    return h ? DASP_ERR_ARG : DASP_OK;
+}
+
+int devpack_window_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridW, int R, int *lo, int *hi, long long *wnnz)
+{
+    const int nmed = (int)ridW.size(), nW = (nmed + R - 1) / R;
+    if (nW == 0) return DASP_OK;
+    RemapHolder rm; if (int rc = rm.init(p)) return rc;
+    DevVec<int> dr; if (int rc = dr.init(ridW)) return rc;
+    int *dlo = nullptr; long long *dn = nullptr;
+    HIP_TRYP(hipMalloc(&dlo, sizeof(int) * 2 * (size_t)nW));
+    HIP_TRYP(hipMalloc(&dn, sizeof(long long) * (size_t)nW));
+    hipLaunchKernelGGL(k_window_spans, dim3(waves_grid(nW)), dim3(256), 0, 0, d.rp, d.ci, dr.d, nmed, R, rm.r, dlo, dlo + nW, dn, nW);
+    hipError_t e1 = hipMemcpy(lo, dlo, sizeof(int) * (size_t)nW, hipMemcpyDeviceToHost);
+    hipError_t e2 = hipMemcpy(hi, dlo + nW, sizeof(int) * (size_t)nW, hipMemcpyDeviceToHost);
+    hipError_t e3 = hipMemcpy(wnnz, dn, sizeof(long long) * (size_t)nW, hipMemcpyDeviceToHost);
+    (void)hipFree(dlo); (void)hipFree(dn);
+    HIP_TRYP(e1); HIP_TRYP(e2); HIP_TRYP(e3);
+    return DASP_OK;
+}
+
+int devpack_chunk_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridM, const std::vector<int> &lenM,
+                        const std::vector<int> &nchunks, int *k16)
+{
+    const int nmed = (int)ridM.size(), nb = (nmed + kMedRows - 1) / kMedRows;
+    if (nb == 0) return DASP_OK;
+    RemapHolder rm; if (int rc = rm.init(p)) return rc;
+    DevVec<int> dr, dl, dk;
+    if (int rc = dr.init(ridM)) return rc;
+    if (int rc = dl.init(lenM)) return rc;
+    if (int rc = dk.init(nchunks)) return rc;
+    int *dout = nullptr;
+    HIP_TRYP(hipMalloc(&dout, sizeof(int) * (size_t)nb));
+    if (p.precision == 64)
+        hipLaunchKernelGGL((k_chunk_spans<4>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, dr.d, dl.d, dk.d, nmed, nb, rm.r, dout);
+    else
+        hipLaunchKernelGGL((k_chunk_spans<16>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, dr.d, dl.d, dk.d, nmed, nb, rm.r, dout);
+    hipError_t e = hipMemcpy(k16, dout, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost);
+    (void)hipFree(dout);
+    HIP_TRYP(e);
+    return DASP_OK;
+}
+
+template <class T>
+static int pack_all_typed(Plan &p, const DevCsr &d, const PackMeta &m)
+{
+    DevicePlan &dp = *p.dev;
+    char *base = static_cast<char *>(dp.arena);
+    const T *val = static_cast<const T *>(d.val);
+    RemapHolder rm; if (int rc = rm.init(p)) return rc;
+    const int nlong = (int)m.ridL->size(), nmed = (int)m.ridM->size(), nb = (nmed + kMedRows - 1) / kMedRows;
+    if (nlong > 0) {
+        DevVec<int> dr; DevVec<long long> ds;
+        if (int rc = dr.init(*m.ridL)) return rc;
+        if (int rc = ds.init(*m.startL)) return rc;
+        hipLaunchKernelGGL((k_pack_long<T>), dim3(waves_grid(nlong)), dim3(256), 0, 0, d.rp, d.ci, val, dr.d, ds.d, nlong, rm.r,
+                           reinterpret_cast<T *>(base + dp.map.long_val), reinterpret_cast<int *>(base + dp.map.long_cid));
+        HIP_TRYP(hipDeviceSynchronize());
+    }
+    if (nb > 0) {
+        DevVec<int> dr, dl;
+        if (int rc = dr.init(*m.ridM)) return rc;
+        if (int rc = dl.init(*m.lenM)) return rc;
+        T *mv = reinterpret_cast<T *>(base + dp.map.med_val), *iv = reinterpret_cast<T *>(base + dp.map.irr_val);
+        int *mc = reinterpret_cast<int *>(base + dp.map.med_cid), *ic = reinterpret_cast<int *>(base + dp.map.irr_cid);
+        unsigned short *mc16 = reinterpret_cast<unsigned short *>(base + dp.map.med_cid16);
+        int *mb = reinterpret_cast<int *>(base + dp.map.med_base);
+        if (p.cid16)
+            hipLaunchKernelGGL((k_pack_medium<T, true>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, val, dr.d, dl.d, dp.args.med_ptr,
+                               dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic);
+        else
+            hipLaunchKernelGGL((k_pack_medium<T, false>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, val, dr.d, dl.d, dp.args.med_ptr,
+                               dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic);
+        HIP_TRYP(hipDeviceSynchronize());
+    }
+    for (int g = 0; g < 4; ++g) {
+        const ShortGroup &G = p.grp[g];
+        if (G.tiles == 0) continue;
+        DevVec<int> dl;
+        if (int rc = dl.init(*m.glist[g])) return rc;
+        const long long n = (long long)G.tiles * p.geo.short_rows * G.len;
+        hipLaunchKernelGGL((k_pack_short<T>), dim3((unsigned)std::min<long long>((n + 255) / 256, 65535)), dim3(256), 0, 0, d.rp, d.ci, val,
+                           dl.d, G.count, G.tiles, G.len, G.elem_off, p.geo.short_rows, rm.r,
+                           reinterpret_cast<T *>(base + dp.map.short_val), reinterpret_cast<int *>(base + dp.map.short_cid));
+        HIP_TRYP(hipDeviceSynchronize());
+    }
+    HIP_TRYP(hipGetLastError());
+    return DASP_OK;
+}
+
+int devpack_all(Plan &p, const DevCsr &d, const PackMeta &m)
+{
+    // arena + every O(rows) array through the normal upload path (the nnz-sized regions are left unwritten) ...
+    if (int rc = upload_plan(p)) return rc;
+    // ... then the kernels above fill those regions straight from the device CSR
+    const int rc = p.precision == 64 ? pack_all_typed<double>(p, d, m) : pack_all_typed<_Float16>(p, d, m);
+    if (rc == DASP_OK) p.host_dropped = true;       // no host copies of the packed nonzeros exist
+    return rc;
+}
+
+// copy a packed array back to the host (tests; serialising a device-built plan)
+int download_array(Plan &p, const char *name, void *dst, size_t bytes)
+{
+    if (!p.dev || !p.dev->arena) { set_error("plan not on the device"); return DASP_ERR_STATE; }
+    const ArenaMap &mp = p.dev->map;
+    const size_t vb = (size_t)p.geo.vbytes;
+    struct { const char *n; size_t off, len; } tab[] = {
+        {"long_val", mp.long_val, p.cnt_long * vb}, {"long_cid", mp.long_cid, p.cnt_long * 4},
+        {"med_val", mp.med_val, p.cnt_reg * vb}, {"med_cid", mp.med_cid, p.cid16 ? 0 : p.cnt_reg * 4},
+        {"med_cid16", mp.med_cid16, p.cid16 ? p.cnt_reg * 2 : 0}, {"med_base", mp.med_base, p.cid16 ? (size_t)p.med_ptr.back() * 4 : 0},
+        {"irr_val", mp.irr_val, p.cnt_irr * vb}, {"irr_cid", mp.irr_cid, p.cnt_irr * 4},
+        {"short_val", mp.short_val, p.cnt_short * vb}, {"short_cid", mp.short_cid, p.cnt_short * 4},
+    };
+    for (auto &t : tab)
+        if (std::strcmp(t.n, name) == 0) {
+            if (bytes != t.len) { set_error(std::string("size mismatch for ") + name); return DASP_ERR_ARG; }
+            if (t.len) HIP_TRYP(hipMemcpy(dst, static_cast<char *>(p.dev->arena) + t.off, t.len, hipMemcpyDeviceToHost));
+            return DASP_OK;
+        }
+    set_error(std::string("unknown device array: ") + name);
+    return DASP_ERR_ARG;
+}
+
+}  // namespace dasp

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "plan.hpp"
+#include "device.hpp"
 
 namespace dasp {
 
@@ -35,46 +36,6 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-
-struct ShortDev {
-    int len, count, tiles, tile0;
-    long long elem_off;
-    SlotMap map;
-};
-
-struct DevArgs {
-    const void *x;
-    void *y;
-    // long
-    const void *long_val; const int *long_cid; const int *piece_ptr; const int *piece_dst; void *partial;
-    const int *multi_ptr; const int *multi_dst;
-    int n_pieces, n_multi;
-    // medium
-    const int *med_ptr; const void *med_val; const int *med_cid;
-    const unsigned short *med_cid16; const int *med_base;   // cid16 mode: u16 offsets + per-chunk base column
-    const int *irr_ptr; const void *irr_val; const int *irr_cid;
-    int n_blocks, row_block, row_long;
-    // windowed mode (LDS-staged x)
-    const int *med_dst; const int *win_cmin; const int *win_len;
-    int n_windows, blocks_per_win;
-    int wpw;   // waves per workgroup of this launch (4, or blocks_per_win in windowed mode)
-    // short
-    const void *short_val; const int *short_cid; const ShortDev *groups;
-    int n_short_tiles;
-    // permutation (DASP_Y_NATURAL only)
-    const int *order;
-    // workgroup ranges
-    int wg_long, wg_med, wg_short;
-};
-
-struct DevicePlan {
-    void *arena = nullptr;
-    size_t arena_bytes = 0;
-    DevArgs args{};
-    bool nt = false;
-    bool lds_attr_set = false;
-    int device = -1;
-};
 
 // ------------------------------------------------------------------ device helpers
 
@@ -674,6 +635,7 @@ static int require_device()
 int upload_plan(Plan &p)
 {
     if (int rc = require_device()) return rc;
+    if (p.host_dropped && p.dev) return DASP_OK;   // already on the device (packed there, or host copies released)
     if (p.host_dropped) { set_error("host arrays were dropped"); return DASP_ERR_STATE; }
     if (p.dev) { if (p.dev->arena) (void)hipFree(p.dev->arena); delete p.dev; p.dev = nullptr; }
     auto *d = new DevicePlan();
@@ -698,26 +660,29 @@ int upload_plan(Plan &p)
         if (bytes == 0) total += 256;
         return off;
     };
-    const size_t o_lv = add(p.long_val.data(), p.long_val.size());
-    const size_t o_lc = add(p.long_cid.data(), p.long_cid.size() * 4);
+    // nnz-sized arrays: sized by their element counts; a plan packed on the device has no host copy (src = nullptr)
+    auto src_of = [](const auto &v) -> const void * { return v.empty() ? nullptr : v.data(); };
+    const size_t vbytes = (size_t)p.geo.vbytes;
+    const size_t o_lv = add(src_of(p.long_val), p.cnt_long * vbytes);
+    const size_t o_lc = add(src_of(p.long_cid), p.cnt_long * 4);
     const size_t o_pp = add(p.piece_ptr.data(), p.piece_ptr.size() * 4);
     const size_t o_pd = add(p.piece_dst.data(), p.piece_dst.size() * 4);
     const size_t o_mp = add(p.multi_ptr.data(), p.multi_ptr.size() * 4);
     const size_t o_md = add(p.multi_dst.data(), p.multi_dst.size() * 4);
     const size_t o_part = add(nullptr, part_bytes);
     const size_t o_mptr = add(p.med_ptr.data(), p.med_ptr.size() * 4);
-    const size_t o_mv = add(p.med_val.data(), p.med_val.size());
-    const size_t o_mc = add(p.med_cid.data(), p.med_cid.size() * 4);
-    const size_t o_mc16 = add(p.med_cid16.data(), p.med_cid16.size() * 2);
-    const size_t o_mb = add(p.med_base.data(), p.med_base.size() * 4);
+    const size_t o_mv = add(src_of(p.med_val), p.cnt_reg * vbytes);
+    const size_t o_mc = add(src_of(p.med_cid), p.cid16 ? 0 : p.cnt_reg * 4);
+    const size_t o_mc16 = add(src_of(p.med_cid16), p.cid16 ? p.cnt_reg * 2 : 0);
+    const size_t o_mb = add(src_of(p.med_base), p.cid16 ? (size_t)p.med_ptr.back() * 4 : 0);
     const size_t o_ip = add(p.irr_ptr.data(), p.irr_ptr.size() * 4);
-    const size_t o_iv = add(p.irr_val.data(), p.irr_val.size());
-    const size_t o_ic = add(p.irr_cid.data(), p.irr_cid.size() * 4);
+    const size_t o_iv = add(src_of(p.irr_val), p.cnt_irr * vbytes);
+    const size_t o_ic = add(src_of(p.irr_cid), p.cnt_irr * 4);
     const size_t o_mdst = add(p.med_dst.data(), p.med_dst.size() * 4);
     const size_t o_wc = add(p.win_cmin.data(), p.win_cmin.size() * 4);
     const size_t o_wl = add(p.win_len.data(), p.win_len.size() * 4);
-    const size_t o_sv = add(p.short_val.data(), p.short_val.size());
-    const size_t o_sc = add(p.short_cid.data(), p.short_cid.size() * 4);
+    const size_t o_sv = add(src_of(p.short_val), p.cnt_short * vbytes);
+    const size_t o_sc = add(src_of(p.short_cid), p.cnt_short * 4);
     const size_t o_g = add(groups.data(), groups.size() * sizeof(ShortDev));
     const size_t o_ord = add(natural ? p.order.data() : nullptr, natural ? p.order.size() * 4 : 0);
 
@@ -727,6 +692,8 @@ int upload_plan(Plan &p)
     for (const Item &it : items)
         if (it.src && it.bytes) HIP_TRY(hipMemcpy(base + it.off, it.src, it.bytes, hipMemcpyHostToDevice));
 
+    d->map.long_val = o_lv; d->map.long_cid = o_lc; d->map.med_val = o_mv; d->map.med_cid = o_mc; d->map.med_cid16 = o_mc16;
+    d->map.med_base = o_mb; d->map.irr_val = o_iv; d->map.irr_cid = o_ic; d->map.short_val = o_sv; d->map.short_cid = o_sc;
     DevArgs &a = d->args;
     a.long_val = base + o_lv; a.long_cid = (const int *)(base + o_lc);
     a.piece_ptr = (const int *)(base + o_pp); a.piece_dst = (const int *)(base + o_pd);

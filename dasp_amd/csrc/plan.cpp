@@ -59,7 +59,7 @@ struct Remap {
 }  // namespace
 
 template <class T>
-static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
+static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const DevCsr *dev)
 {
     using clk = std::chrono::steady_clock;
     const auto t_begin = clk::now();
@@ -84,7 +84,8 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
             for (long long i = b; i < e; ++i) if (rp[i + 1] < rp[i]) { bad = 1; return; }
         });
         const int ncol = p.n;
-        parallel_for(nnz, threads, 1 << 18, [&](long long b, long long e) {
+        if (dev) { if (!bad && devpack_validate(p, *dev) != DASP_OK) bad = 2; }
+        else parallel_for(nnz, threads, 1 << 18, [&](long long b, long long e) {
             for (long long i = b; i < e; ++i) if ((unsigned)ci[i] >= (unsigned)ncol) { bad = 2; return; }
         });
         if (bad) { set_error(bad == 1 ? "csrRowPtr not monotone" : "column index out of range"); return DASP_ERR_ARG; }
@@ -168,6 +169,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
 
     lap("order_rid");
     // ---- long rows: compact, padded to kLongAlign; one wave per piece
+    std::vector<long long> startL;
     int piece = p.opt.long_piece > 0 ? p.opt.long_piece : 1024;
     if (p.opt.long_piece <= 0 && nnz_long <= 2000000) {
         // few long nonzeros (launch-bound matrices): one piece per row, so that the second launch (long_reduce) disappears;
@@ -185,8 +187,12 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
         }
         const long long total = start[nlong];
         if (total >= (1LL << 31)) { set_error("long-row segment exceeds 2^31 elements"); return DASP_ERR_ARG; }
+        p.cnt_long = (size_t)total;
+        startL = start;
+        if (!dev) {
         p.long_val.resize((size_t)total * sizeof(T));          // not zero-filled: rows + their pads are written below
         p.long_cid.resize((size_t)total);
+        }
         p.piece_ptr.clear(); p.piece_dst.clear(); p.multi_ptr.assign(1, 0); p.multi_dst.clear();
         int n_partial = 0;
         for (int i = 0; i < nlong; ++i) {
@@ -200,7 +206,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
         }
         p.piece_ptr.push_back((int)total);
         T *lv = reinterpret_cast<T *>(p.long_val.data());
-        parallel_for(nlong, threads, 64, [&](long long b, long long e) {
+        if (!dev) parallel_for(nlong, threads, 64, [&](long long b, long long e) {
             for (long long i = b; i < e; ++i) {
                 const int r = ridL[i], len = rp[r + 1] - rp[r];
                 const size_t at = (size_t)start[i];
@@ -247,7 +253,9 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
         const int nW = ceil_div(nmed, R);
         std::vector<int> cmin(nW), wlen(nW);
         std::vector<long long> wnnz(nW);
-        parallel_for(nW, threads, 8, [&](long long w0, long long w1) {
+        std::vector<int> wlo(nW), whi(nW);
+        if (dev) { if (int rc = devpack_window_spans(p, *dev, ridW, R, wlo.data(), whi.data(), wnnz.data())) return rc; }
+        else parallel_for(nW, threads, 8, [&](long long w0, long long w1) {
             for (long long w = w0; w < w1; ++w) {
                 const int a0 = (int)w * R, a1 = std::min(nmed, a0 + R);
                 int lo = 2147483647, hi = -1; long long k = 0;
@@ -256,13 +264,15 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
                     for (int j = rp[r]; j < rp[r + 1]; ++j) { const int c = remap(ci[j]); lo = std::min(lo, c); hi = std::max(hi, c); }
                     k += rp[r + 1] - rp[r];
                 }
-                lo = (lo / A) * A;
-                const long long span = (long long)hi - lo + 1;
-                wnnz[w] = k;
-                if (hi >= 0 && span * geo.vbytes <= cap_bytes) { cmin[w] = lo; wlen[w] = (int)span; }
-                else { cmin[w] = 0; wlen[w] = 0; }
+                wlo[w] = lo; whi[w] = hi; wnnz[w] = k;
             }
         });
+        for (int w = 0; w < nW; ++w) {
+            const int lo = (wlo[w] / A) * A, hi = whi[w];
+            const long long span = (long long)hi - lo + 1;
+            if (hi >= 0 && span * geo.vbytes <= cap_bytes) { cmin[w] = lo; wlen[w] = (int)span; }
+            else { cmin[w] = 0; wlen[w] = 0; }
+        }
         long long fit = 0, all = 0; int maxlen = 0;
         for (int w = 0; w < nW; ++w) { all += wnnz[w]; if (wlen[w] > 0) { fit += wnnz[w]; maxlen = std::max(maxlen, wlen[w]); } }
         window_frac = all > 0 ? (double)fit / (double)all : 0.0;
@@ -304,7 +314,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
             }
             nchunks[b] = k;
             int k16 = k;
-            if (try16) {
+            if (try16 && !dev) {
                 for (int c = 0; c < k; ++c) {
                     int lo = 2147483647, hi = -1;
                     for (int r = r0; r < r1; ++r) {
@@ -317,6 +327,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
             nchunks16[b] = k16;
         }
     });
+    if (try16 && dev) { if (int rc = devpack_chunk_spans(p, *dev, ridM, lenM, nchunks, nchunks16.data())) return rc; }
     {
         long long e32 = 0, e16 = 0;
         for (int b = 0; b < nb; ++b) { e32 += nchunks[b]; e16 += nchunks16[b]; }
@@ -343,13 +354,16 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
     }
     const long long n_reg = (long long)p.med_ptr[nb] * CH;
     const int nnz_irreg = p.irr_ptr[nmed];
+    p.cnt_reg = (size_t)n_reg; p.cnt_irr = (size_t)nnz_irreg;
+    p.med_base.assign(p.cid16 && !dev ? (size_t)p.med_ptr[nb] : 0, 0);
+    if (!dev) {
     p.med_val.resize((size_t)n_reg * sizeof(T));               // not zero-filled: each block pads its own region first
     p.med_cid.resize(p.cid16 ? 0 : (size_t)n_reg);
     p.med_cid16.resize(p.cid16 ? (size_t)n_reg : 0);
-    p.med_base.assign(p.cid16 ? (size_t)p.med_ptr[nb] : 0, 0);
     p.irr_val.resize((size_t)nnz_irreg * sizeof(T));           // fully covered by the rows' tails
     p.irr_cid.resize((size_t)nnz_irreg);
-    {
+    }
+    if (!dev) {
         T *mv = reinterpret_cast<T *>(p.med_val.data());
         T *iv = reinterpret_cast<T *>(p.irr_val.data());
         parallel_for(nb, threads, 64, [&](long long b0, long long b1) {
@@ -409,6 +423,8 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
             off += (long long)G.tiles * SR * G.len;
         }
         if (off >= (1LL << 40)) { set_error("short segment too large"); return DASP_ERR_ARG; }
+        p.cnt_short = (size_t)off;
+        if (!dev) {
         p.short_val.resize((size_t)off * sizeof(T));           // not zero-filled: only a slab's last tile has pads
         p.short_cid.resize((size_t)off);
         T *sv = reinterpret_cast<T *>(p.short_val.data());
@@ -434,9 +450,17 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
                 }
             });
         }
+        }   // !dev
     }
 
     lap("pack short");
+    if (dev) {   // the O(nnz) copies happen on the GPU; the plan comes back uploaded
+        PackMeta meta;
+        meta.ridL = &ridL; meta.startL = &startL; meta.ridM = &ridM; meta.lenM = &lenM;
+        for (int g = 0; g < kNumShortGroups; ++g) meta.glist[g] = glist[g];
+        if (int rc = devpack_all(p, *dev, meta)) return rc;
+        lap("device pack");
+    }
     // ---- stats: the reference's CSV counters (dasp_f64.h:1439-1441) + native sizes
     dasp_stats_t &s = p.stats;
     std::memset(&s, 0, sizeof s);
@@ -446,8 +470,8 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
     s.nnz_short = nnz_short; s.nnz_long = (int)nnz_long; s.nnz_irreg = nnz_irreg;
     s.origin_nnz_reg = nnz - nnz_irreg - (int)nnz_long - nnz_short;
     s.rowloop = nmed < 59990 ? 1 : (nmed < 400000 ? 2 : 4);
-    s.fill0_nnz_short = (long long)p.short_cid.size();
-    s.fill0_nnz_long = (long long)p.long_cid.size();
+    s.fill0_nnz_short = (long long)p.cnt_short;
+    s.fill0_nnz_long = (long long)p.cnt_long;
     s.fill0_nnz_reg = n_reg;
     const long long stored = s.fill0_nnz_short + s.fill0_nnz_long + s.fill0_nnz_reg + nnz_irreg;
     s.rate_fill0 = nnz > 0 ? (double)(stored - nnz) / nnz : 0.0;
@@ -473,11 +497,11 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val)
     return DASP_OK;
 }
 
-int build_plan(Plan &p, const int *rp, const int *ci, const void *val)
+int build_plan(Plan &p, const int *rp, const int *ci, const void *val, const DevCsr *dev)
 {
     p.geo = geometry_for(p.precision);
-    if (p.precision == 64) return build_impl<double>(p, rp, ci, static_cast<const double *>(val));
-    return build_impl<_Float16>(p, rp, ci, static_cast<const _Float16 *>(val));
+    if (p.precision == 64) return build_impl<double>(p, rp, ci, static_cast<const double *>(val), dev);
+    return build_impl<_Float16>(p, rp, ci, static_cast<const _Float16 *>(val), dev);
 }
 
 }  // namespace dasp

@@ -111,14 +111,32 @@ struct Plan {
     raw_vector<char> short_val;
     raw_vector<int> short_cid;
 
+    // element counts of the nnz-sized arrays (the host vectors are empty when the plan was packed on the device)
+    size_t cnt_long = 0, cnt_reg = 0, cnt_irr = 0, cnt_short = 0;
+
     bool host_dropped = false;
     DevicePlan *dev = nullptr;
 
     ~Plan();
 };
 
-// builds every host array of `p` from CSR.  T = double or _Float16.
-int build_plan(Plan &p, const int *rp, const int *ci, const void *val);
+// ---- device-side packing (dasp_plan_create_device): the CSR stays on the GPU; the host keeps doing the O(rows) decisions
+// from the row pointer alone and hands the O(nnz) work to the kernels in devpack.hip through these hooks.
+struct DevCsr { const int *rp, *ci; const void *val; };      // device pointers
+struct PackMeta {                                             // what the device packers need, in packing order
+    const std::vector<int> *ridL = nullptr; const std::vector<long long> *startL = nullptr;
+    const std::vector<int> *ridM = nullptr, *lenM = nullptr;
+    const std::vector<int> *glist[kNumShortGroups] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+int devpack_validate(const Plan &p, const DevCsr &d);
+int devpack_window_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridW, int R, int *lo, int *hi, long long *wnnz);
+int devpack_chunk_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridM, const std::vector<int> &lenM,
+                        const std::vector<int> &nchunks, int *k16);
+int devpack_all(Plan &p, const DevCsr &d, const PackMeta &m);
+
+// builds every host array of `p` from CSR.  T = double or _Float16.  With `dev` set, rp is a host copy of the row pointer,
+// ci / val are ignored and the nnz-sized arrays are produced on the device (the plan comes back uploaded).
+int build_plan(Plan &p, const int *rp, const int *ci, const void *val, const DevCsr *dev = nullptr);
 
 // loader (mmio.cpp).  val_out: malloc'd array of double or binary16.
 int load_mtx(const char *path, int precision, int *m, int *n, int *nnz, int *sym, int **rp, int **ci, void **val);

@@ -84,6 +84,8 @@ int load_plan(Plan &p, const char *path)
                       (p.cid16 ? p.med_val.size() == p.med_cid16.size() * vb : p.med_val.size() == p.med_cid.size() * vb) &&
                       p.irr_ptr.size() == (size_t)p.stats.row_block + 1 && (!p.windowed || p.med_dst.size() == (size_t)p.stats.row_block);
     if (!sane) { set_error("truncated or inconsistent plan file"); return DASP_ERR_ENTRY; }
+    p.cnt_long = p.long_cid.size(); p.cnt_irr = p.irr_cid.size(); p.cnt_short = p.short_cid.size();
+    p.cnt_reg = p.cid16 ? p.med_cid16.size() : p.med_cid.size();
     p.host_dropped = false;
     return DASP_OK;
 }

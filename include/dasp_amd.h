@@ -139,6 +139,13 @@ typedef struct dasp_stats {
 int dasp_plan_create(dasp_plan_t **plan, int precision, int rowA, int colA, int nnzA,
                      const int *csrRowPtr, const int *csrColIdx, const void *csrVal,
                      const dasp_options_t *opt /* NULL = defaults */);
+/* the same with the CSR already on the current HIP device (dRowPtr / dColIdx / dVal are device pointers): only the row
+ * pointer visits the host; the nonzeros are range-checked, scanned and packed by kernels.  The plan comes
+ * back uploaded and produces bit-identical packed arrays to dasp_plan_create. */
+int dasp_plan_create_device(dasp_plan_t **plan, int precision, int rowA, int colA, int nnzA,
+                            const int *dRowPtr, const int *dColIdx, const void *dVal, const dasp_options_t *opt);
+/* copy one nnz-sized packed array (names as dasp_plan_host_array) from the device arena to `dst` (tests, serialisation) */
+int dasp_plan_download_array(dasp_plan_t *plan, const char *name, void *dst, size_t bytes);
 void dasp_plan_destroy(dasp_plan_t *plan);
 
 /* serialised plan (no reference counterpart): every packed host array + order_rid + stats, so that a later

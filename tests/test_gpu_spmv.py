@@ -303,3 +303,46 @@ def test_bench_rank_setup_assembles_full_y(dasp, torch_cuda):
     want = np.add.reduceat(parts[0]["lengths"][ci_all].astype(np.float64), rp_all[:-1].astype(np.int64))
     got = np.concatenate([P["y"][: P["r1"] - P["r0"]].cpu().numpy() for P in parts])
     assert (got == want).all()
+
+
+NNZ_ARRAYS = ("long_val long_cid med_val med_cid med_cid16 med_base irr_val irr_cid short_val short_cid").split()
+META_ARRAYS = ("piece_ptr piece_dst multi_ptr multi_dst med_ptr irr_ptr med_dst win_cmin win_len short_groups").split()
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("kw", [dict(), dict(cid16=1), dict(cid16=-1, x_window=-1), dict(x_window=100000, y_order=1),
+                                dict(part_bounds=np.array([0, 700, 2500], np.int32), part_stride=2048, y_order=1, cid16=1)])
+@pytest.mark.parametrize("tag,builder,m,n,seed", [("mixed", util.mixed_matrix, 3000, 2500, 7), ("pairs", util.pair_heavy_matrix, 4000, 2500, 11)])
+def test_device_packed_plan_is_bit_identical(oracle, dasp, torch_cuda, prec, kw, tag, builder, m, n, seed):
+    """dasp_plan_create_device (CSR on the GPU, packed by kernels) == dasp_plan_create (host packers), array by array,
+    and the plan it returns is ready to run"""
+    torch = torch_cuda
+    dt = np.float64 if prec == 64 else np.float16
+    rp, ci, v = builder(m, n, seed, values="f16" if prec == 16 else "uniform", dtype=dt)
+    host = dasp.Plan(rp, ci, v, n, precision=prec, **kw)
+    d_rp, d_ci, d_v = torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(v).cuda()
+    dev = dasp.Plan.from_device(d_rp.data_ptr(), d_ci.data_ptr(), d_v.data_ptr(), m, n, int(rp[-1]), precision=prec, **kw)
+    hs, ds = host.stats, dev.stats
+    hs.pop("pre_ms"), ds.pop("pre_ms")
+    assert hs == ds
+    assert (host.order_rid == dev.order_rid).all()
+    for name in META_ARRAYS:
+        assert np.array_equal(host.host_array(name), dev.host_array(name)), name
+    for name in NNZ_ARRAYS:
+        h = host.host_array(name)
+        d = dev.device_array(name, h.size, h.dtype)
+        assert np.array_equal(h, d), name
+    x = (np.random.default_rng(3).uniform(0.5, 1.5, dev.x_len)).astype(dt)
+    y_h = run_spmv(torch, host.upload(), x, m, prec)
+    y_d = run_spmv(torch, dev, x, m, prec)
+    assert np.array_equal(y_h, y_d)
+
+
+def test_device_plan_rejects_bad_columns(dasp, torch_cuda):
+    torch = torch_cuda
+    rp = torch.tensor([0, 2, 3], dtype=torch.int32, device="cuda")
+    ci = torch.tensor([0, 7, 1], dtype=torch.int32, device="cuda")      # 7 >= colA
+    v = torch.ones(3, dtype=torch.float64, device="cuda")
+    with pytest.raises(dasp.DaspError) as e:
+        dasp.Plan.from_device(rp.data_ptr(), ci.data_ptr(), v.data_ptr(), 2, 3, 3)
+    assert e.value.status == -10
