@@ -193,7 +193,12 @@ long long dasp_plan_host_array(const dasp_plan_t *plan, const char *name, const 
 {
     if (!plan || !name || !ptr || !elem_bytes) return DASP_ERR_ARG;
     const Plan &p = plan->impl;
-    if (p.host_dropped && std::strcmp(name, "order") != 0) { set_error("host arrays were dropped"); return DASP_ERR_STATE; }
+    // the nnz-sized arrays exist on the host only until dasp_plan_drop_host (never, for a plan packed on the device);
+    // the O(rows) arrays and order_rid always do
+    static const char *const kBulk[] = {"long_val", "long_cid", "med_val", "med_cid", "med_cid16", "irr_val", "irr_cid", "short_val", "short_cid"};
+    if (p.host_dropped)
+        for (const char *b : kBulk)
+            if (std::strcmp(name, b) == 0) { set_error("host copy of this array was dropped (use dasp_plan_download_array)"); return DASP_ERR_STATE; }
     const int vb = p.geo.vbytes;
     auto ints = [&](const std::vector<int> &v) { *ptr = v.data(); *elem_bytes = 4; return (long long)v.size(); };
     auto vals = [&](const raw_vector<char> &v) { *ptr = v.data(); *elem_bytes = vb; return (long long)(v.size() / vb); };
@@ -213,7 +218,10 @@ long long dasp_plan_host_array(const dasp_plan_t *plan, const char *name, const 
     if (n == "irr_val") return vals(p.irr_val);
     if (n == "irr_cid") return rints(p.irr_cid);
     if (n == "med_cid16") { *ptr = p.med_cid16.data(); *elem_bytes = 2; return (long long)p.med_cid16.size(); }
-    if (n == "med_base") return ints(p.med_base);
+    if (n == "med_base") {
+        if (p.cid16 && p.med_base.empty() && p.med_ptr.back() > 0) { set_error("med_base lives on the device only (use dasp_plan_download_array)"); return DASP_ERR_STATE; }
+        return ints(p.med_base);
+    }
     if (n == "med_dst") return ints(p.med_dst);
     if (n == "win_cmin") return ints(p.win_cmin);
     if (n == "win_len") return ints(p.win_len);
