@@ -454,13 +454,6 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     }
 
     lap("pack short");
-    if (dev) {   // the O(nnz) copies happen on the GPU; the plan comes back uploaded
-        PackMeta meta;
-        meta.ridL = &ridL; meta.startL = &startL; meta.ridM = &ridM; meta.lenM = &lenM;
-        for (int g = 0; g < kNumShortGroups; ++g) meta.glist[g] = glist[g];
-        if (int rc = devpack_all(p, *dev, meta)) return rc;
-        lap("device pack");
-    }
     // ---- stats: the reference's CSV counters (dasp_f64.h:1439-1441) + native sizes
     dasp_stats_t &s = p.stats;
     std::memset(&s, 0, sizeof s);
@@ -493,6 +486,13 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     for (int v : p.win_len) s.n_windows_lds += v > 0;
     s.window_nnz_frac = window_frac;
     if (p.windowed) { const int wpw = std::min(16, p.row_window / kMedRows); s.n_workgroups = ceil_div(s.n_long_pieces, wpw) + s.n_windows + ceil_div(s.n_short_tiles, wpw); }
+    if (dev) {   // the O(nnz) copies happen on the GPU; the plan comes back uploaded
+        PackMeta meta;
+        meta.ridL = &ridL; meta.startL = &startL; meta.ridM = &ridM; meta.lenM = &lenM;
+        for (int g = 0; g < kNumShortGroups; ++g) meta.glist[g] = glist[g];
+        if (int rc = devpack_all(p, *dev, meta)) return rc;
+        lap("device pack");
+    }
     s.pre_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
     return DASP_OK;
 }
