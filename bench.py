@@ -32,9 +32,53 @@ def algorithmic_bytes(m, n, nnz, vbytes):
     return (nnz + n + m) * vbytes + nnz * 4 + (m + 1) * 4
 
 
+_REAL = {}
+
+
+def real_matrix(D, name):
+    """The real SuiteSparse file, when DASP_MTX_DIR holds <name>.mtx; pattern only: values are set to 1
+    as the reference's driver does.  Parsed once per process, with a binary CSR cache next to the file."""
+    d = os.environ.get("DASP_MTX_DIR")
+    if not d:
+        return None
+    if name not in _REAL:
+        path = os.path.join(d, name + ".mtx")
+        _REAL[name] = None
+        if os.path.exists(path):
+            cache = path + ".f64.csrbin"
+            try:
+                m, n, nnz, sym, rp, ci, v = D.csr_load(cache, 64)
+            except Exception:
+                m, n, nnz, sym, rp, ci, v = D.mmio_allinone(path, 64)
+                try:
+                    D.csr_save(cache, rp, ci, v, n, sym, 64)
+                except Exception:
+                    pass
+            _REAL[name] = (m, n, rp.astype(np.int64), ci)
+    return _REAL[name]
+
+
+def matrix_dims(D, name, scale):
+    real = real_matrix(D, name)
+    return (real[0], real[1]) if real else D.synth_dims(name, scale)
+
+
+def matrix_lengths(D, name, scale):
+    real = real_matrix(D, name)
+    return np.diff(real[2]).astype(np.int32) if real else D.synth_row_lengths(name, scale)
+
+
+def matrix_rows(D, name, scale, r0, r1, lengths):
+    real = real_matrix(D, name)
+    if real:
+        rp, ci = real[2], real[3]
+        return (rp[r0:r1 + 1] - rp[r0]).astype(np.int32), np.ascontiguousarray(ci[rp[r0]:rp[r1]])
+    return D.synth_csr(name, scale, r0, r1, lengths=lengths[r0:r1])
+
+
 def build_slice(D, name, scale, precision, r0, r1, lengths, bounds=None, stride=0, natural=False, threads=0):
-    rp, ci = D.synth_csr(name, scale, r0, r1, lengths=lengths[r0:r1])
-    rows, cols = D.synth_dims(name, scale)
+    rp, ci = matrix_rows(D, name, scale, r0, r1, lengths)
+    rows, cols = matrix_dims(D, name, scale)
     dt = np.float64 if precision == 64 else np.float16
     val = np.ones(ci.size, dt)                                  # initVec(csrValA): utils.h:93-100
     t0 = time.time()
@@ -51,8 +95,8 @@ def time_plan(torch, plan, x, y, iters, warmup):
 
 def suite_entry(torch, D, name, precision, scale, budget_s=2.0):
     """Reference protocol (100 warm-up + up to 1000 timed launches, dasp_f64.h:1285-1286) on one stand-in."""
-    rows, cols = D.synth_dims(name, scale)
-    lengths = D.synth_row_lengths(name, scale)
+    rows, cols = matrix_dims(D, name, scale)
+    lengths = matrix_lengths(D, name, scale)
     plan, rp, ci, val, pre_s = build_slice(D, name, scale, precision, 0, rows, lengths)
     nnz = int(rp[-1])
     del ci, val
@@ -85,8 +129,8 @@ def suite_entry(torch, D, name, precision, scale, budget_s=2.0):
 def setup_rank(torch, D, name, scale, prec, rank, world):
     """Everything one rank owns: its row range (equal nonzeros), the DASP plan of that slice with column ids remapped
     into the all-gather layout, x in that layout, the padded y slice and the gather buffer."""
-    rows, cols = D.synth_dims(name, scale)
-    lengths = D.synth_row_lengths(name, scale)                      # every rank: cheap, deterministic
+    rows, cols = matrix_dims(D, name, scale)
+    lengths = matrix_lengths(D, name, scale)                        # every rank: cheap, deterministic
     rp_full = np.zeros(rows + 1, np.int64)
     np.cumsum(lengths, out=rp_full[1:])
     nnz_total = int(rp_full[-1])
@@ -229,8 +273,9 @@ def main():
         "metric": "SpMV GFLOP/s (f64)" if prec == 64 else "SpMV GFLOP/s (f16)", "value": round(value, 2), "unit": "GFLOP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 6),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64" if prec == 64 else "f16 (f32 accumulate)", "data": "synthetic",
-        "config": {"workload": "%s synthetic stand-in (seeded; SuiteSparse dims/row statistics), A=1, x=1" % name,
+        "dtype": "f64" if prec == 64 else "f16 (f32 accumulate)", "data": "suitesparse" if real_matrix(D, name) else "synthetic",
+        "config": {"workload": ("%s from DASP_MTX_DIR, A=1, x=1" % name) if real_matrix(D, name) else
+                   "%s synthetic stand-in (seeded; SuiteSparse dims/row statistics), A=1, x=1" % name,
                    "rows": rows, "cols": cols, "nnz": nnz_total, "scale": scale,
                    "partition": "single GPU" if world == 1 else "row ranges by nnz + RCCL all_gather(y)",
                    "row_long": st["row_long"], "row_block": st["row_block"], "rate_fill0": round(st["rate_fill0"], 4)},
@@ -265,7 +310,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_vendor:
         # vendor comparator on the same box and matrix: rocSPARSE CSR SpMV (the reference's cuSPARSE column, main_f64.cu:18-100)
         exe = os.path.join(ROOT, "dasp_amd", "bin", "dasp_rocsparse")
-        if prec == 64 and os.path.exists(exe):
+        if prec == 64 and os.path.exists(exe) and not real_matrix(D, name):   # the comparator driver generates the stand-in itself
             import re
             import subprocess
             try:

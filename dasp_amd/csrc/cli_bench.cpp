@@ -64,9 +64,24 @@ int main(int argc, char **argv)
         for (int i = 0; i < rows; ++i) bad += reinterpret_cast<double *>(y.data())[i] != (double)(rp[order[i] + 1] - rp[order[i]]);
     dasp_stats_t s;
     dasp_plan_stats(plan, &s);
+    // the same plan packed on the GPU from a device-resident CSR (dasp_plan_create_device): preprocessing time only
+    double dev_pre = -1;
+    {
+        int *drp = nullptr, *dci = nullptr; void *dv = nullptr;
+        if (hipMalloc(&drp, 4 * ((size_t)rows + 1)) == hipSuccess && hipMalloc(&dci, 4 * (size_t)nnz + 8) == hipSuccess && hipMalloc(&dv, vb * (size_t)nnz + 8) == hipSuccess &&
+            hipMemcpy(drp, rp.data(), 4 * ((size_t)rows + 1), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dci, ci.data(), 4 * (size_t)nnz, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(dv, val.data(), vb * (size_t)nnz, hipMemcpyHostToDevice) == hipSuccess) {
+            dasp_plan_t *dp = nullptr;
+            if (dasp_plan_create_device(&dp, prec, rows, cols, nnz, drp, dci, dv, &opt) == 0) {
+                dasp_stats_t ds; dasp_plan_stats(dp, &ds); dev_pre = ds.pre_ms;
+                dasp_plan_destroy(dp);
+            }
+        }
+        if (drp) (void)hipFree(drp); if (dci) (void)hipFree(dci); if (dv) (void)hipFree(dv);
+    }
     const double balg = (double)s.data_origin1;
-    std::printf("%s scale=%g f%d rows=%d nnz=%d long=%d med=%d fill0=%.4f pre=%.1fms win=%d/%d lds=%dB c16=%d | %.4f ms (event %.4f) %.1f GFLOP/s %.1f GB/s alg = %.3f of 8 TB/s | graph: %.4f ms %.3f | mismatches=%lld\n",
-                name, scale, prec, rows, nnz, s.row_long, s.row_block, s.rate_fill0, s.pre_ms, s.n_windows_lds, s.n_windows, s.lds_bytes, s.cid16_on, wall, ev, 2.0 * nnz / (wall * 1e6),
+    std::printf("%s scale=%g f%d rows=%d nnz=%d long=%d med=%d fill0=%.4f pre=%.1fms devpre=%.1fms win=%d/%d lds=%dB c16=%d | %.4f ms (event %.4f) %.1f GFLOP/s %.1f GB/s alg = %.3f of 8 TB/s | graph: %.4f ms %.3f | mismatches=%lld\n",
+                name, scale, prec, rows, nnz, s.row_long, s.row_block, s.rate_fill0, s.pre_ms, dev_pre, s.n_windows_lds, s.n_windows, s.lds_bytes, s.cid16_on, wall, ev, 2.0 * nnz / (wall * 1e6),
                 balg / (ev * 1e6), balg / (ev * 1e6) / 8000.0, gev, balg / (gev * 1e6) / 8000.0, bad);
     (void)hipFree(dX); (void)hipFree(dY);
     dasp_plan_destroy(plan);

@@ -50,7 +50,6 @@ struct DevicePlan {
     ArenaMap map{};
     DevArgs args{};
     bool nt = false;
-    bool lds_attr_set = false;
     int device = -1;
 };
 

@@ -716,6 +716,22 @@ int upload_plan(Plan &p)
     // streamed-once matrix data bypasses the caches (the reference's ld.global.cs, dasp_f64.h:34-51)
     // only when it cannot stay resident in the 256 MiB Infinity Cache between two SpMVs anyway.
     d->nt = p.stats.data_X > (200ll << 20);
+    if (p.windowed && p.lds_bytes > 65536) {
+        // more than the default 64 KiB of dynamic LDS must be requested per kernel; done here, not in the launch path,
+        // so that dasp_plan_spmv stays free of anything a stream capture would reject
+        const int bytes = p.lds_bytes;
+        const bool c16 = p.cid16, nt = d->nt;
+        hipError_t e;
+        if (p.precision == 64) e = nt ? (c16 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<double, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+                                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<double, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
+                                      : (c16 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<double, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+                                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<double, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        else e = nt ? (c16 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<_Float16, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<_Float16, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
+                    : (c16 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<_Float16, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<_Float16, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIP_TRY(e);
+    }
     return DASP_OK;
 }
 
@@ -732,12 +748,6 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
         else if (nt && p.windowed) { M(true, false, true); } else if (nt) { M(true, false, false); } \
         else if (c16 && p.windowed) { M(false, true, true); } else if (c16) { M(false, true, false); } \
         else if (p.windowed) { M(false, false, true); } else { M(false, false, false); }
-        if (lds > 65536 && !p.dev->lds_attr_set) {   // more than the default 64 KiB of dynamic LDS must be requested per kernel
-#define DASP_ATTR(NTV, CV, WINV) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<T, NTV, CV, WINV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-            DASP_FOR_EACH(DASP_ATTR)
-#undef DASP_ATTR
-            p.dev->lds_attr_set = true;
-        }
 #define DASP_LAUNCH(NTV, CV, WINV) hipLaunchKernelGGL((dasp_spmv_kernel<T, NTV, CV, WINV>), dim3(grid), dim3(kWave * a.wpw), lds, s, a)
         DASP_FOR_EACH(DASP_LAUNCH)
 #undef DASP_LAUNCH

@@ -174,7 +174,9 @@ int dasp_plan_drop_host(dasp_plan_t *plan);
 /* one SpMV, y = A*x, asynchronous on `stream`.  dX: colA values (or the part_stride layout),
  * dY: rowA values, both device pointers of the plan's precision.
  * Replaces the launches dasp_spmv2<rowloop><<<>>> + longPart_sum<<<>>>
- * (dasp_f64.h:1291-1319 / dasp_f16.h:1548-1704). */
+ * (dasp_f64.h:1291-1319 / dasp_f16.h:1548-1704).  Only kernel launches: safe inside a hipStreamBeginCapture region.
+ * One SpMV of a given plan may be in flight at a time (rows cut into several pieces share the plan's partial-sum
+ * buffer); different plans are independent. */
 int dasp_plan_spmv(dasp_plan_t *plan, const void *dX, void *dY, void *stream);
 
 /* the reference's timing protocol (dasp_f64.h:1285-1320,1394): `warmup` untimed + `iters`
