@@ -11,7 +11,7 @@ rp, ci = D.synth_csr("Queen_4147", 0.01)
 r = np.repeat(np.arange(rows), np.diff(rp))
 keep = r >= ci                                    # lower triangle of the symmetric stand-in
 with open(os.path.join(d, "Queen_4147.mtx"), "w") as f:
-    f.write("%%MatrixMarket matrix coordinate pattern symmetric\n%d %d %d\n" % (rows, cols, int(keep.sum())))
+    f.write("%%%%MatrixMarket matrix coordinate pattern symmetric\n%d %d %d\n" % (rows, cols, int(keep.sum())))
     np.savetxt(f, np.column_stack([r[keep] + 1, ci[keep] + 1]), fmt="%d %d")
 env = dict(os.environ, DASP_MTX_DIR=d)
 out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "Queen_4147", "--steps", "50", "--no-suite", "--no-cpu-baseline"],
