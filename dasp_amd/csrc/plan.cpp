@@ -139,7 +139,6 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     const int base_s = nlong + nmed;
     const int pg = f16 ? 32 : 8;
     {
-        SlotMap lin{};  // helper
         auto linear = [](int count, int base) { SlotMap s{}; s.split = count; s.base[0] = base; s.base[1] = base; return s; };
         SlotMap m1{}, m3{};
         int b1, b13, b3, b4, b2, b0;
@@ -151,7 +150,6 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         // len-3 list: first c13 paired, rest unpaired
         m3.split = c13; m3.base[0] = b13; m3.grp[0] = pg; m3.off[0] = pg;
         m3.base[1] = b3; m3.grp[1] = 0; m3.off[1] = 0;
-        (void)lin;
         p.grp[0].len = 1; p.grp[0].count = n1_all; p.grp[0].map = m1;
         p.grp[1].len = 2; p.grp[1].count = n2; p.grp[1].map = linear(n2, b2);
         p.grp[2].len = 3; p.grp[2].count = n3_all; p.grp[2].map = m3;
