@@ -338,7 +338,10 @@ static int spmv_all_impl(int precision, const char *filename, const void *val, c
     const double gflops = (double)((long long)nnzA * 2) / (t * 1e6);        // :1395
     const long long data_X2 = s.data_X + (long long)(nnzA - colA) * (long long)vb;  // x counted per gather, :1168-1172
     const double bw1 = (double)s.data_X / (t * 1e6), bw2 = (double)data_X2 / (t * 1e6);
-    std::printf("SpMV_X:  %8.4lf ms, %8.4lf GFlop/s, %9.4lf GB/s, %9.4lf GB/s\n\n", t, gflops, bw1, bw2);   // :1398
+    std::printf("SpMV_X:  %8.4lf ms, %8.4lf GFlop/s, %9.4lf GB/s, %9.4lf GB/s\n", t, gflops, bw1, bw2);     // dasp_f64.h:1398
+    if (precision == 16)                                                                                      // dasp_f16.h:1718
+        std::printf("SpMV_X2: %8.4lf ms, %8.4lf GFlop/s, %9.4lf GB/s, %9.4lf GB/s\n", t, gflops, bw1, bw2);
+    std::printf("\n");
     std::fflush(stdout);
     struct stat st;
     if (stat("data", &st) == 0 && S_ISDIR(st.st_mode)) {
@@ -349,9 +352,10 @@ static int spmv_all_impl(int precision, const char *filename, const void *val, c
                          s.nnz_short, s.fill0_nnz_short, s.nnz_long, s.fill0_nnz_long, s.origin_nnz_reg, s.fill0_nnz_reg, s.nnz_irreg);
             if (precision == 64)
                 std::fprintf(fo, "%lf,%d,%lld,%lf,%lf,%lf,%lf,", s.rate_fill0, block_longest, s.data_X, t, gflops, bw1, bw2);
-            else
-                std::fprintf(fo, "%lf,%d,%lld,%lf,%lf,%lf,%lf,%lf,%lf,%lf,", s.rate_fill0, block_longest, s.data_X, s.pre_ms, t, gflops,
-                             bw1, bw2, t, gflops);
+            else   // dasp_f16.h:1757-1758: ..., dasp_pre, dasp_time, dasp_gflops, dasp_time_bypass, dasp_gflops_bypass, bandwidth1, bandwidth2
+                   // (one kernel here: its cache policy is chosen per plan, so the "bypass" pair repeats the same measurement)
+                std::fprintf(fo, "%lf,%d,%lld,%lf,%lf,%lf,%lf,%lf,%lf,%lf,", s.rate_fill0, block_longest, s.data_X, s.pre_ms, t, gflops, t,
+                             gflops, bw1, bw2);
             std::fclose(fo);
         }
     }
