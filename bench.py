@@ -201,12 +201,19 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the DASP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # test hooks (tests/test_gpu_spmv.py runs the N > 1 flow on a one-GPU box): DASP_BENCH_SHARE_GPU=1 puts every rank on
+    # cuda:0, DASP_BENCH_BACKEND=gloo stages the all-gather through host memory.  The driver's runs use neither.
+    share_gpu = os.environ.get("DASP_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("DASP_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(0 if share_gpu else local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     name, scale, prec = args.workload, args.scale, args.precision
     vb = prec // 8
@@ -218,8 +225,12 @@ def main():
 
     def step():
         plan.spmv(x.data_ptr(), y.data_ptr(), stream)
-        if world > 1:
+        if world > 1 and backend == "nccl":
             dist.all_gather_into_tensor(gathered, y[:stride])   # RCCL over xGMI; `gathered` has the layout x is read in
+        elif world > 1:                                          # test hook: same exchange through host memory
+            parts = [torch.empty(stride, dtype=y.dtype) for _ in range(world)]
+            dist.all_gather(parts, y[:stride].cpu())
+            gathered.copy_(torch.cat(parts))
 
     def fence():
         torch.cuda.synchronize()
@@ -239,7 +250,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     region_event_ms = ev0.elapsed_time(ev1) / args.steps
@@ -255,7 +266,7 @@ def main():
     if world > 1:
         full = torch.cat([gathered[g * stride: g * stride + int(bounds[g + 1] - bounds[g])] for g in range(world)]).double()
         ok = ok and bool((full == torch.from_numpy(lengths.astype(np.float64)).cuda()).all().item())
-        okt = torch.tensor([1 if ok else 0], device="cuda")
+        okt = torch.tensor([1 if ok else 0], device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
 

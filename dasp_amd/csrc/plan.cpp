@@ -132,7 +132,6 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         for (int L = block_longest; L >= 0; --L) { int c = bucket[L]; bucket[L] = run; run += c; }
         for (int r : ridM_in) { int L = rp[r + 1] - rp[r]; int at = bucket[L]++; ridM[at] = r; lenM[at] = L; }
     }
-    std::vector<int>().swap(ridM_in);
 
     lap("sort medium");
     // ---- output permutation (order_rid): dasp_f64.h:960-976 / dasp_f16.h:1253-1270
@@ -233,8 +232,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         // medium rows in row order, then a stable descending length sort inside each window
         std::vector<int> ridW(nmed), lenW(nmed);
         {
-            std::vector<int> rows(ridM);                       // ridM is length-sorted; recover row order
-            std::sort(rows.begin(), rows.end());
+            const std::vector<int> &rows = ridM_in;            // the medium rows in row order
             const int nW = ceil_div(nmed, R);
             parallel_for(nW, threads, 8, [&](long long w0, long long w1) {
                 std::vector<int> bucket;

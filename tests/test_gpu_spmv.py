@@ -390,3 +390,21 @@ def test_power_iteration_example_matches_scipy(dasp, torch_cuda, monkeypatch):
         ref = np.linalg.norm(y)
         x = y / ref
     assert abs(lam - ref) <= 1e-10 * ref
+
+
+def test_bench_multi_rank_flow_on_one_gpu(torch_cuda):
+    """bench.py --gpus 2 end to end (partition, per-rank plans, exchange, max-over-ranks timing, full-y check, JSON line),
+    both ranks sharing this box's single GPU and the all-gather staged through gloo: everything but RCCL itself"""
+    import json
+    import socket
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, DASP_BENCH_SHARE_GPU="1", DASP_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--scale", "0.02"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["verified"] is True and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["partition"].startswith("row ranges") and "roofline" in out and "suite" not in out
