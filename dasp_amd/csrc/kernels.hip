@@ -488,6 +488,9 @@ __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
 #ifndef DASP_XCD
 #define DASP_XCD 0
 #endif
+#ifndef DASP_BPW
+#define DASP_BPW 1
+#endif
 #ifndef DASP_LB
 #define DASP_LB 1
 #endif
@@ -518,9 +521,12 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? DASP_LB_WIN : DASP_LB) void
                 m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
             }
 #endif
-            const int b = m * kWavesPerWG + wave;
             const XGlobal<T> x{static_cast<const T *>(a.x)};
-            if (b < a.n_blocks) medium_block<T, NT, C16, 0>(a, b, lane, x);
+#pragma unroll 1
+            for (int q = 0; q < DASP_BPW; ++q) {       // DASP_BPW consecutive-by-4 blocks per wave (see upload: wg_med)
+                const int b = (m * DASP_BPW + q) * kWavesPerWG + wave;
+                if (b < a.n_blocks) medium_block<T, NT, C16, 0>(a, b, lane, x);
+            }
         } else {
             // one window per workgroup; its blocks_per_win blocks are dealt round-robin to the wpw waves
             const int w = wg - a.wg_long;
@@ -711,7 +717,7 @@ int upload_plan(Plan &p)
     a.med_cid16 = (const unsigned short *)(base + o_mc16); a.med_base = (const int *)(base + o_mb);
     a.med_dst = (const int *)(base + o_mdst); a.win_cmin = (const int *)(base + o_wc); a.win_len = (const int *)(base + o_wl);
     a.n_windows = (int)p.win_len.size(); a.blocks_per_win = p.windowed ? p.row_window / kMedRows : 0;
-    a.wg_med = p.windowed ? a.n_windows : (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG;
+    a.wg_med = p.windowed ? a.n_windows : (a.n_blocks + kWavesPerWG * DASP_BPW - 1) / (kWavesPerWG * DASP_BPW);
     a.wg_short = (a.n_short_tiles + a.wpw - 1) / a.wpw;
     // streamed-once matrix data bypasses the caches (the reference's ld.global.cs, dasp_f64.h:34-51)
     // only when it cannot stay resident in the 256 MiB Infinity Cache between two SpMVs anyway.
