@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -769,6 +770,9 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream)
 {
     if (!p.dev || !p.dev->arena) { set_error("plan not uploaded"); return DASP_ERR_STATE; }
     if (!dX || !dY) { set_error("null device pointer"); return DASP_ERR_ARG; }
+    if (p.windowed && (reinterpret_cast<uintptr_t>(dX) & 15)) {   // the window copy uses 16-byte loads from x + cmin (cmin is 16-byte granular)
+        set_error("dX must be 16-byte aligned for a plan with LDS-staged x windows"); return DASP_ERR_ARG;
+    }
     DevArgs a = p.dev->args;
     a.x = dX; a.y = dY;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -172,7 +172,7 @@ int dasp_plan_upload(dasp_plan_t *plan);
 int dasp_plan_drop_host(dasp_plan_t *plan);
 
 /* one SpMV, y = A*x, asynchronous on `stream`.  dX: colA values (or the part_stride layout),
- * dY: rowA values, both device pointers of the plan's precision.
+ * dY: rowA values, both device pointers of the plan's precision (dX 16-byte aligned when the plan uses x windows).
  * Replaces the launches dasp_spmv2<rowloop><<<>>> + longPart_sum<<<>>>
  * (dasp_f64.h:1291-1319 / dasp_f16.h:1548-1704).  Only kernel launches: safe inside a hipStreamBeginCapture region.
  * One SpMV of a given plan may be in flight at a time (rows cut into several pieces share the plan's partial-sum
