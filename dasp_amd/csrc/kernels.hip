@@ -489,8 +489,8 @@ __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
 #ifndef DASP_XCD
 #define DASP_XCD 0
 #endif
-#ifndef DASP_BPW
-#define DASP_BPW 1
+#ifndef DASP_PERSIST
+#define DASP_PERSIST 0
 #endif
 #ifndef DASP_LB
 #define DASP_LB 1
@@ -523,11 +523,10 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? DASP_LB_WIN : DASP_LB) void
             }
 #endif
             const XGlobal<T> x{static_cast<const T *>(a.x)};
+            // grid-stride over the blocks: wg_med is capped (upload_plan) so the medium range is a persistent set of workgroups
 #pragma unroll 1
-            for (int q = 0; q < DASP_BPW; ++q) {       // DASP_BPW consecutive-by-4 blocks per wave (see upload: wg_med)
-                const int b = (m * DASP_BPW + q) * kWavesPerWG + wave;
-                if (b < a.n_blocks) medium_block<T, NT, C16, 0>(a, b, lane, x);
-            }
+            for (int b = m * kWavesPerWG + wave; b < a.n_blocks; b += a.wg_med * kWavesPerWG)
+                medium_block<T, NT, C16, 0>(a, b, lane, x);
         } else {
             // one window per workgroup; its blocks_per_win blocks are dealt round-robin to the wpw waves
             const int w = wg - a.wg_long;
@@ -718,7 +717,10 @@ int upload_plan(Plan &p)
     a.med_cid16 = (const unsigned short *)(base + o_mc16); a.med_base = (const int *)(base + o_mb);
     a.med_dst = (const int *)(base + o_mdst); a.win_cmin = (const int *)(base + o_wc); a.win_len = (const int *)(base + o_wl);
     a.n_windows = (int)p.win_len.size(); a.blocks_per_win = p.windowed ? p.row_window / kMedRows : 0;
-    a.wg_med = p.windowed ? a.n_windows : (a.n_blocks + kWavesPerWG * DASP_BPW - 1) / (kWavesPerWG * DASP_BPW);
+    a.wg_med = p.windowed ? a.n_windows : (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG;
+#if DASP_PERSIST > 0
+    if (!p.windowed) a.wg_med = std::min(a.wg_med, 256 * DASP_PERSIST);   // persistent medium workgroups: DASP_PERSIST per CU
+#endif
     a.wg_short = (a.n_short_tiles + a.wpw - 1) / a.wpw;
     // streamed-once matrix data bypasses the caches (the reference's ld.global.cs, dasp_f64.h:34-51)
     // only when it cannot stay resident in the 256 MiB Infinity Cache between two SpMVs anyway.
