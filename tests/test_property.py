@@ -1,0 +1,93 @@
+"""Property-based checks of the host half of the plan (no GPU): for arbitrary small matrices and option corners, the
+native packed format decodes to exactly the CSR rows, and categories / output permutation equal the oracle's."""
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import util
+
+LENGTH_POOL = [0, 0, 1, 1, 2, 3, 3, 4, 5, 6, 8, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 255, 256, 257, 300, 1023, 1024, 1025, 2100]
+
+
+@st.composite
+def matrices(draw):
+    m = draw(st.integers(0, 260))
+    n = draw(st.sampled_from([1, 2, 7, 64, 1000, 70000, 200000]))
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    rng = np.random.default_rng(seed)
+    heavy = draw(st.sampled_from(["mixed", "short", "medium", "pairs"]))
+    pool = {"mixed": LENGTH_POOL, "short": [0, 1, 2, 3, 4, 1, 3], "medium": [5, 6, 7, 9, 12, 20, 40, 80, 200, 255],
+            "pairs": [1, 3] * 6 + [2, 4, 9]}[heavy]
+    lens = rng.choice(pool, size=m) if m else np.zeros(0, np.int64)
+    if heavy == "pairs" and m:
+        lens = np.concatenate([lens, rng.choice([1, 3], size=300)])       # enough len-1 / len-3 rows for common_13 > 0
+    rp = np.zeros(lens.size + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    band = draw(st.sampled_from([0, 50, 5000]))
+    if band and lens.size:
+        rows = np.repeat(np.arange(lens.size), lens)
+        ci = np.clip(rows * max(1, n // max(lens.size, 1)) + rng.integers(-band, band + 1, rows.size), 0, n - 1)
+    else:
+        ci = rng.integers(0, n, int(rp[-1]))
+    v = rng.integers(1, 9, int(rp[-1])).astype(np.float64) / 4.0           # exactly representable in f16
+    return rp.astype(np.int32), ci.astype(np.int32), v, n
+
+
+OPTS = st.fixed_dictionaries(dict(
+    threshold=st.sampled_from([0.75, 0.75, 0.3, 1.0]), block_longest=st.sampled_from([256, 256, 64, 16, 700]),
+    long_piece=st.sampled_from([0, 64, 256, 4096]), x_window=st.sampled_from([0, -1, 2048, 100000]),
+    row_window=st.sampled_from([0, 64, 256, 1024]), cid16=st.sampled_from([0, -1, 1]), y_order=st.sampled_from([0, 1])))
+
+
+@settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(mat=matrices(), opts=OPTS, prec=st.sampled_from([64, 16]))
+def test_packed_format_round_trips(dasp, oracle, mat, opts, prec):
+    rp, ci, v, n = mat
+    m = rp.size - 1
+    dt = np.float64 if prec == 64 else np.float16
+    plan = dasp.Plan(rp, ci, v.astype(dt), n, precision=prec, **opts)
+    # categories and the output permutation: the oracle's (reference geometry), whatever the native options are
+    P = oracle.Packed(prec, rp, ci, v, n, threshold=opts["threshold"], block_longest=opts["block_longest"])
+    st_ = plan.stats
+    for f in "row_long row_block row_zero short_row_1 short_row_2 short_row_3 short_row_4 common_13 nnz_short nnz_long".split():
+        assert st_[f] == getattr(P, f), f
+    order = plan.order_rid
+    assert (order == P.order_rid).all()
+    # the packed arrays hold every nonzero of every row exactly once, in row order
+    rows = util.decode_plan(plan)
+    assert sorted(rows) == list(range(m))
+    for slot in range(m):
+        r = order[slot]
+        cs, vs = rows[slot]
+        assert cs == ci[rp[r]:rp[r + 1]].tolist()
+        assert np.array_equal(np.asarray(vs, np.float64), v[rp[r]:rp[r + 1]])
+    stored = st_["fill0_nnz_short"] + st_["fill0_nnz_long"] + st_["fill0_nnz_reg"] + st_["nnz_irreg"]
+    assert stored >= st_["nnzA"]
+
+
+@pytest.mark.gpu
+@settings(max_examples=80, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(mat=matrices(), opts=OPTS, prec=st.sampled_from([64, 16]), from_device=st.booleans())
+def test_spmv_matches_csr_for_arbitrary_matrices(dasp, oracle, mat, opts, prec, from_device):
+    import torch
+    rp, ci, v, n = mat
+    m = rp.size - 1
+    dt = np.float64 if prec == 64 else np.float16
+    tdt = torch.float64 if prec == 64 else torch.float16
+    xh = (np.random.default_rng(int(rp[-1]) + m).integers(1, 9, n) / 8.0).astype(dt)
+    if from_device and m > 0:
+        d = [torch.from_numpy(a).cuda() for a in (rp, ci if ci.size else np.zeros(1, np.int32), v.astype(dt) if v.size else np.zeros(1, dt))]
+        plan = dasp.Plan.from_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), m, n, int(rp[-1]), precision=prec, **opts)
+    else:
+        plan = dasp.Plan(rp, ci, v.astype(dt), n, precision=prec, **opts).upload()
+    x = torch.from_numpy(xh).cuda()
+    y = torch.full((max(m, 1),), float("nan"), dtype=tdt, device="cuda")
+    plan.spmv(x.data_ptr(), y.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = y[:m].double().cpu().numpy()
+    ref = oracle.csr_spmv(rp, ci, v, xh.astype(np.float64))
+    scale = np.maximum(oracle.csr_absrow(rp, ci, v, xh.astype(np.float64)), 1e-300)
+    perm = plan.order_rid if opts["y_order"] == 0 else np.arange(m)
+    assert np.isfinite(got).all()
+    assert (np.abs(got - ref[perm]) / scale[perm]).max(initial=0.0) <= (1e-12 if prec == 64 else 1e-2)
+    plan.close()
