@@ -85,7 +85,7 @@ class Plan:
     """DASP plan: classifier + packers on the host, kernels on the current HIP device."""
 
     def __init__(self, csrRowPtr, csrColIdx, csrVal, colA, precision=64, threshold=0.75, block_longest=256,
-                 y_order=Y_PERMUTED, long_piece=0, host_threads=0, part_bounds=None, part_stride=0, x_window=0, row_window=0, cid16=0):
+                 y_order=Y_PERMUTED, long_piece=0, host_threads=0, part_bounds=None, part_stride=0, x_window=0, row_window=0, cid16=0, stream_policy=0):
         L = _lib.lib()
         self.precision = precision
         dt = _dtype(precision)
@@ -97,7 +97,7 @@ class Plan:
         L.dasp_options_default(C.byref(opt))
         opt.threshold, opt.block_longest, opt.y_order = threshold, block_longest, y_order
         opt.long_piece, opt.host_threads = long_piece, host_threads
-        opt.x_window, opt.row_window, opt.cid16 = x_window, row_window, cid16
+        opt.x_window, opt.row_window, opt.cid16, opt.stream_policy = x_window, row_window, cid16, stream_policy
         self._pb = None
         if part_bounds is not None:
             self._pb = np.ascontiguousarray(part_bounds, np.int32)
@@ -192,6 +192,10 @@ class Plan:
 
     def drop_host(self):
         _lib.check(_lib.lib().dasp_plan_drop_host(self._h))
+
+    def set_stream_policy(self, policy):
+        """0 auto, 1 plain loads (reference dasp_spmv), 2 non-temporal loads (reference dasp_spmv2 'bypass')."""
+        _lib.check(_lib.lib().dasp_plan_set_stream_policy(self._h, int(policy)))
 
     def spmv(self, dX, dY, stream=0):
         """dX, dY: integer device addresses (e.g. torch_tensor.data_ptr()); stream: hipStream_t as int."""

@@ -724,22 +724,19 @@ int upload_plan(Plan &p)
     a.wg_short = (a.n_short_tiles + a.wpw - 1) / a.wpw;
     // streamed-once matrix data bypasses the caches (the reference's ld.global.cs, dasp_f64.h:34-51)
     // only when it cannot stay resident in the 256 MiB Infinity Cache between two SpMVs anyway.
-    d->nt = p.stats.data_X > (200ll << 20);
+    d->nt = p.opt.stream_policy == 2 || (p.opt.stream_policy != 1 && p.stats.data_X > (200ll << 20));
     if (p.windowed && p.lds_bytes > 65536) {
-        // more than the default 64 KiB of dynamic LDS must be requested per kernel; done here, not in the launch path,
-        // so that dasp_plan_spmv stays free of anything a stream capture would reject
+        // more than the default 64 KiB of dynamic LDS must be requested per kernel; done here (for both cache-policy
+        // variants), not in the launch path, so that dasp_plan_spmv stays free of anything a stream capture would reject
         const int bytes = p.lds_bytes;
-        const bool c16 = p.cid16, nt = d->nt;
-        hipError_t e;
-        if (p.precision == 64) e = nt ? (c16 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<double, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
-                                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<double, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
-                                      : (c16 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<double, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
-                                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<double, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        else e = nt ? (c16 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<_Float16, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
-                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<_Float16, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
-                    : (c16 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<_Float16, false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
-                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<_Float16, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIP_TRY(e);
+        const bool c16 = p.cid16;
+        hipError_t e1, e2;
+#define DASP_ATTR(TT, NTV, CV) hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<TT, NTV, CV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+        if (p.precision == 64) { e1 = c16 ? DASP_ATTR(double, true, true) : DASP_ATTR(double, true, false); e2 = c16 ? DASP_ATTR(double, false, true) : DASP_ATTR(double, false, false); }
+        else { e1 = c16 ? DASP_ATTR(_Float16, true, true) : DASP_ATTR(_Float16, true, false); e2 = c16 ? DASP_ATTR(_Float16, false, true) : DASP_ATTR(_Float16, false, false); }
+#undef DASP_ATTR
+        HIP_TRY(e1);
+        HIP_TRY(e2);
     }
     return DASP_OK;
 }
@@ -765,6 +762,14 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
     if (a.n_multi > 0)
         hipLaunchKernelGGL((dasp_long_reduce_kernel<T>), dim3((a.n_multi + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, s, a);
     HIP_TRY(hipGetLastError());
+    return DASP_OK;
+}
+
+int set_stream_policy(Plan &p, int policy)
+{
+    if (policy < 0 || policy > 2) { set_error("stream_policy must be 0, 1 or 2"); return DASP_ERR_ARG; }
+    p.opt.stream_policy = policy;
+    if (p.dev) p.dev->nt = policy == 2 || (policy != 1 && p.stats.data_X > (200ll << 20));
     return DASP_OK;
 }
 

@@ -109,6 +109,10 @@ typedef struct dasp_options {
      * part (the rest goes to the 32-bit irregular tail).  0 = auto (on when that loses < 3 % of the regular elements),
      * -1 = off, 1 = force on. */
     int cid16;
+    /* cache policy of the streamed tiles: 0 = auto (non-temporal when the packed matrix exceeds ~200 MiB and cannot stay in
+     * the Infinity Cache anyway), 1 = plain loads (the reference's dasp_spmv, dasp_f16.h:593-1013), 2 = non-temporal loads
+     * (the reference's "bypass" kernel dasp_spmv2 with ld.global.cs, dasp_f64.h:34-51).  x gathers always use plain loads. */
+    int stream_policy;
 } dasp_options_t;
 
 void dasp_options_default(dasp_options_t *opt);
@@ -170,6 +174,9 @@ long long dasp_plan_host_array(const dasp_plan_t *plan, const char *name, const 
 int dasp_plan_upload(dasp_plan_t *plan);
 /* release the host copies of the packed arrays once uploaded (order_rid and stats stay) */
 int dasp_plan_drop_host(dasp_plan_t *plan);
+
+/* switch the cache policy of an uploaded plan (values as dasp_options_t::stream_policy); no re-upload */
+int dasp_plan_set_stream_policy(dasp_plan_t *plan, int policy);
 
 /* one SpMV, y = A*x, asynchronous on `stream`.  dX: colA values (or the part_stride layout),
  * dY: rowA values, both device pointers of the plan's precision (dX 16-byte aligned when the plan uses x windows).

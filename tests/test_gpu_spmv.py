@@ -139,7 +139,8 @@ def test_one_shot_spmv_all(oracle, dasp, torch_cuda, capfd):
         assert (order == P.order_rid).all()
         want = np.diff(rp)[order].astype(dt).astype(np.float64)
         assert (y.astype(np.float64) == want).all()
-    assert "SpMV_X:" in capfd.readouterr().out          # dasp_f64.h:1398
+    out = capfd.readouterr().out
+    assert out.count("SpMV_X:") == 2 and out.count("SpMV_X2:") == 1     # dasp_f64.h:1398 ; dasp_f16.h:1717-1718 (f16 prints both)
 
 
 def test_partitioned_x_layout(oracle, dasp, torch_cuda):
@@ -408,3 +409,20 @@ def test_bench_multi_rank_flow_on_one_gpu(torch_cuda):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["verified"] is True and out["scaling"] == "strong" and out["value"] > 0
     assert out["config"]["partition"].startswith("row ranges") and "roofline" in out and "suite" not in out
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+def test_stream_policies_give_identical_results(dasp, torch_cuda, prec):
+    """plain loads (reference dasp_spmv) vs non-temporal loads (reference "bypass" dasp_spmv2): same bits, switchable at run time"""
+    dt = np.float64 if prec == 64 else np.float16
+    rp, ci, v = util.mixed_matrix(3000, 2500, 7, values="f16" if prec == 16 else "uniform", dtype=dt)
+    x = np.random.default_rng(8).uniform(0.5, 1.5, 2500).astype(dt)
+    plan = dasp.Plan(rp, ci, v, 2500, precision=prec, stream_policy=1).upload()
+    y1 = run_spmv(torch_cuda, plan, x, 3000, prec)
+    plan.set_stream_policy(2)
+    y2 = run_spmv(torch_cuda, plan, x, 3000, prec)
+    plan.set_stream_policy(0)
+    y0 = run_spmv(torch_cuda, plan, x, 3000, prec)
+    assert np.array_equal(y1, y2) and np.array_equal(y1, y0)
+    with pytest.raises(dasp.DaspError):
+        plan.set_stream_policy(5)
