@@ -221,13 +221,14 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     p.windowed = false; p.row_window = 0; p.lds_bytes = 0;
     p.med_dst.clear(); p.win_cmin.clear(); p.win_len.clear();
     double window_frac = 0.0;
-    if (p.opt.x_window >= 0 && nmed > 0) {
+    if ((p.opt.x_window >= 0 || p.opt.x_window == -2) && nmed > 0) {
         // default window height: taller windows amortise the x copy over more rows but leave fewer workgroups
         // (A/B on the cop20k_A stand-in: 11.8 us at 512 vs 14.0 at 256 for 108 k rows; 127 us at 1024 vs 156 at 256 for 1.7 M)
         int R = p.opt.row_window > 0 ? p.opt.row_window : (nmed >= 400000 ? 1024 : (nmed >= 50000 ? 512 : 256));
         R = std::min(1024, std::max(64, (R / 64) * 64));         // <= 16 waves per workgroup, 1-4 blocks per wave
         // default cap: 80 KiB = two workgroups per CU out of gfx950's 160 KiB of LDS
-        const int cap_bytes = p.opt.x_window > 0 ? std::min(p.opt.x_window, 160 * 1024) : 80 * 1024;
+        const bool order_only = p.opt.x_window == -2;          // windowed order, no LDS staging (every window gathers from global memory)
+        const int cap_bytes = order_only ? 0 : (p.opt.x_window > 0 ? std::min(p.opt.x_window, 160 * 1024) : 80 * 1024);
         const int A = 16 / geo.vbytes;                         // window base aligned for 16-byte copies
         // medium rows in row order, then a stable descending length sort inside each window
         std::vector<int> ridW(nmed), lenW(nmed);
@@ -274,7 +275,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         window_frac = all > 0 ? (double)fit / (double)all : 0.0;
         const bool force = p.opt.x_window > 0;
         const bool worth = window_frac >= 0.5 && (double)all >= 0.5 * (double)nnz;
-        if ((force || worth) && fit > 0) {
+        if (((force || worth) && fit > 0) || order_only) {
             p.windowed = true; p.row_window = R;
             p.lds_bytes = ((maxlen * geo.vbytes + 255) / 256) * 256;
             p.win_cmin.swap(cmin); p.win_len.swap(wlen);

@@ -98,6 +98,7 @@ typedef struct dasp_options {
      * once into LDS (coalesced) and every gather of the window is served from LDS.  y still goes to the slots
      * of the reference permutation (order_rid is unchanged), through a per-row destination table.
      *   x_window: 0 = auto (on when the windows of >= half of the medium nonzeros fit), -1 = off,
+     *             -2 = windowed order without LDS staging (measurement knob: slower than either alternative),
      *             > 0 = force on with this many bytes of LDS per workgroup as the cap (<= 163840; auto uses 81920,
      *                   i.e. two workgroups per CU)
      *   row_window: rows per window, multiple of 64 up to 1024 (16 rows per block, up to 16 waves per workgroup);
