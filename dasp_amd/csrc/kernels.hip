@@ -16,6 +16,14 @@
 // Short rows (1..4 nonzeros) are uniform-length slabs: a lane owns whole rows, so the
 // segmented dot product needs no cross-lane step; cross-lane sums (long rows, stage 2)
 // use DPP row rotations + readlane.
+//
+// dasp_spmv_kernel<T, NT, C16, WIN>:
+//   NT   streamed tiles with non-temporal loads (the reference's ld.global.cs "bypass" kernel) or plain loads
+//   C16  regular medium tiles carry u16 column offsets from a per-chunk base (10 instead of 12 bytes per f64 nonzero)
+//   WIN  windowed mode: one window of rows per 1024-thread workgroup, its span of x staged once in LDS
+//        (dynamic LDS), every gather of the window served from LDS; y through med_dst
+// Experiment knobs kept as macros (DASP_XG, DASP_LB, DASP_LB_WIN, DASP_XCD, DASP_PERSIST): see DESIGN.md section 4 for
+// the same-device A/B results behind their defaults.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
