@@ -118,7 +118,7 @@ def suite_entry(torch, D, name, precision, scale, budget_s=2.0):
            "ms": round(w, 6), "event_ms": round(e, 6), "iters": iters, "gflops": round(2.0 * nnz / (w * 1e6), 2),
            "achieved_GBps": round(b_alg / (e * 1e6), 1), "frac_hbm_roofline": round(b_alg / (e * 1e6) / HBM_PEAK_GBPS, 4),
            "rate_fill0": round(st["rate_fill0"], 4), "pre_ms": round(st["pre_ms"], 1), "verified": ok,
-           "row_long": st["row_long"], "row_block": st["row_block"],
+           "col_panels": st["n_col_panels"], "row_long": st["row_long"], "row_block": st["row_block"],
            "row_short": rows - st["row_long"] - st["row_block"] - st["row_zero"]}
     plan.close()
     del x, y

@@ -23,6 +23,7 @@ class Options(C.Structure):
         ("threshold", C.c_double), ("block_longest", C.c_int), ("y_order", C.c_int), ("long_piece", C.c_int),
         ("host_threads", C.c_int), ("n_parts", C.c_int), ("part_bounds", C.POINTER(C.c_int)), ("part_stride", C.c_int),
         ("x_window", C.c_int), ("row_window", C.c_int), ("cid16", C.c_int), ("stream_policy", C.c_int),
+        ("col_panels", C.c_int),
     ]
 
 
@@ -35,7 +36,8 @@ class Stats(C.Structure):
         ("n_med_blocks", C.c_int), ("n_long_pieces", C.c_int), ("n_long_multi", C.c_int), ("n_short_tiles", C.c_int),
         ("n_workgroups", C.c_int), ("pre_ms", C.c_double),
         ("x_window_on", C.c_int), ("n_windows", C.c_int), ("n_windows_lds", C.c_int), ("lds_bytes", C.c_int),
-        ("row_window", C.c_int), ("window_nnz_frac", C.c_double), ("cid16_on", C.c_int)]
+        ("row_window", C.c_int), ("window_nnz_frac", C.c_double), ("cid16_on", C.c_int),
+        ("n_col_panels", C.c_int)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -111,6 +113,10 @@ def lib():
     L.dasp_plan_x_len.restype = C.c_longlong
     L.dasp_plan_host_array.argtypes = [vp, C.c_char_p, C.POINTER(vp), ip]
     L.dasp_plan_host_array.restype = C.c_longlong
+    L.dasp_plan_panel_count.argtypes = [vp]
+    L.dasp_plan_panel.argtypes = [vp, C.c_int]
+    L.dasp_plan_panel.restype = vp
+    L.dasp_plan_panel_range.argtypes = [vp, C.c_int, ip, ip]
     L.dasp_plan_upload.argtypes = [vp]
     L.dasp_plan_drop_host.argtypes = [vp]
     L.dasp_plan_set_stream_policy.argtypes = [vp, C.c_int]
@@ -135,6 +141,6 @@ def check(rc):
 
 EXPORTS = (
     "dasp_last_error dasp_version dasp_mmio_allinone_f64 dasp_mmio_allinone_f16 dasp_free dasp_csr_save dasp_csr_load dasp_options_default "
-    "dasp_plan_create dasp_plan_create_device dasp_plan_download_array dasp_plan_destroy dasp_plan_save dasp_plan_load dasp_plan_order dasp_plan_stats dasp_plan_y_order dasp_plan_x_len dasp_plan_host_array dasp_plan_upload "
+    "dasp_plan_create dasp_plan_create_device dasp_plan_download_array dasp_plan_destroy dasp_plan_save dasp_plan_load dasp_plan_order dasp_plan_stats dasp_plan_y_order dasp_plan_x_len dasp_plan_panel_count dasp_plan_panel dasp_plan_panel_range dasp_plan_host_array dasp_plan_upload "
     "dasp_plan_drop_host dasp_plan_set_stream_policy dasp_plan_spmv dasp_plan_time dasp_plan_time_graph dasp_spmv_all_f64 dasp_spmv_all_f16 dasp_partition_rows "
     "dasp_selftest_mfma dasp_synth_dims dasp_synth_row_lengths dasp_synth_rows").split()

@@ -85,7 +85,8 @@ class Plan:
     """DASP plan: classifier + packers on the host, kernels on the current HIP device."""
 
     def __init__(self, csrRowPtr, csrColIdx, csrVal, colA, precision=64, threshold=0.75, block_longest=256,
-                 y_order=Y_PERMUTED, long_piece=0, host_threads=0, part_bounds=None, part_stride=0, x_window=0, row_window=0, cid16=0, stream_policy=0):
+                 y_order=Y_PERMUTED, long_piece=0, host_threads=0, part_bounds=None, part_stride=0, x_window=0, row_window=0, cid16=0, stream_policy=0,
+                 col_panels=0):
         L = _lib.lib()
         self.precision = precision
         dt = _dtype(precision)
@@ -98,6 +99,7 @@ class Plan:
         opt.threshold, opt.block_longest, opt.y_order = threshold, block_longest, y_order
         opt.long_piece, opt.host_threads = long_piece, host_threads
         opt.x_window, opt.row_window, opt.cid16, opt.stream_policy = x_window, row_window, cid16, stream_policy
+        opt.col_panels = col_panels
         self._pb = None
         if part_bounds is not None:
             self._pb = np.ascontiguousarray(part_bounds, np.int32)
@@ -111,7 +113,7 @@ class Plan:
 
     @classmethod
     def from_device(cls, d_row_ptr, d_col_idx, d_val, rowA, colA, nnzA, precision=64, threshold=0.75, block_longest=256,
-                    y_order=Y_PERMUTED, long_piece=0, part_bounds=None, part_stride=0, x_window=0, row_window=0, cid16=0):
+                    y_order=Y_PERMUTED, long_piece=0, part_bounds=None, part_stride=0, x_window=0, row_window=0, cid16=0, col_panels=0):
         """Plan from a CSR that already lives on the GPU (integer device addresses): packed by kernels, comes back uploaded."""
         L = _lib.lib()
         self = cls.__new__(cls)
@@ -119,7 +121,7 @@ class Plan:
         opt = Options()
         L.dasp_options_default(C.byref(opt))
         opt.threshold, opt.block_longest, opt.y_order, opt.long_piece = threshold, block_longest, y_order, long_piece
-        opt.x_window, opt.row_window, opt.cid16 = x_window, row_window, cid16
+        opt.x_window, opt.row_window, opt.cid16, opt.col_panels = x_window, row_window, cid16, col_panels
         self._pb = None
         if part_bounds is not None:
             self._pb = np.ascontiguousarray(part_bounds, np.int32)
@@ -169,6 +171,25 @@ class Plan:
         _lib.check(_lib.lib().dasp_plan_stats(self._h, C.byref(s)))
         return s.as_dict()
 
+    @property
+    def n_panels(self):
+        return int(_lib.lib().dasp_plan_panel_count(self._h))
+
+    def panel(self, k):
+        """Borrowed view of column panel k: (Plan, col_begin, col_end).  Valid while this plan lives."""
+        L = _lib.lib()
+        h = L.dasp_plan_panel(self._h, k)
+        if not h:
+            raise _lib.DaspError(-10, L.dasp_last_error().decode("utf-8", "replace"))
+        b, e = C.c_int(), C.c_int()
+        _lib.check(L.dasp_plan_panel_range(self._h, k, C.byref(b), C.byref(e)))
+        sub = Plan.__new__(Plan)
+        sub._h, sub._pb, sub._borrowed, sub._parent = C.c_void_p(h), None, True, self
+        st = sub.stats
+        sub.precision, sub.rowA, sub.colA, sub.nnzA = st["precision"], st["rowA"], st["colA"], st["nnzA"]
+        sub.y_order, sub.x_len = Y_NATURAL, st["colA"]
+        return sub, b.value, e.value
+
     def host_array(self, name):
         ptr, eb = C.c_void_p(), C.c_int()
         n = _lib.lib().dasp_plan_host_array(self._h, name.encode(), C.byref(ptr), C.byref(eb))
@@ -215,7 +236,8 @@ class Plan:
 
     def close(self):
         if getattr(self, "_h", None):
-            _lib.lib().dasp_plan_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                _lib.lib().dasp_plan_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -12,10 +12,6 @@
 
 #include "plan.hpp"
 
-struct dasp_plan {
-    dasp::Plan impl;
-};
-
 namespace dasp {
 const char *last_error_cstr();
 int upload_plan(Plan &p);
@@ -190,6 +186,21 @@ int dasp_plan_stats(const dasp_plan_t *plan, dasp_stats_t *out)
     return DASP_OK;
 }
 
+int dasp_plan_panel_count(const dasp_plan_t *plan) { return plan ? (int)plan->impl.panels.size() : DASP_ERR_ARG; }
+
+dasp_plan_t *dasp_plan_panel(dasp_plan_t *plan, int k)
+{
+    if (!plan || k < 0 || k >= (int)plan->impl.panels.size()) { set_error("no such column panel"); return nullptr; }
+    return plan->impl.panels[(size_t)k].get();
+}
+
+int dasp_plan_panel_range(const dasp_plan_t *plan, int k, int *col_begin, int *col_end)
+{
+    if (!plan || k < 0 || k >= (int)plan->impl.panels.size() || !col_begin || !col_end) { set_error("no such column panel"); return DASP_ERR_ARG; }
+    *col_begin = plan->impl.panel_bounds[2 * (size_t)k]; *col_end = plan->impl.panel_bounds[2 * (size_t)k + 1];
+    return DASP_OK;
+}
+
 long long dasp_plan_host_array(const dasp_plan_t *plan, const char *name, const void **ptr, int *elem_bytes)
 {
     if (!plan || !name || !ptr || !elem_bytes) return DASP_ERR_ARG;
@@ -206,6 +217,7 @@ long long dasp_plan_host_array(const dasp_plan_t *plan, const char *name, const 
     auto rints = [&](const raw_vector<int> &v) { *ptr = v.data(); *elem_bytes = 4; return (long long)v.size(); };
     const std::string n(name);
     if (n == "order") return ints(p.order);
+    if (n == "dst_map") return ints(p.dst_map);
     if (n == "long_val") return vals(p.long_val);
     if (n == "long_cid") return rints(p.long_cid);
     if (n == "piece_ptr") return ints(p.piece_ptr);
@@ -259,6 +271,7 @@ int dasp_plan_drop_host(dasp_plan_t *plan)
     dropc(p.long_val); dropi(p.long_cid); dropc(p.med_val); dropi(p.med_cid); raw_vector<uint16_t>().swap(p.med_cid16);
     dropc(p.irr_val); dropi(p.irr_cid); dropc(p.short_val); dropi(p.short_cid);
     p.host_dropped = true;
+    for (auto &h : p.panels) if (int rc = dasp_plan_drop_host(h.get())) return rc;
     return DASP_OK;
 }
 

@@ -15,7 +15,7 @@
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { std::printf("usage: dasp_bench <workload> [scale] [precision] [iters] [warmup] [threshold] [long_piece]\n"); return 0; }
+    if (argc < 2) { std::printf("usage: dasp_bench <workload> [scale] [precision] [iters] [warmup] [threshold] [long_piece] [x_window] [row_window] [cid16] [col_panels]\n"); return 0; }
     const char *name = argv[1];
     const double scale = argc > 2 ? std::atof(argv[2]) : 1.0;
     const int prec = argc > 3 ? std::atoi(argv[3]) : 64;
@@ -26,6 +26,7 @@ int main(int argc, char **argv)
     const int x_window = argc > 8 ? std::atoi(argv[8]) : 0;
     const int row_window = argc > 9 ? std::atoi(argv[9]) : 0;
     const int cid16 = argc > 10 ? std::atoi(argv[10]) : 0;
+    const int col_panels = argc > 11 ? std::atoi(argv[11]) : 0;
     int rows, cols;
     CHECK(dasp_synth_dims(name, scale, &rows, &cols));
     std::vector<int> rp((size_t)rows + 1, 0);
@@ -41,7 +42,7 @@ int main(int argc, char **argv)
     else for (int i = 0; i < nnz; ++i) reinterpret_cast<uint16_t *>(val.data())[i] = 0x3C00;
     dasp_options_t opt;
     dasp_options_default(&opt);
-    opt.threshold = threshold; opt.long_piece = long_piece; opt.x_window = x_window; opt.row_window = row_window; opt.cid16 = cid16;
+    opt.threshold = threshold; opt.long_piece = long_piece; opt.x_window = x_window; opt.row_window = row_window; opt.cid16 = cid16; opt.col_panels = col_panels;
     dasp_plan_t *plan = nullptr;
     CHECK(dasp_plan_create(&plan, prec, rows, cols, nnz, rp.data(), ci.data(), val.data(), &opt));
     CHECK(dasp_plan_upload(plan));
@@ -72,7 +73,9 @@ int main(int argc, char **argv)
             hipMemcpy(drp, rp.data(), 4 * ((size_t)rows + 1), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dci, ci.data(), 4 * (size_t)nnz, hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(dv, val.data(), vb * (size_t)nnz, hipMemcpyHostToDevice) == hipSuccess) {
             dasp_plan_t *dp = nullptr;
-            if (dasp_plan_create_device(&dp, prec, rows, cols, nnz, drp, dci, dv, &opt) == 0) {
+            dasp_options_t dopt = opt;
+            dopt.col_panels = 1;                       // column panels are split on the host
+            if (dasp_plan_create_device(&dp, prec, rows, cols, nnz, drp, dci, dv, &dopt) == 0) {
                 dasp_stats_t ds; dasp_plan_stats(dp, &ds); dev_pre = ds.pre_ms;
                 dasp_plan_destroy(dp);
             }
@@ -80,8 +83,8 @@ int main(int argc, char **argv)
         if (drp) (void)hipFree(drp); if (dci) (void)hipFree(dci); if (dv) (void)hipFree(dv);
     }
     const double balg = (double)s.data_origin1;
-    std::printf("%s scale=%g f%d rows=%d nnz=%d long=%d med=%d fill0=%.4f pre=%.1fms devpre=%.1fms win=%d/%d lds=%dB c16=%d | %.4f ms (event %.4f) %.1f GFLOP/s %.1f GB/s alg = %.3f of 8 TB/s | graph: %.4f ms %.3f | mismatches=%lld\n",
-                name, scale, prec, rows, nnz, s.row_long, s.row_block, s.rate_fill0, s.pre_ms, dev_pre, s.n_windows_lds, s.n_windows, s.lds_bytes, s.cid16_on, wall, ev, 2.0 * nnz / (wall * 1e6),
+    std::printf("%s scale=%g f%d rows=%d nnz=%d long=%d med=%d fill0=%.4f pre=%.1fms devpre=%.1fms win=%d/%d lds=%dB c16=%d panels=%d | %.4f ms (event %.4f) %.1f GFLOP/s %.1f GB/s alg = %.3f of 8 TB/s | graph: %.4f ms %.3f | mismatches=%lld\n",
+                name, scale, prec, rows, nnz, s.row_long, s.row_block, s.rate_fill0, s.pre_ms, dev_pre, s.n_windows_lds, s.n_windows, s.lds_bytes, s.cid16_on, s.n_col_panels, wall, ev, 2.0 * nnz / (wall * 1e6),
                 balg / (ev * 1e6), balg / (ev * 1e6) / 8000.0, gev, balg / (gev * 1e6) / 8000.0, bad);
     (void)hipFree(dX); (void)hipFree(dY);
     dasp_plan_destroy(plan);

@@ -51,6 +51,8 @@ struct DevicePlan {
     DevArgs args{};
     bool nt = false;
     int device = -1;
+    // column-panel parent: arena = the panels' partial results, panel k at ypart + k * ypart_stride elements
+    size_t ypart_stride = 0;
 };
 
 

@@ -592,6 +592,37 @@ __global__ __launch_bounds__(256) void dasp_long_reduce_kernel(DevArgs a)
     if (lane == 0) static_cast<T *>(a.y)[a.multi_dst[i]] = (T)s;
 }
 
+// column panels (dasp_options_t::col_panels): y[i] = sum over the panels of part[k][i].  Streaming, V elements (16 bytes)
+// per thread; the partial results are read once, so they bypass the caches.
+template <class T, int V>
+__global__ __launch_bounds__(256) void dasp_panel_sum_kernel(const T *__restrict__ part, size_t stride, int np, T *__restrict__ y, int m)
+{
+    using Acc = typename Tr<T>::part_t;
+    const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
+    if (i0 >= m) return;
+    if (V > 1 && i0 + V <= m) {
+        typedef T vec_t __attribute__((ext_vector_type(V)));
+        Acc acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = (Acc)0;
+        for (int k = 0; k < np; ++k) {
+            const vec_t v = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(part + (size_t)k * stride + i0));
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += (Acc)v[j];
+        }
+        vec_t o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = (T)acc[j];
+        *reinterpret_cast<vec_t *>(y + i0) = o;
+    } else {
+        for (long long i = i0; i < m && i < i0 + V; ++i) {
+            Acc acc = (Acc)0;
+            for (int k = 0; k < np; ++k) acc += (Acc)part[(size_t)k * stride + i];
+            y[i] = (T)acc;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ MFMA lane-map self test
 __global__ void selftest_f64_kernel(double *D)
 {
@@ -655,6 +686,13 @@ int upload_plan(Plan &p)
     auto *d = new DevicePlan();
     p.dev = d;
     HIP_TRY(hipGetDevice(&d->device));
+    if (!p.panels.empty()) {   // column panels: every panel is a plan of its own; this one only owns their partial results
+        for (auto &h : p.panels) if (int rc = upload_plan(h->impl)) return rc;
+        d->ypart_stride = ((size_t)std::max(p.m, 1) + 127) & ~size_t(127);
+        d->arena_bytes = d->ypart_stride * p.panels.size() * (size_t)p.geo.vbytes;
+        HIP_TRY(hipMalloc(&d->arena, d->arena_bytes));
+        return DASP_OK;
+    }
 
     std::vector<ShortDev> groups(kNumShortGroups);
     for (int g = 0; g < kNumShortGroups; ++g) {
@@ -698,7 +736,9 @@ int upload_plan(Plan &p)
     const size_t o_sv = add(src_of(p.short_val), p.cnt_short * vbytes);
     const size_t o_sc = add(src_of(p.short_cid), p.cnt_short * 4);
     const size_t o_g = add(groups.data(), groups.size() * sizeof(ShortDev));
-    const size_t o_ord = add(natural ? p.order.data() : nullptr, natural ? p.order.size() * 4 : 0);
+    std::vector<int> ord_mapped;   // a column panel writes row r to dst_map[r] (its parent's slot), not to r
+    if (natural && !p.dst_map.empty()) { ord_mapped.resize(p.order.size()); for (size_t i = 0; i < p.order.size(); ++i) ord_mapped[i] = p.dst_map[(size_t)p.order[i]]; }
+    const size_t o_ord = add(natural ? (ord_mapped.empty() ? p.order.data() : ord_mapped.data()) : nullptr, natural ? p.order.size() * 4 : 0);
 
     HIP_TRY(hipMalloc(&d->arena, total));
     d->arena_bytes = total;
@@ -778,6 +818,9 @@ int set_stream_policy(Plan &p, int policy)
     if (policy < 0 || policy > 2) { set_error("stream_policy must be 0, 1 or 2"); return DASP_ERR_ARG; }
     p.opt.stream_policy = policy;
     if (p.dev) p.dev->nt = policy == 2 || (policy != 1 && p.stats.data_X > (200ll << 20));
+    // panels follow the whole matrix: auto means non-temporal when the sum of the panels streams from HBM
+    const int sub = policy != 0 ? policy : (p.stats.data_X > (200ll << 20) ? 2 : 1);
+    for (auto &h : p.panels) if (int rc = set_stream_policy(h->impl, sub)) return rc;
     return DASP_OK;
 }
 
@@ -785,6 +828,26 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream)
 {
     if (!p.dev || !p.dev->arena) { set_error("plan not uploaded"); return DASP_ERR_STATE; }
     if (!dX || !dY) { set_error("null device pointer"); return DASP_ERR_ARG; }
+    if (!p.panels.empty()) {
+        const size_t vb = (size_t)p.geo.vbytes, stride = p.dev->ypart_stride;
+        char *part = static_cast<char *>(p.dev->arena);
+        for (size_t k = 0; k < p.panels.size(); ++k)
+            if (int rc = launch_spmv(p.panels[k]->impl, dX, part + k * stride * vb, stream)) return rc;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const int np = (int)p.panels.size(), m = p.m;
+        const bool wide = (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
+        if (m > 0) {
+            if (p.precision == 64) {
+                if (wide) hipLaunchKernelGGL((dasp_panel_sum_kernel<double, 2>), dim3((m + 511) / 512), dim3(256), 0, s, (const double *)part, stride, np, (double *)dY, m);
+                else hipLaunchKernelGGL((dasp_panel_sum_kernel<double, 1>), dim3((m + 255) / 256), dim3(256), 0, s, (const double *)part, stride, np, (double *)dY, m);
+            } else {
+                if (wide) hipLaunchKernelGGL((dasp_panel_sum_kernel<_Float16, 8>), dim3((m + 2047) / 2048), dim3(256), 0, s, (const _Float16 *)part, stride, np, (_Float16 *)dY, m);
+                else hipLaunchKernelGGL((dasp_panel_sum_kernel<_Float16, 1>), dim3((m + 255) / 256), dim3(256), 0, s, (const _Float16 *)part, stride, np, (_Float16 *)dY, m);
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        return DASP_OK;
+    }
     if (p.windowed && (reinterpret_cast<uintptr_t>(dX) & 15)) {   // the window copy uses 16-byte loads from x + cmin (cmin is 16-byte granular)
         set_error("dX must be 16-byte aligned for a plan with LDS-staged x windows"); return DASP_ERR_ARG;
     }

@@ -58,8 +58,13 @@ struct Remap {
 };
 }  // namespace
 
+enum BuildMode { kTop = 0, kMetaOnly = 1, kPanel = 2 };   // whole plan (may choose column panels) / order+stats only / one panel
+
+template <class T> static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int P);
+static int decide_panels(const Plan &p, const int *rp, const int *ci, const Remap &remap, bool dev);
+
 template <class T>
-static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const DevCsr *dev)
+static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const DevCsr *dev, BuildMode mode = kTop)
 {
     using clk = std::chrono::steady_clock;
     const auto t_begin = clk::now();
@@ -74,11 +79,13 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     const double threshold = p.opt.threshold;
     Remap remap;
     remap.n_parts = p.opt.n_parts; remap.stride = p.opt.part_stride; remap.b = p.part_bounds.data();
+    const bool meta_only = mode == kMetaOnly;
+    const bool pack = !dev && !meta_only;          // the nnz-sized arrays are written here (else: on the device / by the panels)
 
     // ---- validate CSR (the reference trusts its input; an out-of-range column here would be a
     // wild device read, so it is an argument error instead)
     if (rp[0] != 0 || rp[m] != nnz) { set_error("csrRowPtr[0] != 0 or csrRowPtr[rowA] != nnzA"); return DASP_ERR_ARG; }
-    {
+    if (mode == kTop) {
         std::atomic<int> bad{0};
         parallel_for(m, threads, 1 << 16, [&](long long b, long long e) {
             for (long long i = b; i < e; ++i) if (rp[i + 1] < rp[i]) { bad = 1; return; }
@@ -92,6 +99,11 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     }
 
     lap("validate");
+    if (mode == kTop) {
+        const int P = decide_panels(p, rp, ci, remap, dev != nullptr);
+        if (P < 0) return P;
+        if (P >= 2) return build_panels<T>(p, rp, ci, val, P);
+    }
     // ---- classifier: same tests in the same order as dasp_f64.h:499-531
     int n1 = 0, n2 = 0, n3 = 0, n4 = 0, nz0 = 0, nlong = 0, nmed = 0;
     for (int i = 0; i < m; ++i) {
@@ -162,7 +174,9 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     for (int g = 0; g < kNumShortGroups; ++g)
         for (int t = 0; t < p.grp[g].count; ++t) p.order[p.grp[g].map.slot(t)] = (*glist[g])[t];
     const bool natural = p.opt.y_order == DASP_Y_NATURAL;
-    auto ydst = [&](int slot) { return natural ? p.order[slot] : slot; };
+    const bool mapped = natural && !p.dst_map.empty();     // a panel writing into its parent's slot order
+    auto rowdst = [&](int row) { return mapped ? p.dst_map[row] : row; };
+    auto ydst = [&](int slot) { return natural ? rowdst(p.order[slot]) : slot; };
 
     lap("order_rid");
     // ---- long rows: compact, padded to kLongAlign; one wave per piece
@@ -186,7 +200,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         if (total >= (1LL << 31)) { set_error("long-row segment exceeds 2^31 elements"); return DASP_ERR_ARG; }
         p.cnt_long = (size_t)total;
         startL = start;
-        if (!dev) {
+        if (pack) {
         p.long_val.resize((size_t)total * sizeof(T));          // not zero-filled: rows + their pads are written below
         p.long_cid.resize((size_t)total);
         }
@@ -203,7 +217,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         }
         p.piece_ptr.push_back((int)total);
         T *lv = reinterpret_cast<T *>(p.long_val.data());
-        if (!dev) parallel_for(nlong, threads, 64, [&](long long b, long long e) {
+        if (pack) parallel_for(nlong, threads, 64, [&](long long b, long long e) {
             for (long long i = b; i < e; ++i) {
                 const int r = ridL[i], len = rp[r + 1] - rp[r];
                 const size_t at = (size_t)start[i];
@@ -221,7 +235,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     p.windowed = false; p.row_window = 0; p.lds_bytes = 0;
     p.med_dst.clear(); p.win_cmin.clear(); p.win_len.clear();
     double window_frac = 0.0;
-    if ((p.opt.x_window >= 0 || p.opt.x_window == -2) && nmed > 0) {
+    if ((p.opt.x_window >= 0 || p.opt.x_window == -2) && nmed > 0 && !meta_only) {
         // default window height: taller windows amortise the x copy over more rows but leave fewer workgroups
         // (A/B on the cop20k_A stand-in: 11.8 us at 512 vs 14.0 at 256 for 108 k rows; 127 us at 1024 vs 156 at 256 for 1.7 M)
         int R = p.opt.row_window > 0 ? p.opt.row_window : (nmed >= 400000 ? 1024 : (nmed >= 50000 ? 512 : 256));
@@ -282,7 +296,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             std::vector<int> slot_of_row((size_t)m, -1);
             for (int i = 0; i < nmed; ++i) slot_of_row[ridM[i]] = nlong + i;       // reference slot of each medium row
             p.med_dst.resize(nmed);
-            for (int i = 0; i < nmed; ++i) p.med_dst[i] = natural ? ridW[i] : slot_of_row[ridW[i]];
+            for (int i = 0; i < nmed; ++i) p.med_dst[i] = natural ? rowdst(ridW[i]) : slot_of_row[ridW[i]];
             ridM.swap(ridW); lenM.swap(lenW);                                      // the packers below follow the windowed order
         }
     }
@@ -299,7 +313,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     // 65534 cannot be stored that way; in cid16 mode the regular part of its block ends there and the rest of those rows
     // joins the irregular tail (32-bit ids).  opt.cid16: 0 = auto (on when that costs < 3 % of the regular elements).
     std::vector<int> nchunks16((size_t)nb + 1, 0);
-    const bool try16 = p.opt.cid16 >= 0;
+    const bool try16 = p.opt.cid16 >= 0 && !meta_only;
     parallel_for(nb, threads, 256, [&](long long b0, long long b1) {
         for (long long b = b0; b < b1; ++b) {
             const int r0 = (int)b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
@@ -352,15 +366,15 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     const long long n_reg = (long long)p.med_ptr[nb] * CH;
     const int nnz_irreg = p.irr_ptr[nmed];
     p.cnt_reg = (size_t)n_reg; p.cnt_irr = (size_t)nnz_irreg;
-    p.med_base.assign(p.cid16 && !dev ? (size_t)p.med_ptr[nb] : 0, 0);
-    if (!dev) {
+    p.med_base.assign(p.cid16 && pack ? (size_t)p.med_ptr[nb] : 0, 0);
+    if (pack) {
     p.med_val.resize((size_t)n_reg * sizeof(T));               // not zero-filled: each block pads its own region first
     p.med_cid.resize(p.cid16 ? 0 : (size_t)n_reg);
     p.med_cid16.resize(p.cid16 ? (size_t)n_reg : 0);
     p.irr_val.resize((size_t)nnz_irreg * sizeof(T));           // fully covered by the rows' tails
     p.irr_cid.resize((size_t)nnz_irreg);
     }
-    if (!dev) {
+    if (pack) {
         T *mv = reinterpret_cast<T *>(p.med_val.data());
         T *iv = reinterpret_cast<T *>(p.irr_val.data());
         parallel_for(nb, threads, 64, [&](long long b0, long long b1) {
@@ -421,7 +435,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         }
         if (off >= (1LL << 40)) { set_error("short segment too large"); return DASP_ERR_ARG; }
         p.cnt_short = (size_t)off;
-        if (!dev) {
+        if (pack) {
         p.short_val.resize((size_t)off * sizeof(T));           // not zero-filled: only a slab's last tile has pads
         p.short_cid.resize((size_t)off);
         T *sv = reinterpret_cast<T *>(p.short_val.data());
@@ -447,7 +461,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                 }
             });
         }
-        }   // !dev
+        }   // pack
     }
 
     lap("pack short");
@@ -490,6 +504,150 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         if (int rc = devpack_all(p, *dev, meta)) return rc;
         lap("device pack");
     }
+    if (meta_only) {   // the panels own the packed data; this plan keeps order_rid + the whole-matrix counters
+        p.cnt_long = p.cnt_reg = p.cnt_irr = p.cnt_short = 0;
+        p.piece_ptr.clear(); p.piece_dst.clear(); p.multi_ptr.clear(); p.multi_dst.clear();
+        p.med_ptr.clear(); p.irr_ptr.clear();
+        for (int g = 0; g < kNumShortGroups; ++g) { p.grp[g].tiles = 0; p.grp[g].tile0 = 0; p.grp[g].elem_off = 0; }
+    }
+    s.pre_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
+    return DASP_OK;
+}
+
+// ---- column panels (opt.col_panels; DESIGN.md section 4 "column panels") -------------------------------------------------
+// auto rule: only matrices whose rows scatter over more x than an XCD's L2 holds gain from cache blocking; anything with
+// locality (FEM / stencil rows touch runs of neighbouring columns, banded rows stay inside a narrow span) is left alone.
+static int decide_panels(const Plan &p, const int *rp, const int *ci, const Remap &remap, bool dev)
+{
+    const int want = p.opt.col_panels;
+    if (want == 1 || want < 0) return 1;
+    if (want > 64) { set_error("col_panels must be <= 64"); return DASP_ERR_ARG; }
+    if (dev) {
+        if (want >= 2) { set_error("col_panels needs the CSR on the host (dasp_plan_create)"); return DASP_ERR_ARG; }
+        return 1;
+    }
+    if (!p.dst_map.empty()) return 1;
+    if (want >= 2) return p.nnz > 0 && p.m > 0 ? want : 1;
+    const long long xlen = p.opt.n_parts > 0 ? (long long)p.opt.n_parts * p.opt.part_stride : (long long)p.n;
+    const long long vb = p.geo.vbytes, xbytes = xlen * vb;
+    if (xbytes <= (6ll << 20) || p.nnz < (16 << 20) || p.m <= 0) return 1;
+    const int line_shift = vb == 8 ? 4 : 6;                       // 128-byte lines of x
+    const int S = 4096;
+    long long entries = 0, lines = 0, wide = 0;
+    std::vector<int> cols;
+    for (int s = 0; s < S; ++s) {
+        const int r = (int)((long long)p.m * s / S);
+        const int len = rp[r + 1] - rp[r];
+        if (len < 4) continue;
+        const int take = std::min(len, 512);
+        cols.resize((size_t)take);
+        for (int j = 0; j < take; ++j) cols[j] = remap(ci[rp[r] + j]);
+        std::sort(cols.begin(), cols.end());
+        int distinct = 1;
+        for (int j = 1; j < take; ++j) distinct += (cols[j] >> line_shift) != (cols[j - 1] >> line_shift);
+        entries += take; lines += distinct;
+        if ((long long)(cols[take - 1] - cols[0]) * vb > xbytes / 4) wide += take;
+    }
+    if (entries < 4096) return 1;
+    if ((double)lines <= 0.75 * (double)entries || (double)wide < 0.5 * (double)entries) return 1;
+    // panels of ~2.75 MiB of x (they must fit the 4 MiB L2 of an XCD next to the streamed tiles), and >= ~4 nonzeros per row
+    // and panel: every extra panel re-pays the per-row cost (row tables, a partial y, shorter rows with fewer gathers in
+    // flight).  Sweep on the stand-ins (tools/panel_probe.py): powerlaw_1M f64 (x 8 MB) 0.99 / 0.71 / 0.68 / 0.70 / 0.82 ms at
+    // 1 / 2 / 3 / 4 / 8 panels, ljournal-2008 f16 (x 10.7 MB) 0.95 / 0.65 / 0.61 / 0.61 / 0.71 ms.
+    const long long target = (11ll << 20) / 4;
+    const long long by_x = (xbytes + target - 1) / target;
+    const long long by_len = std::max<long long>(2, ((long long)p.nnz / p.m + 2) / 4);
+    return (int)std::max<long long>(2, std::min<long long>(std::min(by_x, by_len), 8));
+}
+
+template <class T>
+static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int P)
+{
+    using clk = std::chrono::steady_clock;
+    const auto t_begin = clk::now();
+    // whole-matrix classification: order_rid and the reference's counters are those of the unsplit matrix
+    if (int rc = build_impl<T>(p, rp, ci, val, nullptr, kMetaOnly)) return rc;
+    const int m = p.m;
+    const int threads = resolve_threads(p.opt.host_threads);
+    Remap remap;
+    remap.n_parts = p.opt.n_parts; remap.stride = p.opt.part_stride; remap.b = p.part_bounds.data();
+    const long long xlen = p.opt.n_parts > 0 ? (long long)p.opt.n_parts * p.opt.part_stride : (long long)p.n;
+    std::vector<int> bnd((size_t)P + 1);
+    for (int k = 0; k <= P; ++k) bnd[k] = (int)std::min<long long>(xlen, ((xlen * k / P + 63) / 64) * 64);   // whole 128-byte lines
+    bnd[0] = 0; bnd[P] = (int)xlen;
+    auto panel_of = [&](int c) { return (int)(std::upper_bound(bnd.begin() + 1, bnd.end(), c) - bnd.begin()) - 1; };
+
+    // split the CSR by column range: count, prefix, scatter (row-parallel; the rows' internal order is kept)
+    std::vector<std::vector<int>> rpP((size_t)P);
+    for (auto &v : rpP) v.assign((size_t)m + 1, 0);
+    parallel_for(m, threads, 1 << 12, [&](long long b, long long e) {
+        for (long long i = b; i < e; ++i)
+            for (int j = rp[i]; j < rp[i + 1]; ++j) rpP[panel_of(remap(ci[j]))][i + 1]++;
+    });
+    parallel_for(P, threads, 1, [&](long long k0, long long k1) {
+        for (long long k = k0; k < k1; ++k) { int *q = rpP[k].data(); for (int i = 0; i < m; ++i) q[i + 1] += q[i]; }
+    });
+    std::vector<raw_vector<int>> ciP((size_t)P);
+    std::vector<raw_vector<T>> valP((size_t)P);
+    for (int k = 0; k < P; ++k) { ciP[k].resize((size_t)rpP[k][m]); valP[k].resize((size_t)rpP[k][m]); }
+    parallel_for(m, threads, 1 << 12, [&](long long b, long long e) {
+        std::vector<int> cur((size_t)P);
+        for (long long i = b; i < e; ++i) {
+            for (int k = 0; k < P; ++k) cur[k] = rpP[k][i];
+            for (int j = rp[i]; j < rp[i + 1]; ++j) {
+                const int c = remap(ci[j]), k = panel_of(c), at = cur[k]++;
+                ciP[k][at] = c; valP[k][at] = val[j];
+            }
+        }
+    });
+
+    const bool natural = p.opt.y_order == DASP_Y_NATURAL;
+    std::vector<int> slot_of_row;
+    if (!natural) { slot_of_row.resize((size_t)m); for (int i = 0; i < m; ++i) slot_of_row[p.order[i]] = i; }
+    const bool streams = (long long)p.nnz * (p.geo.vbytes + 4) > (200ll << 20);
+    p.panels.clear(); p.panel_bounds.clear();
+    for (int k = 0; k < P; ++k) {
+        const int nnz_k = rpP[k][m];
+        if (nnz_k == 0) continue;                       // an empty panel adds nothing
+        std::unique_ptr<dasp_plan> h(new dasp_plan());
+        Plan &q = h->impl;
+        q.precision = p.precision; q.geo = p.geo; q.m = m; q.n = (int)xlen; q.nnz = nnz_k;
+        q.opt = p.opt;
+        q.opt.y_order = DASP_Y_NATURAL; q.opt.n_parts = 0; q.opt.part_bounds = nullptr; q.opt.part_stride = 0;
+        q.opt.col_panels = 1;
+        if (q.opt.stream_policy == 0) q.opt.stream_policy = streams ? 2 : 1;   // the policy follows the whole matrix, not one panel
+        q.dst_map = slot_of_row;
+        if (int rc = build_impl<T>(q, rpP[k].data(), ciP[k].data(), valP[k].data(), nullptr, kPanel)) return rc;
+        std::vector<int>().swap(rpP[k]); raw_vector<int>().swap(ciP[k]); raw_vector<T>().swap(valP[k]);
+        p.panels.push_back(std::move(h));
+        p.panel_bounds.push_back(bnd[k]); p.panel_bounds.push_back(bnd[k + 1]);
+    }
+
+    // native counters: sums over the panels (the classifier counters above stay those of the whole matrix)
+    dasp_stats_t &s = p.stats;
+    const long long vb = p.geo.vbytes;
+    const int K = (int)p.panels.size();
+    s.fill0_nnz_short = s.fill0_nnz_long = s.fill0_nnz_reg = 0;
+    s.n_med_blocks = s.n_long_pieces = s.n_long_multi = s.n_short_tiles = s.n_workgroups = 0;
+    s.x_window_on = s.n_windows = s.n_windows_lds = s.lds_bytes = s.row_window = s.cid16_on = 0;
+    s.window_nnz_frac = 0.0;
+    long long stored = 0, dataX = 0;
+    for (const auto &h : p.panels) {
+        const dasp_stats_t &t = h->impl.stats;
+        s.fill0_nnz_short += t.fill0_nnz_short; s.fill0_nnz_long += t.fill0_nnz_long; s.fill0_nnz_reg += t.fill0_nnz_reg;
+        stored += t.fill0_nnz_short + t.fill0_nnz_long + t.fill0_nnz_reg + t.nnz_irreg;
+        dataX += t.data_X - (long long)(m + h->impl.n) * vb;
+        s.n_med_blocks += t.n_med_blocks; s.n_long_pieces += t.n_long_pieces; s.n_long_multi += t.n_long_multi;
+        s.n_short_tiles += t.n_short_tiles; s.n_workgroups += t.n_workgroups;
+        s.x_window_on |= t.x_window_on; s.n_windows += t.n_windows; s.n_windows_lds += t.n_windows_lds;
+        s.lds_bytes = std::max(s.lds_bytes, t.lds_bytes); s.row_window = std::max(s.row_window, t.row_window);
+        s.cid16_on |= t.cid16_on;
+        s.window_nnz_frac += t.window_nnz_frac * (double)t.nnzA / (double)std::max(1, p.nnz);
+    }
+    s.rate_fill0 = p.nnz > 0 ? (double)(stored - p.nnz) / p.nnz : 0.0;
+    // packed panels + x once + every panel's partial y written and read back + y
+    s.data_X = dataX + xlen * vb + (long long)(2 * K + 1) * m * vb;
+    s.n_col_panels = K;
     s.pre_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
     return DASP_OK;
 }

@@ -71,6 +71,9 @@ struct ShortGroup {
 };
 
 struct DevicePlan;  // kernels.hip
+}  // namespace dasp
+struct dasp_plan;      // the C handle (defined at the end of this file): one Plan
+namespace dasp {
 
 struct Plan {
     int precision = 64;
@@ -114,6 +117,13 @@ struct Plan {
     // element counts of the nnz-sized arrays (the host vectors are empty when the plan was packed on the device)
     size_t cnt_long = 0, cnt_reg = 0, cnt_irr = 0, cnt_short = 0;
 
+    // column panels (opt.col_panels): this plan then holds only order / stats of the whole matrix and owns one natural-order
+    // plan per column range [panel_bounds[k], panel_bounds[k+1]); panel k writes its partial result for row r to
+    // ypart[k][dst_map[r]] (dst_map = the parent's slot of each row; empty when the parent itself is in natural order)
+    std::vector<std::unique_ptr<dasp_plan>> panels;
+    std::vector<int> panel_bounds;     // [panels.size()+1] pairs flattened: begin/end per kept panel (empty panels are dropped)
+    std::vector<int> dst_map;          // [m] set on a panel: row -> y index (instead of the row id) in natural order
+
     bool host_dropped = false;
     DevicePlan *dev = nullptr;
 
@@ -153,3 +163,7 @@ void set_error(const std::string &s);
 int resolve_threads(int requested);
 
 }  // namespace dasp
+
+struct dasp_plan {
+    dasp::Plan impl;
+};

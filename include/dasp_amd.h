@@ -114,6 +114,15 @@ typedef struct dasp_options {
      * the Infinity Cache anyway), 1 = plain loads (the reference's dasp_spmv, dasp_f16.h:593-1013), 2 = non-temporal loads
      * (the reference's "bypass" kernel dasp_spmv2 with ld.global.cs, dasp_f64.h:34-51).  x gathers always use plain loads. */
     int stream_policy;
+    /* column panels (cache blocking for gather-bound matrices, no reference counterpart).  The matrix is split into
+     * `col_panels` column ranges of equal width, each packed as its own DASP plan and launched back to back, so that
+     * the x entries a launch gathers (x_len / col_panels of them) stay in the 4 MiB L2 of every XCD; a last streaming
+     * kernel adds the panels' partial results.  order_rid and the classifier counters stay those of the whole matrix.
+     *   0 = auto (on for matrices whose rows scatter over more x than the L2 holds: x > 6 MiB, >= 16 M nonzeros,
+     *       > 75 % of a row's nonzeros on distinct 128-byte lines of x and rows spanning > x/4; host CSR only),
+     *   1 or -1 = off,  2..64 = that many panels.
+     * f16: the per-panel partial results are rounded to binary16 before they are added (in f32). */
+    int col_panels;
 } dasp_options_t;
 
 void dasp_options_default(dasp_options_t *opt);
@@ -136,6 +145,8 @@ typedef struct dasp_stats {
     int x_window_on, n_windows, n_windows_lds, lds_bytes, row_window;
     double window_nnz_frac;    /* share of the medium nonzeros whose window fits in LDS */
     int cid16_on;              /* regular medium tiles carry 16-bit column ids */
+    int n_col_panels;          /* 0 = single plan; else the number of (non-empty) column panels: the fill0_*, data_X, n_* and
+                                  window / cid16 fields are then sums (or any-of) over the panels */
 } dasp_stats_t;
 
 /* classifier + packers on the host (no GPU needed).  CSR arrays are read-only and may be
@@ -166,6 +177,13 @@ int dasp_plan_stats(const dasp_plan_t *plan, dasp_stats_t *out);
 /* dasp_y_order of the plan; number of x elements a SpMV reads (colA, or n_parts * part_stride in the partitioned layout) */
 int dasp_plan_y_order(const dasp_plan_t *plan);
 long long dasp_plan_x_len(const dasp_plan_t *plan);
+
+/* column panels of a plan built with col_panels (0 for a single plan), and a BORROWED handle to panel k: a natural-order
+ * plan over the same rows whose column ids lie in the panel's range.  The handle belongs to the parent (never destroy it);
+ * it answers the query functions (stats, host_array, ...) and dasp_plan_panel_range. */
+int dasp_plan_panel_count(const dasp_plan_t *plan);
+dasp_plan_t *dasp_plan_panel(dasp_plan_t *plan, int k);
+int dasp_plan_panel_range(const dasp_plan_t *plan, int k, int *col_begin, int *col_end);
 
 /* read-only view of a packed host array, for format tests and serialisation.
  * returns element count, or a negative dasp_status for an unknown name. */

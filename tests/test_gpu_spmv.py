@@ -426,3 +426,64 @@ def test_stream_policies_give_identical_results(dasp, torch_cuda, prec):
     assert np.array_equal(y1, y2) and np.array_equal(y1, y0)
     with pytest.raises(dasp.DaspError):
         plan.set_stream_policy(5)
+
+
+# ---- column panels (dasp_options_t::col_panels): P natural-order plans over column ranges + a streaming sum
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("kw", [dict(col_panels=2), dict(col_panels=3, cid16=1), dict(col_panels=8, x_window=-1), dict(col_panels=5, long_piece=256),
+                                dict(col_panels=64)])
+@pytest.mark.parametrize("tag,builder,m,n,seed", [("mixed", util.mixed_matrix, 3000, 2500, 7), ("pairs", util.pair_heavy_matrix, 4000, 2500, 11)])
+def test_column_panels_parity(oracle, dasp, torch_cuda, prec, kw, tag, builder, m, n, seed):
+    rp, ci, v = builder(m, n, seed)
+    check(oracle, dasp, torch_cuda, rp, ci, v, n, prec, **kw)
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+def test_column_panels_with_long_rows_and_unaligned_y(oracle, dasp, torch_cuda, prec):
+    torch = torch_cuda
+    dt = np.float64 if prec == 64 else np.float16
+    m, n = 777, 40000
+    lens = np.random.default_rng(5).choice([0, 1, 3, 7, 60, 500, 6000], size=m, p=[.1, .2, .2, .2, .2, .08, .02])
+    rp, ci, v = util.csr_from_lengths(lens, n, 21, dtype=dt)
+    check(oracle, dasp, torch, rp, ci, v, n, prec, col_panels=4)
+    # y not 16-byte aligned -> the scalar form of the sum kernel; same numbers
+    plan = dasp.Plan(rp, ci, v, n, precision=prec, col_panels=4).upload()
+    plan.drop_host()
+    x = torch.ones(n, dtype=tdtype(torch, prec), device="cuda")
+    ya = torch.zeros(m + 16, dtype=x.dtype, device="cuda")
+    yb = torch.zeros(m + 16, dtype=x.dtype, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    plan.spmv(x.data_ptr(), ya.data_ptr(), s)
+    plan.spmv(x.data_ptr(), yb.data_ptr() + yb.element_size(), s)
+    torch.cuda.synchronize()
+    assert torch.equal(ya[:m], yb[1:m + 1]) and float(yb[0]) == 0 and float(yb[m + 1]) == 0
+    w, e = plan.time_graph(x.data_ptr(), ya.data_ptr(), 0, 5, 20, 5)      # P + 1 kernels per SpMV captured into a graph
+    assert e > 0
+    plan.close()
+
+
+def test_column_panels_multi_gpu_layout_and_file(oracle, dasp, torch_cuda, tmp_path):
+    torch = torch_cuda
+    m, n = 2000, 3000
+    rp, ci, v = util.mixed_matrix(m, n, 17)
+    bounds, stride = np.array([0, 1100, 3000], np.int32), 2048
+    plan = dasp.Plan(rp, ci, v, n, col_panels=3, part_bounds=bounds, part_stride=stride, y_order=dasp.Y_NATURAL)
+    plan.save(tmp_path / "p.plan")
+    xh = np.random.default_rng(1).uniform(-1, 1, n)
+    xl = np.zeros(2 * stride)
+    xl[:1100] = xh[:1100]
+    xl[stride:stride + 1900] = xh[1100:]
+    ref = oracle.csr_spmv(rp, ci, v, xh)
+    scale = np.maximum(oracle.csr_absrow(rp, ci, v, xh), 1e-300)
+    for pl in (plan.upload(), dasp.Plan.load(tmp_path / "p.plan").upload()):
+        got = run_spmv(torch, pl, xl, m, 64)
+        assert (np.abs(got - ref) / scale).max() <= TOL[64]
+        pl.close()
+
+
+def test_column_panels_need_a_host_csr(dasp, torch_cuda):
+    torch = torch_cuda
+    rp, ci, v = util.mixed_matrix(500, 400, 3)
+    d = [torch.from_numpy(a).cuda() for a in (rp, ci, v)]
+    with pytest.raises(dasp.DaspError):
+        dasp.Plan.from_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), 500, 400, ci.size, col_panels=2)

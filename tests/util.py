@@ -58,6 +58,9 @@ def decode_plan(plan):
     # piece_dst / multi_dst hold final y indices: slots (Y_PERMUTED) or natural row ids (Y_NATURAL)
     natural = getattr(plan, "y_order", 0) == 1
     inv = np.argsort(plan.order_rid) if natural else None
+    dmap = plan.host_array("dst_map")
+    if natural and dmap.size:     # a column panel: row r is written to dst_map[r] (the parent's slot) instead of r
+        inv = inv[np.argsort(dmap)]
     part_owner = {}
     for i in range(md.size):
         for q in range(mp[i], mp[i + 1]):
