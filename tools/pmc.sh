@@ -12,6 +12,8 @@ groups=(
  "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum"
  "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_LEVEL_VMEM SQ_INSTS_SMEM SQ_INSTS_SALU SQ_IFETCH"
 )
+# PMC_GROUPS="A B;C D" replaces the default groups
+if [ -n "$PMC_GROUPS" ]; then IFS=';' read -r -a groups <<< "$PMC_GROUPS"; fi
 i=0
 for g in "${groups[@]}"; do
   # a group the hardware cannot schedule makes rocprofv3 abort and then hang in its signal handler: always bound it
