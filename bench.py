@@ -126,15 +126,16 @@ def suite_entry(torch, D, name, precision, scale, budget_s=2.0):
     return out
 
 
-def setup_rank(torch, D, name, scale, prec, rank, world):
+def setup_rank(torch, D, name, scale, prec, rank, world, multi=None):
     """Everything one rank owns: its row range (equal nonzeros), the DASP plan of that slice with column ids remapped
     into the all-gather layout, x in that layout, the padded y slice and the gather buffer."""
+    multi = world > 1 if multi is None else multi                   # the partitioned layout (forced at world 1 by a test hook)
     rows, cols = matrix_dims(D, name, scale)
     lengths = matrix_lengths(D, name, scale)                        # every rank: cheap, deterministic
     rp_full = np.zeros(rows + 1, np.int64)
     np.cumsum(lengths, out=rp_full[1:])
     nnz_total = int(rp_full[-1])
-    if world > 1:
+    if multi:
         # same rule as dasp_partition_rows (first row whose start >= g/world of the nonzeros), on int64 prefix sums
         bounds = np.searchsorted(rp_full, nnz_total * np.arange(world + 1) // world, side="left").astype(np.int32)
         bounds[0], bounds[-1] = 0, rows
@@ -142,16 +143,16 @@ def setup_rank(torch, D, name, scale, prec, rank, world):
         stride = (int(np.diff(bounds).max()) + 63) // 64 * 64
     else:
         bounds, stride = None, 0
-    r0, r1 = (0, rows) if world == 1 else (int(bounds[rank]), int(bounds[rank + 1]))
+    r0, r1 = (0, rows) if not multi else (int(bounds[rank]), int(bounds[rank + 1]))
     threads = max(1, (os.cpu_count() or 8) // max(1, world))
-    plan, rp, ci, val, pre_s = build_slice(D, name, scale, prec, r0, r1, lengths, bounds, stride, natural=world > 1, threads=threads)
+    plan, rp, ci, val, pre_s = build_slice(D, name, scale, prec, r0, r1, lengths, bounds, stride, natural=multi, threads=threads)
     del val
     plan.upload()
     plan.drop_host()
     tdt = torch.float64 if prec == 64 else torch.float16
     x = torch.ones(plan.x_len, dtype=tdt, device="cuda")
     y = torch.zeros(max(stride, r1 - r0), dtype=tdt, device="cuda")
-    gathered = torch.zeros(world * stride, dtype=tdt, device="cuda") if world > 1 else None
+    gathered = torch.zeros(world * stride, dtype=tdt, device="cuda") if multi else None
     return dict(plan=plan, rp=rp, ci=ci, stats=plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total, lengths=lengths,
                 bounds=bounds, stride=stride, r0=r0, r1=r1, x=x, y=y, gathered=gathered)
 
@@ -206,8 +207,11 @@ def main():
     share_gpu = os.environ.get("DASP_BENCH_SHARE_GPU") == "1"
     backend = os.environ.get("DASP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(0 if share_gpu else local_rank)
+    # DASP_BENCH_FORCE_DIST=1 (test hook): run the partitioned + RCCL flow even at world size 1, which is all a one-GPU box
+    # can offer RCCL (two ranks may not share a device)
+    multi = world > 1 or os.environ.get("DASP_BENCH_FORCE_DIST") == "1"
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -217,7 +221,7 @@ def main():
 
     name, scale, prec = args.workload, args.scale, args.precision
     vb = prec // 8
-    R = setup_rank(torch, D, name, scale, prec, rank, world)
+    R = setup_rank(torch, D, name, scale, prec, rank, world, multi)
     plan, rp, ci, st, pre_s = R["plan"], R["rp"], R["ci"], R["stats"], R["pre_s"]
     rows, cols, nnz_total, lengths = R["rows"], R["cols"], R["nnz_total"], R["lengths"]
     bounds, stride, r0, r1, x, y, gathered = R["bounds"], R["stride"], R["r0"], R["r1"], R["x"], R["y"], R["gathered"]
@@ -225,16 +229,16 @@ def main():
 
     def step():
         plan.spmv(x.data_ptr(), y.data_ptr(), stream)
-        if world > 1 and backend == "nccl":
+        if multi and backend == "nccl":
             dist.all_gather_into_tensor(gathered, y[:stride])   # RCCL over xGMI; `gathered` has the layout x is read in
-        elif world > 1:                                          # test hook: same exchange through host memory
+        elif multi:                                              # test hook: same exchange through host memory
             parts = [torch.empty(stride, dtype=y.dtype) for _ in range(world)]
             dist.all_gather(parts, y[:stride].cpu())
             gathered.copy_(torch.cat(parts))
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -249,7 +253,7 @@ def main():
     ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -258,12 +262,12 @@ def main():
     # ---- exact check: values and x all ones => y == row length
     want = torch.from_numpy(lengths[r0:r1].astype(np.float64)).cuda()
     got = y[: r1 - r0].double()
-    if world == 1:
+    if not multi:
         got_nat = torch.empty_like(got)
         got_nat[torch.from_numpy(plan.order_rid.astype(np.int64)).cuda()] = got
         got = got_nat
     ok = bool((got == want).all().item()) if prec == 64 else bool(((got - want).abs() <= 1e-2 * want.clamp(min=1)).all().item())
-    if world > 1:
+    if multi:
         full = torch.cat([gathered[g * stride: g * stride + int(bounds[g + 1] - bounds[g])] for g in range(world)]).double()
         ok = ok and bool((full == torch.from_numpy(lengths.astype(np.float64)).cuda()).all().item())
         okt = torch.tensor([1 if ok else 0], device="cuda" if backend == "nccl" else "cpu")
@@ -288,7 +292,7 @@ def main():
         "config": {"workload": ("%s from DASP_MTX_DIR, A=1, x=1" % name) if real_matrix(D, name) else
                    "%s synthetic stand-in (seeded; SuiteSparse dims/row statistics), A=1, x=1" % name,
                    "rows": rows, "cols": cols, "nnz": nnz_total, "scale": scale,
-                   "partition": "single GPU" if world == 1 else "row ranges by nnz + RCCL all_gather(y)",
+                   "partition": "single GPU" if not multi else "row ranges by nnz + RCCL all_gather(y)",
                    "row_long": st["row_long"], "row_block": st["row_block"], "rate_fill0": round(st["rate_fill0"], 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
@@ -343,7 +347,7 @@ def main():
                 suite.append({"workload": nm, "error": repr(exc)})
         out["suite"] = suite
 
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

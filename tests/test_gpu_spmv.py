@@ -411,6 +411,23 @@ def test_bench_multi_rank_flow_on_one_gpu(torch_cuda):
     assert out["config"]["partition"].startswith("row ranges") and "roofline" in out and "suite" not in out
 
 
+def test_bench_rccl_calls_run_at_world_size_one(torch_cuda):
+    """The exact RCCL sequence of the N > 1 bench (init_process_group("nccl", device_id), all_gather_into_tensor into the x
+    layout, barrier, MAX / MIN all_reduce) on the one GPU of this box: world size 1 is all RCCL allows here (two ranks may not
+    share a device), the partitioned plan + natural-order y + gathered-layout check are the real ones."""
+    import json
+    import socket
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, DASP_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+                        "--scale", "0.02", "--no-suite", "--no-cpu-baseline", "--no-vendor"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["verified"] is True and out["config"]["partition"].startswith("row ranges")
+
+
 @pytest.mark.parametrize("prec", [64, 16])
 def test_stream_policies_give_identical_results(dasp, torch_cuda, prec):
     """plain loads (reference dasp_spmv) vs non-temporal loads (reference "bypass" dasp_spmv2): same bits, switchable at run time"""
