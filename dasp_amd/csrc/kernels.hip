@@ -105,14 +105,27 @@ __device__ __forceinline__ int slot_of(const SlotMap &m, int t)
     return g ? m.base[p] + (u / g) * 2 * g + m.off[p] + u % g : m.base[p] + u;
 }
 
+// chunks per software-pipeline batch / per one-shot (A/B knobs; defaults chosen on the HBM-bound stand-ins)
+#ifndef DASP_BF
+#define DASP_BF 4
+#endif
+#ifndef DASP_SF
+#define DASP_SF 8   // f64 rows of <= 32 nonzeros in one shot: cop20k_A 11.5 -> 10.9 us, 4x 31.2 -> 30.2, HBM-bound stand-ins +0.5-1 %
+#endif
+#ifndef DASP_BH
+#define DASP_BH 2
+#endif
+#ifndef DASP_SH
+#define DASP_SH 2
+#endif
 template <class T> struct Tr;
 template <> struct Tr<double> {
     using acc_t = f64x4; using part_t = double;
-    static constexpr int CHUNK = 64, SHORT_ROWS = 128, BATCH = 4, SHOT = 4;
+    static constexpr int CHUNK = 64, SHORT_ROWS = 128, BATCH = DASP_BF, SHOT = DASP_SF;
 };
 template <> struct Tr<_Float16> {
     using acc_t = f32x4; using part_t = float;
-    static constexpr int CHUNK = 256, SHORT_ROWS = 256, BATCH = 2, SHOT = 2;
+    static constexpr int CHUNK = 256, SHORT_ROWS = 256, BATCH = DASP_BH, SHOT = DASP_SH;
 };
 
 // ---- chunk = one MFMA worth of elements in lane-linear order.  Loads, gathers and MFMAs are kept
