@@ -70,6 +70,25 @@ int dasp_csr_load(const char *path, int precision, int *m, int *n, int *nnz, int
     return load_csr_bin(path, precision, m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, csrVal);
 }
 
+// options as the builders expect them: defaults for unset fields, a private, validated copy of the column partition
+static int normalise_options(Plan &p, const dasp_options_t *opt, int colA)
+{
+    if (opt) p.opt = *opt; else dasp_options_default(&p.opt);
+    if (!(p.opt.threshold > 0)) p.opt.threshold = 0.75;
+    if (p.opt.block_longest < 6) p.opt.block_longest = 256;
+    if (p.opt.n_parts > 0) {
+        if (!p.opt.part_bounds || p.opt.part_stride <= 0) { set_error("bad column partition"); return DASP_ERR_ARG; }
+        p.part_bounds.assign(p.opt.part_bounds, p.opt.part_bounds + p.opt.n_parts + 1);
+        if (p.part_bounds.front() != 0 || p.part_bounds.back() != colA) { set_error("part_bounds must span [0,colA]"); return DASP_ERR_ARG; }
+        for (int g = 0; g < p.opt.n_parts; ++g)
+            if (p.part_bounds[g + 1] < p.part_bounds[g] || p.part_bounds[g + 1] - p.part_bounds[g] > p.opt.part_stride) {
+                set_error("part_bounds not monotone or wider than part_stride"); return DASP_ERR_ARG;
+            }
+        p.opt.part_bounds = p.part_bounds.data();
+    } else { p.opt.n_parts = 0; p.opt.part_bounds = nullptr; }
+    return DASP_OK;
+}
+
 int dasp_plan_create(dasp_plan_t **out, int precision, int rowA, int colA, int nnzA, const int *rp, const int *ci,
                      const void *val, const dasp_options_t *opt)
 {
@@ -83,19 +102,7 @@ int dasp_plan_create(dasp_plan_t **out, int precision, int rowA, int colA, int n
     if (!h) return DASP_ERR_NOMEM;
     Plan &p = h->impl;
     p.precision = precision; p.m = rowA; p.n = colA; p.nnz = nnzA;
-    if (opt) p.opt = *opt; else dasp_options_default(&p.opt);
-    if (!(p.opt.threshold > 0)) p.opt.threshold = 0.75;
-    if (p.opt.block_longest < 6) p.opt.block_longest = 256;
-    if (p.opt.n_parts > 0) {
-        if (!p.opt.part_bounds || p.opt.part_stride <= 0) { delete h; set_error("bad column partition"); return DASP_ERR_ARG; }
-        p.part_bounds.assign(p.opt.part_bounds, p.opt.part_bounds + p.opt.n_parts + 1);
-        if (p.part_bounds.front() != 0 || p.part_bounds.back() != colA) { delete h; set_error("part_bounds must span [0,colA]"); return DASP_ERR_ARG; }
-        for (int g = 0; g < p.opt.n_parts; ++g)
-            if (p.part_bounds[g + 1] < p.part_bounds[g] || p.part_bounds[g + 1] - p.part_bounds[g] > p.opt.part_stride) {
-                delete h; set_error("part_bounds not monotone or wider than part_stride"); return DASP_ERR_ARG;
-            }
-        p.opt.part_bounds = p.part_bounds.data();
-    } else { p.opt.n_parts = 0; p.opt.part_bounds = nullptr; }
+    if (int rc = normalise_options(p, opt, colA)) { delete h; return rc; }
     int rc;
     try { rc = build_plan(p, rp, ci, val); }
     catch (const std::bad_alloc &) { rc = DASP_ERR_NOMEM; set_error("out of host memory"); }
@@ -123,14 +130,7 @@ int dasp_plan_create_device(dasp_plan_t **out, int precision, int rowA, int colA
     if (!h) return DASP_ERR_NOMEM;
     Plan &p = h->impl;
     p.precision = precision; p.m = rowA; p.n = colA; p.nnz = nnzA;
-    if (opt) p.opt = *opt; else dasp_options_default(&p.opt);
-    if (!(p.opt.threshold > 0)) p.opt.threshold = 0.75;
-    if (p.opt.block_longest < 6) p.opt.block_longest = 256;
-    if (p.opt.n_parts > 0) {
-        if (!p.opt.part_bounds || p.opt.part_stride <= 0) { delete h; set_error("bad column partition"); return DASP_ERR_ARG; }
-        p.part_bounds.assign(p.opt.part_bounds, p.opt.part_bounds + p.opt.n_parts + 1);
-        p.opt.part_bounds = p.part_bounds.data();
-    } else { p.opt.n_parts = 0; p.opt.part_bounds = nullptr; }
+    if (int rc = normalise_options(p, opt, colA)) { delete h; return rc; }
     const DevCsr dev{dRowPtr, dColIdx, dVal};
     int rc;
     try { rc = build_plan(p, rp.data(), nullptr, nullptr, &dev); }
