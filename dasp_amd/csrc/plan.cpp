@@ -217,12 +217,16 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         }
         p.piece_ptr.push_back((int)total);
         T *lv = reinterpret_cast<T *>(p.long_val.data());
-        if (pack) parallel_for(nlong, threads, 64, [&](long long b, long long e) {
-            for (long long i = b; i < e; ++i) {
+        // element-parallel (not row-parallel): a power-law matrix keeps most of its long nonzeros in a handful of rows
+        if (pack) parallel_for(total, threads, 1 << 16, [&](long long b, long long e) {
+            long long i = std::upper_bound(start.begin(), start.end(), b) - start.begin() - 1;   // row holding element b
+            for (; i < nlong && start[i] < e; ++i) {
                 const int r = ridL[i], len = rp[r + 1] - rp[r];
-                const size_t at = (size_t)start[i];
-                for (int j = 0; j < len; ++j) { lv[at + j] = val[rp[r] + j]; p.long_cid[at + j] = remap(ci[rp[r] + j]); }
-                for (size_t j = at + len; j < (size_t)start[i + 1]; ++j) { lv[j] = (T)0; p.long_cid[j] = -1; }   // pad to kLongAlign
+                const long long s0 = std::max(b, start[i]), s1 = std::min(e, start[i + 1]);
+                const long long real_end = std::min(s1, start[i] + len);
+                const long long src = (long long)rp[r] - start[i];
+                for (long long j = s0; j < real_end; ++j) { lv[j] = val[src + j]; p.long_cid[(size_t)j] = remap(ci[src + j]); }
+                for (long long j = std::max(s0, real_end); j < s1; ++j) { lv[j] = (T)0; p.long_cid[(size_t)j] = -1; }   // pad to kLongAlign
             }
         });
     }
@@ -606,20 +610,41 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     if (!natural) { slot_of_row.resize((size_t)m); for (int i = 0; i < m; ++i) slot_of_row[p.order[i]] = i; }
     const bool streams = (long long)p.nnz * (p.geo.vbytes + 4) > (200ll << 20);
     p.panels.clear(); p.panel_bounds.clear();
+    // the panels are built side by side (their O(rows) classifier passes are serial), each with its share of the threads
+    std::vector<std::unique_ptr<dasp_plan>> built((size_t)P);
+    std::vector<int> rcs((size_t)P, DASP_OK);
+    std::vector<std::string> errs((size_t)P);
+    {
+        const int side = std::min(P, threads), each = std::max(1, threads / side);
+        std::atomic<int> next{0};
+        std::vector<std::thread> workers;
+        for (int t = 0; t < side; ++t)
+            workers.emplace_back([&] {
+                for (int k = next++; k < P; k = next++) {
+                    const int nnz_k = rpP[k][m];
+                    if (nnz_k == 0) continue;                       // an empty panel adds nothing
+                    std::unique_ptr<dasp_plan> h(new dasp_plan());
+                    Plan &q = h->impl;
+                    q.precision = p.precision; q.geo = p.geo; q.m = m; q.n = (int)xlen; q.nnz = nnz_k;
+                    q.opt = p.opt;
+                    q.opt.y_order = DASP_Y_NATURAL; q.opt.n_parts = 0; q.opt.part_bounds = nullptr; q.opt.part_stride = 0;
+                    q.opt.col_panels = 1; q.opt.host_threads = each;
+                    if (q.opt.stream_policy == 0) q.opt.stream_policy = streams ? 2 : 1;   // the policy follows the whole matrix, not one panel
+                    q.dst_map = slot_of_row;
+                    try { rcs[k] = build_impl<T>(q, rpP[k].data(), ciP[k].data(), valP[k].data(), nullptr, kPanel); }
+                    catch (const std::bad_alloc &) { rcs[k] = DASP_ERR_NOMEM; set_error("out of host memory"); }
+                    if (rcs[k] != DASP_OK) { errs[k] = last_error_cstr(); continue; }
+                    q.opt.host_threads = p.opt.host_threads;
+                    std::vector<int>().swap(rpP[k]); raw_vector<int>().swap(ciP[k]); raw_vector<T>().swap(valP[k]);
+                    built[k] = std::move(h);
+                }
+            });
+        for (auto &w : workers) w.join();
+    }
     for (int k = 0; k < P; ++k) {
-        const int nnz_k = rpP[k][m];
-        if (nnz_k == 0) continue;                       // an empty panel adds nothing
-        std::unique_ptr<dasp_plan> h(new dasp_plan());
-        Plan &q = h->impl;
-        q.precision = p.precision; q.geo = p.geo; q.m = m; q.n = (int)xlen; q.nnz = nnz_k;
-        q.opt = p.opt;
-        q.opt.y_order = DASP_Y_NATURAL; q.opt.n_parts = 0; q.opt.part_bounds = nullptr; q.opt.part_stride = 0;
-        q.opt.col_panels = 1;
-        if (q.opt.stream_policy == 0) q.opt.stream_policy = streams ? 2 : 1;   // the policy follows the whole matrix, not one panel
-        q.dst_map = slot_of_row;
-        if (int rc = build_impl<T>(q, rpP[k].data(), ciP[k].data(), valP[k].data(), nullptr, kPanel)) return rc;
-        std::vector<int>().swap(rpP[k]); raw_vector<int>().swap(ciP[k]); raw_vector<T>().swap(valP[k]);
-        p.panels.push_back(std::move(h));
+        if (rcs[k] != DASP_OK) { set_error(errs[k]); return rcs[k]; }
+        if (!built[k]) continue;
+        p.panels.push_back(std::move(built[k]));
         p.panel_bounds.push_back(bnd[k]); p.panel_bounds.push_back(bnd[k + 1]);
     }
 
