@@ -504,3 +504,51 @@ def test_column_panels_need_a_host_csr(dasp, torch_cuda):
     d = [torch.from_numpy(a).cuda() for a in (rp, ci, v)]
     with pytest.raises(dasp.DaspError):
         dasp.Plan.from_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), 500, 400, ci.size, col_panels=2)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_option_combinations(oracle, dasp, torch_cuda, seed):
+    """Feature interactions (panels x windows x 16-bit ids x partitioned x layout x piece / threshold / block_longest corners):
+    every seeded combination must match the CSR product within the stated tolerance."""
+    torch = torch_cuda
+    rng = np.random.default_rng(1000 + seed)
+    prec = int(rng.choice([64, 16]))
+    dt = np.float64 if prec == 64 else np.float16
+    m = int(rng.integers(1, 6000))
+    n = int(rng.choice([1, 17, 300, 5000, 70000, 1_500_000]))
+    kinds = [0, 1, 2, 3, 4, 5, 9, 17, 40, 130, 300, 900]
+    w = rng.dirichlet(np.ones(len(kinds)) * 0.5)
+    lens = np.minimum(rng.choice(kinds, size=m, p=w), n)
+    if rng.random() < 0.3:                                    # a banded variant: windows fit
+        rp, ci, v = util.csr_from_lengths(lens, min(n, 2000), int(rng.integers(1 << 30)), dtype=dt)
+        ci = np.minimum(ci + (np.repeat(np.arange(m), np.diff(rp)) * max(1, (n - 2000)) // max(m, 1)).astype(np.int32), n - 1).astype(np.int32)
+        for r in range(m):
+            ci[rp[r]:rp[r + 1]].sort()
+    else:
+        rp, ci, v = util.csr_from_lengths(lens, n, int(rng.integers(1 << 30)), dtype=dt)
+    kw = dict(col_panels=int(rng.choice([1, 1, 2, 3, 6])), cid16=int(rng.choice([-1, 0, 1])),
+              x_window=int(rng.choice([-1, 0, 0, 40000, 163840])), row_window=int(rng.choice([0, 64, 256, 1024])),
+              long_piece=int(rng.choice([0, 64, 300, 4096])), block_longest=int(rng.choice([256, 256, 32, 1000])),
+              threshold=float(rng.choice([0.75, 0.75, 0.3, 1.0])), y_order=int(rng.choice([0, 1])))
+    part = None
+    if rng.random() < 0.4 and n >= 3:
+        cuts = np.sort(rng.choice(np.arange(1, n), size=min(2, n - 1), replace=False))
+        bounds = np.concatenate([[0], cuts, [n]]).astype(np.int32)
+        stride = int((np.diff(bounds).max() + 63) // 64 * 64)
+        part = (bounds, stride)
+        kw.update(part_bounds=bounds, part_stride=stride)
+    xh = (rng.uniform(-1, 1, n) if prec == 64 else rng.uniform(0.5, 1.5, n)).astype(dt)
+    if part is None:
+        xl = xh
+    else:
+        xl = np.zeros((part[0].size - 1) * part[1], dt)
+        for g in range(part[0].size - 1):
+            xl[g * part[1]: g * part[1] + part[0][g + 1] - part[0][g]] = xh[part[0][g]:part[0][g + 1]]
+    ref = oracle.csr_spmv(rp, ci, v.astype(np.float64), xh.astype(np.float64))
+    scale = np.maximum(oracle.csr_absrow(rp, ci, v.astype(np.float64), xh.astype(np.float64)), 1e-300)
+    plan = dasp.Plan(rp, ci, v, n, precision=prec, **kw).upload()
+    got = run_spmv(torch, plan, xl, m, prec)
+    perm = plan.order_rid if kw["y_order"] == 0 else np.arange(m)
+    err = np.abs(got - ref[perm]) / scale[perm]
+    assert np.isfinite(got).all() and err.max() <= TOL[prec], (kw, prec, m, n, float(err.max()), int(err.argmax()))
+    plan.close()
