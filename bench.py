@@ -3,14 +3,15 @@
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N == 1 : one process, one GPU.
-  N  > 1 : launched by torch.distributed.run, one rank per GPU (RCCL).  The matrix is
-           partitioned by contiguous row ranges of equal nonzero count; every rank builds the
-           DASP plan of its slice (column ids remapped so that the all-gather buffer IS the next
-           x), one step = local SpMV + all-gather of y over xGMI.  Fixed total work => "strong".
-A step is one y = A*x over the whole matrix.  Input: the seeded synthetic stand-in of the
-SuiteSparse matrix named by --workload (no .mtx files / network on the bench machines), values
-and x all ones as in the reference's driver (src/main_f64.cu:131-132), so y[i] == nnz(row) is
-checked exactly after the timed region.
+  N  > 1 : launched by torch.distributed.run, one rank per GPU (RCCL).  The matrix is partitioned by contiguous
+           row ranges of equal nonzero count; every rank builds the DASP plans of its slice (dasp_amd/multi.py): one over
+           its own columns, one over the other ranks' columns remapped so that the all-gather buffer IS the next x.
+           One step = y = A*x over the whole matrix + all-gather of y over xGMI, chained (x_{t+1} = y_t); the product
+           over a rank's own columns overlaps the all-gather still in flight.  Fixed total work => "strong".
+A step is one y = A*x over the whole matrix.  Input: the seeded synthetic stand-in of the SuiteSparse matrix named by
+--workload (no .mtx files / network on the bench machines).  N == 1: values and x all ones as in the reference's driver
+(src/main_f64.cu:131-132), y[i] == nnz(row) checked exactly after the timed region.  N > 1: a_ij = 0.5 / len(row i), x_0 = 1,
+so x_t = 2^-t, checked on the gathered y after the timed region.
 Prints ONE JSON line on rank 0.  The GPU path has no CPU fallback: without a GPU this exits non-zero.
 """
 import argparse
@@ -127,8 +128,9 @@ def suite_entry(torch, D, name, precision, scale, budget_s=2.0):
 
 
 def setup_rank(torch, D, name, scale, prec, rank, world, multi=None):
-    """Everything one rank owns: its row range (equal nonzeros), the DASP plan of that slice with column ids remapped
-    into the all-gather layout, x in that layout, the padded y slice and the gather buffer."""
+    """Everything one rank owns.  Single GPU: the plan of the whole matrix (A = 1, x = 1, the reference driver's mode).
+    Partitioned: its row range (equal nonzeros) as a dasp_amd.multi.RowPartitionedSpMV -- a plan over the rank's own columns
+    and one over the other ranks' columns remapped into the all-gather layout, the padded y slices and the gather buffer."""
     multi = world > 1 if multi is None else multi                   # the partitioned layout (forced at world 1 by a test hook)
     rows, cols = matrix_dims(D, name, scale)
     lengths = matrix_lengths(D, name, scale)                        # every rank: cheap, deterministic
@@ -145,16 +147,35 @@ def setup_rank(torch, D, name, scale, prec, rank, world, multi=None):
         bounds, stride = None, 0
     r0, r1 = (0, rows) if not multi else (int(bounds[rank]), int(bounds[rank + 1]))
     threads = max(1, (os.cpu_count() or 8) // max(1, world))
-    plan, rp, ci, val, pre_s = build_slice(D, name, scale, prec, r0, r1, lengths, bounds, stride, natural=multi, threads=threads)
+    if multi:
+        # chained iteration x_{t+1} = all_gather(A x_t) (what a solver does with the gathered y).  Values c / len(row) make A
+        # row-stochastic up to the factor c, so x_t = c^t * ones: bounded for any number of steps, and (f64, c = 1/2, exact
+        # powers of two) a product that read a stale x is off by a factor 2 and fails the check.
+        from dasp_amd.multi import RowPartitionedSpMV
+        rp, ci = matrix_rows(D, name, scale, r0, r1, lengths)
+        dt = np.float64 if prec == 64 else np.float16
+        c = CHAIN_FACTOR[prec]
+        val = np.repeat(c / np.maximum(np.diff(rp), 1), np.diff(rp)).astype(dt)
+        t0 = time.time()
+        mp = RowPartitionedSpMV(torch, rp, ci, val, cols, bounds, rank, precision=prec, threads=threads, stride=stride,
+                                overlap=os.environ.get("DASP_BENCH_OVERLAP", "1") != "0")
+        pre_s = time.time() - t0
+        mp.seed(np.ones(cols, dt))
+        del val
+        return dict(mp=mp, plan=mp.plan, rp=rp, ci=ci, stats=mp.plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total,
+                    lengths=lengths, bounds=bounds, stride=stride, r0=r0, r1=r1, x=mp.ys[0], y=mp.yl, gathered=mp.gathered)
+    plan, rp, ci, val, pre_s = build_slice(D, name, scale, prec, r0, r1, lengths, threads=threads)
     del val
     plan.upload()
     plan.drop_host()
     tdt = torch.float64 if prec == 64 else torch.float16
     x = torch.ones(plan.x_len, dtype=tdt, device="cuda")
-    y = torch.zeros(max(stride, r1 - r0), dtype=tdt, device="cuda")
-    gathered = torch.zeros(world * stride, dtype=tdt, device="cuda") if multi else None
-    return dict(plan=plan, rp=rp, ci=ci, stats=plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total, lengths=lengths,
-                bounds=bounds, stride=stride, r0=r0, r1=r1, x=x, y=y, gathered=gathered)
+    y = torch.zeros(r1 - r0, dtype=tdt, device="cuda")
+    return dict(mp=None, plan=plan, rp=rp, ci=ci, stats=plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total, lengths=lengths,
+                bounds=bounds, stride=stride, r0=r0, r1=r1, x=x, y=y, gathered=None)
+
+
+CHAIN_FACTOR = {64: 0.5, 16: 1.0}     # f16: 0.5^t would underflow after 24 steps
 
 
 def cpu_baseline(O, rp, ci, n_cols, budget_s=20.0):
@@ -227,16 +248,29 @@ def main():
     bounds, stride, r0, r1, x, y, gathered = R["bounds"], R["stride"], R["r0"], R["r1"], R["x"], R["y"], R["gathered"]
     stream = torch.cuda.current_stream().cuda_stream
 
+    mp = R["mp"]
+
+    class _Done:                                                  # a host-staged exchange has completed when it returns
+        def wait(self):
+            pass
+
+    def exchange(dst, src):
+        if backend == "nccl":                                     # RCCL over xGMI; `dst` has the layout the next product reads
+            return dist.all_gather_into_tensor(dst, src, async_op=True)
+        parts = [torch.empty(stride, dtype=src.dtype) for _ in range(world)]      # test hook: the same exchange through host memory
+        dist.all_gather(parts, src.cpu())
+        dst.copy_(torch.cat(parts))
+        return _Done()
+
     def step():
-        plan.spmv(x.data_ptr(), y.data_ptr(), stream)
-        if multi and backend == "nccl":
-            dist.all_gather_into_tensor(gathered, y[:stride])   # RCCL over xGMI; `gathered` has the layout x is read in
-        elif multi:                                              # test hook: same exchange through host memory
-            parts = [torch.empty(stride, dtype=y.dtype) for _ in range(world)]
-            dist.all_gather(parts, y[:stride].cpu())
-            gathered.copy_(torch.cat(parts))
+        if mp is None:
+            plan.spmv(x.data_ptr(), y.data_ptr(), stream)
+        else:
+            mp.step(exchange)     # local-column product | wait for the previous all-gather | remote-column product | start the next
 
     def fence():
+        if mp is not None:
+            mp.finish()
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
@@ -259,17 +293,24 @@ def main():
         elapsed = float(tt.item())
     region_event_ms = ev0.elapsed_time(ev1) / args.steps
 
-    # ---- exact check: values and x all ones => y == row length
-    want = torch.from_numpy(lengths[r0:r1].astype(np.float64)).cuda()
-    got = y[: r1 - r0].double()
-    if not multi:
+    if mp is None:
+        # ---- exact check: values and x all ones => y == row length
+        want = torch.from_numpy(lengths[r0:r1].astype(np.float64)).cuda()
+        got = y[: r1 - r0].double()
         got_nat = torch.empty_like(got)
         got_nat[torch.from_numpy(plan.order_rid.astype(np.int64)).cuda()] = got
-        got = got_nat
-    ok = bool((got == want).all().item()) if prec == 64 else bool(((got - want).abs() <= 1e-2 * want.clamp(min=1)).all().item())
-    if multi:
-        full = torch.cat([gathered[g * stride: g * stride + int(bounds[g + 1] - bounds[g])] for g in range(world)]).double()
-        ok = ok and bool((full == torch.from_numpy(lengths.astype(np.float64)).cuda()).all().item())
+        ok = bool((got_nat == want).all().item()) if prec == 64 else bool(((got_nat - want).abs() <= 1e-2 * want.clamp(min=1)).all().item())
+    else:
+        # ---- chained check: x_t = c^t on every non-empty row (0 on empty ones) after warmup + steps products, on the gathered y
+        t_all = args.warmup + args.steps
+        full = mp.full_y().double()
+        nonempty = torch.from_numpy((lengths > 0).astype(np.float64)).cuda()
+        if prec == 64:
+            want = (CHAIN_FACTOR[64] ** t_all) * nonempty
+            ok = bool(((full - want).abs() <= 1e-9 * want).all().item())
+        else:
+            ok = bool(torch.isfinite(full).all().item() and ((full >= 0.5 * nonempty) & (full <= 2.0)).all().item())
+        ok = ok and bool(torch.equal(mp.y_local, mp.gathered[rank * stride: rank * stride + (r1 - r0)]))
         okt = torch.tensor([1 if ok else 0], device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
@@ -277,22 +318,27 @@ def main():
     # ---- dominant kernel alone: HIP events on the launch stream around back-to-back launches
     k_iters = max(20, min(args.steps, 1000))
     kw, ke = plan.time(x.data_ptr(), y.data_ptr(), stream, warmup=5, iters=k_iters)
-    nnz_local = int(rp[-1])
-    b_alg_local = algorithmic_bytes(r1 - r0, cols, nnz_local, vb)
+    # partitioned: the dominant kernel is the rank's local-column plan (its x is the rank's own slice)
+    nnz_local = int(rp[-1]) if mp is None else mp.nnz_local
+    b_alg_local = algorithmic_bytes(r1 - r0, cols if mp is None else stride, nnz_local, vb)
     b_alg_total = algorithmic_bytes(rows, cols, nnz_total, vb)
     achieved = b_alg_local / (ke * 1e6)
     ms_per_step = elapsed * 1e3 / args.steps
     value = 2.0 * nnz_total / (ms_per_step * 1e6)
 
+    vals_desc = "A=1, x=1" if mp is None else "a_ij = %g/len(row i), x_0 = 1, x_{t+1} = y_t" % CHAIN_FACTOR[prec]
     out = {
         "metric": "SpMV GFLOP/s (f64)" if prec == 64 else "SpMV GFLOP/s (f16)", "value": round(value, 2), "unit": "GFLOP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 6),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64" if prec == 64 else "f16 (f32 accumulate)", "data": "suitesparse" if real_matrix(D, name) else "synthetic",
-        "config": {"workload": ("%s from DASP_MTX_DIR, A=1, x=1" % name) if real_matrix(D, name) else
-                   "%s synthetic stand-in (seeded; SuiteSparse dims/row statistics), A=1, x=1" % name,
+        "config": {"workload": ("%s from DASP_MTX_DIR, %s" % (name, vals_desc)) if real_matrix(D, name) else
+                   "%s synthetic stand-in (seeded; SuiteSparse dims/row statistics), %s" % (name, vals_desc),
                    "rows": rows, "cols": cols, "nnz": nnz_total, "scale": scale,
-                   "partition": "single GPU" if not multi else "row ranges by nnz + RCCL all_gather(y)",
+                   "partition": "single GPU" if not multi else
+                   ("row ranges by nnz + RCCL all_gather(y) overlapped with the product over the rank's own columns; x_{t+1} = y_t"
+                    if mp.overlap else "row ranges by nnz + RCCL all_gather(y); x_{t+1} = y_t"),
+                   **({} if mp is None else {"rank0_nnz_own_columns": mp.nnz_local, "rank0_nnz_other_columns": mp.nnz_remote}),
                    "row_long": st["row_long"], "row_block": st["row_block"], "rate_fill0": round(st["rate_fill0"], 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,

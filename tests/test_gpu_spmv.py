@@ -276,34 +276,71 @@ def test_nonfinite_values_stay_in_their_rows(dasp, torch_cuda):
 
 
 def test_bench_rank_setup_assembles_full_y(dasp, torch_cuda):
-    """bench.py's multi-GPU preparation, every rank's part run in turn on one GPU with the all-gather done by hand:
-    partition by nonzeros, per-rank plans with remapped columns, padded slices -> the full y, exactly"""
+    """bench.py's multi-GPU preparation, every rank's part run in turn on one GPU with the all-gather done by hand: partition by
+    nonzeros, per-rank plans over own / other columns, padded slices -> three chained iterations equal to (A_s)^3 x_0"""
     import importlib.util
+    import scipy.sparse as sp
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     torch = torch_cuda
     world = 3
     parts = [bench.setup_rank(torch, dasp, "HV15R", 0.02, 64, r, world) for r in range(world)]
-    stride, bounds = parts[0]["stride"], parts[0]["bounds"]
-    gathered = torch.zeros(world * stride, dtype=torch.float64, device="cuda")
-    for r, P in enumerate(parts):
-        assert P["plan"].x_len == world * stride and P["plan"].y_order == dasp.Y_NATURAL
-        P["plan"].spmv(P["x"].data_ptr(), P["y"].data_ptr(), torch.cuda.current_stream().cuda_stream)
-        gathered[r * stride:(r + 1) * stride] = P["y"][:stride]              # what all_gather_into_tensor does
-    torch.cuda.synchronize()
-    full = torch.cat([gathered[g * stride: g * stride + int(bounds[g + 1] - bounds[g])] for g in range(world)]).cpu().numpy()
-    assert (full == parts[0]["lengths"]).all()
+    mps = [P["mp"] for P in parts]
+    stride, bounds, rows = parts[0]["stride"], parts[0]["bounds"], parts[0]["rows"]
     nnz = [int(P["rp"][-1]) for P in parts]
     assert max(nnz) - min(nnz) <= 2 * 484                                    # balanced to within a row or two
-    # second iteration with x := gathered y (the layout IS the next x): y2 = A (A 1)
-    for r, P in enumerate(parts):
-        P["plan"].spmv(gathered.data_ptr(), P["y"].data_ptr(), torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
+    for mp in mps:
+        assert mp.overlap and mp.plan_rem is not None and mp.nnz_local > 5 * mp.nnz_remote > 0     # banded: mostly own columns
+        assert mp.plan.x_len == stride and mp.plan_rem.x_len == world * stride and mp.plan.y_order == dasp.Y_NATURAL
+    rng = np.random.default_rng(4)
+    x0 = rng.uniform(0.5, 1.5, rows)
+    for mp in mps:
+        mp.seed(x0)
+
+    class Done:
+        def wait(self):
+            pass
+    sent = {}
+
+    def make(r):
+        def gather(dst, src):
+            sent[r] = src
+            return Done()
+        return gather
     rp_all, ci_all = dasp.synth_csr("HV15R", 0.02)
-    want = np.add.reduceat(parts[0]["lengths"][ci_all].astype(np.float64), rp_all[:-1].astype(np.int64))
-    got = np.concatenate([P["y"][: P["r1"] - P["r0"]].cpu().numpy() for P in parts])
-    assert (got == want).all()
+    lens = np.diff(rp_all)
+    A = sp.csr_matrix((np.repeat(0.5 / np.maximum(lens, 1), lens), ci_all, rp_all), shape=(rows, rows))
+    want = x0
+    for it in range(3):
+        for r, mp in enumerate(mps):
+            mp.step(make(r))
+        torch.cuda.synchronize()
+        g = torch.cat([sent[r] for r in range(world)])                       # what all_gather_into_tensor delivers to every rank
+        for mp in mps:
+            mp.gathered.copy_(g)
+        want = A @ want
+        full = mps[it % world].full_y().cpu().numpy()
+        assert np.abs(full - want).max() <= 1e-13 * np.abs(want).max()
+        for r, mp in enumerate(mps):
+            assert torch.equal(mp.y_local, mp.gathered[r * stride: r * stride + mp.rows])
+    # the same three iterations without the own / other split
+    os.environ["DASP_BENCH_OVERLAP"] = "0"
+    try:
+        plain = [bench.setup_rank(torch, dasp, "HV15R", 0.02, 64, r, world)["mp"] for r in range(world)]
+    finally:
+        del os.environ["DASP_BENCH_OVERLAP"]
+    for mp in plain:
+        assert not mp.overlap and mp.plan_rem is None
+        mp.seed(x0)
+    for it in range(3):
+        for r, mp in enumerate(plain):
+            mp.step(make(r))
+        torch.cuda.synchronize()
+        g = torch.cat([sent[r] for r in range(world)])
+        for mp in plain:
+            mp.gathered.copy_(g)
+    assert np.abs(plain[0].full_y().cpu().numpy() - want).max() <= 1e-13 * np.abs(want).max()
 
 
 NNZ_ARRAYS = ("long_val long_cid med_val med_cid med_cid16 med_base irr_val irr_cid short_val short_cid").split()

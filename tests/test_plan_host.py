@@ -215,3 +215,19 @@ def test_serialised_plan_round_trip(dasp, tmp_path, prec):
         f.truncate(200)
     with pytest.raises(dasp.DaspError):
         dasp.Plan.load(path)
+
+
+def test_split_by_owner_partitions_a_row_slice(dasp):
+    """dasp_amd.multi: the own-column / other-column split behind the overlapped all-gather keeps every entry exactly once."""
+    from dasp_amd.multi import split_by_owner
+    rp, ci, v = util.mixed_matrix(700, 900, 31)
+    lo, hi = 250, 610
+    (rpl, cil, vl), (rpr, cir, vr) = split_by_owner(rp, ci, v, lo, hi)
+    assert cil.size + cir.size == ci.size and rpl[-1] == cil.size and rpr[-1] == cir.size
+    assert cil.min() >= 0 and cil.max() < hi - lo and not ((cir >= lo) & (cir < hi)).any()
+    for r in range(700):
+        own = (ci[rp[r]:rp[r + 1]] >= lo) & (ci[rp[r]:rp[r + 1]] < hi)
+        np.testing.assert_array_equal(cil[rpl[r]:rpl[r + 1]] + lo, ci[rp[r]:rp[r + 1]][own])
+        np.testing.assert_array_equal(vl[rpl[r]:rpl[r + 1]], v[rp[r]:rp[r + 1]][own])
+        np.testing.assert_array_equal(cir[rpr[r]:rpr[r + 1]], ci[rp[r]:rp[r + 1]][~own])
+        np.testing.assert_array_equal(vr[rpr[r]:rpr[r + 1]], v[rp[r]:rp[r + 1]][~own])
