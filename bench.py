@@ -163,7 +163,7 @@ def setup_rank(torch, D, name, scale, prec, rank, world, multi=None):
         mp.seed(np.ones(cols, dt))
         del val
         return dict(mp=mp, plan=mp.plan, rp=rp, ci=ci, stats=mp.plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total,
-                    lengths=lengths, bounds=bounds, stride=stride, r0=r0, r1=r1, x=mp.ys[0], y=mp.yl, gathered=mp.gathered)
+                    lengths=lengths, bounds=bounds, stride=stride, r0=r0, r1=r1, x=mp.ys[0], y=mp.ys[1], gathered=mp.gathered)
     plan, rp, ci, val, pre_s = build_slice(D, name, scale, prec, r0, r1, lengths, threads=threads)
     del val
     plan.upload()

@@ -121,6 +121,7 @@ def lib():
     L.dasp_plan_drop_host.argtypes = [vp]
     L.dasp_plan_set_stream_policy.argtypes = [vp, C.c_int]
     L.dasp_plan_spmv.argtypes = [vp, vp, vp, vp]
+    L.dasp_plan_spmv_acc.argtypes = [vp, vp, vp, vp]
     L.dasp_plan_time.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dasp_plan_time_graph.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dasp_spmv_all_f64.argtypes = [C.c_char_p, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
@@ -142,5 +143,5 @@ def check(rc):
 EXPORTS = (
     "dasp_last_error dasp_version dasp_mmio_allinone_f64 dasp_mmio_allinone_f16 dasp_free dasp_csr_save dasp_csr_load dasp_options_default "
     "dasp_plan_create dasp_plan_create_device dasp_plan_download_array dasp_plan_destroy dasp_plan_save dasp_plan_load dasp_plan_order dasp_plan_stats dasp_plan_y_order dasp_plan_x_len dasp_plan_panel_count dasp_plan_panel dasp_plan_panel_range dasp_plan_host_array dasp_plan_upload "
-    "dasp_plan_drop_host dasp_plan_set_stream_policy dasp_plan_spmv dasp_plan_time dasp_plan_time_graph dasp_spmv_all_f64 dasp_spmv_all_f16 dasp_partition_rows "
+    "dasp_plan_drop_host dasp_plan_set_stream_policy dasp_plan_spmv dasp_plan_spmv_acc dasp_plan_time dasp_plan_time_graph dasp_spmv_all_f64 dasp_spmv_all_f16 dasp_partition_rows "
     "dasp_selftest_mfma dasp_synth_dims dasp_synth_row_lengths dasp_synth_rows").split()

@@ -218,9 +218,11 @@ class Plan:
         """0 auto, 1 plain loads (reference dasp_spmv), 2 non-temporal loads (reference dasp_spmv2 'bypass')."""
         _lib.check(_lib.lib().dasp_plan_set_stream_policy(self._h, int(policy)))
 
-    def spmv(self, dX, dY, stream=0):
-        """dX, dY: integer device addresses (e.g. torch_tensor.data_ptr()); stream: hipStream_t as int."""
-        _lib.check(_lib.lib().dasp_plan_spmv(self._h, C.c_void_p(dX), C.c_void_p(dY), C.c_void_p(stream)))
+    def spmv(self, dX, dY, stream=0, accumulate=False):
+        """dX, dY: integer device addresses (e.g. torch_tensor.data_ptr()); stream: hipStream_t as int.
+        accumulate: y += A x instead of y = A x (dasp_plan_spmv_acc)."""
+        f = _lib.lib().dasp_plan_spmv_acc if accumulate else _lib.lib().dasp_plan_spmv
+        _lib.check(f(self._h, C.c_void_p(dX), C.c_void_p(dY), C.c_void_p(stream)))
 
     def time(self, dX, dY, stream=0, warmup=100, iters=1000):
         """The reference's protocol (dasp_f64.h:1285-1320): returns (wall_ms, event_ms) per SpMV."""

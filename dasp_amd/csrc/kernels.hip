@@ -359,6 +359,14 @@ __device__ __forceinline__ void run_stream(ACC &acc, const SRC &src, int N, cons
     FinishDispatch<T, U, U - 1, SRC, ACC, XV>::run(acc, src, cur, i - U, i, rem, x);
 }
 
+// the one store of a row's result: y = v, or y += v in accumulate mode (wave-uniform flag; one writer per y index)
+template <class T, class P>
+__device__ __forceinline__ void put_y(const DevArgs &a, int yi, P v)
+{
+    T *y = static_cast<T *>(a.y) + yi;
+    *y = a.acc ? (T)((P)*y + v) : (T)v;
+}
+
 // diagonal element D[row][row] held by this lane (valid only on the 16 "diagonal lanes")
 __device__ __forceinline__ bool diag_of(const f64x4 &acc, int lane, double &d)
 {
@@ -401,7 +409,7 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     if (diag_of(acc, lane, d) && r < a.row_block) {
         const int slot = a.row_long + r;
         const int yi = YM == 2 ? a.med_dst[r] : (a.order ? a.order[slot] : slot);
-        static_cast<T *>(a.y)[yi] = (T)d;
+        put_y<T>(a, yi, d);
     }
 }
 
@@ -439,7 +447,7 @@ __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
     const part_t total = wave_sum(on_diag ? d : (part_t)0);
     if (lane == 0) {
         const int dst = a.piece_dst[p];
-        if (dst >= 0) static_cast<T *>(a.y)[dst] = (T)total;
+        if (dst >= 0) put_y<T>(a, dst, total);
         else static_cast<part_t *>(a.partial)[~dst] = total;
     }
 }
@@ -482,7 +490,7 @@ __device__ __forceinline__ void short_rows(const DevArgs &a, const ShortDev &g, 
         if (t < g.count) {
             const int slot = slot_of(g.map, t);
             const int yi = a.order ? a.order[slot] : slot;
-            static_cast<T *>(a.y)[yi] = (T)s[v];
+            put_y<T>(a, yi, s[v]);
         }
     }
 }
@@ -602,13 +610,13 @@ __global__ __launch_bounds__(256) void dasp_long_reduce_kernel(DevArgs a)
     part_t s = 0;
     for (int q = q0 + lane; q < q1; q += kWave) s += part[q];
     s = wave_sum(s);
-    if (lane == 0) static_cast<T *>(a.y)[a.multi_dst[i]] = (T)s;
+    if (lane == 0) put_y<T>(a, a.multi_dst[i], s);
 }
 
 // column panels (dasp_options_t::col_panels): y[i] = sum over the panels of part[k][i].  Streaming, V elements (16 bytes)
 // per thread; the partial results are read once, so they bypass the caches.
 template <class T, int V>
-__global__ __launch_bounds__(256) void dasp_panel_sum_kernel(const T *__restrict__ part, size_t stride, int np, T *__restrict__ y, int m)
+__global__ __launch_bounds__(256) void dasp_panel_sum_kernel(const T *__restrict__ part, size_t stride, int np, T *__restrict__ y, int m, int accum)
 {
     using Acc = typename Tr<T>::part_t;
     const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
@@ -618,6 +626,11 @@ __global__ __launch_bounds__(256) void dasp_panel_sum_kernel(const T *__restrict
         Acc acc[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) acc[j] = (Acc)0;
+        if (accum) {
+            const vec_t o = *reinterpret_cast<const vec_t *>(y + i0);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] = (Acc)o[j];
+        }
         for (int k = 0; k < np; ++k) {
             const vec_t v = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(part + (size_t)k * stride + i0));
 #pragma unroll
@@ -629,7 +642,7 @@ __global__ __launch_bounds__(256) void dasp_panel_sum_kernel(const T *__restrict
         *reinterpret_cast<vec_t *>(y + i0) = o;
     } else {
         for (long long i = i0; i < m && i < i0 + V; ++i) {
-            Acc acc = (Acc)0;
+            Acc acc = accum ? (Acc)y[i] : (Acc)0;
             for (int k = 0; k < np; ++k) acc += (Acc)part[(size_t)k * stride + i];
             y[i] = (T)acc;
         }
@@ -837,7 +850,7 @@ int set_stream_policy(Plan &p, int policy)
     return DASP_OK;
 }
 
-int launch_spmv(Plan &p, const void *dX, void *dY, void *stream)
+int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate)
 {
     if (!p.dev || !p.dev->arena) { set_error("plan not uploaded"); return DASP_ERR_STATE; }
     if (!dX || !dY) { set_error("null device pointer"); return DASP_ERR_ARG; }
@@ -845,17 +858,17 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream)
         const size_t vb = (size_t)p.geo.vbytes, stride = p.dev->ypart_stride;
         char *part = static_cast<char *>(p.dev->arena);
         for (size_t k = 0; k < p.panels.size(); ++k)
-            if (int rc = launch_spmv(p.panels[k]->impl, dX, part + k * stride * vb, stream)) return rc;
+            if (int rc = launch_spmv(p.panels[k]->impl, dX, part + k * stride * vb, stream, false)) return rc;
         hipStream_t s = static_cast<hipStream_t>(stream);
         const int np = (int)p.panels.size(), m = p.m;
         const bool wide = (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
         if (m > 0) {
             if (p.precision == 64) {
-                if (wide) hipLaunchKernelGGL((dasp_panel_sum_kernel<double, 2>), dim3((m + 511) / 512), dim3(256), 0, s, (const double *)part, stride, np, (double *)dY, m);
-                else hipLaunchKernelGGL((dasp_panel_sum_kernel<double, 1>), dim3((m + 255) / 256), dim3(256), 0, s, (const double *)part, stride, np, (double *)dY, m);
+                if (wide) hipLaunchKernelGGL((dasp_panel_sum_kernel<double, 2>), dim3((m + 511) / 512), dim3(256), 0, s, (const double *)part, stride, np, (double *)dY, m, accumulate ? 1 : 0);
+                else hipLaunchKernelGGL((dasp_panel_sum_kernel<double, 1>), dim3((m + 255) / 256), dim3(256), 0, s, (const double *)part, stride, np, (double *)dY, m, accumulate ? 1 : 0);
             } else {
-                if (wide) hipLaunchKernelGGL((dasp_panel_sum_kernel<_Float16, 8>), dim3((m + 2047) / 2048), dim3(256), 0, s, (const _Float16 *)part, stride, np, (_Float16 *)dY, m);
-                else hipLaunchKernelGGL((dasp_panel_sum_kernel<_Float16, 1>), dim3((m + 255) / 256), dim3(256), 0, s, (const _Float16 *)part, stride, np, (_Float16 *)dY, m);
+                if (wide) hipLaunchKernelGGL((dasp_panel_sum_kernel<_Float16, 8>), dim3((m + 2047) / 2048), dim3(256), 0, s, (const _Float16 *)part, stride, np, (_Float16 *)dY, m, accumulate ? 1 : 0);
+                else hipLaunchKernelGGL((dasp_panel_sum_kernel<_Float16, 1>), dim3((m + 255) / 256), dim3(256), 0, s, (const _Float16 *)part, stride, np, (_Float16 *)dY, m, accumulate ? 1 : 0);
             }
         }
         HIP_TRY(hipGetLastError());
@@ -865,7 +878,7 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream)
         set_error("dX must be 16-byte aligned for a plan with LDS-staged x windows"); return DASP_ERR_ARG;
     }
     DevArgs a = p.dev->args;
-    a.x = dX; a.y = dY;
+    a.x = dX; a.y = dY; a.acc = accumulate ? 1 : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.precision == 64 ? launch_typed<double>(p, a, s) : launch_typed<_Float16>(p, a, s);
 }
@@ -890,14 +903,14 @@ struct GraphHolder {
 int time_spmv(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, double *wall_ms, double *event_ms)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    for (int i = 0; i < warmup; ++i) if (int rc = launch_spmv(p, dX, dY, stream)) return rc;
+    for (int i = 0; i < warmup; ++i) if (int rc = launch_spmv(p, dX, dY, stream, false)) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     EventPair ev;
     HIP_TRY(hipEventCreate(&ev.e0));
     HIP_TRY(hipEventCreate(&ev.e1));
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipEventRecord(ev.e0, s));
-    for (int i = 0; i < iters; ++i) if (int rc = launch_spmv(p, dX, dY, stream)) return rc;
+    for (int i = 0; i < iters; ++i) if (int rc = launch_spmv(p, dX, dY, stream, false)) return rc;
     HIP_TRY(hipEventRecord(ev.e1, s));
     HIP_TRY(hipStreamSynchronize(s));
     const auto t1 = std::chrono::steady_clock::now();
@@ -923,7 +936,7 @@ int time_spmv_graph(Plan &p, const void *dX, void *dY, void *stream, int warmup,
     }
     HIP_TRY(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
     int rc = DASP_OK;
-    for (int i = 0; i < batch && rc == DASP_OK; ++i) rc = launch_spmv(p, dX, dY, cap);
+    for (int i = 0; i < batch && rc == DASP_OK; ++i) rc = launch_spmv(p, dX, dY, cap, false);
     const hipError_t ee = hipStreamEndCapture(cap, &g.graph);      // always end the capture, even after a failed launch
     if (rc != DASP_OK) return rc;
     HIP_TRY(ee);

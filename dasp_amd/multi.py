@@ -60,7 +60,6 @@ class RowPartitionedSpMV:
         tdt = torch.float64 if precision == 64 else torch.float16
         z = lambda n: torch.zeros(n, dtype=tdt, device="cuda")
         self.ys = [z(self.stride), z(self.stride)]       # this rank's padded slice of x / y, ping-pong
-        self.yl, self.yr = z(self.stride), z(self.stride)
         self.gathered = z(self.world * self.stride)      # every rank's slice: the x the remote (or whole) plan reads
         self.cur = 0
         self.pending = None
@@ -82,13 +81,11 @@ class RowPartitionedSpMV:
         s = torch.cuda.current_stream().cuda_stream
         cur, nxt = self.cur, 1 - self.cur
         if self.overlap:
-            out = self.yl if self.plan_rem is not None else self.ys[nxt]
-            self.plan.spmv(self.ys[cur].data_ptr(), out.data_ptr(), s)            # needs only this rank's own x
+            self.plan.spmv(self.ys[cur].data_ptr(), self.ys[nxt].data_ptr(), s)   # needs only this rank's own x
             if self.pending is not None:
                 self.pending.wait()                                               # the other ranks' x has arrived
-            if self.plan_rem is not None:
-                self.plan_rem.spmv(self.gathered.data_ptr(), self.yr.data_ptr(), s)
-                torch.add(self.yl, self.yr, out=self.ys[nxt])
+            if self.plan_rem is not None:                                         # y += (other ranks' columns) * x
+                self.plan_rem.spmv(self.gathered.data_ptr(), self.ys[nxt].data_ptr(), s, accumulate=True)
         else:
             if self.pending is not None:
                 self.pending.wait()

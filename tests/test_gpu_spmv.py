@@ -589,3 +589,34 @@ def test_random_option_combinations(oracle, dasp, torch_cuda, seed):
     err = np.abs(got - ref[perm]) / scale[perm]
     assert np.isfinite(got).all() and err.max() <= TOL[prec], (kw, prec, m, n, float(err.max()), int(err.argmax()))
     plan.close()
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("kw", [dict(), dict(y_order=1), dict(col_panels=3), dict(x_window=100000, row_window=128), dict(long_piece=64)])
+def test_accumulate_mode_adds_into_y(oracle, dasp, torch_cuda, prec, kw):
+    """dasp_plan_spmv_acc: y += A x through every store site (medium, long single / multi piece, short, empty rows, panel sum)"""
+    torch = torch_cuda
+    dt = np.float64 if prec == 64 else np.float16
+    m, n = 2500, 3000
+    lens = np.random.default_rng(8).choice([0, 1, 2, 3, 4, 9, 40, 300, 900], size=m, p=[.05, .15, .1, .15, .1, .2, .15, .07, .03])
+    rp, ci, v = util.csr_from_lengths(lens, n, 77, values="f16" if prec == 16 else "uniform", dtype=dt)
+    rng = np.random.default_rng(2)
+    xh = rng.uniform(0.5, 1.5, n).astype(dt)
+    y0 = rng.uniform(-3, 3, m).astype(dt)
+    plan = dasp.Plan(rp, ci, v, n, precision=prec, **kw).upload()
+    x = torch.from_numpy(xh).cuda()
+    y = torch.from_numpy(y0).cuda()
+    ya = y.clone()
+    s = torch.cuda.current_stream().cuda_stream
+    plan.spmv(x.data_ptr(), y.data_ptr(), s)                       # y  = A x
+    plan.spmv(x.data_ptr(), ya.data_ptr(), s, accumulate=True)     # ya = y0 + A x
+    torch.cuda.synchronize()
+    ax, got = y.double().cpu().numpy(), ya.double().cpu().numpy()
+    perm = plan.order_rid if kw.get("y_order", 0) == 0 else np.arange(m)
+    ref = oracle.csr_spmv(rp, ci, v.astype(np.float64), xh.astype(np.float64))[perm]
+    scale = np.maximum(oracle.csr_absrow(rp, ci, v.astype(np.float64), xh.astype(np.float64))[perm], 1e-300) + np.abs(y0.astype(np.float64))
+    assert (np.abs(ax - ref) / scale).max() <= TOL[prec]
+    assert (np.abs(got - (y0.astype(np.float64) + ref)) / scale).max() <= TOL[prec]
+    if prec == 64 and "col_panels" not in kw:
+        assert (got == y0 + ax).all()                               # same products, one extra add: bit-identical to y0 + (A x)
+    plan.close()
