@@ -127,7 +127,7 @@ def suite_entry(torch, D, name, precision, scale, budget_s=2.0):
     return out
 
 
-def setup_rank(torch, D, name, scale, prec, rank, world, multi=None):
+def setup_rank(torch, D, name, scale, prec, rank, world, multi=None, chain=None):
     """Everything one rank owns.  Single GPU: the plan of the whole matrix (A = 1, x = 1, the reference driver's mode).
     Partitioned: its row range (equal nonzeros) as a dasp_amd.multi.RowPartitionedSpMV -- a plan over the rank's own columns
     and one over the other ranks' columns remapped into the all-gather layout, the padded y slices and the gather buffer."""
@@ -154,7 +154,7 @@ def setup_rank(torch, D, name, scale, prec, rank, world, multi=None):
         from dasp_amd.multi import RowPartitionedSpMV
         rp, ci = matrix_rows(D, name, scale, r0, r1, lengths)
         dt = np.float64 if prec == 64 else np.float16
-        c = CHAIN_FACTOR[prec]
+        c = CHAIN_FACTOR[prec] if chain is None else chain
         val = np.repeat(c / np.maximum(np.diff(rp), 1), np.diff(rp)).astype(dt)
         t0 = time.time()
         mp = RowPartitionedSpMV(torch, rp, ci, val, cols, bounds, rank, precision=prec, threads=threads, stride=stride,
@@ -162,7 +162,7 @@ def setup_rank(torch, D, name, scale, prec, rank, world, multi=None):
         pre_s = time.time() - t0
         mp.seed(np.ones(cols, dt))
         del val
-        return dict(mp=mp, plan=mp.plan, rp=rp, ci=ci, stats=mp.plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total,
+        return dict(chain=c, mp=mp, plan=mp.plan, rp=rp, ci=ci, stats=mp.plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total,
                     lengths=lengths, bounds=bounds, stride=stride, r0=r0, r1=r1, x=mp.ys[0], y=mp.ys[1], gathered=mp.gathered)
     plan, rp, ci, val, pre_s = build_slice(D, name, scale, prec, r0, r1, lengths, threads=threads)
     del val
@@ -171,11 +171,11 @@ def setup_rank(torch, D, name, scale, prec, rank, world, multi=None):
     tdt = torch.float64 if prec == 64 else torch.float16
     x = torch.ones(plan.x_len, dtype=tdt, device="cuda")
     y = torch.zeros(r1 - r0, dtype=tdt, device="cuda")
-    return dict(mp=None, plan=plan, rp=rp, ci=ci, stats=plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total, lengths=lengths,
+    return dict(chain=None, mp=None, plan=plan, rp=rp, ci=ci, stats=plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total, lengths=lengths,
                 bounds=bounds, stride=stride, r0=r0, r1=r1, x=x, y=y, gathered=None)
 
 
-CHAIN_FACTOR = {64: 0.5, 16: 1.0}     # f16: 0.5^t would underflow after 24 steps
+CHAIN_FACTOR = {64: 0.5, 16: 1.0}     # f16: 0.5^t would underflow after 24 steps (f64: after 1022, see main)
 
 
 def cpu_baseline(O, rp, ci, n_cols, budget_s=20.0):
@@ -242,7 +242,9 @@ def main():
 
     name, scale, prec = args.workload, args.scale, args.precision
     vb = prec // 8
-    R = setup_rank(torch, D, name, scale, prec, rank, world, multi)
+    # x_t = c^t must stay a normal number over warmup + steps products: c = 1/2 up to 1000 of them, else 1
+    chain = None if args.warmup + args.steps <= 1000 else 1.0
+    R = setup_rank(torch, D, name, scale, prec, rank, world, multi, chain)
     plan, rp, ci, st, pre_s = R["plan"], R["rp"], R["ci"], R["stats"], R["pre_s"]
     rows, cols, nnz_total, lengths = R["rows"], R["cols"], R["nnz_total"], R["lengths"]
     bounds, stride, r0, r1, x, y, gathered = R["bounds"], R["stride"], R["r0"], R["r1"], R["x"], R["y"], R["gathered"]
@@ -306,7 +308,7 @@ def main():
         full = mp.full_y().double()
         nonempty = torch.from_numpy((lengths > 0).astype(np.float64)).cuda()
         if prec == 64:
-            want = (CHAIN_FACTOR[64] ** t_all) * nonempty
+            want = (R["chain"] ** t_all) * nonempty
             ok = bool(((full - want).abs() <= 1e-9 * want).all().item())
         else:
             ok = bool(torch.isfinite(full).all().item() and ((full >= 0.5 * nonempty) & (full <= 2.0)).all().item())
@@ -326,7 +328,7 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = 2.0 * nnz_total / (ms_per_step * 1e6)
 
-    vals_desc = "A=1, x=1" if mp is None else "a_ij = %g/len(row i), x_0 = 1, x_{t+1} = y_t" % CHAIN_FACTOR[prec]
+    vals_desc = "A=1, x=1" if mp is None else "a_ij = %g/len(row i), x_0 = 1, x_{t+1} = y_t" % R["chain"]
     out = {
         "metric": "SpMV GFLOP/s (f64)" if prec == 64 else "SpMV GFLOP/s (f16)", "value": round(value, 2), "unit": "GFLOP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 6),
