@@ -22,8 +22,10 @@
 //   C16  regular medium tiles carry u16 column offsets from a per-chunk base (10 instead of 12 bytes per f64 nonzero)
 //   WIN  windowed mode: one window of rows per 1024-thread workgroup, its span of x staged once in LDS
 //        (dynamic LDS), every gather of the window served from LDS; y through med_dst
-// Experiment knobs kept as macros (DASP_XG, DASP_LB, DASP_LB_WIN, DASP_XCD, DASP_PERSIST): see DESIGN.md section 4 for
-// the same-device A/B results behind their defaults.
+// DevArgs::acc turns every store of a row's result into y += (dasp_plan_spmv_acc); a plan split into column panels runs one
+// such launch per panel into a partial buffer and dasp_panel_sum_kernel adds the partials.
+// Experiment knobs kept as macros (DASP_XG, DASP_LB, DASP_LB_WIN, DASP_XCD, DASP_PERSIST, DASP_BF/SF/BH/SH): see DESIGN.md
+// section 4 for the same-device A/B results behind their defaults.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
