@@ -65,10 +65,35 @@ def test_packed_format_round_trips(dasp, oracle, mat, opts, prec):
     assert stored >= st_["nnzA"]
 
 
+@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(mat=matrices(), opts=OPTS, prec=st.sampled_from([64, 16]), panels=st.integers(2, 6))
+def test_column_panels_partition_arbitrary_matrices(dasp, mat, opts, prec, panels):
+    """col_panels: the parent keeps the single plan's order_rid; the panels' packed arrays hold every nonzero exactly once,
+    each inside its panel's column range."""
+    rp, ci, v, n = mat
+    m = rp.size - 1
+    dt = np.float64 if prec == 64 else np.float16
+    single = dasp.Plan(rp, ci, v.astype(dt), n, precision=prec, col_panels=1, **opts)
+    plan = dasp.Plan(rp, ci, v.astype(dt), n, precision=prec, col_panels=panels, **opts)
+    assert (plan.order_rid == single.order_rid).all()
+    if ci.size == 0 or m == 0:
+        assert plan.n_panels == 0
+        return
+    got = [[] for _ in range(m)]
+    for k in range(plan.n_panels):
+        sub, cb, ce = plan.panel(k)
+        order = sub.order_rid
+        for slot, (cs, vs) in util.decode_plan(sub).items():
+            assert all(cb <= c < ce for c in cs)
+            got[int(order[slot])] += list(zip(cs, [float(x) for x in vs]))
+    for r in range(m):
+        assert sorted(got[r]) == sorted(zip(ci[rp[r]:rp[r + 1]].tolist(), v[rp[r]:rp[r + 1]].astype(dt).astype(np.float64).tolist()))
+
+
 @pytest.mark.gpu
 @settings(max_examples=80, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
-@given(mat=matrices(), opts=OPTS, prec=st.sampled_from([64, 16]), from_device=st.booleans())
-def test_spmv_matches_csr_for_arbitrary_matrices(dasp, oracle, mat, opts, prec, from_device):
+@given(mat=matrices(), opts=OPTS, prec=st.sampled_from([64, 16]), from_device=st.booleans(), panels=st.sampled_from([1, 1, 2, 3, 5]))
+def test_spmv_matches_csr_for_arbitrary_matrices(dasp, oracle, mat, opts, prec, from_device, panels):
     import torch
     rp, ci, v, n = mat
     m = rp.size - 1
@@ -79,7 +104,7 @@ def test_spmv_matches_csr_for_arbitrary_matrices(dasp, oracle, mat, opts, prec, 
         d = [torch.from_numpy(a).cuda() for a in (rp, ci if ci.size else np.zeros(1, np.int32), v.astype(dt) if v.size else np.zeros(1, dt))]
         plan = dasp.Plan.from_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), m, n, int(rp[-1]), precision=prec, **opts)
     else:
-        plan = dasp.Plan(rp, ci, v.astype(dt), n, precision=prec, **opts).upload()
+        plan = dasp.Plan(rp, ci, v.astype(dt), n, precision=prec, col_panels=panels, **opts).upload()
     x = torch.from_numpy(xh).cuda()
     y = torch.full((max(m, 1),), float("nan"), dtype=tdt, device="cuda")
     plan.spmv(x.data_ptr(), y.data_ptr(), torch.cuda.current_stream().cuda_stream)
