@@ -251,13 +251,16 @@ struct BlockSrc {
             f.a = ldg<NT>(ival + ee);
             f.c = ldg<NT>(icid + ee);
         } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int e = t0 + 16 * j + 4 * kq + q;
-                const int ee = e < t1 ? e : 0;
-                f.a[q] = ival[ee];
-                f.c[q] = icid[ee];
-            }
+            // the lane's 4 consecutive tail entries as one 8-byte + one 16-byte load; the row's tail starts anywhere, so the
+            // loads are only element-aligned (gfx950 global loads take any alignment).  Entries past t1 belong to the next
+            // row (or the arena's padding) and are zeroed in gather().
+            typedef _Float16 f16x4_u __attribute__((ext_vector_type(4), aligned(2)));
+            typedef int i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+            const int e = t0 + 16 * j + 4 * kq;
+            const int ee = e < t1 ? e : 0;
+            const f16x4_u av = *reinterpret_cast<const f16x4_u *>(ival + ee);
+            const i32x4_u cv = *reinterpret_cast<const i32x4_u *>(icid + ee);
+            f.a = av; f.c = cv;
         }
     }
     template <class XV> __device__ __forceinline__ void gather(Frag<T> &f, int i, const XV &x) const
