@@ -64,6 +64,19 @@ __global__ void k_window_spans(const int *rp, const int *ci, const int *ridW, in
     if (lane == 0) { lo_out[w] = lo; hi_out[w] = hi; nnz_out[w] = k; }
 }
 
+// one thread per sampled row: entries, and entries on another 128-byte line of x than the previous entry of the row
+__global__ void k_line_scatter(const int *rp, const int *ci, const int *rows, int n, int shift, RemapDev remap, unsigned long long *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = rows[i], b = rp[r], e = min(rp[r + 1], b + 512);
+    if (e <= b) return;
+    int prev = remap(ci[b]) >> shift, lines = 1;
+    for (int j = b + 1; j < e; ++j) { const int l = remap(ci[j]) >> shift; lines += l != prev; prev = l; }
+    atomicAdd(out, (unsigned long long)lines);
+    atomicAdd(out + 1, (unsigned long long)(e - b));
+}
+
 // one wave per medium block: first chunk (of the nchunks[b] the fill rule keeps) whose columns span more than 65534
 template <int K>
 __global__ void k_chunk_spans(const int *rp, const int *ci, const int *ridM, const int *lenM, const int *nchunks, int nmed, int nb,
@@ -221,6 +234,24 @@ int devpack_window_spans(const Plan &p, const DevCsr &d, const std::vector<int> 
     hipError_t e3 = hipMemcpy(wnnz, dn, sizeof(long long) * (size_t)nW, hipMemcpyDeviceToHost);
     (void)hipFree(dlo); (void)hipFree(dn);
     HIP_TRYP(e1); HIP_TRYP(e2); HIP_TRYP(e3);
+    return DASP_OK;
+}
+
+int devpack_line_scatter(const Plan &p, const DevCsr &d, const std::vector<int> &rows, long long *lines, long long *entries)
+{
+    *lines = 0; *entries = 0;
+    if (rows.empty()) return DASP_OK;
+    RemapHolder rm; if (int rc = rm.init(p)) return rc;
+    DevVec<int> dr; if (int rc = dr.init(rows)) return rc;
+    unsigned long long *dout = nullptr, h[2] = {0, 0};
+    HIP_TRYP(hipMalloc(&dout, sizeof h));
+    hipError_t e0 = hipMemset(dout, 0, sizeof h);
+    const int n = (int)rows.size();
+    hipLaunchKernelGGL(k_line_scatter, dim3((n + 255) / 256), dim3(256), 0, 0, d.rp, d.ci, dr.d, n, p.geo.vbytes == 8 ? 4 : 6, rm.r, dout);
+    hipError_t e1 = hipMemcpy(h, dout, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(dout);
+    HIP_TRYP(e0); HIP_TRYP(e1);
+    *lines = (long long)h[0]; *entries = (long long)h[1];
     return DASP_OK;
 }
 

@@ -292,7 +292,28 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         for (int w = 0; w < nW; ++w) { all += wnnz[w]; if (wlen[w] > 0) { fit += wnnz[w]; maxlen = std::max(maxlen, wlen[w]); } }
         window_frac = all > 0 ? (double)fit / (double)all : 0.0;
         const bool force = p.opt.x_window > 0;
-        const bool worth = window_frac >= 0.5 && (double)all >= 0.5 * (double)nnz;
+        bool worth = window_frac >= 0.5 && (double)all >= 0.5 * (double)nnz;
+        if (worth && !force && !order_only) {
+            // staging pays only when a row's gathers are scattered over the window: if neighbouring nonzeros of a row share
+            // 128-byte lines of x anyway (FEM / stencil rows: runs of adjacent columns), the L1 already serves them and the
+            // copy + window workgroups are pure overhead (HV15R x0.03: 18.2 -> 24.5 us, nlpkkt160 x0.01: 5.7 -> 8.5 us with
+            // windows; line-scatter 0.08-0.37 on the FEM-like stand-ins, 0.89-0.97 on the cop20k_A band)
+            std::vector<int> sample;
+            const int step = std::max(1, nmed / 2048);
+            for (int i = 0; i < nmed; i += step) sample.push_back(ridM_in[i]);
+            long long lines = 0, entries = 0;
+            if (dev) { if (int rc = devpack_line_scatter(p, *dev, sample, &lines, &entries)) return rc; }
+            else {
+                const int shift = geo.vbytes == 8 ? 4 : 6;
+                for (int r : sample) {
+                    const int b = rp[r], e = std::min(rp[r + 1], b + 512);
+                    int prev = remap(ci[b]) >> shift; lines += 1;
+                    for (int j = b + 1; j < e; ++j) { const int l = remap(ci[j]) >> shift; lines += l != prev; prev = l; }
+                    entries += e - b;
+                }
+            }
+            worth = entries > 0 && (double)lines >= 0.6 * (double)entries;
+        }
         if (((force || worth) && fit > 0) || order_only) {
             p.windowed = true; p.row_window = R;
             p.lds_bytes = ((maxlen * geo.vbytes + 255) / 256) * 256;

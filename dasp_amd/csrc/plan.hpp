@@ -140,6 +140,8 @@ struct PackMeta {                                             // what the device
 };
 int devpack_validate(const Plan &p, const DevCsr &d);
 int devpack_window_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridW, int R, int *lo, int *hi, long long *wnnz);
+// over the sampled rows: nonzeros, and how many of them start a new 128-byte line of x relative to their predecessor in the row
+int devpack_line_scatter(const Plan &p, const DevCsr &d, const std::vector<int> &rows, long long *lines, long long *entries);
 int devpack_chunk_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridM, const std::vector<int> &lenM,
                         const std::vector<int> &nchunks, int *k16);
 int devpack_all(Plan &p, const DevCsr &d, const PackMeta &m);

@@ -97,7 +97,8 @@ typedef struct dasp_options {
      * length inside the window only) so that one workgroup's rows share a narrow span of x; that span is copied
      * once into LDS (coalesced) and every gather of the window is served from LDS.  y still goes to the slots
      * of the reference permutation (order_rid is unchanged), through a per-row destination table.
-     *   x_window: 0 = auto (on when the windows of >= half of the medium nonzeros fit), -1 = off,
+     *   x_window: 0 = auto (on when the windows of >= half of the medium nonzeros fit AND the rows' gathers are scattered:
+     *             >= 60 % of a sampled row's nonzeros lie on another 128-byte line of x than their predecessor), -1 = off,
      *             -2 = windowed order without LDS staging (measurement knob: slower than either alternative),
      *             > 0 = force on with this many bytes of LDS per workgroup as the cap (<= 163840; auto uses 81920,
      *                   i.e. two workgroups per CU)

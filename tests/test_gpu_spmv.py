@@ -221,6 +221,7 @@ def test_cop20k_standin_uses_windows(dasp, torch_cuda):
     assert st["x_window_on"] == 1 and st["window_nnz_frac"] > 0.9
 
 
+
 @pytest.mark.parametrize("prec", [64, 16])
 @pytest.mark.parametrize("cid16", [-1, 1])
 @pytest.mark.parametrize("tag,builder,m,n,seed", [("mixed", util.mixed_matrix, 3000, 2500, 7), ("wide", util.mixed_matrix, 2000, 3_000_000, 9)])

@@ -231,3 +231,14 @@ def test_split_by_owner_partitions_a_row_slice(dasp):
         np.testing.assert_array_equal(vl[rpl[r]:rpl[r + 1]], v[rp[r]:rp[r + 1]][own])
         np.testing.assert_array_equal(cir[rpr[r]:rpr[r + 1]], ci[rp[r]:rp[r + 1]][~own])
         np.testing.assert_array_equal(vr[rpr[r]:rpr[r + 1]], v[rp[r]:rp[r + 1]][~own])
+
+
+def test_auto_windows_skip_rows_with_adjacent_columns(dasp):
+    """FEM-like rows gather runs of neighbouring columns: even when their windows fit in LDS, auto leaves staging off"""
+    for name, scale in (("HV15R", 0.03), ("nlpkkt160", 0.01)):
+        rp, ci = dasp.synth_csr(name, scale)
+        _, n = dasp.synth_dims(name, scale)
+        v = np.ones(ci.size)
+        assert dasp.Plan(rp, ci, v, n).stats["x_window_on"] == 0
+        st = dasp.Plan(rp, ci, v, n, x_window=81920).stats                       # they do fit: forcing turns it on
+        assert st["x_window_on"] == 1 and st["n_windows_lds"] == st["n_windows"] > 0
