@@ -803,7 +803,7 @@ int upload_plan(Plan &p)
     a.wg_short = (a.n_short_tiles + a.wpw - 1) / a.wpw;
     // streamed-once matrix data bypasses the caches (the reference's ld.global.cs, dasp_f64.h:34-51)
     // only when it cannot stay resident in the 256 MiB Infinity Cache between two SpMVs anyway.
-    d->nt = p.opt.stream_policy == 2 || (p.opt.stream_policy != 1 && p.stats.data_X > (200ll << 20));
+    d->nt = p.opt.stream_policy == 2 || (p.opt.stream_policy != 1 && p.stats.data_X > kStreamBytes);
     if (p.windowed && p.lds_bytes > 65536) {
         // more than the default 64 KiB of dynamic LDS must be requested per kernel; done here (for both cache-policy
         // variants), not in the launch path, so that dasp_plan_spmv stays free of anything a stream capture would reject
@@ -848,9 +848,9 @@ int set_stream_policy(Plan &p, int policy)
 {
     if (policy < 0 || policy > 2) { set_error("stream_policy must be 0, 1 or 2"); return DASP_ERR_ARG; }
     p.opt.stream_policy = policy;
-    if (p.dev) p.dev->nt = policy == 2 || (policy != 1 && p.stats.data_X > (200ll << 20));
+    if (p.dev) p.dev->nt = policy == 2 || (policy != 1 && p.stats.data_X > kStreamBytes);
     // panels follow the whole matrix: auto means non-temporal when the sum of the panels streams from HBM
-    const int sub = policy != 0 ? policy : (p.stats.data_X > (200ll << 20) ? 2 : 1);
+    const int sub = policy != 0 ? policy : (p.stats.data_X > kStreamBytes ? 2 : 1);
     for (auto &h : p.panels) if (int rc = set_stream_policy(h->impl, sub)) return rc;
     return DASP_OK;
 }

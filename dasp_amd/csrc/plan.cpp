@@ -367,9 +367,11 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     {
         long long e32 = 0, e16 = 0;
         for (int b = 0; b < nb; ++b) { e32 += nchunks[b]; e16 += nchunks16[b]; }
-        // auto: only for matrices that stream from HBM (a cache-resident matrix is latency-bound; there the extra
-        // per-chunk base load costs more than the 2 bytes per nonzero save: cop20k_A 11.6 vs 12.4 us)
-        const bool streams = (long long)nnz * (geo.vbytes + 4) > (200ll << 20);
+        // auto: not for small or LDS-windowed matrices (latency-bound; there the extra per-chunk base load costs more than the
+        // 2 bytes per nonzero save: cop20k_A 11.6 vs 12.4 us).  From ~64 MiB of CSR on it pays on every FEM-like stand-in
+        // (nlpkkt160 x0.03 16.7 -> 15.5 us, Queen x0.05 31.2 -> 27.7, x0.08 56.8 -> 42.5: the packed matrix then fits the
+        // Infinity Cache); windowed plans keep the old bound.
+        const bool streams = (long long)nnz * (geo.vbytes + 4) > (p.windowed ? kStreamBytes : (64ll << 20));
         p.cid16 = try16 && e32 > 0 && (p.opt.cid16 > 0 || (streams && (double)e16 >= 0.97 * (double)e32));
         if (p.cid16) nchunks.swap(nchunks16);
     }
@@ -629,7 +631,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     const bool natural = p.opt.y_order == DASP_Y_NATURAL;
     std::vector<int> slot_of_row;
     if (!natural) { slot_of_row.resize((size_t)m); for (int i = 0; i < m; ++i) slot_of_row[p.order[i]] = i; }
-    const bool streams = (long long)p.nnz * (p.geo.vbytes + 4) > (200ll << 20);
+    const bool streams = (long long)p.nnz * (p.geo.vbytes + 4) > kStreamBytes;
     p.panels.clear(); p.panel_bounds.clear();
     // the panels are built side by side (their O(rows) classifier passes are serial), each with its share of the threads
     std::vector<std::unique_ptr<dasp_plan>> built((size_t)P);

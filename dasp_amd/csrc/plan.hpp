@@ -32,6 +32,9 @@ struct NoInit : std::allocator<T> {
 template <class T> using raw_vector = std::vector<T, NoInit<T>>;
 
 constexpr int kWave = 64;         // gfx950 wavefront
+// packed bytes above which the streamed tiles use non-temporal loads: the 256 MiB Infinity Cache cannot keep the matrix between two
+// SpMVs anyway (A/B around it: 212 MB plain 35.6 us vs nt 42.8; 257 MB plain 42.5 vs nt 51.9; 275 MB nt 54.9 vs plain 57.8)
+constexpr long long kStreamBytes = 256ll << 20;
 constexpr int kWavesPerWG = 4;    // 256-thread workgroups
 constexpr int kMedRows = 16;      // rows of one MFMA tile (v_mfma_*_16x16x*)
 constexpr int kLongAlign = 4;     // long rows start on a multiple of 4 elements

@@ -108,10 +108,10 @@ typedef struct dasp_options {
     int row_window;
     /* 16-bit column ids for the regular medium tiles: u16 offsets from a per-chunk base column (10 instead of 12 bytes
      * per f64 nonzero, 4 instead of 6 for f16).  Chunks spanning more than 65534 columns end their block's regular
-     * part (the rest goes to the 32-bit irregular tail).  0 = auto (on when that loses < 3 % of the regular elements),
+     * part (the rest goes to the 32-bit irregular tail).  0 = auto (on for >= 64 MiB of CSR without x windows -- 256 MiB with them -- when that loses < 3 % of the regular elements),
      * -1 = off, 1 = force on. */
     int cid16;
-    /* cache policy of the streamed tiles: 0 = auto (non-temporal when the packed matrix exceeds ~200 MiB and cannot stay in
+    /* cache policy of the streamed tiles: 0 = auto (non-temporal when the packed matrix exceeds 256 MiB and cannot stay in
      * the Infinity Cache anyway), 1 = plain loads (the reference's dasp_spmv, dasp_f16.h:593-1013), 2 = non-temporal loads
      * (the reference's "bypass" kernel dasp_spmv2 with ld.global.cs, dasp_f64.h:34-51).  x gathers always use plain loads. */
     int stream_policy;
