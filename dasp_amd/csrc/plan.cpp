@@ -240,9 +240,17 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     p.med_dst.clear(); p.win_cmin.clear(); p.win_len.clear();
     double window_frac = 0.0;
     if ((p.opt.x_window >= 0 || p.opt.x_window == -2) && nmed > 0 && !meta_only) {
-        // default window height: taller windows amortise the x copy over more rows but leave fewer workgroups
-        // (A/B on the cop20k_A stand-in: 11.8 us at 512 vs 14.0 at 256 for 108 k rows; 127 us at 1024 vs 156 at 256 for 1.7 M)
-        int R = p.opt.row_window > 0 ? p.opt.row_window : (nmed >= 400000 ? 1024 : (nmed >= 50000 ? 512 : 256));
+        // default window height: every window pays the same x copy whatever its height, so as few windows as still occupy the
+        // 256 CUs -- one workgroup each, or two each (2 x 80 KiB of LDS) once a window would pass 1024 rows.  Just under the
+        // CU count, not at it: sweeps on the cop20k_A stand-in put the optimum at 200-230 windows (162 k medium rows: 318 / 255 /
+        // 231 / 212 / 159 windows = 17.7 / 18.6 / 14.6 / 14.6 / 16.0 us; 130 k: 255 / 226 / 170 = 15.4 / 13.2 / 13.4; 65 k:
+        // 507 / 254 / 127 / 64 = 8.4 / 7.4 / 9.1 / 13.4) and at ~424 for 325 k rows (424 / 318 = 24.6 / 27.3 us).
+        int R = p.opt.row_window;
+        if (R <= 0) {
+            R = ceil_div(ceil_div(nmed, 224), 64) * 64;
+            if (R > 1024) R = ceil_div(ceil_div(nmed, 448), 64) * 64;
+            R = std::max(128, R);
+        }
         R = std::min(1024, std::max(64, (R / 64) * 64));         // <= 16 waves per workgroup, 1-4 blocks per wave
         // default cap: 80 KiB = two workgroups per CU out of gfx950's 160 KiB of LDS
         const bool order_only = p.opt.x_window == -2;          // windowed order, no LDS staging (every window gathers from global memory)

@@ -103,7 +103,7 @@ typedef struct dasp_options {
      *             > 0 = force on with this many bytes of LDS per workgroup as the cap (<= 163840; auto uses 81920,
      *                   i.e. two workgroups per CU)
      *   row_window: rows per window, multiple of 64 up to 1024 (16 rows per block, up to 16 waves per workgroup);
-     *               0 = by size (256 / 512 / 1024 for < 50 k / < 400 k / more medium rows) */
+     *               0 = by size: ~224 windows (one per CU, with slack), ~448 once a window would pass 1024 rows */
     int x_window;
     int row_window;
     /* 16-bit column ids for the regular medium tiles: u16 offsets from a per-chunk base column (10 instead of 12 bytes
