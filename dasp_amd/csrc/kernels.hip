@@ -108,6 +108,10 @@ __device__ __forceinline__ int slot_of(const SlotMap &m, int t)
 }
 
 // chunks per software-pipeline batch / per one-shot (A/B knobs; defaults chosen on the HBM-bound stand-ins)
+#ifndef DASP_TAILV
+#define DASP_TAILV 0   // 1: f16 tail entries as one 8-byte + one 16-byte element-aligned load per lane instead of eight scalar loads:
+                       // +2-4 % on the small f16 stand-ins, -5 % on the column panels of ljournal-2008
+#endif
 #ifndef DASP_BF
 #define DASP_BF 4
 #endif
@@ -254,6 +258,7 @@ struct BlockSrc {
             // the lane's 4 consecutive tail entries as one 8-byte + one 16-byte load; the row's tail starts anywhere, so the
             // loads are only element-aligned (gfx950 global loads take any alignment).  Entries past t1 belong to the next
             // row (or the arena's padding) and are zeroed in gather().
+#if DASP_TAILV
             typedef _Float16 f16x4_u __attribute__((ext_vector_type(4), aligned(2)));
             typedef int i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
             const int e = t0 + 16 * j + 4 * kq;
@@ -261,6 +266,15 @@ struct BlockSrc {
             const f16x4_u av = *reinterpret_cast<const f16x4_u *>(ival + ee);
             const i32x4_u cv = *reinterpret_cast<const i32x4_u *>(icid + ee);
             f.a = av; f.c = cv;
+#else
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = t0 + 16 * j + 4 * kq + q;
+                const int ee = e < t1 ? e : 0;
+                f.a[q] = ival[ee];
+                f.c[q] = icid[ee];
+            }
+#endif
         }
     }
     template <class XV> __device__ __forceinline__ void gather(Frag<T> &f, int i, const XV &x) const

@@ -661,7 +661,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
                     q.opt.y_order = DASP_Y_NATURAL; q.opt.n_parts = 0; q.opt.part_bounds = nullptr; q.opt.part_stride = 0;
                     q.opt.col_panels = 1; q.opt.host_threads = each;
                     if (q.opt.stream_policy == 0) q.opt.stream_policy = streams ? 2 : 1;   // the policy follows the whole matrix, not one panel
-                    q.dst_map = slot_of_row;
+                    q.dst_map = slot_of_row; q.panel = true;
                     try { rcs[k] = build_impl<T>(q, rpP[k].data(), ciP[k].data(), valP[k].data(), nullptr, kPanel); }
                     catch (const std::bad_alloc &) { rcs[k] = DASP_ERR_NOMEM; set_error("out of host memory"); }
                     if (rcs[k] != DASP_OK) { errs[k] = last_error_cstr(); continue; }

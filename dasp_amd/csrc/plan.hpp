@@ -125,6 +125,7 @@ struct Plan {
     // ypart[k][dst_map[r]] (dst_map = the parent's slot of each row; empty when the parent itself is in natural order)
     std::vector<std::unique_ptr<dasp_plan>> panels;
     std::vector<int> panel_bounds;     // [panels.size()+1] pairs flattened: begin/end per kept panel (empty panels are dropped)
+    bool panel = false;                // this plan is one column panel of another
     std::vector<int> dst_map;          // [m] set on a panel: row -> y index (instead of the row id) in natural order
 
     bool host_dropped = false;

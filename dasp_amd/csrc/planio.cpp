@@ -79,6 +79,7 @@ static bool read_plan(Reader &r, Plan &p, int depth)
     p.cnt_long = p.long_cid.size(); p.cnt_irr = p.irr_cid.size(); p.cnt_short = p.short_cid.size();
     p.cnt_reg = p.cid16 ? p.med_cid16.size() : p.med_cid.size();
     p.host_dropped = false;
+    p.panel = depth > 0;
     p.opt.col_panels = np > 0 ? np : 1;
     for (int k = 0; k < np; ++k) {
         std::unique_ptr<dasp_plan> h(new dasp_plan());
