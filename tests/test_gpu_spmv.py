@@ -621,3 +621,26 @@ def test_accumulate_mode_adds_into_y(oracle, dasp, torch_cuda, prec, kw):
     if prec == 64 and "col_panels" not in kw:
         assert (got == y0 + ax).all()                               # same products, one extra add: bit-identical to y0 + (A x)
     plan.close()
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("shape", ["one_huge_row", "single_row", "single_column", "all_long", "tall_thin_len1"])
+def test_extreme_shapes(oracle, dasp, torch_cuda, prec, shape):
+    dt = np.float64 if prec == 64 else np.float16
+    rng = np.random.default_rng(5)
+    if shape == "one_huge_row":            # 3 M nonzeros in one row (2930 pieces -> the partial-sum stage) among ordinary rows
+        lens = rng.choice([0, 1, 3, 7, 30], size=300)
+        lens[137] = 3_000_000
+        n = 4_000_000
+    elif shape == "single_row":
+        lens, n = np.array([70_000]), 100_000
+    elif shape == "single_column":         # every row reads x[0]
+        lens, n = rng.choice([0, 1, 1, 1], size=50_000), 1
+    elif shape == "all_long":
+        lens, n = rng.integers(256, 3000, size=400), 50_000
+    else:
+        lens, n = np.ones(300_000, np.int64), 7
+    rp, ci, v = util.csr_from_lengths(lens, n, 9, values="f16" if prec == 16 else "uniform", dtype=dt)
+    if prec == 16 and shape in ("one_huge_row", "single_row"):
+        v = (v.astype(np.float64) / 64).astype(dt)          # keep the long sums inside binary16
+    check(oracle, dasp, torch_cuda, rp, ci, v, n, prec)
