@@ -388,7 +388,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_suite:
         suite = []
         for nm, pr in (("cop20k_A", 64), ("nlpkkt160", 64), ("powerlaw_1M", 64), ("Queen_4147", 64),
-                       ("webbase-1M", 16), ("ljournal-2008", 16)):
+                       ("webbase-1M", 16), ("ljournal-2008", 16), ("rmat_2M", 16)):
             try:
                 suite.append(suite_entry(torch, D, nm, pr, args.suite_scale))
             except Exception as exc:   # a failing extra must not hide the headline line

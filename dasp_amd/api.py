@@ -280,7 +280,7 @@ def selftest_mfma():
 
 
 # ---- synthetic stand-ins for the SuiteSparse inputs (dasp_amd/csrc/gen.cpp) -----------------
-SYNTH_NAMES = ("cop20k_A", "nlpkkt160", "powerlaw_1M", "webbase-1M", "ljournal-2008", "HV15R", "Queen_4147")
+SYNTH_NAMES = ("cop20k_A", "nlpkkt160", "powerlaw_1M", "webbase-1M", "ljournal-2008", "HV15R", "Queen_4147", "rmat_2M")
 
 
 def synth_dims(name, scale=1.0):

@@ -12,6 +12,8 @@
 //   webbase-1M    1000005 rows, power-law lengths (mean ~3.1, max 4700), 70% near / 30% uniform columns
 //   ljournal-2008 5363260 rows, power-law lengths (mean ~14.7, max 2469), uniform columns
 //   powerlaw_1M   2^20 rows, Zipf(1.8) lengths clipped at 200000 (mean ~48), uniform columns
+//   rmat_2M       2^21 rows, R-MAT / Graph500 (a, b, c, d = 0.57, 0.19, 0.19, 0.05), 16 edges per row on average: skewed degrees AND
+//                 skewed, community-structured columns -- a closer proxy for web / social graphs than uniform columns
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -35,7 +37,7 @@ inline uint64_t h2(uint64_t seed, uint64_t a, uint64_t b) { return mix(mix(seed 
 inline double u01(uint64_t h) { return ((h >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
 
 struct Synth {
-    enum Kind { GRID, BAND, POWER } kind;
+    enum Kind { GRID, BAND, POWER, RMAT } kind;
     int rows = 0, cols = 0;
     uint64_t seed = 0;
     // GRID
@@ -45,6 +47,8 @@ struct Synth {
     int band = 0; double deg_mean = 0, deg_sd = 0; int deg_max = 0; double tbar = 1;
     // POWER
     double alpha = 2, xmin = 1, p_zero = 0, near_frac = 0; int len_max = 0, near_w = 0;
+    // RMAT
+    int levels = 0; double edge_factor = 16;
 };
 
 int scaled(int full, double s) { return std::max(64, (int)std::llround(full * s)); }
@@ -79,6 +83,12 @@ bool make(const char *name, double scale, Synth &g)
     if (n == "webbase-1M") { power(1000005, 2.45, 1.32, 0.02, 4700, 0.7, 1000, 20004); return true; }
     if (n == "ljournal-2008") { power(5363260, 2.35, 4.6, 0.01, 2469, 0.0, 0, 20005); return true; }
     if (n == "powerlaw_1M") { power(1 << 20, 1.8, 2.05, 0.0, 200000, 0.0, 0, 20003); return true; }
+    if (n == "rmat_2M") {
+        g.kind = Synth::RMAT; g.seed = 20008; g.rows = g.cols = scaled(1 << 21, scale);
+        g.levels = 1; while ((1ll << g.levels) < g.rows) g.levels++;
+        g.edge_factor = 16; g.len_max = std::max(8, g.cols / 2);
+        return true;
+    }
     return false;
 }
 
@@ -199,9 +209,40 @@ int power_row(const Synth &g, int i, int *out)
     return len;
 }
 
+// ---- RMAT rows --------------------------------------------------------------------------
+// Row i of an R-MAT matrix, generated on its own: the expected degree of source i is edges * prod over its bits of
+// (a+b = 0.76 for a 0 bit, c+d = 0.24 for a 1 bit); each destination bit is 1 with probability b/(a+b) = 1/4 under a 0 source
+// bit and d/(c+d) ~ 7/32 under a 1 source bit.  Entries are not de-duplicated (the plan takes duplicates as they come).
+inline int rmat_len(const Synth &g, int i)
+{
+    double d = g.edge_factor * (double)g.rows;
+    for (int b = 0; b < g.levels; ++b) d *= ((i >> b) & 1) ? 0.24 : 0.76;
+    const double u = u01(h2(g.seed, (uint64_t)i, 21));
+    return (int)std::min<double>(g.len_max, std::floor(d + u));      // stochastic rounding: E[len] = d
+}
+
+int rmat_row(const Synth &g, int i, int *out)
+{
+    const int len = rmat_len(g, i);
+    if (!out) return len;
+    for (int k = 0; k < len; ++k) {
+        uint64_t h = h2(g.seed ^ 0x7a7aull, (uint64_t)i, (uint64_t)k);
+        long long col = 0;
+        for (int b = 0, used = 0; b < g.levels; ++b, used += 5) {
+            if (used + 5 > 64) { h = mix(h ^ 0x1234567ull); used = 0; }
+            const unsigned r5 = (unsigned)(h >> used) & 31u;
+            const unsigned cut = ((i >> b) & 1) ? 7u : 8u;           // P(bit = 1) = 7/32 or 8/32
+            if (r5 < cut) col |= 1ll << b;
+        }
+        out[k] = (int)(col % g.cols);
+    }
+    return len;
+}
+
 inline int any_row(const Synth &g, int row, int *out, const float *tg, int tg0)
 {
     switch (g.kind) {
+        case Synth::RMAT: return rmat_row(g, row, out);
         case Synth::GRID: return grid_row(g, row, out);
         case Synth::BAND: return band_row(g, row, out, tg, tg0);
         default: return power_row(g, row, out);

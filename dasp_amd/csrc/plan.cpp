@@ -585,6 +585,22 @@ static int decide_panels(const Plan &p, const int *rp, const int *ci, const Rema
     }
     if (entries < 4096) return 1;
     if ((double)lines <= 0.75 * (double)entries || (double)wide < 0.5 * (double)entries) return 1;
+    {   // scattered is not enough: real graphs have popular columns, and if the hottest 3 MiB of x lines already take most of
+        // the gathers the L2 serves them without blocking (R-MAT 2^21 f64: 92 % of the gathers on 3 MiB of lines, panels
+        // -24 %; 2^23: 76 %, panels +9 %; the uniform stand-ins: 25-44 %, panels +45-55 %)
+        const long long xlines = (xlen >> line_shift) + 1;
+        std::vector<int> hist((size_t)xlines, 0);
+        const long long S2 = std::min<long long>(p.nnz, 1ll << 21), stride = std::max<long long>(1, p.nnz / S2);
+        long long taken = 0;
+        for (long long j = 0; j < p.nnz; j += stride) { hist[(size_t)(remap(ci[j]) >> line_shift)]++; ++taken; }
+        const size_t cap = (size_t)((3ll << 20) / 128);
+        long long hot = 0;
+        if (hist.size() > cap) {
+            std::nth_element(hist.begin(), hist.begin() + (long long)cap, hist.end(), std::greater<int>());
+            for (size_t k = 0; k < cap; ++k) hot += hist[k];
+        } else hot = taken;
+        if ((double)hot >= 0.8 * (double)taken) return 1;
+    }
     // panels of ~2.75 MiB of x (they must fit the 4 MiB L2 of an XCD next to the streamed tiles), and >= ~4 nonzeros per row
     // and panel: every extra panel re-pays the per-row cost (row tables, a partial y, shorter rows with fewer gathers in
     // flight).  Sweep on the stand-ins (tools/panel_probe.py): powerlaw_1M f64 (x 8 MB) 0.99 / 0.71 / 0.68 / 0.70 / 0.82 ms at

@@ -120,7 +120,8 @@ typedef struct dasp_options {
      * the x entries a launch gathers (x_len / col_panels of them) stay in the 4 MiB L2 of every XCD; a last streaming
      * kernel adds the panels' partial results.  order_rid and the classifier counters stay those of the whole matrix.
      *   0 = auto (on for matrices whose rows scatter over more x than the L2 holds: x > 4 MiB, >= 16 M nonzeros,
-     *       > 75 % of a row's nonzeros on distinct 128-byte lines of x and rows spanning > x/4; host CSR only),
+     *       > 75 % of a row's nonzeros on distinct 128-byte lines of x, rows spanning > x/4, and < 80 % of the gathers on the
+     *       hottest 3 MiB of x lines; host CSR only),
      *   1 or -1 = off,  2..64 = that many panels.
      * f16: the per-panel partial results are rounded to binary16 before they are added (in f32). */
     int col_panels;

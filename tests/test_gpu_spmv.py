@@ -107,7 +107,7 @@ def test_empty_matrix(dasp, torch_cuda, prec):
 
 @pytest.mark.parametrize("name,prec,scale", [
     ("cop20k_A", 64, 0.1), ("nlpkkt160", 64, 0.004), ("powerlaw_1M", 64, 0.05), ("HV15R", 64, 0.01),
-    ("Queen_4147", 64, 0.005), ("webbase-1M", 16, 0.1), ("ljournal-2008", 16, 0.01),
+    ("Queen_4147", 64, 0.005), ("webbase-1M", 16, 0.1), ("ljournal-2008", 16, 0.01), ("rmat_2M", 64, 0.02), ("rmat_2M", 16, 0.02),
 ])
 def test_parity_synthetic_standins(oracle, dasp, torch_cuda, name, prec, scale):
     rows, cols = dasp.synth_dims(name, scale)
