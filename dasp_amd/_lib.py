@@ -23,7 +23,7 @@ class Options(C.Structure):
         ("threshold", C.c_double), ("block_longest", C.c_int), ("y_order", C.c_int), ("long_piece", C.c_int),
         ("host_threads", C.c_int), ("n_parts", C.c_int), ("part_bounds", C.POINTER(C.c_int)), ("part_stride", C.c_int),
         ("x_window", C.c_int), ("row_window", C.c_int), ("cid16", C.c_int), ("stream_policy", C.c_int),
-        ("col_panels", C.c_int),
+        ("col_panels", C.c_int), ("slab_max_len", C.c_int),
     ]
 
 

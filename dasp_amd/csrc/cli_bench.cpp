@@ -15,7 +15,7 @@
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { std::printf("usage: dasp_bench <workload> [scale] [precision] [iters] [warmup] [threshold] [long_piece] [x_window] [row_window] [cid16] [col_panels] [stream_policy]\n"); return 0; }
+    if (argc < 2) { std::printf("usage: dasp_bench <workload> [scale] [precision] [iters] [warmup] [threshold] [long_piece] [x_window] [row_window] [cid16] [col_panels] [stream_policy] [slab_max_len]\n"); return 0; }
     const char *name = argv[1];
     const double scale = argc > 2 ? std::atof(argv[2]) : 1.0;
     const int prec = argc > 3 ? std::atoi(argv[3]) : 64;
@@ -28,6 +28,7 @@ int main(int argc, char **argv)
     const int cid16 = argc > 10 ? std::atoi(argv[10]) : 0;
     const int col_panels = argc > 11 ? std::atoi(argv[11]) : 0;
     const int stream_policy = argc > 12 ? std::atoi(argv[12]) : 0;
+    const int slab_max_len = argc > 13 ? std::atoi(argv[13]) : 0;
     int rows, cols;
     CHECK(dasp_synth_dims(name, scale, &rows, &cols));
     std::vector<int> rp((size_t)rows + 1, 0);
@@ -43,7 +44,7 @@ int main(int argc, char **argv)
     else for (int i = 0; i < nnz; ++i) reinterpret_cast<uint16_t *>(val.data())[i] = 0x3C00;
     dasp_options_t opt;
     dasp_options_default(&opt);
-    opt.threshold = threshold; opt.long_piece = long_piece; opt.x_window = x_window; opt.row_window = row_window; opt.cid16 = cid16; opt.col_panels = col_panels; opt.stream_policy = stream_policy;
+    opt.threshold = threshold; opt.long_piece = long_piece; opt.x_window = x_window; opt.row_window = row_window; opt.cid16 = cid16; opt.col_panels = col_panels; opt.stream_policy = stream_policy; opt.slab_max_len = slab_max_len;
     dasp_plan_t *plan = nullptr;
     CHECK(dasp_plan_create(&plan, prec, rows, cols, nnz, rp.data(), ci.data(), val.data(), &opt));
     CHECK(dasp_plan_upload(plan));

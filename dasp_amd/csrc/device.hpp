@@ -33,6 +33,7 @@ struct DevArgs {
     // short
     const void *short_val; const int *short_cid; const ShortDev *groups;
     int n_short_tiles;
+    int grp_tile0[kNumShortGroups];   // first tile of every slab group (kernel arguments: the lookup is scalar)
     // permutation (DASP_Y_NATURAL only)
     const int *order;
     // workgroup ranges

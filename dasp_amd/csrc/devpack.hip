@@ -77,6 +77,18 @@ __global__ void k_line_scatter(const int *rp, const int *ci, const int *rows, in
     atomicAdd(out + 1, (unsigned long long)(e - b));
 }
 
+// one thread per pair of equally long rows: positions whose columns lie within 16 of each other
+__global__ void k_row_coherence(const int *rp, const int *ci, const int *rows, int npairs, RemapDev remap, unsigned long long *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npairs) return;
+    const int a = rp[rows[2 * i]], b = rp[rows[2 * i + 1]], len = rp[rows[2 * i] + 1] - a;
+    int near = 0;
+    for (int k = 0; k < len; ++k) { const int d = remap(ci[a + k]) - remap(ci[b + k]); near += d > -16 && d < 16; }
+    atomicAdd(out, (unsigned long long)near);
+    atomicAdd(out + 1, (unsigned long long)len);
+}
+
 // one wave per medium block: first chunk (of the nchunks[b] the fill rule keeps) whose columns span more than 65534
 template <int K>
 __global__ void k_chunk_spans(const int *rp, const int *ci, const int *ridM, const int *lenM, const int *nchunks, int nmed, int nb,
@@ -255,6 +267,24 @@ int devpack_line_scatter(const Plan &p, const DevCsr &d, const std::vector<int> 
     return DASP_OK;
 }
 
+int devpack_row_coherence(const Plan &p, const DevCsr &d, const std::vector<int> &rows, long long *near, long long *entries)
+{
+    *near = 0; *entries = 0;
+    const int npairs = (int)(rows.size() / 2);
+    if (npairs == 0) return DASP_OK;
+    RemapHolder rm; if (int rc = rm.init(p)) return rc;
+    DevVec<int> dr; if (int rc = dr.init(rows)) return rc;
+    unsigned long long *dout = nullptr, h[2] = {0, 0};
+    HIP_TRYP(hipMalloc(&dout, sizeof h));
+    hipError_t e0 = hipMemset(dout, 0, sizeof h);
+    hipLaunchKernelGGL(k_row_coherence, dim3((npairs + 255) / 256), dim3(256), 0, 0, d.rp, d.ci, dr.d, npairs, rm.r, dout);
+    hipError_t e1 = hipMemcpy(h, dout, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(dout);
+    HIP_TRYP(e0); HIP_TRYP(e1);
+    *near = (long long)h[0]; *entries = (long long)h[1];
+    return DASP_OK;
+}
+
 int devpack_chunk_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridM, const std::vector<int> &lenM,
                         const std::vector<int> &nchunks, int *k16)
 {
@@ -309,9 +339,9 @@ static int pack_all_typed(Plan &p, const DevCsr &d, const PackMeta &m)
                                dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic);
         HIP_TRYP(hipDeviceSynchronize());
     }
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < kNumShortGroups; ++g) {
         const ShortGroup &G = p.grp[g];
-        if (G.tiles == 0) continue;
+        if (G.tiles == 0 || G.len == 0) continue;
         DevVec<int> dl;
         if (int rc = dl.init(*m.glist[g])) return rc;
         const long long n = (long long)G.tiles * p.geo.short_rows * G.len;

@@ -514,20 +514,64 @@ __device__ __forceinline__ void short_rows(const DevArgs &a, const ShortDev &g, 
     }
 }
 
+// the same for the medium rows stored as slabs (5 <= L <= kSlabMaxLen): L is a run-time value, four steps in flight
+template <class T, bool NT>
+__device__ __forceinline__ void slab_rows(const DevArgs &a, const ShortDev &g, int local_tile, int lane)
+{
+    constexpr int SR = Tr<T>::SHORT_ROWS;
+    constexpr int V = SR / kWave;
+    const T *x = static_cast<const T *>(a.x);
+    const T *val = static_cast<const T *>(a.short_val);
+    using part_t = typename Tr<T>::part_t;
+    const int L = g.len;
+    part_t s[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) s[v] = 0;
+    const size_t base = (size_t)g.elem_off + (size_t)local_tile * L * SR + (size_t)V * lane;
+#pragma unroll 4
+    for (int k = 0; k < L; ++k) {
+        if constexpr (V == 2) {
+            const f64x2 av = ldg<NT>(reinterpret_cast<const f64x2 *>(val + base + (size_t)k * SR));
+            const i32x2 c = ldg<NT>(reinterpret_cast<const i32x2 *>(a.short_cid + base + (size_t)k * SR));
+            const double x0 = x[c[0] < 0 ? 0 : c[0]], x1 = x[c[1] < 0 ? 0 : c[1]];
+            s[0] += av[0] * (c[0] < 0 ? 0.0 : x0);
+            s[1] += av[1] * (c[1] < 0 ? 0.0 : x1);
+        } else {
+            const f16x4 av = ldg<NT>(reinterpret_cast<const f16x4 *>(val + base + (size_t)k * SR));
+            const i32x4 c = ldg<NT>(reinterpret_cast<const i32x4 *>(a.short_cid + base + (size_t)k * SR));
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const _Float16 xv = x[c[v] < 0 ? 0 : c[v]];
+                s[v] += (float)av[v] * (c[v] < 0 ? 0.0f : (float)xv);
+            }
+        }
+    }
+    const int t0 = local_tile * SR + V * lane;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int t = t0 + v;
+        if (t < g.count) {
+            const int slot = g.map.base[0] + t;                  // slab groups map linearly onto the medium slots
+            const int yi = a.order ? a.order[slot] : slot;
+            put_y<T>(a, yi, s[v]);
+        }
+    }
+}
+
 template <class T, bool NT>
 __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
 {
     int gi = 0;
-#pragma unroll
-    for (int g = 1; g < kNumShortGroups; ++g) if (tile >= a.groups[g].tile0) gi = g;
+    for (int g = 1; g < kNumShortGroups; ++g) if (tile >= a.grp_tile0[g]) gi = g;     // kernel arguments: scalar compares
     const ShortDev g = a.groups[gi];
     const int local = tile - g.tile0;
     switch (g.len) {
+        case 0: short_rows<T, 0, NT>(a, g, local, lane); break;    // empty rows: y = 0
         case 1: short_rows<T, 1, NT>(a, g, local, lane); break;
         case 2: short_rows<T, 2, NT>(a, g, local, lane); break;
         case 3: short_rows<T, 3, NT>(a, g, local, lane); break;
         case 4: short_rows<T, 4, NT>(a, g, local, lane); break;
-        default: short_rows<T, 0, NT>(a, g, local, lane); break;   // empty rows: y = 0
+        default: slab_rows<T, NT>(a, g, local, lane); break;
     }
 }
 
@@ -801,7 +845,8 @@ int upload_plan(Plan &p)
     a.n_pieces = (int)p.piece_dst.size(); a.n_multi = (int)p.multi_dst.size();
     a.med_ptr = (const int *)(base + o_mptr); a.med_val = base + o_mv; a.med_cid = (const int *)(base + o_mc);
     a.irr_ptr = (const int *)(base + o_ip); a.irr_val = base + o_iv; a.irr_cid = (const int *)(base + o_ic);
-    a.n_blocks = p.stats.n_med_blocks; a.row_block = p.stats.row_block; a.row_long = p.stats.row_long;
+    a.n_blocks = p.stats.n_med_blocks; a.row_block = p.n_mfma_rows; a.row_long = p.stats.row_long;
+    for (int g = 0; g < kNumShortGroups; ++g) a.grp_tile0[g] = p.grp[g].tile0;
     a.short_val = base + o_sv; a.short_cid = (const int *)(base + o_sc); a.groups = (const ShortDev *)(base + o_g);
     a.n_short_tiles = p.stats.n_short_tiles;
     a.order = natural ? (const int *)(base + o_ord) : nullptr;

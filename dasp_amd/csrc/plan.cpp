@@ -58,6 +58,9 @@ struct Remap {
 };
 }  // namespace
 
+// default longest slab-stored medium row (rowlen_probe: blocks reach the slabs' efficiency only past these lengths)
+constexpr int kSlabDefaultF64 = 16, kSlabDefaultF16 = 24;
+
 enum BuildMode { kTop = 0, kMetaOnly = 1, kPanel = 2 };   // whole plan (may choose column panels) / order+stats only / one panel
 
 template <class T> static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int P);
@@ -147,7 +150,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
 
     lap("sort medium");
     // ---- output permutation (order_rid): dasp_f64.h:960-976 / dasp_f16.h:1253-1270
-    const int base_s = nlong + nmed;
+    const int base_s = nlong + nmed;   // (all medium rows: the slab split happens below)
     const int pg = f16 ? 32 : 8;
     {
         auto linear = [](int count, int base) { SlotMap s{}; s.split = count; s.base[0] = base; s.base[1] = base; return s; };
@@ -166,13 +169,61 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         p.grp[2].len = 3; p.grp[2].count = n3_all; p.grp[2].map = m3;
         p.grp[3].len = 4; p.grp[3].count = n4; p.grp[3].map = linear(n4, b4);
         p.grp[4].len = 0; p.grp[4].count = nz0; p.grp[4].map = linear(nz0, b0);
+        for (int g = 5; g < kNumShortGroups; ++g) { p.grp[g] = ShortGroup{}; p.grp[g].len = g; }
+    }
+    // ---- medium rows short enough to be stored as uniform-length slabs instead of MFMA blocks (opt.slab_max_len): the
+    // sorted order puts them last, each length a contiguous run, so a slab's rows keep the slots nlong + position.
+    // Defaults from tools/rowlen_probe.py (8 M rows of one length, fraction of the roofline as blocks / as slabs).
+    int slab_max = std::min(kSlabMaxLen, std::max(4, p.opt.slab_max_len > 0 ? p.opt.slab_max_len : (f16 ? kSlabDefaultF16 : kSlabDefaultF64)));
+    const int nmed_all = nmed;
+    int nmf = nmed;
+    while (nmf > 0 && lenM[nmf - 1] <= slab_max) --nmf;               // lenM is sorted descending
+    if (p.opt.slab_max_len <= 0 && nmf < nmed_all && !meta_only) {
+        // auto: a slab lane owns whole rows, so the 64 lanes of a step gather x for 128 / 256 different rows.  That only beats
+        // the blocks when neighbouring rows read neighbouring columns (stencils: the step's gathers coalesce, 8 M rows of 5:
+        // 0.39 -> 0.82 of the roofline); on graph-like rows every lane hits another line and fewer, longer waves lose
+        // (webbase-1M 16.9 -> 22 us, ljournal-2008 0.61 -> 0.70 ms, cop20k_A loses its LDS windows: 11 -> 32 us).
+        // Measure it: pairs of successive equally long candidate rows, share of positions whose columns differ by < 16.
+        std::vector<int> pairs;
+        const int cand = nmed_all - nmf, step = std::max(2, (cand / 4096) & ~1);
+        for (int i = nmf; i + 1 < nmed_all; i += step)
+            if (lenM[i] == lenM[i + 1]) { pairs.push_back(ridM[i]); pairs.push_back(ridM[i + 1]); }
+        long long near = 0, entries = 0;
+        if (dev) { if (int rc = devpack_row_coherence(p, *dev, pairs, &near, &entries)) return rc; }
+        else
+            for (size_t q = 0; q + 1 < pairs.size(); q += 2) {
+                const int a = rp[pairs[q]], b = rp[pairs[q + 1]], len = rp[pairs[q] + 1] - a;
+                for (int k = 0; k < len; ++k) { const int d = remap(ci[a + k]) - remap(ci[b + k]); near += d > -16 && d < 16; }
+                entries += len;
+            }
+        if (entries == 0 || (double)near < 0.5 * (double)entries) { slab_max = 4; nmf = nmed_all; }
+    }
+    std::vector<std::vector<int>> slab_rows((size_t)kSlabMaxLen + 1);
+    for (int i = nmf; i < nmed_all; ) {
+        const int L = lenM[i];
+        int j = i;
+        while (j < nmed_all && lenM[j] == L) ++j;
+        slab_rows[L].assign(ridM.begin() + i, ridM.begin() + j);
+        ShortGroup &G = p.grp[L];                                       // group index == row length for L >= 5
+        G.count = j - i; G.map = SlotMap{}; G.map.split = G.count; G.map.base[0] = G.map.base[1] = nlong + i;
+        i = j;
     }
     const std::vector<int> *glist[kNumShortGroups] = {&rid1, &rid2, &rid3, &rid4, &rid0};
+    for (int g = 5; g < kNumShortGroups; ++g) glist[g] = &slab_rows[g];
     p.order.assign((size_t)m, -1);
     for (int i = 0; i < nlong; ++i) p.order[i] = ridL[i];
     for (int i = 0; i < nmed; ++i) p.order[nlong + i] = ridM[i];
     for (int g = 0; g < kNumShortGroups; ++g)
         for (int t = 0; t < p.grp[g].count; ++t) p.order[p.grp[g].map.slot(t)] = (*glist[g])[t];
+    // from here on "medium" means the MFMA part only
+    if (nmf < nmed_all) {
+        ridM.resize((size_t)nmf); lenM.resize((size_t)nmf);
+        std::vector<int> keep; keep.reserve((size_t)nmf);
+        for (int r : ridM_in) if (rp[r + 1] - rp[r] > slab_max) keep.push_back(r);
+        ridM_in.swap(keep);
+        nmed = nmf;
+    }
+    p.n_mfma_rows = nmf;
     const bool natural = p.opt.y_order == DASP_Y_NATURAL;
     const bool mapped = natural && !p.dst_map.empty();     // a panel writing into its parent's slot order
     auto rowdst = [&](int row) { return mapped ? p.dst_map[row] : row; };
@@ -474,15 +525,16 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         p.short_val.resize((size_t)off * sizeof(T));           // not zero-filled: only a slab's last tile has pads
         p.short_cid.resize((size_t)off);
         T *sv = reinterpret_cast<T *>(p.short_val.data());
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < kNumShortGroups; ++g) {
             const ShortGroup &G = p.grp[g];
-            if (G.tiles == 0) continue;
+            if (G.tiles == 0 || G.len == 0) continue;
             const size_t t0 = (size_t)G.elem_off + (size_t)(G.tiles - 1) * G.len * SR, t1 = t0 + (size_t)G.len * SR;
             std::fill(sv + t0, sv + t1, (T)0);
             std::fill(p.short_cid.begin() + t0, p.short_cid.begin() + t1, -1);
         }
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < kNumShortGroups; ++g) {
             const ShortGroup &G = p.grp[g];
+            if (G.len == 0 || G.count == 0) continue;
             const std::vector<int> &list = *glist[g];
             parallel_for(G.count, threads, 1 << 14, [&](long long b, long long e) {
                 for (long long t = b; t < e; ++t) {
@@ -505,7 +557,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     std::memset(&s, 0, sizeof s);
     s.precision = p.precision; s.rowA = m; s.colA = p.n; s.nnzA = nnz;
     s.short_row_1 = n1; s.common_13 = c13; s.short_row_3 = n3; s.short_row_4 = n4; s.short_row_2 = n2;
-    s.row_long = nlong; s.row_block = nmed; s.row_zero = nz0;
+    s.row_long = nlong; s.row_block = nmed_all; s.row_zero = nz0;
     s.nnz_short = nnz_short; s.nnz_long = (int)nnz_long; s.nnz_irreg = nnz_irreg;
     s.origin_nnz_reg = nnz - nnz_irreg - (int)nnz_long - nnz_short;
     s.rowloop = nmed < 59990 ? 1 : (nmed < 400000 ? 2 : 4);

@@ -38,7 +38,9 @@ constexpr long long kStreamBytes = 256ll << 20;
 constexpr int kWavesPerWG = 4;    // 256-thread workgroups
 constexpr int kMedRows = 16;      // rows of one MFMA tile (v_mfma_*_16x16x*)
 constexpr int kLongAlign = 4;     // long rows start on a multiple of 4 elements
-constexpr int kNumShortGroups = 5;  // row lengths 1,2,3,4 and 0 (zero rows only get y=0)
+constexpr int kSlabMaxLen = 32;     // longest medium row that can be stored as a uniform-length slab (opt.slab_max_len)
+// slab groups: row lengths 1,2,3,4 and 0 (zero rows only get y=0) -- the reference's short rows -- then 5..kSlabMaxLen
+constexpr int kNumShortGroups = 5 + (kSlabMaxLen - 4);
 
 struct Geometry {
     int vbytes;      // 8 / 2
@@ -103,7 +105,8 @@ struct Plan {
     bool cid16 = false;
     raw_vector<uint16_t> med_cid16;  // u16 offsets from med_base[chunk], 0xFFFF = pad (cid16 on)
     std::vector<int> med_base;        // [chunks]
-    std::vector<int> irr_ptr;       // [row_block+1]
+    int n_mfma_rows = 0;            // medium rows handled as MFMA blocks (the longest ones; the rest are slabs, see grp[5..])
+    std::vector<int> irr_ptr;       // [n_mfma_rows+1]
     raw_vector<char> irr_val;
     raw_vector<int> irr_cid;
     // windowed mode (LDS-staged x): medium positions follow the windowed order; med_dst[pos] = y index,
@@ -140,12 +143,15 @@ struct DevCsr { const int *rp, *ci; const void *val; };      // device pointers
 struct PackMeta {                                             // what the device packers need, in packing order
     const std::vector<int> *ridL = nullptr; const std::vector<long long> *startL = nullptr;
     const std::vector<int> *ridM = nullptr, *lenM = nullptr;
-    const std::vector<int> *glist[kNumShortGroups] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const std::vector<int> *glist[kNumShortGroups] = {};
 };
 int devpack_validate(const Plan &p, const DevCsr &d);
 int devpack_window_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridW, int R, int *lo, int *hi, long long *wnnz);
 // over the sampled rows: nonzeros, and how many of them start a new 128-byte line of x relative to their predecessor in the row
 int devpack_line_scatter(const Plan &p, const DevCsr &d, const std::vector<int> &rows, long long *lines, long long *entries);
+// over pairs of equally long rows (rows[2i], rows[2i+1]): entries compared, and how many lie within 16 columns of the other row's
+// entry at the same position
+int devpack_row_coherence(const Plan &p, const DevCsr &d, const std::vector<int> &rows, long long *near, long long *entries);
 int devpack_chunk_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridM, const std::vector<int> &lenM,
                         const std::vector<int> &nchunks, int *k16);
 int devpack_all(Plan &p, const DevCsr &d, const PackMeta &m);

@@ -2,7 +2,7 @@
 // A plan file holds every host array of a Plan, so a later run (or every rank of a multi-GPU job)
 // skips classification and packing: load -> upload -> spmv.
 // layout: "DASPPLN3" | plan, where plan = int32 precision, m, n, nnz, y_order, windowed, row_window, lds_bytes, cid16, n_parts,
-//         part_stride, stream_policy, n_panels | dasp_stats_t | ShortGroup[5] | for each array, in a fixed order: int64 byte
+//         part_stride, stream_policy, n_panels, n_mfma_rows | dasp_stats_t | ShortGroup[5] | for each array, in a fixed order: int64 byte
 //         count + bytes | the n_panels column panels, each a nested plan
 #include <cstdio>
 #include <cstring>
@@ -44,8 +44,8 @@ template <class IO> void arrays(IO &io, Plan &p)
 
 static void write_plan(Writer &w, Plan &p)
 {
-    const int hdr[13] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
-                         p.opt.n_parts, p.opt.part_stride, p.opt.stream_policy, (int)p.panels.size()};
+    const int hdr[14] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
+                         p.opt.n_parts, p.opt.part_stride, p.opt.stream_policy, (int)p.panels.size(), p.n_mfma_rows};
     w.raw(hdr, sizeof hdr); w.raw(&p.stats, sizeof p.stats); w.raw(p.grp, sizeof p.grp);
     arrays(w, p);
     for (auto &h : p.panels) write_plan(w, h->impl);
@@ -53,14 +53,14 @@ static void write_plan(Writer &w, Plan &p)
 
 static bool read_plan(Reader &r, Plan &p, int depth)
 {
-    int hdr[13];
+    int hdr[14];
     r.raw(hdr, sizeof hdr);
     if (!r.ok || (hdr[0] != 64 && hdr[0] != 16) || hdr[12] < 0 || hdr[12] > 64 || (depth > 0 && hdr[12] != 0)) return false;
     p.precision = hdr[0]; p.geo = geometry_for(p.precision);
     p.m = hdr[1]; p.n = hdr[2]; p.nnz = hdr[3];
     dasp_options_default(&p.opt);
     p.opt.y_order = hdr[4]; p.windowed = hdr[5] != 0; p.row_window = hdr[6]; p.lds_bytes = hdr[7]; p.cid16 = hdr[8] != 0;
-    p.opt.n_parts = hdr[9]; p.opt.part_stride = hdr[10]; p.opt.stream_policy = hdr[11];
+    p.opt.n_parts = hdr[9]; p.opt.part_stride = hdr[10]; p.opt.stream_policy = hdr[11]; p.n_mfma_rows = hdr[13];
     r.raw(&p.stats, sizeof p.stats); r.raw(p.grp, sizeof p.grp);
     arrays(r, p);
     if (!r.ok) return false;
@@ -73,8 +73,8 @@ static bool read_plan(Reader &r, Plan &p, int depth)
                 p.short_val.size() == p.short_cid.size() * vb &&
                 (p.cid16 ? p.med_val.size() == p.med_cid16.size() * vb : p.med_val.size() == p.med_cid.size() * vb);
     if (np == 0)   // a packed plan (a panel parent keeps none of the row-structure arrays)
-        sane = sane && p.piece_ptr.size() == p.piece_dst.size() + 1 && p.irr_ptr.size() == (size_t)p.stats.row_block + 1 &&
-               (!p.windowed || p.med_dst.size() == (size_t)p.stats.row_block);
+        sane = sane && p.piece_ptr.size() == p.piece_dst.size() + 1 && p.irr_ptr.size() == (size_t)p.n_mfma_rows + 1 &&
+               p.n_mfma_rows >= 0 && p.n_mfma_rows <= p.stats.row_block && (!p.windowed || p.med_dst.size() == (size_t)p.n_mfma_rows);
     if (!sane) return false;
     p.cnt_long = p.long_cid.size(); p.cnt_irr = p.irr_cid.size(); p.cnt_short = p.short_cid.size();
     p.cnt_reg = p.cid16 ? p.med_cid16.size() : p.med_cid.size();

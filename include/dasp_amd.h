@@ -125,6 +125,13 @@ typedef struct dasp_options {
      *   1 or -1 = off,  2..64 = that many panels.
      * f16: the per-panel partial results are rounded to binary16 before they are added (in f32). */
     int col_panels;
+    /* medium rows of at most this many nonzeros are stored as uniform-length slabs (one slab per length, a lane owns whole rows,
+     * no MFMA) like the reference's short rows, instead of 16-row MFMA blocks: a block of rows that short is mostly per-wave
+     * overhead (8 M rows of 5 nonzeros: 0.39 of the roofline as blocks, 0.8+ as slabs).  Their slots in order_rid stay the
+     * medium rows' (sorted by length).  0 = auto: up to 16 (f64) / 24 (f16) nonzeros, and only when neighbouring rows read
+     * neighbouring columns (stencils: the lanes' gathers coalesce; on graph-like rows slabs lose);
+     * 4 = off; 5..32 = that bound, unconditionally. */
+    int slab_max_len;
 } dasp_options_t;
 
 void dasp_options_default(dasp_options_t *opt);

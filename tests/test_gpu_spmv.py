@@ -567,7 +567,8 @@ def test_random_option_combinations(oracle, dasp, torch_cuda, seed):
     kw = dict(col_panels=int(rng.choice([1, 1, 2, 3, 6])), cid16=int(rng.choice([-1, 0, 1])),
               x_window=int(rng.choice([-1, 0, 0, 40000, 163840])), row_window=int(rng.choice([0, 64, 256, 1024])),
               long_piece=int(rng.choice([0, 64, 300, 4096])), block_longest=int(rng.choice([256, 256, 32, 1000])),
-              threshold=float(rng.choice([0.75, 0.75, 0.3, 1.0])), y_order=int(rng.choice([0, 1])))
+              threshold=float(rng.choice([0.75, 0.75, 0.3, 1.0])), y_order=int(rng.choice([0, 1])),
+              slab_max_len=int(rng.choice([0, 4, 7, 16, 32])))
     part = None
     if rng.random() < 0.4 and n >= 3:
         cuts = np.sort(rng.choice(np.arange(1, n), size=min(2, n - 1), replace=False))
@@ -644,3 +645,24 @@ def test_extreme_shapes(oracle, dasp, torch_cuda, prec, shape):
     if prec == 16 and shape in ("one_huge_row", "single_row"):
         v = (v.astype(np.float64) / 64).astype(dt)          # keep the long sums inside binary16
     check(oracle, dasp, torch_cuda, rp, ci, v, n, prec)
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("kw", [dict(), dict(slab_max_len=4), dict(slab_max_len=32), dict(col_panels=2), dict(cid16=1, slab_max_len=6)])
+def test_slab_stored_medium_rows(oracle, dasp, torch_cuda, prec, kw):
+    """medium rows short enough to be stored as slabs (auto for stencil-like rows, forced otherwise): same results, same slots"""
+    import scipy.sparse as sp
+    nx = 90
+    T = sp.diags([1, 1, 1], [-1, 0, 1], shape=(nx, nx))
+    A = (sp.kron(sp.identity(nx), T) + sp.kron(sp.diags([1, 1], [-1, 1], shape=(nx, nx)), sp.identity(nx))).tocsr()     # 2-D 5-point
+    A.sort_indices()
+    rp, ci = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    v = np.random.default_rng(3).uniform(0.5, 1.5, ci.size)
+    if not kw:
+        st = dasp.Plan(rp, ci, v, nx * nx, precision=64).stats
+        assert st["row_block"] > 7000 and st["n_med_blocks"] == 0            # rows of 5 are "medium" by class, slabs by layout
+    check(oracle, dasp, torch_cuda, rp, ci, v, nx * nx, prec, **kw)
+    rp2, ci2, v2 = util.mixed_matrix(3000, 2500, 7)                            # random columns: auto keeps the blocks
+    if not kw:
+        assert dasp.Plan(rp2, ci2, v2, 2500).stats["n_med_blocks"] > 0
+    check(oracle, dasp, torch_cuda, rp2, ci2, v2, 2500, prec, **kw)

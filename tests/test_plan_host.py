@@ -139,7 +139,7 @@ def test_windowed_mode_keeps_reference_slots_and_decodes(dasp, oracle, prec, y_o
     dst = plan.host_array("med_dst")
     R = st["row_window"]
     for w in range(st["n_windows"]):
-        for pos in range(w * R, min((w + 1) * R, st["row_block"])):
+        for pos in range(w * R, min((w + 1) * R, dst.size)):        # the MFMA-block rows (shorter medium rows are slabs)
             r = dst[pos] if y_order == 1 else order[dst[pos]]
             cols = ci[rp[r]:rp[r + 1]]
             assert cols.min() >= cmin[w] and cols.max() < cmin[w] + wlen[w]
@@ -188,7 +188,7 @@ def test_cid16_span_boundary(dasp):
         lens = [8] * 16
         rp = np.arange(0, 8 * 17, 8, dtype=np.int32)
         ci = np.tile(np.array([0, 1, 2, span, 70000, 70001, 70002, 70003], np.int32), 16)
-        plan = dasp.Plan(rp, ci, np.ones(ci.size), 80000, x_window=-1, cid16=1)
+        plan = dasp.Plan(rp, ci, np.ones(ci.size), 80000, x_window=-1, cid16=1, slab_max_len=4)     # rows of 8 as MFMA blocks
         st = plan.stats
         assert (st["nnz_irreg"] == 0) == bool(want), span      # the wide chunk ends the regular part: its rows go to the tail
         rows = util.decode_plan(plan)
@@ -242,3 +242,23 @@ def test_auto_windows_skip_rows_with_adjacent_columns(dasp):
         assert dasp.Plan(rp, ci, v, n).stats["x_window_on"] == 0
         st = dasp.Plan(rp, ci, v, n, x_window=81920).stats                       # they do fit: forcing turns it on
         assert st["x_window_on"] == 1 and st["n_windows_lds"] == st["n_windows"] > 0
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+def test_slab_layout_decodes_and_keeps_the_reference_slots(dasp, oracle, prec):
+    """medium rows stored as slabs: order_rid and the classifier counters are the oracle's, the packed arrays decode to the rows"""
+    dt = np.float64 if prec == 64 else np.float16
+    lens = np.random.default_rng(12).choice([0, 1, 3, 5, 5, 6, 7, 9, 14, 17, 25, 33, 70, 300], size=2500)
+    rp, ci, v = util.csr_from_lengths(lens, 4000, 5, dtype=dt)
+    for smax in (4, 7, 16, 32):
+        plan = dasp.Plan(rp, ci, v, 4000, precision=prec, slab_max_len=smax, x_window=-1)
+        P = oracle.Packed(prec, rp, ci, v.astype(np.float64), 4000)
+        assert (plan.order_rid == P.order_rid).all() and plan.stats["row_block"] == P.row_block
+        n_slab = int(((lens >= 5) & (lens <= smax)).sum())
+        assert plan.host_array("irr_ptr").size - 1 == P.row_block - n_slab
+        rows = util.decode_plan(plan)
+        order = plan.order_rid
+        assert sorted(rows) == list(range(2500))
+        for slot in range(2500):
+            r = order[slot]
+            assert rows[slot][0] == ci[rp[r]:rp[r + 1]].tolist()

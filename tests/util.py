@@ -85,7 +85,7 @@ def decode_plan(plan):
         mc = np.where(off == 0xFFFF, -1, base + off)
     ip_, iv, ic = plan.host_array("irr_ptr"), plan.host_array("irr_val"), plan.host_array("irr_cid")
     nb = mptr.size - 1
-    row_block, row_long = st["row_block"], st["row_long"]
+    row_block, row_long = ip_.size - 1, st["row_long"]       # MFMA-block rows only: shorter medium rows are slabs (short_groups)
     # windowed mode: medium position -> y index through med_dst (a slot, or a row id when Y_NATURAL)
     med_dst = plan.host_array("med_dst") if st.get("x_window_on") else None
     if med_dst is not None and natural and inv is None:
@@ -118,7 +118,7 @@ def decode_plan(plan):
             assert slot not in out
             out[slot] = (cs, vs)
     # short rows
-    sg = plan.host_array("short_groups").reshape(5, 13)
+    sg = plan.host_array("short_groups").reshape(-1, 13)
     sv, sc = plan.host_array("short_val"), plan.host_array("short_cid")
     for g in sg:
         L, count, tiles, tile0 = int(g[0]), int(g[1]), int(g[2]), int(g[3])
