@@ -94,6 +94,13 @@ def time_plan(torch, plan, x, y, iters, warmup):
     return plan.time(x.data_ptr(), y.data_ptr(), s, warmup=warmup, iters=iters)
 
 
+def f16_close(torch, got, want):
+    """f16 check of the all-ones mode: within 1e-2 of the row length, or +inf where the row length itself exceeds binary16 (65504)"""
+    over = want > 65504.0
+    fine = (got - want).abs() <= 1e-2 * want.clamp(min=1)
+    return bool((torch.where(over, torch.isinf(got) | fine, fine)).all().item())
+
+
 def suite_entry(torch, D, name, precision, scale, budget_s=2.0):
     """Reference protocol (100 warm-up + up to 1000 timed launches, dasp_f64.h:1285-1286) on one stand-in."""
     rows, cols = matrix_dims(D, name, scale)
@@ -112,7 +119,7 @@ def suite_entry(torch, D, name, precision, scale, budget_s=2.0):
     order = torch.from_numpy(plan.order_rid.astype(np.int64)).cuda()
     want = torch.from_numpy(np.diff(rp).astype(np.float64)).cuda()[order]
     ok = bool((y.double() == want).all().item()) if precision == 64 or int(np.diff(rp).max()) <= 2048 else \
-        bool(((y.double() - want).abs() <= 1e-2 * want.clamp(min=1)).all().item())
+        f16_close(torch, y.double(), want)
     st = plan.stats
     b_alg = algorithmic_bytes(rows, cols, nnz, precision // 8)
     out = {"workload": name, "dtype": "f64" if precision == 64 else "f16", "rows": rows, "nnz": nnz,
@@ -301,7 +308,7 @@ def main():
         got = y[: r1 - r0].double()
         got_nat = torch.empty_like(got)
         got_nat[torch.from_numpy(plan.order_rid.astype(np.int64)).cuda()] = got
-        ok = bool((got_nat == want).all().item()) if prec == 64 else bool(((got_nat - want).abs() <= 1e-2 * want.clamp(min=1)).all().item())
+        ok = bool((got_nat == want).all().item()) if prec == 64 else f16_close(torch, got_nat, want)
     else:
         # ---- chained check: x_t = c^t on every non-empty row (0 on empty ones) after warmup + steps products, on the gathered y
         t_all = args.warmup + args.steps
