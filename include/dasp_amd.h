@@ -143,7 +143,8 @@ typedef struct dasp_stats {
     int short_row_1, common_13, short_row_3, short_row_4, short_row_2, row_long, row_block, row_zero;
     int nnz_short, nnz_long, origin_nnz_reg, nnz_irreg;
     int rowloop;               /* reference's 59990/400000 rule, reported only (dasp_f64.h:533-536) */
-    /* native (gfx950 geometry) padded sizes, the analogue of fill0_nnz_* */
+    /* native (gfx950 geometry) padded sizes, the analogue of fill0_nnz_*; fill0_nnz_short counts the whole slab segment, i.e. also
+     * the medium rows stored as slabs (slab_max_len), fill0_nnz_reg / n_med_blocks only the MFMA blocks */
     long long fill0_nnz_short, fill0_nnz_long, fill0_nnz_reg;
     double rate_fill0;         /* (stored slots - nnzA) / nnzA, as dasp_f64.h:1159-1160 */
     long long data_X;          /* bytes of the packed format + x + y, as dasp_f64.h:1162-1166 */
