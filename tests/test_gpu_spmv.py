@@ -377,6 +377,43 @@ def test_device_packed_plan_is_bit_identical(oracle, dasp, torch_cuda, prec, kw,
     assert np.array_equal(y_h, y_d)
 
 
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("which", ["stencil", "band", "fem"])
+def test_device_built_plans_take_the_same_automatic_decisions(dasp, torch_cuda, prec, which):
+    """the sampled measures behind the automatic choices (row coherence -> slabs, line scatter -> x windows) run as kernels for a
+    device-resident CSR: same decisions, same packed arrays as the host path"""
+    import scipy.sparse as sp
+    torch = torch_cuda
+    dt = np.float64 if prec == 64 else np.float16
+    if which == "stencil":                 # 2-D 5-point: slabs on
+        nx = 120
+        A = (sp.kron(sp.identity(nx), sp.diags([1, 1, 1], [-1, 0, 1], shape=(nx, nx))) +
+             sp.kron(sp.diags([1, 1], [-1, 1], shape=(nx, nx)), sp.identity(nx))).tocsr()
+        A.sort_indices()
+        rp, ci, n = A.indptr.astype(np.int32), A.indices.astype(np.int32), nx * nx
+    elif which == "band":                  # scattered inside a band: x windows on
+        rp, ci = dasp.synth_csr("cop20k_A", 0.1)
+        n = dasp.synth_dims("cop20k_A", 0.1)[1]
+    else:                                  # runs of adjacent columns whose windows fit: x windows stay off
+        rp, ci = dasp.synth_csr("HV15R", 0.01)
+        n = dasp.synth_dims("HV15R", 0.01)[1]
+    m = rp.size - 1
+    v = np.random.default_rng(1).uniform(0.5, 1.5, ci.size).astype(dt)
+    host = dasp.Plan(rp, ci, v, n, precision=prec)
+    d = [torch.from_numpy(a).cuda() for a in (rp, ci, v)]
+    dev = dasp.Plan.from_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), m, n, ci.size, precision=prec)
+    hs, ds = host.stats, dev.stats
+    hs.pop("pre_ms"), ds.pop("pre_ms")
+    assert hs == ds
+    assert {"stencil": hs["n_med_blocks"] == 0 and hs["n_short_tiles"] > 0, "band": hs["x_window_on"] == 1,
+            "fem": hs["x_window_on"] == 0 and hs["n_med_blocks"] > 0}[which]
+    for name in META_ARRAYS:
+        assert np.array_equal(host.host_array(name), dev.host_array(name)), name
+    for name in NNZ_ARRAYS:
+        h = host.host_array(name)
+        assert np.array_equal(h, dev.device_array(name, h.size, h.dtype)), name
+
+
 def test_device_plan_rejects_bad_columns(dasp, torch_cuda):
     torch = torch_cuda
     rp = torch.tensor([0, 2, 3], dtype=torch.int32, device="cuda")
