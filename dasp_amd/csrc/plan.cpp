@@ -196,7 +196,11 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                 for (int k = 0; k < len; ++k) { const int d = remap(ci[a + k]) - remap(ci[b + k]); near += d > -16 && d < 16; }
                 entries += len;
             }
-        if (entries == 0 || (double)near < 0.5 * (double)entries) { slab_max = 4; nmf = nmed_all; }
+        // ... and only when those rows are most of the matrix: a minority of slab waves (128 rows x up to 16 sequential steps) next
+        // to MFMA blocks only lengthens the tail (nlpkkt160's boundary rows: x0.01 5.7 -> 7.9 us, x0.03 15.4 -> 17.4 us)
+        long long slab_nnz = 0;
+        for (int i = nmf; i < nmed_all; ++i) slab_nnz += lenM[i];
+        if (entries == 0 || (double)near < 0.5 * (double)entries || 2 * slab_nnz < (long long)nnz) { slab_max = 4; nmf = nmed_all; }
     }
     std::vector<std::vector<int>> slab_rows((size_t)kSlabMaxLen + 1);
     for (int i = nmf; i < nmed_all; ) {
@@ -305,7 +309,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         R = std::min(1024, std::max(64, (R / 64) * 64));         // <= 16 waves per workgroup, 1-4 blocks per wave
         // default cap: 80 KiB = two workgroups per CU out of gfx950's 160 KiB of LDS
         const bool order_only = p.opt.x_window == -2;          // windowed order, no LDS staging (every window gathers from global memory)
-        const int cap_bytes = order_only ? 0 : (p.opt.x_window > 0 ? std::min(p.opt.x_window, 160 * 1024) : 80 * 1024);
+        int cap_bytes = order_only ? 0 : (p.opt.x_window > 0 ? std::min(p.opt.x_window, 160 * 1024) : 80 * 1024);
         const int A = 16 / geo.vbytes;                         // window base aligned for 16-byte copies
         // medium rows in row order, then a stable descending length sort inside each window
         std::vector<int> ridW(nmed), lenW(nmed);
@@ -341,15 +345,23 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                 wlo[w] = lo; whi[w] = hi; wnnz[w] = k;
             }
         });
-        for (int w = 0; w < nW; ++w) {
-            const int lo = (wlo[w] / A) * A, hi = whi[w];
-            const long long span = (long long)hi - lo + 1;
-            if (hi >= 0 && span * geo.vbytes <= cap_bytes) { cmin[w] = lo; wlen[w] = (int)span; }
-            else { cmin[w] = 0; wlen[w] = 0; }
-        }
         long long fit = 0, all = 0; int maxlen = 0;
-        for (int w = 0; w < nW; ++w) { all += wnnz[w]; if (wlen[w] > 0) { fit += wnnz[w]; maxlen = std::max(maxlen, wlen[w]); } }
-        window_frac = all > 0 ? (double)fit / (double)all : 0.0;
+        auto fit_windows = [&]() {
+            fit = 0; all = 0; maxlen = 0;
+            for (int w = 0; w < nW; ++w) {
+                const int lo = (wlo[w] / A) * A, hi = whi[w];
+                const long long span = (long long)hi - lo + 1;
+                if (hi >= 0 && span * geo.vbytes <= cap_bytes) { cmin[w] = lo; wlen[w] = (int)span; }
+                else { cmin[w] = 0; wlen[w] = 0; }
+                all += wnnz[w];
+                if (wlen[w] > 0) { fit += wnnz[w]; maxlen = std::max(maxlen, wlen[w]); }
+            }
+            window_frac = all > 0 ? (double)fit / (double)all : 0.0;
+        };
+        fit_windows();
+        // auto: when the spans are too wide for two workgroups per CU (80 KiB each), one workgroup per CU with all of the LDS
+        // still beats global gathers on band-scattered rows (+-30 k columns, f16: 98.8 -> 65.9 us; +-8 k, f64: 166.8 -> 115.8 us)
+        if (p.opt.x_window == 0 && window_frac < 0.5) { cap_bytes = 160 * 1024; fit_windows(); }
         const bool force = p.opt.x_window > 0;
         bool worth = window_frac >= 0.5 && (double)all >= 0.5 * (double)nnz;
         if (worth && !force && !order_only) {

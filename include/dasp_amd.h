@@ -101,7 +101,7 @@ typedef struct dasp_options {
      *             >= 60 % of a sampled row's nonzeros lie on another 128-byte line of x than their predecessor), -1 = off,
      *             -2 = windowed order without LDS staging (measurement knob: slower than either alternative),
      *             > 0 = force on with this many bytes of LDS per workgroup as the cap (<= 163840; auto uses 81920,
-     *                   i.e. two workgroups per CU)
+     *                   i.e. two workgroups per CU, and falls back to 163840 when the spans do not fit that)
      *   row_window: rows per window, multiple of 64 up to 1024 (16 rows per block, up to 16 waves per workgroup);
      *               0 = by size: ~224 windows (one per CU, with slack), ~448 once a window would pass 1024 rows */
     int x_window;
@@ -129,7 +129,8 @@ typedef struct dasp_options {
      * no MFMA) like the reference's short rows, instead of 16-row MFMA blocks: a block of rows that short is mostly per-wave
      * overhead (8 M rows of 5 nonzeros: 0.39 of the roofline as blocks, 0.8+ as slabs).  Their slots in order_rid stay the
      * medium rows' (sorted by length).  0 = auto: up to 16 (f64) / 24 (f16) nonzeros, and only when neighbouring rows read
-     * neighbouring columns (stencils: the lanes' gathers coalesce; on graph-like rows slabs lose);
+     * neighbouring columns (stencils: the lanes' gathers coalesce; on graph-like rows slabs lose) and those
+     * rows hold at least half of the nonzeros;
      * 4 = off; 5..32 = that bound, unconditionally. */
     int slab_max_len;
 } dasp_options_t;
