@@ -581,7 +581,7 @@ def test_column_panels_need_a_host_csr(dasp, torch_cuda):
         dasp.Plan.from_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), 500, 400, ci.size, col_panels=2)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DASP_TEST_SEEDS", "24"))))      # DASP_TEST_SEEDS=2000 for a soak run
 def test_random_option_combinations(oracle, dasp, torch_cuda, seed):
     """Feature interactions (panels x windows x 16-bit ids x partitioned x layout x piece / threshold / block_longest corners):
     every seeded combination must match the CSR product within the stated tolerance."""
@@ -625,7 +625,9 @@ def test_random_option_combinations(oracle, dasp, torch_cuda, seed):
     plan = dasp.Plan(rp, ci, v, n, precision=prec, **kw).upload()
     got = run_spmv(torch, plan, xl, m, prec)
     perm = plan.order_rid if kw["y_order"] == 0 else np.arange(m)
-    err = np.abs(got - ref[perm]) / scale[perm]
+    # binary16 results below 6.1e-5 are subnormal: their rounding step is the absolute 2^-24, whatever the row's magnitude
+    floor = 2.0 ** -24 if prec == 16 else 0.0
+    err = np.maximum(np.abs(got - ref[perm]) - floor, 0.0) / scale[perm]
     assert np.isfinite(got).all() and err.max() <= TOL[prec], (kw, prec, m, n, float(err.max()), int(err.argmax()))
     plan.close()
 
