@@ -594,7 +594,16 @@ def test_random_option_combinations(oracle, dasp, torch_cuda, seed):
     kinds = [0, 1, 2, 3, 4, 5, 9, 17, 40, 130, 300, 900]
     w = rng.dirichlet(np.ones(len(kinds)) * 0.5)
     lens = np.minimum(rng.choice(kinds, size=m, p=w), n)
-    if rng.random() < 0.3:                                    # a banded variant: windows fit
+    shape = rng.random()
+    if shape < 0.2 and n >= 64:                               # stencil-like: equal lengths, neighbouring rows read neighbouring columns
+        L = int(rng.integers(5, 30))
+        offs = np.sort(rng.choice(np.arange(-min(n // 2, 3000), min(n // 2, 3000)), size=L, replace=False))
+        rp = (np.arange(m + 1, dtype=np.int64) * L).astype(np.int32)
+        ci = ((np.arange(m, dtype=np.int64)[:, None] * max(1, n // max(m, 1)) + offs[None, :]) % n)
+        ci.sort(axis=1)
+        ci = ci.reshape(-1).astype(np.int32)
+        v = rng.uniform(-1, 1, ci.size).astype(dt)
+    elif shape < 0.45:                                        # a banded variant: windows fit
         rp, ci, v = util.csr_from_lengths(lens, min(n, 2000), int(rng.integers(1 << 30)), dtype=dt)
         ci = np.minimum(ci + (np.repeat(np.arange(m), np.diff(rp)) * max(1, (n - 2000)) // max(m, 1)).astype(np.int32), n - 1).astype(np.int32)
         for r in range(m):
