@@ -858,6 +858,17 @@ int upload_plan(Plan &p)
     a.wg_med = p.windowed ? a.n_windows : (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG;
 #if DASP_PERSIST > 0
     if (!p.windowed) a.wg_med = std::min(a.wg_med, 256 * DASP_PERSIST);   // persistent medium workgroups: DASP_PERSIST per CU
+#else
+    // f16 blocks of uniform length: a persistent set of 7 workgroups per CU striding over the blocks amortises the per-wave
+    // set-up that weighs twice as much at 2 bytes per value (nlpkkt160 f16 0.675 -> 0.739 of the roofline, Queen_4147 f16
+    // 0.873 -> 0.927).  Static striding needs equal blocks: with HV15R's 2 % of 3x longer rows it loses 10 %, and in f64 it
+    // loses 3-9 % everywhere, so: f16 only, no windows, longest block <= 1.25 x the mean.
+    if (!p.windowed && p.precision == 16 && a.n_blocks > 256 * 7 * kWavesPerWG) {
+        int longest = 0;
+        for (int b = 0; b < a.n_blocks; ++b) longest = std::max(longest, p.med_ptr[(size_t)b + 1] - p.med_ptr[(size_t)b]);
+        const double mean = (double)p.med_ptr[(size_t)a.n_blocks] / (double)a.n_blocks;
+        if (p.cnt_irr * 8 <= p.cnt_reg && mean > 0 && (double)longest <= 1.25 * mean) a.wg_med = std::min(a.wg_med, 256 * 7);
+    }
 #endif
     a.wg_short = (a.n_short_tiles + a.wpw - 1) / a.wpw;
     // streamed-once matrix data bypasses the caches (the reference's ld.global.cs, dasp_f64.h:34-51)
