@@ -877,7 +877,9 @@ int upload_plan(Plan &p)
     if (p.windowed && p.lds_bytes > 65536) {
         // more than the default 64 KiB of dynamic LDS must be requested per kernel; done here (for both cache-policy
         // variants), not in the launch path, so that dasp_plan_spmv stays free of anything a stream capture would reject
-        const int bytes = p.lds_bytes;
+        // the attribute belongs to the kernel, not to the plan: always ask for the device maximum, or a later plan with narrower
+        // windows would lower the limit under an earlier one with wider windows
+        const int bytes = 160 * 1024;
         const bool c16 = p.cid16;
         hipError_t e1, e2;
 #define DASP_ATTR(TT, NTV, CV) hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<TT, NTV, CV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)

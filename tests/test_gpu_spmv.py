@@ -714,3 +714,29 @@ def test_slab_stored_medium_rows(oracle, dasp, torch_cuda, prec, kw):
     if not kw:
         assert dasp.Plan(rp2, ci2, v2, 2500).stats["n_med_blocks"] > 0
     check(oracle, dasp, torch_cuda, rp2, ci2, v2, 2500, prec, **kw)
+
+
+def test_plans_with_different_window_sizes_coexist(oracle, dasp, torch_cuda):
+    """the dynamic-LDS limit is a property of the kernel, not of a plan: a plan with 130 KiB windows must still run after a plan
+    with 70 KiB windows was uploaded (and vice versa)"""
+    torch = torch_cuda
+    rng = np.random.default_rng(11)
+    m = 6000
+    plans = []
+    for band in (7500, 7800, 4400):          # f64 spans of ~120, ~125, ~72 KiB: the narrowest is uploaded last
+        cols = np.clip(rng.integers(-band, band + 1, size=(m, 12)) + np.arange(m)[:, None] + band, 0, m + 2 * band - 1)
+        cols.sort(axis=1)
+        rp = (np.arange(m + 1) * 12).astype(np.int32)
+        ci = cols.reshape(-1).astype(np.int32)
+        v = rng.uniform(-1, 1, ci.size)
+        n = m + 2 * band
+        plan = dasp.Plan(rp, ci, v, n).upload()
+        assert plan.stats["x_window_on"] == 1
+        plans.append((plan, rp, ci, v, n))
+    assert plans[0][0].stats["lds_bytes"] > 100000 > plans[2][0].stats["lds_bytes"] > 65536 < plans[1][0].stats["lds_bytes"]
+    for plan, rp, ci, v, n in plans:          # all three after the last upload
+        xh = rng.uniform(-1, 1, n)
+        got = run_spmv(torch, plan, xh, m, 64)
+        ref = oracle.csr_spmv(rp, ci, v, xh)[plan.order_rid]
+        scale = np.maximum(oracle.csr_absrow(rp, ci, v, xh)[plan.order_rid], 1e-300)
+        assert (np.abs(got - ref) / scale).max() <= TOL[64]
