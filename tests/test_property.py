@@ -1,5 +1,7 @@
 """Property-based checks of the host half of the plan (no GPU): for arbitrary small matrices and option corners, the
 native packed format decodes to exactly the CSR rows, and categories / output permutation equal the oracle's."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import HealthCheck, given, settings, strategies as st
@@ -91,7 +93,7 @@ def test_column_panels_partition_arbitrary_matrices(dasp, mat, opts, prec, panel
 
 
 @pytest.mark.gpu
-@settings(max_examples=80, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@settings(max_examples=int(os.environ.get("DASP_HYP_EXAMPLES", "80")), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(mat=matrices(), opts=OPTS, prec=st.sampled_from([64, 16]), from_device=st.booleans(), panels=st.sampled_from([1, 1, 2, 3, 5]))
 def test_spmv_matches_csr_for_arbitrary_matrices(dasp, oracle, mat, opts, prec, from_device, panels):
     import torch
