@@ -24,8 +24,8 @@
 //        (dynamic LDS), every gather of the window served from LDS; y through med_dst
 // DevArgs::acc turns every store of a row's result into y += (dasp_plan_spmv_acc); a plan split into column panels runs one
 // such launch per panel into a partial buffer and dasp_panel_sum_kernel adds the partials.
-// Experiment knobs kept as macros (DASP_XG, DASP_LB, DASP_LB_WIN, DASP_XCD, DASP_PERSIST, DASP_BF/SF/BH/SH): see DESIGN.md
-// section 4 for the same-device A/B results behind their defaults.
+// Rejected variants (XCD-contiguous ranges, persistent f64 grids, nt / sc1 gathers, vector tail loads, ...) are recorded in
+// DESIGN.md section 4.4 and are not kept in this file; tools/ab.sh compares builds of two git revisions instead.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -107,31 +107,16 @@ __device__ __forceinline__ int slot_of(const SlotMap &m, int t)
     return g ? m.base[p] + (u / g) * 2 * g + m.off[p] + u % g : m.base[p] + u;
 }
 
-// chunks per software-pipeline batch / per one-shot (A/B knobs; defaults chosen on the HBM-bound stand-ins)
-#ifndef DASP_TAILV
-#define DASP_TAILV 0   // 1: f16 tail entries as one 8-byte + one 16-byte element-aligned load per lane instead of eight scalar loads:
-                       // +2-4 % on the small f16 stand-ins, -5 % on the column panels of ljournal-2008
-#endif
-#ifndef DASP_BF
-#define DASP_BF 4
-#endif
-#ifndef DASP_SF
-#define DASP_SF 8   // f64 rows of <= 32 nonzeros in one shot: cop20k_A 11.5 -> 10.9 us, 4x 31.2 -> 30.2, HBM-bound stand-ins +0.5-1 %
-#endif
-#ifndef DASP_BH
-#define DASP_BH 2
-#endif
-#ifndef DASP_SH
-#define DASP_SH 2
-#endif
+// BATCH = chunks per software-pipeline batch, SHOT = longest unit issued in one shot (defaults chosen on the HBM-bound
+// stand-ins, DESIGN.md 4.4: f64 rows of <= 32 nonzeros in one shot: cop20k_A 11.5 -> 10.9 us, HBM-bound stand-ins +0.5-1 %)
 template <class T> struct Tr;
 template <> struct Tr<double> {
     using acc_t = f64x4; using part_t = double;
-    static constexpr int CHUNK = 64, SHORT_ROWS = 128, BATCH = DASP_BF, SHOT = DASP_SF;
+    static constexpr int CHUNK = 64, SHORT_ROWS = 128, BATCH = 4, SHOT = 8;
 };
 template <> struct Tr<_Float16> {
     using acc_t = f32x4; using part_t = float;
-    static constexpr int CHUNK = 256, SHORT_ROWS = 256, BATCH = DASP_BH, SHOT = DASP_SH;
+    static constexpr int CHUNK = 256, SHORT_ROWS = 256, BATCH = 2, SHOT = 2;
 };
 
 // ---- chunk = one MFMA worth of elements in lane-linear order.  Loads, gathers and MFMAs are kept
@@ -161,26 +146,11 @@ __device__ __forceinline__ void frag_load(Frag<T> &f, const T *val, const int *c
 {
     frag_load_at<NT>(f, val, cid, e + (size_t)(Tr<T>::CHUNK / kWave) * lane);
 }
-// x gather cache policy, compile-time experiment knob (-DDASP_XG=n): 0 plain, 1 non-temporal, 2 agent-scope (sc1)
-#ifndef DASP_XG
-#define DASP_XG 0
-#endif
-template <class U>
-__device__ __forceinline__ U ldx(const U *p)
-{
-#if DASP_XG == 1
-    return __builtin_nontemporal_load(p);
-#elif DASP_XG == 2
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-    return *p;
-#endif
-}
 // where x values come from: global memory, or the workgroup's window of x staged in LDS
 template <class T>
 struct XGlobal {
     const T *x;
-    __device__ __forceinline__ T at(int c) const { return ldx(x + (c < 0 ? 0 : c)); }       // pads read x[0], dropped below
+    __device__ __forceinline__ T at(int c) const { return x[c < 0 ? 0 : c]; }       // pads read x[0], dropped below
 };
 template <class T>
 struct XLds {
@@ -255,18 +225,8 @@ struct BlockSrc {
             f.a = ldg<NT>(ival + ee);
             f.c = ldg<NT>(icid + ee);
         } else {
-            // the lane's 4 consecutive tail entries as one 8-byte + one 16-byte load; the row's tail starts anywhere, so the
-            // loads are only element-aligned (gfx950 global loads take any alignment).  Entries past t1 belong to the next
-            // row (or the arena's padding) and are zeroed in gather().
-#if DASP_TAILV
-            typedef _Float16 f16x4_u __attribute__((ext_vector_type(4), aligned(2)));
-            typedef int i32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-            const int e = t0 + 16 * j + 4 * kq;
-            const int ee = e < t1 ? e : 0;
-            const f16x4_u av = *reinterpret_cast<const f16x4_u *>(ival + ee);
-            const i32x4_u cv = *reinterpret_cast<const i32x4_u *>(icid + ee);
-            f.a = av; f.c = cv;
-#else
+            // the lane's 4 consecutive tail entries, element by element (a row's tail starts anywhere); entries past t1 are
+            // zeroed in gather()
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int e = t0 + 16 * j + 4 * kq + q;
@@ -274,7 +234,6 @@ struct BlockSrc {
                 f.a[q] = ival[ee];
                 f.c[q] = icid[ee];
             }
-#endif
         }
     }
     template <class XV> __device__ __forceinline__ void gather(Frag<T> &f, int i, const XV &x) const
@@ -575,26 +534,15 @@ __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
     }
 }
 
-// XCD-contiguous block ranges: measured and rejected (A/B, same device: ljournal 0.94 -> 2.21 ms, powerlaw 0.99 -> 1.25 ms,
-// Queen/nlpkkt 1-3 % slower, HV15R equal).  Blocks are sorted by length, so a contiguous range per XCD puts all the long
-// blocks on one XCD; the default round-robin dispatch is what balances them.  Kept as a knob (-DDASP_XCD=1).
-#ifndef DASP_XCD
-#define DASP_XCD 0
-#endif
-#ifndef DASP_PERSIST
-#define DASP_PERSIST 0
-#endif
-#ifndef DASP_LB
-#define DASP_LB 1
-#endif
-#ifndef DASP_LB_WIN
-#define DASP_LB_WIN 8   // 64 registers: two 1024-thread window workgroups per CU (A/B: 12.9 vs 15.0 us on cop20k_A)
-#endif
+// launch bounds: the windowed kernel is held to 64 registers so that two 1024-thread window workgroups share a CU
+// (A/B: 12.9 vs 15.0 us on cop20k_A); blocks are dealt to workgroups in the default round-robin order (length-sorted
+// blocks in XCD-contiguous ranges put all the long ones on one XCD: DESIGN.md 4.4)
+constexpr int kMinWavesPlain = 1, kMinWavesWin = 8;
 // WIN: windowed mode.  A medium workgroup owns one window of row_window rows (blocks_per_win blocks, strided over its
 // 4 waves); if the window's x span fits, it is copied once into LDS with coalesced 16-byte loads and every gather of
 // the window reads LDS; otherwise that workgroup gathers from global memory like the non-windowed kernel.
 template <class T, bool NT, bool C16, bool WIN>
-__global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? DASP_LB_WIN : DASP_LB) void dasp_spmv_kernel(DevArgs a)
+__global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPlain) void dasp_spmv_kernel(DevArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
@@ -606,14 +554,7 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? DASP_LB_WIN : DASP_LB) void
         if (p < a.n_pieces) long_piece<T, NT>(a, p, lane);
     } else if (wg < a.wg_long + a.wg_med) {
         if constexpr (!WIN) {
-            // optional XCD-contiguous order (see DASP_XCD above): workgroup i and i+8 share an XCD; bijective (q, r) split
-            int m = wg - a.wg_long;
-#if DASP_XCD
-            {
-                const int nwg = a.wg_med, xcd = m & 7, idx = m >> 3, q = nwg >> 3, r = nwg & 7;
-                m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-            }
-#endif
+            const int m = wg - a.wg_long;
             const XGlobal<T> x{static_cast<const T *>(a.x)};
             // grid-stride over the blocks: wg_med is capped (upload_plan) so the medium range is a persistent set of workgroups
 #pragma unroll 1
@@ -856,9 +797,6 @@ int upload_plan(Plan &p)
     a.med_dst = (const int *)(base + o_mdst); a.win_cmin = (const int *)(base + o_wc); a.win_len = (const int *)(base + o_wl);
     a.n_windows = (int)p.win_len.size(); a.blocks_per_win = p.windowed ? p.row_window / kMedRows : 0;
     a.wg_med = p.windowed ? a.n_windows : (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG;
-#if DASP_PERSIST > 0
-    if (!p.windowed) a.wg_med = std::min(a.wg_med, 256 * DASP_PERSIST);   // persistent medium workgroups: DASP_PERSIST per CU
-#else
     // f16 blocks of uniform length: a persistent set of 7 workgroups per CU striding over the blocks amortises the per-wave
     // set-up that weighs twice as much at 2 bytes per value (nlpkkt160 f16 0.675 -> 0.739 of the roofline, Queen_4147 f16
     // 0.873 -> 0.927).  Static striding needs equal blocks: with HV15R's 2 % of 3x longer rows it loses 10 %, and in f64 it
@@ -869,7 +807,6 @@ int upload_plan(Plan &p)
         const double mean = (double)p.med_ptr[(size_t)a.n_blocks] / (double)a.n_blocks;
         if (p.cnt_irr * 8 <= p.cnt_reg && mean > 0 && (double)longest <= 1.25 * mean) a.wg_med = std::min(a.wg_med, 256 * 7);
     }
-#endif
     a.wg_short = (a.n_short_tiles + a.wpw - 1) / a.wpw;
     // streamed-once matrix data bypasses the caches (the reference's ld.global.cs, dasp_f64.h:34-51)
     // only when it cannot stay resident in the 256 MiB Infinity Cache between two SpMVs anyway.

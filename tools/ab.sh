@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/ab.sh -- interleaved A/B of dasp_bench builds on one device (rule 24: same process order, same box)
 # usage: tools/ab.sh "<workload args>" <bench1> <bench2> ...   ; 3 rounds each, prints the event ms per round
+# (other revisions: tools/build_rev.sh <rev> <tag> -> dasp_amd/variants/<tag>/dasp_bench)
 args=$1; shift
 for round in 1 2 3; do
   for b in "$@"; do
