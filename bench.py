@@ -3,20 +3,27 @@
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
   N == 1 : one process, one GPU.
-  N  > 1 : launched by torch.distributed.run, one rank per GPU (RCCL).  The matrix is partitioned by contiguous
-           row ranges of equal nonzero count; every rank builds the DASP plans of its slice (dasp_amd/multi.py): one over
-           its own columns, one over the other ranks' columns remapped so that the all-gather buffer IS the next x.
-           One step = y = A*x over the whole matrix + all-gather of y over xGMI, chained (x_{t+1} = y_t); the product
-           over a rank's own columns overlaps the all-gather still in flight.  Fixed total work => "strong".
+  N  > 1 : one rank per GPU.  Launched by torch.distributed.run (the driver's form) the process IS a rank; launched bare
+           (`python bench.py --gpus N`) it starts `python -m torch.distributed.run --nproc-per-node N ... bench.py` as a CHILD
+           process before anything touches the GPU, relays its output and exits with its code.  The matrix is partitioned by
+           contiguous row ranges of equal nonzero count; every rank builds the DASP plans of its slice through the C ABI
+           (dasp_mg_plan_create: own columns / other columns) and one step is dasp_mg_spmv: y = A*x over the whole matrix +
+           RCCL all-gather of y over xGMI (ncclAllGather called by libdasp_amd.so itself), chained (x_{t+1} = y_t); the product
+           over a rank's own columns overlaps the all-gather still in flight.  torch.distributed (gloo) is only the control
+           plane: unique-id broadcast, barriers, max-over-ranks of the time.  Fixed total work => "strong".
 A step is one y = A*x over the whole matrix.  Input: the seeded synthetic stand-in of the SuiteSparse matrix named by
 --workload (no .mtx files / network on the bench machines).  N == 1: values and x all ones as in the reference's driver
-(src/main_f64.cu:131-132), y[i] == nnz(row) checked exactly after the timed region.  N > 1: a_ij = 0.5 / len(row i), x_0 = 1,
-so x_t = 2^-t, checked on the gathered y after the timed region.
+(src/main_f64.cu:131-132), y[i] == nnz(row) checked exactly after the timed region, then ONE more product with seeded random
+values and x on the same full-size matrix, >= 100 k sampled rows compared with the CPU oracle (`verified_random_x`).
+N > 1: a_ij = 0.5 / len(row i), x_0 = 1, so x_t = 2^-t, checked on the gathered y after the timed region, then one product on a
+random x checked per rank against the oracle.
 Prints ONE JSON line on rank 0.  The GPU path has no CPU fallback: without a GPU this exits non-zero.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+TOL = {64: 1e-12, 16: 1e-2}   # BASELINE.json north_star, relative to sum_j |a_ij x_j|
 
 
 def algorithmic_bytes(m, n, nnz, vbytes):
@@ -77,14 +85,13 @@ def matrix_rows(D, name, scale, r0, r1, lengths):
     return D.synth_csr(name, scale, r0, r1, lengths=lengths[r0:r1])
 
 
-def build_slice(D, name, scale, precision, r0, r1, lengths, bounds=None, stride=0, natural=False, threads=0):
+def build_slice(D, name, scale, precision, r0, r1, lengths, threads=0):
     rp, ci = matrix_rows(D, name, scale, r0, r1, lengths)
     rows, cols = matrix_dims(D, name, scale)
     dt = np.float64 if precision == 64 else np.float16
     val = np.ones(ci.size, dt)                                  # initVec(csrValA): utils.h:93-100
     t0 = time.time()
-    plan = D.Plan(rp, ci, val, cols, precision=precision, y_order=D.Y_NATURAL if natural else D.Y_PERMUTED,
-                  part_bounds=bounds, part_stride=stride, host_threads=threads)
+    plan = D.Plan(rp, ci, val, cols, precision=precision, y_order=D.Y_PERMUTED, host_threads=threads)
     pre_s = time.time() - t0
     return plan, rp, ci, val, pre_s
 
@@ -101,13 +108,109 @@ def f16_close(torch, got, want):
     return bool((torch.where(over, torch.isinf(got) | fine, fine)).all().item())
 
 
-def suite_entry(torch, D, name, precision, scale, budget_s=2.0):
+def random_inputs(prec, nnz, n_cols, seed=12345):
+    """SURVEY 8(d) second mode: f64 values and x ~ U(-1,1); f16 values and x ~ U(0.5,1.5) (stays in binary16 range)"""
+    rng = np.random.default_rng(seed)
+    if prec == 64:
+        return rng.uniform(-1.0, 1.0, nnz), rng.uniform(-1.0, 1.0, n_cols)
+    return (rng.random(nnz, np.float32) + np.float32(0.5)).astype(np.float16), (rng.random(n_cols, np.float32) + np.float32(0.5)).astype(np.float16)
+
+
+def sample_rows(rp, n_sample, seed=777):
+    """row ids to verify: every row if few, else the 4096 longest (all long rows / multi-piece rows of the stand-ins) + a uniform
+    random sample, which reaches every category in proportion (medium blocks, cid16 chunks, short slabs, empty rows)"""
+    m = rp.size - 1
+    if m <= n_sample:
+        return np.arange(m, dtype=np.int64)
+    lens = np.diff(rp)
+    top = np.argpartition(lens, m - 4096)[m - 4096:]
+    rnd = np.random.default_rng(seed).choice(m, n_sample, replace=False)
+    return np.unique(np.concatenate([top, rnd])).astype(np.int64)
+
+
+def oracle_rows(O, rp, ci, val, x, idx):
+    """(y_ref, sum|a x|) of the sampled rows from the CPU oracle's serial CSR loop on the sub-matrix of those rows"""
+    rp = np.asarray(rp, np.int64)
+    lens = (rp[idx + 1] - rp[idx]).astype(np.int64)
+    sub_rp = np.zeros(idx.size + 1, np.int64)
+    np.cumsum(lens, out=sub_rp[1:])
+    take = np.repeat(rp[idx] - sub_rp[:-1], lens) + np.arange(int(sub_rp[-1]), dtype=np.int64)
+    sci = np.ascontiguousarray(ci[take])
+    sv = np.ascontiguousarray(val[take], dtype=np.float64)
+    x64 = np.ascontiguousarray(x, dtype=np.float64)
+    sub_rp = sub_rp.astype(np.int32)
+    return O.csr_spmv(sub_rp, sci, sv, x64), O.csr_absrow(sub_rp, sci, sv, x64)
+
+
+def verify_random_x(torch, D, O, rp, ci, cols, prec, threads=0, n_sample=100000, time_iters=0):
+    """One product with seeded random values and x on the FULL-SIZE matrix, through a plan of its own (same options as the timed
+    one), sampled rows vs the oracle at the north_star tolerance.  The all-ones check cannot see a wrong column id (every x_j
+    is 1); this one can (main_f64.cu:3-16 verify_new compares through order_rid the same way)."""
+    nnz = int(rp[-1])
+    m = rp.size - 1
+    val, xh = random_inputs(prec, nnz, cols)
+    plan = D.Plan(rp, ci, val, cols, precision=prec, host_threads=threads).upload()
+    plan.drop_host()
+    tdt = torch.float64 if prec == 64 else torch.float16
+    x = torch.from_numpy(xh).cuda()
+    y = torch.full((max(m, 1),), float("nan"), dtype=tdt, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    plan.spmv(x.data_ptr(), y.data_ptr(), s)
+    torch.cuda.synchronize()
+    got = np.empty(m, np.float64)
+    got[plan.order_rid] = y[:m].double().cpu().numpy()
+    out = {}
+    if time_iters > 0:
+        w, e = plan.time(x.data_ptr(), y.data_ptr(), s, warmup=5, iters=time_iters)
+        out["random_values_ms"] = round(e, 6)
+    plan.close()
+    idx = sample_rows(rp, n_sample)
+    ref, scale = oracle_rows(O, rp, ci, val, xh, idx)
+    err = np.abs(got[idx] - ref) / np.maximum(scale, 1e-300)
+    worst = float(np.nanmax(err)) if idx.size else 0.0
+    ok = bool(np.isfinite(got[idx]).all() and worst <= TOL[prec])
+    out.update({"ok": ok, "rows_checked": int(idx.size), "max_rel_err": worst, "tol": TOL[prec],
+                "inputs": "values, x ~ U(-1,1) seed 12345" if prec == 64 else "values, x ~ U(0.5,1.5) seed 12345"})
+    return out
+
+
+def load_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/prof.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE,
+    separate passes); counters cannot be read from inside the run, so each entry names the kernel build it was measured on"""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(tpath))
+    except Exception:
+        return []
+
+
+def traffic_for(name, prec, scale, b_alg, kernel_rev):
+    for t in load_traffic():
+        if t["workload"] == name and t["precision"] == prec and abs(t["scale"] - scale) < 1e-12:
+            if t.get("kernel_rev") != kernel_rev:
+                return {"traffic": None, "traffic_reason": "profiles/traffic.json entry was measured on kernel build %s, this run is %s"
+                        % (t.get("kernel_rev"), kernel_rev)}
+            return {"traffic": int(t["traffic_bytes"]), "traffic_source": t["source"],
+                    "traffic_over_algorithmic": round(t["traffic_bytes"] / b_alg, 4)}
+    return {"traffic": None, "traffic_reason": "no PMC pass committed for this workload"}
+
+
+def kernel_revision():
+    """sha1 of the kernel + packer sources: a traffic.json entry is only attached to the build it was measured on"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("kernels.hip", "plan.cpp", "device.hpp", "plan.hpp"):
+        h.update(open(os.path.join(ROOT, "dasp_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def suite_entry(torch, D, O, name, precision, scale, budget_s=2.0):
     """Reference protocol (100 warm-up + up to 1000 timed launches, dasp_f64.h:1285-1286) on one stand-in."""
     rows, cols = matrix_dims(D, name, scale)
     lengths = matrix_lengths(D, name, scale)
     plan, rp, ci, val, pre_s = build_slice(D, name, scale, precision, 0, rows, lengths)
     nnz = int(rp[-1])
-    del ci, val
+    del val
     plan.upload()
     plan.drop_host()
     tdt = torch.float64 if precision == 64 else torch.float16
@@ -116,6 +219,7 @@ def suite_entry(torch, D, name, precision, scale, budget_s=2.0):
     w, e = time_plan(torch, plan, x, y, 20, 10)
     iters = int(max(20, min(1000, budget_s * 1e3 / max(e, 1e-4))))
     w, e = time_plan(torch, plan, x, y, iters, min(100, iters))
+    gw, ge = plan.time_graph(x.data_ptr(), y.data_ptr(), 0, warmup=min(100, iters), iters=iters, batch=min(50, iters))
     order = torch.from_numpy(plan.order_rid.astype(np.int64)).cuda()
     want = torch.from_numpy(np.diff(rp).astype(np.float64)).cuda()[order]
     ok = bool((y.double() == want).all().item()) if precision == 64 or int(np.diff(rp).max()) <= 2048 else \
@@ -123,21 +227,34 @@ def suite_entry(torch, D, name, precision, scale, budget_s=2.0):
     st = plan.stats
     b_alg = algorithmic_bytes(rows, cols, nnz, precision // 8)
     out = {"workload": name, "dtype": "f64" if precision == 64 else "f16", "rows": rows, "nnz": nnz,
-           "ms": round(w, 6), "event_ms": round(e, 6), "iters": iters, "gflops": round(2.0 * nnz / (w * 1e6), 2),
+           "ms": round(w, 6), "event_ms": round(e, 6), "graph_event_ms": round(ge, 6), "iters": iters, "gflops": round(2.0 * nnz / (w * 1e6), 2),
            "achieved_GBps": round(b_alg / (e * 1e6), 1), "frac_hbm_roofline": round(b_alg / (e * 1e6) / HBM_PEAK_GBPS, 4),
+           "frac_hbm_roofline_graph": round(b_alg / (ge * 1e6) / HBM_PEAK_GBPS, 4),
            "rate_fill0": round(st["rate_fill0"], 4), "pre_ms": round(st["pre_ms"], 1), "verified": ok,
            "col_panels": st["n_col_panels"], "row_long": st["row_long"], "row_block": st["row_block"],
-           "row_short": rows - st["row_long"] - st["row_block"] - st["row_zero"]}
+           "row_short": rows - st["row_long"] - st["row_block"] - st["row_zero"], "generator": generator_of(D, name)}
+    out.update(traffic_for(name, precision, scale, b_alg, kernel_revision()))
     plan.close()
     del x, y
     torch.cuda.empty_cache()
+    try:
+        out["verified_random_x"] = verify_random_x(torch, D, O, rp, ci, cols, precision)
+    except Exception as exc:
+        out["verified_random_x"] = {"ok": False, "error": repr(exc)}
     return out
+
+
+def generator_of(D, name):
+    return "DASP_MTX_DIR file" if real_matrix(D, name) else D.synth_generator(name)
+
+
+CHAIN_FACTOR = {64: 0.5, 16: 1.0}     # f16: 0.5^t would underflow after 24 steps (f64: after 1022, see main)
 
 
 def setup_rank(torch, D, name, scale, prec, rank, world, multi=None, chain=None):
     """Everything one rank owns.  Single GPU: the plan of the whole matrix (A = 1, x = 1, the reference driver's mode).
-    Partitioned: its row range (equal nonzeros) as a dasp_amd.multi.RowPartitionedSpMV -- a plan over the rank's own columns
-    and one over the other ranks' columns remapped into the all-gather layout, the padded y slices and the gather buffer."""
+    Partitioned: its row range (equal nonzeros) as a dasp_mg plan (C ABI) -- a plan over the rank's own columns and one over the
+    other ranks' columns remapped into the all-gather layout, the padded y slices and the gather buffer."""
     multi = world > 1 if multi is None else multi                   # the partitioned layout (forced at world 1 by a test hook)
     rows, cols = matrix_dims(D, name, scale)
     lengths = matrix_lengths(D, name, scale)                        # every rank: cheap, deterministic
@@ -149,28 +266,27 @@ def setup_rank(torch, D, name, scale, prec, rank, world, multi=None, chain=None)
         bounds = np.searchsorted(rp_full, nnz_total * np.arange(world + 1) // world, side="left").astype(np.int32)
         bounds[0], bounds[-1] = 0, rows
         bounds = np.maximum.accumulate(bounds)
-        stride = (int(np.diff(bounds).max()) + 63) // 64 * 64
     else:
-        bounds, stride = None, 0
+        bounds = None
     r0, r1 = (0, rows) if not multi else (int(bounds[rank]), int(bounds[rank + 1]))
     threads = max(1, (os.cpu_count() or 8) // max(1, world))
     if multi:
         # chained iteration x_{t+1} = all_gather(A x_t) (what a solver does with the gathered y).  Values c / len(row) make A
         # row-stochastic up to the factor c, so x_t = c^t * ones: bounded for any number of steps, and (f64, c = 1/2, exact
         # powers of two) a product that read a stale x is off by a factor 2 and fails the check.
-        from dasp_amd.multi import RowPartitionedSpMV
+        from dasp_amd.multi import MgPlan
         rp, ci = matrix_rows(D, name, scale, r0, r1, lengths)
         dt = np.float64 if prec == 64 else np.float16
         c = CHAIN_FACTOR[prec] if chain is None else chain
         val = np.repeat(c / np.maximum(np.diff(rp), 1), np.diff(rp)).astype(dt)
         t0 = time.time()
-        mp = RowPartitionedSpMV(torch, rp, ci, val, cols, bounds, rank, precision=prec, threads=threads, stride=stride,
-                                overlap=os.environ.get("DASP_BENCH_OVERLAP", "1") != "0")
+        mg = MgPlan(rp, ci, val, rows, cols, bounds, rank, precision=prec, threads=threads,
+                    overlap=os.environ.get("DASP_BENCH_OVERLAP", "1") != "0").upload()
         pre_s = time.time() - t0
-        mp.seed(np.ones(cols, dt))
-        del val
-        return dict(chain=c, mp=mp, plan=mp.plan, rp=rp, ci=ci, stats=mp.plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total,
-                    lengths=lengths, bounds=bounds, stride=stride, r0=r0, r1=r1, x=mp.ys[0], y=mp.ys[1], gathered=mp.gathered)
+        mg.set_x(np.ones(cols, dt))
+        own = mg.subplan(0)
+        return dict(chain=c, mg=mg, plan=own, rp=rp, ci=ci, val=val, stats=own.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total,
+                    lengths=lengths, bounds=bounds, stride=mg.stride, r0=r0, r1=r1, x=None, y=None)
     plan, rp, ci, val, pre_s = build_slice(D, name, scale, prec, r0, r1, lengths, threads=threads)
     del val
     plan.upload()
@@ -178,11 +294,8 @@ def setup_rank(torch, D, name, scale, prec, rank, world, multi=None, chain=None)
     tdt = torch.float64 if prec == 64 else torch.float16
     x = torch.ones(plan.x_len, dtype=tdt, device="cuda")
     y = torch.zeros(r1 - r0, dtype=tdt, device="cuda")
-    return dict(chain=None, mp=None, plan=plan, rp=rp, ci=ci, stats=plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total, lengths=lengths,
-                bounds=bounds, stride=stride, r0=r0, r1=r1, x=x, y=y, gathered=None)
-
-
-CHAIN_FACTOR = {64: 0.5, 16: 1.0}     # f16: 0.5^t would underflow after 24 steps (f64: after 1022, see main)
+    return dict(chain=None, mg=None, plan=plan, rp=rp, ci=ci, val=None, stats=plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total,
+                lengths=lengths, bounds=bounds, stride=0, r0=r0, r1=r1, x=x, y=y)
 
 
 def cpu_baseline(O, rp, ci, n_cols, budget_s=20.0):
@@ -205,6 +318,31 @@ def cpu_baseline(O, rp, ci, n_cols, budget_s=20.0):
             "achieved_GBps": round(algorithmic_bytes(rp.size - 1, n_cols, nnz, 8) / med / 1e9, 2)}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run job (this parent never
+    touches the GPU), relay the output, exit with the job's code.  Too few devices is an error of its own (rc 4), not a usage
+    error."""
+    share = os.environ.get("DASP_BENCH_SHARE_GPU") == "1"
+    if not share:
+        probe = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
+        try:
+            ndev = int(probe.stdout.strip().splitlines()[-1])
+        except Exception:
+            ndev = 0
+        if ndev < args.gpus:
+            sys.stderr.write("bench.py --gpus %d: this machine exposes %d GPU(s); need %d devices (one rank per GPU)\n" % (args.gpus, ndev, args.gpus))
+            sys.exit(4)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,8 +354,12 @@ def main():
     ap.add_argument("--no-suite", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vendor", action="store_true")
+    ap.add_argument("--no-random-x", action="store_true")
     ap.add_argument("--suite-scale", type=float, default=1.0)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                                         # does not return
 
     import torch
     import dasp_amd as D
@@ -226,14 +368,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(args.gpus, 1):
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # test hooks (tests/test_gpu_spmv.py runs the N > 1 flow on a one-GPU box): DASP_BENCH_SHARE_GPU=1 puts every rank on
+    # cuda:0 and moves the y slices between the ranks through host memory (RCCL cannot place two ranks on one device).
+    # The driver's runs use neither.
+    share_gpu = os.environ.get("DASP_BENCH_SHARE_GPU") == "1"
+    if not share_gpu and torch.cuda.device_count() < world:
+        sys.stderr.write("bench.py --gpus %d: this machine exposes %d GPU(s); need %d devices (one rank per GPU)\n"
+                         % (args.gpus, torch.cuda.device_count(), world))
+        sys.exit(4)
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible; the DASP path has no CPU fallback")
-    # test hooks (tests/test_gpu_spmv.py runs the N > 1 flow on a one-GPU box): DASP_BENCH_SHARE_GPU=1 puts every rank on
-    # cuda:0, DASP_BENCH_BACKEND=gloo stages the all-gather through host memory.  The driver's runs use neither.
-    share_gpu = os.environ.get("DASP_BENCH_SHARE_GPU") == "1"
-    backend = os.environ.get("DASP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(0 if share_gpu else local_rank)
     # DASP_BENCH_FORCE_DIST=1 (test hook): run the partitioned + RCCL flow even at world size 1, which is all a one-GPU box
     # can offer RCCL (two ranks may not share a device)
@@ -242,10 +387,8 @@ def main():
     if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)      # control plane only; the data path is RCCL inside libdasp_amd.so
 
     name, scale, prec = args.workload, args.scale, args.precision
     vb = prec // 8
@@ -254,32 +397,29 @@ def main():
     R = setup_rank(torch, D, name, scale, prec, rank, world, multi, chain)
     plan, rp, ci, st, pre_s = R["plan"], R["rp"], R["ci"], R["stats"], R["pre_s"]
     rows, cols, nnz_total, lengths = R["rows"], R["cols"], R["nnz_total"], R["lengths"]
-    bounds, stride, r0, r1, x, y, gathered = R["bounds"], R["stride"], R["r0"], R["r1"], R["x"], R["y"], R["gathered"]
+    bounds, stride, r0, r1, x, y = R["bounds"], R["stride"], R["r0"], R["r1"], R["x"], R["y"]
     stream = torch.cuda.current_stream().cuda_stream
-
-    mp = R["mp"]
-
-    class _Done:                                                  # a host-staged exchange has completed when it returns
-        def wait(self):
-            pass
-
-    def exchange(dst, src):
-        if backend == "nccl":                                     # RCCL over xGMI; `dst` has the layout the next product reads
-            return dist.all_gather_into_tensor(dst, src, async_op=True)
-        parts = [torch.empty(stride, dtype=src.dtype) for _ in range(world)]      # test hook: the same exchange through host memory
-        dist.all_gather(parts, src.cpu())
-        dst.copy_(torch.cat(parts))
-        return _Done()
+    mg = R["mg"]
+    host_exchange = multi and share_gpu
+    if multi and not host_exchange:
+        uid = torch.from_numpy(D.multi.unique_id() if rank == 0 else np.zeros(128, np.uint8))
+        dist.broadcast(uid, 0)
+        mg.comm_init(uid.numpy())                                 # ncclCommInitRank, one communicator per rank, on its own GPU
 
     def step():
-        if mp is None:
+        if mg is None:
             plan.spmv(x.data_ptr(), y.data_ptr(), stream)
-        else:
-            mp.step(exchange)     # local-column product | wait for the previous all-gather | remote-column product | start the next
+        elif not host_exchange:
+            mg.spmv(stream)        # own-column product | wait for the previous all-gather | other-column product | ncclAllGather
+        else:                      # test hook: the same products, the exchange through host memory (gloo)
+            mg.product(stream)
+            parts = [None] * world
+            dist.all_gather_object(parts, mg.get_y_local())
+            mg.set_x(np.concatenate(parts))
 
     def fence():
-        if mp is not None:
-            mp.finish()
+        if mg is not None:
+            mg.wait(stream)
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
@@ -297,12 +437,14 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if multi:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     region_event_ms = ev0.elapsed_time(ev1) / args.steps
 
-    if mp is None:
+    from oracle import oracle as O          # checker / baseline only, after the timed region; never on the measured path
+    rx = None
+    if mg is None:
         # ---- exact check: values and x all ones => y == row length
         want = torch.from_numpy(lengths[r0:r1].astype(np.float64)).cuda()
         got = y[: r1 - r0].double()
@@ -312,30 +454,52 @@ def main():
     else:
         # ---- chained check: x_t = c^t on every non-empty row (0 on empty ones) after warmup + steps products, on the gathered y
         t_all = args.warmup + args.steps
-        full = mp.full_y().double()
-        nonempty = torch.from_numpy((lengths > 0).astype(np.float64)).cuda()
+        full = mg.get_y().astype(np.float64)
+        nonempty = (lengths > 0).astype(np.float64)
         if prec == 64:
             want = (R["chain"] ** t_all) * nonempty
-            ok = bool(((full - want).abs() <= 1e-9 * want).all().item())
+            ok = bool((np.abs(full - want) <= 1e-9 * want).all())
         else:
-            ok = bool(torch.isfinite(full).all().item() and ((full >= 0.5 * nonempty) & (full <= 2.0)).all().item())
-        ok = ok and bool(torch.equal(mp.y_local, mp.gathered[rank * stride: rank * stride + (r1 - r0)]))
-        okt = torch.tensor([1 if ok else 0], device="cuda" if backend == "nccl" else "cpu")
+            ok = bool(np.isfinite(full).all() and ((full >= 0.5 * nonempty) & (full <= 2.0)).all())
+        ok = ok and bool(np.array_equal(mg.get_y_local().astype(np.float64), full[r0:r1]))
+        if not args.no_random_x:
+            # one more product on a random x (same on every rank): this rank's rows vs the oracle on its CSR slice -- a wrong
+            # column id or a misplaced slice of the gathered x cannot hide behind x = const
+            dt = np.float64 if prec == 64 else np.float16
+            xr = random_inputs(prec, 1, cols, seed=4242)[1].astype(dt)
+            mg.set_x(xr)
+            step()
+            fence()
+            got = mg.get_y_local().astype(np.float64)
+            idx = sample_rows(rp, 100000)
+            ref, sc = oracle_rows(O, rp, ci, R["val"], xr, idx)
+            err = np.abs(got[idx] - ref) / np.maximum(sc, 1e-300)
+            worst = float(err.max()) if idx.size else 0.0
+            rx = {"ok": bool(np.isfinite(got[idx]).all() and worst <= TOL[prec]), "rows_checked": int(idx.size), "max_rel_err": worst,
+                  "tol": TOL[prec], "inputs": "a_ij = c/len(row), x random seed 4242 (rank 0's slice; every rank checks its own)"}
+            ok = ok and rx["ok"]
+        okt = torch.tensor([1 if ok else 0])
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
 
     # ---- dominant kernel alone: HIP events on the launch stream around back-to-back launches
     k_iters = max(20, min(args.steps, 1000))
-    kw, ke = plan.time(x.data_ptr(), y.data_ptr(), stream, warmup=5, iters=k_iters)
-    # partitioned: the dominant kernel is the rank's local-column plan (its x is the rank's own slice)
-    nnz_local = int(rp[-1]) if mp is None else mp.nnz_local
-    b_alg_local = algorithmic_bytes(r1 - r0, cols if mp is None else stride, nnz_local, vb)
+    if mg is None:
+        kx, ky = x, y
+    else:
+        tdt = torch.float64 if prec == 64 else torch.float16
+        kx = torch.ones(plan.x_len, dtype=tdt, device="cuda")
+        ky = torch.zeros(stride, dtype=tdt, device="cuda")
+    kw, ke = plan.time(kx.data_ptr(), ky.data_ptr(), stream, warmup=5, iters=k_iters)
+    # partitioned: the dominant kernel is the rank's own-column plan (its x is the rank's own slice)
+    nnz_local = int(rp[-1]) if mg is None else mg.nnz_local
+    b_alg_local = algorithmic_bytes(r1 - r0, cols if mg is None else (stride if mg.overlap else cols), nnz_local, vb)
     b_alg_total = algorithmic_bytes(rows, cols, nnz_total, vb)
     achieved = b_alg_local / (ke * 1e6)
     ms_per_step = elapsed * 1e3 / args.steps
     value = 2.0 * nnz_total / (ms_per_step * 1e6)
 
-    vals_desc = "A=1, x=1" if mp is None else "a_ij = %g/len(row i), x_0 = 1, x_{t+1} = y_t" % R["chain"]
+    vals_desc = "A=1, x=1" if mg is None else "a_ij = %g/len(row i), x_0 = 1, x_{t+1} = y_t" % R["chain"]
     out = {
         "metric": "SpMV GFLOP/s (f64)" if prec == 64 else "SpMV GFLOP/s (f16)", "value": round(value, 2), "unit": "GFLOP/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 6),
@@ -343,11 +507,13 @@ def main():
         "dtype": "f64" if prec == 64 else "f16 (f32 accumulate)", "data": "suitesparse" if real_matrix(D, name) else "synthetic",
         "config": {"workload": ("%s from DASP_MTX_DIR, %s" % (name, vals_desc)) if real_matrix(D, name) else
                    "%s synthetic stand-in (seeded; SuiteSparse dims/row statistics), %s" % (name, vals_desc),
+                   "generator": generator_of(D, name),
                    "rows": rows, "cols": cols, "nnz": nnz_total, "scale": scale,
                    "partition": "single GPU" if not multi else
-                   ("row ranges by nnz + RCCL all_gather(y) overlapped with the product over the rank's own columns; x_{t+1} = y_t"
-                    if mp.overlap else "row ranges by nnz + RCCL all_gather(y); x_{t+1} = y_t"),
-                   **({} if mp is None else {"rank0_nnz_own_columns": mp.nnz_local, "rank0_nnz_other_columns": mp.nnz_remote}),
+                   ("row ranges by nnz + ncclAllGather(y) from libdasp_amd.so (dasp_mg_spmv), overlapped with the product over the rank's own columns; x_{t+1} = y_t"
+                    if mg.overlap else "row ranges by nnz + ncclAllGather(y) from libdasp_amd.so (dasp_mg_spmv); x_{t+1} = y_t"),
+                   **({} if mg is None else {"rank0_nnz_own_columns": mg.nnz_local, "rank0_nnz_other_columns": mg.nnz_remote,
+                                             "exchange": "host memory (test hook)" if host_exchange else "RCCL"}),
                    "row_long": st["row_long"], "row_block": st["row_block"], "rate_fill0": round(st["rate_fill0"], 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
@@ -358,31 +524,33 @@ def main():
         "frac_hbm_roofline_whole_job": round(b_alg_total / (ms_per_step * 1e6) / (HBM_PEAK_GBPS * world), 4),
         "region_event_ms_per_step": round(region_event_ms, 6), "verified": ok, "preprocess_s": round(pre_s, 3),
     }
+    if world == 1 and mg is None:
+        out["roofline"].update(traffic_for(name, prec, scale, b_alg_local, kernel_revision()))
+    if rx is not None:
+        out["verified_random_x"] = rx
 
-    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload (tools/prof.sh;
-    # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), when there is one; PMC cannot be read from inside the run
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if world == 1 and os.path.exists(tpath):
-        for t in json.load(open(tpath)):
-            if t["workload"] == name and t["precision"] == prec and abs(t["scale"] - scale) < 1e-12:
-                out["roofline"]["traffic"] = int(t["traffic_bytes"])
-                out["roofline"]["traffic_source"] = t["source"]
-                out["roofline"]["traffic_over_algorithmic"] = round(t["traffic_bytes"] / b_alg_local, 4)
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as O      # checker / baseline only; never on the measured path
+    if rank == 0 and world == 1 and mg is None and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(O, rp, ci, cols)
-    del ci
-    plan.close()
-    del x, y
+    if mg is None:
+        plan.close()
+    del x, y, kx, ky
     torch.cuda.empty_cache()
 
-    if rank == 0 and world == 1 and not args.no_vendor:
+    if rank == 0 and world == 1 and mg is None and not args.no_random_x:
+        try:
+            out["verified_random_x"] = verify_random_x(torch, D, O, rp, ci, cols, prec, time_iters=20)
+        except Exception as exc:
+            out["verified_random_x"] = {"ok": False, "error": repr(exc)}
+        ok = ok and bool(out["verified_random_x"].get("ok"))
+    del ci
+    if mg is not None:
+        mg.close()
+
+    if rank == 0 and world == 1 and not multi and not args.no_vendor:
         # vendor comparator on the same box and matrix: rocSPARSE CSR SpMV (the reference's cuSPARSE column, main_f64.cu:18-100)
         exe = os.path.join(ROOT, "dasp_amd", "bin", "dasp_rocsparse")
         if prec == 64 and os.path.exists(exe) and not real_matrix(D, name):   # the comparator driver generates the stand-in itself
             import re
-            import subprocess
             try:
                 r = subprocess.run([exe, name, repr(scale), "100", "10"], capture_output=True, text=True, timeout=600)
                 mt = re.search(r"\| ([0-9.]+) ms ([0-9.]+) GFLOP/s", r.stdout)
@@ -392,12 +560,12 @@ def main():
             except Exception as exc:
                 out["rocsparse_csr"] = {"error": repr(exc)}
 
-    if rank == 0 and world == 1 and not args.no_suite:
+    if rank == 0 and world == 1 and not multi and not args.no_suite:
         suite = []
         for nm, pr in (("cop20k_A", 64), ("nlpkkt160", 64), ("powerlaw_1M", 64), ("Queen_4147", 64),
                        ("webbase-1M", 16), ("ljournal-2008", 16), ("rmat_2M", 16)):
             try:
-                suite.append(suite_entry(torch, D, nm, pr, args.suite_scale))
+                suite.append(suite_entry(torch, D, O, nm, pr, args.suite_scale))
             except Exception as exc:   # a failing extra must not hide the headline line
                 suite.append({"workload": nm, "error": repr(exc)})
         out["suite"] = suite

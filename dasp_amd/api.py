@@ -281,7 +281,16 @@ def selftest_mfma():
 
 
 # ---- synthetic stand-ins for the SuiteSparse inputs (dasp_amd/csrc/gen.cpp) -----------------
-SYNTH_NAMES = ("cop20k_A", "nlpkkt160", "powerlaw_1M", "webbase-1M", "ljournal-2008", "HV15R", "Queen_4147", "rmat_2M")
+SYNTH_NAMES = ("cop20k_A", "nlpkkt160", "powerlaw_1M", "webbase-1M", "ljournal-2008", "HV15R", "Queen_4147", "rmat_2M",
+               "webbase-1M-uniform", "ljournal-2008-uniform")
+
+
+def synth_generator(name):
+    """One-line description of the stand-in's generator (seed, structure, locality parameters)."""
+    t = _lib.lib().dasp_synth_generator(name.encode())
+    if t is None:
+        raise _lib.DaspError(-10, _lib.lib().dasp_last_error().decode("utf-8", "replace"))
+    return t.decode()
 
 
 def synth_dims(name, scale=1.0):

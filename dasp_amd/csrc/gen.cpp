@@ -9,8 +9,15 @@
 //   nlpkkt160     8345600 = 2 dof x 160x160x163 grid, symmetric, <= 28 per row (19-pt + 9-pt coupling)
 //   Queen_4147    4147110 rows, 3 dof x 27-point stencil (<= 81 per row), symmetric
 //   HV15R         2017169 rows, 5 dof x 27-point stencil (135) with 2% / 0.2% extended rows (375 / 484)
-//   webbase-1M    1000005 rows, power-law lengths (mean ~3.1, max 4700), 70% near / 30% uniform columns
-//   ljournal-2008 5363260 rows, power-law lengths (mean ~14.7, max 2469), uniform columns
+//   webbase-1M    1000005 rows, power-law lengths (mean ~3.1, max 4700); HOST-BLOCK columns: the pages of a host are contiguous
+//                 (a crawl in URL order), host sizes are power-law distributed, 85 % of a page's links stay inside its host
+//                 (half of them within +-32 pages, half skewed to the host's first pages), 3 % go to a neighbouring host, 12 %
+//                 to globally popular pages (power-law popularity, the popular ids scattered over the whole range)
+//   ljournal-2008 5363260 rows, power-law lengths (mean ~14.7, max 2469); COMMUNITY columns: contiguous communities of
+//                 power-law size, 45 % of a user's links inside the community, 15 % to the four neighbouring ones, 40 % to
+//                 globally popular users (scattered ids).  Assumed, not measured: no SuiteSparse file is available here;
+//                 the figures follow what is commonly reported for host-ordered web crawls and LiveJournal communities.
+//   webbase-1M-uniform / ljournal-2008-uniform: the round-1 stand-ins (70 % near / 30 % uniform; all uniform): worst-case gathers
 //   powerlaw_1M   2^20 rows, Zipf(1.8) lengths clipped at 200000 (mean ~48), uniform columns
 //   rmat_2M       2^21 rows, R-MAT / Graph500 (a, b, c, d = 0.57, 0.19, 0.19, 0.05), 16 edges per row on average: skewed degrees AND
 //                 skewed, community-structured columns -- a closer proxy for web / social graphs than uniform columns
@@ -37,7 +44,7 @@ inline uint64_t h2(uint64_t seed, uint64_t a, uint64_t b) { return mix(mix(seed 
 inline double u01(uint64_t h) { return ((h >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
 
 struct Synth {
-    enum Kind { GRID, BAND, POWER, RMAT } kind;
+    enum Kind { GRID, BAND, POWER, RMAT, BLOCKS } kind;
     int rows = 0, cols = 0;
     uint64_t seed = 0;
     // GRID
@@ -49,6 +56,10 @@ struct Synth {
     double alpha = 2, xmin = 1, p_zero = 0, near_frac = 0; int len_max = 0, near_w = 0;
     // RMAT
     int levels = 0; double edge_factor = 16;
+    // BLOCKS (hosts / communities): contiguous blocks of power-law size; row lengths as POWER
+    std::vector<int> bstart;             // [nblocks+1]
+    double p_in = 0, p_nb = 0, in_near = 0, in_skew = 1, g_skew = 2; int nb_reach = 1; uint64_t perm_mul = 1;
+    const char *desc = "";
 };
 
 int scaled(int full, double s) { return std::max(64, (int)std::llround(full * s)); }
@@ -65,14 +76,15 @@ bool make(const char *name, double scale, Synth &g)
         const long long cap = (long long)g.nx * g.ny * g.nz * dof;
         g.rows = g.cols = (int)std::min<long long>(cap, scale == 1.0 ? rows_full : (long long)scaled(rows_full, scale));
     };
-    if (n == "Queen_4147") { grid(113, 111, 111, 3, 4147110, 0, 20007); return true; }
-    if (n == "HV15R") { grid(74, 74, 74, 5, 2017169, 2, 20006); return true; }
-    if (n == "nlpkkt160") { grid(160, 160, 163, 2, 8345600, 1, 20002); return true; }
+    if (n == "Queen_4147") { grid(113, 111, 111, 3, 4147110, 0, 20007); g.desc = "3 dof x 27-point stencil on a 113x111x111 grid"; return true; }
+    if (n == "HV15R") { grid(74, 74, 74, 5, 2017169, 2, 20006); g.desc = "5 dof x 27-point stencil on a 74^3 grid, 2% / 0.2% extended rows (375 / 484)"; return true; }
+    if (n == "nlpkkt160") { grid(160, 160, 163, 2, 8345600, 1, 20002); g.desc = "2 dof on a 160x160x163 grid, 19-point + 9-point coupling"; return true; }
     if (n == "cop20k_A") {
         g.kind = Synth::BAND; g.seed = 20001; g.rows = g.cols = scaled(121192, scale);
         g.band = std::min(4000, std::max(8, g.rows / 4)); g.deg_mean = 21.7; g.deg_sd = 14; g.deg_max = 81;
         // E[clip(N(21.7,14),0,81)] ~ 21.95 ; t_i / sqrt(tbar) propensities give E[deg_i] ~ t_i
         g.tbar = 21.95;
+        g.desc = "symmetric, degree ~ clip(N(21.7,14),0,81), columns uniform in a +-4000 band";
         return true;
     }
     auto power = [&](int rows_full, double alpha, double xmin, double pz, int lmax, double nearf, int nearw, uint64_t seed) {
@@ -80,13 +92,42 @@ bool make(const char *name, double scale, Synth &g)
         g.alpha = alpha; g.xmin = xmin; g.p_zero = pz; g.len_max = std::min(lmax, std::max(8, g.cols / 2));
         g.near_frac = nearf; g.near_w = nearw;
     };
-    if (n == "webbase-1M") { power(1000005, 2.45, 1.32, 0.02, 4700, 0.7, 1000, 20004); return true; }
-    if (n == "ljournal-2008") { power(5363260, 2.35, 4.6, 0.01, 2469, 0.0, 0, 20005); return true; }
-    if (n == "powerlaw_1M") { power(1 << 20, 1.8, 2.05, 0.0, 200000, 0.0, 0, 20003); return true; }
+    // contiguous blocks of Pareto(balpha) size in [bmin, bmax], laid end to end until the rows are covered
+    auto blocks = [&](double balpha, int bmin, int bmax) {
+        g.kind = Synth::BLOCKS;
+        bmax = std::max(bmin, std::min(bmax, g.rows / 4));
+        g.bstart.assign(1, 0);
+        for (uint64_t k = 0; g.bstart.back() < g.rows; ++k) {
+            const double v = u01(h2(g.seed ^ 0xB10Cull, k, 5));
+            const int sz = (int)std::min<double>(bmax, std::floor(bmin * std::pow(v, -1.0 / (balpha - 1.0))));
+            g.bstart.push_back((int)std::min<long long>(g.rows, (long long)g.bstart.back() + std::max(1, sz)));
+        }
+        // bijection r -> (r * perm_mul) mod rows scatters the popular ids (perm_mul odd prime, rows never a multiple of it)
+        g.perm_mul = 2654435761ull;
+        while (g.rows % g.perm_mul == 0) g.perm_mul += 2;
+    };
+    if (n == "webbase-1M-uniform") { power(1000005, 2.45, 1.32, 0.02, 4700, 0.7, 1000, 20004); g.desc = "power-law lengths; 70% of the columns within +-1000 of the row, 30% uniform (round-1 stand-in)"; return true; }
+    if (n == "ljournal-2008-uniform") { power(5363260, 2.35, 4.6, 0.01, 2469, 0.0, 0, 20005); g.desc = "power-law lengths; uniform random columns (round-1 stand-in, worst-case gathers)"; return true; }
+    if (n == "webbase-1M") {
+        power(1000005, 2.45, 1.32, 0.02, 4700, 0.0, 0, 20004);
+        blocks(1.9, 24, 60000);
+        g.p_in = 0.85; g.in_near = 0.5; g.in_skew = 2.0; g.p_nb = 0.03; g.nb_reach = 1; g.g_skew = 3.0;
+        g.desc = "power-law lengths; host blocks (Pareto 1.9, 24..60000 pages): 85% of the links intra-host (half +-32, half skewed to the host's first pages), 3% next host, 12% popular pages (scattered ids)";
+        return true;
+    }
+    if (n == "ljournal-2008") {
+        power(5363260, 2.35, 4.6, 0.01, 2469, 0.0, 0, 20005);
+        blocks(2.2, 256, 120000);
+        g.p_in = 0.45; g.in_near = 0.0; g.in_skew = 1.0; g.p_nb = 0.15; g.nb_reach = 4; g.g_skew = 2.5;
+        g.desc = "power-law lengths; communities (Pareto 2.2, 256..120000 users): 45% of the links inside the community, 15% to the 4 neighbouring ones, 40% to popular users (scattered ids)";
+        return true;
+    }
+    if (n == "powerlaw_1M") { power(1 << 20, 1.8, 2.05, 0.0, 200000, 0.0, 0, 20003); g.desc = "Zipf(1.8) lengths clipped at 200000; uniform random columns"; return true; }
     if (n == "rmat_2M") {
         g.kind = Synth::RMAT; g.seed = 20008; g.rows = g.cols = scaled(1 << 21, scale);
         g.levels = 1; while ((1ll << g.levels) < g.rows) g.levels++;
         g.edge_factor = 16; g.len_max = std::max(8, g.cols / 2);
+        g.desc = "R-MAT (0.57, 0.19, 0.19, 0.05), 16 edges per row";
         return true;
     }
     return false;
@@ -209,6 +250,38 @@ int power_row(const Synth &g, int i, int *out)
     return len;
 }
 
+// ---- BLOCKS rows (host / community structure) -----------------------------------------
+int blocks_row(const Synth &g, int i, int *out)
+{
+    const int len = power_len(g, i);
+    if (!out) return len;
+    const int nb = (int)g.bstart.size() - 1;
+    const int b = (int)(std::upper_bound(g.bstart.begin(), g.bstart.end(), i) - g.bstart.begin()) - 1;
+    const int b0 = g.bstart[(size_t)b], bs = g.bstart[(size_t)b + 1] - b0;
+    for (int k = 0; k < len; ++k) {
+        const uint64_t h = h2(g.seed ^ 0x5151ull, (uint64_t)i, (uint64_t)k);
+        const double u = u01(h), v = u01(mix(h ^ 0x77ull));
+        long long col;
+        if (u < g.p_in) {
+            if (u < g.p_in * g.in_near) {                       // a page next to this one
+                col = (long long)i + (long long)(mix(h ^ 0x99ull) % 65ull) - 32;
+                col = std::min<long long>(b0 + bs - 1, std::max<long long>(b0, col));
+            } else col = b0 + (long long)(bs * std::pow(v, g.in_skew));
+        } else if (u < g.p_in + g.p_nb) {                       // a neighbouring block
+            int d = 1 + (int)(mix(h ^ 0x33ull) % (uint64_t)g.nb_reach);
+            if (mix(h ^ 0x44ull) & 1) d = -d;
+            const int bb = std::min(nb - 1, std::max(0, b + d));
+            const int c0 = g.bstart[(size_t)bb], cs = g.bstart[(size_t)bb + 1] - c0;
+            col = c0 + (long long)(cs * v);
+        } else {                                                // a globally popular target, ids scattered by a bijection
+            const long long r = (long long)(g.cols * std::pow(v, g.g_skew));
+            col = (long long)(((unsigned __int128)(uint64_t)r * g.perm_mul) % (uint64_t)g.cols);
+        }
+        out[k] = (int)std::min<long long>(g.cols - 1, std::max<long long>(0, col));
+    }
+    return len;
+}
+
 // ---- RMAT rows --------------------------------------------------------------------------
 // Row i of an R-MAT matrix, generated on its own: the expected degree of source i is edges * prod over its bits of
 // (a+b = 0.76 for a 0 bit, c+d = 0.24 for a 1 bit); each destination bit is 1 with probability b/(a+b) = 1/4 under a 0 source
@@ -245,6 +318,7 @@ inline int any_row(const Synth &g, int row, int *out, const float *tg, int tg0)
         case Synth::RMAT: return rmat_row(g, row, out);
         case Synth::GRID: return grid_row(g, row, out);
         case Synth::BAND: return band_row(g, row, out, tg, tg0);
+        case Synth::BLOCKS: return blocks_row(g, row, out);
         default: return power_row(g, row, out);
     }
 }
@@ -286,6 +360,15 @@ extern "C" int dasp_synth_dims(const char *name, double scale, int *rows, int *c
     if (!make(name, scale, g) || !rows || !cols) { set_error("unknown synthetic matrix name"); return DASP_ERR_ARG; }
     *rows = g.rows; *cols = g.cols;
     return DASP_OK;
+}
+
+extern "C" const char *dasp_synth_generator(const char *name)
+{
+    static thread_local std::string text;
+    Synth g;
+    if (!make(name, 1.0, g)) { set_error("unknown synthetic matrix name"); return nullptr; }
+    text = std::string("dasp_amd/csrc/gen.cpp seed ") + std::to_string((unsigned long long)g.seed) + ": " + g.desc;
+    return text.c_str();
 }
 
 extern "C" int dasp_synth_row_lengths(const char *name, double scale, int row_begin, int row_end, int *len_out)

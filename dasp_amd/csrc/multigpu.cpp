@@ -1,0 +1,407 @@
+// multigpu.cpp -- row-partitioned y = A*x over the GPUs of one node, one process per GPU: the dasp_mg_* part of the C ABI
+// (include/dasp_amd.h).  The reference is single-GPU (src/main_f64.cu:102-168, one device, one
+// spmv_all call), so there is no reference counterpart; the design follows BASELINE.json's north_star: contiguous row
+// ranges, every rank runs the complete DASP pipeline on its slice, RCCL all-gather of y over xGMI.
+//
+// A rank's nonzeros are split by column ownership into two DASP plans (square matrices):
+//     own   : columns inside the rank's own row range -> read the rank's own padded slice of x (its previous y),
+//     other : every other column                      -> read the all-gather buffer (ids remapped to its padded layout),
+// so that product t+1 over the own columns runs while all-gather t is still in flight on the communication stream and only
+// the (small, for banded matrices) other-column product waits for it.  RCCL is reached through dlopen: one copy per process
+// (the one PyTorch already mapped, if any), and libdasp_amd.so loads on machines without it.
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <exception>
+#include <mutex>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "plan.hpp"
+
+using namespace dasp;
+
+namespace {
+
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+// the process-wide RCCL: an already mapped copy first (PyTorch's wheel bundles its own librccl.so with the same soname;
+// two copies in one process would each bring their own bootstrap state), then the system one
+RcclApi *rccl()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *forced = std::getenv("DASP_RCCL_LIB");
+        void *h = nullptr;
+        if (forced && *forced) h = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { const char *e = dlerror(); api.err = std::string("cannot load librccl.so.1: ") + (e ? e : "?"); return; }
+        api.handle = h;
+        api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
+        api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) {
+            api.err = "librccl.so.1 lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+            api.handle = nullptr;
+        }
+    });
+    return &api;
+}
+
+int rccl_fail(const char *what, ncclResult_t r)
+{
+    RcclApi *a = rccl();
+    set_error(std::string(what) + ": " + (a->GetErrorString ? a->GetErrorString(r) : "RCCL error") + " (" + std::to_string((int)r) + ")");
+    return DASP_ERR_HIP;
+}
+
+#define MG_HIP(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));              \
+            return e_ == hipErrorNoDevice ? DASP_ERR_NO_DEVICE : DASP_ERR_HIP;         \
+        }                                                                              \
+    } while (0)
+
+}  // namespace
+
+struct dasp_mg_plan {
+    int precision = 64, world = 1, rank = 0, rowA = 0, colA = 0, stride = 0;
+    bool square = false, overlap = false, uploaded = false;
+    std::vector<int> bounds;
+    long long nnz_own = 0, nnz_other = 0;
+    dasp_plan_t *own = nullptr;        // own columns (x = this rank's padded slice) -- or the whole slice when there is no split
+    dasp_plan_t *other = nullptr;      // other ranks' columns (x = the gather buffer); may be absent
+    // device state
+    int device = -1;
+    void *ys[2] = {nullptr, nullptr};  // this rank's padded slice of y, ping-pong (the one last written is the next x slice)
+    void *yg = nullptr;                // world * stride: every rank's slice; for a square matrix also the x the products read
+    void *xg = nullptr;                // what the products read: yg (square) or a plain colA vector (rectangular)
+    int cur = 0;
+    bool pending = false;              // an all-gather into yg is in flight on `cs`
+    hipStream_t cs = nullptr;          // communication stream
+    hipEvent_t ev_y = nullptr, ev_g = nullptr;
+    ncclComm_t comm = nullptr;
+
+    size_t vb() const { return precision == 64 ? 8 : 2; }
+    int rows() const { return bounds[(size_t)rank + 1] - bounds[(size_t)rank]; }
+    ~dasp_mg_plan()
+    {
+        if (comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(comm);
+        if (ev_y) (void)hipEventDestroy(ev_y);
+        if (ev_g) (void)hipEventDestroy(ev_g);
+        if (cs) (void)hipStreamDestroy(cs);
+        for (void *p : {ys[0], ys[1], yg}) if (p) (void)hipFree(p);
+        if (xg && xg != yg) (void)hipFree(xg);
+        if (own) dasp_plan_destroy(own);
+        if (other) dasp_plan_destroy(other);
+    }
+};
+
+namespace {
+
+// CSR slice -> (own, other): entries with lo <= col < hi (columns re-based to 0) and the rest (global columns); the order
+// inside a row is kept.  Row-parallel count + scatter.
+template <class T>
+void split_by_owner(int m, const int *rp, const int *ci, const T *val, int lo, int hi, int threads,
+                    std::vector<int> &rpO, std::vector<int> &ciO, std::vector<T> &vO,
+                    std::vector<int> &rpR, std::vector<int> &ciR, std::vector<T> &vR)
+{
+    rpO.assign((size_t)m + 1, 0); rpR.assign((size_t)m + 1, 0);
+    auto par = [&](auto f) {
+        const int parts = std::max(1, std::min(threads, m / 4096 + 1));
+        std::vector<std::thread> th;
+        for (int t = 0; t < parts; ++t) {
+            const int b = (int)((long long)m * t / parts), e = (int)((long long)m * (t + 1) / parts);
+            th.emplace_back([=] { f(b, e); });
+        }
+        for (auto &x : th) x.join();
+    };
+    par([&](int b, int e) {
+        for (int i = b; i < e; ++i) {
+            int o = 0;
+            for (int j = rp[i]; j < rp[i + 1]; ++j) o += ci[j] >= lo && ci[j] < hi;
+            rpO[(size_t)i + 1] = o; rpR[(size_t)i + 1] = rp[i + 1] - rp[i] - o;
+        }
+    });
+    for (int i = 0; i < m; ++i) { rpO[(size_t)i + 1] += rpO[i]; rpR[(size_t)i + 1] += rpR[i]; }
+    ciO.resize((size_t)rpO[m]); vO.resize((size_t)rpO[m]); ciR.resize((size_t)rpR[m]); vR.resize((size_t)rpR[m]);
+    par([&](int b, int e) {
+        for (int i = b; i < e; ++i) {
+            int o = rpO[i], r = rpR[i];
+            for (int j = rp[i]; j < rp[i + 1]; ++j) {
+                if (ci[j] >= lo && ci[j] < hi) { ciO[(size_t)o] = ci[j] - lo; vO[(size_t)o++] = val[j]; }
+                else { ciR[(size_t)r] = ci[j]; vR[(size_t)r++] = val[j]; }
+            }
+        }
+    });
+}
+
+template <class T>
+int create_impl(dasp_mg_plan &g, const int *rp, const int *ci, const T *val, const dasp_options_t *user)
+{
+    const int m = g.rows();
+    const int lo = g.bounds[(size_t)g.rank], hi = g.bounds[(size_t)g.rank + 1];
+    dasp_options_t opt;
+    if (user) opt = *user; else dasp_options_default(&opt);
+    opt.y_order = DASP_Y_NATURAL;              // the padded y slice is what the all-gather sends: un-permute fused into the stores
+    opt.n_parts = 0; opt.part_bounds = nullptr; opt.part_stride = 0;
+    const int nnz = rp[m];
+    if (!g.square) {
+        // rectangular: x is not y; the products read a plain colA vector, the all-gather only assembles y
+        g.nnz_own = nnz; g.nnz_other = 0;
+        return dasp_plan_create(&g.own, g.precision, m, g.colA, nnz, rp, ci, val, &opt);
+    }
+    dasp_options_t part = opt;
+    part.n_parts = g.world; part.part_bounds = g.bounds.data(); part.part_stride = g.stride;
+    if (!g.overlap) {
+        g.nnz_own = nnz; g.nnz_other = 0;
+        return dasp_plan_create(&g.own, g.precision, m, g.colA, nnz, rp, ci, val, &part);
+    }
+    std::vector<int> rpO, ciO, rpR, ciR;
+    std::vector<T> vO, vR;
+    split_by_owner<T>(m, rp, ci, val, lo, hi, resolve_threads(opt.host_threads), rpO, ciO, vO, rpR, ciR, vR);
+    g.nnz_own = rpO[(size_t)m]; g.nnz_other = rpR[(size_t)m];
+    static const int zero = 0;
+    if (int rc = dasp_plan_create(&g.own, g.precision, m, g.stride, rpO[(size_t)m], rpO.data(), ciO.empty() ? &zero : ciO.data(),
+                                  vO.empty() ? static_cast<const void *>(&zero) : vO.data(), &opt)) return rc;
+    if (g.nnz_other > 0)
+        if (int rc = dasp_plan_create(&g.other, g.precision, m, g.colA, rpR[(size_t)m], rpR.data(), ciR.data(), vR.data(), &part)) return rc;
+    return DASP_OK;
+}
+
+int product(dasp_mg_plan &g, hipStream_t s)
+{
+    const int cur = g.cur, nxt = 1 - g.cur;
+    if (g.overlap) {
+        // own columns: needs only this rank's slice of x, i.e. its own previous y -- no communication
+        if (int rc = dasp_plan_spmv(g.own, g.ys[cur], g.ys[nxt], s)) return rc;
+        if (g.pending) { MG_HIP(hipStreamWaitEvent(s, g.ev_g, 0)); g.pending = false; }     // the other ranks' x has arrived
+        if (g.other) if (int rc = dasp_plan_spmv_acc(g.other, g.yg, g.ys[nxt], s)) return rc;   // y += (other columns) * x
+    } else {
+        if (g.pending) { MG_HIP(hipStreamWaitEvent(s, g.ev_g, 0)); g.pending = false; }
+        if (int rc = dasp_plan_spmv(g.own, g.xg, g.ys[nxt], s)) return rc;
+    }
+    g.cur = nxt;
+    return DASP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dasp_mg_unique_id(void *id)
+{
+    if (!id) return DASP_ERR_ARG;
+    RcclApi *a = rccl();
+    if (!a->handle) { set_error(a->err); return DASP_ERR_STATE; }
+    static_assert(sizeof(ncclUniqueId) == DASP_MG_ID_BYTES, "DASP_MG_ID_BYTES must match ncclUniqueId");
+    ncclUniqueId u;
+    const ncclResult_t r = a->GetUniqueId(&u);
+    if (r != ncclSuccess) return rccl_fail("ncclGetUniqueId", r);
+    std::memcpy(id, &u, sizeof u);
+    return DASP_OK;
+}
+
+int dasp_mg_plan_create(dasp_mg_plan_t **out, int precision, int rowA, int colA, int n_gpus, int rank, const int *row_bounds,
+                        const int *csrRowPtr, const int *csrColIdx, const void *csrVal, const dasp_options_t *opt, int overlap)
+{
+    if (!out) return DASP_ERR_ARG;
+    *out = nullptr;
+    if ((precision != 64 && precision != 16) || rowA < 0 || colA < 0 || n_gpus <= 0 || rank < 0 || rank >= n_gpus || !row_bounds || !csrRowPtr) {
+        set_error("dasp_mg_plan_create: bad arguments"); return DASP_ERR_ARG;
+    }
+    if (row_bounds[0] != 0 || row_bounds[n_gpus] != rowA) { set_error("row_bounds must span [0,rowA]"); return DASP_ERR_ARG; }
+    for (int g = 0; g < n_gpus; ++g)
+        if (row_bounds[g + 1] < row_bounds[g]) { set_error("row_bounds not monotone"); return DASP_ERR_ARG; }
+    try {
+        std::unique_ptr<dasp_mg_plan> g(new dasp_mg_plan());
+        g->precision = precision; g->world = n_gpus; g->rank = rank; g->rowA = rowA; g->colA = colA;
+        g->bounds.assign(row_bounds, row_bounds + n_gpus + 1);
+        int widest = 0;
+        for (int k = 0; k < n_gpus; ++k) widest = std::max(widest, row_bounds[k + 1] - row_bounds[k]);
+        g->stride = std::max(64, (widest + 63) / 64 * 64);        // equal padded slices: what ncclAllGather needs
+        if ((long long)g->stride * n_gpus >= (1ll << 31)) { set_error("gathered vector exceeds 2^31 elements"); return DASP_ERR_ARG; }
+        g->square = rowA == colA;
+        g->overlap = g->square && overlap != 0 && n_gpus > 1;
+        const int m = g->rows();
+        const int nnz = csrRowPtr[m];
+        if (csrRowPtr[0] != 0 || nnz < 0 || (nnz > 0 && (!csrColIdx || !csrVal))) { set_error("dasp_mg_plan_create: bad local CSR"); return DASP_ERR_ARG; }
+        for (long long j = 0; j < nnz; ++j)
+            if ((unsigned)csrColIdx[j] >= (unsigned)colA) { set_error("column index out of range"); return DASP_ERR_ARG; }
+        const int rc = precision == 64 ? create_impl<double>(*g, csrRowPtr, csrColIdx, static_cast<const double *>(csrVal), opt)
+                                       : create_impl<uint16_t>(*g, csrRowPtr, csrColIdx, static_cast<const uint16_t *>(csrVal), opt);
+        if (rc) return rc;
+        *out = g.release();
+        return DASP_OK;
+    } catch (const std::bad_alloc &) { set_error("out of host memory"); return DASP_ERR_NOMEM; }
+    catch (const std::exception &e) { set_error(std::string("dasp_mg_plan_create: ") + e.what()); return DASP_ERR_ARG; }
+}
+
+void dasp_mg_destroy(dasp_mg_plan_t *mg) { delete mg; }
+
+int dasp_mg_upload(dasp_mg_plan_t *mg)
+{
+    if (!mg) return DASP_ERR_ARG;
+    dasp_mg_plan &g = *mg;
+    if (g.uploaded) return DASP_OK;
+    if (int rc = dasp_plan_upload(g.own)) return rc;
+    if (g.other) if (int rc = dasp_plan_upload(g.other)) return rc;
+    (void)dasp_plan_drop_host(g.own);
+    if (g.other) (void)dasp_plan_drop_host(g.other);
+    MG_HIP(hipGetDevice(&g.device));
+    const size_t vb = g.vb(), sl = (size_t)g.stride * vb, all = sl * (size_t)g.world;
+    for (int k = 0; k < 2; ++k) { MG_HIP(hipMalloc(&g.ys[k], sl)); MG_HIP(hipMemset(g.ys[k], 0, sl)); }
+    MG_HIP(hipMalloc(&g.yg, all)); MG_HIP(hipMemset(g.yg, 0, all));
+    if (g.square) g.xg = g.yg;
+    else { const size_t xb = std::max<size_t>((size_t)g.colA * vb, 16); MG_HIP(hipMalloc(&g.xg, xb)); MG_HIP(hipMemset(g.xg, 0, xb)); }
+    MG_HIP(hipStreamCreateWithFlags(&g.cs, hipStreamNonBlocking));
+    MG_HIP(hipEventCreateWithFlags(&g.ev_y, hipEventDisableTiming));
+    MG_HIP(hipEventCreateWithFlags(&g.ev_g, hipEventDisableTiming));
+    MG_HIP(hipDeviceSynchronize());
+    g.uploaded = true;
+    return DASP_OK;
+}
+
+int dasp_mg_comm_init(dasp_mg_plan_t *mg, const void *id)
+{
+    if (!mg || !id) return DASP_ERR_ARG;
+    if (mg->comm) { set_error("communicator already initialised"); return DASP_ERR_STATE; }
+    RcclApi *a = rccl();
+    if (!a->handle) { set_error(a->err); return DASP_ERR_STATE; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { set_error("no HIP device visible"); return DASP_ERR_NO_DEVICE; }
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof u);
+    const ncclResult_t r = a->CommInitRank(&mg->comm, mg->world, u, mg->rank);
+    if (r != ncclSuccess) { mg->comm = nullptr; return rccl_fail("ncclCommInitRank", r); }
+    return DASP_OK;
+}
+
+int dasp_mg_set_x(dasp_mg_plan_t *mg, const void *x_host)
+{
+    if (!mg || !x_host) return DASP_ERR_ARG;
+    dasp_mg_plan &g = *mg;
+    if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
+    const size_t vb = g.vb();
+    const char *x = static_cast<const char *>(x_host);
+    MG_HIP(hipDeviceSynchronize());
+    g.pending = false;
+    if (!g.square) { MG_HIP(hipMemcpy(g.xg, x, (size_t)g.colA * vb, hipMemcpyHostToDevice)); return DASP_OK; }
+    try {
+        std::vector<char> lay((size_t)g.world * g.stride * vb, 0);
+        for (int k = 0; k < g.world; ++k)
+            std::memcpy(lay.data() + (size_t)k * g.stride * vb, x + (size_t)g.bounds[(size_t)k] * vb, (size_t)(g.bounds[(size_t)k + 1] - g.bounds[(size_t)k]) * vb);
+        MG_HIP(hipMemcpy(g.yg, lay.data(), lay.size(), hipMemcpyHostToDevice));
+        MG_HIP(hipMemcpy(g.ys[g.cur], lay.data() + (size_t)g.rank * g.stride * vb, (size_t)g.stride * vb, hipMemcpyHostToDevice));
+    } catch (const std::bad_alloc &) { set_error("out of host memory"); return DASP_ERR_NOMEM; }
+    return DASP_OK;
+}
+
+int dasp_mg_product(dasp_mg_plan_t *mg, void *stream)
+{
+    if (!mg) return DASP_ERR_ARG;
+    if (!mg->uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
+    return product(*mg, static_cast<hipStream_t>(stream));
+}
+
+int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream)
+{
+    if (!mg) return DASP_ERR_ARG;
+    dasp_mg_plan &g = *mg;
+    if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
+    if (!g.comm && g.world > 1) { set_error("dasp_mg_spmv needs dasp_mg_comm_init (or use dasp_mg_product with your own exchange)"); return DASP_ERR_STATE; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = product(g, s)) return rc;
+    // y (this rank's padded slice) -> every rank's gather buffer, on the communication stream, behind the products
+    MG_HIP(hipEventRecord(g.ev_y, s));
+    MG_HIP(hipStreamWaitEvent(g.cs, g.ev_y, 0));
+    if (g.comm) {
+        const ncclResult_t r = rccl()->AllGather(g.ys[g.cur], g.yg, (size_t)g.stride, g.precision == 64 ? ncclFloat64 : ncclFloat16, g.comm, g.cs);
+        if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
+    } else {
+        MG_HIP(hipMemcpyAsync(g.yg, g.ys[g.cur], (size_t)g.stride * g.vb(), hipMemcpyDeviceToDevice, g.cs));   // one rank: the gather is a copy
+    }
+    MG_HIP(hipEventRecord(g.ev_g, g.cs));
+    g.pending = true;
+    return DASP_OK;
+}
+
+int dasp_mg_wait(dasp_mg_plan_t *mg, void *stream)
+{
+    if (!mg) return DASP_ERR_ARG;
+    if (mg->pending) { MG_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), mg->ev_g, 0)); mg->pending = false; }
+    return DASP_OK;
+}
+
+int dasp_mg_get_y(dasp_mg_plan_t *mg, void *y_host)
+{
+    if (!mg || !y_host) return DASP_ERR_ARG;
+    dasp_mg_plan &g = *mg;
+    if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
+    MG_HIP(hipDeviceSynchronize());
+    g.pending = false;
+    const size_t vb = g.vb();
+    try {
+        std::vector<char> lay((size_t)g.world * g.stride * vb);
+        MG_HIP(hipMemcpy(lay.data(), g.yg, lay.size(), hipMemcpyDeviceToHost));
+        char *y = static_cast<char *>(y_host);
+        for (int k = 0; k < g.world; ++k)
+            std::memcpy(y + (size_t)g.bounds[(size_t)k] * vb, lay.data() + (size_t)k * g.stride * vb, (size_t)(g.bounds[(size_t)k + 1] - g.bounds[(size_t)k]) * vb);
+    } catch (const std::bad_alloc &) { set_error("out of host memory"); return DASP_ERR_NOMEM; }
+    return DASP_OK;
+}
+
+int dasp_mg_get_y_local(dasp_mg_plan_t *mg, void *y_host)
+{
+    if (!mg || !y_host) return DASP_ERR_ARG;
+    if (!mg->uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
+    MG_HIP(hipDeviceSynchronize());
+    if (mg->rows() > 0) MG_HIP(hipMemcpy(y_host, mg->ys[mg->cur], (size_t)mg->rows() * mg->vb(), hipMemcpyDeviceToHost));
+    return DASP_OK;
+}
+
+void *dasp_mg_y_local(dasp_mg_plan_t *mg) { return mg && mg->uploaded ? mg->ys[mg->cur] : nullptr; }
+void *dasp_mg_gathered(dasp_mg_plan_t *mg) { return mg && mg->uploaded ? mg->yg : nullptr; }
+void *dasp_mg_x(dasp_mg_plan_t *mg) { return mg && mg->uploaded ? mg->xg : nullptr; }
+
+dasp_plan_t *dasp_mg_subplan(dasp_mg_plan_t *mg, int which)
+{
+    if (!mg || which < 0 || which > 1) return nullptr;
+    return which == 0 ? mg->own : mg->other;
+}
+
+int dasp_mg_info(const dasp_mg_plan_t *mg, dasp_mg_info_t *out)
+{
+    if (!mg || !out) return DASP_ERR_ARG;
+    std::memset(out, 0, sizeof *out);
+    out->precision = mg->precision; out->n_gpus = mg->world; out->rank = mg->rank; out->rowA = mg->rowA; out->colA = mg->colA;
+    out->row_begin = mg->bounds[(size_t)mg->rank]; out->row_end = mg->bounds[(size_t)mg->rank + 1]; out->stride = mg->stride;
+    out->nnz_own = mg->nnz_own; out->nnz_other = mg->nnz_other;
+    out->overlap = mg->overlap ? 1 : 0; out->has_comm = mg->comm ? 1 : 0; out->square = mg->square ? 1 : 0;
+    return DASP_OK;
+}
+
+}  // extern "C"

@@ -1,113 +1,128 @@
-"""Row-partitioned y = A x over several GPUs, one process per GPU (no reference counterpart: the reference is
-single-GPU, src/main_f64.cu).
+"""ctypes mirror of the dasp_mg_* part of the C ABI (include/dasp_amd.h): row-partitioned y = A x over several GPUs, one
+process per GPU (no reference counterpart: the reference is single-GPU, src/main_f64.cu).
 
-Rank r owns the rows [bounds[r], bounds[r+1]) and, for a square matrix, the x entries of the same indices.  After every product
-the padded y slices are all-gathered into the buffer the next product reads as x.  With `overlap` the rank's nonzeros are split
-by column ownership into two DASP plans:
-
-    local  : columns inside the rank's own range -> reads the rank's own slice of x, available as soon as the rank's previous
-             product is done;
-    remote : everything else -> reads the all-gather buffer (columns remapped into its padded layout by the plan).
-
-so the local product of iteration t+1 runs while the all-gather of iteration t is still in flight; only the (small, for banded
-matrices) remote product waits for it.  The exchange is a callback so that the same choreography runs over RCCL
-(`all_gather_into_tensor(..., async_op=True)`) and, in tests, through host memory.
+All of the choreography -- the own / other column split, the accumulate launch, the communication stream, the RCCL
+all-gather -- lives in dasp_amd/csrc/multigpu.cpp; this file only converts arguments.  Rank r owns the rows
+[bounds[r], bounds[r+1]) and, for a square matrix, the x entries of the same indices; after every product the padded y
+slices are all-gathered into the buffer the next product reads as x.
 """
+import ctypes as C
+
 import numpy as np
 
+from . import _lib
 from . import api as D
 
 
-def split_by_owner(rp, ci, val, lo, hi):
-    """CSR slice -> (local, remote): entries with lo <= col < hi (columns re-based to 0) and the rest (global columns)."""
-    m = rp.size - 1
-    own = (ci >= lo) & (ci < hi)
-    rows = np.repeat(np.arange(m, dtype=np.int32), np.diff(rp))
-
-    def sub(mask, shift):
-        rp2 = np.zeros(m + 1, np.int64)
-        np.cumsum(np.bincount(rows[mask], minlength=m), out=rp2[1:])
-        return rp2.astype(np.int32), (ci[mask] - shift).astype(np.int32), val[mask]
-
-    return sub(own, lo), sub(~own, 0)
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
 
 
-class RowPartitionedSpMV:
-    def __init__(self, torch, rp, ci, val, n_cols, bounds, rank, precision=64, overlap=True, threads=0, stride=None):
-        self.torch = torch
-        bounds = np.ascontiguousarray(bounds, np.int32)
-        self.bounds, self.rank, self.world = bounds, rank, bounds.size - 1
-        self.rows = int(bounds[rank + 1] - bounds[rank])
-        self.stride = int(stride) if stride else (int(np.diff(bounds).max()) + 63) // 64 * 64
+def unique_id():
+    """ncclGetUniqueId: 128 bytes that rank 0 creates and every rank passes to MgPlan.comm_init."""
+    buf = np.zeros(128, np.uint8)
+    _lib.check(_lib.lib().dasp_mg_unique_id(_vp(buf)))
+    return buf
+
+
+class MgPlan:
+    def __init__(self, rp, ci, val, n_rows, n_cols, bounds, rank, precision=64, overlap=True, threads=0, **opts):
+        """rp / ci / val: this rank's CSR slice (local row pointer, GLOBAL column ids)."""
+        L = _lib.lib()
         self.precision = precision
-        square = int(bounds[-1]) == int(n_cols)
-        self.overlap = bool(overlap) and square
-        kw = dict(precision=precision, y_order=D.Y_NATURAL, host_threads=threads)
-        self.plan_rem = None
-        if self.overlap:
-            (rpl, cil, vl), (rpr, cir, vr) = split_by_owner(rp, ci, val, int(bounds[rank]), int(bounds[rank + 1]))
-            self.plan = D.Plan(rpl, cil, vl, self.stride, **kw)                   # x = this rank's own padded slice
-            if cir.size:
-                self.plan_rem = D.Plan(rpr, cir, vr, n_cols, part_bounds=bounds, part_stride=self.stride, **kw)
-            self.nnz_local, self.nnz_remote = int(cil.size), int(cir.size)
-        else:
-            self.plan = D.Plan(rp, ci, val, n_cols, part_bounds=bounds, part_stride=self.stride, **kw)
-            self.nnz_local, self.nnz_remote = int(ci.size), 0
-        for p in (self.plan, self.plan_rem):
-            if p is not None:
-                p.upload()
-                p.drop_host()
-        tdt = torch.float64 if precision == 64 else torch.float16
-        z = lambda n: torch.zeros(n, dtype=tdt, device="cuda")
-        self.ys = [z(self.stride), z(self.stride)]       # this rank's padded slice of x / y, ping-pong
-        self.gathered = z(self.world * self.stride)      # every rank's slice: the x the remote (or whole) plan reads
-        self.cur = 0
-        self.pending = None
-
-    def seed(self, x_full):
-        """x_0 (host array of the n columns / rows) -> this rank's slice and the gathered layout."""
-        torch, b, s = self.torch, self.bounds, self.stride
-        g = np.zeros(self.world * s, x_full.dtype)
-        for r in range(self.world):
-            g[r * s: r * s + b[r + 1] - b[r]] = x_full[b[r]:b[r + 1]]
-        self.gathered.copy_(torch.from_numpy(g))
-        self.ys[0].copy_(self.gathered[self.rank * s:(self.rank + 1) * s])
-        self.cur, self.pending = 0, None
-
-    def step(self, gather):
-        """One iteration: y = A x, then start the exchange that makes y the next x.  `gather(dst, src)` starts the all-gather of
-        the ranks' `src` slices into `dst` and returns an object with .wait() (stream-side) or None if it already completed."""
-        torch = self.torch
-        s = torch.cuda.current_stream().cuda_stream
-        cur, nxt = self.cur, 1 - self.cur
-        if self.overlap:
-            self.plan.spmv(self.ys[cur].data_ptr(), self.ys[nxt].data_ptr(), s)   # needs only this rank's own x
-            if self.pending is not None:
-                self.pending.wait()                                               # the other ranks' x has arrived
-            if self.plan_rem is not None:                                         # y += (other ranks' columns) * x
-                self.plan_rem.spmv(self.gathered.data_ptr(), self.ys[nxt].data_ptr(), s, accumulate=True)
-        else:
-            if self.pending is not None:
-                self.pending.wait()
-            self.plan.spmv(self.gathered.data_ptr(), self.ys[nxt].data_ptr(), s)
-        self.pending = gather(self.gathered, self.ys[nxt])
-        self.cur = nxt
-
-    def finish(self):
-        if self.pending is not None:
-            self.pending.wait()
-            self.pending = None
+        dt = np.float64 if precision == 64 else np.float16
+        rp = np.ascontiguousarray(rp, np.int32)
+        ci = np.ascontiguousarray(ci, np.int32)
+        v = np.ascontiguousarray(val, dt)
+        b = np.ascontiguousarray(bounds, np.int32)
+        opt = _lib.Options()
+        L.dasp_options_default(C.byref(opt))
+        opt.host_threads = threads
+        for k, x in opts.items():
+            setattr(opt, k, x)
+        self._h = C.c_void_p()
+        _lib.check(L.dasp_mg_plan_create(C.byref(self._h), precision, int(n_rows), int(n_cols), b.size - 1, int(rank), _vp(b), _vp(rp),
+                                         _vp(ci), _vp(v), C.byref(opt), 1 if overlap else 0))
+        self.bounds, self.rank, self.world = b, int(rank), b.size - 1
+        i = self.info
+        self.stride, self.rows, self.overlap = i["stride"], i["row_end"] - i["row_begin"], bool(i["overlap"])
+        self.nnz_local, self.nnz_remote = i["nnz_own"], i["nnz_other"]
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
 
     @property
-    def y_local(self):
-        return self.ys[self.cur][: self.rows]
+    def info(self):
+        s = _lib.MgInfo()
+        _lib.check(_lib.lib().dasp_mg_info(self._h, C.byref(s)))
+        return s.as_dict()
 
-    def full_y(self):
-        """The gathered result without the padding (valid after finish())."""
-        b, s = self.bounds, self.stride
-        return self.torch.cat([self.gathered[r * s: r * s + int(b[r + 1] - b[r])] for r in range(self.world)])
+    def subplan(self, which):
+        """Borrowed api.Plan view of the own-column (0) / other-column (1) plan; None if absent."""
+        h = _lib.lib().dasp_mg_subplan(self._h, which)
+        if not h:
+            return None
+        sub = D.Plan.__new__(D.Plan)
+        sub._h, sub._pb, sub._borrowed, sub._parent = C.c_void_p(h), None, True, self
+        st = sub.stats
+        sub.precision, sub.rowA, sub.colA, sub.nnzA = st["precision"], st["rowA"], st["colA"], st["nnzA"]
+        sub.y_order, sub.x_len = D.Y_NATURAL, int(_lib.lib().dasp_plan_x_len(sub._h))
+        return sub
+
+    def upload(self):
+        _lib.check(_lib.lib().dasp_mg_upload(self._h))
+        return self
+
+    def comm_init(self, uid):
+        uid = np.ascontiguousarray(uid, np.uint8)
+        assert uid.size == 128
+        _lib.check(_lib.lib().dasp_mg_comm_init(self._h, _vp(uid)))
+
+    def set_x(self, x_full):
+        dt = np.float64 if self.precision == 64 else np.float16
+        x = np.ascontiguousarray(x_full, dt)
+        assert x.size == self.n_cols
+        _lib.check(_lib.lib().dasp_mg_set_x(self._h, _vp(x)))
+
+    def spmv(self, stream=0):
+        _lib.check(_lib.lib().dasp_mg_spmv(self._h, C.c_void_p(stream)))
+
+    def product(self, stream=0):
+        _lib.check(_lib.lib().dasp_mg_product(self._h, C.c_void_p(stream)))
+
+    def wait(self, stream=0):
+        _lib.check(_lib.lib().dasp_mg_wait(self._h, C.c_void_p(stream)))
+
+    def get_y(self):
+        dt = np.float64 if self.precision == 64 else np.float16
+        y = np.zeros(self.n_rows, dt)
+        _lib.check(_lib.lib().dasp_mg_get_y(self._h, _vp(y)))
+        return y
+
+    def get_y_local(self):
+        dt = np.float64 if self.precision == 64 else np.float16
+        y = np.zeros(self.rows, dt)
+        _lib.check(_lib.lib().dasp_mg_get_y_local(self._h, _vp(y)))
+        return y
+
+    # integer device addresses (as torch's data_ptr())
+    @property
+    def y_local_ptr(self):
+        return int(_lib.lib().dasp_mg_y_local(self._h) or 0)
+
+    @property
+    def gathered_ptr(self):
+        return int(_lib.lib().dasp_mg_gathered(self._h) or 0)
+
+    @property
+    def x_ptr(self):
+        return int(_lib.lib().dasp_mg_x(self._h) or 0)
 
     def close(self):
-        for p in (self.plan, self.plan_rem):
-            if p is not None:
-                p.close()
+        if getattr(self, "_h", None):
+            _lib.lib().dasp_mg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -248,10 +248,69 @@ int dasp_spmv_all_f16(const char *filename, const uint16_t *csrValA, const int *
                       const int *csrColIdxA, const uint16_t *X_val, uint16_t *Y_val, int *order_rid,
                       int rowA, int colA, int nnzA, int NUM, double threshold, int block_longest);
 
-/* ---------------------------------------------------------------- multi-GPU helper
- * (no reference counterpart: the reference is single-GPU).  Contiguous row ranges with
- * equal nonzero counts: bounds[0]=0 <= ... <= bounds[n_parts]=rowA. */
+/* ---------------------------------------------------------------- multi-GPU
+ * No reference counterpart: the reference drives one device (src/main_f64.cu:102-168).  Row-partitioned y = A*x over the
+ * GPUs of one node, ONE PROCESS PER GPU: rank g owns the contiguous rows [row_bounds[g], row_bounds[g+1]) (and, for a square
+ * matrix, the x entries of the same indices), runs the complete DASP pipeline on its slice and sends its y slice to every
+ * rank with one RCCL all-gather over xGMI; the gathered y is laid out exactly as the next product reads x
+ * (x_{t+1} = y_t, what an iterative solver does), in equal padded slices: element i of rank g's slice sits at
+ * g * stride + i.  With `overlap` the slice is split by column ownership into two plans -- own columns (read the rank's
+ * own previous y: no communication) and other columns (read the gather buffer, y += ) -- so the own-column product of
+ * iteration t+1 runs while the all-gather of iteration t is still in flight on a private communication stream.
+ * librccl.so.1 is opened with dlopen on first use (the copy already mapped in the process, e.g. PyTorch's, else the
+ * system one; DASP_RCCL_LIB overrides): libdasp_amd.so itself does not depend on it. */
+typedef struct dasp_mg_plan dasp_mg_plan_t;
+enum { DASP_MG_ID_BYTES = 128 };   /* sizeof(ncclUniqueId) */
+
+typedef struct dasp_mg_info {
+    int precision, n_gpus, rank, rowA, colA;
+    int row_begin, row_end;        /* this rank's rows */
+    int stride;                    /* padded slice length in elements (multiple of 64) */
+    long long nnz_own, nnz_other;  /* nonzeros in the rank's own column range / elsewhere (nnz_other = 0 without the split) */
+    int overlap, has_comm, square;
+} dasp_mg_info_t;
+
+/* contiguous row ranges with equal nonzero counts: bounds[0]=0 <= ... <= bounds[n_parts]=rowA */
 int dasp_partition_rows(int rowA, const int *csrRowPtr, int n_parts, int *bounds);
+
+/* rank 0: ncclGetUniqueId into id[DASP_MG_ID_BYTES]; hand the bytes to every rank out of band (MPI_Bcast, a file, a
+ * torch.distributed broadcast ...), then every rank calls dasp_mg_comm_init with them */
+int dasp_mg_unique_id(void *id);
+
+/* host part (no GPU needed): classifier + packers of this rank's slice.  csrRowPtr [rows+1] is local (starts at 0),
+ * csrColIdx holds GLOBAL column ids, csrVal as dasp_plan_create.  opt: NULL = defaults (y_order and the column partition
+ * fields are set by this call).  overlap: 1 = own / other column split (square matrices, n_gpus > 1), 0 = one plan. */
+int dasp_mg_plan_create(dasp_mg_plan_t **mg, int precision, int rowA, int colA, int n_gpus, int rank, const int *row_bounds,
+                        const int *csrRowPtr, const int *csrColIdx, const void *csrVal, const dasp_options_t *opt, int overlap);
+void dasp_mg_destroy(dasp_mg_plan_t *mg);
+/* the plans + the slice / gather buffers + the communication stream, on the CURRENT device */
+int dasp_mg_upload(dasp_mg_plan_t *mg);
+/* ncclCommInitRank(n_gpus, id, rank) on the current device: collective, every rank must call it */
+int dasp_mg_comm_init(dasp_mg_plan_t *mg, const void *id);
+/* x_0: colA host values -> the device layout the products read (synchronises the device) */
+int dasp_mg_set_x(dasp_mg_plan_t *mg, const void *x_host);
+/* one iteration, asynchronous: own-column product | wait for the previous all-gather | other-column product (y +=) on
+ * `stream`, then ncclAllGather(y slice -> gather buffer) on the communication stream behind them.  Square matrices: the
+ * gathered y is the next call's x.  Rectangular: x stays what dasp_mg_set_x stored. */
+int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream);
+/* the products of one iteration only (no exchange): for callers that move dasp_mg_y_local into every rank's
+ * dasp_mg_gathered themselves (tests; transports other than RCCL) */
+int dasp_mg_product(dasp_mg_plan_t *mg, void *stream);
+/* make `stream` wait for the all-gather still in flight (after it, dasp_mg_gathered holds the full y) */
+int dasp_mg_wait(dasp_mg_plan_t *mg, void *stream);
+/* the gathered y without the padding, rowA host values (synchronises the device) */
+int dasp_mg_get_y(dasp_mg_plan_t *mg, void *y_host);
+/* this rank's y slice without the padding, row_end - row_begin host values (synchronises the device) */
+int dasp_mg_get_y_local(dasp_mg_plan_t *mg, void *y_host);
+/* device pointers: this rank's current padded y slice [stride]; the gather buffer [n_gpus * stride]; what the products
+ * read as x (the gather buffer for a square matrix, a colA vector otherwise) */
+void *dasp_mg_y_local(dasp_mg_plan_t *mg);
+void *dasp_mg_gathered(dasp_mg_plan_t *mg);
+void *dasp_mg_x(dasp_mg_plan_t *mg);
+/* BORROWED handle of the rank's plan over its own columns / the whole slice (which = 0) or over the other ranks' columns
+ * (which = 1; NULL if there is none): stats, host arrays, timing */
+dasp_plan_t *dasp_mg_subplan(dasp_mg_plan_t *mg, int which);
+int dasp_mg_info(const dasp_mg_plan_t *mg, dasp_mg_info_t *out);
 
 /* ---------------------------------------------------------------- device self-test
  * known-answer check of the MFMA operand / accumulator lane maps this library relies on
@@ -263,9 +322,13 @@ int dasp_selftest_mfma(void);
  * network on the build/bench machines).  Rows [row_begin,row_end) of the named matrix are
  * generated as CSR (global column ids, file-like order inside a row); every row can be
  * generated independently, so ranks of a multi-GPU run build only their slice.
- *   names: "cop20k_A" "nlpkkt160" "powerlaw_1M" "webbase-1M" "ljournal-2008" "HV15R" "Queen_4147"
+ *   names: "cop20k_A" "nlpkkt160" "powerlaw_1M" "webbase-1M" "ljournal-2008" "HV15R" "Queen_4147" "rmat_2M", and the
+ *          round-1 worst-case variants "webbase-1M-uniform" "ljournal-2008-uniform" (dasp_synth_generator describes each)
  *   scale: 1.0 = the collection's size; <1 shrinks the row count (tests). */
 int dasp_synth_dims(const char *name, double scale, int *rows, int *cols);
+/* one-line description of the generator behind `name` (seed, structure class, locality parameters); NULL for an unknown
+ * name.  Thread-local storage, valid until the next call. */
+const char *dasp_synth_generator(const char *name);
 int dasp_synth_row_lengths(const char *name, double scale, int row_begin, int row_end, int *len_out);
 int dasp_synth_rows(const char *name, double scale, int row_begin, int row_end,
                     const int *row_ptr_local /* [row_end-row_begin+1], exclusive scan of lengths */,

@@ -117,6 +117,20 @@ def test_parity_synthetic_standins(oracle, dasp, torch_cuda, name, prec, scale):
     check(oracle, dasp, torch_cuda, rp, ci, v, cols, prec)
 
 
+@pytest.mark.parametrize("name,prec", [("HV15R", 64), ("ljournal-2008", 16)])
+def test_full_size_random_x_parity(oracle, dasp, torch_cuda, name, prec):
+    """BASELINE's full sizes (scale 1.0): seeded random values and x, >= 100 k sampled rows (the 4096 longest + a uniform sample)
+    against the oracle at the north_star tolerance -- bench.py's verified_random_x, the check the all-ones mode cannot make"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rows, cols = dasp.synth_dims(name, 1.0)
+    rp, ci = dasp.synth_csr(name, 1.0)
+    res = bench.verify_random_x(torch_cuda, dasp, oracle, rp, ci, cols, prec)
+    assert res["ok"] and res["rows_checked"] >= 100000 and res["max_rel_err"] <= TOL[prec], res
+
+
 def test_padded_slots_do_not_read_x0(oracle, dasp, torch_cuda):
     """the reference's padded slots multiply 0 by x[0] (dasp_f64.h:1127-1128): x[0] = inf poisons
     unrelated rows there.  Here pads never touch x."""
@@ -277,8 +291,9 @@ def test_nonfinite_values_stay_in_their_rows(dasp, torch_cuda):
 
 
 def test_bench_rank_setup_assembles_full_y(dasp, torch_cuda):
-    """bench.py's multi-GPU preparation, every rank's part run in turn on one GPU with the all-gather done by hand: partition by
-    nonzeros, per-rank plans over own / other columns, padded slices -> three chained iterations equal to (A_s)^3 x_0"""
+    """bench.py's multi-GPU preparation, every rank's dasp_mg plan stepped in turn on one GPU with the exchange done by hand
+    (dasp_mg_product + dasp_mg_get_y_local / dasp_mg_set_x): partition by nonzeros, per-rank plans over own / other columns,
+    padded slices -> three chained iterations equal to (A_s)^3 x_0"""
     import importlib.util
     import scipy.sparse as sp
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
@@ -286,62 +301,80 @@ def test_bench_rank_setup_assembles_full_y(dasp, torch_cuda):
     spec.loader.exec_module(bench)
     torch = torch_cuda
     world = 3
-    parts = [bench.setup_rank(torch, dasp, "HV15R", 0.02, 64, r, world) for r in range(world)]
-    mps = [P["mp"] for P in parts]
-    stride, bounds, rows = parts[0]["stride"], parts[0]["bounds"], parts[0]["rows"]
-    nnz = [int(P["rp"][-1]) for P in parts]
-    assert max(nnz) - min(nnz) <= 2 * 484                                    # balanced to within a row or two
-    for mp in mps:
-        assert mp.overlap and mp.plan_rem is not None and mp.nnz_local > 5 * mp.nnz_remote > 0     # banded: mostly own columns
-        assert mp.plan.x_len == stride and mp.plan_rem.x_len == world * stride and mp.plan.y_order == dasp.Y_NATURAL
-    rng = np.random.default_rng(4)
-    x0 = rng.uniform(0.5, 1.5, rows)
-    for mp in mps:
-        mp.seed(x0)
-
-    class Done:
-        def wait(self):
-            pass
-    sent = {}
-
-    def make(r):
-        def gather(dst, src):
-            sent[r] = src
-            return Done()
-        return gather
+    rows, _ = dasp.synth_dims("HV15R", 0.02)
     rp_all, ci_all = dasp.synth_csr("HV15R", 0.02)
     lens = np.diff(rp_all)
     A = sp.csr_matrix((np.repeat(0.5 / np.maximum(lens, 1), lens), ci_all, rp_all), shape=(rows, rows))
-    want = x0
-    for it in range(3):
-        for r, mp in enumerate(mps):
-            mp.step(make(r))
-        torch.cuda.synchronize()
-        g = torch.cat([sent[r] for r in range(world)])                       # what all_gather_into_tensor delivers to every rank
-        for mp in mps:
-            mp.gathered.copy_(g)
-        want = A @ want
-        full = mps[it % world].full_y().cpu().numpy()
-        assert np.abs(full - want).max() <= 1e-13 * np.abs(want).max()
-        for r, mp in enumerate(mps):
-            assert torch.equal(mp.y_local, mp.gathered[r * stride: r * stride + mp.rows])
-    # the same three iterations without the own / other split
-    os.environ["DASP_BENCH_OVERLAP"] = "0"
-    try:
-        plain = [bench.setup_rank(torch, dasp, "HV15R", 0.02, 64, r, world)["mp"] for r in range(world)]
-    finally:
-        del os.environ["DASP_BENCH_OVERLAP"]
-    for mp in plain:
-        assert not mp.overlap and mp.plan_rem is None
-        mp.seed(x0)
-    for it in range(3):
-        for r, mp in enumerate(plain):
-            mp.step(make(r))
-        torch.cuda.synchronize()
-        g = torch.cat([sent[r] for r in range(world)])
-        for mp in plain:
-            mp.gathered.copy_(g)
-    assert np.abs(plain[0].full_y().cpu().numpy() - want).max() <= 1e-13 * np.abs(want).max()
+    x0 = np.random.default_rng(4).uniform(0.5, 1.5, rows)
+    for overlap in ("1", "0"):
+        os.environ["DASP_BENCH_OVERLAP"] = overlap
+        try:
+            parts = [bench.setup_rank(torch, dasp, "HV15R", 0.02, 64, r, world) for r in range(world)]
+        finally:
+            del os.environ["DASP_BENCH_OVERLAP"]
+        mgs = [P["mg"] for P in parts]
+        nnz = [int(P["rp"][-1]) for P in parts]
+        assert max(nnz) - min(nnz) <= 2 * 484                                    # balanced to within a row or two
+        for mg in mgs:
+            if overlap == "1":
+                assert mg.overlap and mg.subplan(1) is not None and mg.nnz_local > 5 * mg.nnz_remote > 0     # banded: mostly own columns
+                assert mg.subplan(0).x_len == mg.stride and mg.subplan(1).x_len == world * mg.stride
+            else:
+                assert not mg.overlap and mg.subplan(1) is None and mg.subplan(0).x_len == world * mg.stride
+            mg.set_x(x0)
+        want = x0
+        for it in range(3):
+            for mg in mgs:
+                mg.product(0)
+            full = np.concatenate([mg.get_y_local() for mg in mgs])              # what the all-gather delivers to every rank
+            want = A @ want
+            assert np.abs(full - want).max() <= 1e-13 * np.abs(want).max()
+            for mg in mgs:
+                mg.set_x(full)
+        for mg in mgs:
+            mg.close()
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("square", [True, False])
+def test_mg_spmv_world_size_one_against_the_oracle(oracle, dasp, torch_cuda, prec, square):
+    """dasp_mg_spmv through the C ABI with a real RCCL communicator (ncclCommInitRank / ncclAllGather called by libdasp_amd.so
+    itself) at world size 1 -- all a one-GPU box allows: chained products equal the oracle's, the gathered y is the next x."""
+    from dasp_amd.multi import MgPlan, unique_id
+    m = 3000
+    n = m if square else 2200
+    dt = np.float64 if prec == 64 else np.float16
+    rp, ci, v = util.mixed_matrix(m, n, 21, values="f16" if prec == 16 else "uniform", dtype=dt)
+    if square:                                                        # keep x_t bounded over the chain
+        v = (v.astype(np.float64) / np.maximum(np.repeat(np.diff(rp), np.diff(rp)), 1)).astype(dt)
+    mg = MgPlan(rp, ci, v, m, n, np.array([0, m], np.int32), 0, precision=prec).upload()
+    mg.comm_init(unique_id())
+    assert mg.info["has_comm"] == 1 and mg.info["square"] == int(square)
+    x = (np.random.default_rng(8).uniform(0.5, 1.5, n)).astype(dt)
+    mg.set_x(x)
+    want = x.astype(np.float64)
+    steps = 3 if square else 1
+    for _ in range(steps):
+        mg.spmv(0)
+        ref = oracle.csr_spmv(rp, ci, v.astype(np.float64), want)
+        scale = np.maximum(oracle.csr_absrow(rp, ci, v.astype(np.float64), want), 1e-300)
+        mg.wait(0)
+        got = mg.get_y().astype(np.float64)
+        assert (np.abs(got - ref) <= TOL[prec] * scale).all()
+        np.testing.assert_array_equal(mg.get_y_local().astype(np.float64), got)
+        want = got                                                    # the next product reads exactly what was gathered
+    mg.close()
+
+
+def test_bench_bare_multi_gpu_launch_needs_that_many_devices(torch_cuda):
+    """`python bench.py --gpus 2` without a launcher on a one-GPU box: a clear error and rc 4, not a usage error"""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    assert r.returncode == 4 and "need 2 devices" in r.stderr
 
 
 NNZ_ARRAYS = ("long_val long_cid med_val med_cid med_cid16 med_base irr_val irr_cid short_val short_cid").split()
@@ -469,27 +502,27 @@ def test_power_iteration_example_matches_scipy(dasp, torch_cuda, monkeypatch):
 
 
 def test_bench_multi_rank_flow_on_one_gpu(torch_cuda):
-    """bench.py --gpus 2 end to end (partition, per-rank plans, exchange, max-over-ranks timing, full-y check, JSON line),
-    both ranks sharing this box's single GPU and the all-gather staged through gloo: everything but RCCL itself"""
+    """`python bench.py --gpus 2` end to end, launched bare (bench.py spawns its own two ranks as a child torch.distributed.run
+    job): partition, per-rank dasp_mg plans, exchange, max-over-ranks timing, chained + random-x checks, JSON line -- both ranks
+    sharing this box's single GPU with the y slices moved through host memory: everything but RCCL itself"""
     import json
-    import socket
     import sys
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, DASP_BENCH_SHARE_GPU="1", DASP_BENCH_BACKEND="gloo")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+    env = dict(os.environ, DASP_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
                         "--scale", "0.02"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["verified"] is True and out["scaling"] == "strong" and out["value"] > 0
     assert out["config"]["partition"].startswith("row ranges") and "roofline" in out and "suite" not in out
+    assert out["verified_random_x"]["ok"] is True and out["verified_random_x"]["rows_checked"] > 1000
 
 
 def test_bench_rccl_calls_run_at_world_size_one(torch_cuda):
-    """The exact RCCL sequence of the N > 1 bench (init_process_group("nccl", device_id), all_gather_into_tensor into the x
-    layout, barrier, MAX / MIN all_reduce) on the one GPU of this box: world size 1 is all RCCL allows here (two ranks may not
-    share a device), the partitioned plan + natural-order y + gathered-layout check are the real ones."""
+    """The exact sequence of the N > 1 bench (gloo control plane, unique-id broadcast, dasp_mg_comm_init -> ncclCommInitRank,
+    dasp_mg_spmv -> ncclAllGather into the x layout, barrier, MAX / MIN all_reduce) on the one GPU of this box: world size 1 is
+    all RCCL allows here (two ranks may not share a device), the partitioned plan + natural-order y + gathered-layout check are
+    the real ones."""
     import json
     import socket
     import sys
@@ -501,6 +534,7 @@ def test_bench_rccl_calls_run_at_world_size_one(torch_cuda):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["verified"] is True and out["config"]["partition"].startswith("row ranges")
+    assert out["config"]["exchange"] == "RCCL" and out["verified_random_x"]["ok"] is True
 
 
 @pytest.mark.parametrize("prec", [64, 16])

@@ -1,7 +1,7 @@
-"""N > 1 path on CPU (gloo, world_size 2): row partition by nonzeros, per-rank plans with the
-column remap, all-gather of padded y slices into the layout x is read from.  The local SpMV is
-done by the CPU oracle here (tests may use it; the product path has no CPU fallback) -- what is
-under test is the sharding / exchange logic bench.py uses with RCCL."""
+"""N > 1 path on CPU (gloo, world_size 2): row partition by nonzeros, per-rank dasp_mg plans (C ABI, host part) with the
+own / other column split and the column remap, all-gather of padded y slices into the layout x is read from.  The local
+product is done by decoding the packed plans here (tests may use the oracle; the product path has no CPU fallback) -- what is
+under test is the sharding / exchange layout that dasp_mg_spmv drives with RCCL on the GPUs."""
 import os
 import socket
 import sys
@@ -38,18 +38,25 @@ def _worker(rank, world, port, q):
         stride = (int(np.diff(bounds).max()) + 63) // 64 * 64
         r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
         sl = slice(rp[r0], rp[r1])
-        plan = D.Plan(rp[r0:r1 + 1] - rp[r0], ci[sl], v[sl], n, y_order=D.Y_NATURAL, part_bounds=bounds, part_stride=stride)
+        from dasp_amd.multi import MgPlan
+        mg = MgPlan(rp[r0:r1 + 1] - rp[r0], ci[sl], v[sl], m, n, bounds, rank, overlap=True)
+        assert mg.stride == stride
         # x in the gathered layout; every rank starts from the same x
         x = np.random.default_rng(5).uniform(-1, 1, n)
         xg = np.zeros(world * stride)
         for g in range(world):
             xg[g * stride: g * stride + bounds[g + 1] - bounds[g]] = x[bounds[g]:bounds[g + 1]]
-        # the plan's remapped columns index xg exactly where the global column's x lives
-        rows = util.decode_plan(plan)
-        order = plan.order_rid
+        x_own = xg[rank * stride:(rank + 1) * stride]
+        # own-column plan reads the rank's own slice, other-column plan the gathered layout: y = own + other
         y_local = np.zeros(stride)
-        for slot, (cs, vs) in rows.items():
-            y_local[order[slot]] = float(np.dot(np.asarray(vs, np.float64), xg[np.asarray(cs, np.int64)])) if cs else 0.0
+        for which, xv in ((0, x_own), (1, xg)):
+            sub = mg.subplan(which)
+            if sub is None:
+                continue
+            order = sub.order_rid
+            for slot, (cs, vs) in util.decode_plan(sub).items():
+                if cs:
+                    y_local[order[slot]] += float(np.dot(np.asarray(vs, np.float64), xv[np.asarray(cs, np.int64)]))
         gathered = torch.zeros(world * stride, dtype=torch.float64)
         dist.all_gather_into_tensor(gathered, torch.from_numpy(y_local))
         full = np.concatenate([gathered.numpy()[g * stride: g * stride + bounds[g + 1] - bounds[g]] for g in range(world)])

@@ -217,20 +217,59 @@ def test_serialised_plan_round_trip(dasp, tmp_path, prec):
         dasp.Plan.load(path)
 
 
-def test_split_by_owner_partitions_a_row_slice(dasp):
-    """dasp_amd.multi: the own-column / other-column split behind the overlapped all-gather keeps every entry exactly once."""
-    from dasp_amd.multi import split_by_owner
-    rp, ci, v = util.mixed_matrix(700, 900, 31)
-    lo, hi = 250, 610
-    (rpl, cil, vl), (rpr, cir, vr) = split_by_owner(rp, ci, v, lo, hi)
-    assert cil.size + cir.size == ci.size and rpl[-1] == cil.size and rpr[-1] == cir.size
-    assert cil.min() >= 0 and cil.max() < hi - lo and not ((cir >= lo) & (cir < hi)).any()
-    for r in range(700):
-        own = (ci[rp[r]:rp[r + 1]] >= lo) & (ci[rp[r]:rp[r + 1]] < hi)
-        np.testing.assert_array_equal(cil[rpl[r]:rpl[r + 1]] + lo, ci[rp[r]:rp[r + 1]][own])
-        np.testing.assert_array_equal(vl[rpl[r]:rpl[r + 1]], v[rp[r]:rp[r + 1]][own])
-        np.testing.assert_array_equal(cir[rpr[r]:rpr[r + 1]], ci[rp[r]:rp[r + 1]][~own])
-        np.testing.assert_array_equal(vr[rpr[r]:rpr[r + 1]], v[rp[r]:rp[r + 1]][~own])
+def test_mg_plan_splits_a_row_slice_by_column_owner(dasp):
+    """dasp_mg_plan_create (multigpu.cpp, host part: no GPU needed): the own-column / other-column plans behind the overlapped
+    all-gather hold every entry of the rank's rows exactly once -- own columns re-based to the rank's slice, the others remapped
+    to the padded all-gather layout -- for every rank of a 3-way partition, with and without the split."""
+    from dasp_amd.multi import MgPlan
+    m = n = 900
+    rp, ci, v = util.mixed_matrix(m, n, 31)
+    world = 3
+    bounds = dasp.partition_rows(rp, world)
+    for overlap in (True, False):
+        for rank in range(world):
+            r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+            sl = slice(rp[r0], rp[r1])
+            mg = MgPlan(rp[r0:r1 + 1] - rp[r0], ci[sl], v[sl], m, n, bounds, rank, overlap=overlap)
+            info = mg.info
+            stride = info["stride"]
+            assert stride % 64 == 0 and stride >= np.diff(bounds).max() and info["overlap"] == int(overlap)
+            assert info["nnz_own"] + info["nnz_other"] == rp[r1] - rp[r0]
+            own, oth = mg.subplan(0), mg.subplan(1)
+            assert (oth is not None) == (overlap and info["nnz_other"] > 0)
+            rows_own = util.decode_plan(own)
+            rows_oth = util.decode_plan(oth) if oth is not None else {}
+            o_own = own.order_rid
+            o_oth = oth.order_rid if oth is not None else None
+            by_row = {}
+            for slot, (cs, vs) in rows_own.items():
+                cs = np.asarray(cs, np.int64)
+                glob = cs + r0 if overlap else bounds[cs // stride] + cs % stride       # own slice / gathered layout -> global column
+                by_row.setdefault(int(o_own[slot]), []).extend(zip(glob.tolist(), vs))
+            for slot, (cs, vs) in rows_oth.items():
+                cs = np.asarray(cs, np.int64)
+                glob = bounds[cs // stride] + cs % stride
+                assert not ((glob >= r0) & (glob < r1)).any()
+                by_row.setdefault(int(o_oth[slot]), []).extend(zip(glob.tolist(), vs))
+            for r in range(r1 - r0):
+                want = sorted(zip(ci[rp[r0 + r]:rp[r0 + r + 1]].tolist(), v[rp[r0 + r]:rp[r0 + r + 1]].tolist()))
+                assert sorted(by_row.get(r, [])) == want
+            mg.close()
+
+
+def test_mg_plan_argument_errors(dasp):
+    from dasp_amd.multi import MgPlan
+    rp, ci, v = util.mixed_matrix(100, 100, 3)
+    with pytest.raises(dasp.DaspError):
+        MgPlan(rp, ci, v, 100, 100, np.array([0, 50, 90], np.int32), 0)          # bounds do not reach rowA
+    with pytest.raises(dasp.DaspError):
+        MgPlan(rp, ci, v, 100, 100, np.array([0, 100], np.int32), 1)             # rank out of range
+    with pytest.raises(dasp.DaspError):
+        MgPlan(rp, ci + 1000, v, 100, 100, np.array([0, 100], np.int32), 0)      # column out of range
+    mg = MgPlan(rp, ci, v, 100, 100, np.array([0, 100], np.int32), 0)
+    with pytest.raises(dasp.DaspError) as e:
+        mg.spmv()                                                                # not uploaded
+    assert e.value.status == -22
 
 
 def test_auto_windows_skip_rows_with_adjacent_columns(dasp):
