@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <memory>
 #include <new>
 #include <string>
 #include <sys/stat.h>
@@ -25,6 +27,17 @@ int download_array(Plan &p, const char *name, void *dst, size_t bytes);
 
 using namespace dasp;
 
+// no exception may cross the C ABI (ctypes / cgo / JNI callers would reach std::terminate): every entry point that can
+// allocate runs inside this guard and reports DASP_ERR_NOMEM / DASP_ERR_ENTRY instead
+template <class F>
+static int guarded(const char *what, F f) noexcept
+{
+    try { return f(); }
+    catch (const std::bad_alloc &) { set_error(std::string(what) + ": out of host memory"); return DASP_ERR_NOMEM; }
+    catch (const std::exception &e) { set_error(std::string(what) + ": " + e.what()); return DASP_ERR_ENTRY; }
+    catch (...) { set_error(std::string(what) + ": unknown exception"); return DASP_ERR_ENTRY; }
+}
+
 extern "C" {
 
 const char *dasp_last_error(void) { return last_error_cstr(); }
@@ -44,7 +57,7 @@ int dasp_mmio_allinone_f64(int *m, int *n, int *nnz, int *isSymmetric, int **csr
                            double **csrVal, const char *filename)
 {
     void *v = nullptr;
-    int rc = load_mtx(filename, 64, m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, &v);
+    int rc = guarded("dasp_mmio_allinone_f64", [&] { return load_mtx(filename, 64, m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, &v); });
     if (rc == DASP_OK) *csrVal = static_cast<double *>(v);
     return rc;
 }
@@ -53,7 +66,7 @@ int dasp_mmio_allinone_f16(int *m, int *n, int *nnz, int *isSymmetric, int **csr
                            uint16_t **csrVal, const char *filename)
 {
     void *v = nullptr;
-    int rc = load_mtx(filename, 16, m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, &v);
+    int rc = guarded("dasp_mmio_allinone_f16", [&] { return load_mtx(filename, 16, m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, &v); });
     if (rc == DASP_OK) *csrVal = static_cast<uint16_t *>(v);
     return rc;
 }
@@ -61,13 +74,13 @@ int dasp_mmio_allinone_f16(int *m, int *n, int *nnz, int *isSymmetric, int **csr
 int dasp_csr_save(const char *path, int precision, int m, int n, int nnz, int isSymmetric, const int *csrRowPtr,
                   const int *csrColIdx, const void *csrVal)
 {
-    return save_csr_bin(path, precision, m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, csrVal);
+    return guarded("dasp_csr_save", [&] { return save_csr_bin(path, precision, m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, csrVal); });
 }
 
 int dasp_csr_load(const char *path, int precision, int *m, int *n, int *nnz, int *isSymmetric, int **csrRowPtr,
                   int **csrColIdx, void **csrVal)
 {
-    return load_csr_bin(path, precision, m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, csrVal);
+    return guarded("dasp_csr_load", [&] { return load_csr_bin(path, precision, m, n, nnz, isSymmetric, csrRowPtr, csrColIdx, csrVal); });
 }
 
 // options as the builders expect them: defaults for unset fields, a private, validated copy of the column partition
@@ -98,17 +111,15 @@ int dasp_plan_create(dasp_plan_t **out, int precision, int rowA, int colA, int n
         set_error("dasp_plan_create: bad arguments");
         return DASP_ERR_ARG;
     }
-    dasp_plan *h = new (std::nothrow) dasp_plan();
-    if (!h) return DASP_ERR_NOMEM;
-    Plan &p = h->impl;
-    p.precision = precision; p.m = rowA; p.n = colA; p.nnz = nnzA;
-    if (int rc = normalise_options(p, opt, colA)) { delete h; return rc; }
-    int rc;
-    try { rc = build_plan(p, rp, ci, val); }
-    catch (const std::bad_alloc &) { rc = DASP_ERR_NOMEM; set_error("out of host memory"); }
-    if (rc != DASP_OK) { delete h; return rc; }
-    *out = h;
-    return DASP_OK;
+    return guarded("dasp_plan_create", [&] {
+        std::unique_ptr<dasp_plan> h(new dasp_plan());
+        Plan &p = h->impl;
+        p.precision = precision; p.m = rowA; p.n = colA; p.nnz = nnzA;
+        if (int rc = normalise_options(p, opt, colA)) return rc;
+        if (int rc = build_plan(p, rp, ci, val)) return rc;
+        *out = h.release();
+        return (int)DASP_OK;
+    });
 }
 
 // CSR already on the GPU: row pointer to the host (4(m+1) bytes), every O(rows) decision there, the nonzeros never leave the device
@@ -121,29 +132,27 @@ int dasp_plan_create_device(dasp_plan_t **out, int precision, int rowA, int colA
         set_error("dasp_plan_create_device: bad arguments");
         return DASP_ERR_ARG;
     }
-    std::vector<int> rp((size_t)rowA + 1);
-    if (hipMemcpy(rp.data(), dRowPtr, sizeof(int) * ((size_t)rowA + 1), hipMemcpyDeviceToHost) != hipSuccess) {
-        set_error("cannot read the device row pointer (no HIP device, or not a device pointer)");
-        return DASP_ERR_HIP;
-    }
-    dasp_plan *h = new (std::nothrow) dasp_plan();
-    if (!h) return DASP_ERR_NOMEM;
-    Plan &p = h->impl;
-    p.precision = precision; p.m = rowA; p.n = colA; p.nnz = nnzA;
-    if (int rc = normalise_options(p, opt, colA)) { delete h; return rc; }
-    const DevCsr dev{dRowPtr, dColIdx, dVal};
-    int rc;
-    try { rc = build_plan(p, rp.data(), nullptr, nullptr, &dev); }
-    catch (const std::bad_alloc &) { rc = DASP_ERR_NOMEM; set_error("out of host memory"); }
-    if (rc != DASP_OK) { delete h; return rc; }
-    *out = h;
-    return DASP_OK;
+    return guarded("dasp_plan_create_device", [&] {
+        std::vector<int> rp((size_t)rowA + 1);
+        if (hipMemcpy(rp.data(), dRowPtr, sizeof(int) * ((size_t)rowA + 1), hipMemcpyDeviceToHost) != hipSuccess) {
+            set_error("cannot read the device row pointer (no HIP device, or not a device pointer)");
+            return (int)DASP_ERR_HIP;
+        }
+        std::unique_ptr<dasp_plan> h(new dasp_plan());
+        Plan &p = h->impl;
+        p.precision = precision; p.m = rowA; p.n = colA; p.nnz = nnzA;
+        if (int rc = normalise_options(p, opt, colA)) return rc;
+        const DevCsr dev{dRowPtr, dColIdx, dVal};
+        if (int rc = build_plan(p, rp.data(), nullptr, nullptr, &dev)) return rc;
+        *out = h.release();
+        return (int)DASP_OK;
+    });
 }
 
 int dasp_plan_download_array(dasp_plan_t *plan, const char *name, void *dst, size_t bytes)
 {
     if (!plan || !name || (!dst && bytes)) return DASP_ERR_ARG;
-    return download_array(plan->impl, name, dst, bytes);
+    return guarded("dasp_plan_download_array", [&] { return download_array(plan->impl, name, dst, bytes); });
 }
 
 void dasp_plan_destroy(dasp_plan_t *plan) { delete plan; }
@@ -151,21 +160,19 @@ void dasp_plan_destroy(dasp_plan_t *plan) { delete plan; }
 int dasp_plan_save(dasp_plan_t *plan, const char *path)
 {
     if (!plan) return DASP_ERR_ARG;
-    return save_plan(plan->impl, path);
+    return guarded("dasp_plan_save", [&] { return save_plan(plan->impl, path); });
 }
 
 int dasp_plan_load(dasp_plan_t **out, const char *path)
 {
     if (!out) return DASP_ERR_ARG;
     *out = nullptr;
-    dasp_plan *h = new (std::nothrow) dasp_plan();
-    if (!h) return DASP_ERR_NOMEM;
-    int rc;
-    try { rc = load_plan(h->impl, path); }
-    catch (const std::bad_alloc &) { rc = DASP_ERR_NOMEM; set_error("out of host memory"); }
-    if (rc != DASP_OK) { delete h; return rc; }
-    *out = h;
-    return DASP_OK;
+    return guarded("dasp_plan_load", [&] {
+        std::unique_ptr<dasp_plan> h(new dasp_plan());
+        if (int rc = load_plan(h->impl, path)) return rc;
+        *out = h.release();
+        return (int)DASP_OK;
+    });
 }
 
 const int *dasp_plan_order(const dasp_plan_t *plan) { return plan ? plan->impl.order.data() : nullptr; }
@@ -201,9 +208,15 @@ int dasp_plan_panel_range(const dasp_plan_t *plan, int k, int *col_begin, int *c
     return DASP_OK;
 }
 
+static long long host_array_impl(const dasp_plan_t *plan, const char *name, const void **ptr, int *elem_bytes);
 long long dasp_plan_host_array(const dasp_plan_t *plan, const char *name, const void **ptr, int *elem_bytes)
 {
     if (!plan || !name || !ptr || !elem_bytes) return DASP_ERR_ARG;
+    try { return host_array_impl(plan, name, ptr, elem_bytes); }
+    catch (const std::exception &e) { set_error(std::string("dasp_plan_host_array: ") + e.what()); return DASP_ERR_NOMEM; }
+}
+static long long host_array_impl(const dasp_plan_t *plan, const char *name, const void **ptr, int *elem_bytes)
+{
     const Plan &p = plan->impl;
     // the nnz-sized arrays exist on the host only until dasp_plan_drop_host (never, for a plan packed on the device);
     // the O(rows) arrays and order_rid always do
@@ -258,7 +271,7 @@ long long dasp_plan_host_array(const dasp_plan_t *plan, const char *name, const 
 int dasp_plan_upload(dasp_plan_t *plan)
 {
     if (!plan) return DASP_ERR_ARG;
-    return upload_plan(plan->impl);
+    return guarded("dasp_plan_upload", [&] { return upload_plan(plan->impl); });
 }
 
 int dasp_plan_drop_host(dasp_plan_t *plan)
@@ -297,14 +310,14 @@ int dasp_plan_time(dasp_plan_t *plan, const void *dX, void *dY, void *stream, in
                    double *event_ms)
 {
     if (!plan || iters <= 0 || warmup < 0) return DASP_ERR_ARG;
-    return time_spmv(plan->impl, dX, dY, stream, warmup, iters, wall_ms, event_ms);
+    return guarded("dasp_plan_time", [&] { return time_spmv(plan->impl, dX, dY, stream, warmup, iters, wall_ms, event_ms); });
 }
 
 int dasp_plan_time_graph(dasp_plan_t *plan, const void *dX, void *dY, void *stream, int warmup, int iters, int batch,
                          double *wall_ms, double *event_ms)
 {
     if (!plan || iters <= 0 || warmup < 0 || batch <= 0) return DASP_ERR_ARG;
-    return time_spmv_graph(plan->impl, dX, dY, stream, warmup, iters, batch, wall_ms, event_ms);
+    return guarded("dasp_plan_time_graph", [&] { return time_spmv_graph(plan->impl, dX, dY, stream, warmup, iters, batch, wall_ms, event_ms); });
 }
 
 int dasp_selftest_mfma(void) { return selftest_mfma(); }
@@ -405,8 +418,9 @@ int dasp_spmv_all_f64(const char *filename, const double *csrValA, const int *cs
                       double threshold, int block_longest)
 {
     (void)NUM;
-    return spmv_all_impl(64, filename, csrValA, csrRowPtrA, csrColIdxA, X_val, Y_val, order_rid, rowA, colA, nnzA, threshold,
-                         block_longest);
+    return guarded("dasp_spmv_all_f64", [&] {
+        return spmv_all_impl(64, filename, csrValA, csrRowPtrA, csrColIdxA, X_val, Y_val, order_rid, rowA, colA, nnzA, threshold, block_longest);
+    });
 }
 
 int dasp_spmv_all_f16(const char *filename, const uint16_t *csrValA, const int *csrRowPtrA, const int *csrColIdxA,
@@ -414,8 +428,9 @@ int dasp_spmv_all_f16(const char *filename, const uint16_t *csrValA, const int *
                       double threshold, int block_longest)
 {
     (void)NUM;
-    return spmv_all_impl(16, filename, csrValA, csrRowPtrA, csrColIdxA, X_val, Y_val, order_rid, rowA, colA, nnzA, threshold,
-                         block_longest);
+    return guarded("dasp_spmv_all_f16", [&] {
+        return spmv_all_impl(16, filename, csrValA, csrRowPtrA, csrColIdxA, X_val, Y_val, order_rid, rowA, colA, nnzA, threshold, block_longest);
+    });
 }
 
 }  // extern "C"

@@ -3,6 +3,7 @@
 //   dasp_bench <workload> [scale=1] [precision=64] [iters=200] [warmup=20] [threshold=0.75] [long_piece=0] [x_window=0] [row_window=0] [cid16=0]
 #include <hip/hip_runtime_api.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -10,6 +11,8 @@
 #include <vector>
 
 #include "../../include/dasp_amd.h"
+
+static int s_panels(dasp_plan_t *p) { return dasp_plan_panel_count(p); }
 
 #define CHECK(x) do { int rc_ = (x); if (rc_ != 0) { std::fprintf(stderr, "%s failed: %d (%s)\n", #x, rc_, dasp_last_error()); return 1; } } while (0)
 
@@ -65,6 +68,16 @@ int main(int argc, char **argv)
     long long bad = 0;
     if (prec == 64)
         for (int i = 0; i < rows; ++i) bad += reinterpret_cast<double *>(y.data())[i] != (double)(rp[order[i] + 1] - rp[order[i]]);
+    else   // binary16 result: exact up to 2048, then within f16 rounding (1e-2 relative covers column panels too), +inf past 65504
+        for (int i = 0; i < rows; ++i) {
+            const uint16_t h = reinterpret_cast<uint16_t *>(y.data())[i];
+            const int e = (h >> 10) & 31, f = h & 1023;
+            const double got = (h >> 15) ? -1.0 : (e == 0 ? std::ldexp((double)f, -24) : (e == 31 ? (f ? NAN : INFINITY) : std::ldexp((double)(f | 1024), e - 25)));
+            const double want = (double)(rp[order[i] + 1] - rp[order[i]]);
+            const bool ok = want > 65504.0 ? (std::isinf(got) || std::fabs(got - want) <= 1e-2 * want)
+                                           : (want <= 2048.0 && s_panels(plan) == 0 ? got == want : std::fabs(got - want) <= 1e-2 * (want > 1 ? want : 1));
+            bad += !ok;
+        }
     dasp_stats_t s;
     dasp_plan_stats(plan, &s);
     // the same plan packed on the GPU from a device-resident CSR (dasp_plan_create_device): preprocessing time only

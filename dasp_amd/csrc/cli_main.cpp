@@ -4,11 +4,13 @@
 // The reference's comparator is cuSPARSE and its verify call is commented out (main_f64.cu:157);
 // here the comparator is a serial CSR loop on the host and the check is on, through order_rid,
 // with the reference's absolute tolerances (1e-5 f64, 1.0 f16: main_f64.cu:8, main_f16.cu:10).
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <sys/stat.h>
 #include <vector>
 
 #include "../../include/dasp_amd.h"
@@ -60,12 +62,33 @@ int main(int argc, char **argv)
     const long long data_origin1 = (long long)(nnzA + colA + rowA) * (long long)sizeof(val_t) + (long long)nnzA * 4 + (long long)(rowA + 1) * 4;
     rc = SPMV(filename, val, rpt, cid, X.data(), Y.data(), order.data(), rowA, colA, nnzA, 4, 0.75, 256);
     if (rc != 0) { std::fprintf(stderr, "%s: spmv_all failed (status %d: %s)\n", kName, rc, dasp_last_error()); return 2; }
-    // host CSR comparator (the reference has cuSPARSE here)
+    // host CSR comparator (the reference has cuSPARSE here): its time fills the comparator columns of the CSV record
+    std::vector<double> ycsr((size_t)rowA);
+    const auto c0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < rowA; ++r) {
+        double s = 0;
+        for (int j = rpt[r]; j < rpt[r + 1]; ++j) s += to_d(val[j]) * to_d(X[cid[j]]);
+        ycsr[(size_t)r] = s;
+    }
+    const double cmp_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
+    {   // the reference's main() completes the record that spmv_all left open (main_f64.cu:151-153: data_origin1, cu_time,
+        // cu_gflops, cu_bandwidth1, cu_bandwidth2; main_f16.cu:148-150 adds pre_time in front of cu_time) -- newline included
+        struct stat st;
+        if (stat("data", &st) == 0 && S_ISDIR(st.st_mode)) {
+            FILE *fo = std::fopen(sizeof(val_t) == 8 ? "data/spmv_f64_record.csv" : "data/spmv_f16_record.csv", "a");
+            if (fo) {
+                const long long data_origin2 = (long long)(nnzA + nnzA + rowA) * (long long)sizeof(val_t) + (long long)nnzA * 4 + (long long)(rowA + 1) * 4;
+                const double t = cmp_ms > 0 ? cmp_ms : 1e-9, gf = 2.0 * nnzA / (t * 1e6), b1 = (double)data_origin1 / (t * 1e6), b2 = (double)data_origin2 / (t * 1e6);
+                if (sizeof(val_t) == 8) std::fprintf(fo, "%lld,%lf,%lf,%lf,%lf\n", data_origin1, t, gf, b1, b2);
+                else std::fprintf(fo, "%lld,%lf,%lf,%lf,%lf,%lf\n", data_origin1, 0.0, t, gf, b1, b2);
+                std::fclose(fo);
+            }
+        }
+    }
     int bad = 0;
     for (int i = 0; i < rowA && !bad; ++i) {
         const int r = order[i];
-        double s = 0;
-        for (int j = rpt[r]; j < rpt[r + 1]; ++j) s += to_d(val[j]) * to_d(X[cid[j]]);
+        const double s = ycsr[(size_t)r];
         if (std::fabs(s - to_d(Y[i])) > kTol) {
             std::printf("error in (%d), csr(%4.2f), dasp(%4.2f),please check your code!\n", i, s, to_d(Y[i]));
             bad = 1;

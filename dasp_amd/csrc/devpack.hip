@@ -6,6 +6,7 @@
 // the same bytes plan.cpp's host packers produce (tests compare them bit for bit).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -202,6 +203,18 @@ struct DevVec {
     ~DevVec() { if (d) (void)hipFree(d); }
 };
 
+// uninitialised device scratch of n elements, freed on scope exit
+template <class U>
+struct DevBuf {
+    U *d = nullptr;
+    int init(size_t n)
+    {
+        if (hipMalloc(&d, std::max<size_t>(n, 1) * sizeof(U)) != hipSuccess) { d = nullptr; set_error("hipMalloc (device packing scratch)"); return DASP_ERR_HIP; }
+        return DASP_OK;
+    }
+    ~DevBuf() { if (d) (void)hipFree(d); }
+};
+
 struct RemapHolder {
     DevVec<int> bounds;
     RemapDev r{nullptr, 0, 0};
@@ -221,14 +234,14 @@ inline int waves_grid(int units) { return (units + 3) / 4; }   // 4 waves per 25
 int devpack_validate(const Plan &p, const DevCsr &d)
 {
     if (p.nnz == 0) return DASP_OK;
-    int *bad = nullptr, h = 0;
-    HIP_TRYP(hipMalloc(&bad, sizeof(int)));
-    HIP_TRYP(hipMemset(bad, 0, sizeof(int)));
-    hipLaunchKernelGGL(k_validate, dim3(2048), dim3(256), 0, 0, d.ci, (long long)p.nnz, p.n, bad);
-    hipError_t e = hipMemcpy(&h, bad, sizeof(int), hipMemcpyDeviceToHost);
-    (void)hipFree(bad);
-    HIP_TRYP(e);
-    return h ? DASP_ERR_ARG : DASP_OK;
+    DevBuf<int> bad; if (int rc = bad.init(1)) return rc;
+    int h = 0;
+    HIP_TRYP(hipMemset(bad.d, 0, sizeof(int)));
+    hipLaunchKernelGGL(k_validate, dim3(2048), dim3(256), 0, 0, d.ci, (long long)p.nnz, p.n, bad.d);
+    HIP_TRYP(hipGetLastError());            // a failed launch would leave `bad` at 0 and wave every id through
+    HIP_TRYP(hipMemcpy(&h, bad.d, sizeof(int), hipMemcpyDeviceToHost));
+    if (h) { set_error("column index out of range"); return DASP_ERR_ARG; }
+    return DASP_OK;
 }
 
 int devpack_window_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridW, int R, int *lo, int *hi, long long *wnnz)
@@ -237,15 +250,14 @@ int devpack_window_spans(const Plan &p, const DevCsr &d, const std::vector<int> 
     if (nW == 0) return DASP_OK;
     RemapHolder rm; if (int rc = rm.init(p)) return rc;
     DevVec<int> dr; if (int rc = dr.init(ridW)) return rc;
-    int *dlo = nullptr; long long *dn = nullptr;
-    HIP_TRYP(hipMalloc(&dlo, sizeof(int) * 2 * (size_t)nW));
-    HIP_TRYP(hipMalloc(&dn, sizeof(long long) * (size_t)nW));
-    hipLaunchKernelGGL(k_window_spans, dim3(waves_grid(nW)), dim3(256), 0, 0, d.rp, d.ci, dr.d, nmed, R, rm.r, dlo, dlo + nW, dn, nW);
-    hipError_t e1 = hipMemcpy(lo, dlo, sizeof(int) * (size_t)nW, hipMemcpyDeviceToHost);
-    hipError_t e2 = hipMemcpy(hi, dlo + nW, sizeof(int) * (size_t)nW, hipMemcpyDeviceToHost);
-    hipError_t e3 = hipMemcpy(wnnz, dn, sizeof(long long) * (size_t)nW, hipMemcpyDeviceToHost);
-    (void)hipFree(dlo); (void)hipFree(dn);
-    HIP_TRYP(e1); HIP_TRYP(e2); HIP_TRYP(e3);
+    DevBuf<int> dlo; DevBuf<long long> dn;
+    if (int rc = dlo.init(2 * (size_t)nW)) return rc;
+    if (int rc = dn.init((size_t)nW)) return rc;
+    hipLaunchKernelGGL(k_window_spans, dim3(waves_grid(nW)), dim3(256), 0, 0, d.rp, d.ci, dr.d, nmed, R, rm.r, dlo.d, dlo.d + nW, dn.d, nW);
+    HIP_TRYP(hipGetLastError());
+    HIP_TRYP(hipMemcpy(lo, dlo.d, sizeof(int) * (size_t)nW, hipMemcpyDeviceToHost));
+    HIP_TRYP(hipMemcpy(hi, dlo.d + nW, sizeof(int) * (size_t)nW, hipMemcpyDeviceToHost));
+    HIP_TRYP(hipMemcpy(wnnz, dn.d, sizeof(long long) * (size_t)nW, hipMemcpyDeviceToHost));
     return DASP_OK;
 }
 
@@ -255,14 +267,13 @@ int devpack_line_scatter(const Plan &p, const DevCsr &d, const std::vector<int> 
     if (rows.empty()) return DASP_OK;
     RemapHolder rm; if (int rc = rm.init(p)) return rc;
     DevVec<int> dr; if (int rc = dr.init(rows)) return rc;
-    unsigned long long *dout = nullptr, h[2] = {0, 0};
-    HIP_TRYP(hipMalloc(&dout, sizeof h));
-    hipError_t e0 = hipMemset(dout, 0, sizeof h);
+    unsigned long long h[2] = {0, 0};
+    DevBuf<unsigned long long> dout; if (int rc = dout.init(2)) return rc;
+    HIP_TRYP(hipMemset(dout.d, 0, sizeof h));
     const int n = (int)rows.size();
-    hipLaunchKernelGGL(k_line_scatter, dim3((n + 255) / 256), dim3(256), 0, 0, d.rp, d.ci, dr.d, n, p.geo.vbytes == 8 ? 4 : 6, rm.r, dout);
-    hipError_t e1 = hipMemcpy(h, dout, sizeof h, hipMemcpyDeviceToHost);
-    (void)hipFree(dout);
-    HIP_TRYP(e0); HIP_TRYP(e1);
+    hipLaunchKernelGGL(k_line_scatter, dim3((n + 255) / 256), dim3(256), 0, 0, d.rp, d.ci, dr.d, n, p.geo.vbytes == 8 ? 4 : 6, rm.r, dout.d);
+    HIP_TRYP(hipGetLastError());
+    HIP_TRYP(hipMemcpy(h, dout.d, sizeof h, hipMemcpyDeviceToHost));
     *lines = (long long)h[0]; *entries = (long long)h[1];
     return DASP_OK;
 }
@@ -274,13 +285,12 @@ int devpack_row_coherence(const Plan &p, const DevCsr &d, const std::vector<int>
     if (npairs == 0) return DASP_OK;
     RemapHolder rm; if (int rc = rm.init(p)) return rc;
     DevVec<int> dr; if (int rc = dr.init(rows)) return rc;
-    unsigned long long *dout = nullptr, h[2] = {0, 0};
-    HIP_TRYP(hipMalloc(&dout, sizeof h));
-    hipError_t e0 = hipMemset(dout, 0, sizeof h);
-    hipLaunchKernelGGL(k_row_coherence, dim3((npairs + 255) / 256), dim3(256), 0, 0, d.rp, d.ci, dr.d, npairs, rm.r, dout);
-    hipError_t e1 = hipMemcpy(h, dout, sizeof h, hipMemcpyDeviceToHost);
-    (void)hipFree(dout);
-    HIP_TRYP(e0); HIP_TRYP(e1);
+    unsigned long long h[2] = {0, 0};
+    DevBuf<unsigned long long> dout; if (int rc = dout.init(2)) return rc;
+    HIP_TRYP(hipMemset(dout.d, 0, sizeof h));
+    hipLaunchKernelGGL(k_row_coherence, dim3((npairs + 255) / 256), dim3(256), 0, 0, d.rp, d.ci, dr.d, npairs, rm.r, dout.d);
+    HIP_TRYP(hipGetLastError());
+    HIP_TRYP(hipMemcpy(h, dout.d, sizeof h, hipMemcpyDeviceToHost));
     *near = (long long)h[0]; *entries = (long long)h[1];
     return DASP_OK;
 }
@@ -295,15 +305,13 @@ int devpack_chunk_spans(const Plan &p, const DevCsr &d, const std::vector<int> &
     if (int rc = dr.init(ridM)) return rc;
     if (int rc = dl.init(lenM)) return rc;
     if (int rc = dk.init(nchunks)) return rc;
-    int *dout = nullptr;
-    HIP_TRYP(hipMalloc(&dout, sizeof(int) * (size_t)nb));
+    DevBuf<int> dout; if (int rc = dout.init((size_t)nb)) return rc;
     if (p.precision == 64)
-        hipLaunchKernelGGL((k_chunk_spans<4>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, dr.d, dl.d, dk.d, nmed, nb, rm.r, dout);
+        hipLaunchKernelGGL((k_chunk_spans<4>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, dr.d, dl.d, dk.d, nmed, nb, rm.r, dout.d);
     else
-        hipLaunchKernelGGL((k_chunk_spans<16>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, dr.d, dl.d, dk.d, nmed, nb, rm.r, dout);
-    hipError_t e = hipMemcpy(k16, dout, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost);
-    (void)hipFree(dout);
-    HIP_TRYP(e);
+        hipLaunchKernelGGL((k_chunk_spans<16>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, dr.d, dl.d, dk.d, nmed, nb, rm.r, dout.d);
+    HIP_TRYP(hipGetLastError());
+    HIP_TRYP(hipMemcpy(k16, dout.d, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost));
     return DASP_OK;
 }
 
@@ -321,6 +329,7 @@ static int pack_all_typed(Plan &p, const DevCsr &d, const PackMeta &m)
         if (int rc = ds.init(*m.startL)) return rc;
         hipLaunchKernelGGL((k_pack_long<T>), dim3(waves_grid(nlong)), dim3(256), 0, 0, d.rp, d.ci, val, dr.d, ds.d, nlong, rm.r,
                            reinterpret_cast<T *>(base + dp.map.long_val), reinterpret_cast<int *>(base + dp.map.long_cid));
+        HIP_TRYP(hipGetLastError());
         HIP_TRYP(hipDeviceSynchronize());
     }
     if (nb > 0) {
@@ -337,6 +346,7 @@ static int pack_all_typed(Plan &p, const DevCsr &d, const PackMeta &m)
         else
             hipLaunchKernelGGL((k_pack_medium<T, false>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, val, dr.d, dl.d, dp.args.med_ptr,
                                dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic);
+        HIP_TRYP(hipGetLastError());
         HIP_TRYP(hipDeviceSynchronize());
     }
     for (int g = 0; g < kNumShortGroups; ++g) {
@@ -348,6 +358,7 @@ static int pack_all_typed(Plan &p, const DevCsr &d, const PackMeta &m)
         hipLaunchKernelGGL((k_pack_short<T>), dim3((unsigned)std::min<long long>((n + 255) / 256, 65535)), dim3(256), 0, 0, d.rp, d.ci, val,
                            dl.d, G.count, G.tiles, G.len, G.elem_off, p.geo.short_rows, rm.r,
                            reinterpret_cast<T *>(base + dp.map.short_val), reinterpret_cast<int *>(base + dp.map.short_cid));
+        HIP_TRYP(hipGetLastError());
         HIP_TRYP(hipDeviceSynchronize());
     }
     HIP_TRYP(hipGetLastError());

@@ -354,12 +354,22 @@ void par_rows(int r0, int r1, F f)
 
 using namespace dasp;
 
+template <class F>
+static int synth_guard(F f) noexcept
+{
+    try { return f(); }
+    catch (const std::bad_alloc &) { set_error("synthetic generator: out of host memory"); return DASP_ERR_NOMEM; }
+    catch (const std::exception &e) { set_error(std::string("synthetic generator: ") + e.what()); return DASP_ERR_ARG; }
+}
+
 extern "C" int dasp_synth_dims(const char *name, double scale, int *rows, int *cols)
 {
-    Synth g;
-    if (!make(name, scale, g) || !rows || !cols) { set_error("unknown synthetic matrix name"); return DASP_ERR_ARG; }
-    *rows = g.rows; *cols = g.cols;
-    return DASP_OK;
+    return synth_guard([&] {
+        Synth g;
+        if (!make(name, scale, g) || !rows || !cols) { set_error("unknown synthetic matrix name"); return (int)DASP_ERR_ARG; }
+        *rows = g.rows; *cols = g.cols;
+        return (int)DASP_OK;
+    });
 }
 
 extern "C" const char *dasp_synth_generator(const char *name)
@@ -373,24 +383,28 @@ extern "C" const char *dasp_synth_generator(const char *name)
 
 extern "C" int dasp_synth_row_lengths(const char *name, double scale, int row_begin, int row_end, int *len_out)
 {
-    Synth g;
-    if (!make(name, scale, g) || !len_out || row_begin < 0 || row_end > g.rows || row_begin > row_end) {
-        set_error("bad arguments to dasp_synth_row_lengths"); return DASP_ERR_ARG;
-    }
-    std::vector<float> tg; int tg0;
-    band_cache(g, row_begin, row_end, tg, tg0);
-    par_rows(row_begin, row_end, [&](int r) { len_out[r - row_begin] = any_row(g, r, nullptr, tg.data(), tg0); });
-    return DASP_OK;
+    return synth_guard([&] {
+        Synth g;
+        if (!make(name, scale, g) || !len_out || row_begin < 0 || row_end > g.rows || row_begin > row_end) {
+            set_error("bad arguments to dasp_synth_row_lengths"); return (int)DASP_ERR_ARG;
+        }
+        std::vector<float> tg; int tg0;
+        band_cache(g, row_begin, row_end, tg, tg0);
+        par_rows(row_begin, row_end, [&](int r) { len_out[r - row_begin] = any_row(g, r, nullptr, tg.data(), tg0); });
+        return (int)DASP_OK;
+    });
 }
 
 extern "C" int dasp_synth_rows(const char *name, double scale, int row_begin, int row_end, const int *rp, int *col_idx_out)
 {
-    Synth g;
-    if (!make(name, scale, g) || !rp || !col_idx_out || row_begin < 0 || row_end > g.rows || row_begin > row_end) {
-        set_error("bad arguments to dasp_synth_rows"); return DASP_ERR_ARG;
-    }
-    std::vector<float> tg; int tg0;
-    band_cache(g, row_begin, row_end, tg, tg0);
-    par_rows(row_begin, row_end, [&](int r) { any_row(g, r, col_idx_out + rp[r - row_begin], tg.data(), tg0); });
-    return DASP_OK;
+    return synth_guard([&] {
+        Synth g;
+        if (!make(name, scale, g) || !rp || !col_idx_out || row_begin < 0 || row_end > g.rows || row_begin > row_end) {
+            set_error("bad arguments to dasp_synth_rows"); return (int)DASP_ERR_ARG;
+        }
+        std::vector<float> tg; int tg0;
+        band_cache(g, row_begin, row_end, tg, tg0);
+        par_rows(row_begin, row_end, [&](int r) { any_row(g, r, col_idx_out + rp[r - row_begin], tg.data(), tg0); });
+        return (int)DASP_OK;
+    });
 }

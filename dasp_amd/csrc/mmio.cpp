@@ -95,8 +95,8 @@ void lower(std::string &s) { for (auto &ch : s) ch = (char)std::tolower((unsigne
 // (mmio_highlevel.h:702-756), parallel over row ranges: every thread streams over all entries but only
 // counts / places those whose row -- or mirrored row -- it owns, so the order inside a row stays file order.
 template <class T>
-int finish(int M, int N, int nz, bool sym, const std::vector<int> &ri, const std::vector<int> &cj,
-           const std::vector<double> &vv, int *m, int *n, int *nnz, int *symflag, int **rp_out, int **ci_out, void **val_out)
+int finish(int M, int N, int nz, bool sym, const raw_vector<int> &ri, const raw_vector<int> &cj,
+           const raw_vector<double> &vv, int *m, int *n, int *nnz, int *symflag, int **rp_out, int **ci_out, void **val_out)
 {
     int nthreads = nz < (1 << 20) ? 1 : resolve_threads(0);
     nthreads = std::min(nthreads, std::max(1, M));
@@ -204,8 +204,6 @@ int load_mtx(const char *path, int precision, int *m, int *n, int *nnz, int *sym
     // (fscanf semantics: an entry may span lines), tpe tokens per entry.  Parsed in parallel: the buffer is cut at
     // token boundaries, tokens are counted per piece, and with the prefix sums every piece knows which
     // (entry, field) each of its tokens is.
-    std::vector<int> ri((size_t)nz), cj((size_t)nz);
-    std::vector<double> vv((size_t)nz);
     const int tpe = is_pattern ? 2 : (is_complex ? 4 : 3);
     const long long need = (long long)nz * tpe;
     c.skip_ws();
@@ -242,6 +240,12 @@ int load_mtx(const char *path, int precision, int *m, int *n, int *nnz, int *sym
     if (ntok[nthreads] < need) {
         set_error("entry " + std::to_string(ntok[nthreads] / tpe + 1) + ": malformed or missing"); return DASP_ERR_ENTRY;
     }
+    // only now (the file is known to hold nz entries, so nz <= bytes / 4) are the nz-sized arrays allocated: a size line
+    // promising 2 G entries in a 30-byte file never reaches an allocation.  Not zero-filled: every slot is parsed into.
+    raw_vector<int> ri, cj;
+    raw_vector<double> vv;
+    try { ri.resize((size_t)nz); cj.resize((size_t)nz); vv.resize((size_t)nz); }
+    catch (const std::bad_alloc &) { set_error("out of host memory"); return DASP_ERR_NOMEM; }
     std::vector<long long> bad_entry((size_t)nthreads, -1);
     std::vector<int> bad_kind((size_t)nthreads, 0);
     auto parse_piece = [&](int t) {

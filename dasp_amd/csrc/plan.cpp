@@ -94,7 +94,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             for (long long i = b; i < e; ++i) if (rp[i + 1] < rp[i]) { bad = 1; return; }
         });
         const int ncol = p.n;
-        if (dev) { if (!bad && devpack_validate(p, *dev) != DASP_OK) bad = 2; }
+        if (dev) { if (!bad) { const int rc = devpack_validate(p, *dev); if (rc == DASP_ERR_ARG) bad = 2; else if (rc != DASP_OK) return rc; } }   // a HIP failure is not "bad column"
         else parallel_for(nnz, threads, 1 << 18, [&](long long b, long long e) {
             for (long long i = b; i < e; ++i) if ((unsigned)ci[i] >= (unsigned)ncol) { bad = 2; return; }
         });

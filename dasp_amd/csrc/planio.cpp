@@ -1,18 +1,24 @@
 // planio.cpp -- serialised plans (the reference never stores its packed format).
 // A plan file holds every host array of a Plan, so a later run (or every rank of a multi-GPU job)
 // skips classification and packing: load -> upload -> spmv.
-// layout: "DASPPLN3" | plan, where plan = int32 precision, m, n, nnz, y_order, windowed, row_window, lds_bytes, cid16, n_parts,
-//         part_stride, stream_policy, n_panels, n_mfma_rows | dasp_stats_t | ShortGroup[5] | for each array, in a fixed order: int64 byte
-//         count + bytes | the n_panels column panels, each a nested plan
+// layout: "DASPPLN4" | int32 sizeof(dasp_stats_t), kNumShortGroups, sizeof(ShortGroup) | plan, where plan = int32 precision, m, n, nnz,
+//         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows | dasp_stats_t |
+//         ShortGroup[kNumShortGroups] | for each array, in a fixed order: int64 byte count + bytes | the n_panels column panels, each
+//         a nested plan.
+// A file is not trusted more than a caller's CSR: after reading, every count, pointer array and column id the kernels index
+// with is re-derived and checked (validate_plan), because upload_plan / the kernels would otherwise turn a stale or corrupt
+// file into wild host, device or LDS accesses.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <string>
 
 #include "plan.hpp"
 
 namespace dasp {
 
 namespace {
-const char kPlanMagic[8] = {'D', 'A', 'S', 'P', 'P', 'L', 'N', '3'};
+const char kPlanMagic[8] = {'D', 'A', 'S', 'P', 'P', 'L', 'N', '4'};
 
 struct Writer {
     FILE *f; bool ok = true;
@@ -20,12 +26,17 @@ struct Writer {
     template <class V> void vec(const V &v) { long long b = (long long)(v.size() * sizeof(typename V::value_type)); raw(&b, 8); raw(v.data(), (size_t)b); }
 };
 struct Reader {
-    FILE *f; bool ok = true;
-    void raw(void *p, size_t n) { if (ok && n && std::fread(p, 1, n, f) != n) ok = false; }
+    FILE *f; long long left; bool ok = true;      // left: bytes of the file not yet consumed -- no array may claim more
+    void raw(void *p, size_t n)
+    {
+        if (!ok || !n) return;
+        if ((long long)n > left || std::fread(p, 1, n, f) != n) { ok = false; return; }
+        left -= (long long)n;
+    }
     template <class V> void vec(V &v)
     {
         long long b = -1; raw(&b, 8);
-        if (!ok || b < 0 || b % (long long)sizeof(typename V::value_type)) { ok = false; return; }
+        if (!ok || b < 0 || b > left || b % (long long)sizeof(typename V::value_type)) { ok = false; return; }
         v.resize((size_t)b / sizeof(typename V::value_type));
         raw(v.data(), (size_t)b);
     }
@@ -42,6 +53,108 @@ template <class IO> void arrays(IO &io, Plan &p)
 }
 }  // namespace
 
+// Everything upload_plan and the kernels rely on, re-derived from the arrays themselves.  `why` names the first violation.
+static bool validate_plan(const Plan &p, int n_panels, std::string &why)
+{
+    auto fail = [&](const char *w) { why = w; return false; };
+    const Geometry geo = p.geo;
+    const long long vb = geo.vbytes, CH = geo.chunk, SR = geo.short_rows;
+    const long long m = p.m;
+    if (p.m < 0 || p.n < 0 || p.nnz < 0) return fail("negative dimension");
+    if (p.opt.y_order != DASP_Y_PERMUTED && p.opt.y_order != DASP_Y_NATURAL) return fail("y_order");
+    if (p.opt.n_parts < 0 || p.opt.n_parts > (1 << 20) || (p.opt.n_parts > 0 && p.opt.part_stride <= 0)) return fail("column partition");
+    if (p.opt.n_parts > 0) {
+        if (p.part_bounds.size() != (size_t)p.opt.n_parts + 1 || p.part_bounds.front() != 0 || p.part_bounds.back() != p.n) return fail("part_bounds size / span");
+        for (int g = 0; g < p.opt.n_parts; ++g)
+            if (p.part_bounds[g + 1] < p.part_bounds[g] || p.part_bounds[g + 1] - p.part_bounds[g] > p.opt.part_stride) return fail("part_bounds not monotone or wider than part_stride");
+    } else if (!p.part_bounds.empty()) return fail("part_bounds without n_parts");
+    const long long xlen = p.opt.n_parts > 0 ? (long long)p.opt.n_parts * p.opt.part_stride : (long long)p.n;
+    if (xlen >= (1ll << 31)) return fail("x length");
+    if (p.order.size() != (size_t)m) return fail("order size");
+    for (int v : p.order) if ((unsigned)v >= (unsigned)m) return fail("order_rid entry out of range");
+    if (!p.dst_map.empty()) {
+        if (p.dst_map.size() != (size_t)m) return fail("dst_map size");
+        for (int v : p.dst_map) if ((unsigned)v >= (unsigned)m) return fail("dst_map entry out of range");
+    }
+    if (p.stats.rowA != p.m || p.stats.colA != p.n || p.stats.nnzA != p.nnz || p.stats.precision != p.precision) return fail("stats header");
+    if (p.stats.row_long < 0 || p.n_mfma_rows < 0 || p.n_mfma_rows > p.stats.row_block || (long long)p.stats.row_long + p.stats.row_block > m) return fail("category counters");
+    if (p.panel_bounds.size() != 2 * (size_t)n_panels) return fail("panel_bounds size");
+    if (n_panels > 0) {   // a panel parent keeps order + stats only
+        if (p.cnt_long || p.cnt_reg || p.cnt_irr || p.cnt_short || !p.med_ptr.empty() || !p.irr_ptr.empty() || !p.piece_ptr.empty()) return fail("panel parent holds packed arrays");
+        for (int k = 0; k < n_panels; ++k)
+            if (p.panel_bounds[2 * k] < 0 || p.panel_bounds[2 * k + 1] < p.panel_bounds[2 * k] || p.panel_bounds[2 * k + 1] > xlen) return fail("panel_bounds range");
+        return true;
+    }
+    auto cid_ok = [&](const raw_vector<int> &c) { for (int v : c) if (v < -1 || v >= xlen) return false; return true; };
+    auto mono = [](const std::vector<int> &a) { if (a.empty() || a[0] != 0) return false; for (size_t i = 1; i < a.size(); ++i) if (a[i] < a[i - 1]) return false; return true; };
+    // ---- long rows
+    if (p.long_val.size() != p.cnt_long * (size_t)vb || p.long_cid.size() != p.cnt_long) return fail("long arrays");
+    if (p.piece_ptr.size() != p.piece_dst.size() + 1 || !mono(p.piece_ptr) || (size_t)p.piece_ptr.back() != p.cnt_long) return fail("piece_ptr");
+    if (p.multi_ptr.size() != p.multi_dst.size() + 1 || !mono(p.multi_ptr)) return fail("multi_ptr");
+    const long long n_partial = p.multi_ptr.back();
+    for (int d : p.piece_dst) if (d >= 0 ? d >= m : (long long)~d >= n_partial) return fail("piece_dst out of range");
+    for (int d : p.multi_dst) if ((unsigned)d >= (unsigned)m) return fail("multi_dst out of range");
+    for (size_t i = 0; i + 1 < p.piece_ptr.size(); ++i) if (p.piece_ptr[i] % kLongAlign) return fail("piece_ptr alignment");
+    if (!cid_ok(p.long_cid)) return fail("long_cid out of range");
+    // ---- medium rows
+    const long long nb = (p.n_mfma_rows + kMedRows - 1) / kMedRows;
+    if (p.med_ptr.size() != (size_t)nb + 1 || !mono(p.med_ptr) || p.stats.n_med_blocks != nb) return fail("med_ptr size / n_med_blocks");
+    if ((size_t)p.med_ptr.back() * (size_t)CH != p.cnt_reg || p.med_val.size() != p.cnt_reg * (size_t)vb) return fail("regular tiles");
+    if (p.cid16 ? (p.med_cid16.size() != p.cnt_reg || !p.med_cid.empty() || p.med_base.size() != (size_t)p.med_ptr.back())
+                : (p.med_cid.size() != p.cnt_reg || !p.med_cid16.empty() || !p.med_base.empty())) return fail("medium column ids");
+    if (p.irr_ptr.size() != (size_t)p.n_mfma_rows + 1 || !mono(p.irr_ptr) || (size_t)p.irr_ptr.back() != p.cnt_irr) return fail("irr_ptr");
+    if (p.irr_val.size() != p.cnt_irr * (size_t)vb || p.irr_cid.size() != p.cnt_irr) return fail("irregular arrays");
+    if (!cid_ok(p.irr_cid) || !cid_ok(p.med_cid)) return fail("medium column id out of range");
+    if (p.cid16)
+        for (size_t c = 0; c < p.med_base.size(); ++c) {
+            const long long b = p.med_base[c];
+            if (b < 0 || b >= std::max<long long>(xlen, 1)) return fail("med_base out of range");
+            for (long long e = 0; e < CH; ++e) { const unsigned o = p.med_cid16[c * (size_t)CH + (size_t)e]; if (o != 0xFFFFu && b + o >= xlen) return fail("16-bit column id out of range"); }
+        }
+    // ---- windows
+    if (p.lds_bytes < 0 || p.lds_bytes > 160 * 1024) return fail("lds_bytes");
+    if (p.windowed) {
+        if (p.row_window < 64 || p.row_window > 1024 || p.row_window % 64) return fail("row_window");
+        const long long nW = (p.n_mfma_rows + p.row_window - 1) / p.row_window;
+        if (p.win_len.size() != (size_t)nW || p.win_cmin.size() != (size_t)nW || p.med_dst.size() != (size_t)p.n_mfma_rows) return fail("window tables");
+        for (int d : p.med_dst) if ((unsigned)d >= (unsigned)m) return fail("med_dst out of range");
+        const long long A = 16 / vb, bpw = p.row_window / kMedRows;
+        for (long long w = 0; w < nW; ++w) {
+            const long long len = p.win_len[(size_t)w], c0 = p.win_cmin[(size_t)w];
+            if (len < 0 || c0 < 0 || len * vb > p.lds_bytes || c0 % A || (len > 0 && c0 + len > xlen)) return fail("window span");
+            if (len == 0) continue;
+            // every gather of an LDS-staged window must fall inside the staged span
+            for (long long b = w * bpw; b < std::min(nb, (w + 1) * bpw); ++b) {
+                for (long long c = p.med_ptr[(size_t)b]; c < p.med_ptr[(size_t)b + 1]; ++c)
+                    for (long long e = 0; e < CH; ++e) {
+                        long long col;
+                        if (p.cid16) { const unsigned o = p.med_cid16[(size_t)(c * CH + e)]; if (o == 0xFFFFu) continue; col = (long long)p.med_base[(size_t)c] + o; }
+                        else { col = p.med_cid[(size_t)(c * CH + e)]; if (col < 0) continue; }
+                        if (col < c0 || col >= c0 + len) return fail("windowed column id outside its LDS span");
+                    }
+                for (long long r = b * kMedRows; r < std::min<long long>(p.n_mfma_rows, (b + 1) * kMedRows); ++r)
+                    for (int t = p.irr_ptr[(size_t)r]; t < p.irr_ptr[(size_t)r + 1]; ++t) { const int col = p.irr_cid[(size_t)t]; if (col >= 0 && (col < c0 || col >= c0 + len)) return fail("windowed tail id outside its LDS span"); }
+            }
+        }
+    } else if (!p.med_dst.empty() || !p.win_len.empty() || !p.win_cmin.empty()) return fail("window tables without windows");
+    // ---- short rows / slabs
+    if (p.short_val.size() != p.cnt_short * (size_t)vb || p.short_cid.size() != p.cnt_short || !cid_ok(p.short_cid)) return fail("short arrays");
+    long long off = 0, tile0 = 0;
+    static const int kLen[5] = {1, 2, 3, 4, 0};
+    for (int g = 0; g < kNumShortGroups; ++g) {
+        const ShortGroup &G = p.grp[g];
+        if (G.len != (g < 5 ? kLen[g] : g) || G.count < 0 || G.count > m) return fail("short group length / count");
+        if (G.tiles != (G.count + SR - 1) / SR || G.tile0 != tile0 || G.elem_off != off) return fail("short group tiles / offsets");
+        tile0 += G.tiles; off += (long long)G.tiles * SR * G.len;
+        const SlotMap &M = G.map;
+        if (M.split < 0 || M.grp[0] < 0 || M.grp[1] < 0) return fail("slot map");
+        for (int t : {0, M.split - 1, M.split, G.count - 1})
+            if (t >= 0 && t < G.count) { const long long sl = M.slot(t); if (sl < 0 || sl >= m) return fail("slot map leaves the permutation"); }
+    }
+    if ((size_t)off != p.cnt_short || p.stats.n_short_tiles != tile0) return fail("short segment size");
+    return true;
+}
+
 static void write_plan(Writer &w, Plan &p)
 {
     const int hdr[14] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
@@ -51,7 +164,7 @@ static void write_plan(Writer &w, Plan &p)
     for (auto &h : p.panels) write_plan(w, h->impl);
 }
 
-static bool read_plan(Reader &r, Plan &p, int depth)
+static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
 {
     int hdr[14];
     r.raw(hdr, sizeof hdr);
@@ -80,10 +193,11 @@ static bool read_plan(Reader &r, Plan &p, int depth)
     p.cnt_reg = p.cid16 ? p.med_cid16.size() : p.med_cid.size();
     p.host_dropped = false;
     p.panel = depth > 0;
+    if (!validate_plan(p, np, r_why)) return false;
     p.opt.col_panels = np > 0 ? np : 1;
     for (int k = 0; k < np; ++k) {
         std::unique_ptr<dasp_plan> h(new dasp_plan());
-        if (!read_plan(r, h->impl, depth + 1) || h->impl.m != p.m || h->impl.precision != p.precision) return false;
+        if (!read_plan(r, h->impl, depth + 1, r_why) || h->impl.m != p.m || h->impl.precision != p.precision) return false;
         p.panels.push_back(std::move(h));
     }
     return true;
@@ -97,6 +211,8 @@ int save_plan(Plan &p, const char *path)
     if (!f) { set_error(std::string("cannot create ") + path); return DASP_ERR_OPEN; }
     Writer w{f};
     w.raw(kPlanMagic, 8);
+    const int abi[3] = {(int)sizeof(dasp_stats_t), kNumShortGroups, (int)sizeof(ShortGroup)};
+    w.raw(abi, sizeof abi);
     write_plan(w, p);
     const bool ok = (std::fclose(f) == 0) && w.ok;
     if (!ok) { set_error(std::string("short write to ") + path); return DASP_ERR_OPEN; }
@@ -108,13 +224,23 @@ int load_plan(Plan &p, const char *path)
     if (!path) return DASP_ERR_ARG;
     FILE *f = std::fopen(path, "rb");
     if (!f) { set_error(std::string("cannot open ") + path); return DASP_ERR_OPEN; }
-    Reader r{f};
+    std::fseek(f, 0, SEEK_END);
+    const long long size = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    Reader r{f, size < 0 ? 0 : size};
     char magic[8];
+    int abi[3] = {0, 0, 0};
     r.raw(magic, 8);
-    if (!r.ok || std::memcmp(magic, kPlanMagic, 8) != 0) { std::fclose(f); set_error("not a DASPPLN3 plan file"); return DASP_ERR_BANNER; }
-    const bool ok = read_plan(r, p, 0);
+    r.raw(abi, sizeof abi);
+    if (!r.ok || std::memcmp(magic, kPlanMagic, 8) != 0 || abi[0] != (int)sizeof(dasp_stats_t) || abi[1] != kNumShortGroups || abi[2] != (int)sizeof(ShortGroup)) {
+        std::fclose(f); set_error("not a DASPPLN4 plan file of this build (magic / struct sizes differ)"); return DASP_ERR_BANNER;
+    }
+    std::string why;
+    bool ok = false;
+    try { ok = read_plan(r, p, 0, why); }
+    catch (...) { std::fclose(f); throw; }
     std::fclose(f);
-    if (!ok) { set_error("truncated or inconsistent plan file"); return DASP_ERR_ENTRY; }
+    if (!ok) { set_error("truncated or inconsistent plan file" + (why.empty() ? std::string() : ": " + why)); return DASP_ERR_ENTRY; }
     return DASP_OK;
 }
 

@@ -97,6 +97,42 @@ void oracle_exclusive_scan(int *a, int len)
     for (int i = 0; i < len; ++i) { int v = a[i]; a[i] = carry; carry += v; }
 }
 
+/* the entry loop of mmio_allinone, src/mmio_highlevel.h:663-697, on its own: file-order COO triples (0-based, as after the
+ * loop's --i / --j), value = real part / integer / 1.0 for pattern; `im` (may be NULL) receives the imaginary part that
+ * mmio_allinone drops.  Pinned against the reference's own entry parsers mm_read_mtx_crd_data / mm_read_mtx_crd_entry
+ * (src/mmio.h:866-980) in tests/test_oracle.py.  Arrays are malloc'd (oracle_free). */
+static int coo_from_file(FILE *f, const char tc[4], int nz_file, int *ri, int *ci, double *vv, double *vi)
+{
+    const int is_pattern = tc[2] == 'P', is_real = tc[2] == 'R', is_complex = tc[2] == 'C',
+              is_integer = tc[2] == 'I';                /* :632-635 */
+    for (int e = 0; e < nz_file; ++e) {                 /* :663-697 */
+        int i = 0, j = 0, iv = 0;
+        double re = 0.0, im = 0.0;
+        if (is_real) { if (fscanf(f, "%d %d %lg\n", &i, &j, &re) < 0) {} }
+        else if (is_complex) { if (fscanf(f, "%d %d %lg %lg\n", &i, &j, &re, &im) < 0) {} }
+        else if (is_integer) { if (fscanf(f, "%d %d %d\n", &i, &j, &iv) < 0) {} re = iv; }
+        else if (is_pattern) { if (fscanf(f, "%d %d\n", &i, &j) < 0) {} re = 1.0; }
+        --i; --j;
+        ri[e] = i; ci[e] = j; vv[e] = re;
+        if (vi) vi[e] = im;
+    }
+    return 0;
+}
+
+int oracle_mm_read_coo(const char *path, char typecode[4], int *M, int *N, int *nz, int **I, int **J, double **re, double **im)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    if (banner_from_file(f, typecode) != 0) { fclose(f); return -2; }
+    if (size_from_file(f, M, N, nz) != 0) { fclose(f); return -4; }
+    const size_t n = (size_t)(*nz > 0 ? *nz : 1);
+    *I = (int *)malloc(sizeof(int) * n); *J = (int *)malloc(sizeof(int) * n);
+    *re = (double *)malloc(sizeof(double) * n); *im = (double *)malloc(sizeof(double) * n);
+    coo_from_file(f, typecode, *nz, *I, *J, *re, *im);
+    fclose(f);
+    return 0;
+}
+
 /* src/mmio_highlevel.h:608-774 (mmio_allinone) */
 int oracle_mmio_allinone(const char *path, int *m, int *n, int *nnz, int *is_symmetric,
                          int **row_ptr, int **col_idx, double **val)
@@ -110,8 +146,6 @@ int oracle_mmio_allinone(const char *path, int *m, int *n, int *nnz, int *is_sym
         fclose(f);
         return -2;
     }
-    const int is_pattern = tc[2] == 'P', is_real = tc[2] == 'R', is_complex = tc[2] == 'C',
-              is_integer = tc[2] == 'I';                /* :632-635 */
     if (size_from_file(f, &M, &N, &nz_file) != 0) { fclose(f); return -4; } /* :638-640 */
     const int sym = (tc[3] == 'S' || tc[3] == 'H');     /* :642: skew is NOT mirrored */
 
@@ -120,17 +154,8 @@ int oracle_mmio_allinone(const char *path, int *m, int *n, int *nnz, int *is_sym
     int *ci = (int *)malloc(sizeof(int) * (size_t)(nz_file > 0 ? nz_file : 1));
     double *vv = (double *)malloc(sizeof(double) * (size_t)(nz_file > 0 ? nz_file : 1));
 
-    for (int e = 0; e < nz_file; ++e) {                 /* :663-697 */
-        int i = 0, j = 0, iv = 0;
-        double re = 0.0, im = 0.0;
-        if (is_real) { if (fscanf(f, "%d %d %lg\n", &i, &j, &re) < 0) {} }
-        else if (is_complex) { if (fscanf(f, "%d %d %lg %lg\n", &i, &j, &re, &im) < 0) {} }
-        else if (is_integer) { if (fscanf(f, "%d %d %d\n", &i, &j, &iv) < 0) {} re = iv; }
-        else if (is_pattern) { if (fscanf(f, "%d %d\n", &i, &j) < 0) {} re = 1.0; }
-        --i; --j;
-        cnt[i]++;
-        ri[e] = i; ci[e] = j; vv[e] = re;
-    }
+    coo_from_file(f, tc, nz_file, ri, ci, vv, NULL);    /* :663-697 */
+    for (int e = 0; e < nz_file; ++e) cnt[ri[e]]++;
     fclose(f);
 
     if (sym)                                            /* :702-709 */

@@ -38,6 +38,9 @@ int oracle_mm_read_size(const char *path, int *M, int *N, int *nz);
  * arrays are malloc'd; free with oracle_free. values as double. */
 int oracle_mmio_allinone(const char *path, int *m, int *n, int *nnz, int *is_symmetric,
                          int **row_ptr, int **col_idx, double **val);
+/* the entry loop of mmio_allinone alone (mmio_highlevel.h:663-697): file-order COO, 0-based; pinned against the reference's
+ * mm_read_mtx_crd_data / mm_read_mtx_crd_entry (mmio.h:866-980).  returns 0 / -1 / -2 / -4 as above. */
+int oracle_mm_read_coo(const char *path, char typecode[4], int *M, int *N, int *nz, int **I, int **J, double **re, double **im);
 void oracle_free(void *p);
 
 /* ---- utilities ----------------------------------------------------------- */

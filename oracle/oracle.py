@@ -46,6 +46,7 @@ def lib():
         L.oracle_mm_read_size.argtypes = [C.c_char_p, ip, ip, ip]
         L.oracle_mmio_allinone.argtypes = [C.c_char_p, ip, ip, ip, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(dp)]
         L.oracle_free.argtypes = [C.c_void_p]
+        L.oracle_mm_read_coo.argtypes = [C.c_char_p, C.c_char_p, ip, ip, ip, C.POINTER(ip), C.POINTER(ip), C.POINTER(dp), C.POINTER(dp)]
         L.oracle_exclusive_scan.argtypes = [C.c_void_p, C.c_int]
         L.oracle_radix_sort_desc.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_csr_spmv_f64.argtypes = [C.c_int] + [C.c_void_p] * 5
@@ -76,6 +77,8 @@ def ref_mmio():
         ip = C.POINTER(C.c_int)
         R.ref_mm_read_banner_path.argtypes = [C.c_char_p, C.c_char_p]
         R.ref_mm_read_size_path.argtypes = [C.c_char_p, ip, ip, ip]
+        R.ref_mm_read_crd_data_path.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, ip]
+        R.ref_mm_read_crd_entries_path.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, ip]
         _REF = R
     return _REF
 
@@ -112,6 +115,42 @@ def mmio_allinone(path):
     for q in (rp, ci, v):
         L.oracle_free(C.cast(q, C.c_void_p))
     return rc, m.value, n.value, nnz.value, sym.value, row_ptr, col_idx, val
+
+
+def mm_read_coo(path):
+    """The entry loop of mmio_allinone alone -> (rc, typecode, M, N, I, J, re, im): file-order COO, 0-based."""
+    L = lib()
+    ip, dp = C.POINTER(C.c_int), C.POINTER(C.c_double)
+    tc = C.create_string_buffer(4)
+    M, N, nz = C.c_int(), C.c_int(), C.c_int()
+    I, J, re, im = ip(), ip(), dp(), dp()
+    rc = L.oracle_mm_read_coo(os.fsencode(path), tc, C.byref(M), C.byref(N), C.byref(nz), C.byref(I), C.byref(J), C.byref(re), C.byref(im))
+    if rc != 0:
+        return rc, tc.raw.decode("latin1"), 0, 0, None, None, None, None
+    k = nz.value
+    arr = lambda p: np.ctypeslib.as_array(p, (max(k, 1),))[:k].copy()
+    out = (rc, tc.raw.decode("latin1"), M.value, N.value, arr(I), arr(J), arr(re), arr(im))
+    for q in (I, J, re, im):
+        L.oracle_free(C.cast(q, C.c_void_p))
+    return out
+
+
+def ref_read_crd(path, cap=1 << 22):
+    """The REFERENCE's entry parsers on `path` (oracle/_ref, built from src/mmio.h:866-980):
+    -> dict(bulk=(rc, I, J, val), entries=(rc, I, J, re, im), nz) with I, J 1-based as the reference returns them."""
+    R = ref_mmio()
+    if R is None:
+        return None
+    I, J = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    val = np.full(2 * cap, np.nan)
+    nz = C.c_int(0)
+    rc = R.ref_mm_read_crd_data_path(os.fsencode(path), cap, _p(I), _p(J), _p(val), C.byref(nz))
+    k = max(nz.value, 0)
+    bulk = (rc, I[:k].copy(), J[:k].copy(), val[:2 * k].copy())
+    I2, J2 = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    re, im = np.zeros(cap), np.zeros(cap)
+    rc2 = R.ref_mm_read_crd_entries_path(os.fsencode(path), cap, _p(I2), _p(J2), _p(re), _p(im), C.byref(nz))
+    return dict(bulk=bulk, entries=(rc2, I2[:k].copy(), J2[:k].copy(), re[:k].copy(), im[:k].copy()), nz=k)
 
 
 def exclusive_scan(a):

@@ -78,6 +78,18 @@ def test_entry_errors(dasp, tmp_path):
     assert e.value.status == -5
 
 
+def test_size_line_larger_than_the_file_allocates_nothing(dasp, tmp_path):
+    """a tiny file whose size line promises 2 G entries is an entry error, decided before any nz-sized allocation"""
+    import resource
+    p = tmp_path / "liar.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real general\n1 1 2000000000\n1 1 1.0\n")
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    with pytest.raises(dasp.DaspError) as e:
+        dasp.mmio_allinone(str(p))
+    assert e.value.status == -5
+    assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before < 200 * 1024      # KiB: nowhere near the 32 GB the line asks for
+
+
 @pytest.mark.parametrize("prec", [64, 16])
 def test_binary_csr_cache_round_trip(dasp, tmp_path, prec):
     m, n, nnz, sym, rp, ci, v = dasp.mmio_allinone(os.path.join(GOLD, "sym_real.mtx"), prec)

@@ -50,6 +50,62 @@ def test_banner_and_size_match_reference_mmio(oracle, name):
     assert (rc2, M.value, N.value, nz.value) == oracle.mm_read_size(p.decode())
 
 
+def _coo_matches_reference(oracle, path):
+    """file-order COO triples: the REFERENCE's mm_read_mtx_crd_data and mm_read_mtx_crd_entry (src/mmio.h:866-980, compiled
+    into oracle/_ref from where the file lies) == the oracle's restatement of mmio_allinone's entry loop
+    (src/mmio_highlevel.h:663-697).  Returns the number of entries compared, or None when the reference rejects the file."""
+    ref = oracle.ref_read_crd(path)
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference tree absent and no prebuilt copy)")
+    rc, tc, M, N, I, J, re, im = oracle.mm_read_coo(path)
+    if rc != 0:
+        return None
+    brc, bI, bJ, bval = ref["bulk"]
+    erc, eI, eJ, ere, eim = ref["entries"]
+    if tc[2] == "I":
+        # the reference's mmio.h parsers do not take integer matrices (MM_UNSUPPORTED_TYPE = 15): mmio_allinone reads them with its
+        # own fscanf("%d %d %d") (mmio_highlevel.h:680-684), which only the restatement covers
+        assert brc == 15 and erc == 15
+        return 0
+    assert brc == 0 and erc == 0 and ref["nz"] == I.size
+    assert (bI - 1 == I).all() and (bJ - 1 == J).all() and (eI - 1 == I).all() and (eJ - 1 == J).all()
+    if tc[2] == "C":
+        assert (bval[0::2] == re).all() and (bval[1::2] == im).all() and (ere == re).all() and (eim == im).all()
+    elif tc[2] == "R":
+        assert (bval[: I.size] == re).all() and (ere == re).all()
+    else:
+        assert (re == 1.0).all()                              # pattern: the parsers leave val alone, mmio_allinone stores 1.0 (:692)
+    return int(I.size)
+
+
+@pytest.mark.parametrize("name", MTX)
+def test_coo_entries_match_reference_mmio(oracle, name):
+    if EXP[name]["rc"] != 0:
+        pytest.skip("file the loader rejects")
+    if name == "multi_per_line.mtx":
+        # fscanf-token semantics on a file whose entries straddle lines: both sides read whitespace-separated tokens
+        pass
+    n = _coo_matches_reference(oracle, os.path.join(GOLD, name))
+    assert n is not None
+
+
+@pytest.mark.parametrize("field", ["real", "pattern", "complex"])
+@pytest.mark.parametrize("symm", ["general", "symmetric", "hermitian", "skew-symmetric"])
+def test_coo_entries_match_reference_mmio_random_files(oracle, tmp_path, field, symm):
+    from test_loader import write_mtx
+    rng = np.random.default_rng(hash((field, symm, 1)) % 2 ** 32)
+    m = n = 300
+    k = 4000
+    rows = rng.integers(0, m, k)
+    cols = rng.integers(0, n, k)
+    if symm != "general":
+        lo = np.minimum(rows, cols)
+        rows, cols = np.maximum(rows, cols), lo
+    p = str(tmp_path / "r.mtx")
+    write_mtx(p, m, n, rows, cols, rng.uniform(-50, 50, k), field, symm, rng)
+    assert _coo_matches_reference(oracle, p) == k
+
+
 @pytest.mark.parametrize("name", MTX)
 def test_loader_fixtures(oracle, name):
     e = EXP[name]
@@ -108,3 +164,29 @@ def test_packer_regression_values(oracle):
 def test_round_f16(oracle):
     a = np.array([0.0, 1.0, 1.0009765625, 1.00048828125, 65504.0, 1e-8, 3.14159, -2.71828])
     assert (oracle.round_f16(a) == a.astype(np.float16).astype(np.float64)).all()
+
+
+HAND = json.load(open(os.path.join(GOLD, "handworked.json")))
+
+
+@pytest.mark.parametrize("case", ["small24", "pairs300"])
+@pytest.mark.parametrize("prec", [64, 16])
+def test_handworked_classifier_and_order(oracle, dasp, case, prec):
+    """Counters and order_rid worked out by hand from the reference's source lines (tests/golden/make_handworked.py holds the
+    derivation) == the oracle's restatement == the product's classifier (plan.cpp): a pin that trusts neither."""
+    h = HAND[case]
+    lens = np.asarray(h["lengths"])
+    n = 400
+    rp, ci, v = util.csr_from_lengths(lens, n, 5)
+    want_c = h.get("counters") or h["counters_f%d" % prec]
+    want_o = h["order_f%d" % prec]
+    P = oracle.Packed(prec, rp, ci, v, n, block_longest=h["block_longest"])
+    assert P.order_rid.tolist() == want_o
+    for k, val in want_c.items():
+        assert int(getattr(P, k)) == val, (k, "oracle")
+    plan = dasp.Plan(rp, ci, v.astype(np.float64 if prec == 64 else np.float16), n, precision=prec, block_longest=h["block_longest"])
+    assert plan.order_rid.tolist() == want_o
+    st = plan.stats
+    for k, val in want_c.items():
+        assert st[k] == val, (k, "product")
+    plan.close()

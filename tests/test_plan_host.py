@@ -217,6 +217,42 @@ def test_serialised_plan_round_trip(dasp, tmp_path, prec):
         dasp.Plan.load(path)
 
 
+def test_corrupt_plan_files_are_rejected_not_trusted(dasp, tmp_path):
+    """dasp_plan_load re-derives what the kernels index with: a plan file with one damaged table / column id / header field comes
+    back as an error (never an exception through the C ABI, never a plan that would read out of bounds on upload)"""
+    rp, ci, v = util.mixed_matrix(2500, 2000, 13)
+    good = str(tmp_path / "g.plan")
+    for kw in (dict(), dict(x_window=100000, row_window=128), dict(cid16=1), dict(col_panels=3)):
+        dasp.Plan(rp, ci, v, 2000, **kw).save(good)
+        blob = bytearray(open(good, "rb").read())
+        dasp.Plan.load(good).close()                                   # the undamaged file loads
+        rng = np.random.default_rng(1)
+        rejected = 0
+        for trial in range(60):
+            bad = bytearray(blob)
+            at = int(rng.integers(8, len(bad) - 4))
+            if trial % 3 == 0:                                         # a wild 32-bit value (ids, pointers, counts)
+                bad[at:at + 4] = int(rng.integers(1 << 28, 1 << 31)).to_bytes(4, "little")
+            elif trial % 3 == 1:                                       # a negative one
+                bad[at:at + 4] = (-int(rng.integers(2, 1 << 30))).to_bytes(4, "little", signed=True)
+            else:                                                      # a length field claiming more than the file holds
+                bad[at:at + 8] = (1 << 40).to_bytes(8, "little")
+            q = str(tmp_path / "b.plan")
+            open(q, "wb").write(bad)
+            try:
+                dasp.Plan.load(q).close()                              # a hit inside a value array is harmless and loads
+            except dasp.DaspError as e:
+                assert e.status in (-2, -5, -11)
+                rejected += 1
+        assert rejected >= 5
+    bad = bytearray(blob)
+    bad[7:8] = b"3"                                                    # an older layout's magic
+    open(good, "wb").write(bad)
+    with pytest.raises(dasp.DaspError) as e:
+        dasp.Plan.load(good)
+    assert e.value.status == -2
+
+
 def test_mg_plan_splits_a_row_slice_by_column_owner(dasp):
     """dasp_mg_plan_create (multigpu.cpp, host part: no GPU needed): the own-column / other-column plans behind the overlapped
     all-gather hold every entry of the rank's rows exactly once -- own columns re-based to the rank's slice, the others remapped
