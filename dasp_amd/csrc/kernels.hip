@@ -157,6 +157,21 @@ struct XLds {
     const T *xw; int cmin;
     __device__ __forceinline__ T at(int c) const { return xw[c < 0 ? 0 : c - cmin]; }
 };
+// hybrid window: the densest span of the window's columns is in LDS, everything else is gathered from global memory.
+// The two loads sit in divergent branches on purpose: a lane whose column is staged issues no global load.
+template <class T>
+struct XHyb {
+    const T *xw; const T *xg; int cmin; unsigned len;
+    __device__ __forceinline__ T at(int c) const
+    {
+        const unsigned o = (unsigned)(c - cmin);
+        T v;
+        if (c < 0) v = (T)0;                    // pad: dropped by the caller
+        else if (o < len) v = xw[o];
+        else v = xg[c];
+        return v;
+    }
+};
 template <class XV>
 __device__ __forceinline__ void frag_gather(Frag<double> &f, const XV &xv)
 {
@@ -582,10 +597,18 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPla
                 }
                 for (int i = nvec * A + threadIdx.x; i < len; i += nth) xw[i] = xg[cmin + i];
                 __syncthreads();
-                const XLds<T> x{xw, cmin};
-                for (int q = wave; q < a.blocks_per_win; q += wpw) {
-                    const int b = w * a.blocks_per_win + q;
-                    if (b < a.n_blocks) medium_block<T, NT, C16, 2>(a, b, lane, x);
+                if (a.win_hybrid) {
+                    const XHyb<T> x{xw, xg, cmin, (unsigned)len};
+                    for (int q = wave; q < a.blocks_per_win; q += wpw) {
+                        const int b = w * a.blocks_per_win + q;
+                        if (b < a.n_blocks) medium_block<T, NT, C16, 2>(a, b, lane, x);
+                    }
+                } else {
+                    const XLds<T> x{xw, cmin};
+                    for (int q = wave; q < a.blocks_per_win; q += wpw) {
+                        const int b = w * a.blocks_per_win + q;
+                        if (b < a.n_blocks) medium_block<T, NT, C16, 2>(a, b, lane, x);
+                    }
                 }
             } else {
                 const XGlobal<T> x{xg};
@@ -796,6 +819,7 @@ int upload_plan(Plan &p)
     a.med_cid16 = (const unsigned short *)(base + o_mc16); a.med_base = (const int *)(base + o_mb);
     a.med_dst = (const int *)(base + o_mdst); a.win_cmin = (const int *)(base + o_wc); a.win_len = (const int *)(base + o_wl);
     a.n_windows = (int)p.win_len.size(); a.blocks_per_win = p.windowed ? p.row_window / kMedRows : 0;
+    a.win_hybrid = p.win_hybrid ? 1 : 0;
     a.wg_med = p.windowed ? a.n_windows : (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG;
     // f16 blocks of uniform length: a persistent set of 7 workgroups per CU striding over the blocks amortises the per-wave
     // set-up that weighs twice as much at 2 bytes per value (nlpkkt160 f16 0.675 -> 0.739 of the roofline, Queen_4147 f16

@@ -291,7 +291,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     // medium rows globally by length, which scatters the 16 rows of a block over the matrix; here rows are sorted inside
     // windows of `row_window` consecutive medium rows only, one window per workgroup, so a workgroup's rows share a narrow
     // span of x that is staged once in LDS.  Output slots stay the reference's (order_rid untouched): y goes through med_dst.
-    p.windowed = false; p.row_window = 0; p.lds_bytes = 0;
+    p.windowed = false; p.win_hybrid = false; p.row_window = 0; p.lds_bytes = 0;
     p.med_dst.clear(); p.win_cmin.clear(); p.win_len.clear();
     double window_frac = 0.0;
     if ((p.opt.x_window >= 0 || p.opt.x_window == -2) && nmed > 0 && !meta_only) {
@@ -363,6 +363,54 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         // still beats global gathers on band-scattered rows (+-30 k columns, f16: 98.8 -> 65.9 us; +-8 k, f64: 166.8 -> 115.8 us)
         if (p.opt.x_window == 0 && window_frac < 0.5) { cap_bytes = 160 * 1024; fit_windows(); }
         const bool force = p.opt.x_window > 0;
+        // ---- hybrid windows: when the whole span of a window does not fit (graph-like rows: most columns near the rows -- the
+        // pages of a host, the members of a community -- plus a scattered remainder), stage the DENSEST span of cap bytes and let
+        // the gathers that fall outside it read global memory (kernel: XHyb).  Host CSR only.  Auto: when the strict windows
+        // cover < half of the medium nonzeros and the densest spans would cover >= half.
+        p.win_hybrid = false;
+        if (!dev && !order_only && p.opt.x_window_hybrid >= 0 && (p.opt.x_window_hybrid > 0 || (p.opt.x_window == 0 && window_frac < 0.5))) {
+            const int hcap = p.opt.x_window > 0 ? std::min(p.opt.x_window, 160 * 1024) : 80 * 1024;    // two workgroups per CU
+            const long long cap_cols = std::max<long long>(A, (hcap / geo.vbytes / A) * A);
+            const long long xl = p.opt.n_parts > 0 ? (long long)p.opt.n_parts * p.opt.part_stride : (long long)p.n;
+            std::vector<int> hmin(nW), hlen(nW);
+            std::vector<long long> hin(nW);
+            parallel_for(nW, threads, 4, [&](long long w0, long long w1) {
+                std::vector<int> cols;
+                for (long long w = w0; w < w1; ++w) {
+                    const int a0 = (int)w * R, a1 = std::min(nmed, a0 + R);
+                    cols.clear();
+                    for (int i = a0; i < a1; ++i) { const int r = ridW[i]; for (int j = rp[r]; j < rp[r + 1]; ++j) cols.push_back(remap(ci[j])); }
+                    std::sort(cols.begin(), cols.end());
+                    // best 16-byte-aligned start: for every distinct aligned start taken from an entry, count the entries in [s, s + cap_cols)
+                    long long best = 0; int bs = 0;
+                    size_t hi_i = 0;
+                    for (size_t lo_i = 0; lo_i < cols.size(); ++lo_i) {
+                        if (lo_i && cols[lo_i] == cols[lo_i - 1]) continue;
+                        const long long st = (cols[lo_i] / A) * A;
+                        if (hi_i < lo_i) hi_i = lo_i;
+                        while (hi_i < cols.size() && cols[hi_i] < st + cap_cols) ++hi_i;
+                        // entries between the aligned start and cols[lo_i] belong to the span too, but they are < A away: ignore them
+                        const long long cnt = (long long)(hi_i - lo_i);
+                        if (cnt > best) { best = cnt; bs = (int)st; }
+                    }
+                    hmin[w] = bs; hin[w] = best;
+                    hlen[w] = (int)std::min<long long>(cap_cols, xl - bs);
+                }
+            });
+            long long in = 0;
+            for (int w = 0; w < nW; ++w) in += hin[w];
+            const double cover = all > 0 ? (double)in / (double)all : 0.0;
+            if (p.opt.x_window_hybrid > 0 || cover >= 0.5) {
+                p.win_hybrid = true;
+                fit = 0; maxlen = 0;
+                for (int w = 0; w < nW; ++w) {
+                    // a window whose best span holds under a quarter of its gathers is not worth its copy: global gathers only
+                    if (hin[w] * 4 < wnnz[w] || hlen[w] <= 0) { cmin[w] = 0; wlen[w] = 0; continue; }
+                    cmin[w] = hmin[w]; wlen[w] = hlen[w]; fit += hin[w]; maxlen = std::max(maxlen, wlen[w]);
+                }
+                window_frac = all > 0 ? (double)fit / (double)all : 0.0;
+            }
+        }
         bool worth = window_frac >= 0.5 && (double)all >= 0.5 * (double)nnz;
         if (worth && !force && !order_only) {
             // staging pays only when a row's gathers are scattered over the window: if neighbouring nonzeros of a row share
@@ -385,6 +433,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             }
             worth = entries > 0 && (double)lines >= 0.6 * (double)entries;
         }
+        if (!(((force || worth) && fit > 0) || order_only)) p.win_hybrid = false;
         if (((force || worth) && fit > 0) || order_only) {
             p.windowed = true; p.row_window = R;
             p.lds_bytes = ((maxlen * geo.vbytes + 255) / 256) * 256;
@@ -595,6 +644,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     s.n_windows_lds = 0;
     for (int v : p.win_len) s.n_windows_lds += v > 0;
     s.window_nnz_frac = window_frac;
+    s.x_window_hybrid = p.win_hybrid ? 1 : 0;
     if (p.windowed) { const int wpw = std::min(16, p.row_window / kMedRows); s.n_workgroups = ceil_div(s.n_long_pieces, wpw) + s.n_windows + ceil_div(s.n_short_tiles, wpw); }
     if (dev) {   // the O(nnz) copies happen on the GPU; the plan comes back uploaded
         PackMeta meta;
@@ -765,7 +815,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     const int K = (int)p.panels.size();
     s.fill0_nnz_short = s.fill0_nnz_long = s.fill0_nnz_reg = 0;
     s.n_med_blocks = s.n_long_pieces = s.n_long_multi = s.n_short_tiles = s.n_workgroups = 0;
-    s.x_window_on = s.n_windows = s.n_windows_lds = s.lds_bytes = s.row_window = s.cid16_on = 0;
+    s.x_window_on = s.n_windows = s.n_windows_lds = s.lds_bytes = s.row_window = s.cid16_on = s.x_window_hybrid = 0;
     s.window_nnz_frac = 0.0;
     long long stored = 0, dataX = 0;
     for (const auto &h : p.panels) {
@@ -777,7 +827,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
         s.n_short_tiles += t.n_short_tiles; s.n_workgroups += t.n_workgroups;
         s.x_window_on |= t.x_window_on; s.n_windows += t.n_windows; s.n_windows_lds += t.n_windows_lds;
         s.lds_bytes = std::max(s.lds_bytes, t.lds_bytes); s.row_window = std::max(s.row_window, t.row_window);
-        s.cid16_on |= t.cid16_on;
+        s.cid16_on |= t.cid16_on; s.x_window_hybrid |= t.x_window_hybrid;
         s.window_nnz_frac += t.window_nnz_frac * (double)t.nnzA / (double)std::max(1, p.nnz);
     }
     s.rate_fill0 = p.nnz > 0 ? (double)(stored - p.nnz) / p.nnz : 0.0;

@@ -112,6 +112,7 @@ struct Plan {
     // windowed mode (LDS-staged x): medium positions follow the windowed order; med_dst[pos] = y index,
     // win_cmin/win_len = the x span of window w (len 0: span too wide, that window gathers from global memory)
     bool windowed = false;
+    bool win_hybrid = false;        // windows stage their densest span only: gathers outside it read global memory
     int row_window = 0, lds_bytes = 0;
     std::vector<int> med_dst, win_cmin, win_len;
 

@@ -2,7 +2,7 @@
 // A plan file holds every host array of a Plan, so a later run (or every rank of a multi-GPU job)
 // skips classification and packing: load -> upload -> spmv.
 // layout: "DASPPLN4" | int32 sizeof(dasp_stats_t), kNumShortGroups, sizeof(ShortGroup) | plan, where plan = int32 precision, m, n, nnz,
-//         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows | dasp_stats_t |
+//         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows, win_hybrid, 0 | dasp_stats_t |
 //         ShortGroup[kNumShortGroups] | for each array, in a fixed order: int64 byte count + bytes | the n_panels column panels, each
 //         a nested plan.
 // A file is not trusted more than a caller's CSR: after reading, every count, pointer array and column id the kernels index
@@ -122,7 +122,7 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
         for (long long w = 0; w < nW; ++w) {
             const long long len = p.win_len[(size_t)w], c0 = p.win_cmin[(size_t)w];
             if (len < 0 || c0 < 0 || len * vb > p.lds_bytes || c0 % A || (len > 0 && c0 + len > xlen)) return fail("window span");
-            if (len == 0) continue;
+            if (len == 0 || p.win_hybrid) continue;     // hybrid: gathers outside the span read global memory (ids already range-checked)
             // every gather of an LDS-staged window must fall inside the staged span
             for (long long b = w * bpw; b < std::min(nb, (w + 1) * bpw); ++b) {
                 for (long long c = p.med_ptr[(size_t)b]; c < p.med_ptr[(size_t)b + 1]; ++c)
@@ -157,8 +157,8 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
 
 static void write_plan(Writer &w, Plan &p)
 {
-    const int hdr[14] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
-                         p.opt.n_parts, p.opt.part_stride, p.opt.stream_policy, (int)p.panels.size(), p.n_mfma_rows};
+    const int hdr[16] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
+                         p.opt.n_parts, p.opt.part_stride, p.opt.stream_policy, (int)p.panels.size(), p.n_mfma_rows, p.win_hybrid ? 1 : 0, 0};
     w.raw(hdr, sizeof hdr); w.raw(&p.stats, sizeof p.stats); w.raw(p.grp, sizeof p.grp);
     arrays(w, p);
     for (auto &h : p.panels) write_plan(w, h->impl);
@@ -166,14 +166,14 @@ static void write_plan(Writer &w, Plan &p)
 
 static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
 {
-    int hdr[14];
+    int hdr[16];
     r.raw(hdr, sizeof hdr);
     if (!r.ok || (hdr[0] != 64 && hdr[0] != 16) || hdr[12] < 0 || hdr[12] > 64 || (depth > 0 && hdr[12] != 0)) return false;
     p.precision = hdr[0]; p.geo = geometry_for(p.precision);
     p.m = hdr[1]; p.n = hdr[2]; p.nnz = hdr[3];
     dasp_options_default(&p.opt);
     p.opt.y_order = hdr[4]; p.windowed = hdr[5] != 0; p.row_window = hdr[6]; p.lds_bytes = hdr[7]; p.cid16 = hdr[8] != 0;
-    p.opt.n_parts = hdr[9]; p.opt.part_stride = hdr[10]; p.opt.stream_policy = hdr[11]; p.n_mfma_rows = hdr[13];
+    p.opt.n_parts = hdr[9]; p.opt.part_stride = hdr[10]; p.opt.stream_policy = hdr[11]; p.n_mfma_rows = hdr[13]; p.win_hybrid = hdr[14] != 0;
     r.raw(&p.stats, sizeof p.stats); r.raw(p.grp, sizeof p.grp);
     arrays(r, p);
     if (!r.ok) return false;

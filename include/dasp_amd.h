@@ -133,6 +133,11 @@ typedef struct dasp_options {
      * rows hold at least half of the nonzeros;
      * 4 = off; 5..32 = that bound, unconditionally. */
     int slab_max_len;
+    /* hybrid x windows (graph-like rows: most columns near the rows, a scattered remainder).  When the whole span of a window
+     * does not fit in LDS, the window's DENSEST span of `x_window` bytes (auto: 81920) is staged and the gathers that fall outside
+     * it read global memory.  0 = auto (only when the strict windows cover < half of the medium nonzeros and the densest spans
+     * cover >= half; host CSR only), -1 = never, 1 = force (with x_window >= 0). */
+    int x_window_hybrid;
 } dasp_options_t;
 
 void dasp_options_default(dasp_options_t *opt);
@@ -158,6 +163,7 @@ typedef struct dasp_stats {
     int cid16_on;              /* regular medium tiles carry 16-bit column ids */
     int n_col_panels;          /* 0 = single plan; else the number of (non-empty) column panels: the fill0_*, data_X, n_* and
                                   window / cid16 fields are then sums (or any-of) over the panels */
+    int x_window_hybrid;       /* windows stage their densest span; window_nnz_frac = share of the medium gathers served from LDS */
 } dasp_stats_t;
 
 /* classifier + packers on the host (no GPU needed).  CSR arrays are read-only and may be

@@ -228,6 +228,31 @@ def test_lds_staged_x_windows(oracle, dasp, torch_cuda, prec, kw):
     check(oracle, dasp, torch_cuda, rp2, ci2, v2, 3000, prec, x_window=65536)
 
 
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("kw", [dict(x_window=4096, x_window_hybrid=1), dict(x_window=20000, row_window=128, x_window_hybrid=1),
+                                dict(x_window=8192, x_window_hybrid=1, cid16=1, y_order=1)])
+def test_hybrid_windows_mix_lds_and_global_gathers(oracle, dasp, torch_cuda, prec, kw):
+    """graph-like rows (half of the columns near the row, half anywhere): the window stages its densest span only, the gathers
+    outside it read global memory -- same results, same permutation; a share of the gathers strictly between 0 and 1 comes from LDS"""
+    rng = np.random.default_rng(17)
+    m = n = 20000
+    lens = rng.choice([5, 7, 9, 14, 30, 60], size=m)
+    rp = np.zeros(m + 1, np.int64)
+    np.cumsum(lens, out=rp[1:])
+    rows = np.repeat(np.arange(m), lens)
+    near = rng.random(rp[-1]) < 0.55
+    ci = np.where(near, np.clip(rows + rng.integers(-150, 151, rp[-1]), 0, n - 1), rng.integers(0, n, rp[-1])).astype(np.int32)
+    v = rng.uniform(0.5, 1.5, rp[-1])
+    rp = rp.astype(np.int32)
+    kw = dict(kw)
+    y_order = kw.pop("y_order", None)
+    st = dasp.Plan(rp, ci, v.astype(np.float64 if prec == 64 else np.float16), n, precision=prec, **kw).stats
+    assert st["x_window_on"] == 1 and st["x_window_hybrid"] == 1 and 0.2 < st["window_nnz_frac"] < 0.95
+    check(oracle, dasp, torch_cuda, rp, ci, v, n, prec, **kw)
+    auto = dasp.Plan(rp, ci, v.astype(np.float64 if prec == 64 else np.float16), n, precision=prec).stats
+    assert auto["x_window_on"] == 1 and auto["x_window_hybrid"] == 1       # auto: strict windows do not fit, densest spans cover > half
+
+
 def test_cop20k_standin_uses_windows(dasp, torch_cuda):
     rows, cols = dasp.synth_dims("cop20k_A", 0.25)
     rp, ci = dasp.synth_csr("cop20k_A", 0.25)
@@ -645,7 +670,7 @@ def test_random_option_combinations(oracle, dasp, torch_cuda, seed):
     else:
         rp, ci, v = util.csr_from_lengths(lens, n, int(rng.integers(1 << 30)), dtype=dt)
     kw = dict(col_panels=int(rng.choice([1, 1, 2, 3, 6])), cid16=int(rng.choice([-1, 0, 1])),
-              x_window=int(rng.choice([-1, 0, 0, 40000, 163840])), row_window=int(rng.choice([0, 64, 256, 1024])),
+              x_window=int(rng.choice([-1, 0, 0, 40000, 163840])), row_window=int(rng.choice([0, 64, 256, 1024])), x_window_hybrid=int(rng.choice([0, 0, 1, -1])),
               long_piece=int(rng.choice([0, 64, 300, 4096])), block_longest=int(rng.choice([256, 256, 32, 1000])),
               threshold=float(rng.choice([0.75, 0.75, 0.3, 1.0])), y_order=int(rng.choice([0, 1])),
               slab_max_len=int(rng.choice([0, 4, 7, 16, 32])))

@@ -37,7 +37,7 @@ def matrices(draw):
 
 OPTS = st.fixed_dictionaries(dict(
     threshold=st.sampled_from([0.75, 0.75, 0.3, 1.0]), block_longest=st.sampled_from([256, 256, 64, 16, 700]),
-    long_piece=st.sampled_from([0, 64, 256, 4096]), x_window=st.sampled_from([0, -1, 2048, 100000]),
+    long_piece=st.sampled_from([0, 64, 256, 4096]), x_window=st.sampled_from([0, -1, 2048, 100000]), x_window_hybrid=st.sampled_from([0, 1, -1]),
     row_window=st.sampled_from([0, 64, 256, 1024]), cid16=st.sampled_from([0, -1, 1]), y_order=st.sampled_from([0, 1]),
     slab_max_len=st.sampled_from([0, 0, 4, 9, 32])))
 
