@@ -33,6 +33,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+# Gather bounds for matrices whose x gathers miss the L1 (graphs): one nonzero = one gather = (at worst) one distinct 128-byte line.
+#   TA / L1 tag rate : 256 CUs x 2.4 GHz x 1 line per cycle                                   = 614.4 G lines/s
+#   L1 miss queue    : 256 CUs x 64 misses in flight per CU / 257 cycles L2-hit round trip    = 153 G lines/s
+#     (Little's law on the PMC counters of the uniform-column stand-ins, profiles/r02_gather_pmc.md: TCP_TCC_READ_REQ x
+#      TCP_TCC_READ_REQ_LATENCY / busy cycles = 61-64 requests in flight per CU whatever the kernel does)
+GATHER_PEAK_TA_G = 256 * 2.4
+GATHER_PEAK_L1MISS_G = 256 * 64 * 2.4 / 257.0
+
+
+def gather_roofline(nnz, event_ms):
+    g = nnz / (event_ms * 1e6)          # G gathers / s
+    return {"achieved_Ggathers_per_s": round(g, 1), "peak_ta_Glines_per_s": round(GATHER_PEAK_TA_G, 1),
+            "peak_l1_miss_queue_Glines_per_s": round(GATHER_PEAK_L1MISS_G, 1), "frac_of_ta": round(g / GATHER_PEAK_TA_G, 4),
+            "frac_of_l1_miss_queue": round(g / GATHER_PEAK_L1MISS_G, 4),
+            "note": "one gather per nonzero; > 1 of the miss-queue bound means gathers hit the L1 / LDS (FEM rows, staged windows)"}
 TOL = {64: 1e-12, 16: 1e-2}   # BASELINE.json north_star, relative to sum_j |a_ij x_j|
 
 
@@ -239,7 +254,9 @@ def suite_entry(torch, D, O, name, precision, scale, budget_s=2.0):
            "frac_hbm_roofline_graph": round(b_alg / (ge * 1e6) / HBM_PEAK_GBPS, 4),
            "rate_fill0": round(st["rate_fill0"], 4), "pre_ms": round(st["pre_ms"], 1), "verified": ok,
            "col_panels": st["n_col_panels"], "row_long": st["row_long"], "row_block": st["row_block"],
-           "row_short": rows - st["row_long"] - st["row_block"] - st["row_zero"], "generator": generator_of(D, name)}
+           "row_short": rows - st["row_long"] - st["row_block"] - st["row_zero"], "generator": generator_of(D, name),
+           "x_window": {"on": st["x_window_on"], "hybrid": st["x_window_hybrid"], "lds_share_of_medium_gathers": round(st["window_nnz_frac"], 3)},
+           "gather_roofline": gather_roofline(nnz, e)}
     out.update(traffic_for(name, precision, scale, b_alg, kernel_revision()))
     plan.close()
     del x, y
@@ -570,7 +587,7 @@ def main():
     if rank == 0 and world == 1 and not multi and not args.no_suite:
         suite = []
         for nm, pr in (("cop20k_A", 64), ("nlpkkt160", 64), ("powerlaw_1M", 64), ("Queen_4147", 64),
-                       ("webbase-1M", 16), ("ljournal-2008", 16), ("rmat_2M", 16)):
+                       ("webbase-1M", 16), ("ljournal-2008", 16), ("rmat_2M", 16), ("ljournal-2008-uniform", 16)):
             try:
                 suite.append(suite_entry(torch, D, O, nm, pr, args.suite_scale))
             except Exception as exc:   # a failing extra must not hide the headline line

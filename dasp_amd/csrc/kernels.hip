@@ -400,7 +400,7 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
 
     typename Tr<T>::part_t d;
     if (diag_of(acc, lane, d) && r < a.row_block) {
-        const int slot = a.row_long + r;
+        const int slot = a.row_long + r;                 // row_long here = slot of the first MFMA medium row (Plan::med_slot0)
         const int yi = YM == 2 ? a.med_dst[r] : (a.order ? a.order[slot] : slot);
         put_y<T>(a, yi, d);
     }
@@ -809,7 +809,7 @@ int upload_plan(Plan &p)
     a.n_pieces = (int)p.piece_dst.size(); a.n_multi = (int)p.multi_dst.size();
     a.med_ptr = (const int *)(base + o_mptr); a.med_val = base + o_mv; a.med_cid = (const int *)(base + o_mc);
     a.irr_ptr = (const int *)(base + o_ip); a.irr_val = base + o_iv; a.irr_cid = (const int *)(base + o_ic);
-    a.n_blocks = p.stats.n_med_blocks; a.row_block = p.n_mfma_rows; a.row_long = p.stats.row_long;
+    a.n_blocks = p.stats.n_med_blocks; a.row_block = p.n_mfma_rows; a.row_long = p.med_slot0;
     for (int g = 0; g < kNumShortGroups; ++g) a.grp_tile0[g] = p.grp[g].tile0;
     a.short_val = base + o_sv; a.short_cid = (const int *)(base + o_sc); a.groups = (const ShortDev *)(base + o_g);
     a.n_short_tiles = p.stats.n_short_tiles;

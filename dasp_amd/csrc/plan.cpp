@@ -227,6 +227,51 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         ridM_in.swap(keep);
         nmed = nmf;
     }
+    // ---- the longest medium rows as wave-sized pieces (opt.piece_min_len).  A 16-row block of rows with L nonzeros is a serial
+    // chain of ceil(L / K) MFMA steps in ONE wave, each batch of steps one memory latency; on a small matrix with a power-law
+    // tail the kernel then lasts as long as its longest block (webbase-1M stand-in, f16: rows of 255 = 16 steps = 8 batches ~ 8 us
+    // of a 14.6 us kernel).  Such rows are stored like the reference's long rows instead -- CSR order, one wave per piece, all 64
+    // lanes on one row -- while their slots in order_rid stay the medium rows' (they are the FIRST medium slots, right behind the
+    // long rows, so "index in the combined piece list == slot" holds as it does for the long rows).  Classifier counters unchanged.
+    const int nlong_cls = nlong;                      // the reference's row_long
+    int nsp = 0;
+    if (nmf > 0 && !meta_only && p.opt.piece_min_len >= 0 && !(p.opt.x_window > 0)) {
+        int Tmin = p.opt.piece_min_len > 0 ? std::max(5, p.opt.piece_min_len) : 0;
+        if (Tmin == 0) {
+            // auto: only when the matrix is latency-bound (a couple of batches of the longest block already take as long as
+            // streaming the whole matrix at ~5 TB/s) and the rows concerned are a tail (<= 15 % of the nonzeros)
+            const double est_us = (double)nnz * (geo.vbytes + 4) / 5.0e6;
+            const int shot = f16 ? 2 : 8, batch = f16 ? 2 : 4;
+            auto batches = [&](int L) { const int st = ceil_div(L, geo.med_k); return st <= shot ? 1 : ceil_div(st, batch); };
+            const int allowed = std::max(2, (int)(0.25 * est_us / 0.8));
+            if (batches(lenM[0]) > allowed) {
+                int Lmax = lenM[0];
+                while (Lmax > 5 && batches(Lmax) > allowed) --Lmax;
+                Tmin = Lmax + 1;
+            }
+        }
+        if (Tmin > 0) {
+            // rows from the front (the longest) while they are >= Tmin and, in auto mode, stay a tail of <= 15 % of the nonzeros;
+            // never cut inside a run of equal lengths (the row-order list is filtered by length below)
+            const bool forced = p.opt.piece_min_len > 0;
+            int cnt = 0; long long k = 0;
+            while (cnt < nmf && lenM[cnt] >= Tmin && (forced || (k + lenM[cnt]) * 100 <= 15ll * nnz)) { k += lenM[cnt]; ++cnt; }
+            while (cnt > 0 && cnt < nmf && lenM[cnt] == lenM[cnt - 1]) --cnt;
+            nsp = cnt;
+        }
+    }
+    if (nsp > 0) {
+        const int Tcut = lenM[nsp - 1];
+        ridL.insert(ridL.end(), ridM.begin(), ridM.begin() + nsp);
+        ridM.erase(ridM.begin(), ridM.begin() + nsp); lenM.erase(lenM.begin(), lenM.begin() + nsp);
+        std::vector<int> keep; keep.reserve(ridM_in.size());
+        for (int r : ridM_in) if (rp[r + 1] - rp[r] < Tcut) keep.push_back(r);
+        ridM_in.swap(keep);
+        nmf -= nsp; nmed = nmf; nlong += nsp;         // from here on nlong counts the rows STORED as pieces
+    }
+    p.med_slot0 = nlong;
+    long long nnz_pieces = 0;
+    for (int r : ridL) nnz_pieces += rp[r + 1] - rp[r];
     p.n_mfma_rows = nmf;
     const bool natural = p.opt.y_order == DASP_Y_NATURAL;
     const bool mapped = natural && !p.dst_map.empty();     // a panel writing into its parent's slot order
@@ -237,7 +282,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     // ---- long rows: compact, padded to kLongAlign; one wave per piece
     std::vector<long long> startL;
     int piece = p.opt.long_piece > 0 ? p.opt.long_piece : 1024;
-    if (p.opt.long_piece <= 0 && nnz_long <= 2000000) {
+    if (p.opt.long_piece <= 0 && nnz_pieces <= 2000000) {
         // few long nonzeros (launch-bound matrices): one piece per row, so that the second launch (long_reduce) disappears;
         // it costs ~2.7 us per SpMV on the webbase-1M stand-in (19.7 -> 17.0 us)
         int longest = 0;
@@ -365,10 +410,13 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         const bool force = p.opt.x_window > 0;
         // ---- hybrid windows: when the whole span of a window does not fit (graph-like rows: most columns near the rows -- the
         // pages of a host, the members of a community -- plus a scattered remainder), stage the DENSEST span of cap bytes and let
-        // the gathers that fall outside it read global memory (kernel: XHyb).  Host CSR only.  Auto: when the strict windows
-        // cover < half of the medium nonzeros and the densest spans would cover >= half.
+        // the gathers that fall outside it read global memory (kernel: XHyb).  Host CSR only, and only on request
+        // (x_window_hybrid = 1): on the power-law stand-ins the window workgroups themselves cost more than the LDS gathers
+        // save (webbase-1M 14.6 -> 22.4 us with 85 % of the medium gathers staged, ljournal-2008 0.545 -> 0.587 ms with 53 %:
+        // one 1024-thread workgroup per window balances rows of 5..255 nonzeros badly); it pays on rows of even length whose
+        // columns form a band plus outliers (tools/hybrid_probe.py).
         p.win_hybrid = false;
-        if (!dev && !order_only && p.opt.x_window_hybrid >= 0 && (p.opt.x_window_hybrid > 0 || (p.opt.x_window == 0 && window_frac < 0.5))) {
+        if (!dev && !order_only && p.opt.x_window_hybrid > 0) {
             const int hcap = p.opt.x_window > 0 ? std::min(p.opt.x_window, 160 * 1024) : 80 * 1024;    // two workgroups per CU
             const long long cap_cols = std::max<long long>(A, (hcap / geo.vbytes / A) * A);
             const long long xl = p.opt.n_parts > 0 ? (long long)p.opt.n_parts * p.opt.part_stride : (long long)p.n;
@@ -400,7 +448,8 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             long long in = 0;
             for (int w = 0; w < nW; ++w) in += hin[w];
             const double cover = all > 0 ? (double)in / (double)all : 0.0;
-            if (p.opt.x_window_hybrid > 0 || cover >= 0.5) {
+            (void)cover;
+            {
                 p.win_hybrid = true;
                 fit = 0; maxlen = 0;
                 for (int w = 0; w < nW; ++w) {
@@ -439,7 +488,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             p.lds_bytes = ((maxlen * geo.vbytes + 255) / 256) * 256;
             p.win_cmin.swap(cmin); p.win_len.swap(wlen);
             std::vector<int> slot_of_row((size_t)m, -1);
-            for (int i = 0; i < nmed; ++i) slot_of_row[ridM[i]] = nlong + i;       // reference slot of each medium row
+            for (int i = 0; i < nmed; ++i) slot_of_row[ridM[i]] = nlong + i;       // reference slot of each (MFMA) medium row: p.med_slot0 + i
             p.med_dst.resize(nmed);
             for (int i = 0; i < nmed; ++i) p.med_dst[i] = natural ? rowdst(ridW[i]) : slot_of_row[ridW[i]];
             ridM.swap(ridW); lenM.swap(lenW);                                      // the packers below follow the windowed order
@@ -618,7 +667,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     std::memset(&s, 0, sizeof s);
     s.precision = p.precision; s.rowA = m; s.colA = p.n; s.nnzA = nnz;
     s.short_row_1 = n1; s.common_13 = c13; s.short_row_3 = n3; s.short_row_4 = n4; s.short_row_2 = n2;
-    s.row_long = nlong; s.row_block = nmed_all; s.row_zero = nz0;
+    s.row_long = nlong_cls; s.row_block = nmed_all; s.row_zero = nz0; s.med_rows_as_pieces = nsp;
     s.nnz_short = nnz_short; s.nnz_long = (int)nnz_long; s.nnz_irreg = nnz_irreg;
     s.origin_nnz_reg = nnz - nnz_irreg - (int)nnz_long - nnz_short;
     s.rowloop = nmed < 59990 ? 1 : (nmed < 400000 ? 2 : 4);

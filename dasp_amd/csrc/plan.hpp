@@ -105,7 +105,8 @@ struct Plan {
     bool cid16 = false;
     raw_vector<uint16_t> med_cid16;  // u16 offsets from med_base[chunk], 0xFFFF = pad (cid16 on)
     std::vector<int> med_base;        // [chunks]
-    int n_mfma_rows = 0;            // medium rows handled as MFMA blocks (the longest ones; the rest are slabs, see grp[5..])
+    int n_mfma_rows = 0;            // medium rows handled as MFMA blocks (the shortest are slabs, see grp[5..]; the longest may be pieces)
+    int med_slot0 = 0;              // slot of the first MFMA medium row: row_long + the medium rows stored as pieces (opt.piece_min_len)
     std::vector<int> irr_ptr;       // [n_mfma_rows+1]
     raw_vector<char> irr_val;
     raw_vector<int> irr_cid;

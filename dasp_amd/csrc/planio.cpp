@@ -2,7 +2,7 @@
 // A plan file holds every host array of a Plan, so a later run (or every rank of a multi-GPU job)
 // skips classification and packing: load -> upload -> spmv.
 // layout: "DASPPLN4" | int32 sizeof(dasp_stats_t), kNumShortGroups, sizeof(ShortGroup) | plan, where plan = int32 precision, m, n, nnz,
-//         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows, win_hybrid, 0 | dasp_stats_t |
+//         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows, win_hybrid, med_slot0 | dasp_stats_t |
 //         ShortGroup[kNumShortGroups] | for each array, in a fixed order: int64 byte count + bytes | the n_panels column panels, each
 //         a nested plan.
 // A file is not trusted more than a caller's CSR: after reading, every count, pointer array and column id the kernels index
@@ -78,6 +78,7 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
     }
     if (p.stats.rowA != p.m || p.stats.colA != p.n || p.stats.nnzA != p.nnz || p.stats.precision != p.precision) return fail("stats header");
     if (p.stats.row_long < 0 || p.n_mfma_rows < 0 || p.n_mfma_rows > p.stats.row_block || (long long)p.stats.row_long + p.stats.row_block > m) return fail("category counters");
+    if (n_panels == 0 && (p.med_slot0 < p.stats.row_long || (long long)p.med_slot0 + p.n_mfma_rows > (long long)p.stats.row_long + p.stats.row_block)) return fail("med_slot0");
     if (p.panel_bounds.size() != 2 * (size_t)n_panels) return fail("panel_bounds size");
     if (n_panels > 0) {   // a panel parent keeps order + stats only
         if (p.cnt_long || p.cnt_reg || p.cnt_irr || p.cnt_short || !p.med_ptr.empty() || !p.irr_ptr.empty() || !p.piece_ptr.empty()) return fail("panel parent holds packed arrays");
@@ -158,7 +159,7 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
 static void write_plan(Writer &w, Plan &p)
 {
     const int hdr[16] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
-                         p.opt.n_parts, p.opt.part_stride, p.opt.stream_policy, (int)p.panels.size(), p.n_mfma_rows, p.win_hybrid ? 1 : 0, 0};
+                         p.opt.n_parts, p.opt.part_stride, p.opt.stream_policy, (int)p.panels.size(), p.n_mfma_rows, p.win_hybrid ? 1 : 0, p.med_slot0};
     w.raw(hdr, sizeof hdr); w.raw(&p.stats, sizeof p.stats); w.raw(p.grp, sizeof p.grp);
     arrays(w, p);
     for (auto &h : p.panels) write_plan(w, h->impl);
@@ -173,7 +174,7 @@ static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
     p.m = hdr[1]; p.n = hdr[2]; p.nnz = hdr[3];
     dasp_options_default(&p.opt);
     p.opt.y_order = hdr[4]; p.windowed = hdr[5] != 0; p.row_window = hdr[6]; p.lds_bytes = hdr[7]; p.cid16 = hdr[8] != 0;
-    p.opt.n_parts = hdr[9]; p.opt.part_stride = hdr[10]; p.opt.stream_policy = hdr[11]; p.n_mfma_rows = hdr[13]; p.win_hybrid = hdr[14] != 0;
+    p.opt.n_parts = hdr[9]; p.opt.part_stride = hdr[10]; p.opt.stream_policy = hdr[11]; p.n_mfma_rows = hdr[13]; p.win_hybrid = hdr[14] != 0; p.med_slot0 = hdr[15];
     r.raw(&p.stats, sizeof p.stats); r.raw(p.grp, sizeof p.grp);
     arrays(r, p);
     if (!r.ok) return false;

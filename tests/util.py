@@ -85,7 +85,7 @@ def decode_plan(plan):
         mc = np.where(off == 0xFFFF, -1, base + off)
     ip_, iv, ic = plan.host_array("irr_ptr"), plan.host_array("irr_val"), plan.host_array("irr_cid")
     nb = mptr.size - 1
-    row_block, row_long = ip_.size - 1, st["row_long"]       # MFMA-block rows only: shorter medium rows are slabs (short_groups)
+    row_block, row_long = ip_.size - 1, st["row_long"] + st.get("med_rows_as_pieces", 0)   # MFMA-block rows only: shorter medium rows are slabs (short_groups), the longest may be pieces
     # windowed mode: medium position -> y index through med_dst (a slot, or a row id when Y_NATURAL)
     med_dst = plan.host_array("med_dst") if st.get("x_window_on") else None
     if med_dst is not None and natural and inv is None:

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""tools/traffic.py <tag> <workload> <precision> <scale> -> one profiles/traffic.json entry (stdout, JSON) + a markdown summary (stderr)
+from the three rocprofv3 passes tools/prof.sh wrote under gpurun_out/prof_<tag>/ for `dasp_bench <workload> <scale> <precision> ...`:
+kernel trace + stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes: the two do not fit one pass on gfx950).
+HBM bytes per SpMV = sum over every dasp_* kernel of one SpMV (column panels: P fused kernels + the panel sum; long rows: + stage 2) of
+2 x FETCH_SIZE (gfx950 tallies the 128-byte requests of wide streaming reads at 64 B: MI355X_MICROARCH.md, HBM) + WRITE_SIZE.
+The x2 is calibrated for wide coalesced streams only: for gather-bound kernels the entry says so and also carries the raw sum."""
+import csv, glob, hashlib, json, os, sys
+tag, workload, prec, scale = sys.argv[1], sys.argv[2], int(sys.argv[3]), float(sys.argv[4])
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d = os.path.join(root, "gpurun_out", "prof_" + tag)
+
+
+def rev():
+    h = hashlib.sha1()
+    for f in ("kernels.hip", "plan.cpp", "device.hpp", "plan.hpp"):
+        h.update(open(os.path.join(root, "dasp_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
+
+
+def per_kernel(kind):
+    rows = list(csv.DictReader(open(glob.glob(d + "/pmc_%s/*/*counter_collection.csv" % kind)[0])))
+    tot, cnt = {}, {}
+    for r in rows:
+        k = r["Kernel_Name"]
+        if "dasp" not in k:
+            continue
+        k = k.split("(")[0].replace("void dasp::", "")
+        tot[k] = tot.get(k, 0.0) + float(r["Counter_Value"]) * 1024
+        cnt[k] = cnt.get(k, 0) + 1
+    return tot, cnt, rows
+
+
+fetch, fcnt, frows = per_kernel("fetch")
+write, wcnt, _ = per_kernel("write")
+log = open(d + "/trace.log").read()
+panels = 0
+for tok in log.replace("|", " ").split():
+    if tok.startswith("panels="):
+        panels = int(tok.split("=")[1])
+main = [k for k in fcnt if k.startswith("dasp_spmv_kernel")]
+n_spmv = sum(fcnt[k] for k in main) / max(1, panels)
+f_raw = sum(fetch.values()) / n_spmv
+w = sum(write.values()) / (sum(wcnt[k] for k in wcnt if k.startswith("dasp_spmv_kernel")) / max(1, panels))
+stats = list(csv.DictReader(open(glob.glob(d + "/trace/*/*kernel_stats.csv")[0])))
+sys.stderr.write("## rocprofv3 --kernel-trace --stats -- dasp_bench %s %g %d (tag %s)\n\n| kernel | calls | avg ns | %% |\n|---|---|---|---|\n" % (workload, scale, prec, tag))
+for r in stats[:5]:
+    sys.stderr.write("| %s | %s | %.0f | %s |\n" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]), r["Percentage"]))
+g = [r for r in frows if "dasp_spmv_kernel" in r["Kernel_Name"]][0]
+sys.stderr.write("\nVGPR_Count=%s SGPR_Count=%s LDS=%s scratch=%s workgroup=%s; %d column panels; %.0f SpMVs profiled\n" %
+                 (g["VGPR_Count"], g["SGPR_Count"], g["LDS_Block_Size"], g["Scratch_Size"], g["Workgroup_Size"], panels, n_spmv))
+sys.stderr.write("FETCH_SIZE (own pass) = %.4f GB raw per SpMV -> x2 = %.4f GB; WRITE_SIZE (own pass) = %.2f MB; traffic = %.4f GB per SpMV\n\n" %
+                 (f_raw / 1e9, 2 * f_raw / 1e9, w / 1e6, (2 * f_raw + w) / 1e9))
+avg = {r["Name"].split("(")[0].replace("void dasp::", ""): float(r["AverageNs"]) for r in stats if "dasp" in r["Name"]}
+print(json.dumps({"workload": workload, "precision": prec, "scale": scale, "kernel_rev": rev(), "kernels": sorted(fcnt),
+                  "fetch_size_bytes_raw": round(f_raw), "write_size_bytes": round(w), "traffic_bytes": round(2 * f_raw + w),
+                  "kernel_avg_ns": avg, "column_panels": panels,
+                  "correction": "2 x FETCH_SIZE (gfx950, MI355X_MICROARCH.md HBM section; calibrated for wide coalesced streams) + WRITE_SIZE, summed over the kernels of one SpMV",
+                  "source": "profiles/r02_traffic.md"}))
