@@ -227,51 +227,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         ridM_in.swap(keep);
         nmed = nmf;
     }
-    // ---- the longest medium rows as wave-sized pieces (opt.piece_min_len).  A 16-row block of rows with L nonzeros is a serial
-    // chain of ceil(L / K) MFMA steps in ONE wave, each batch of steps one memory latency; on a small matrix with a power-law
-    // tail the kernel then lasts as long as its longest block (webbase-1M stand-in, f16: rows of 255 = 16 steps = 8 batches ~ 8 us
-    // of a 14.6 us kernel).  Such rows are stored like the reference's long rows instead -- CSR order, one wave per piece, all 64
-    // lanes on one row -- while their slots in order_rid stay the medium rows' (they are the FIRST medium slots, right behind the
-    // long rows, so "index in the combined piece list == slot" holds as it does for the long rows).  Classifier counters unchanged.
     const int nlong_cls = nlong;                      // the reference's row_long
-    int nsp = 0;
-    if (nmf > 0 && !meta_only && p.opt.piece_min_len >= 0 && !(p.opt.x_window > 0)) {
-        int Tmin = p.opt.piece_min_len > 0 ? std::max(5, p.opt.piece_min_len) : 0;
-        if (Tmin == 0) {
-            // auto: only when the matrix is latency-bound (a couple of batches of the longest block already take as long as
-            // streaming the whole matrix at ~5 TB/s) and the rows concerned are a tail (<= 15 % of the nonzeros)
-            const double est_us = (double)nnz * (geo.vbytes + 4) / 5.0e6;
-            const int shot = f16 ? 2 : 8, batch = f16 ? 2 : 4;
-            auto batches = [&](int L) { const int st = ceil_div(L, geo.med_k); return st <= shot ? 1 : ceil_div(st, batch); };
-            const int allowed = std::max(2, (int)(0.25 * est_us / 0.8));
-            if (batches(lenM[0]) > allowed) {
-                int Lmax = lenM[0];
-                while (Lmax > 5 && batches(Lmax) > allowed) --Lmax;
-                Tmin = Lmax + 1;
-            }
-        }
-        if (Tmin > 0) {
-            // rows from the front (the longest) while they are >= Tmin and, in auto mode, stay a tail of <= 15 % of the nonzeros;
-            // never cut inside a run of equal lengths (the row-order list is filtered by length below)
-            const bool forced = p.opt.piece_min_len > 0;
-            int cnt = 0; long long k = 0;
-            while (cnt < nmf && lenM[cnt] >= Tmin && (forced || (k + lenM[cnt]) * 100 <= 15ll * nnz)) { k += lenM[cnt]; ++cnt; }
-            while (cnt > 0 && cnt < nmf && lenM[cnt] == lenM[cnt - 1]) --cnt;
-            nsp = cnt;
-        }
-    }
-    if (nsp > 0) {
-        const int Tcut = lenM[nsp - 1];
-        ridL.insert(ridL.end(), ridM.begin(), ridM.begin() + nsp);
-        ridM.erase(ridM.begin(), ridM.begin() + nsp); lenM.erase(lenM.begin(), lenM.begin() + nsp);
-        std::vector<int> keep; keep.reserve(ridM_in.size());
-        for (int r : ridM_in) if (rp[r + 1] - rp[r] < Tcut) keep.push_back(r);
-        ridM_in.swap(keep);
-        nmf -= nsp; nmed = nmf; nlong += nsp;         // from here on nlong counts the rows STORED as pieces
-    }
-    p.med_slot0 = nlong;
-    long long nnz_pieces = 0;
-    for (int r : ridL) nnz_pieces += rp[r + 1] - rp[r];
     p.n_mfma_rows = nmf;
     const bool natural = p.opt.y_order == DASP_Y_NATURAL;
     const bool mapped = natural && !p.dst_map.empty();     // a panel writing into its parent's slot order
@@ -279,59 +235,6 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     auto ydst = [&](int slot) { return natural ? rowdst(p.order[slot]) : slot; };
 
     lap("order_rid");
-    // ---- long rows: compact, padded to kLongAlign; one wave per piece
-    std::vector<long long> startL;
-    int piece = p.opt.long_piece > 0 ? p.opt.long_piece : 1024;
-    if (p.opt.long_piece <= 0 && nnz_pieces <= 2000000) {
-        // few long nonzeros (launch-bound matrices): one piece per row, so that the second launch (long_reduce) disappears;
-        // it costs ~2.7 us per SpMV on the webbase-1M stand-in (19.7 -> 17.0 us)
-        int longest = 0;
-        for (int r : ridL) longest = std::max(longest, rp[r + 1] - rp[r]);
-        if (longest <= 16384) piece = std::max(piece, longest);
-    }
-    piece = std::max(geo.chunk, ceil_div(piece, geo.chunk) * geo.chunk);
-    {
-        std::vector<long long> start((size_t)nlong + 1, 0);
-        for (int i = 0; i < nlong; ++i) {
-            const int len = rp[ridL[i] + 1] - rp[ridL[i]];
-            start[i + 1] = start[i] + (long long)ceil_div(len, kLongAlign) * kLongAlign;
-        }
-        const long long total = start[nlong];
-        if (total >= (1LL << 31)) { set_error("long-row segment exceeds 2^31 elements"); return DASP_ERR_ARG; }
-        p.cnt_long = (size_t)total;
-        startL = start;
-        if (pack) {
-        p.long_val.resize((size_t)total * sizeof(T));          // not zero-filled: rows + their pads are written below
-        p.long_cid.resize((size_t)total);
-        }
-        p.piece_ptr.clear(); p.piece_dst.clear(); p.multi_ptr.assign(1, 0); p.multi_dst.clear();
-        int n_partial = 0;
-        for (int i = 0; i < nlong; ++i) {
-            const long long lp = start[i + 1] - start[i];
-            const int np = (int)((lp + piece - 1) / piece);
-            for (int q = 0; q < np; ++q) {
-                p.piece_ptr.push_back((int)(start[i] + (long long)q * piece));
-                p.piece_dst.push_back(np == 1 ? ydst(i) : ~(n_partial++));
-            }
-            if (np > 1) { p.multi_ptr.push_back(n_partial); p.multi_dst.push_back(ydst(i)); }
-        }
-        p.piece_ptr.push_back((int)total);
-        T *lv = reinterpret_cast<T *>(p.long_val.data());
-        // element-parallel (not row-parallel): a power-law matrix keeps most of its long nonzeros in a handful of rows
-        if (pack) parallel_for(total, threads, 1 << 16, [&](long long b, long long e) {
-            long long i = std::upper_bound(start.begin(), start.end(), b) - start.begin() - 1;   // row holding element b
-            for (; i < nlong && start[i] < e; ++i) {
-                const int r = ridL[i], len = rp[r + 1] - rp[r];
-                const long long s0 = std::max(b, start[i]), s1 = std::min(e, start[i + 1]);
-                const long long real_end = std::min(s1, start[i] + len);
-                const long long src = (long long)rp[r] - start[i];
-                for (long long j = s0; j < real_end; ++j) { lv[j] = val[src + j]; p.long_cid[(size_t)j] = remap(ci[src + j]); }
-                for (long long j = std::max(s0, real_end); j < s1; ++j) { lv[j] = (T)0; p.long_cid[(size_t)j] = -1; }   // pad to kLongAlign
-            }
-        });
-    }
-
-    lap("long rows");
     // ---- optional windowed order for the medium rows (LDS-staged x).  The reference sorts all
     // medium rows globally by length, which scatters the 16 rows of a block over the matrix; here rows are sorted inside
     // windows of `row_window` consecutive medium rows only, one window per workgroup, so a workgroup's rows share a narrow
@@ -410,13 +313,16 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         const bool force = p.opt.x_window > 0;
         // ---- hybrid windows: when the whole span of a window does not fit (graph-like rows: most columns near the rows -- the
         // pages of a host, the members of a community -- plus a scattered remainder), stage the DENSEST span of cap bytes and let
-        // the gathers that fall outside it read global memory (kernel: XHyb).  Host CSR only, and only on request
-        // (x_window_hybrid = 1): on the power-law stand-ins the window workgroups themselves cost more than the LDS gathers
-        // save (webbase-1M 14.6 -> 22.4 us with 85 % of the medium gathers staged, ljournal-2008 0.545 -> 0.587 ms with 53 %:
-        // one 1024-thread workgroup per window balances rows of 5..255 nonzeros badly); it pays on rows of even length whose
-        // columns form a band plus outliers (tools/hybrid_probe.py).
+        // the gathers that fall outside it read global memory (kernel: XHyb).  Host CSR only.  It pays on rows of even length whose
+        // columns form a band plus outliers (tools/hybrid_probe.py: 2 M rows of 14, +-3000 band + 10 % anywhere, f64 0.234 -> 0.189 ms,
+        // f16 0.086 -> 0.061 ms; +-8000 + 3 %: 0.190 -> 0.126 ms); on the power-law stand-ins the window workgroups themselves cost
+        // more than the LDS gathers save (webbase-1M 14.6 -> 22.4 us with 85 % of the medium gathers staged, ljournal-2008
+        // 0.545 -> 0.587 ms with 53 %: one 1024-thread workgroup per window balances rows of 5..255 nonzeros badly).  So auto
+        // asks for even rows (longest <= 4 x the mean) on top of: strict windows cover < half, densest spans cover >= 60 %.
         p.win_hybrid = false;
-        if (!dev && !order_only && p.opt.x_window_hybrid > 0) {
+        const bool even_rows = nmed > 0 && (long long)lenM[0] * nmed <= 4 * std::max<long long>(1, all);
+        if (!dev && !order_only && p.opt.x_window_hybrid >= 0 &&
+            (p.opt.x_window_hybrid > 0 || (p.opt.x_window == 0 && window_frac < 0.5 && even_rows))) {
             const int hcap = p.opt.x_window > 0 ? std::min(p.opt.x_window, 160 * 1024) : 80 * 1024;    // two workgroups per CU
             const long long cap_cols = std::max<long long>(A, (hcap / geo.vbytes / A) * A);
             const long long xl = p.opt.n_parts > 0 ? (long long)p.opt.n_parts * p.opt.part_stride : (long long)p.n;
@@ -448,8 +354,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             long long in = 0;
             for (int w = 0; w < nW; ++w) in += hin[w];
             const double cover = all > 0 ? (double)in / (double)all : 0.0;
-            (void)cover;
-            {
+            if (p.opt.x_window_hybrid > 0 || cover >= 0.6) {
                 p.win_hybrid = true;
                 fit = 0; maxlen = 0;
                 for (int w = 0; w < nW; ++w) {
@@ -496,6 +401,104 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     }
 
     lap("window decision");
+    // ---- the longest medium rows as wave-sized pieces (opt.piece_min_len).  A 16-row block of rows with L nonzeros is a serial
+    // chain of ceil(L / K) MFMA steps in ONE wave, each batch of steps one memory latency; on a small matrix with a power-law
+    // tail the kernel then lasts as long as its longest block (webbase-1M stand-in, f16: rows of 255 = 16 steps = 8 batches ~ 8 us
+    // of a 14.6 us kernel).  Such rows are stored like the reference's long rows instead -- CSR order, one wave per piece, all 64
+    // lanes on one row -- while their slots in order_rid stay the medium rows' (they are the FIRST medium slots, right behind the
+    // long rows, so "index in the combined piece list == slot" holds as it does for the long rows).  Classifier counters unchanged.
+    int nsp = 0;
+    if (nmf > 0 && !meta_only && p.opt.piece_min_len >= 0 && !p.windowed) {   // window rows keep their LDS gathers (cop20k_A: 11.1 -> 14.7 us when split)
+        int Tmin = p.opt.piece_min_len > 0 ? std::max(5, p.opt.piece_min_len) : 0;
+        if (Tmin == 0) {
+            // auto: only when the matrix is latency-bound (a couple of batches of the longest block already take as long as
+            // streaming the whole matrix at ~5 TB/s) and the rows concerned are a tail (<= 15 % of the nonzeros)
+            const double est_us = (double)nnz * (geo.vbytes + 4) / 5.0e6;
+            const int shot = f16 ? 2 : 8, batch = f16 ? 2 : 4;
+            auto batches = [&](int L) { const int st = ceil_div(L, geo.med_k); return st <= shot ? 1 : ceil_div(st, batch); };
+            const int allowed = std::max(2, (int)(0.25 * est_us / 0.8));
+            if (batches(lenM[0]) > allowed) {
+                int Lmax = lenM[0];
+                while (Lmax > 5 && batches(Lmax) > allowed) --Lmax;
+                Tmin = Lmax + 1;
+            }
+        }
+        if (Tmin > 0) {
+            // rows from the front (the longest) while they are >= Tmin and, in auto mode, stay a tail of <= 15 % of the nonzeros;
+            // never cut inside a run of equal lengths (the row-order list is filtered by length below)
+            const bool forced = p.opt.piece_min_len > 0;
+            int cnt = 0; long long k = 0;
+            while (cnt < nmf && lenM[cnt] >= Tmin && (forced || (k + lenM[cnt]) * 100 <= 15ll * nnz)) { k += lenM[cnt]; ++cnt; }
+            while (cnt > 0 && cnt < nmf && lenM[cnt] == lenM[cnt - 1]) --cnt;
+            nsp = cnt;
+        }
+    }
+    if (nsp > 0) {
+        const int Tcut = lenM[nsp - 1];
+        ridL.insert(ridL.end(), ridM.begin(), ridM.begin() + nsp);
+        ridM.erase(ridM.begin(), ridM.begin() + nsp); lenM.erase(lenM.begin(), lenM.begin() + nsp);
+        std::vector<int> keep; keep.reserve(ridM_in.size());
+        for (int r : ridM_in) if (rp[r + 1] - rp[r] < Tcut) keep.push_back(r);
+        ridM_in.swap(keep);
+        nmf -= nsp; nmed = nmf; nlong += nsp;         // from here on nlong counts the rows STORED as pieces
+    }
+    p.med_slot0 = nlong;
+    p.n_mfma_rows = nmf;
+    long long nnz_pieces = 0;
+    for (int r : ridL) nnz_pieces += rp[r + 1] - rp[r];
+    // ---- long rows: compact, padded to kLongAlign; one wave per piece
+    std::vector<long long> startL;
+    int piece = p.opt.long_piece > 0 ? p.opt.long_piece : 1024;
+    if (p.opt.long_piece <= 0 && nnz_pieces <= 2000000) {
+        // few long nonzeros (launch-bound matrices): one piece per row, so that the second launch (long_reduce) disappears;
+        // it costs ~2.7 us per SpMV on the webbase-1M stand-in (19.7 -> 17.0 us)
+        int longest = 0;
+        for (int r : ridL) longest = std::max(longest, rp[r + 1] - rp[r]);
+        if (longest <= 16384) piece = std::max(piece, longest);
+    }
+    piece = std::max(geo.chunk, ceil_div(piece, geo.chunk) * geo.chunk);
+    {
+        std::vector<long long> start((size_t)nlong + 1, 0);
+        for (int i = 0; i < nlong; ++i) {
+            const int len = rp[ridL[i] + 1] - rp[ridL[i]];
+            start[i + 1] = start[i] + (long long)ceil_div(len, kLongAlign) * kLongAlign;
+        }
+        const long long total = start[nlong];
+        if (total >= (1LL << 31)) { set_error("long-row segment exceeds 2^31 elements"); return DASP_ERR_ARG; }
+        p.cnt_long = (size_t)total;
+        startL = start;
+        if (pack) {
+        p.long_val.resize((size_t)total * sizeof(T));          // not zero-filled: rows + their pads are written below
+        p.long_cid.resize((size_t)total);
+        }
+        p.piece_ptr.clear(); p.piece_dst.clear(); p.multi_ptr.assign(1, 0); p.multi_dst.clear();
+        int n_partial = 0;
+        for (int i = 0; i < nlong; ++i) {
+            const long long lp = start[i + 1] - start[i];
+            const int np = (int)((lp + piece - 1) / piece);
+            for (int q = 0; q < np; ++q) {
+                p.piece_ptr.push_back((int)(start[i] + (long long)q * piece));
+                p.piece_dst.push_back(np == 1 ? ydst(i) : ~(n_partial++));
+            }
+            if (np > 1) { p.multi_ptr.push_back(n_partial); p.multi_dst.push_back(ydst(i)); }
+        }
+        p.piece_ptr.push_back((int)total);
+        T *lv = reinterpret_cast<T *>(p.long_val.data());
+        // element-parallel (not row-parallel): a power-law matrix keeps most of its long nonzeros in a handful of rows
+        if (pack) parallel_for(total, threads, 1 << 16, [&](long long b, long long e) {
+            long long i = std::upper_bound(start.begin(), start.end(), b) - start.begin() - 1;   // row holding element b
+            for (; i < nlong && start[i] < e; ++i) {
+                const int r = ridL[i], len = rp[r + 1] - rp[r];
+                const long long s0 = std::max(b, start[i]), s1 = std::min(e, start[i + 1]);
+                const long long real_end = std::min(s1, start[i] + len);
+                const long long src = (long long)rp[r] - start[i];
+                for (long long j = s0; j < real_end; ++j) { lv[j] = val[src + j]; p.long_cid[(size_t)j] = remap(ci[src + j]); }
+                for (long long j = std::max(s0, real_end); j < s1; ++j) { lv[j] = (T)0; p.long_cid[(size_t)j] = -1; }   // pad to kLongAlign
+            }
+        });
+    }
+
+    lap("long rows");
     // ---- medium rows: regular tiles kept while a 16 x K chunk is >= threshold full
     // (the reference's rule, dasp_f64.h:1044-1091, on this geometry's tile), rest = irregular tail
     const int K = geo.med_k, CH = geo.chunk;

@@ -135,15 +135,16 @@ typedef struct dasp_options {
     int slab_max_len;
     /* hybrid x windows (graph-like rows: most columns near the rows, a scattered remainder).  When the whole span of a window
      * does not fit in LDS, the window's DENSEST span of `x_window` bytes (auto: 81920) is staged and the gathers that fall outside
-     * it read global memory.  0 / -1 = off (auto never chooses it: on power-law rows the window workgroups cost more than the
-     * LDS gathers save), 1 = on (with x_window >= 0; host CSR only): for rows of even length whose columns form
-     * a band plus outliers. */
+     * it read global memory.  0 = auto: when the strict windows cover < half of the medium nonzeros, the densest spans would
+     * cover >= 60 % and the rows are of even length (longest <= 4 x the mean: a band plus outliers; on power-law rows the window
+     * workgroups cost more than the LDS gathers save); -1 = never; 1 = force (with x_window >= 0).  Host CSR only. */
     int x_window_hybrid;
     /* the longest medium rows as wave-sized pieces (stored and multiplied like the long rows: CSR order, one wave per piece of
      * <= long_piece nonzeros, all 64 lanes on one row) instead of 16-row blocks, whose ceil(len / K) MFMA steps run serially in one
      * wave.  Their slots in order_rid and every classifier counter stay the medium rows'.  0 = auto: only on latency-bound
      * matrices (two batches of the longest block would already take as long as streaming the matrix) whose long medium rows are
-     * a tail (<= 15 % of the nonzeros); -1 = off; n >= 5 = every medium row of >= n nonzeros.  Not combined with forced x windows. */
+     * a tail (<= 15 % of the nonzeros); -1 = off; n >= 5 = every medium row of >= n nonzeros.  Ignored by plans that use x windows
+     * (their rows keep the LDS gathers). */
     int piece_min_len;
 } dasp_options_t;
 

@@ -217,6 +217,65 @@ def test_serialised_plan_round_trip(dasp, tmp_path, prec):
         dasp.Plan.load(path)
 
 
+@pytest.mark.parametrize("prec", [64, 16])
+def test_auto_hybrid_windows_need_even_rows_and_keep_the_format(dasp, prec):
+    """rows of equal length whose columns form a band plus 10 % outliers: the strict windows cannot fit (every window spans the
+    matrix), auto stages the densest span (hybrid) and the packed plan still decodes to the rows; power-law rows with the same
+    columns leave it off (the window workgroups would cost more than they save)"""
+    rng = np.random.default_rng(23)
+    m = n = 120000
+    dt = np.float64 if prec == 64 else np.float16
+
+    def cols(rows):
+        return np.where(rng.random(rows.size) < 0.9, np.clip(rows + rng.integers(-500, 501, rows.size), 0, n - 1), rng.integers(0, n, rows.size)).astype(np.int32)
+    rp = (np.arange(m + 1, dtype=np.int64) * 12).astype(np.int32)
+    ci = cols(np.repeat(np.arange(m), 12))
+    plan = dasp.Plan(rp, ci, np.ones(ci.size, dt), n, precision=prec)
+    st = plan.stats
+    assert st["x_window_on"] == 1 and st["x_window_hybrid"] == 1 and 0.8 < st["window_nnz_frac"] < 0.97 and st["lds_bytes"] <= 81920
+    rows = util.decode_plan(plan)
+    order = plan.order_rid
+    for slot in list(range(0, m, 997)):
+        r = order[slot]
+        assert sorted(rows[slot][0]) == sorted(ci[rp[r]:rp[r + 1]].tolist())
+    assert dasp.Plan(rp, ci, np.ones(ci.size, dt), n, precision=prec, x_window_hybrid=-1).stats["x_window_on"] == 0
+    lens = np.minimum(5 + (rng.pareto(1.3, m) * 3).astype(np.int64), 250)
+    rp2 = np.zeros(m + 1, np.int64)
+    np.cumsum(lens, out=rp2[1:])
+    ci2 = cols(np.repeat(np.arange(m), lens))
+    st2 = dasp.Plan(rp2.astype(np.int32), ci2, np.ones(ci2.size, dt), n, precision=prec).stats
+    assert st2["x_window_hybrid"] == 0
+
+
+def test_medium_rows_as_pieces_keep_slots_and_counters(dasp, oracle):
+    """piece_min_len: the longest medium rows stored as wave-sized pieces -- order_rid and every classifier counter are still the
+    oracle's, the packed arrays decode to the rows, the rows concerned sit in the first medium slots"""
+    rng = np.random.default_rng(5)
+    lens = np.concatenate([rng.choice([5, 9, 17, 40], 3000), rng.choice([100, 180, 255], 60), [300, 1200], rng.choice([1, 2, 3, 4, 0], 500)])
+    rng.shuffle(lens)
+    rp, ci, v = util.csr_from_lengths(lens, 5000, 3)
+    for prec in (64, 16):
+        dt = np.float64 if prec == 64 else np.float16
+        P = oracle.Packed(prec, rp, ci, v, 5000)
+        for kw in (dict(piece_min_len=100, x_window=-1), dict(piece_min_len=17, y_order=1, x_window=-1), dict()):
+            plan = dasp.Plan(rp, ci, v.astype(dt), 5000, precision=prec, **kw)
+            st = plan.stats
+            if kw.get("piece_min_len") == 100:
+                assert st["med_rows_as_pieces"] == 60
+            if "piece_min_len" in kw:
+                assert st["med_rows_as_pieces"] > 0
+            for f in "row_long row_block row_zero short_row_1 short_row_2 short_row_3 short_row_4 common_13 nnz_short nnz_long".split():
+                assert st[f] == getattr(P, f), f
+            assert (plan.order_rid == P.order_rid).all()
+            rows = util.decode_plan(plan)
+            order = plan.order_rid
+            assert len(rows) == lens.size
+            for slot, (cs, vs) in rows.items():
+                r = order[slot]
+                assert cs == ci[rp[r]:rp[r + 1]].tolist()
+            plan.close()
+
+
 def test_corrupt_plan_files_are_rejected_not_trusted(dasp, tmp_path):
     """dasp_plan_load re-derives what the kernels index with: a plan file with one damaged table / column id / header field comes
     back as an error (never an exception through the C ABI, never a plan that would read out of bounds on upload)"""
