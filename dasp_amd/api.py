@@ -113,7 +113,8 @@ class Plan:
 
     @classmethod
     def from_device(cls, d_row_ptr, d_col_idx, d_val, rowA, colA, nnzA, precision=64, threshold=0.75, block_longest=256,
-                    y_order=Y_PERMUTED, long_piece=0, part_bounds=None, part_stride=0, x_window=0, row_window=0, cid16=0, col_panels=0, slab_max_len=0):
+                    y_order=Y_PERMUTED, long_piece=0, part_bounds=None, part_stride=0, x_window=0, row_window=0, cid16=0, col_panels=0, slab_max_len=0,
+                    x_window_hybrid=0, piece_min_len=0):
         """Plan from a CSR that already lives on the GPU (integer device addresses): packed by kernels, comes back uploaded."""
         L = _lib.lib()
         self = cls.__new__(cls)
@@ -122,7 +123,7 @@ class Plan:
         L.dasp_options_default(C.byref(opt))
         opt.threshold, opt.block_longest, opt.y_order, opt.long_piece = threshold, block_longest, y_order, long_piece
         opt.x_window, opt.row_window, opt.cid16, opt.col_panels = x_window, row_window, cid16, col_panels
-        opt.slab_max_len = slab_max_len
+        opt.slab_max_len, opt.x_window_hybrid, opt.piece_min_len = slab_max_len, x_window_hybrid, piece_min_len
         self._pb = None
         if part_bounds is not None:
             self._pb = np.ascontiguousarray(part_bounds, np.int32)

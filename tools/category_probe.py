@@ -1,4 +1,6 @@
 import sys, numpy as np, torch
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dasp_amd as D
 name, prec = sys.argv[1], int(sys.argv[2])
 m, n = D.synth_dims(name, 1.0)

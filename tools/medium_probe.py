@@ -7,6 +7,8 @@ import sys
 import numpy as np
 import torch
 
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dasp_amd as D
 
 name, prec = sys.argv[1], int(sys.argv[2])
