@@ -277,7 +277,12 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
     MG_HIP(hipMalloc(&g.yg, all)); MG_HIP(hipMemset(g.yg, 0, all));
     if (g.square) g.xg = g.yg;
     else { const size_t xb = std::max<size_t>((size_t)g.colA * vb, 16); MG_HIP(hipMalloc(&g.xg, xb)); MG_HIP(hipMemset(g.xg, 0, xb)); }
-    MG_HIP(hipStreamCreateWithFlags(&g.cs, hipStreamNonBlocking));
+    {   // the communication stream gets the highest priority: the all-gather's few workgroups must not queue behind the thousands of
+        // the product that is launched at the same moment on the caller's stream (own-column product of the next iteration)
+        int lo = 0, hi = 0;
+        MG_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        MG_HIP(hipStreamCreateWithPriority(&g.cs, hipStreamNonBlocking, hi));
+    }
     MG_HIP(hipEventCreateWithFlags(&g.ev_y, hipEventDisableTiming));
     MG_HIP(hipEventCreateWithFlags(&g.ev_g, hipEventDisableTiming));
     MG_HIP(hipDeviceSynchronize());
