@@ -18,14 +18,24 @@ def rev():
     return h.hexdigest()[:12]
 
 
+SPMV_KERNELS = ("dasp_spmv_kernel", "dasp_long_reduce_kernel", "dasp_panel_sum_kernel")   # the kernels of one SpMV (not dasp_bench's packers)
+
+
+def spmv_kernel(name):
+    """which SpMV kernel a (possibly mangled: rocprofv3 does not demangle the _Float16 instantiations) name is, or None"""
+    for k in SPMV_KERNELS:
+        if k in name:
+            return k
+    return None
+
+
 def per_kernel(kind):
     rows = list(csv.DictReader(open(glob.glob(d + "/pmc_%s/*/*counter_collection.csv" % kind)[0])))
     tot, cnt = {}, {}
     for r in rows:
-        k = r["Kernel_Name"]
-        if "dasp" not in k:
+        k = spmv_kernel(r["Kernel_Name"])
+        if k is None:
             continue
-        k = k.split("(")[0].replace("void dasp::", "")
         tot[k] = tot.get(k, 0.0) + float(r["Counter_Value"]) * 1024
         cnt[k] = cnt.get(k, 0) + 1
     return tot, cnt, rows
@@ -38,10 +48,9 @@ panels = 0
 for tok in log.replace("|", " ").split():
     if tok.startswith("panels="):
         panels = int(tok.split("=")[1])
-main = [k for k in fcnt if k.startswith("dasp_spmv_kernel")]
-n_spmv = sum(fcnt[k] for k in main) / max(1, panels)
+n_spmv = fcnt["dasp_spmv_kernel"] / max(1, panels)
 f_raw = sum(fetch.values()) / n_spmv
-w = sum(write.values()) / (sum(wcnt[k] for k in wcnt if k.startswith("dasp_spmv_kernel")) / max(1, panels))
+w = sum(write.values()) / (wcnt["dasp_spmv_kernel"] / max(1, panels))
 stats = list(csv.DictReader(open(glob.glob(d + "/trace/*/*kernel_stats.csv")[0])))
 sys.stderr.write("## rocprofv3 --kernel-trace --stats -- dasp_bench %s %g %d (tag %s)\n\n| kernel | calls | avg ns | %% |\n|---|---|---|---|\n" % (workload, scale, prec, tag))
 for r in stats[:5]:
@@ -51,7 +60,11 @@ sys.stderr.write("\nVGPR_Count=%s SGPR_Count=%s LDS=%s scratch=%s workgroup=%s; 
                  (g["VGPR_Count"], g["SGPR_Count"], g["LDS_Block_Size"], g["Scratch_Size"], g["Workgroup_Size"], panels, n_spmv))
 sys.stderr.write("FETCH_SIZE (own pass) = %.4f GB raw per SpMV -> x2 = %.4f GB; WRITE_SIZE (own pass) = %.2f MB; traffic = %.4f GB per SpMV\n\n" %
                  (f_raw / 1e9, 2 * f_raw / 1e9, w / 1e6, (2 * f_raw + w) / 1e9))
-avg = {r["Name"].split("(")[0].replace("void dasp::", ""): float(r["AverageNs"]) for r in stats if "dasp" in r["Name"]}
+avg = {}
+for r in stats:
+    k = spmv_kernel(r["Name"])
+    if k:
+        avg[k] = avg.get(k, 0.0) + float(r["AverageNs"]) * (max(1, panels) if k == "dasp_spmv_kernel" else 1)   # per SpMV
 print(json.dumps({"workload": workload, "precision": prec, "scale": scale, "kernel_rev": rev(), "kernels": sorted(fcnt),
                   "fetch_size_bytes_raw": round(f_raw), "write_size_bytes": round(w), "traffic_bytes": round(2 * f_raw + w),
                   "kernel_avg_ns": avg, "column_panels": panels,
