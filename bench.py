@@ -426,6 +426,7 @@ def main():
     mg = R["mg"]
     host_exchange = multi and share_gpu
     if multi and not host_exchange:
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")          # one node: RCCL's bootstrap sockets need no NIC (and must not fail for lack of one)
         uid = torch.from_numpy(D.multi.unique_id() if rank == 0 else np.zeros(128, np.uint8))
         dist.broadcast(uid, 0)
         mg.comm_init(uid.numpy())                                 # ncclCommInitRank, one communicator per rank, on its own GPU
