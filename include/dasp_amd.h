@@ -232,7 +232,7 @@ int dasp_plan_set_stream_policy(dasp_plan_t *plan, int policy);
 int dasp_plan_spmv(dasp_plan_t *plan, const void *dX, void *dY, void *stream);
 /* the same launches with y += A*x: every y index has exactly one writer per launch, so the update is a plain
  * read-modify-write (deterministic; f16: old y widened to f32, added, rounded once).  Lets a matrix split by columns
- * into several plans (dasp_amd/multi.py: own / other ranks' columns) produce one y without a separate add. */
+ * into several plans (dasp_mg_spmv: own / other ranks' columns) produce one y without a separate add. */
 int dasp_plan_spmv_acc(dasp_plan_t *plan, const void *dX, void *dY, void *stream);
 
 /* the reference's timing protocol (dasp_f64.h:1285-1320,1394): `warmup` untimed + `iters`
