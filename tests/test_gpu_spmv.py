@@ -197,14 +197,46 @@ def test_spmv_before_upload_is_an_error(dasp, torch_cuda):
 
 @pytest.mark.parametrize("exe,fixture", [("dasp_f64", "sym_real.mtx"), ("dasp_f16", "gen_real.mtx")])
 def test_cli_drivers(torch_cuda, exe, fixture, tmp_path):
-    """spmv_double / spmv_half equivalents: load .mtx, all-ones, spmv_all, verify through order_rid"""
+    """spmv_double / spmv_half equivalents: load .mtx, all-ones, spmv_all, verify through order_rid; the CSV record is the
+    reference's: spmv_all's partial row completed by the driver with the comparator columns and a newline (main_f64.cu:151-153,
+    main_f16.cu:148-150), one row per run"""
     (tmp_path / "data").mkdir()
-    r = subprocess.run([os.path.join(ROOT, "dasp_amd", "bin", exe), os.path.join(ROOT, "tests", "golden", fixture)],
-                       cwd=tmp_path, capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert "compute succeed" in r.stdout and "SpMV_X:" in r.stdout
+    for run in range(2):
+        r = subprocess.run([os.path.join(ROOT, "dasp_amd", "bin", exe), os.path.join(ROOT, "tests", "golden", fixture)],
+                           cwd=tmp_path, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "compute succeed" in r.stdout and "SpMV_X:" in r.stdout
     csv = (tmp_path / "data" / ("spmv_f64_record.csv" if exe == "dasp_f64" else "spmv_f16_record.csv")).read_text()
-    assert csv.startswith(os.path.join(ROOT, "tests", "golden", fixture) + ",")
+    assert csv.endswith("\n")
+    rows = csv.splitlines()
+    assert len(rows) == 2
+    ncol = {"dasp_f64": 18 + 7 + 5, "dasp_f16": 18 + 10 + 6}[exe]       # spmv_all's columns + main()'s tail
+    for row in rows:
+        assert row.startswith(os.path.join(ROOT, "tests", "golden", fixture) + ",")
+        assert len(row.split(",")) == ncol and not row.endswith(",")
+
+
+def test_bench_reads_real_matrices_from_dasp_mtx_dir(dasp, torch_cuda, tmp_path):
+    """DASP_MTX_DIR: bench.py takes <workload>.mtx from that directory (through the product loader + CSR cache) instead of the
+    seeded stand-in -- here a MatrixMarket file written from the small stand-in itself, so the result is known"""
+    import json
+    import sys
+    rows, cols = dasp.synth_dims("HV15R", 0.01)
+    rp, ci = dasp.synth_csr("HV15R", 0.01)
+    with open(tmp_path / "HV15R.mtx", "w") as f:
+        f.write("%%%%MatrixMarket matrix coordinate pattern general\n%d %d %d\n" % (rows, cols, ci.size))
+        r = np.repeat(np.arange(rows), np.diff(rp))
+        np.savetxt(f, np.stack([r + 1, ci + 1], 1), fmt="%d")
+    env = dict(os.environ, DASP_MTX_DIR=str(tmp_path))
+    out = None
+    for run in range(2):                                   # second run: from the binary CSR cache written by the first
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-suite", "--no-vendor",
+                            "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+        out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        assert out["data"] == "suitesparse" and out["verified"] is True and out["verified_random_x"]["ok"] is True
+        assert out["config"]["rows"] == rows and out["config"]["nnz"] == ci.size and "DASP_MTX_DIR" in out["config"]["workload"]
+    assert (tmp_path / "HV15R.mtx.f64.csrbin").exists()
 
 
 @pytest.mark.parametrize("prec", [64, 16])
