@@ -507,6 +507,35 @@ def main():
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
 
+    # ---- N > 1: what a step is made of, each part alone (events on the launch stream): own-column product, other-column product,
+    # the all-gather by itself.  With the overlap a step costs ~ max(own, all-gather) + other; without it their sum.
+    parts = None
+    if mg is not None and not host_exchange:
+        tdt = torch.float64 if prec == 64 else torch.float16
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        for _ in range(3):
+            mg.allgather(stream)
+        torch.cuda.synchronize()
+        dist.barrier()
+        e0.record()
+        for _ in range(reps):
+            mg.allgather(stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ag_ms = e0.elapsed_time(e1) / reps
+        oth = mg.subplan(1)
+        oth_ms = 0.0
+        if oth is not None:
+            ox = torch.ones(oth.x_len, dtype=tdt, device="cuda")
+            oy = torch.zeros(stride, dtype=tdt, device="cuda")
+            oth_ms = oth.time(ox.data_ptr(), oy.data_ptr(), stream, warmup=3, iters=reps)[1]
+            del ox, oy
+        tt = torch.tensor([ag_ms, oth_ms], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        parts = {"allgather_alone_ms": round(float(tt[0]), 6), "other_column_product_ms": round(float(tt[1]), 6),
+                 "allgather_bytes_per_rank": int(stride * vb), "note": "max over ranks; own-column product = roofline.kernel_ms (rank 0)"}
+
     # ---- dominant kernel alone: HIP events on the launch stream around back-to-back launches
     k_iters = max(20, min(args.steps, 1000))
     if mg is None:
@@ -553,6 +582,8 @@ def main():
         out["roofline"].update(traffic_for(name, prec, scale, b_alg_local, kernel_revision()))
     if rx is not None:
         out["verified_random_x"] = rx
+    if parts is not None:
+        out["step_parts"] = parts
 
     if rank == 0 and world == 1 and mg is None and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(O, rp, ci, cols)

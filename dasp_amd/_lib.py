@@ -144,6 +144,7 @@ def lib():
     L.dasp_mg_set_x.argtypes = [vp, vp]
     L.dasp_mg_spmv.argtypes = [vp, vp]
     L.dasp_mg_product.argtypes = [vp, vp]
+    L.dasp_mg_allgather.argtypes = [vp, vp]
     L.dasp_mg_wait.argtypes = [vp, vp]
     L.dasp_mg_get_y.argtypes = [vp, vp]
     L.dasp_mg_get_y_local.argtypes = [vp, vp]
@@ -172,5 +173,5 @@ EXPORTS = (
     "dasp_plan_create dasp_plan_create_device dasp_plan_download_array dasp_plan_destroy dasp_plan_save dasp_plan_load dasp_plan_order dasp_plan_stats dasp_plan_y_order dasp_plan_x_len dasp_plan_panel_count dasp_plan_panel dasp_plan_panel_range dasp_plan_host_array dasp_plan_upload "
     "dasp_plan_drop_host dasp_plan_set_stream_policy dasp_plan_spmv dasp_plan_spmv_acc dasp_plan_time dasp_plan_time_graph dasp_spmv_all_f64 dasp_spmv_all_f16 dasp_partition_rows "
     "dasp_selftest_mfma dasp_synth_dims dasp_synth_generator dasp_synth_row_lengths dasp_synth_rows "
-    "dasp_mg_unique_id dasp_mg_plan_create dasp_mg_destroy dasp_mg_upload dasp_mg_comm_init dasp_mg_set_x dasp_mg_spmv dasp_mg_product "
+    "dasp_mg_unique_id dasp_mg_plan_create dasp_mg_destroy dasp_mg_upload dasp_mg_comm_init dasp_mg_set_x dasp_mg_spmv dasp_mg_product dasp_mg_allgather "
     "dasp_mg_wait dasp_mg_get_y dasp_mg_get_y_local dasp_mg_y_local dasp_mg_gathered dasp_mg_x dasp_mg_subplan dasp_mg_info").split()

@@ -354,6 +354,25 @@ int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream)
     return DASP_OK;
 }
 
+// the exchange alone (no product): the current y slice -> every rank's gather buffer.  For timing the collective by itself
+// (bench.py reports it next to the products so that a scaling line can be read: step ~ max(own product, all-gather) + other product).
+int dasp_mg_allgather(dasp_mg_plan_t *mg, void *stream)
+{
+    if (!mg) return DASP_ERR_ARG;
+    dasp_mg_plan &g = *mg;
+    if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
+    if (!g.comm && g.world > 1) { set_error("dasp_mg_allgather needs dasp_mg_comm_init"); return DASP_ERR_STATE; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (g.pending) { MG_HIP(hipStreamWaitEvent(s, g.ev_g, 0)); g.pending = false; }
+    if (g.comm) {
+        const ncclResult_t r = rccl()->AllGather(g.ys[g.cur], g.yg, (size_t)g.stride, g.precision == 64 ? ncclFloat64 : ncclFloat16, g.comm, s);
+        if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
+    } else {
+        MG_HIP(hipMemcpyAsync(g.yg, g.ys[g.cur], (size_t)g.stride * g.vb(), hipMemcpyDeviceToDevice, s));
+    }
+    return DASP_OK;
+}
+
 int dasp_mg_wait(dasp_mg_plan_t *mg, void *stream)
 {
     if (!mg) return DASP_ERR_ARG;

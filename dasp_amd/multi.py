@@ -88,6 +88,10 @@ class MgPlan:
     def product(self, stream=0):
         _lib.check(_lib.lib().dasp_mg_product(self._h, C.c_void_p(stream)))
 
+    def allgather(self, stream=0):
+        """the exchange alone (collective): current y slice -> every rank's gather buffer"""
+        _lib.check(_lib.lib().dasp_mg_allgather(self._h, C.c_void_p(stream)))
+
     def wait(self, stream=0):
         _lib.check(_lib.lib().dasp_mg_wait(self._h, C.c_void_p(stream)))
 

@@ -311,6 +311,9 @@ int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream);
 /* the products of one iteration only (no exchange): for callers that move dasp_mg_y_local into every rank's
  * dasp_mg_gathered themselves (tests; transports other than RCCL) */
 int dasp_mg_product(dasp_mg_plan_t *mg, void *stream);
+/* the exchange alone, on `stream` (no product): the current y slice -> every rank's gather buffer; collective.  For timing the
+ * all-gather by itself next to the products. */
+int dasp_mg_allgather(dasp_mg_plan_t *mg, void *stream);
 /* make `stream` wait for the all-gather still in flight (after it, dasp_mg_gathered holds the full y) */
 int dasp_mg_wait(dasp_mg_plan_t *mg, void *stream);
 /* the gathered y without the padding, rowA host values (synchronises the device) */
