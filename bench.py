@@ -567,7 +567,8 @@ def main():
                    ("row ranges by nnz + ncclAllGather(y) from libdasp_amd.so (dasp_mg_spmv), overlapped with the product over the rank's own columns; x_{t+1} = y_t"
                     if mg.overlap else "row ranges by nnz + ncclAllGather(y) from libdasp_amd.so (dasp_mg_spmv); x_{t+1} = y_t"),
                    **({} if mg is None else {"rank0_nnz_own_columns": mg.nnz_local, "rank0_nnz_other_columns": mg.nnz_remote,
-                                             "exchange": "host memory (test hook)" if host_exchange else "RCCL"}),
+                                             "exchange": "host memory (test hook)" if host_exchange else "RCCL",
+                                             "stream_handoff": "hipStreamWriteValue64 / hipStreamWaitValue64" if mg.info["stream_memops"] else "events"}),
                    "row_long": st["row_long"], "row_block": st["row_block"], "rate_fill0": round(st["rate_fill0"], 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,

@@ -45,7 +45,7 @@ class Stats(C.Structure):
 
 class MgInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in "precision n_gpus rank rowA colA row_begin row_end stride".split()] + [
-        ("nnz_own", C.c_longlong), ("nnz_other", C.c_longlong), ("overlap", C.c_int), ("has_comm", C.c_int), ("square", C.c_int)]
+        ("nnz_own", C.c_longlong), ("nnz_other", C.c_longlong), ("overlap", C.c_int), ("has_comm", C.c_int), ("square", C.c_int), ("stream_memops", C.c_int)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -10,6 +10,7 @@
 // the (small, for banded matrices) other-column product waits for it.  RCCL is reached through dlopen: one copy per process
 // (the one PyTorch already mapped, if any), and libdasp_amd.so loads on machines without it.
 #include <hip/hip_runtime_api.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
@@ -103,6 +104,12 @@ struct dasp_mg_plan {
     bool pending = false;              // an all-gather into yg is in flight on `cs`
     hipStream_t cs = nullptr;          // communication stream
     hipEvent_t ev_y = nullptr, ev_g = nullptr;
+    // cross-stream hand-offs by stream memory operations where the device supports them (hipStreamWriteValue64 on the producing
+    // stream, hipStreamWaitValue64 on the consuming one, on two counters in device memory): the command processors poll a word
+    // instead of going through an event's signal + barrier packet (measured, world size 1: device time of a step 95 -> see DESIGN 5)
+    uint64_t *sig = nullptr;           // device words: [0] = products of step k done, [1] = all-gather of step k done
+    uint64_t step = 0, pending_step = 0;
+    bool use_sig = false;
     ncclComm_t comm = nullptr;
 
     size_t vb() const { return precision == 64 ? 8 : 2; }
@@ -113,6 +120,7 @@ struct dasp_mg_plan {
         if (ev_y) (void)hipEventDestroy(ev_y);
         if (ev_g) (void)hipEventDestroy(ev_g);
         if (cs) (void)hipStreamDestroy(cs);
+        if (sig) (void)hipFree(sig);
         for (void *p : {ys[0], ys[1], yg}) if (p) (void)hipFree(p);
         if (xg && xg != yg) (void)hipFree(xg);
         if (own) dasp_plan_destroy(own);
@@ -192,16 +200,26 @@ int create_impl(dasp_mg_plan &g, const int *rp, const int *ci, const T *val, con
     return DASP_OK;
 }
 
+// consumer side of "the all-gather of the pending step is done" on stream s
+int wait_gathered(dasp_mg_plan &g, hipStream_t s)
+{
+    if (!g.pending) return DASP_OK;
+    if (g.use_sig) MG_HIP(hipStreamWaitValue64(s, &g.sig[1], g.pending_step, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+    else MG_HIP(hipStreamWaitEvent(s, g.ev_g, 0));
+    g.pending = false;
+    return DASP_OK;
+}
+
 int product(dasp_mg_plan &g, hipStream_t s)
 {
     const int cur = g.cur, nxt = 1 - g.cur;
     if (g.overlap) {
         // own columns: needs only this rank's slice of x, i.e. its own previous y -- no communication
         if (int rc = dasp_plan_spmv(g.own, g.ys[cur], g.ys[nxt], s)) return rc;
-        if (g.pending) { MG_HIP(hipStreamWaitEvent(s, g.ev_g, 0)); g.pending = false; }     // the other ranks' x has arrived
+        if (int rc = wait_gathered(g, s)) return rc;                                         // the other ranks' x has arrived
         if (g.other) if (int rc = dasp_plan_spmv_acc(g.other, g.yg, g.ys[nxt], s)) return rc;   // y += (other columns) * x
     } else {
-        if (g.pending) { MG_HIP(hipStreamWaitEvent(s, g.ev_g, 0)); g.pending = false; }
+        if (int rc = wait_gathered(g, s)) return rc;
         if (int rc = dasp_plan_spmv(g.own, g.xg, g.ys[nxt], s)) return rc;
     }
     g.cur = nxt;
@@ -285,6 +303,19 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
     }
     MG_HIP(hipEventCreateWithFlags(&g.ev_y, hipEventDisableTiming));
     MG_HIP(hipEventCreateWithFlags(&g.ev_g, hipEventDisableTiming));
+    {
+        int can = 0;
+        const char *e = std::getenv("DASP_MG_SYNC");                        // "event" forces the event path (A/B, fallback)
+        if (!(e && std::strcmp(e, "event") == 0) && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, g.device) == hipSuccess && can) {
+            void *p = nullptr;
+            // plain device memory: signal memory (hipMallocSignalMemory) only comes in single 8-byte allocations and buys nothing here
+            // (tools/micro/memops.cpp: a hand-off through a plain word costs ~8 us, through an event ~16 us)
+            if (hipMalloc(&p, 2 * sizeof(uint64_t)) == hipSuccess && hipMemset(p, 0, 2 * sizeof(uint64_t)) == hipSuccess) {
+                g.sig = static_cast<uint64_t *>(p); g.use_sig = true;
+            } else if (p) (void)hipFree(p);
+        }
+        (void)hipGetLastError();
+    }
     MG_HIP(hipDeviceSynchronize());
     g.uploaded = true;
     return DASP_OK;
@@ -341,16 +372,23 @@ int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = product(g, s)) return rc;
     // y (this rank's padded slice) -> every rank's gather buffer, on the communication stream, behind the products
-    MG_HIP(hipEventRecord(g.ev_y, s));
-    MG_HIP(hipStreamWaitEvent(g.cs, g.ev_y, 0));
+    const uint64_t k = ++g.step;
+    if (g.use_sig) {
+        MG_HIP(hipStreamWriteValue64(s, &g.sig[0], k, 0));
+        MG_HIP(hipStreamWaitValue64(g.cs, &g.sig[0], k, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+    } else {
+        MG_HIP(hipEventRecord(g.ev_y, s));
+        MG_HIP(hipStreamWaitEvent(g.cs, g.ev_y, 0));
+    }
     if (g.comm) {
         const ncclResult_t r = rccl()->AllGather(g.ys[g.cur], g.yg, (size_t)g.stride, g.precision == 64 ? ncclFloat64 : ncclFloat16, g.comm, g.cs);
         if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
     } else {
         MG_HIP(hipMemcpyAsync(g.yg, g.ys[g.cur], (size_t)g.stride * g.vb(), hipMemcpyDeviceToDevice, g.cs));   // one rank: the gather is a copy
     }
-    MG_HIP(hipEventRecord(g.ev_g, g.cs));
-    g.pending = true;
+    if (g.use_sig) MG_HIP(hipStreamWriteValue64(g.cs, &g.sig[1], k, 0));
+    else MG_HIP(hipEventRecord(g.ev_g, g.cs));
+    g.pending = true; g.pending_step = k;
     return DASP_OK;
 }
 
@@ -363,7 +401,7 @@ int dasp_mg_allgather(dasp_mg_plan_t *mg, void *stream)
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
     if (!g.comm && g.world > 1) { set_error("dasp_mg_allgather needs dasp_mg_comm_init"); return DASP_ERR_STATE; }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (g.pending) { MG_HIP(hipStreamWaitEvent(s, g.ev_g, 0)); g.pending = false; }
+    if (int rc = wait_gathered(g, s)) return rc;
     if (g.comm) {
         const ncclResult_t r = rccl()->AllGather(g.ys[g.cur], g.yg, (size_t)g.stride, g.precision == 64 ? ncclFloat64 : ncclFloat16, g.comm, s);
         if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
@@ -376,8 +414,7 @@ int dasp_mg_allgather(dasp_mg_plan_t *mg, void *stream)
 int dasp_mg_wait(dasp_mg_plan_t *mg, void *stream)
 {
     if (!mg) return DASP_ERR_ARG;
-    if (mg->pending) { MG_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), mg->ev_g, 0)); mg->pending = false; }
-    return DASP_OK;
+    return wait_gathered(*mg, static_cast<hipStream_t>(stream));
 }
 
 int dasp_mg_get_y(dasp_mg_plan_t *mg, void *y_host)
@@ -425,6 +462,7 @@ int dasp_mg_info(const dasp_mg_plan_t *mg, dasp_mg_info_t *out)
     out->row_begin = mg->bounds[(size_t)mg->rank]; out->row_end = mg->bounds[(size_t)mg->rank + 1]; out->stride = mg->stride;
     out->nnz_own = mg->nnz_own; out->nnz_other = mg->nnz_other;
     out->overlap = mg->overlap ? 1 : 0; out->has_comm = mg->comm ? 1 : 0; out->square = mg->square ? 1 : 0;
+    out->stream_memops = mg->use_sig ? 1 : 0;
     return DASP_OK;
 }
 

@@ -283,6 +283,8 @@ typedef struct dasp_mg_info {
     int stride;                    /* padded slice length in elements (multiple of 64) */
     long long nnz_own, nnz_other;  /* nonzeros in the rank's own column range / elsewhere (nnz_other = 0 without the split) */
     int overlap, has_comm, square;
+    int stream_memops;             /* (after dasp_mg_upload) 1: the two streams hand over through hipStreamWriteValue64 / hipStreamWaitValue64
+                                      on two device words; 0: through events (device without support, or DASP_MG_SYNC=event) */
 } dasp_mg_info_t;
 
 /* contiguous row ranges with equal nonzero counts: bounds[0]=0 <= ... <= bounds[n_parts]=rowA */
