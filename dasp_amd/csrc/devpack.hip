@@ -375,6 +375,21 @@ int devpack_all(Plan &p, const DevCsr &d, const PackMeta &m)
     return rc;
 }
 
+// test hook of the multi-GPU choreography (multigpu.cpp, DASP_MG_FAKE_ALLGATHER_US): a kernel that occupies `stream` for ~micros
+// microseconds (one lane polling the 100 MHz wall clock), standing in for the duration of an all-gather on a one-GPU box
+__global__ void k_spin_us(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+int devpack_spin(void *stream, int micros)
+{
+    if (micros <= 0) return DASP_OK;
+    hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), (long long)micros * 100);
+    HIP_TRYP(hipGetLastError());
+    return DASP_OK;
+}
+
 // copy a packed array back to the host (tests; serialising a device-built plan)
 int download_array(Plan &p, const char *name, void *dst, size_t bytes)
 {

@@ -29,6 +29,8 @@
 
 using namespace dasp;
 
+namespace dasp { int devpack_spin(void *stream, int micros); }
+
 namespace {
 
 struct RcclApi {
@@ -110,6 +112,7 @@ struct dasp_mg_plan {
     uint64_t *sig = nullptr;           // device words: [0] = products of step k done, [1] = all-gather of step k done
     uint64_t step = 0, pending_step = 0;
     bool use_sig = false;
+    int fake_us = -1;                  // test hook DASP_MG_FAKE_ALLGATHER_US: world > 1 without a communicator, the exchange = local copy + a kernel of that duration
     ncclComm_t comm = nullptr;
 
     size_t vb() const { return precision == 64 ? 8 : 2; }
@@ -316,6 +319,7 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
         }
         (void)hipGetLastError();
     }
+    if (const char *e = std::getenv("DASP_MG_FAKE_ALLGATHER_US")) g.fake_us = std::atoi(e);
     MG_HIP(hipDeviceSynchronize());
     g.uploaded = true;
     return DASP_OK;
@@ -368,7 +372,7 @@ int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream)
     if (!mg) return DASP_ERR_ARG;
     dasp_mg_plan &g = *mg;
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
-    if (!g.comm && g.world > 1) { set_error("dasp_mg_spmv needs dasp_mg_comm_init (or use dasp_mg_product with your own exchange)"); return DASP_ERR_STATE; }
+    if (!g.comm && g.world > 1 && g.fake_us < 0) { set_error("dasp_mg_spmv needs dasp_mg_comm_init (or use dasp_mg_product with your own exchange)"); return DASP_ERR_STATE; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = product(g, s)) return rc;
     // y (this rank's padded slice) -> every rank's gather buffer, on the communication stream, behind the products
@@ -383,8 +387,9 @@ int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream)
     if (g.comm) {
         const ncclResult_t r = rccl()->AllGather(g.ys[g.cur], g.yg, (size_t)g.stride, g.precision == 64 ? ncclFloat64 : ncclFloat16, g.comm, g.cs);
         if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
-    } else {
-        MG_HIP(hipMemcpyAsync(g.yg, g.ys[g.cur], (size_t)g.stride * g.vb(), hipMemcpyDeviceToDevice, g.cs));   // one rank: the gather is a copy
+    } else {   // one rank (or the test hook): the gather is a copy of the own slice into its slot, plus the emulated duration
+        MG_HIP(hipMemcpyAsync(static_cast<char *>(g.yg) + (size_t)g.rank * g.stride * g.vb(), g.ys[g.cur], (size_t)g.stride * g.vb(), hipMemcpyDeviceToDevice, g.cs));
+        if (g.world > 1) if (int rc = devpack_spin(g.cs, g.fake_us)) return rc;
     }
     if (g.use_sig) MG_HIP(hipStreamWriteValue64(g.cs, &g.sig[1], k, 0));
     else MG_HIP(hipEventRecord(g.ev_g, g.cs));
