@@ -222,9 +222,8 @@ class Plan:
 
     def spmv(self, dX, dY, stream=0, accumulate=False):
         """dX, dY: integer device addresses (e.g. torch_tensor.data_ptr()); stream: hipStream_t as int.
-        accumulate: y += A x instead of y = A x (dasp_plan_spmv_acc); accumulate="atomic": with f64 atomic adds (dasp_plan_spmv_atomic)."""
-        L = _lib.lib()
-        f = L.dasp_plan_spmv_atomic if accumulate == "atomic" else (L.dasp_plan_spmv_acc if accumulate else L.dasp_plan_spmv)
+        accumulate: y += A x instead of y = A x (dasp_plan_spmv_acc)."""
+        f = _lib.lib().dasp_plan_spmv_acc if accumulate else _lib.lib().dasp_plan_spmv
         _lib.check(f(self._h, C.c_void_p(dX), C.c_void_p(dY), C.c_void_p(stream)))
 
     def time(self, dX, dY, stream=0, warmup=100, iters=1000):

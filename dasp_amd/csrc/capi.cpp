@@ -17,7 +17,7 @@
 namespace dasp {
 const char *last_error_cstr();
 int upload_plan(Plan &p);
-int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, int accumulate);
+int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate);
 int time_spmv(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, double *wall_ms, double *event_ms);
 int time_spmv_graph(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, int batch, double *wall_ms, double *event_ms);
 int selftest_mfma();
@@ -297,19 +297,13 @@ int dasp_plan_set_stream_policy(dasp_plan_t *plan, int policy)
 int dasp_plan_spmv(dasp_plan_t *plan, const void *dX, void *dY, void *stream)
 {
     if (!plan) return DASP_ERR_ARG;
-    return launch_spmv(plan->impl, dX, dY, stream, 0);
+    return launch_spmv(plan->impl, dX, dY, stream, false);
 }
 
 int dasp_plan_spmv_acc(dasp_plan_t *plan, const void *dX, void *dY, void *stream)
 {
     if (!plan) return DASP_ERR_ARG;
-    return launch_spmv(plan->impl, dX, dY, stream, 1);
-}
-
-int dasp_plan_spmv_atomic(dasp_plan_t *plan, const void *dX, void *dY, void *stream)
-{
-    if (!plan) return DASP_ERR_ARG;
-    return launch_spmv(plan->impl, dX, dY, stream, 2);
+    return launch_spmv(plan->impl, dX, dY, stream, true);
 }
 
 int dasp_plan_time(dasp_plan_t *plan, const void *dX, void *dY, void *stream, int warmup, int iters, double *wall_ms,

@@ -29,7 +29,7 @@ struct DevArgs {
     const int *med_dst; const int *win_cmin; const int *win_len;
     int n_windows, blocks_per_win;
     int win_hybrid;   // windows stage their densest span only: a gather outside [cmin, cmin + len) reads global memory
-    int acc;   // 1: y += A x (every y index has exactly one writer per launch, so a plain read-modify-write is exact); 2: f64 atomic add
+    int acc;   // 1: y += A x (every y index has exactly one writer per launch, so a plain read-modify-write is exact)
     int wpw;   // waves per workgroup of this launch (4, or blocks_per_win in windowed mode)
     // short
     const void *short_val; const int *short_cid; const ShortDev *groups;

@@ -352,16 +352,11 @@ __device__ __forceinline__ void run_stream(ACC &acc, const SRC &src, int N, cons
     FinishDispatch<T, U, U - 1, SRC, ACC, XV>::run(acc, src, cur, i - U, i, rem, x);
 }
 
-// the one store of a row's result: y = v, or y += v in accumulate mode (wave-uniform flag; one writer per y index and launch)
+// the one store of a row's result: y = v, or y += v in accumulate mode (wave-uniform flag; one writer per y index)
 template <class T, class P>
 __device__ __forceinline__ void put_y(const DevArgs &a, int yi, P v)
 {
     T *y = static_cast<T *>(a.y) + yi;
-    if constexpr (sizeof(T) == 8) {
-        // acc == 2: hardware f64 atomic add (global_atomic_add_f64, no CAS loop): several launches -- of different plans, on different
-        // streams -- may add into one zeroed y at the same time (dasp_plan_spmv_atomic; the multi-GPU own / other column products)
-        if (a.acc == 2) { unsafeAtomicAdd(y, (double)v); return; }
-    }
     *y = a.acc ? (T)((P)*y + v) : (T)v;
 }
 
@@ -893,16 +888,15 @@ int set_stream_policy(Plan &p, int policy)
     return DASP_OK;
 }
 
-int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, int accumulate)      // 0: y = A x, 1: y += A x (read-modify-write), 2: atomic y += A x (f64)
+int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate)
 {
     if (!p.dev || !p.dev->arena) { set_error("plan not uploaded"); return DASP_ERR_STATE; }
     if (!dX || !dY) { set_error("null device pointer"); return DASP_ERR_ARG; }
-    if (accumulate == 2 && (p.precision != 64 || !p.panels.empty())) { set_error("atomic accumulation: f64 plans without column panels only"); return DASP_ERR_ARG; }
     if (!p.panels.empty()) {
         const size_t vb = (size_t)p.geo.vbytes, stride = p.dev->ypart_stride;
         char *part = static_cast<char *>(p.dev->arena);
         for (size_t k = 0; k < p.panels.size(); ++k)
-            if (int rc = launch_spmv(p.panels[k]->impl, dX, part + k * stride * vb, stream, 0)) return rc;
+            if (int rc = launch_spmv(p.panels[k]->impl, dX, part + k * stride * vb, stream, false)) return rc;
         hipStream_t s = static_cast<hipStream_t>(stream);
         const int np = (int)p.panels.size(), m = p.m;
         const bool wide = (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
@@ -922,7 +916,7 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, int accumulate)
         set_error("dX must be 16-byte aligned for a plan with LDS-staged x windows"); return DASP_ERR_ARG;
     }
     DevArgs a = p.dev->args;
-    a.x = dX; a.y = dY; a.acc = accumulate;
+    a.x = dX; a.y = dY; a.acc = accumulate ? 1 : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.precision == 64 ? launch_typed<double>(p, a, s) : launch_typed<_Float16>(p, a, s);
 }
@@ -947,14 +941,14 @@ struct GraphHolder {
 int time_spmv(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, double *wall_ms, double *event_ms)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    for (int i = 0; i < warmup; ++i) if (int rc = launch_spmv(p, dX, dY, stream, 0)) return rc;
+    for (int i = 0; i < warmup; ++i) if (int rc = launch_spmv(p, dX, dY, stream, false)) return rc;
     HIP_TRY(hipStreamSynchronize(s));
     EventPair ev;
     HIP_TRY(hipEventCreate(&ev.e0));
     HIP_TRY(hipEventCreate(&ev.e1));
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipEventRecord(ev.e0, s));
-    for (int i = 0; i < iters; ++i) if (int rc = launch_spmv(p, dX, dY, stream, 0)) return rc;
+    for (int i = 0; i < iters; ++i) if (int rc = launch_spmv(p, dX, dY, stream, false)) return rc;
     HIP_TRY(hipEventRecord(ev.e1, s));
     HIP_TRY(hipStreamSynchronize(s));
     const auto t1 = std::chrono::steady_clock::now();
@@ -980,7 +974,7 @@ int time_spmv_graph(Plan &p, const void *dX, void *dY, void *stream, int warmup,
     }
     HIP_TRY(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
     int rc = DASP_OK;
-    for (int i = 0; i < batch && rc == DASP_OK; ++i) rc = launch_spmv(p, dX, dY, cap, 0);
+    for (int i = 0; i < batch && rc == DASP_OK; ++i) rc = launch_spmv(p, dX, dY, cap, false);
     const hipError_t ee = hipStreamEndCapture(cap, &g.graph);      // always end the capture, even after a failed launch
     if (rc != DASP_OK) return rc;
     HIP_TRY(ee);

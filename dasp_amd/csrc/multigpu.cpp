@@ -109,11 +109,7 @@ struct dasp_mg_plan {
     // cross-stream hand-offs by stream memory operations where the device supports them (hipStreamWriteValue64 on the producing
     // stream, hipStreamWaitValue64 on the consuming one, on two counters in device memory): the command processors poll a word
     // instead of going through an event's signal + barrier packet (measured, world size 1: device time of a step 95 -> see DESIGN 5)
-    uint64_t *sig = nullptr;           // device words: [0] = products (own product) of step k done, [1] = all-gather of step k done,
-                                       // concurrent mode: [2] = y target of step k zeroed, [3] = other-column product of step k done
-    bool concurrent = false;           // own-column product on the caller's stream and other-column product on the communication stream, both adding
-                                       // atomically into a zeroed y slice (f64, memory-operation hand-offs): see dasp_mg_spmv
-    uint64_t other_done = 0;           // last step whose "other product done" word will be written (what the next own product waits for)
+    uint64_t *sig = nullptr;           // device words: [0] = products of step k done, [1] = all-gather of step k done
     uint64_t step = 0, pending_step = 0;
     bool use_sig = false;
     int fake_us = -1;                  // test hook DASP_MG_FAKE_ALLGATHER_US: world > 1 without a communicator, the exchange = local copy + a kernel of that duration
@@ -217,17 +213,9 @@ int wait_gathered(dasp_mg_plan &g, hipStream_t s)
     return DASP_OK;
 }
 
-// after a concurrent step the slice is complete only once the communication stream has run the other-column product
-int wait_other(dasp_mg_plan &g, hipStream_t s)
-{
-    if (g.concurrent && g.other_done) MG_HIP(hipStreamWaitValue64(s, &g.sig[3], g.other_done, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
-    return DASP_OK;
-}
-
 int product(dasp_mg_plan &g, hipStream_t s)
 {
     const int cur = g.cur, nxt = 1 - g.cur;
-    if (int rc = wait_other(g, s)) return rc;
     if (g.overlap) {
         // own columns: needs only this rank's slice of x, i.e. its own previous y -- no communication
         if (int rc = dasp_plan_spmv(g.own, g.ys[cur], g.ys[nxt], s)) return rc;
@@ -325,18 +313,13 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
             void *p = nullptr;
             // plain device memory: signal memory (hipMallocSignalMemory) only comes in single 8-byte allocations and buys nothing here
             // (tools/micro/memops.cpp: a hand-off through a plain word costs ~8 us, through an event ~16 us)
-            if (hipMalloc(&p, 4 * sizeof(uint64_t)) == hipSuccess && hipMemset(p, 0, 4 * sizeof(uint64_t)) == hipSuccess) {
+            if (hipMalloc(&p, 2 * sizeof(uint64_t)) == hipSuccess && hipMemset(p, 0, 2 * sizeof(uint64_t)) == hipSuccess) {
                 g.sig = static_cast<uint64_t *>(p); g.use_sig = true;
             } else if (p) (void)hipFree(p);
         }
         (void)hipGetLastError();
     }
     if (const char *e = std::getenv("DASP_MG_FAKE_ALLGATHER_US")) g.fake_us = std::atoi(e);
-    {
-        const char *e = std::getenv("DASP_MG_CONCURRENT");                   // "0": keep the two products on one stream (A/B, fallback)
-        g.concurrent = g.use_sig && g.overlap && g.other && g.precision == 64 && dasp_plan_panel_count(g.own) == 0 &&
-                       dasp_plan_panel_count(g.other) == 0 && !(e && std::atoi(e) == 0);
-    }
     MG_HIP(hipDeviceSynchronize());
     g.uploaded = true;
     return DASP_OK;
@@ -391,54 +374,23 @@ int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream)
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
     if (!g.comm && g.world > 1 && g.fake_us < 0) { set_error("dasp_mg_spmv needs dasp_mg_comm_init (or use dasp_mg_product with your own exchange)"); return DASP_ERR_STATE; }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const uint64_t all = 0xFFFFFFFFFFFFFFFFull;
-    auto exchange = [&](hipStream_t on) -> int {      // y slice -> every rank's gather buffer (or the one-rank / test-hook stand-in)
-        if (g.comm) {
-            const ncclResult_t r = rccl()->AllGather(g.ys[g.cur], g.yg, (size_t)g.stride, g.precision == 64 ? ncclFloat64 : ncclFloat16, g.comm, on);
-            if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
-        } else {   // one rank (or the test hook): the gather is a copy of the own slice into its slot, plus the emulated duration
-            MG_HIP(hipMemcpyAsync(static_cast<char *>(g.yg) + (size_t)g.rank * g.stride * g.vb(), g.ys[g.cur], (size_t)g.stride * g.vb(), hipMemcpyDeviceToDevice, on));
-            if (g.world > 1) if (int rc = devpack_spin(on, g.fake_us)) return rc;
-        }
-        return DASP_OK;
-    };
-    if (g.concurrent) {
-        // The two products of a step run CONCURRENTLY: own columns on the caller's stream, other columns on the communication stream right
-        // behind the previous all-gather (in order there: no hand-off), both adding with f64 atomics into the zeroed slice (two addends per
-        // element: the sum does not depend on their order).  The caller's stream then carries back-to-back own-column products only:
-        //   caller's stream : wait other(k-1) | zero y_k | signal zeroed(k) | own_k (atomic) | signal own(k)
-        //   comm stream     : wait zeroed(k) | other_k (atomic, reads gathered k-1) | signal other(k) | wait own(k) | all-gather_k | signal gathered(k)
-        // other(k-1) done implies all-gather(k-2) done (same stream), so the buffer zeroed for step k is no longer being sent; own_k reads
-        // y_(k-1) = own + other of step k-1, hence the first wait.
-        const uint64_t k = ++g.step;
-        const int cur = g.cur, nxt = 1 - g.cur;
-        if (g.other_done) MG_HIP(hipStreamWaitValue64(s, &g.sig[3], g.other_done, hipStreamWaitValueGte, all));
-        MG_HIP(hipMemsetAsync(g.ys[nxt], 0, (size_t)g.stride * g.vb(), s));
-        MG_HIP(hipStreamWriteValue64(s, &g.sig[2], k, 0));
-        if (int rc = dasp_plan_spmv_atomic(g.own, g.ys[cur], g.ys[nxt], s)) return rc;
-        MG_HIP(hipStreamWriteValue64(s, &g.sig[0], k, 0));
-        MG_HIP(hipStreamWaitValue64(g.cs, &g.sig[2], k, hipStreamWaitValueGte, all));
-        if (int rc = dasp_plan_spmv_atomic(g.other, g.yg, g.ys[nxt], g.cs)) return rc;
-        MG_HIP(hipStreamWriteValue64(g.cs, &g.sig[3], k, 0));
-        g.other_done = k;
-        MG_HIP(hipStreamWaitValue64(g.cs, &g.sig[0], k, hipStreamWaitValueGte, all));
-        g.cur = nxt;
-        if (int rc = exchange(g.cs)) return rc;
-        MG_HIP(hipStreamWriteValue64(g.cs, &g.sig[1], k, 0));
-        g.pending = true; g.pending_step = k;
-        return DASP_OK;
-    }
     if (int rc = product(g, s)) return rc;
     // y (this rank's padded slice) -> every rank's gather buffer, on the communication stream, behind the products
     const uint64_t k = ++g.step;
     if (g.use_sig) {
         MG_HIP(hipStreamWriteValue64(s, &g.sig[0], k, 0));
-        MG_HIP(hipStreamWaitValue64(g.cs, &g.sig[0], k, hipStreamWaitValueGte, all));
+        MG_HIP(hipStreamWaitValue64(g.cs, &g.sig[0], k, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
     } else {
         MG_HIP(hipEventRecord(g.ev_y, s));
         MG_HIP(hipStreamWaitEvent(g.cs, g.ev_y, 0));
     }
-    if (int rc = exchange(g.cs)) return rc;
+    if (g.comm) {
+        const ncclResult_t r = rccl()->AllGather(g.ys[g.cur], g.yg, (size_t)g.stride, g.precision == 64 ? ncclFloat64 : ncclFloat16, g.comm, g.cs);
+        if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
+    } else {   // one rank (or the test hook): the gather is a copy of the own slice into its slot, plus the emulated duration
+        MG_HIP(hipMemcpyAsync(static_cast<char *>(g.yg) + (size_t)g.rank * g.stride * g.vb(), g.ys[g.cur], (size_t)g.stride * g.vb(), hipMemcpyDeviceToDevice, g.cs));
+        if (g.world > 1) if (int rc = devpack_spin(g.cs, g.fake_us)) return rc;
+    }
     if (g.use_sig) MG_HIP(hipStreamWriteValue64(g.cs, &g.sig[1], k, 0));
     else MG_HIP(hipEventRecord(g.ev_g, g.cs));
     g.pending = true; g.pending_step = k;
@@ -455,7 +407,6 @@ int dasp_mg_allgather(dasp_mg_plan_t *mg, void *stream)
     if (!g.comm && g.world > 1) { set_error("dasp_mg_allgather needs dasp_mg_comm_init"); return DASP_ERR_STATE; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = wait_gathered(g, s)) return rc;
-    if (int rc = wait_other(g, s)) return rc;
     if (g.comm) {
         const ncclResult_t r = rccl()->AllGather(g.ys[g.cur], g.yg, (size_t)g.stride, g.precision == 64 ? ncclFloat64 : ncclFloat16, g.comm, s);
         if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
@@ -516,7 +467,7 @@ int dasp_mg_info(const dasp_mg_plan_t *mg, dasp_mg_info_t *out)
     out->row_begin = mg->bounds[(size_t)mg->rank]; out->row_end = mg->bounds[(size_t)mg->rank + 1]; out->stride = mg->stride;
     out->nnz_own = mg->nnz_own; out->nnz_other = mg->nnz_other;
     out->overlap = mg->overlap ? 1 : 0; out->has_comm = mg->comm ? 1 : 0; out->square = mg->square ? 1 : 0;
-    out->stream_memops = mg->use_sig ? 1 : 0; out->concurrent_products = mg->concurrent ? 1 : 0;
+    out->stream_memops = mg->use_sig ? 1 : 0;
     return DASP_OK;
 }
 

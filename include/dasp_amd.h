@@ -234,10 +234,6 @@ int dasp_plan_spmv(dasp_plan_t *plan, const void *dX, void *dY, void *stream);
  * read-modify-write (deterministic; f16: old y widened to f32, added, rounded once).  Lets a matrix split by columns
  * into several plans (dasp_mg_spmv: own / other ranks' columns) produce one y without a separate add. */
 int dasp_plan_spmv_acc(dasp_plan_t *plan, const void *dX, void *dY, void *stream);
-/* y += A*x with hardware f64 atomic adds (DASP_F64 plans without column panels): launches of DIFFERENT plans on DIFFERENT streams may
- * add into the same y at the same time; the caller zeroes y first.  With two addends per element (dasp_mg_spmv: own-column and
- * other-column product) the result does not depend on the order: 0 + a + b == 0 + b + a exactly. */
-int dasp_plan_spmv_atomic(dasp_plan_t *plan, const void *dX, void *dY, void *stream);
 
 /* the reference's timing protocol (dasp_f64.h:1285-1320,1394): `warmup` untimed + `iters`
  * timed back-to-back SpMVs on `stream`, one sync at the end.
@@ -289,8 +285,6 @@ typedef struct dasp_mg_info {
     int overlap, has_comm, square;
     int stream_memops;             /* (after dasp_mg_upload) 1: the two streams hand over through hipStreamWriteValue64 / hipStreamWaitValue64
                                       on two device words; 0: through events (device without support, or DASP_MG_SYNC=event) */
-    int concurrent_products;       /* (after dasp_mg_upload) 1: own-column product on the caller's stream and other-column product on the
-                                      communication stream at the same time, both adding with f64 atomics into the zeroed slice */
 } dasp_mg_info_t;
 
 /* contiguous row ranges with equal nonzero counts: bounds[0]=0 <= ... <= bounds[n_parts]=rowA */
@@ -314,11 +308,7 @@ int dasp_mg_comm_init(dasp_mg_plan_t *mg, const void *id);
 int dasp_mg_set_x(dasp_mg_plan_t *mg, const void *x_host);
 /* one iteration, asynchronous: own-column product | wait for the previous all-gather | other-column product (y +=) on
  * `stream`, then ncclAllGather(y slice -> gather buffer) on the communication stream behind them.  Square matrices: the
- * gathered y is the next call's x.  Rectangular: x stays what dasp_mg_set_x stored.
- * f64 with the own / other split and stream memory operations available (dasp_mg_info.concurrent_products): the other-column
- * product runs on the communication stream right behind the previous all-gather, concurrently with the own-column product on
- * `stream`; both add with f64 atomics into the zeroed slice (two addends per element: order-independent, bit-identical to the
- * sequential form), so `stream` carries back-to-back own-column products only.  DASP_MG_CONCURRENT=0 keeps the sequential form. */
+ * gathered y is the next call's x.  Rectangular: x stays what dasp_mg_set_x stored. */
 int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream);
 /* the products of one iteration only (no exchange): for callers that move dasp_mg_y_local into every rank's
  * dasp_mg_gathered themselves (tests; transports other than RCCL) */

@@ -423,43 +423,6 @@ def test_mg_spmv_world_size_one_against_the_oracle(oracle, dasp, torch_cuda, pre
     mg.close()
 
 
-def test_mg_concurrent_products_are_bit_identical_to_the_sequential_form(oracle, dasp, torch_cuda, monkeypatch):
-    """dasp_mg_spmv for one rank of a 4-way partition (test hook DASP_MG_FAKE_ALLGATHER_US: no communicator, the exchange is a local
-    copy + a short kernel): the concurrent form (own-column product on the caller's stream, other-column product on the communication
-    stream, f64 atomic adds into the zeroed slice) gives bit for bit what the sequential form (y = own; y += other) gives, over chained
-    steps, and the first step equals the oracle's product of the rank's rows"""
-    from dasp_amd.multi import MgPlan
-    m = n = 6000
-    rp, ci, v = util.mixed_matrix(m, n, 41)
-    v = v / np.maximum(np.repeat(np.diff(rp), np.diff(rp)), 1)
-    world, rank = 4, 1
-    bounds = dasp.partition_rows(rp, world)
-    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
-    sl = slice(rp[r0], rp[r1])
-    x0 = np.random.default_rng(2).uniform(-1, 1, n)
-    monkeypatch.setenv("DASP_MG_FAKE_ALLGATHER_US", "5")
-    out = {}
-    for conc in ("1", "0"):
-        monkeypatch.setenv("DASP_MG_CONCURRENT", conc)
-        mg = MgPlan(rp[r0:r1 + 1] - rp[r0], ci[sl], v[sl], m, n, bounds, rank).upload()
-        info = mg.info
-        assert info["overlap"] == 1 and info["nnz_other"] > 0 and info["concurrent_products"] == int(conc) and info["stream_memops"] == 1
-        mg.set_x(x0)
-        ys = []
-        for it in range(4):
-            mg.spmv(0)
-            mg.wait(0)
-            ys.append(mg.get_y_local())
-        out[conc] = ys
-        mg.close()
-    for a, b in zip(out["1"], out["0"]):
-        assert np.array_equal(a, b)
-    ref = oracle.csr_spmv(rp, ci, v, x0)[r0:r1]
-    scale = np.maximum(oracle.csr_absrow(rp, ci, v, x0)[r0:r1], 1e-300)
-    assert (np.abs(out["1"][0] - ref) <= 1e-12 * scale).all()
-    assert not np.array_equal(out["1"][0], out["1"][1])                   # the chain really moves
-
-
 def test_bench_bare_multi_gpu_launch_needs_that_many_devices(torch_cuda):
     """`python bench.py --gpus 2` without a launcher on a one-GPU box: a clear error and rc 4, not a usage error"""
     import sys

@@ -35,14 +35,14 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     if oth is not None:
         xo = torch.ones(oth.x_len, dtype=torch.float64, device="cuda")
         t_oth = oth.time(xo.data_ptr(), y.data_ptr(), s, warmup=5, iters=100)[1]
-    print("fake all-gather %3s us  overlap=%d  memops=%d concurrent=%d | step %.1f us | own-column product alone %.1f us (%d nnz), other-column %.1f us (%d nnz)" %
-          (os.environ.get("DASP_MG_FAKE_ALLGATHER_US"), overlap, mg.info["stream_memops"], mg.info["concurrent_products"], e0.elapsed_time(e1) / n * 1e3, t_own * 1e3, mg.nnz_local, t_oth * 1e3, mg.nnz_remote), flush=True)
+    print("fake all-gather %3s us  overlap=%d  memops=%d | step %.1f us | own-column product alone %.1f us (%d nnz), other-column %.1f us (%d nnz)" %
+          (os.environ.get("DASP_MG_FAKE_ALLGATHER_US"), overlap, mg.info["stream_memops"], e0.elapsed_time(e1) / n * 1e3, t_own * 1e3, mg.nnz_local, t_oth * 1e3, mg.nnz_remote), flush=True)
     sys.exit(0)
 world = sys.argv[1] if len(sys.argv) > 1 else "8"
 rank = sys.argv[2] if len(sys.argv) > 2 else "3"
 name = sys.argv[3] if len(sys.argv) > 3 else "HV15R"
-for overlap, conc in (("1", "1"), ("1", "0"), ("0", "0")):
+for overlap in ("1", "0"):
     for us in ("0", "20", "40", "60", "80"):
-        env = dict(os.environ, DASP_MG_FAKE_ALLGATHER_US=us, DASP_MG_CONCURRENT=conc)
+        env = dict(os.environ, DASP_MG_FAKE_ALLGATHER_US=us)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", world, rank, name, overlap], env=env, capture_output=True, text=True)
         print("\n".join(l for l in (r.stdout + r.stderr).splitlines() if "fake all-gather" in l or "Error" in l or "error" in l), flush=True)
