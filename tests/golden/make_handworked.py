@@ -25,6 +25,16 @@ Case "small24" (24 rows, block_longest 256), row: length
   f64: 5 10 | 18 7 15 22 3 9 20 14 | 1 8 17 | 0 11 19 | 6 16 23 | 4 12 21 | 2 13
   f16: 5 10 | 18 7 15 22 3 9 20 14 | 0 11 19 | 6 16 23 | 4 12 21 | 1 8 17 | 2 13
 
+  Regular / irregular split of the one block of 8 sorted medium rows, lengths 255 12 12 9 7 7 7 5 (src/dasp_f64.h:1044-1091: chunk k of a block is
+  kept while sum over its rows of min(4, max(0, len - 4(k-1))) >= 0.75 * 32 = 24):
+    k=1: 4 x 8 = 32 -> kept ; k=2: 4+4+4+4+3+3+3+1 = 26 -> kept ; k=3: 4+4+4+1+0+0+0+0 = 13 -> stop.
+    blockPtr[0] = 2 * 32 = 64 ; irreg_len = max(len - 8, 0) = 247 4 4 1 0 0 0 0 -> irreg_rpt (scan) 0 247 251 255 256 256 256 256 256, nnz_irreg = 256 ;
+    blocknum = ceil(8/8) = 1 rounded up to a multiple of 4 * rowloop = 4 (:1045) -> blockPtr (scan) 0 64 64 64 64, fill0_nnz_reg = 64 (f64).
+    f16 rounds every block's span up to a multiple of 128 (src/dasp_f16.h:1356): blockPtr 0 128 128 128 128, fill0_nnz_reg = 128.
+    origin_nnz_reg = nnzA - nnz_irreg - nnz_long - nnz_short = 900 - 256 - 556 - 30 = 58 (:1091)  (= 8+8+8+8+7+7+7+5).
+  Long rows 256 and 300 (src/dasp_f64.h:1000-1039): ceil(len / 64) = 4 and 5 warps -> long_rpt_new 0 4 9, 9 warps rounded up to a multiple of 4 = 12,
+    fill0_nnz_long = 12 * 64 = 768 (f64).  f16: groups of 256 (src/dasp_f16.h:1273-1314): 1 and 2 warps -> 0 1 3, rounded to 4, fill0_nnz_long = 1024.
+
 Case "pairs300" (300 rows): rows 0..271: length 1 if the row id is even, 3 if odd (136 of each: short_rid_1 = 0 2 4 .. 270,
   short_rid_3 = 1 3 5 .. 271); 272..279: length 2; 280..287: length 4; 288..291: length 0; 292..295: length 6; 296: length 300;
   297..299: length 9.
@@ -44,6 +54,10 @@ small = {
     "block_longest": 256, "lengths": small_len,
     "counters": {"row_long": 2, "row_block": 8, "row_zero": 2, "short_row_1": 3, "short_row_3": 3, "short_row_2": 3, "short_row_4": 3,
                  "common_13": 0, "nnz_short": 30, "nnz_long": 556, "rowloop": 1},
+    "packer_f64": {"nnz_irreg": 256, "origin_nnz_reg": 58, "fill0_nnz_reg": 64, "blocknum": 4, "fill0_nnz_long": 768, "warp_number": 12,
+                   "block_ptr": [0, 64, 64, 64, 64], "irreg_rpt": [0, 247, 251, 255, 256, 256, 256, 256, 256], "long_rpt_new": [0, 4, 9]},
+    "packer_f16": {"nnz_irreg": 256, "origin_nnz_reg": 58, "fill0_nnz_reg": 128, "blocknum": 4, "fill0_nnz_long": 1024, "warp_number": 4,
+                   "block_ptr": [0, 128, 128, 128, 128], "irreg_rpt": [0, 247, 251, 255, 256, 256, 256, 256, 256], "long_rpt_new": [0, 1, 3]},
     "order_f64": [5, 10, 18, 7, 15, 22, 3, 9, 20, 14, 1, 8, 17, 0, 11, 19, 6, 16, 23, 4, 12, 21, 2, 13],
     "order_f16": [5, 10, 18, 7, 15, 22, 3, 9, 20, 14, 0, 11, 19, 6, 16, 23, 4, 12, 21, 1, 8, 17, 2, 13],
 }

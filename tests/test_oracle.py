@@ -184,6 +184,9 @@ def test_handworked_classifier_and_order(oracle, dasp, case, prec):
     assert P.order_rid.tolist() == want_o
     for k, val in want_c.items():
         assert int(getattr(P, k)) == val, (k, "oracle")
+    for k, val in h.get("packer_f%d" % prec, {}).items():              # padded sizes and pointer arrays of the reference-geometry packers
+        got = getattr(P, k)
+        assert (got.tolist() if isinstance(val, list) else int(got)) == val, (k, "oracle packer")
     plan = dasp.Plan(rp, ci, v.astype(np.float64 if prec == 64 else np.float16), n, precision=prec, block_longest=h["block_longest"])
     assert plan.order_rid.tolist() == want_o
     st = plan.stats
