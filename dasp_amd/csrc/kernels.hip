@@ -47,7 +47,6 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-typedef const __attribute__((address_space(1))) unsigned char *gbyte_p;
 
 // ------------------------------------------------------------------ device helpers
 
@@ -110,13 +109,10 @@ __device__ __forceinline__ int slot_of(const SlotMap &m, int t)
 
 // BATCH = chunks per software-pipeline batch, SHOT = longest unit issued in one shot (defaults chosen on the HBM-bound
 // stand-ins, DESIGN.md 4.4: f64 rows of <= 32 nonzeros in one shot: cop20k_A 11.5 -> 10.9 us, HBM-bound stand-ins +0.5-1 %)
-#ifndef DASP_B64
-#define DASP_B64 4
-#endif
 template <class T> struct Tr;
 template <> struct Tr<double> {
     using acc_t = f64x4; using part_t = double;
-    static constexpr int CHUNK = 64, SHORT_ROWS = 128, BATCH = DASP_B64, SHOT = 8;
+    static constexpr int CHUNK = 64, SHORT_ROWS = 128, BATCH = 4, SHOT = 8;
 };
 template <> struct Tr<_Float16> {
     using acc_t = f32x4; using part_t = float;
@@ -150,7 +146,6 @@ __device__ __forceinline__ void frag_load(Frag<T> &f, const T *val, const int *c
 {
     frag_load_at<NT>(f, val, cid, e + (size_t)(Tr<T>::CHUNK / kWave) * lane);
 }
-#define LDS_AS __attribute__((address_space(3)))
 // where x values come from: global memory, or the workgroup's window of x staged in LDS
 template <class T>
 struct XGlobal {
@@ -159,14 +154,14 @@ struct XGlobal {
 };
 template <class T>
 struct XLds {
-    const LDS_AS T *xw; int cmin;
+    const T *xw; int cmin;
     __device__ __forceinline__ T at(int c) const { return xw[c < 0 ? 0 : c - cmin]; }
 };
 // hybrid window: the densest span of the window's columns is in LDS, everything else is gathered from global memory.
 // The two loads sit in divergent branches on purpose: a lane whose column is staged issues no global load.
 template <class T>
 struct XHyb {
-    const LDS_AS T *xw; const T *xg; int cmin; unsigned len;
+    const T *xw; const T *xg; int cmin; unsigned len;
     __device__ __forceinline__ T at(int c) const
     {
         const unsigned o = (unsigned)(c - cmin);
@@ -207,7 +202,6 @@ __device__ __forceinline__ void frag_mfma(f32x4 &acc, const Frag<_Float16> &f)
 // lane-linear chunks only (long pieces)
 template <class T, bool NT>
 struct ChunkSrc {
-    static constexpr bool kPairs = false;
     const T *val; const int *cid; size_t e0; int lane;
     __device__ __forceinline__ void load(Frag<T> &f, int i) const { frag_load<NT>(f, val, cid, e0 + (size_t)i * Tr<T>::CHUNK, lane); }
     template <class XV> __device__ __forceinline__ void gather(Frag<T> &f, int, const XV &x) const { frag_gather(f, x); }
@@ -219,28 +213,8 @@ struct ChunkSrc {
 template <class T, bool NT, bool C16>
 struct BlockSrc {
     ChunkSrc<T, NT> reg; int nc;
-    // C16: ids of the regular chunks as offsets from base[chunk].  f64: the block's first n8 (even) chunks one byte per id (columns span
-    // <= 254), pair-interleaved [pair][lane][2]; the others two bytes; e8 / e16 = the block's first element in the two planes
-    const unsigned char *cid8; const unsigned short *cid16; const int *base; int c0, n8; size_t e8, e16;
+    const unsigned short *cid16; const int *base; int c0;      // C16: ids of the regular chunks as u16 offsets from base[chunk]
     const T *ival; const int *icid; int t0, t1, kq;
-    static constexpr bool kPairs = C16 && sizeof(T) == 8;
-    // steps i (even) and i + 1: a narrow pair shares ONE id row (one load, one L1 miss); anything else is two single loads
-    __device__ __forceinline__ void load2(Frag<T> &f0, Frag<T> &f1, int i) const
-    {
-        if constexpr (kPairs) {
-            if (i < n8) {                                       // wave-uniform; n8 is even, so i + 1 < n8 too
-                constexpr int CH = Tr<T>::CHUNK;
-                const size_t at = reg.e0 + (size_t)i * CH + reg.lane;
-                f0.a = ldg<NT>(reg.val + at);
-                f1.a = ldg<NT>(reg.val + at + CH);
-                const gbyte_p sb = (gbyte_p)(cid8 + e8 + (size_t)i * CH);
-                const int raw = (int)ldg<NT>((const __attribute__((address_space(1))) unsigned short *)(sb + 2 * reg.lane));
-                f0.c = raw; f1.c = raw;
-                return;
-            }
-        }
-        load(f0, i); load(f1, i + 1);
-    }
     __device__ __forceinline__ void load(Frag<T> &f, int i) const
     {
         if (i < nc) {
@@ -249,13 +223,8 @@ struct BlockSrc {
                 constexpr int CH = Tr<T>::CHUNK;
                 const size_t at = reg.e0 + (size_t)i * CH + (size_t)(CH / kWave) * reg.lane;
                 if constexpr (sizeof(T) == 8) {
-                    // one aligned u16 per lane whatever the chunk's id width, chosen by a wave-uniform base (SGPRs; no branch): a wide chunk's
-                    // own id, or the ids of a PAIR of narrow chunks (2q, 2q+1) -- both chunks of the pair read the same 128-byte line, so the
-                    // pair costs one L1 miss.  Decoded in gather().  (Explicitly global: a select of flat pointers is not inferred.)
-                    const bool narrow = i < n8;
-                    const gbyte_p sb = narrow ? (gbyte_p)(cid8 + e8 + (size_t)(i >> 1) * (2 * CH)) : (gbyte_p)(cid16 + e16 + (size_t)(i - n8) * CH);
                     f.a = ldg<NT>(reg.val + at);
-                    f.c = (int)ldg<NT>((const __attribute__((address_space(1))) unsigned short *)(sb + 2 * reg.lane));
+                    f.c = (int)ldg<NT>(cid16 + at);             // raw offset; rebased in gather()
                 } else {
                     f.a = ldg<NT>(reinterpret_cast<const f16x4 *>(reg.val + at));
                     const u16x4 o = ldg<NT>(reinterpret_cast<const u16x4 *>(cid16 + at));
@@ -300,12 +269,8 @@ struct BlockSrc {
             }
         } else if constexpr (C16) {
             const int b = base[c0 + i];                         // wave-uniform: one scalar load per chunk
-            if constexpr (sizeof(T) == 8) {
-                const bool narrow = i < n8;                     // wave-uniform
-                const unsigned pad = narrow ? 0xFFu : 0xFFFFu;
-                const unsigned o = ((unsigned)f.c >> (narrow ? 8 * (i & 1) : 0)) & pad;
-                f.c = o == pad ? -1 : b + (int)o;
-            } else {
+            if constexpr (sizeof(T) == 8) f.c = f.c == 0xFFFF ? -1 : b + f.c;
+            else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) f.c[q] = f.c[q] == 0xFFFF ? -1 : b + f.c[q];
             }
@@ -319,24 +284,12 @@ template <class T, int N, class SRC, class ACC, class XV>
 __device__ __forceinline__ void shot(ACC &acc, const SRC &src, int i0, const XV &x)
 {
     Frag<T> f[N];
-    load_steps<N>(src, f, i0);
+#pragma unroll
+    for (int u = 0; u < N; ++u) src.load(f[u], i0 + u);
 #pragma unroll
     for (int u = 0; u < N; ++u) src.gather(f[u], i0 + u, x);
 #pragma unroll
     for (int u = 0; u < N; ++u) frag_mfma(acc, f[u]);
-}
-// the loads of N consecutive steps from i0 (i0 even); a source with kPairs loads two steps at a time (one id row for a narrow pair)
-template <int N, class SRC, class T>
-__device__ __forceinline__ void load_steps(const SRC &src, Frag<T> *f, int i0)
-{
-    if constexpr (SRC::kPairs) {
-#pragma unroll
-        for (int u = 0; u + 1 < N; u += 2) src.load2(f[u], f[u + 1], i0 + u);
-        if constexpr (N % 2) src.load(f[N - 1], i0 + N - 1);
-    } else {
-#pragma unroll
-        for (int u = 0; u < N; ++u) src.load(f[u], i0 + u);
-    }
 }
 template <class T, int N, class SRC, class ACC, class XV>
 struct ShotDispatch {
@@ -360,7 +313,8 @@ struct FinishDispatch {
             Frag<T> r[R > 0 ? R : 1];
 #pragma unroll
             for (int u = 0; u < U; ++u) src.gather(cur[u], ibase + u, x);
-            load_steps<R>(src, r, i);
+#pragma unroll
+            for (int u = 0; u < R; ++u) src.load(r[u], i + u);
 #pragma unroll
             for (int u = 0; u < U; ++u) frag_mfma(acc, cur[u]);
 #pragma unroll
@@ -381,13 +335,15 @@ __device__ __forceinline__ void run_stream(ACC &acc, const SRC &src, int N, cons
     if (N <= S) { ShotDispatch<T, S, SRC, ACC, XV>::run(acc, src, 0, N, x); return; }
     const int nfull = N / U, rem = N % U;
     Frag<T> cur[U];
-    load_steps<U>(src, cur, 0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) src.load(cur[u], u);
     int i = U;
     for (int it = 1; it < nfull; ++it, i += U) {
         Frag<T> nxt[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) src.gather(cur[u], i - U + u, x);
-        load_steps<U>(src, nxt, i);
+#pragma unroll
+        for (int u = 0; u < U; ++u) src.load(nxt[u], i + u);
 #pragma unroll
         for (int u = 0; u < U; ++u) frag_mfma(acc, cur[u]);
 #pragma unroll
@@ -438,12 +394,7 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     const int nt = (__builtin_amdgcn_readfirstlane(t1 - t0) + TK - 1) / TK;
     BlockSrc<T, NT, C16> src;
     src.reg.val = val; src.reg.cid = a.med_cid; src.reg.e0 = (size_t)c0 * CH; src.reg.lane = lane;
-    src.nc = c1 - c0; src.cid16 = a.med_cid16; src.cid8 = a.med_cid8; src.base = a.med_base; src.c0 = c0;
-    src.n8 = 0; src.e8 = 0; src.e16 = 0;
-    if constexpr (C16) {
-        const int q0 = a.med_c8ptr[b], q1 = a.med_c8ptr[b + 1];
-        src.n8 = q1 - q0; src.e8 = (size_t)q0 * CH; src.e16 = (size_t)(c0 - q0) * CH;
-    }
+    src.nc = c1 - c0; src.cid16 = a.med_cid16; src.base = a.med_base; src.c0 = c0;
     src.ival = static_cast<const T *>(a.irr_val); src.icid = a.irr_cid; src.t0 = t0; src.t1 = t1; src.kq = kq;
     run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, src.nc + nt, x);
 
@@ -601,10 +552,7 @@ __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
 // launch bounds: the windowed kernel is held to 64 registers so that two 1024-thread window workgroups share a CU
 // (A/B: 12.9 vs 15.0 us on cop20k_A); blocks are dealt to workgroups in the default round-robin order (length-sorted
 // blocks in XCD-contiguous ranges put all the long ones on one XCD: DESIGN.md 4.4)
-#ifndef DASP_MINW
-#define DASP_MINW 1
-#endif
-constexpr int kMinWavesPlain = DASP_MINW, kMinWavesWin = 8;
+constexpr int kMinWavesPlain = 1, kMinWavesWin = 8;
 // WIN: windowed mode.  A medium workgroup owns one window of row_window rows (blocks_per_win blocks, strided over its
 // 4 waves); if the window's x span fits, it is copied once into LDS with coalesced 16-byte loads and every gather of
 // the window reads LDS; otherwise that workgroup gathers from global memory like the non-windowed kernel.
@@ -632,11 +580,11 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPla
             const int w = wg - a.wg_long;
             const int len = a.win_len[w], cmin = a.win_cmin[w];
             const T *xg = static_cast<const T *>(a.x);
-            LDS_AS T *xw = (LDS_AS T *)lds_raw;        // explicitly an LDS pointer: ds_read gathers, never a flat load
+            T *xw = reinterpret_cast<T *>(lds_raw);
             if (len > 0) {
                 constexpr int A = 16 / (int)sizeof(T);
                 const i32x4 *src = reinterpret_cast<const i32x4 *>(xg + cmin);
-                LDS_AS i32x4 *dst = (LDS_AS i32x4 *)xw;
+                i32x4 *dst = reinterpret_cast<i32x4 *>(xw);
                 const int nvec = len / A, nth = wpw * kWave;
                 for (int i0 = threadIdx.x; i0 < nvec; i0 += 4 * nth) {       // four 16-byte loads in flight per lane
                     const int i1 = i0 + nth, i2 = i0 + 2 * nth, i3 = i0 + 3 * nth;
@@ -830,9 +778,7 @@ int upload_plan(Plan &p)
     const size_t o_mptr = add(p.med_ptr.data(), p.med_ptr.size() * 4);
     const size_t o_mv = add(src_of(p.med_val), p.cnt_reg * vbytes);
     const size_t o_mc = add(src_of(p.med_cid), p.cid16 ? 0 : p.cnt_reg * 4);
-    const size_t o_mc16 = add(src_of(p.med_cid16), p.cid16 ? (p.cnt_reg - p.cnt_reg8) * 2 : 0);
-    const size_t o_mc8 = add(src_of(p.med_cid8), p.cid16 ? p.cnt_reg8 : 0);
-    const size_t o_c8p = add(p.med_c8ptr.data(), p.med_c8ptr.size() * 4);
+    const size_t o_mc16 = add(src_of(p.med_cid16), p.cid16 ? p.cnt_reg * 2 : 0);
     const size_t o_mb = add(src_of(p.med_base), p.cid16 ? (size_t)p.med_ptr.back() * 4 : 0);
     const size_t o_ip = add(p.irr_ptr.data(), p.irr_ptr.size() * 4);
     const size_t o_iv = add(src_of(p.irr_val), p.cnt_irr * vbytes);
@@ -853,7 +799,7 @@ int upload_plan(Plan &p)
     for (const Item &it : items)
         if (it.src && it.bytes) HIP_TRY(hipMemcpy(base + it.off, it.src, it.bytes, hipMemcpyHostToDevice));
 
-    d->map.long_val = o_lv; d->map.long_cid = o_lc; d->map.med_val = o_mv; d->map.med_cid = o_mc; d->map.med_cid16 = o_mc16; d->map.med_cid8 = o_mc8;
+    d->map.long_val = o_lv; d->map.long_cid = o_lc; d->map.med_val = o_mv; d->map.med_cid = o_mc; d->map.med_cid16 = o_mc16;
     d->map.med_base = o_mb; d->map.irr_val = o_iv; d->map.irr_cid = o_ic; d->map.short_val = o_sv; d->map.short_cid = o_sc;
     DevArgs &a = d->args;
     a.long_val = base + o_lv; a.long_cid = (const int *)(base + o_lc);
@@ -871,7 +817,6 @@ int upload_plan(Plan &p)
     a.wpw = p.windowed ? std::min(16, p.row_window / kMedRows) : kWavesPerWG;
     a.wg_long = (a.n_pieces + a.wpw - 1) / a.wpw;
     a.med_cid16 = (const unsigned short *)(base + o_mc16); a.med_base = (const int *)(base + o_mb);
-    a.med_cid8 = (const unsigned char *)(base + o_mc8); a.med_c8ptr = (const int *)(base + o_c8p);
     a.med_dst = (const int *)(base + o_mdst); a.win_cmin = (const int *)(base + o_wc); a.win_len = (const int *)(base + o_wl);
     a.n_windows = (int)p.win_len.size(); a.blocks_per_win = p.windowed ? p.row_window / kMedRows : 0;
     a.win_hybrid = p.win_hybrid ? 1 : 0;

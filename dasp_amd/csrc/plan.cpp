@@ -510,11 +510,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     // 65534 cannot be stored that way; in cid16 mode the regular part of its block ends there and the rest of those rows
     // joins the irregular tail (32-bit ids).  opt.cid16: 0 = auto (on when that costs < 3 % of the regular elements).
     std::vector<int> nchunks16((size_t)nb + 1, 0);
-    std::vector<int> n8of((size_t)nb + 1, 0);                   // of the chunks kept in cid16 mode, how many span <= 254 columns (one-byte offsets)
     const bool try16 = p.opt.cid16 >= 0 && !meta_only;
-    // narrow chunks (one-byte ids): f64 only -- its 64-byte id rows are what costs an L1 miss-queue slot each; the f16 kernel
-    // is not bound by requests and gains nothing.  DASP_CID8=0: A/B knob, every chunk 16-bit.
-    const bool try8 = !f16 && !(std::getenv("DASP_CID8") && std::atoi(std::getenv("DASP_CID8")) == 0);
     parallel_for(nb, threads, 256, [&](long long b0, long long b1) {
         for (long long b = b0; b < b1; ++b) {
             const int r0 = (int)b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
@@ -525,7 +521,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                 if (!(fill >= threshold * CH) || fill == 0) break;
             }
             nchunks[b] = k;
-            int k16 = k, n8 = 0;
+            int k16 = k;
             if (try16 && !dev) {
                 for (int c = 0; c < k; ++c) {
                     int lo = 2147483647, hi = -1;
@@ -534,16 +530,12 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                         for (int i = i0; i < i1; ++i) { const int col = remap(ci[a0 + i]); lo = std::min(lo, col); hi = std::max(hi, col); }
                     }
                     if (hi >= 0 && (long long)hi - lo > 65534) { k16 = c; break; }
-                    n8 += hi >= 0 && hi - lo <= 254;
                 }
             }
-            nchunks16[b] = k16; n8of[b] = try8 ? (n8 & ~1) : 0;      // even: narrow chunks are stored in pairs
+            nchunks16[b] = k16;
         }
     });
-    if (try16 && dev) {
-        if (int rc = devpack_chunk_spans(p, *dev, ridM, lenM, nchunks, nchunks16.data(), n8of.data())) return rc;
-        for (int &v : n8of) v = try8 ? (v & ~1) : 0;
-    }
+    if (try16 && dev) { if (int rc = devpack_chunk_spans(p, *dev, ridM, lenM, nchunks, nchunks16.data())) return rc; }
     {
         long long e32 = 0, e16 = 0;
         for (int b = 0; b < nb; ++b) { e32 += nchunks[b]; e16 += nchunks16[b]; }
@@ -574,18 +566,10 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     const int nnz_irreg = p.irr_ptr[nmed];
     p.cnt_reg = (size_t)n_reg; p.cnt_irr = (size_t)nnz_irreg;
     p.med_base.assign(p.cid16 && pack ? (size_t)p.med_ptr[nb] : 0, 0);
-    p.med_c8ptr.clear(); p.med_korig.clear(); p.cnt_reg8 = 0;
-    if (p.cid16) {
-        p.med_c8ptr.assign((size_t)nb + 1, 0);
-        for (int b = 0; b < nb; ++b) p.med_c8ptr[(size_t)b + 1] = p.med_c8ptr[b] + n8of[b];
-        p.cnt_reg8 = (size_t)p.med_c8ptr[nb] * CH;
-        p.med_korig.assign((size_t)p.med_ptr[nb], 0);
-    }
     if (pack) {
     p.med_val.resize((size_t)n_reg * sizeof(T));               // not zero-filled: each block pads its own region first
     p.med_cid.resize(p.cid16 ? 0 : (size_t)n_reg);
-    p.med_cid16.resize(p.cid16 ? (size_t)n_reg - p.cnt_reg8 : 0);
-    p.med_cid8.resize(p.cnt_reg8);
+    p.med_cid16.resize(p.cid16 ? (size_t)n_reg : 0);
     p.irr_val.resize((size_t)nnz_irreg * sizeof(T));           // fully covered by the rows' tails
     p.irr_cid.resize((size_t)nnz_irreg);
     }
@@ -593,56 +577,38 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         T *mv = reinterpret_cast<T *>(p.med_val.data());
         T *iv = reinterpret_cast<T *>(p.irr_val.data());
         parallel_for(nb, threads, 64, [&](long long b0, long long b1) {
-            std::vector<int> pos_of, lo_of; std::vector<char> narrow_of;
             for (long long b = b0; b < b1; ++b) {
                 const int nc = p.med_ptr[b + 1] - p.med_ptr[b];
                 const size_t base = (size_t)p.med_ptr[b] * CH;
                 const int r0 = (int)b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
-                // cid16 mode: the chunk stored at position q of the block is the block's chunk pos2k[q]; narrow chunks (columns span <= 254:
-                // one-byte offsets) first, then the wide ones, each group in its original order
-                pos_of.assign((size_t)nc + 1, 0); lo_of.assign((size_t)nc + 1, 0); narrow_of.assign((size_t)nc + 1, 0);
-                const int n8 = p.cid16 ? p.med_c8ptr[b + 1] - p.med_c8ptr[b] : 0;
-                const size_t e8 = p.cid16 ? (size_t)p.med_c8ptr[b] * CH : 0;                                   // this block's narrow chunks in med_cid8
-                const size_t e16 = p.cid16 ? ((size_t)p.med_ptr[b] - (size_t)p.med_c8ptr[b]) * CH : 0;          // its wide chunks in med_cid16
-                if (p.cid16) {
-                    int a8 = 0, a16 = 0;
-                    for (int c = 0; c < nc; ++c) {
-                        int lo = 2147483647, hi = -1;
-                        for (int r = r0; r < r1; ++r) {
-                            const int a0 = rp[ridM[r]], i0 = c * K, i1 = std::min(lenM[r], i0 + K);
-                            for (int i = i0; i < i1; ++i) { const int col = remap(ci[a0 + i]); lo = std::min(lo, col); hi = std::max(hi, col); }
-                        }
-                        narrow_of[c] = a8 < n8 && hi >= 0 && hi - lo <= 254;      // the block's first n8 (even) one-byte-able chunks
-                        lo_of[c] = lo == 2147483647 ? 0 : lo;
-                        pos_of[c] = narrow_of[c] ? a8++ : n8 + a16++;
-                    }
-                    for (int c = 0; c < nc; ++c) {
-                        p.med_base[(size_t)p.med_ptr[b] + pos_of[c]] = lo_of[c];
-                        p.med_korig[(size_t)p.med_ptr[b] + pos_of[c]] = c;
-                    }
-                } else for (int c = 0; c < nc; ++c) pos_of[c] = c;
-                {   // pad the block's region (value 0, id -1 / 0xFFFF / 0xFF); real entries overwrite below
+                {   // pad the block's region (value 0, id -1 / 0xFFFF); real entries overwrite below
                     const size_t n = (size_t)nc * CH;
                     std::fill(mv + base, mv + base + n, (T)0);
-                    if (p.cid16) {
-                        std::fill(p.med_cid8.begin() + e8, p.med_cid8.begin() + e8 + (size_t)n8 * CH, (uint8_t)0xFF);
-                        std::fill(p.med_cid16.begin() + e16, p.med_cid16.begin() + e16 + (size_t)(nc - n8) * CH, (uint16_t)0xFFFF);
-                    } else std::fill(p.med_cid.begin() + base, p.med_cid.begin() + base + n, -1);
+                    if (p.cid16) std::fill(p.med_cid16.begin() + base, p.med_cid16.begin() + base + n, (uint16_t)0xFFFF);
+                    else std::fill(p.med_cid.begin() + base, p.med_cid.begin() + base + n, -1);
                 }
+                if (p.cid16)   // per-chunk base = smallest column of the chunk
+                    for (int c = 0; c < nc; ++c) {
+                        int lo = 2147483647;
+                        for (int r = r0; r < r1; ++r) {
+                            const int a0 = rp[ridM[r]], i0 = c * K, i1 = std::min(lenM[r], i0 + K);
+                            for (int i = i0; i < i1; ++i) lo = std::min(lo, remap(ci[a0 + i]));
+                        }
+                        p.med_base[(size_t)p.med_ptr[b] + c] = lo == 2147483647 ? 0 : lo;
+                    }
                 for (int r = r0; r < r1; ++r) {
                     const int rr = r - r0, row = ridM[r], len = lenM[r], a0 = rp[row];
                     const int nreg = std::min(len, nc * K);
                     for (int i = 0; i < nreg; ++i) {
-                        const int c = i / K, kk = i % K, q = pos_of[c];
+                        const int c = i / K, kk = i % K;
                         // f64: lane = kk*16 + rr holds A[rr][kk]            (one value per lane)
                         // f16: lane = (kk/4)*16 + rr holds A[rr][4*(kk/4)..+3] (four values per lane)
-                        const size_t in_chunk = f16 ? (size_t)(kk / 4) * 64 + rr * 4 + kk % 4 : (size_t)kk * kMedRows + rr;
-                        const size_t at = base + (size_t)q * CH + in_chunk;
+                        const size_t at = f16 ? base + (size_t)c * CH + (size_t)(kk / 4) * 64 + rr * 4 + kk % 4
+                                              : base + (size_t)c * CH + (size_t)kk * kMedRows + rr;
                         mv[at] = val[a0 + i];
                         const int col = remap(ci[a0 + i]);
-                        if (!p.cid16) p.med_cid[at] = col;
-                        else if (narrow_of[c]) p.med_cid8[e8 + (size_t)(q >> 1) * 2 * CH + 2 * in_chunk + (q & 1)] = (uint8_t)(col - lo_of[c]);   // pair-interleaved
-                        else p.med_cid16[e16 + (size_t)(q - n8) * CH + in_chunk] = (uint16_t)(col - lo_of[c]);
+                        if (p.cid16) p.med_cid16[at] = (uint16_t)(col - p.med_base[(size_t)p.med_ptr[b] + c]);
+                        else p.med_cid[at] = col;
                     }
                     const int t0 = p.irr_ptr[r], tl = p.irr_ptr[r + 1] - t0;
                     for (int j = 0; j < tl; ++j) {   // the LAST tl entries of the row (dasp_f64.h:1094-1106)
@@ -715,7 +681,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     s.rate_fill0 = nnz > 0 ? (double)(stored - nnz) / nnz : 0.0;
     const long long sv = geo.vbytes;
     s.cid16_on = p.cid16 ? 1 : 0;
-    s.data_X = (long long)(m + p.n) * sv + stored * (sv + 4) - (p.cid16 ? 2 * n_reg + (long long)p.cnt_reg8 - 5ll * p.med_ptr[nb] - 4ll * (nb + 1) : 0) +
+    s.data_X = (long long)(m + p.n) * sv + stored * (sv + 4) - (p.cid16 ? 2 * n_reg - 4ll * p.med_ptr[nb] : 0) +
                (long long)(p.piece_ptr.size() + p.piece_dst.size() + p.multi_ptr.size() + p.multi_dst.size()) * 4 +
                (long long)(p.med_ptr.size() + p.irr_ptr.size()) * 4 + (natural ? (long long)m * 4 : 0) +
                (long long)(p.med_dst.size() + 2 * p.win_len.size()) * 4;

@@ -103,17 +103,8 @@ struct Plan {
     raw_vector<char> med_val;       // chunk-major, lane-linear inside a chunk
     raw_vector<int> med_cid;        // 32-bit ids (cid16 off)
     bool cid16 = false;
-    raw_vector<uint16_t> med_cid16;  // u16 offsets from med_base[chunk], 0xFFFF = pad (cid16 on): the WIDE chunks only, in position order
+    raw_vector<uint16_t> med_cid16;  // u16 offsets from med_base[chunk], 0xFFFF = pad (cid16 on)
     std::vector<int> med_base;        // [chunks]
-    // narrow chunks (f64, cid16 on; r2): a chunk whose columns span <= 254 stores its offsets in ONE byte (0xFF = pad).  Inside a block the
-    // narrow chunks come first, then the wide ones (a block's chunks are independent MFMA steps: their order is free), so one scalar
-    // compare per step selects the plane; a block keeps an EVEN number of them (an odd last one stays wide) and stores them in pairs,
-    // [pair][lane][2 chunks], so that the two id rows of a pair are one 128-byte line = one L1 miss.  med_c8ptr[b] = narrow chunks before
-    // block b, hence wide chunks before it = med_ptr[b] - med_c8ptr[b].
-    raw_vector<uint8_t> med_cid8;     // CH bytes per narrow chunk
-    std::vector<int> med_c8ptr;       // [nb+1]
-    std::vector<int> med_korig;  // [chunks] which chunk of its block (entries K*k .. K*k+K-1 of the rows) sits at this position
-    size_t cnt_reg8 = 0;              // elements of the narrow chunks (cnt_reg counts all regular elements)
     int n_mfma_rows = 0;            // medium rows handled as MFMA blocks (the shortest are slabs, see grp[5..]; the longest may be pieces)
     int med_slot0 = 0;              // slot of the first MFMA medium row: row_long + the medium rows stored as pieces (opt.piece_min_len)
     std::vector<int> irr_ptr;       // [n_mfma_rows+1]
@@ -163,9 +154,8 @@ int devpack_line_scatter(const Plan &p, const DevCsr &d, const std::vector<int> 
 // over pairs of equally long rows (rows[2i], rows[2i+1]): entries compared, and how many lie within 16 columns of the other row's
 // entry at the same position
 int devpack_row_coherence(const Plan &p, const DevCsr &d, const std::vector<int> &rows, long long *near, long long *entries);
-// per block: k16 = leading chunks (of the nchunks the fill rule keeps) whose columns span <= 65534, n8 = how many of those span <= 254
 int devpack_chunk_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridM, const std::vector<int> &lenM,
-                        const std::vector<int> &nchunks, int *k16, int *n8);
+                        const std::vector<int> &nchunks, int *k16);
 int devpack_all(Plan &p, const DevCsr &d, const PackMeta &m);
 
 // builds every host array of `p` from CSR.  T = double or _Float16.  With `dev` set, rp is a host copy of the row pointer,

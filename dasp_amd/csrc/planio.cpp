@@ -1,7 +1,7 @@
 // planio.cpp -- serialised plans (the reference never stores its packed format).
 // A plan file holds every host array of a Plan, so a later run (or every rank of a multi-GPU job)
 // skips classification and packing: load -> upload -> spmv.
-// layout: "DASPPLN5" | int32 sizeof(dasp_stats_t), kNumShortGroups, sizeof(ShortGroup) | plan, where plan = int32 precision, m, n, nnz,
+// layout: "DASPPLN4" | int32 sizeof(dasp_stats_t), kNumShortGroups, sizeof(ShortGroup) | plan, where plan = int32 precision, m, n, nnz,
 //         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows, win_hybrid, med_slot0 | dasp_stats_t |
 //         ShortGroup[kNumShortGroups] | for each array, in a fixed order: int64 byte count + bytes | the n_panels column panels, each
 //         a nested plan.
@@ -46,7 +46,7 @@ template <class IO> void arrays(IO &io, Plan &p)
 {
     io.vec(p.part_bounds); io.vec(p.order); io.vec(p.dst_map); io.vec(p.panel_bounds);
     io.vec(p.long_val); io.vec(p.long_cid); io.vec(p.piece_ptr); io.vec(p.piece_dst); io.vec(p.multi_ptr); io.vec(p.multi_dst);
-    io.vec(p.med_ptr); io.vec(p.med_val); io.vec(p.med_cid); io.vec(p.med_cid16); io.vec(p.med_cid8); io.vec(p.med_c8ptr); io.vec(p.med_korig); io.vec(p.med_base);
+    io.vec(p.med_ptr); io.vec(p.med_val); io.vec(p.med_cid); io.vec(p.med_cid16); io.vec(p.med_base);
     io.vec(p.irr_ptr); io.vec(p.irr_val); io.vec(p.irr_cid);
     io.vec(p.med_dst); io.vec(p.win_cmin); io.vec(p.win_len);
     io.vec(p.short_val); io.vec(p.short_cid);
@@ -101,42 +101,17 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
     const long long nb = (p.n_mfma_rows + kMedRows - 1) / kMedRows;
     if (p.med_ptr.size() != (size_t)nb + 1 || !mono(p.med_ptr) || p.stats.n_med_blocks != nb) return fail("med_ptr size / n_med_blocks");
     if ((size_t)p.med_ptr.back() * (size_t)CH != p.cnt_reg || p.med_val.size() != p.cnt_reg * (size_t)vb) return fail("regular tiles");
-    if (p.cid16 ? (p.med_cid16.size() + p.med_cid8.size() != p.cnt_reg || p.med_cid8.size() != p.cnt_reg8 || !p.med_cid.empty() ||
-                   p.med_base.size() != (size_t)p.med_ptr.back() || p.med_korig.size() != p.med_base.size() || p.med_c8ptr.size() != (size_t)nb + 1)
-                : (p.med_cid.size() != p.cnt_reg || !p.med_cid16.empty() || !p.med_cid8.empty() || !p.med_base.empty() || !p.med_c8ptr.empty() || !p.med_korig.empty()))
-        return fail("medium column ids");
-    // cid16 mode: block b keeps its narrow chunks (one-byte ids, plane med_cid8) in front of its wide ones (med_cid16)
-    if (p.cid16) {
-        if (!mono(p.med_c8ptr) || (size_t)p.med_c8ptr.back() * (size_t)CH != p.cnt_reg8) return fail("med_c8ptr");
-        for (long long b = 0; b < nb; ++b) {
-            const int nc = p.med_ptr[(size_t)b + 1] - p.med_ptr[(size_t)b], n8 = p.med_c8ptr[(size_t)b + 1] - p.med_c8ptr[(size_t)b];
-            if (n8 > nc || (n8 & 1) || (n8 && vb != 8)) return fail("med_c8ptr: narrow chunks come in pairs, f64 only, inside their block");
-            std::vector<char> seen((size_t)nc, 0);
-            for (int q = 0; q < nc; ++q) {
-                const unsigned k = p.med_korig[(size_t)p.med_ptr[(size_t)b] + (size_t)q];
-                if (k >= (unsigned)nc || seen[k]) return fail("med_korig is not a permutation of its block");
-                seen[k] = 1;
-            }
-        }
-    }
-    // column id of element e of the chunk at position q (absolute chunk index) of block b, -1 = pad
-    auto cid_at = [&](long long b, long long q, long long e) -> long long {
-        if (!p.cid16) return p.med_cid[(size_t)(q * CH + e)];
-        const long long c0 = p.med_ptr[(size_t)b], c8 = p.med_c8ptr[(size_t)b], n8 = p.med_c8ptr[(size_t)b + 1] - c8, pos = q - c0;
-        if (pos < n8) { const unsigned o = p.med_cid8[(size_t)((c8 + (pos & ~1ll)) * CH + 2 * e + (pos & 1))]; return o == 0xFFu ? -1 : (long long)p.med_base[(size_t)q] + o; }   // pair-interleaved
-        const unsigned o = p.med_cid16[(size_t)((c0 - c8 + pos - n8) * CH + e)];
-        return o == 0xFFFFu ? -1 : (long long)p.med_base[(size_t)q] + o;
-    };
+    if (p.cid16 ? (p.med_cid16.size() != p.cnt_reg || !p.med_cid.empty() || p.med_base.size() != (size_t)p.med_ptr.back())
+                : (p.med_cid.size() != p.cnt_reg || !p.med_cid16.empty() || !p.med_base.empty())) return fail("medium column ids");
     if (p.irr_ptr.size() != (size_t)p.n_mfma_rows + 1 || !mono(p.irr_ptr) || (size_t)p.irr_ptr.back() != p.cnt_irr) return fail("irr_ptr");
     if (p.irr_val.size() != p.cnt_irr * (size_t)vb || p.irr_cid.size() != p.cnt_irr) return fail("irregular arrays");
     if (!cid_ok(p.irr_cid) || !cid_ok(p.med_cid)) return fail("medium column id out of range");
     if (p.cid16)
-        for (long long b = 0; b < nb; ++b)
-            for (long long q = p.med_ptr[(size_t)b]; q < p.med_ptr[(size_t)b + 1]; ++q) {
-                const long long base = p.med_base[(size_t)q];
-                if (base < 0 || base >= std::max<long long>(xlen, 1)) return fail("med_base out of range");
-                for (long long e = 0; e < CH; ++e) if (cid_at(b, q, e) >= xlen) return fail("narrow column id out of range");
-            }
+        for (size_t c = 0; c < p.med_base.size(); ++c) {
+            const long long b = p.med_base[c];
+            if (b < 0 || b >= std::max<long long>(xlen, 1)) return fail("med_base out of range");
+            for (long long e = 0; e < CH; ++e) { const unsigned o = p.med_cid16[c * (size_t)CH + (size_t)e]; if (o != 0xFFFFu && b + o >= xlen) return fail("16-bit column id out of range"); }
+        }
     // ---- windows
     if (p.lds_bytes < 0 || p.lds_bytes > 160 * 1024) return fail("lds_bytes");
     if (p.windowed) {
@@ -153,8 +128,9 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
             for (long long b = w * bpw; b < std::min(nb, (w + 1) * bpw); ++b) {
                 for (long long c = p.med_ptr[(size_t)b]; c < p.med_ptr[(size_t)b + 1]; ++c)
                     for (long long e = 0; e < CH; ++e) {
-                        const long long col = cid_at(b, c, e);
-                        if (col < 0) continue;
+                        long long col;
+                        if (p.cid16) { const unsigned o = p.med_cid16[(size_t)(c * CH + e)]; if (o == 0xFFFFu) continue; col = (long long)p.med_base[(size_t)c] + o; }
+                        else { col = p.med_cid[(size_t)(c * CH + e)]; if (col < 0) continue; }
                         if (col < c0 || col >= c0 + len) return fail("windowed column id outside its LDS span");
                     }
                 for (long long r = b * kMedRows; r < std::min<long long>(p.n_mfma_rows, (b + 1) * kMedRows); ++r)
@@ -209,14 +185,13 @@ static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
                 (p.dst_map.empty() || p.dst_map.size() == (size_t)p.m) && p.panel_bounds.size() == 2 * (size_t)np &&
                 p.long_val.size() == p.long_cid.size() * vb && p.irr_val.size() == p.irr_cid.size() * vb &&
                 p.short_val.size() == p.short_cid.size() * vb &&
-                (p.cid16 ? p.med_val.size() == (p.med_cid16.size() + p.med_cid8.size()) * vb : p.med_val.size() == p.med_cid.size() * vb);
+                (p.cid16 ? p.med_val.size() == p.med_cid16.size() * vb : p.med_val.size() == p.med_cid.size() * vb);
     if (np == 0)   // a packed plan (a panel parent keeps none of the row-structure arrays)
         sane = sane && p.piece_ptr.size() == p.piece_dst.size() + 1 && p.irr_ptr.size() == (size_t)p.n_mfma_rows + 1 &&
                p.n_mfma_rows >= 0 && p.n_mfma_rows <= p.stats.row_block && (!p.windowed || p.med_dst.size() == (size_t)p.n_mfma_rows);
     if (!sane) return false;
     p.cnt_long = p.long_cid.size(); p.cnt_irr = p.irr_cid.size(); p.cnt_short = p.short_cid.size();
-    p.cnt_reg = p.cid16 ? p.med_cid16.size() + p.med_cid8.size() : p.med_cid.size();
-    p.cnt_reg8 = p.med_cid8.size();
+    p.cnt_reg = p.cid16 ? p.med_cid16.size() : p.med_cid.size();
     p.host_dropped = false;
     p.panel = depth > 0;
     if (!validate_plan(p, np, r_why)) return false;
@@ -259,7 +234,7 @@ int load_plan(Plan &p, const char *path)
     r.raw(magic, 8);
     r.raw(abi, sizeof abi);
     if (!r.ok || std::memcmp(magic, kPlanMagic, 8) != 0 || abi[0] != (int)sizeof(dasp_stats_t) || abi[1] != kNumShortGroups || abi[2] != (int)sizeof(ShortGroup)) {
-        std::fclose(f); set_error("not a DASPPLN5 plan file of this build (magic / struct sizes differ)"); return DASP_ERR_BANNER;
+        std::fclose(f); set_error("not a DASPPLN4 plan file of this build (magic / struct sizes differ)"); return DASP_ERR_BANNER;
     }
     std::string why;
     bool ok = false;

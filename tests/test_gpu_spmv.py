@@ -434,8 +434,8 @@ def test_bench_bare_multi_gpu_launch_needs_that_many_devices(torch_cuda):
     assert r.returncode == 4 and "need 2 devices" in r.stderr
 
 
-NNZ_ARRAYS = ("long_val long_cid med_val med_cid med_cid16 med_cid8 med_base irr_val irr_cid short_val short_cid").split()
-META_ARRAYS = ("piece_ptr piece_dst multi_ptr multi_dst med_ptr med_c8ptr med_korig irr_ptr med_dst win_cmin win_len short_groups").split()
+NNZ_ARRAYS = ("long_val long_cid med_val med_cid med_cid16 med_base irr_val irr_cid short_val short_cid").split()
+META_ARRAYS = ("piece_ptr piece_dst multi_ptr multi_dst med_ptr irr_ptr med_dst win_cmin win_len short_groups").split()
 
 
 @pytest.mark.parametrize("prec", [64, 16])

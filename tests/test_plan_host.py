@@ -196,55 +196,6 @@ def test_cid16_span_boundary(dasp):
             assert rows[slot][0] == ci[:8].tolist()
 
 
-def test_cid8_narrow_chunks(dasp, monkeypatch):
-    """f64, inside cid16 mode: a chunk whose columns span <= 254 stores one-byte ids (255 does not); a block keeps an even number
-    of them, in front of its wide chunks, pair-interleaved [pair][lane][2]; the values follow their chunk;
-    DASP_CID8=0 keeps every chunk in the 16-bit plane"""
-    for span, n8 in ((254, 2), (255, 0)):
-        # K = 4 entries per chunk and row; chunk 0 = cols {0,1,2,span}, chunk 1 = a wide one, chunks 2 and 3 = 4 adjacent columns each:
-        # span 254 -> three one-byte-able chunks, two kept (0 and 2); span 255 -> two (2 and 3)
-        rp = np.arange(0, 16 * 17, 16, dtype=np.int32)
-        ci = np.tile(np.array([0, 1, 2, span, 1000, 3000, 5000, 9000, 70000, 70001, 70002, 70003, 70010, 70011, 70012, 70013], np.int32), 16)
-        v = np.arange(1, ci.size + 1, dtype=np.float64)
-        plan = dasp.Plan(rp, ci, v, 80000, x_window=-1, cid16=1, slab_max_len=4)
-        assert plan.stats["cid16_on"] == 1 and plan.host_array("med_ptr").tolist() == [0, 4]
-        assert plan.host_array("med_c8ptr").tolist() == [0, 2]
-        assert plan.host_array("med_korig").tolist() == ([0, 2, 1, 3] if span == 254 else [2, 3, 0, 1])
-        assert plan.host_array("med_cid8").size == 128 and plan.host_array("med_cid16").size == 128
-        assert plan.host_array("med_base").tolist() == ([0, 70000, 1000, 70010] if span == 254 else [70000, 70010, 0, 1000])
-        c8 = plan.host_array("med_cid8").reshape(64, 2)          # [lane][chunk of the pair]; lane = k*16 + row
-        first = [0, 1, 2, 254] if span == 254 else [0, 1, 2, 3]
-        assert c8[:, 0].reshape(4, 16)[:, 0].tolist() == first and c8[:, 1].reshape(4, 16)[:, 5].tolist() == [0, 1, 2, 3]
-        rows = util.decode_plan(plan)
-        order = plan.order_rid
-        for slot in range(16):
-            r = order[slot]
-            assert rows[slot][0] == ci[:16].tolist() and rows[slot][1] == v[rp[r]:rp[r + 1]].tolist()
-    monkeypatch.setenv("DASP_CID8", "0")
-    plan = dasp.Plan(rp, ci, v, 80000, x_window=-1, cid16=1, slab_max_len=4)
-    assert plan.host_array("med_c8ptr").tolist() == [0, 0] and plan.host_array("med_korig").tolist() == [0, 1, 2, 3]
-    assert plan.host_array("med_cid8").size == 0 and plan.host_array("med_cid16").size == 256
-    assert util.decode_plan(plan)[0][0] == ci[:16].tolist()
-
-
-@pytest.mark.parametrize("prec", [64, 16])
-def test_cid8_mixed_blocks_decode(dasp, prec):
-    """FEM-like rows (runs of adjacent columns + a few far ones): narrow and wide chunks interleave inside the f64 blocks;
-    f16 plans keep every chunk 16-bit"""
-    dt = np.float64 if prec == 64 else np.float16
-    rp, ci = dasp.synth_csr("HV15R", 0.002)
-    m, n = rp.size - 1, dasp.synth_dims("HV15R", 0.002)[1]
-    v = np.random.default_rng(5).uniform(0.5, 1.5, ci.size).astype(dt)
-    plan = dasp.Plan(rp, ci, v, n, precision=prec, cid16=1)
-    c8, mp = plan.host_array("med_c8ptr"), plan.host_array("med_ptr")
-    assert (0 < c8[-1] < mp[-1] and (np.diff(c8) % 2 == 0).all()) if prec == 64 else c8[-1] == 0
-    rows = util.decode_plan(plan)
-    order = plan.order_rid
-    for slot in range(0, m, 7):
-        r = order[slot]
-        assert rows[slot][0] == ci[rp[r]:rp[r + 1]].tolist() and rows[slot][1] == v[rp[r]:rp[r + 1]].tolist()
-
-
 @pytest.mark.parametrize("prec", [64, 16])
 def test_serialised_plan_round_trip(dasp, tmp_path, prec):
     dt = np.float64 if prec == 64 else np.float16
@@ -256,7 +207,7 @@ def test_serialised_plan_round_trip(dasp, tmp_path, prec):
         back = dasp.Plan.load(path)
         assert back.stats == plan.stats and (back.order_rid == plan.order_rid).all()
         assert (back.y_order, back.x_len, back.precision) == (plan.y_order, plan.x_len, prec)
-        for name in ("long_val long_cid piece_ptr piece_dst multi_ptr multi_dst med_ptr med_val med_cid med_cid16 med_cid8 med_c8ptr med_korig med_base "
+        for name in ("long_val long_cid piece_ptr piece_dst multi_ptr multi_dst med_ptr med_val med_cid med_cid16 med_base "
                      "irr_ptr irr_val irr_cid med_dst win_cmin win_len short_val short_cid short_groups").split():
             a, b = plan.host_array(name), back.host_array(name)
             assert a.dtype == b.dtype and np.array_equal(a, b), name

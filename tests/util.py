@@ -79,29 +79,10 @@ def decode_plan(plan):
     # medium rows
     mptr, mv, mc = plan.host_array("med_ptr"), plan.host_array("med_val"), plan.host_array("med_cid")
     if st.get("cid16_on"):       # u16 offsets from a per-chunk base column, 0xFFFF = pad
-        # per block: narrow chunks (u8 offsets, 0xFF = pad, plane med_cid8) first, then the wide ones (u16, plane med_cid16);
-        # med_korig[position] = the chunk's index in row order.  Rebuilt here in row order so the walk below is the i32 one.
-        off16, off8 = plan.host_array("med_cid16").astype(np.int64), plan.host_array("med_cid8").astype(np.int64)
-        c8p, korig = plan.host_array("med_c8ptr").astype(np.int64), plan.host_array("med_korig").astype(np.int64)
-        base = plan.host_array("med_base").astype(np.int64)
-        assert mc.size == 0 and off16.size + off8.size == base.size * CH and korig.size == base.size
-        mc = np.full(base.size * CH, -1, np.int64)
-        mv2 = np.empty_like(mv)
-        for b in range(mptr.size - 1):
-            c0, n8 = int(mptr[b]), int(c8p[b + 1] - c8p[b])
-            for pos in range(int(mptr[b + 1]) - c0):
-                if pos < n8:
-                    assert prec == 64 and n8 % 2 == 0            # narrow chunks: f64 only, stored in pairs [pair][lane][2]
-                    pair0 = (c8p[b] + (pos & ~1)) * CH
-                    o = off8[pair0 + (pos & 1):pair0 + 2 * CH:2]; pad = 0xFF
-                    assert o[o != pad].size == 0 or o[o != pad].max() <= 254
-                else:
-                    w = c0 - c8p[b] + pos - n8
-                    o = off16[w * CH:(w + 1) * CH]; pad = 0xFFFF
-                k = c0 + int(korig[c0 + pos])
-                mc[k * CH:(k + 1) * CH] = np.where(o == pad, -1, base[c0 + pos] + o)
-                mv2[k * CH:(k + 1) * CH] = mv[(c0 + pos) * CH:(c0 + pos + 1) * CH]
-        mv = mv2
+        off = plan.host_array("med_cid16").astype(np.int64)
+        base = np.repeat(plan.host_array("med_base").astype(np.int64), CH)
+        assert mc.size == 0 and off.size == base.size
+        mc = np.where(off == 0xFFFF, -1, base + off)
     ip_, iv, ic = plan.host_array("irr_ptr"), plan.host_array("irr_val"), plan.host_array("irr_cid")
     nb = mptr.size - 1
     row_block, row_long = ip_.size - 1, st["row_long"] + st.get("med_rows_as_pieces", 0)   # MFMA-block rows only: shorter medium rows are slabs (short_groups), the longest may be pieces
