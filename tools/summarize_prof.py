@@ -4,13 +4,20 @@ Reads the three rocprofv3 passes tools/prof.sh wrote (kernel trace + stats, --pm
 import csv, glob, sys
 d, cmd = sys.argv[1], sys.argv[2]
 print(f"## rocprofv3 --kernel-trace --stats --output-format csv -- {cmd}\n")
-rows = list(csv.DictReader(open(glob.glob(d + "/trace/*/*kernel_stats.csv")[0])))
+def pick(pattern):
+    """the CSV of the process that ran the DASP kernels (bench.py's vendor comparator is a child process with its own files)"""
+    files = sorted(glob.glob(pattern))
+    for f in files:
+        if "dasp_spmv_kernel" in open(f).read():
+            return f
+    return files[0]
+rows = list(csv.DictReader(open(pick(d + "/trace/*/*kernel_stats.csv"))))
 print("| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|")
 for r in rows[:4]:
     print(f"| {r['Name'][:80]} | {r['Calls']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {r['Percentage']} |")
 res = {}
 for kind, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    rows = list(csv.DictReader(open(glob.glob(d + f"/pmc_{kind}/*/*counter_collection.csv")[0])))
+    rows = list(csv.DictReader(open(pick(d + f"/pmc_{kind}/*/*counter_collection.csv"))))
     v = [float(r["Counter_Value"]) for r in rows if "dasp_spmv_kernel" in r["Kernel_Name"]]
     res[cname] = sum(v) / len(v) * 1024
     g = [r for r in rows if "dasp_spmv_kernel" in r["Kernel_Name"]][0]
