@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -270,6 +271,8 @@ int dasp_mg_plan_create(dasp_mg_plan_t **out, int precision, int rowA, int colA,
         const int m = g->rows();
         const int nnz = csrRowPtr[m];
         if (csrRowPtr[0] != 0 || nnz < 0 || (nnz > 0 && (!csrColIdx || !csrVal))) { set_error("dasp_mg_plan_create: bad local CSR"); return DASP_ERR_ARG; }
+        for (int i = 0; i < m; ++i)      // the owner split walks the rows before dasp_plan_create gets to validate them
+            if (csrRowPtr[i + 1] < csrRowPtr[i]) { set_error("dasp_mg_plan_create: row pointer not monotone"); return DASP_ERR_ARG; }
         for (long long j = 0; j < nnz; ++j)
             if ((unsigned)csrColIdx[j] >= (unsigned)colA) { set_error("column index out of range"); return DASP_ERR_ARG; }
         const int rc = precision == 64 ? create_impl<double>(*g, csrRowPtr, csrColIdx, static_cast<const double *>(csrVal), opt)

@@ -361,6 +361,9 @@ def test_mg_plan_argument_errors(dasp):
         MgPlan(rp, ci, v, 100, 100, np.array([0, 100], np.int32), 1)             # rank out of range
     with pytest.raises(dasp.DaspError):
         MgPlan(rp, ci + 1000, v, 100, 100, np.array([0, 100], np.int32), 0)      # column out of range
+    bad = rp.copy(); bad[40] = bad[41] + 5
+    with pytest.raises(dasp.DaspError):
+        MgPlan(bad, ci, v, 100, 100, np.array([0, 100], np.int32), 0)             # row pointer not monotone
     mg = MgPlan(rp, ci, v, 100, 100, np.array([0, 100], np.int32), 0)
     with pytest.raises(dasp.DaspError) as e:
         mg.spmv()                                                                # not uploaded
