@@ -138,6 +138,7 @@ __global__ void k_pack_medium(const int *rp, const int *ci, const T *val, const 
     if (b >= nb) return;
     const int c0 = med_ptr[b], nc = med_ptr[b + 1] - c0;
     const int r0 = b * kMedRows;
+    const int npair = med_npair(nc, (irr_ptr[r0 + 1] - irr_ptr[r0] + K - 1) / K, (int)sizeof(T));      // r0 < nmed: a block has at least one row
     const int rr = lane & 15, kq = lane >> 4, r = r0 + rr;
     const bool row_ok = r < nmed;
     const int a0 = row_ok ? rp[ridM[r]] : 0, len = row_ok ? lenM[r] : 0;
@@ -153,7 +154,7 @@ __global__ void k_pack_medium(const int *rp, const int *ci, const T *val, const 
             col[q] = in ? remap(ci[a0 + i]) : -1;
             if (in) lo = min(lo, col[q]);
         }
-        const size_t at = (size_t)(c0 + c) * CH + (size_t)lane * VPL;
+        const size_t at = (size_t)c0 * CH + med_elem_index(npair, c, lane, 0, VPL, CH);      // pipelined blocks: pairs of chunks interleaved per lane (plan.hpp)
         if constexpr (C16) {
             lo = wave_min(lo);
             if (lo == 2147483647) lo = 0;

@@ -47,6 +47,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------ device helpers
 
@@ -118,6 +120,8 @@ template <> struct Tr<_Float16> {
     using acc_t = f32x4; using part_t = float;
     static constexpr int CHUNK = 256, SHORT_ROWS = 256, BATCH = 2, SHOT = 2;
 };
+static_assert(Tr<double>::BATCH == kMedBatch64 && Tr<double>::SHOT == kMedShot64 && Tr<_Float16>::BATCH == kMedBatch16 &&
+              Tr<_Float16>::SHOT == kMedShot16 && kMedBatch64 % 2 == 0 && kMedBatch16 % 2 == 0, "the packers' pairing rule (plan.hpp) follows the kernel's batches");
 
 // ---- chunk = one MFMA worth of elements in lane-linear order.  Loads, gathers and MFMAs are kept
 // as separate branch-free stages so that a batch of chunks has all its streaming loads, then all
@@ -146,6 +150,7 @@ __device__ __forceinline__ void frag_load(Frag<T> &f, const T *val, const int *c
 {
     frag_load_at<NT>(f, val, cid, e + (size_t)(Tr<T>::CHUNK / kWave) * lane);
 }
+#define LDS_AS __attribute__((address_space(3)))
 // where x values come from: global memory, or the workgroup's window of x staged in LDS
 template <class T>
 struct XGlobal {
@@ -154,14 +159,14 @@ struct XGlobal {
 };
 template <class T>
 struct XLds {
-    const T *xw; int cmin;
+    const LDS_AS T *xw; int cmin;
     __device__ __forceinline__ T at(int c) const { return xw[c < 0 ? 0 : c - cmin]; }
 };
 // hybrid window: the densest span of the window's columns is in LDS, everything else is gathered from global memory.
 // The two loads sit in divergent branches on purpose: a lane whose column is staged issues no global load.
 template <class T>
 struct XHyb {
-    const T *xw; const T *xg; int cmin; unsigned len;
+    const LDS_AS T *xw; const T *xg; int cmin; unsigned len;
     __device__ __forceinline__ T at(int c) const
     {
         const unsigned o = (unsigned)(c - cmin);
@@ -202,6 +207,7 @@ __device__ __forceinline__ void frag_mfma(f32x4 &acc, const Frag<_Float16> &f)
 // lane-linear chunks only (long pieces)
 template <class T, bool NT>
 struct ChunkSrc {
+    static constexpr bool kPairs = false;
     const T *val; const int *cid; size_t e0; int lane;
     __device__ __forceinline__ void load(Frag<T> &f, int i) const { frag_load<NT>(f, val, cid, e0 + (size_t)i * Tr<T>::CHUNK, lane); }
     template <class XV> __device__ __forceinline__ void gather(Frag<T> &f, int, const XV &x) const { frag_gather(f, x); }
@@ -212,23 +218,65 @@ struct ChunkSrc {
 // arena pads them) and are zeroed in gather(), so neither stage has a divergent branch.
 template <class T, bool NT, bool C16>
 struct BlockSrc {
+    static constexpr bool kPairs = true;
+    static constexpr int VPL = Tr<T>::CHUNK / kWave;           // values of one chunk per lane: 1 (f64) / 4 (f16)
     ChunkSrc<T, NT> reg; int nc;
+    // a pipelined block's leading chunks are stored in PAIRS, [pair][lane][2 chunks][VPL] (values and ids alike; plan.hpp med_npair):
+    // the two chunks of a pair arrive with one 16-byte load per lane, which the L1 processes in as many passes as an 8-byte load
+    // (4 lanes per pass) -- half the tag lookups per streamed byte (profiles/r02_pairs.md).  npair is a multiple of BATCH, so a
+    // pipeline batch is either all pairs or all lane-linear chunks / tail steps.
+    int npair;                                                  // chunks [0, npair) are paired
     const unsigned short *cid16; const int *base; int c0;      // C16: ids of the regular chunks as u16 offsets from base[chunk]
     const T *ival; const int *icid; int t0, t1, kq;
+    // element index of this lane's first value (and id) of regular chunk i -- wave-uniform part + lane part
+    __device__ __forceinline__ size_t at_of(int i) const
+    {
+        constexpr int CH = Tr<T>::CHUNK;
+        const bool paired = i < npair;
+        const size_t s = reg.e0 + (paired ? (size_t)(i & ~1) * CH + (size_t)(VPL * (i & 1)) : (size_t)i * CH);
+        return s + (size_t)(paired ? 2 * VPL : VPL) * reg.lane;
+    }
+    __device__ __forceinline__ bool pairs_ok(int i0, int n) const { return i0 + n <= npair; }
+    // chunks i (even) and i + 1 of the paired region: one 16-byte load of values, one load of ids
+    __device__ __forceinline__ void load2(Frag<T> &f0, Frag<T> &f1, int i) const
+    {
+        constexpr int CH = Tr<T>::CHUNK;
+        const size_t at = reg.e0 + (size_t)i * CH + (size_t)(2 * VPL) * reg.lane;
+        if constexpr (sizeof(T) == 8) {
+            const f64x2 v = ldg<NT>(reinterpret_cast<const f64x2 *>(reg.val + at));
+            f0.a = v[0]; f1.a = v[1];
+            if constexpr (C16) {
+                const unsigned r = ldg<NT>(reinterpret_cast<const unsigned *>(cid16 + at));      // raw offsets; rebased in gather()
+                f0.c = (int)(r & 0xFFFFu); f1.c = (int)(r >> 16);
+            } else {
+                const i32x2 c = ldg<NT>(reinterpret_cast<const i32x2 *>(reg.cid + at));
+                f0.c = c[0]; f1.c = c[1];
+            }
+        } else {
+            const f16x8 v = ldg<NT>(reinterpret_cast<const f16x8 *>(reg.val + at));
+            f0.a = __builtin_shufflevector(v, v, 0, 1, 2, 3); f1.a = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+            if constexpr (C16) {          // raw u16 offsets, two per dword; unpacked and rebased in gather()
+                const i32x4 o = ldg<NT>(reinterpret_cast<const i32x4 *>(cid16 + at));
+                f0.c[0] = o[0]; f0.c[1] = o[1]; f1.c[0] = o[2]; f1.c[1] = o[3];
+            } else {
+                f0.c = ldg<NT>(reinterpret_cast<const i32x4 *>(reg.cid + at));
+                f1.c = ldg<NT>(reinterpret_cast<const i32x4 *>(reg.cid + at + 4));
+            }
+        }
+    }
     __device__ __forceinline__ void load(Frag<T> &f, int i) const
     {
         if (i < nc) {
-            if constexpr (!C16) reg.load(f, i);
+            const size_t at = at_of(i);
+            if constexpr (!C16) frag_load_at<NT>(f, reg.val, reg.cid, at);
             else {
-                constexpr int CH = Tr<T>::CHUNK;
-                const size_t at = reg.e0 + (size_t)i * CH + (size_t)(CH / kWave) * reg.lane;
                 if constexpr (sizeof(T) == 8) {
                     f.a = ldg<NT>(reg.val + at);
                     f.c = (int)ldg<NT>(cid16 + at);             // raw offset; rebased in gather()
                 } else {
                     f.a = ldg<NT>(reinterpret_cast<const f16x4 *>(reg.val + at));
-                    const u16x4 o = ldg<NT>(reinterpret_cast<const u16x4 *>(cid16 + at));
-                    f.c[0] = o[0]; f.c[1] = o[1]; f.c[2] = o[2]; f.c[3] = o[3];
+                    const i32x2 o = ldg<NT>(reinterpret_cast<const i32x2 *>(cid16 + at));      // raw u16 offsets, two per dword
+                    f.c[0] = o[0]; f.c[1] = o[1];
                 }
             }
             return;
@@ -271,21 +319,38 @@ struct BlockSrc {
             const int b = base[c0 + i];                         // wave-uniform: one scalar load per chunk
             if constexpr (sizeof(T) == 8) f.c = f.c == 0xFFFF ? -1 : b + f.c;
             else {
+                const unsigned lo = (unsigned)f.c[0], hi = (unsigned)f.c[1];
+                const unsigned o[4] = {lo & 0xFFFFu, lo >> 16, hi & 0xFFFFu, hi >> 16};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) f.c[q] = f.c[q] == 0xFFFF ? -1 : b + f.c[q];
+                for (int q = 0; q < 4; ++q) f.c[q] = o[q] == 0xFFFFu ? -1 : b + (int)o[q];
             }
         }
         frag_gather(f, x);
     }
 };
 
+// the loads of the N consecutive steps from i0: pair loads when the source stores pairs and the whole batch lies in its paired
+// region (one wave-uniform test per batch; i0 is then a multiple of the batch), single loads otherwise
+template <int N, class SRC, class T>
+__device__ __forceinline__ void load_steps(const SRC &src, Frag<T> *f, int i0)
+{
+    if constexpr (SRC::kPairs && N == Tr<T>::BATCH) {
+        if (src.pairs_ok(i0, N)) {
+#pragma unroll
+            for (int u = 0; u < N; u += 2) src.load2(f[u], f[u + 1], i0 + u);
+            return;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u) src.load(f[u], i0 + u);
+}
+
 // N steps starting at step i0, everything in flight at once: all loads, then all gathers, then the MFMAs
 template <class T, int N, class SRC, class ACC, class XV>
 __device__ __forceinline__ void shot(ACC &acc, const SRC &src, int i0, const XV &x)
 {
     Frag<T> f[N];
-#pragma unroll
-    for (int u = 0; u < N; ++u) src.load(f[u], i0 + u);
+    load_steps<N>(src, f, i0);
 #pragma unroll
     for (int u = 0; u < N; ++u) src.gather(f[u], i0 + u, x);
 #pragma unroll
@@ -313,8 +378,7 @@ struct FinishDispatch {
             Frag<T> r[R > 0 ? R : 1];
 #pragma unroll
             for (int u = 0; u < U; ++u) src.gather(cur[u], ibase + u, x);
-#pragma unroll
-            for (int u = 0; u < R; ++u) src.load(r[u], i + u);
+            load_steps<R>(src, r, i);
 #pragma unroll
             for (int u = 0; u < U; ++u) frag_mfma(acc, cur[u]);
 #pragma unroll
@@ -335,15 +399,13 @@ __device__ __forceinline__ void run_stream(ACC &acc, const SRC &src, int N, cons
     if (N <= S) { ShotDispatch<T, S, SRC, ACC, XV>::run(acc, src, 0, N, x); return; }
     const int nfull = N / U, rem = N % U;
     Frag<T> cur[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) src.load(cur[u], u);
+    load_steps<U>(src, cur, 0);
     int i = U;
     for (int it = 1; it < nfull; ++it, i += U) {
         Frag<T> nxt[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) src.gather(cur[u], i - U + u, x);
-#pragma unroll
-        for (int u = 0; u < U; ++u) src.load(nxt[u], i + u);
+        load_steps<U>(src, nxt, i);
 #pragma unroll
         for (int u = 0; u < U; ++u) frag_mfma(acc, cur[u]);
 #pragma unroll
@@ -394,7 +456,7 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     const int nt = (__builtin_amdgcn_readfirstlane(t1 - t0) + TK - 1) / TK;
     BlockSrc<T, NT, C16> src;
     src.reg.val = val; src.reg.cid = a.med_cid; src.reg.e0 = (size_t)c0 * CH; src.reg.lane = lane;
-    src.nc = c1 - c0; src.cid16 = a.med_cid16; src.base = a.med_base; src.c0 = c0;
+    src.nc = c1 - c0; src.npair = med_npair(c1 - c0, nt, (int)sizeof(T)); src.cid16 = a.med_cid16; src.base = a.med_base; src.c0 = c0;
     src.ival = static_cast<const T *>(a.irr_val); src.icid = a.irr_cid; src.t0 = t0; src.t1 = t1; src.kq = kq;
     run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, src.nc + nt, x);
 
@@ -580,11 +642,11 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPla
             const int w = wg - a.wg_long;
             const int len = a.win_len[w], cmin = a.win_cmin[w];
             const T *xg = static_cast<const T *>(a.x);
-            T *xw = reinterpret_cast<T *>(lds_raw);
+            LDS_AS T *xw = (LDS_AS T *)lds_raw;        // explicitly an LDS pointer: ds_read gathers, never a flat load
             if (len > 0) {
                 constexpr int A = 16 / (int)sizeof(T);
                 const i32x4 *src = reinterpret_cast<const i32x4 *>(xg + cmin);
-                i32x4 *dst = reinterpret_cast<i32x4 *>(xw);
+                LDS_AS i32x4 *dst = (LDS_AS i32x4 *)xw;
                 const int nvec = len / A, nth = wpw * kWave;
                 for (int i0 = threadIdx.x; i0 < nvec; i0 += 4 * nth) {       // four 16-byte loads in flight per lane
                     const int i1 = i0 + nth, i2 = i0 + 2 * nth, i3 = i0 + 3 * nth;

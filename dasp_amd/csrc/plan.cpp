@@ -501,7 +501,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     lap("long rows");
     // ---- medium rows: regular tiles kept while a 16 x K chunk is >= threshold full
     // (the reference's rule, dasp_f64.h:1044-1091, on this geometry's tile), rest = irregular tail
-    const int K = geo.med_k, CH = geo.chunk;
+    const int K = geo.med_k, CH = geo.chunk, VPL = geo.chunk / 64;      // values of one chunk per lane: 1 (f64) / 4 (f16)
     const int nb = ceil_div(nmed, kMedRows);
     std::vector<int> nchunks((size_t)nb + 1, 0);
     p.irr_ptr.assign((size_t)nmed + 1, 0);
@@ -581,6 +581,8 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                 const int nc = p.med_ptr[b + 1] - p.med_ptr[b];
                 const size_t base = (size_t)p.med_ptr[b] * CH;
                 const int r0 = (int)b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
+                // tail steps of the block = those of its first (longest) row; with them the kernel decides one shot / pipeline, hence the layout
+                const int npair = med_npair(nc, (p.irr_ptr[r0 + 1] - p.irr_ptr[r0] + K - 1) / K, geo.vbytes);
                 {   // pad the block's region (value 0, id -1 / 0xFFFF); real entries overwrite below
                     const size_t n = (size_t)nc * CH;
                     std::fill(mv + base, mv + base + n, (T)0);
@@ -603,8 +605,9 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                         const int c = i / K, kk = i % K;
                         // f64: lane = kk*16 + rr holds A[rr][kk]            (one value per lane)
                         // f16: lane = (kk/4)*16 + rr holds A[rr][4*(kk/4)..+3] (four values per lane)
-                        const size_t at = f16 ? base + (size_t)c * CH + (size_t)(kk / 4) * 64 + rr * 4 + kk % 4
-                                              : base + (size_t)c * CH + (size_t)kk * kMedRows + rr;
+                        // a pipelined block's leading chunks are stored in pairs, [pair][lane][2 chunks][VPL] (plan.hpp med_npair)
+                        const int lane = f16 ? (kk / 4) * kMedRows + rr : kk * kMedRows + rr, j = f16 ? kk % 4 : 0;
+                        const size_t at = base + med_elem_index(npair, c, lane, j, VPL, CH);
                         mv[at] = val[a0 + i];
                         const int col = remap(ci[a0 + i]);
                         if (p.cid16) p.med_cid16[at] = (uint16_t)(col - p.med_base[(size_t)p.med_ptr[b] + c]);

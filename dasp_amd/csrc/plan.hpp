@@ -36,6 +36,30 @@ constexpr int kWave = 64;         // gfx950 wavefront
 // SpMVs anyway (A/B around it: 212 MB plain 35.6 us vs nt 42.8; 257 MB plain 42.5 vs nt 51.9; 275 MB nt 54.9 vs plain 57.8)
 constexpr long long kStreamBytes = 256ll << 20;
 constexpr int kWavesPerWG = 4;    // 256-thread workgroups
+
+// Paired chunks.  A medium block that is long enough for the kernel's software pipeline (nc regular chunks + nt tail steps > the
+// one-shot limit) stores its first npair = nc rounded down to whole pipeline batches chunks in PAIRS -- [pair][lane][2 chunks][vpl],
+// values and ids alike -- so that one 16-byte load per lane brings two chunks (the L1 takes a 16-byte load in as many passes as an
+// 8-byte one: half the tag lookups per streamed byte, profiles/r02_pairs.md).  The remaining chunks, and every chunk of a shorter
+// block, stay lane-linear [chunk][lane][vpl].  kMedBatch / kMedShot are the kernel's Tr<T>::BATCH / SHOT (static_assert there).
+// Shared by the host packer, the device packer and the plan validator; mirrored in tests/util.py.
+constexpr int kMedBatch64 = 4, kMedShot64 = 8, kMedBatch16 = 2, kMedShot16 = 2;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int med_npair(int nc, int nt, int vbytes)
+{
+    const int batch = vbytes == 8 ? kMedBatch64 : kMedBatch16, shot = vbytes == 8 ? kMedShot64 : kMedShot16;
+    return nc + nt > shot ? nc / batch * batch : 0;
+}
+// where element j (< vpl) of lane `lane` of regular chunk c sits inside its block's region of med_val / med_cid / med_cid16 (in elements)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline size_t med_elem_index(int npair, int c, int lane, int j, int vpl, int ch)
+{
+    return c < npair ? (size_t)(c & ~1) * ch + (size_t)vpl * (2 * lane + (c & 1)) + j : (size_t)c * ch + (size_t)vpl * lane + j;
+}
 constexpr int kMedRows = 16;      // rows of one MFMA tile (v_mfma_*_16x16x*)
 constexpr int kLongAlign = 4;     // long rows start on a multiple of 4 elements
 constexpr int kSlabMaxLen = 32;     // longest medium row that can be stored as a uniform-length slab (opt.slab_max_len)

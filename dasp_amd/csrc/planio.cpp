@@ -1,7 +1,7 @@
 // planio.cpp -- serialised plans (the reference never stores its packed format).
 // A plan file holds every host array of a Plan, so a later run (or every rank of a multi-GPU job)
 // skips classification and packing: load -> upload -> spmv.
-// layout: "DASPPLN4" | int32 sizeof(dasp_stats_t), kNumShortGroups, sizeof(ShortGroup) | plan, where plan = int32 precision, m, n, nnz,
+// layout: "DASPPLN5" | int32 sizeof(dasp_stats_t), kNumShortGroups, sizeof(ShortGroup) | plan, where plan = int32 precision, m, n, nnz,
 //         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows, win_hybrid, med_slot0 | dasp_stats_t |
 //         ShortGroup[kNumShortGroups] | for each array, in a fixed order: int64 byte count + bytes | the n_panels column panels, each
 //         a nested plan.
@@ -106,12 +106,24 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
     if (p.irr_ptr.size() != (size_t)p.n_mfma_rows + 1 || !mono(p.irr_ptr) || (size_t)p.irr_ptr.back() != p.cnt_irr) return fail("irr_ptr");
     if (p.irr_val.size() != p.cnt_irr * (size_t)vb || p.irr_cid.size() != p.cnt_irr) return fail("irregular arrays");
     if (!cid_ok(p.irr_cid) || !cid_ok(p.med_cid)) return fail("medium column id out of range");
+    // column id of element e (= lane * vpl + j) of chunk c of block b, -1 = pad: the block's chunks are stored in pairs (plan.hpp med_elem_index)
+    const int vpl = (int)(CH / 64);
+    auto cid_at = [&](long long b, long long c, long long e) -> long long {
+        const long long c0 = p.med_ptr[(size_t)b];
+        const long long r0 = b * kMedRows, K = CH / kMedRows;      // tail steps of the block's first row decide its layout (plan.hpp med_npair)
+        const int npair = med_npair((int)(p.med_ptr[(size_t)b + 1] - c0), (int)((p.irr_ptr[(size_t)r0 + 1] - p.irr_ptr[(size_t)r0] + K - 1) / K), (int)vb);
+        const size_t at = (size_t)c0 * (size_t)CH + med_elem_index(npair, (int)(c - c0), (int)(e / vpl), (int)(e % vpl), vpl, (int)CH);
+        if (!p.cid16) return p.med_cid[at];
+        const unsigned o = p.med_cid16[at];
+        return o == 0xFFFFu ? -1 : (long long)p.med_base[(size_t)c] + o;
+    };
     if (p.cid16)
-        for (size_t c = 0; c < p.med_base.size(); ++c) {
-            const long long b = p.med_base[c];
-            if (b < 0 || b >= std::max<long long>(xlen, 1)) return fail("med_base out of range");
-            for (long long e = 0; e < CH; ++e) { const unsigned o = p.med_cid16[c * (size_t)CH + (size_t)e]; if (o != 0xFFFFu && b + o >= xlen) return fail("16-bit column id out of range"); }
-        }
+        for (long long b = 0; b < nb; ++b)
+            for (long long c = p.med_ptr[(size_t)b]; c < p.med_ptr[(size_t)b + 1]; ++c) {
+                const long long base = p.med_base[(size_t)c];
+                if (base < 0 || base >= std::max<long long>(xlen, 1)) return fail("med_base out of range");
+                for (long long e = 0; e < CH; ++e) if (cid_at(b, c, e) >= xlen) return fail("16-bit column id out of range");
+            }
     // ---- windows
     if (p.lds_bytes < 0 || p.lds_bytes > 160 * 1024) return fail("lds_bytes");
     if (p.windowed) {
@@ -128,9 +140,8 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
             for (long long b = w * bpw; b < std::min(nb, (w + 1) * bpw); ++b) {
                 for (long long c = p.med_ptr[(size_t)b]; c < p.med_ptr[(size_t)b + 1]; ++c)
                     for (long long e = 0; e < CH; ++e) {
-                        long long col;
-                        if (p.cid16) { const unsigned o = p.med_cid16[(size_t)(c * CH + e)]; if (o == 0xFFFFu) continue; col = (long long)p.med_base[(size_t)c] + o; }
-                        else { col = p.med_cid[(size_t)(c * CH + e)]; if (col < 0) continue; }
+                        const long long col = cid_at(b, c, e);
+                        if (col < 0) continue;
                         if (col < c0 || col >= c0 + len) return fail("windowed column id outside its LDS span");
                     }
                 for (long long r = b * kMedRows; r < std::min<long long>(p.n_mfma_rows, (b + 1) * kMedRows); ++r)
@@ -234,7 +245,7 @@ int load_plan(Plan &p, const char *path)
     r.raw(magic, 8);
     r.raw(abi, sizeof abi);
     if (!r.ok || std::memcmp(magic, kPlanMagic, 8) != 0 || abi[0] != (int)sizeof(dasp_stats_t) || abi[1] != kNumShortGroups || abi[2] != (int)sizeof(ShortGroup)) {
-        std::fclose(f); set_error("not a DASPPLN4 plan file of this build (magic / struct sizes differ)"); return DASP_ERR_BANNER;
+        std::fclose(f); set_error("not a DASPPLN5 plan file of this build (magic / struct sizes differ)"); return DASP_ERR_BANNER;
     }
     std::string why;
     bool ok = false;

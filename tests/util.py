@@ -78,8 +78,27 @@ def decode_plan(plan):
         vs.extend(v[keep].tolist())
     # medium rows
     mptr, mv, mc = plan.host_array("med_ptr"), plan.host_array("med_val"), plan.host_array("med_cid")
+    VPL = CH // 64
+
+    ip_all = plan.host_array("irr_ptr")
+    batch, shot = (4, 8) if prec == 64 else (2, 2)       # the kernel's pipeline batch / one-shot limit (plan.hpp med_npair)
+
+    def lane_linear(a):
+        """a block long enough for the kernel's pipeline (chunks + tail steps of its first row > shot) stores its leading
+        nc // batch * batch chunks in pairs, [pair][lane][2 chunks][VPL] (plan.hpp med_elem_index): back to chunk-major"""
+        a = a.copy()
+        for b in range(mptr.size - 1):
+            nc = int(mptr[b + 1] - mptr[b])
+            nt = -(-int(ip_all[b * 16 + 1] - ip_all[b * 16]) // K)
+            npair = nc // batch * batch if nc + nt > shot else 0
+            if npair:
+                lo = int(mptr[b]) * CH
+                a[lo:lo + npair * CH] = a[lo:lo + npair * CH].reshape(npair // 2, 64, 2, VPL).transpose(0, 2, 1, 3).reshape(-1)
+        return a
+    mv = lane_linear(mv)
+    mc = lane_linear(mc) if mc.size else mc
     if st.get("cid16_on"):       # u16 offsets from a per-chunk base column, 0xFFFF = pad
-        off = plan.host_array("med_cid16").astype(np.int64)
+        off = lane_linear(plan.host_array("med_cid16")).astype(np.int64)
         base = np.repeat(plan.host_array("med_base").astype(np.int64), CH)
         assert mc.size == 0 and off.size == base.size
         mc = np.where(off == 0xFFFF, -1, base + off)
