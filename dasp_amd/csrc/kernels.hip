@@ -114,11 +114,11 @@ __device__ __forceinline__ int slot_of(const SlotMap &m, int t)
 template <class T> struct Tr;
 template <> struct Tr<double> {
     using acc_t = f64x4; using part_t = double;
-    static constexpr int CHUNK = 64, SHORT_ROWS = 128, BATCH = 4, SHOT = 8;
+    static constexpr int CHUNK = 64, SHORT_ROWS = 128, BATCH = kMedBatch64, SHOT = kMedShot64;
 };
 template <> struct Tr<_Float16> {
     using acc_t = f32x4; using part_t = float;
-    static constexpr int CHUNK = 256, SHORT_ROWS = 256, BATCH = 2, SHOT = 2;
+    static constexpr int CHUNK = 256, SHORT_ROWS = 256, BATCH = kMedBatch16, SHOT = kMedShot16;
 };
 static_assert(Tr<double>::BATCH == kMedBatch64 && Tr<double>::SHOT == kMedShot64 && Tr<_Float16>::BATCH == kMedBatch16 &&
               Tr<_Float16>::SHOT == kMedShot16 && kMedBatch64 % 2 == 0 && kMedBatch16 % 2 == 0, "the packers' pairing rule (plan.hpp) follows the kernel's batches");
@@ -150,7 +150,6 @@ __device__ __forceinline__ void frag_load(Frag<T> &f, const T *val, const int *c
 {
     frag_load_at<NT>(f, val, cid, e + (size_t)(Tr<T>::CHUNK / kWave) * lane);
 }
-#define LDS_AS __attribute__((address_space(3)))
 // where x values come from: global memory, or the workgroup's window of x staged in LDS
 template <class T>
 struct XGlobal {
@@ -159,14 +158,14 @@ struct XGlobal {
 };
 template <class T>
 struct XLds {
-    const LDS_AS T *xw; int cmin;
+    const T *xw; int cmin;
     __device__ __forceinline__ T at(int c) const { return xw[c < 0 ? 0 : c - cmin]; }
 };
 // hybrid window: the densest span of the window's columns is in LDS, everything else is gathered from global memory.
 // The two loads sit in divergent branches on purpose: a lane whose column is staged issues no global load.
 template <class T>
 struct XHyb {
-    const LDS_AS T *xw; const T *xg; int cmin; unsigned len;
+    const T *xw; const T *xg; int cmin; unsigned len;
     __device__ __forceinline__ T at(int c) const
     {
         const unsigned o = (unsigned)(c - cmin);
@@ -209,16 +208,16 @@ template <class T, bool NT>
 struct ChunkSrc {
     static constexpr bool kPairs = false;
     const T *val; const int *cid; size_t e0; int lane;
-    __device__ __forceinline__ void load(Frag<T> &f, int i) const { frag_load<NT>(f, val, cid, e0 + (size_t)i * Tr<T>::CHUNK, lane); }
+    template <bool PAIRED_OK = true> __device__ __forceinline__ void load(Frag<T> &f, int i) const { frag_load<NT>(f, val, cid, e0 + (size_t)i * Tr<T>::CHUNK, lane); }
     template <class XV> __device__ __forceinline__ void gather(Frag<T> &f, int, const XV &x) const { frag_gather(f, x); }
 };
 
 // a medium block: nc lane-linear chunks, then the irregular tail as extra steps in which lane (row = l&15, kq = l>>4)
 // takes the next entries of its own row.  Out-of-range lanes read element 0 of the tail arrays (never empty: the
 // arena pads them) and are zeroed in gather(), so neither stage has a divergent branch.
-template <class T, bool NT, bool C16>
+template <class T, bool NT, bool C16, bool PAIRS>
 struct BlockSrc {
-    static constexpr bool kPairs = true;
+    static constexpr bool kPairs = PAIRS;          // false: the windowed kernel, whose plans keep every chunk lane-linear
     static constexpr int VPL = Tr<T>::CHUNK / kWave;           // values of one chunk per lane: 1 (f64) / 4 (f16)
     ChunkSrc<T, NT> reg; int nc;
     // a pipelined block's leading chunks are stored in PAIRS, [pair][lane][2 chunks][VPL] (values and ids alike; plan.hpp med_npair):
@@ -229,9 +228,10 @@ struct BlockSrc {
     const unsigned short *cid16; const int *base; int c0;      // C16: ids of the regular chunks as u16 offsets from base[chunk]
     const T *ival; const int *icid; int t0, t1, kq;
     // element index of this lane's first value (and id) of regular chunk i -- wave-uniform part + lane part
-    __device__ __forceinline__ size_t at_of(int i) const
+    template <bool PAIRED_OK> __device__ __forceinline__ size_t at_of(int i) const
     {
         constexpr int CH = Tr<T>::CHUNK;
+        if constexpr (!PAIRED_OK || !PAIRS) return reg.e0 + (size_t)i * CH + (size_t)VPL * reg.lane;       // a one-shot block: nothing is paired
         const bool paired = i < npair;
         const size_t s = reg.e0 + (paired ? (size_t)(i & ~1) * CH + (size_t)(VPL * (i & 1)) : (size_t)i * CH);
         return s + (size_t)(paired ? 2 * VPL : VPL) * reg.lane;
@@ -264,10 +264,11 @@ struct BlockSrc {
             }
         }
     }
-    __device__ __forceinline__ void load(Frag<T> &f, int i) const
+    // PAIRED_OK = false: the caller knows the block has no paired chunks (the one-shot path)
+    template <bool PAIRED_OK = true> __device__ __forceinline__ void load(Frag<T> &f, int i) const
     {
         if (i < nc) {
-            const size_t at = at_of(i);
+            const size_t at = at_of<PAIRED_OK>(i);
             if constexpr (!C16) frag_load_at<NT>(f, reg.val, reg.cid, at);
             else {
                 if constexpr (sizeof(T) == 8) {
@@ -350,7 +351,8 @@ template <class T, int N, class SRC, class ACC, class XV>
 __device__ __forceinline__ void shot(ACC &acc, const SRC &src, int i0, const XV &x)
 {
     Frag<T> f[N];
-    load_steps<N>(src, f, i0);
+#pragma unroll
+    for (int u = 0; u < N; ++u) src.template load<false>(f[u], i0 + u);        // one-shot units are never paired (plan.hpp med_npair)
 #pragma unroll
     for (int u = 0; u < N; ++u) src.gather(f[u], i0 + u, x);
 #pragma unroll
@@ -454,9 +456,9 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     if (r < a.row_block) { t0 = a.irr_ptr[r]; t1 = a.irr_ptr[r + 1]; }
     constexpr int TK = sizeof(T) == 8 ? 4 : 16;                      // tail entries of one row per MFMA step
     const int nt = (__builtin_amdgcn_readfirstlane(t1 - t0) + TK - 1) / TK;
-    BlockSrc<T, NT, C16> src;
+    BlockSrc<T, NT, C16, YM != 2> src;
     src.reg.val = val; src.reg.cid = a.med_cid; src.reg.e0 = (size_t)c0 * CH; src.reg.lane = lane;
-    src.nc = c1 - c0; src.npair = med_npair(c1 - c0, nt, (int)sizeof(T)); src.cid16 = a.med_cid16; src.base = a.med_base; src.c0 = c0;
+    src.nc = c1 - c0; src.npair = med_npair(c1 - c0, nt, (int)sizeof(T), YM == 2); src.cid16 = a.med_cid16; src.base = a.med_base; src.c0 = c0;
     src.ival = static_cast<const T *>(a.irr_val); src.icid = a.irr_cid; src.t0 = t0; src.t1 = t1; src.kq = kq;
     run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, src.nc + nt, x);
 
@@ -642,11 +644,11 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPla
             const int w = wg - a.wg_long;
             const int len = a.win_len[w], cmin = a.win_cmin[w];
             const T *xg = static_cast<const T *>(a.x);
-            LDS_AS T *xw = (LDS_AS T *)lds_raw;        // explicitly an LDS pointer: ds_read gathers, never a flat load
+            T *xw = reinterpret_cast<T *>(lds_raw);
             if (len > 0) {
                 constexpr int A = 16 / (int)sizeof(T);
                 const i32x4 *src = reinterpret_cast<const i32x4 *>(xg + cmin);
-                LDS_AS i32x4 *dst = (LDS_AS i32x4 *)xw;
+                i32x4 *dst = reinterpret_cast<i32x4 *>(xw);
                 const int nvec = len / A, nth = wpw * kWave;
                 for (int i0 = threadIdx.x; i0 < nvec; i0 += 4 * nth) {       // four 16-byte loads in flight per lane
                     const int i1 = i0 + nth, i2 = i0 + 2 * nth, i3 = i0 + 3 * nth;

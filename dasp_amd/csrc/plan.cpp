@@ -582,7 +582,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                 const size_t base = (size_t)p.med_ptr[b] * CH;
                 const int r0 = (int)b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
                 // tail steps of the block = those of its first (longest) row; with them the kernel decides one shot / pipeline, hence the layout
-                const int npair = med_npair(nc, (p.irr_ptr[r0 + 1] - p.irr_ptr[r0] + K - 1) / K, geo.vbytes);
+                const int npair = med_npair(nc, (p.irr_ptr[r0 + 1] - p.irr_ptr[r0] + K - 1) / K, geo.vbytes, p.windowed);
                 {   // pad the block's region (value 0, id -1 / 0xFFFF); real entries overwrite below
                     const size_t n = (size_t)nc * CH;
                     std::fill(mv + base, mv + base + n, (T)0);

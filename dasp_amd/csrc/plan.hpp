@@ -41,14 +41,18 @@ constexpr int kWavesPerWG = 4;    // 256-thread workgroups
 // one-shot limit) stores its first npair = nc rounded down to whole pipeline batches chunks in PAIRS -- [pair][lane][2 chunks][vpl],
 // values and ids alike -- so that one 16-byte load per lane brings two chunks (the L1 takes a 16-byte load in as many passes as an
 // 8-byte one: half the tag lookups per streamed byte, profiles/r02_pairs.md).  The remaining chunks, and every chunk of a shorter
-// block, stay lane-linear [chunk][lane][vpl].  kMedBatch / kMedShot are the kernel's Tr<T>::BATCH / SHOT (static_assert there).
+// block, and every chunk of an LDS-windowed plan, stay lane-linear [chunk][lane][vpl].  kMedBatch / kMedShot are the kernel's Tr<T>::BATCH / SHOT (static_assert there).
 // Shared by the host packer, the device packer and the plan validator; mirrored in tests/util.py.
-constexpr int kMedBatch64 = 4, kMedShot64 = 8, kMedBatch16 = 2, kMedShot16 = 2;
+#ifndef DASP_SHOT64
+#define DASP_SHOT64 8
+#endif
+constexpr int kMedBatch64 = 4, kMedShot64 = DASP_SHOT64, kMedBatch16 = 2, kMedShot16 = 2;
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline int med_npair(int nc, int nt, int vbytes)
+inline int med_npair(int nc, int nt, int vbytes, bool windowed)
 {
+    if (windowed) return 0;     // LDS-windowed plans (latency-bound, short blocks) keep every chunk lane-linear: their kernel is unchanged
     const int batch = vbytes == 8 ? kMedBatch64 : kMedBatch16, shot = vbytes == 8 ? kMedShot64 : kMedShot16;
     return nc + nt > shot ? nc / batch * batch : 0;
 }

@@ -111,7 +111,7 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
     auto cid_at = [&](long long b, long long c, long long e) -> long long {
         const long long c0 = p.med_ptr[(size_t)b];
         const long long r0 = b * kMedRows, K = CH / kMedRows;      // tail steps of the block's first row decide its layout (plan.hpp med_npair)
-        const int npair = med_npair((int)(p.med_ptr[(size_t)b + 1] - c0), (int)((p.irr_ptr[(size_t)r0 + 1] - p.irr_ptr[(size_t)r0] + K - 1) / K), (int)vb);
+        const int npair = med_npair((int)(p.med_ptr[(size_t)b + 1] - c0), (int)((p.irr_ptr[(size_t)r0 + 1] - p.irr_ptr[(size_t)r0] + K - 1) / K), (int)vb, p.windowed);
         const size_t at = (size_t)c0 * (size_t)CH + med_elem_index(npair, (int)(c - c0), (int)(e / vpl), (int)(e % vpl), vpl, (int)CH);
         if (!p.cid16) return p.med_cid[at];
         const unsigned o = p.med_cid16[at];
