@@ -351,8 +351,17 @@ template <class T, int N, class SRC, class ACC, class XV>
 __device__ __forceinline__ void shot(ACC &acc, const SRC &src, int i0, const XV &x)
 {
     Frag<T> f[N];
+    if constexpr (SRC::kPairs && sizeof(T) == 2) {          // one-shot blocks: f16 pairs its chunks, f64 keeps them lane-linear (plan.hpp med_npair)
 #pragma unroll
-    for (int u = 0; u < N; ++u) src.template load<false>(f[u], i0 + u);        // one-shot units are never paired (plan.hpp med_npair)
+        for (int u = 0; u + 1 < N; u += 2) {
+            if (src.pairs_ok(i0 + u, 2)) src.load2(f[u], f[u + 1], i0 + u);
+            else { src.load(f[u], i0 + u); src.load(f[u + 1], i0 + u + 1); }
+        }
+        if constexpr (N % 2 == 1) src.load(f[N - 1], i0 + N - 1);
+    } else {
+#pragma unroll
+        for (int u = 0; u < N; ++u) src.template load<false>(f[u], i0 + u);
+    }
 #pragma unroll
     for (int u = 0; u < N; ++u) src.gather(f[u], i0 + u, x);
 #pragma unroll

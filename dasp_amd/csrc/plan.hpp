@@ -38,15 +38,22 @@ constexpr long long kStreamBytes = 256ll << 20;
 constexpr int kWavesPerWG = 4;    // 256-thread workgroups
 
 // Paired chunks.  A medium block that is long enough for the kernel's software pipeline (nc regular chunks + nt tail steps > the
-// one-shot limit) stores its first npair = nc rounded down to whole pipeline batches chunks in PAIRS -- [pair][lane][2 chunks][vpl],
+// one-shot limit) stores its first npair = nc rounded down to whole pipeline batches chunks (a one-shot f16 block: nc rounded down to
+// even) in PAIRS -- [pair][lane][2 chunks][vpl],
 // values and ids alike -- so that one 16-byte load per lane brings two chunks (the L1 takes a 16-byte load in as many passes as an
-// 8-byte one: half the tag lookups per streamed byte, profiles/r02_pairs.md).  The remaining chunks, and every chunk of a shorter
-// block, and every chunk of an LDS-windowed plan, stay lane-linear [chunk][lane][vpl].  kMedBatch / kMedShot are the kernel's Tr<T>::BATCH / SHOT (static_assert there).
+// 8-byte one: half the tag lookups per streamed byte, profiles/r02_pairs.md).  The remaining chunks, every chunk of a one-shot f64
+// block and every chunk of an LDS-windowed plan stay lane-linear [chunk][lane][vpl].  kMedBatch / kMedShot are the kernel's Tr<T>::BATCH / SHOT (static_assert there).
 // Shared by the host packer, the device packer and the plan validator; mirrored in tests/util.py.
 #ifndef DASP_SHOT64
 #define DASP_SHOT64 8
 #endif
-constexpr int kMedBatch64 = 4, kMedShot64 = DASP_SHOT64, kMedBatch16 = 2, kMedShot16 = 2;
+#ifndef DASP_BATCH16
+#define DASP_BATCH16 2
+#endif
+#ifndef DASP_SHOT16
+#define DASP_SHOT16 2
+#endif
+constexpr int kMedBatch64 = 4, kMedShot64 = DASP_SHOT64, kMedBatch16 = DASP_BATCH16, kMedShot16 = DASP_SHOT16;
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -54,7 +61,8 @@ inline int med_npair(int nc, int nt, int vbytes, bool windowed)
 {
     if (windowed) return 0;     // LDS-windowed plans (latency-bound, short blocks) keep every chunk lane-linear: their kernel is unchanged
     const int batch = vbytes == 8 ? kMedBatch64 : kMedBatch16, shot = vbytes == 8 ? kMedShot64 : kMedShot16;
-    return nc + nt > shot ? nc / batch * batch : 0;
+    // one-shot blocks: f16 pairs them too (nlpkkt160 f16 0.2355 -> 0.2177 ms), f64 does not (nlpkkt160 f64 0.4325 -> 0.4551 when it did)
+    return nc + nt > shot ? nc / batch * batch : (vbytes == 2 ? nc & ~1 : 0);
 }
 // where element j (< vpl) of lane `lane` of regular chunk c sits inside its block's region of med_val / med_cid / med_cid16 (in elements)
 #if defined(__HIPCC__)
