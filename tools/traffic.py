@@ -30,7 +30,7 @@ def spmv_kernel(name):
 
 
 def per_kernel(kind):
-    rows = list(csv.DictReader(open(glob.glob(d + "/pmc_%s/*/*counter_collection.csv" % kind)[0])))
+    rows = list(csv.DictReader(open(max(glob.glob(d + "/pmc_%s/*/*counter_collection.csv" % kind), key=os.path.getmtime))))      # the newest pass
     tot, cnt = {}, {}
     for r in rows:
         k = spmv_kernel(r["Kernel_Name"])
@@ -51,7 +51,7 @@ for tok in log.replace("|", " ").split():
 n_spmv = fcnt["dasp_spmv_kernel"] / max(1, panels)
 f_raw = sum(fetch.values()) / n_spmv
 w = sum(write.values()) / (wcnt["dasp_spmv_kernel"] / max(1, panels))
-stats = list(csv.DictReader(open(glob.glob(d + "/trace/*/*kernel_stats.csv")[0])))
+stats = list(csv.DictReader(open(max(glob.glob(d + "/trace/*/*kernel_stats.csv"), key=os.path.getmtime))))
 sys.stderr.write("## rocprofv3 --kernel-trace --stats -- dasp_bench %s %g %d (tag %s)\n\n| kernel | calls | avg ns | %% |\n|---|---|---|---|\n" % (workload, scale, prec, tag))
 for r in stats[:5]:
     sys.stderr.write("| %s | %s | %.0f | %s |\n" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]), r["Percentage"]))
