@@ -18,7 +18,7 @@ static int s_panels(dasp_plan_t *p) { return dasp_plan_panel_count(p); }
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { std::printf("usage: dasp_bench <workload> [scale] [precision] [iters] [warmup] [threshold] [long_piece] [x_window] [row_window] [cid16] [col_panels] [stream_policy] [slab_max_len] [piece_min_len] [x_window_hybrid]\n"); return 0; }
+    if (argc < 2) { std::printf("usage: dasp_bench <workload> [scale] [precision] [iters] [warmup] [threshold] [long_piece] [x_window] [row_window] [cid16] [col_panels] [stream_policy] [slab_max_len] [piece_min_len] [x_window_hybrid] [chunk_pairs]\n"); return 0; }
     const char *name = argv[1];
     const double scale = argc > 2 ? std::atof(argv[2]) : 1.0;
     const int prec = argc > 3 ? std::atoi(argv[3]) : 64;
@@ -33,6 +33,7 @@ int main(int argc, char **argv)
     const int stream_policy = argc > 12 ? std::atoi(argv[12]) : 0;
     const int slab_max_len = argc > 13 ? std::atoi(argv[13]) : 0;
     const int piece_min_len = argc > 14 ? std::atoi(argv[14]) : 0;
+    const int chunk_pairs = argc > 16 ? std::atoi(argv[16]) : 0;
     const int x_window_hybrid = argc > 15 ? std::atoi(argv[15]) : 0;
     int rows, cols;
     CHECK(dasp_synth_dims(name, scale, &rows, &cols));
@@ -49,7 +50,7 @@ int main(int argc, char **argv)
     else for (int i = 0; i < nnz; ++i) reinterpret_cast<uint16_t *>(val.data())[i] = 0x3C00;
     dasp_options_t opt;
     dasp_options_default(&opt);
-    opt.threshold = threshold; opt.long_piece = long_piece; opt.x_window = x_window; opt.row_window = row_window; opt.cid16 = cid16; opt.col_panels = col_panels; opt.stream_policy = stream_policy; opt.slab_max_len = slab_max_len; opt.piece_min_len = piece_min_len; opt.x_window_hybrid = x_window_hybrid;
+    opt.threshold = threshold; opt.long_piece = long_piece; opt.x_window = x_window; opt.row_window = row_window; opt.cid16 = cid16; opt.col_panels = col_panels; opt.stream_policy = stream_policy; opt.slab_max_len = slab_max_len; opt.piece_min_len = piece_min_len; opt.x_window_hybrid = x_window_hybrid; opt.chunk_pairs = chunk_pairs;
     dasp_plan_t *plan = nullptr;
     CHECK(dasp_plan_create(&plan, prec, rows, cols, nnz, rp.data(), ci.data(), val.data(), &opt));
     CHECK(dasp_plan_upload(plan));

@@ -21,6 +21,7 @@ struct DevArgs {
     const int *multi_ptr; const int *multi_dst;
     int n_pieces, n_multi;
     // medium
+    int pair_mode;                                           // Plan::pair_mode (plan.hpp med_npair)
     const int *med_ptr; const void *med_val; const int *med_cid;
     const unsigned short *med_cid16; const int *med_base;   // cid16 mode: u16 offsets + per-chunk base column
     const int *irr_ptr; const void *irr_val; const int *irr_cid;

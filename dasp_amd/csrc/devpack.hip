@@ -131,14 +131,14 @@ __global__ void k_pack_long(const int *rp, const int *ci, const T *val, const in
 template <class T, bool C16>
 __global__ void k_pack_medium(const int *rp, const int *ci, const T *val, const int *ridM, const int *lenM, const int *med_ptr,
                               const int *irr_ptr, int nmed, int nb, RemapDev remap, T *mv, int *mc, unsigned short *mc16, int *mbase,
-                              T *iv, int *ic, bool windowed)
+                              T *iv, int *ic, int pair_mode)
 {
     constexpr int K = sizeof(T) == 8 ? 4 : 16, CH = kMedRows * K, VPL = CH / 64;
     const int lane = threadIdx.x & 63, b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= nb) return;
     const int c0 = med_ptr[b], nc = med_ptr[b + 1] - c0;
     const int r0 = b * kMedRows;
-    const int npair = med_npair(nc, (irr_ptr[r0 + 1] - irr_ptr[r0] + K - 1) / K, (int)sizeof(T), windowed);      // r0 < nmed: a block has at least one row
+    const int npair = med_npair(nc, (irr_ptr[r0 + 1] - irr_ptr[r0] + K - 1) / K, (int)sizeof(T), pair_mode);      // r0 < nmed: a block has at least one row
     const int rr = lane & 15, kq = lane >> 4, r = r0 + rr;
     const bool row_ok = r < nmed;
     const int a0 = row_ok ? rp[ridM[r]] : 0, len = row_ok ? lenM[r] : 0;
@@ -343,10 +343,10 @@ static int pack_all_typed(Plan &p, const DevCsr &d, const PackMeta &m)
         int *mb = reinterpret_cast<int *>(base + dp.map.med_base);
         if (p.cid16)
             hipLaunchKernelGGL((k_pack_medium<T, true>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, val, dr.d, dl.d, dp.args.med_ptr,
-                               dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic, p.windowed);
+                               dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic, p.pair_mode);
         else
             hipLaunchKernelGGL((k_pack_medium<T, false>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, val, dr.d, dl.d, dp.args.med_ptr,
-                               dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic, p.windowed);
+                               dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic, p.pair_mode);
         HIP_TRYP(hipGetLastError());
         HIP_TRYP(hipDeviceSynchronize());
     }

@@ -358,6 +358,15 @@ __device__ __forceinline__ void shot(ACC &acc, const SRC &src, int i0, const XV 
             else { src.load(f[u], i0 + u); src.load(f[u + 1], i0 + u + 1); }
         }
         if constexpr (N % 2 == 1) src.load(f[N - 1], i0 + N - 1);
+    } else if constexpr (SRC::kPairs && N >= 2) {          // f64: a one-shot block is paired as a whole (no tail steps) or not at all
+        if (src.pairs_ok(i0, N & ~1)) {
+#pragma unroll
+            for (int u = 0; u + 1 < N; u += 2) src.load2(f[u], f[u + 1], i0 + u);
+            if constexpr (N % 2 == 1) src.template load<false>(f[N - 1], i0 + N - 1);       // the odd last chunk is lane-linear
+        } else {
+#pragma unroll
+            for (int u = 0; u < N; ++u) src.template load<false>(f[u], i0 + u);
+        }
     } else {
 #pragma unroll
         for (int u = 0; u < N; ++u) src.template load<false>(f[u], i0 + u);
@@ -467,7 +476,7 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     const int nt = (__builtin_amdgcn_readfirstlane(t1 - t0) + TK - 1) / TK;
     BlockSrc<T, NT, C16, YM != 2> src;
     src.reg.val = val; src.reg.cid = a.med_cid; src.reg.e0 = (size_t)c0 * CH; src.reg.lane = lane;
-    src.nc = c1 - c0; src.npair = med_npair(c1 - c0, nt, (int)sizeof(T), YM == 2); src.cid16 = a.med_cid16; src.base = a.med_base; src.c0 = c0;
+    src.nc = c1 - c0; src.npair = med_npair(c1 - c0, nt, (int)sizeof(T), YM == 2 ? 0 : a.pair_mode); src.cid16 = a.med_cid16; src.base = a.med_base; src.c0 = c0;
     src.ival = static_cast<const T *>(a.irr_val); src.icid = a.irr_cid; src.t0 = t0; src.t1 = t1; src.kq = kq;
     run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, src.nc + nt, x);
 
@@ -892,7 +901,7 @@ int upload_plan(Plan &p)
     a.med_cid16 = (const unsigned short *)(base + o_mc16); a.med_base = (const int *)(base + o_mb);
     a.med_dst = (const int *)(base + o_mdst); a.win_cmin = (const int *)(base + o_wc); a.win_len = (const int *)(base + o_wl);
     a.n_windows = (int)p.win_len.size(); a.blocks_per_win = p.windowed ? p.row_window / kMedRows : 0;
-    a.win_hybrid = p.win_hybrid ? 1 : 0;
+    a.win_hybrid = p.win_hybrid ? 1 : 0; a.pair_mode = p.pair_mode;
     a.wg_med = p.windowed ? a.n_windows : (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG;
     // f16 blocks of uniform length: a persistent set of 7 workgroups per CU striding over the blocks amortises the per-wave
     // set-up that weighs twice as much at 2 bytes per value (nlpkkt160 f16 0.675 -> 0.739 of the roofline, Queen_4147 f16

@@ -551,6 +551,10 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         const int r0 = b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
         for (int r = r0; r < r1; ++r) p.irr_ptr[r] = std::max(0, lenM[r] - K * nchunks[b]);
     }
+    // which blocks store chunk pairs (plan.hpp med_npair): none in a windowed plan; pipelined blocks and one-shot f16 blocks otherwise;
+    // one-shot f64 blocks only when the plan is far beyond the 256 MiB Infinity Cache (nlpkkt160: 2.8 GB -7 % / -1.5 % by box; at 278 MB +4-8 %)
+    p.pair_mode = p.windowed || p.opt.chunk_pairs < 0 ? 0 : p.opt.chunk_pairs > 0 ? std::min(2, p.opt.chunk_pairs)
+                                                                     : ((long long)nnz * (geo.vbytes + 4) > 4 * kStreamBytes ? 2 : 1);
     lap("chunk split (+cid16 spans)");
     p.med_ptr.assign((size_t)nb + 1, 0);
     {
@@ -582,7 +586,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                 const size_t base = (size_t)p.med_ptr[b] * CH;
                 const int r0 = (int)b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
                 // tail steps of the block = those of its first (longest) row; with them the kernel decides one shot / pipeline, hence the layout
-                const int npair = med_npair(nc, (p.irr_ptr[r0 + 1] - p.irr_ptr[r0] + K - 1) / K, geo.vbytes, p.windowed);
+                const int npair = med_npair(nc, (p.irr_ptr[r0 + 1] - p.irr_ptr[r0] + K - 1) / K, geo.vbytes, p.pair_mode);
                 {   // pad the block's region (value 0, id -1 / 0xFFFF); real entries overwrite below
                     const size_t n = (size_t)nc * CH;
                     std::fill(mv + base, mv + base + n, (T)0);
@@ -673,7 +677,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     std::memset(&s, 0, sizeof s);
     s.precision = p.precision; s.rowA = m; s.colA = p.n; s.nnzA = nnz;
     s.short_row_1 = n1; s.common_13 = c13; s.short_row_3 = n3; s.short_row_4 = n4; s.short_row_2 = n2;
-    s.row_long = nlong_cls; s.row_block = nmed_all; s.row_zero = nz0; s.med_rows_as_pieces = nsp;
+    s.row_long = nlong_cls; s.row_block = nmed_all; s.row_zero = nz0; s.med_rows_as_pieces = nsp; s.chunk_pairs = p.pair_mode;
     s.nnz_short = nnz_short; s.nnz_long = (int)nnz_long; s.nnz_irreg = nnz_irreg;
     s.origin_nnz_reg = nnz - nnz_irreg - (int)nnz_long - nnz_short;
     s.rowloop = nmed < 59990 ? 1 : (nmed < 400000 ? 2 : 4);
@@ -870,7 +874,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     const int K = (int)p.panels.size();
     s.fill0_nnz_short = s.fill0_nnz_long = s.fill0_nnz_reg = 0;
     s.n_med_blocks = s.n_long_pieces = s.n_long_multi = s.n_short_tiles = s.n_workgroups = 0;
-    s.x_window_on = s.n_windows = s.n_windows_lds = s.lds_bytes = s.row_window = s.cid16_on = s.x_window_hybrid = 0;
+    s.x_window_on = s.n_windows = s.n_windows_lds = s.lds_bytes = s.row_window = s.cid16_on = s.x_window_hybrid = s.chunk_pairs = 0;
     s.window_nnz_frac = 0.0;
     long long stored = 0, dataX = 0;
     for (const auto &h : p.panels) {
@@ -882,7 +886,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
         s.n_short_tiles += t.n_short_tiles; s.n_workgroups += t.n_workgroups;
         s.x_window_on |= t.x_window_on; s.n_windows += t.n_windows; s.n_windows_lds += t.n_windows_lds;
         s.lds_bytes = std::max(s.lds_bytes, t.lds_bytes); s.row_window = std::max(s.row_window, t.row_window);
-        s.cid16_on |= t.cid16_on; s.x_window_hybrid |= t.x_window_hybrid;
+        s.cid16_on |= t.cid16_on; s.x_window_hybrid |= t.x_window_hybrid; s.chunk_pairs = std::max(s.chunk_pairs, t.chunk_pairs);
         s.window_nnz_frac += t.window_nnz_frac * (double)t.nnzA / (double)std::max(1, p.nnz);
     }
     s.rate_fill0 = p.nnz > 0 ? (double)(stored - p.nnz) / p.nnz : 0.0;

@@ -57,12 +57,15 @@ constexpr int kMedBatch64 = 4, kMedShot64 = DASP_SHOT64, kMedBatch16 = DASP_BATC
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline int med_npair(int nc, int nt, int vbytes, bool windowed)
+// mode (Plan::pair_mode): 0 = nothing paired (LDS-windowed plans: latency-bound short blocks, their kernel is the unpaired one);
+// 1 = pipelined blocks and one-shot f16 blocks; 2 = also the one-shot f64 blocks without tail steps -- plans far beyond the Infinity
+// Cache (nlpkkt160 f64 0.4905 -> 0.4543 ms on a slow-population box, 0.4328 -> 0.4261 on a fast one; at 278 MB it costs 4-8 %)
+inline int med_npair(int nc, int nt, int vbytes, int mode)
 {
-    if (windowed) return 0;     // LDS-windowed plans (latency-bound, short blocks) keep every chunk lane-linear: their kernel is unchanged
+    if (mode == 0) return 0;
     const int batch = vbytes == 8 ? kMedBatch64 : kMedBatch16, shot = vbytes == 8 ? kMedShot64 : kMedShot16;
-    // one-shot blocks: f16 pairs them too (nlpkkt160 f16 0.2355 -> 0.2177 ms), f64 does not (nlpkkt160 f64 0.4325 -> 0.4551 when it did)
-    return nc + nt > shot ? nc / batch * batch : (vbytes == 2 ? nc & ~1 : 0);
+    // one-shot blocks: f16 pairs them (nlpkkt160 f16 0.2355 -> 0.2177 ms); f64 only as a whole (no tail steps: one test per block) and only in mode 2
+    return nc + nt > shot ? nc / batch * batch : (vbytes == 2 || (mode == 2 && nt == 0) ? nc & ~1 : 0);
 }
 // where element j (< vpl) of lane `lane` of regular chunk c sits inside its block's region of med_val / med_cid / med_cid16 (in elements)
 #if defined(__HIPCC__)
@@ -149,6 +152,7 @@ struct Plan {
     // windowed mode (LDS-staged x): medium positions follow the windowed order; med_dst[pos] = y index,
     // win_cmin/win_len = the x span of window w (len 0: span too wide, that window gathers from global memory)
     bool windowed = false;
+    int pair_mode = 0;              // which medium blocks store their chunks in pairs (med_npair): decided before packing
     bool win_hybrid = false;        // windows stage their densest span only: gathers outside it read global memory
     int row_window = 0, lds_bytes = 0;
     std::vector<int> med_dst, win_cmin, win_len;

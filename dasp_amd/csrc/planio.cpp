@@ -2,7 +2,7 @@
 // A plan file holds every host array of a Plan, so a later run (or every rank of a multi-GPU job)
 // skips classification and packing: load -> upload -> spmv.
 // layout: "DASPPLN5" | int32 sizeof(dasp_stats_t), kNumShortGroups, sizeof(ShortGroup) | plan, where plan = int32 precision, m, n, nnz,
-//         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows, win_hybrid, med_slot0 | dasp_stats_t |
+//         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows, win_hybrid, med_slot0, pair_mode, 0 | dasp_stats_t |
 //         ShortGroup[kNumShortGroups] | for each array, in a fixed order: int64 byte count + bytes | the n_panels column panels, each
 //         a nested plan.
 // A file is not trusted more than a caller's CSR: after reading, every count, pointer array and column id the kernels index
@@ -111,7 +111,7 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
     auto cid_at = [&](long long b, long long c, long long e) -> long long {
         const long long c0 = p.med_ptr[(size_t)b];
         const long long r0 = b * kMedRows, K = CH / kMedRows;      // tail steps of the block's first row decide its layout (plan.hpp med_npair)
-        const int npair = med_npair((int)(p.med_ptr[(size_t)b + 1] - c0), (int)((p.irr_ptr[(size_t)r0 + 1] - p.irr_ptr[(size_t)r0] + K - 1) / K), (int)vb, p.windowed);
+        const int npair = med_npair((int)(p.med_ptr[(size_t)b + 1] - c0), (int)((p.irr_ptr[(size_t)r0 + 1] - p.irr_ptr[(size_t)r0] + K - 1) / K), (int)vb, p.pair_mode);
         const size_t at = (size_t)c0 * (size_t)CH + med_elem_index(npair, (int)(c - c0), (int)(e / vpl), (int)(e % vpl), vpl, (int)CH);
         if (!p.cid16) return p.med_cid[at];
         const unsigned o = p.med_cid16[at];
@@ -169,8 +169,8 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
 
 static void write_plan(Writer &w, Plan &p)
 {
-    const int hdr[16] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
-                         p.opt.n_parts, p.opt.part_stride, p.opt.stream_policy, (int)p.panels.size(), p.n_mfma_rows, p.win_hybrid ? 1 : 0, p.med_slot0};
+    const int hdr[18] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
+                         p.opt.n_parts, p.opt.part_stride, p.opt.stream_policy, (int)p.panels.size(), p.n_mfma_rows, p.win_hybrid ? 1 : 0, p.med_slot0, p.pair_mode, 0};
     w.raw(hdr, sizeof hdr); w.raw(&p.stats, sizeof p.stats); w.raw(p.grp, sizeof p.grp);
     arrays(w, p);
     for (auto &h : p.panels) write_plan(w, h->impl);
@@ -178,14 +178,15 @@ static void write_plan(Writer &w, Plan &p)
 
 static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
 {
-    int hdr[16];
+    int hdr[18];
     r.raw(hdr, sizeof hdr);
     if (!r.ok || (hdr[0] != 64 && hdr[0] != 16) || hdr[12] < 0 || hdr[12] > 64 || (depth > 0 && hdr[12] != 0)) return false;
     p.precision = hdr[0]; p.geo = geometry_for(p.precision);
     p.m = hdr[1]; p.n = hdr[2]; p.nnz = hdr[3];
     dasp_options_default(&p.opt);
     p.opt.y_order = hdr[4]; p.windowed = hdr[5] != 0; p.row_window = hdr[6]; p.lds_bytes = hdr[7]; p.cid16 = hdr[8] != 0;
-    p.opt.n_parts = hdr[9]; p.opt.part_stride = hdr[10]; p.opt.stream_policy = hdr[11]; p.n_mfma_rows = hdr[13]; p.win_hybrid = hdr[14] != 0; p.med_slot0 = hdr[15];
+    p.opt.n_parts = hdr[9]; p.opt.part_stride = hdr[10]; p.opt.stream_policy = hdr[11]; p.n_mfma_rows = hdr[13]; p.win_hybrid = hdr[14] != 0; p.med_slot0 = hdr[15]; p.pair_mode = hdr[16];
+    if (p.pair_mode < 0 || p.pair_mode > 2 || (p.windowed && p.pair_mode)) return false;
     r.raw(&p.stats, sizeof p.stats); r.raw(p.grp, sizeof p.grp);
     arrays(r, p);
     if (!r.ok) return false;

@@ -146,6 +146,11 @@ typedef struct dasp_options {
      * a tail (<= 15 % of the nonzeros); -1 = off; n >= 5 = every medium row of >= n nonzeros.  Ignored by plans that use x windows
      * (their rows keep the LDS gathers). */
     int piece_min_len;
+    /* paired medium chunks: blocks store two MFMA steps per lane side by side so that one 16-byte load brings both (half the L1 tag
+     * lookups of the streamed tiles).  0 = auto (1, or 2 for plans of more than 1 GiB of CSR; LDS-windowed plans: off);
+     * -1 = off; 1 = the blocks long enough for the kernel's software pipeline and the one-shot f16 blocks; 2 = also the one-shot f64 blocks
+     * that have no tail steps.  order_rid, the classifier counters and the arithmetic of a row do not depend on it. */
+    int chunk_pairs;
 } dasp_options_t;
 
 void dasp_options_default(dasp_options_t *opt);
@@ -173,6 +178,7 @@ typedef struct dasp_stats {
                                   window / cid16 fields are then sums (or any-of) over the panels */
     int x_window_hybrid;       /* windows stage their densest span; window_nnz_frac = share of the medium gathers served from LDS */
     int med_rows_as_pieces;    /* medium rows (the longest ones: the first medium slots) stored as pieces (piece_min_len) */
+    int chunk_pairs;           /* 0 / 1 / 2: which medium blocks store chunk pairs (options chunk_pairs; column panels: the largest) */
 } dasp_stats_t;
 
 /* classifier + packers on the host (no GPU needed).  CSR arrays are read-only and may be

@@ -439,7 +439,7 @@ META_ARRAYS = ("piece_ptr piece_dst multi_ptr multi_dst med_ptr irr_ptr med_dst 
 
 
 @pytest.mark.parametrize("prec", [64, 16])
-@pytest.mark.parametrize("kw", [dict(), dict(cid16=1), dict(cid16=-1, x_window=-1), dict(x_window=100000, y_order=1),
+@pytest.mark.parametrize("kw", [dict(), dict(cid16=1, chunk_pairs=2), dict(cid16=-1, x_window=-1, chunk_pairs=-1), dict(x_window=100000, y_order=1), dict(x_window=-1, chunk_pairs=2, slab_max_len=4),
                                 dict(part_bounds=np.array([0, 700, 2500], np.int32), part_stride=2048, y_order=1, cid16=1)])
 @pytest.mark.parametrize("tag,builder,m,n,seed", [("mixed", util.mixed_matrix, 3000, 2500, 7), ("pairs", util.pair_heavy_matrix, 4000, 2500, 11)])
 def test_device_packed_plan_is_bit_identical(oracle, dasp, torch_cuda, prec, kw, tag, builder, m, n, seed):
@@ -702,7 +702,7 @@ def test_random_option_combinations(oracle, dasp, torch_cuda, seed):
     else:
         rp, ci, v = util.csr_from_lengths(lens, n, int(rng.integers(1 << 30)), dtype=dt)
     kw = dict(col_panels=int(rng.choice([1, 1, 2, 3, 6])), cid16=int(rng.choice([-1, 0, 1])),
-              x_window=int(rng.choice([-1, 0, 0, 40000, 163840])), row_window=int(rng.choice([0, 64, 256, 1024])), x_window_hybrid=int(rng.choice([0, 0, 1, -1])), piece_min_len=int(rng.choice([0, 0, -1, 6, 40])),
+              x_window=int(rng.choice([-1, 0, 0, 40000, 163840])), row_window=int(rng.choice([0, 64, 256, 1024])), x_window_hybrid=int(rng.choice([0, 0, 1, -1])), piece_min_len=int(rng.choice([0, 0, -1, 6, 40])), chunk_pairs=int(rng.choice([0, 0, -1, 1, 2])),
               long_piece=int(rng.choice([0, 64, 300, 4096])), block_longest=int(rng.choice([256, 256, 32, 1000])),
               threshold=float(rng.choice([0.75, 0.75, 0.3, 1.0])), y_order=int(rng.choice([0, 1])),
               slab_max_len=int(rng.choice([0, 4, 7, 16, 32])))

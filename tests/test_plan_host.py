@@ -197,6 +197,45 @@ def test_cid16_span_boundary(dasp):
 
 
 @pytest.mark.parametrize("prec", [64, 16])
+def test_chunk_pairs_layout(dasp, prec):
+    """paired medium chunks (plan.hpp med_npair / med_elem_index): which chunks of a block are stored [pair][lane][2][vpl], for every
+    mode of the option; the decoder un-pairs them, so rows, values and order_rid are those of the unpaired plan"""
+    dt = np.float64 if prec == 64 else np.float16
+    K, CH, vpl = (4, 64, 1) if prec == 64 else (16, 256, 4)
+    batch, shot = (4, 8) if prec == 64 else (2, 2)
+    # 16 rows of 11 K (pipelined: 11 chunks), 16 rows of 3 K (one shot, no tail), 16 rows of 3 K + 1 (one shot + a tail step)
+    lens = np.array([11 * K] * 16 + [3 * K + 1] * 16 + [3 * K] * 16)
+    rp, ci, v = util.csr_from_lengths(lens, 5000, 3, dtype=dt)
+    ref = None
+    for mode, want in ((-1, (0, 0, 0)), (1, (11 // batch * batch, 2 if prec == 16 else 0, 2 if prec == 16 else 0)),
+                       (2, (11 // batch * batch, 2 if prec == 16 else 0, 2))):
+        plan = dasp.Plan(rp, ci, v, 5000, precision=prec, x_window=-1, slab_max_len=4, chunk_pairs=mode, piece_min_len=-1)
+        st = plan.stats
+        assert st["chunk_pairs"] == max(mode, 0) and plan.host_array("med_ptr").tolist() == [0, 11, 14, 17]
+        mv, ip_ = plan.host_array("med_val"), plan.host_array("irr_ptr")
+        assert (np.diff(ip_)[16:32] == 1).all() and ip_[16] == 0 and ip_[-1] == 16
+        for b, npair in enumerate(want):
+            c0 = [0, 11, 14][b]
+            blk = mv[c0 * CH:]
+            row = 16 * b                                  # the block's first row, its entries 0 .. K-1 of chunk 0 and chunk 1
+            r = plan.order_rid[row]
+            a = v[rp[r]:rp[r + 1]]
+            lane = [k * 16 for k in range(K)] if prec == 64 else [(k // 4) * 16 for k in range(K)]
+            j = [0] * K if prec == 64 else [k % 4 for k in range(K)]
+            for c in (0, 1):
+                got = [blk[(c & ~1) * CH + vpl * (2 * lane[k] + (c & 1)) + j[k]] if c < npair else blk[c * CH + vpl * lane[k] + j[k]] for k in range(K)]
+                assert got == a[c * K:(c + 1) * K].tolist(), (mode, b, c)
+        rows = util.decode_plan(plan)
+        if ref is None:
+            ref = rows
+        assert rows == ref and all(rows[s][0] == ci[rp[plan.order_rid[s]]:rp[plan.order_rid[s] + 1]].tolist() for s in range(48))
+    # automatic: mode 1 below 1 GiB of CSR, nothing paired in a windowed plan
+    assert dasp.Plan(rp, ci, v, 5000, precision=prec, x_window=-1).stats["chunk_pairs"] == 1
+    w = dasp.Plan(rp, ci, v, 5000, precision=prec, x_window=100000, chunk_pairs=2).stats
+    assert w["x_window_on"] == 1 and w["chunk_pairs"] == 0
+
+
+@pytest.mark.parametrize("prec", [64, 16])
 def test_serialised_plan_round_trip(dasp, tmp_path, prec):
     dt = np.float64 if prec == 64 else np.float16
     rp, ci, v = banded_matrix(3000, 400, 4)

@@ -90,9 +90,10 @@ def decode_plan(plan):
         for b in range(mptr.size - 1):
             nc = int(mptr[b + 1] - mptr[b])
             nt = -(-int(ip_all[b * 16 + 1] - ip_all[b * 16]) // K)
-            npair = nc // batch * batch if nc + nt > shot else (nc & ~1 if prec == 16 else 0)    # one-shot blocks: f16 pairs, f64 does not
-            if st.get("x_window_on"):
-                npair = 0                                                                     # windowed plans: all lane-linear
+            mode = st["chunk_pairs"]          # 0: nothing paired (windowed plans / option); 1: pipelined + one-shot f16; 2: + tail-less one-shot f64
+            npair = nc // batch * batch if nc + nt > shot else (nc & ~1 if prec == 16 or (nt == 0 and mode == 2) else 0)
+            if mode == 0:
+                npair = 0
             if npair:
                 lo = int(mptr[b]) * CH
                 a[lo:lo + npair * CH] = a[lo:lo + npair * CH].reshape(npair // 2, 64, 2, VPL).transpose(0, 2, 1, 3).reshape(-1)
