@@ -907,11 +907,22 @@ int upload_plan(Plan &p)
     // set-up that weighs twice as much at 2 bytes per value (nlpkkt160 f16 0.675 -> 0.739 of the roofline, Queen_4147 f16
     // 0.873 -> 0.927).  Static striding needs equal blocks: with HV15R's 2 % of 3x longer rows it loses 10 %, and in f64 it
     // loses 3-9 % everywhere, so: f16 only, no windows, longest block <= 1.25 x the mean.
-    if (!p.windowed && p.precision == 16 && a.n_blocks > 256 * 7 * kWavesPerWG) {
+    if (!p.windowed && p.precision == 16 && a.n_blocks > 256 * 7 * kWavesPerWG) {      // (the threshold: a full set on a 256-CU device)
         int longest = 0;
         for (int b = 0; b < a.n_blocks; ++b) longest = std::max(longest, p.med_ptr[(size_t)b + 1] - p.med_ptr[(size_t)b]);
         const double mean = (double)p.med_ptr[(size_t)a.n_blocks] / (double)a.n_blocks;
-        if (p.cnt_irr * 8 <= p.cnt_reg && mean > 0 && (double)longest <= 1.25 * mean) a.wg_med = std::min(a.wg_med, 256 * 7);
+        if (p.cnt_irr * 8 <= p.cnt_reg && mean > 0 && (double)longest <= 1.25 * mean) {
+            // as many persistent workgroups per CU as the kernel's registers let reside at once (7 at <= 72 VGPRs), on every CU of the device
+            int per_cu = 7, cus = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+            const void *fn = p.cid16 ? reinterpret_cast<const void *>(&dasp_spmv_kernel<_Float16, true, true, false>)
+                                     : reinterpret_cast<const void *>(&dasp_spmv_kernel<_Float16, true, false, false>);
+            int fit = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, fn, kWave * kWavesPerWG, 0) == hipSuccess && fit > 0) per_cu = std::min(per_cu, fit);
+            (void)hipGetLastError();
+            a.wg_med = std::min(a.wg_med, cus * per_cu);
+        }
     }
     a.wg_short = (a.n_short_tiles + a.wpw - 1) / a.wpw;
     // streamed-once matrix data bypasses the caches (the reference's ld.global.cs, dasp_f64.h:34-51)
