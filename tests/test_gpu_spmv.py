@@ -216,6 +216,18 @@ def test_cli_drivers(torch_cuda, exe, fixture, tmp_path):
         assert len(row.split(",")) == ncol and not row.endswith(",")
 
 
+@pytest.mark.parametrize("args", [("HV15R", "0.02", "64"), ("HV15R", "0.02", "16"), ("cop20k_A", "0.5", "64"), ("webbase-1M", "0.2", "16"),
+                                  ("nlpkkt160", "0.01", "64", "5", "2", "0.75", "1024", "0", "0", "1", "0", "0", "0", "0", "0", "2")])
+def test_dasp_bench_checks_values_and_columns(torch_cuda, args):
+    """the A/B driver of tools/ab.sh verifies what it times: the all-ones product exactly (row lengths) and a product with
+    x[j] = 1 + (j % 61) / 64 against a host CSR loop -- an all-ones product alone cannot see a wrong column id.  Last case: 16-bit
+    ids with every pairing mode forced (chunk_pairs = 2)"""
+    a = list(args) + ["5", "2"] if len(args) == 3 else list(args)
+    r = subprocess.run([os.path.join(ROOT, "dasp_amd", "bin", "dasp_bench")] + a, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mismatches=0" in r.stdout.splitlines()[-1], r.stdout
+
+
 def test_bench_reads_real_matrices_from_dasp_mtx_dir(dasp, torch_cuda, tmp_path):
     """DASP_MTX_DIR: bench.py takes <workload>.mtx from that directory (through the product loader + CSR cache) instead of the
     seeded stand-in -- here a MatrixMarket file written from the small stand-in itself, so the result is known"""
