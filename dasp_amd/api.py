@@ -201,6 +201,8 @@ class Plan:
             _lib.check(int(n))
         if name == "med_cid16":
             dt = np.uint16
+        elif name == "med_cid8":
+            dt = np.uint8
         elif eb.value == 4:
             dt = np.int32
         else:

@@ -216,7 +216,9 @@ struct ChunkSrc {
 // a medium block: nc lane-linear chunks, then the irregular tail as extra steps in which lane (row = l&15, kq = l>>4)
 // takes the next entries of its own row.  Out-of-range lanes read element 0 of the tail arrays (never empty: the
 // arena pads them) and are zeroed in gather(), so neither stage has a divergent branch.
-template <class T, bool NT, bool C16, bool PAIRS>
+// C8: the plan has one-byte ids (f64, 16-bit-id plans with narrow chunks): its own kernel instantiation, so that every other plan runs
+// exactly the code it ran before
+template <class T, bool NT, bool C16, bool PAIRS, bool C8>
 struct BlockSrc {
     static constexpr bool kPairs = PAIRS;          // false: the windowed kernel, whose plans keep every chunk lane-linear
     static constexpr int VPL = Tr<T>::CHUNK / kWave;           // values of one chunk per lane: 1 (f64) / 4 (f16)
@@ -251,7 +253,7 @@ struct BlockSrc {
             const f64x2 v = ldg<NT>(reinterpret_cast<const f64x2 *>(reg.val + at));
             f0.a = v[0]; f1.a = v[1];
             if constexpr (C16) {
-                const unsigned r = ldg<NT>(reinterpret_cast<const unsigned *>((PAIRS ? w16 : cid16) + at));      // raw offsets; rebased in gather() (one-shot blocks: n8 = 0)
+                const unsigned r = ldg<NT>(reinterpret_cast<const unsigned *>((kQuadIds ? w16 : cid16) + at));      // raw offsets; rebased in gather() (one-shot blocks: n8 = 0)
                 f0.c = (int)(r & 0xFFFFu); f1.c = (int)(r >> 16);
             } else {
                 const i32x2 c = ldg<NT>(reinterpret_cast<const i32x2 *>(reg.cid + at));
@@ -273,7 +275,7 @@ struct BlockSrc {
     // dword loads of ids, branch-free whether the batch is narrow (i + 4 <= n8: ONE dword per lane holds the four one-byte ids; the second
     // load repeats the first address) or wide (two pairs of u16 offsets): the base pointer is a wave-uniform select.  The raw dword stays
     // in the fragment; gather<true>() cuts the chunk's field out of it.
-    static constexpr bool kQuadIds = PAIRS && C16 && sizeof(T) == 8 && Tr<T>::BATCH == 4;
+    static constexpr bool kQuadIds = C8 && PAIRS && C16 && sizeof(T) == 8 && Tr<T>::BATCH == 4;
     __device__ __forceinline__ void load4(Frag<T> *f, int i) const
     {
         constexpr int CH = Tr<T>::CHUNK;
@@ -298,7 +300,7 @@ struct BlockSrc {
             else {
                 if constexpr (sizeof(T) == 8) {
                     f.a = ldg<NT>(reg.val + at);
-                    f.c = (int)ldg<NT>((PAIRS ? w16 : cid16) + at);             // raw offset; rebased in gather() (single loads only see positions >= n8)
+                    f.c = (int)ldg<NT>((kQuadIds ? w16 : cid16) + at);             // raw offset; rebased in gather() (single loads only see positions >= n8)
                 } else {
                     f.a = ldg<NT>(reinterpret_cast<const f16x4 *>(reg.val + at));
                     const i32x2 o = ldg<NT>(reinterpret_cast<const i32x2 *>(cid16 + at));      // raw u16 offsets, two per dword
@@ -496,7 +498,7 @@ __device__ __forceinline__ bool diag_of(const f32x4 &acc, int lane, float &d)
 // ---- medium: one wave = one block of 16 sorted rows (reference: dasp_f64.h:145-279)
 // YM: where the 16 results go -- 0: the block's own slots (reference permutation), or order[slot] when the plan is
 // DASP_Y_NATURAL (a.order set); 2: med_dst[position] (windowed mode)
-template <class T, bool NT, bool C16, int YM, class XV>
+template <class T, bool NT, bool C16, int YM, bool C8 = false, class XV>
 __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, const XV &x)
 {
     using acc_t = typename Tr<T>::acc_t;
@@ -511,11 +513,11 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     if (r < a.row_block) { t0 = a.irr_ptr[r]; t1 = a.irr_ptr[r + 1]; }
     constexpr int TK = sizeof(T) == 8 ? 4 : 16;                      // tail entries of one row per MFMA step
     const int nt = (__builtin_amdgcn_readfirstlane(t1 - t0) + TK - 1) / TK;
-    BlockSrc<T, NT, C16, YM != 2> src;
+    BlockSrc<T, NT, C16, YM != 2, C8> src;
     src.reg.val = val; src.reg.cid = a.med_cid; src.reg.e0 = (size_t)c0 * CH; src.reg.lane = lane;
     src.nc = c1 - c0; src.npair = med_npair(c1 - c0, nt, (int)sizeof(T), YM == 2 ? 0 : a.pair_mode); src.cid16 = a.med_cid16; src.base = a.med_base; src.c0 = c0;
     src.c8 = a.med_cid8; src.w16 = a.med_cid16; src.n8 = 0;
-    if constexpr (C16 && sizeof(T) == 8 && YM != 2) {
+    if constexpr (C8 && C16 && sizeof(T) == 8 && YM != 2) {
         const int q0 = a.med_c8ptr[b], q1 = a.med_c8ptr[b + 1];
         src.n8 = q1 - q0; src.c8 = a.med_cid8 + (size_t)q0 * CH; src.w16 = a.med_cid16 - (size_t)q1 * CH;      // e16 - (e0 + n8 CH) = -(q0 + n8) CH
     }
@@ -680,7 +682,7 @@ constexpr int kMinWavesPlain = 1, kMinWavesWin = 8;
 // WIN: windowed mode.  A medium workgroup owns one window of row_window rows (blocks_per_win blocks, strided over its
 // 4 waves); if the window's x span fits, it is copied once into LDS with coalesced 16-byte loads and every gather of
 // the window reads LDS; otherwise that workgroup gathers from global memory like the non-windowed kernel.
-template <class T, bool NT, bool C16, bool WIN>
+template <class T, bool NT, bool C16, bool WIN, bool C8 = false>
 __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPlain) void dasp_spmv_kernel(DevArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -698,7 +700,7 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPla
             // grid-stride over the blocks: wg_med is capped (upload_plan) so the medium range is a persistent set of workgroups
 #pragma unroll 1
             for (int b = m * kWavesPerWG + wave; b < a.n_blocks; b += a.wg_med * kWavesPerWG)
-                medium_block<T, NT, C16, 0>(a, b, lane, x);
+                medium_block<T, NT, C16, 0, C8>(a, b, lane, x);
         } else {
             // one window per workgroup; its blocks_per_win blocks are dealt round-robin to the wpw waves
             const int w = wg - a.wg_long;
@@ -1005,6 +1007,10 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
         else if (c16 && p.windowed) { M(false, true, true); } else if (c16) { M(false, true, false); } \
         else if (p.windowed) { M(false, false, true); } else { M(false, false, false); }
 #define DASP_LAUNCH(NTV, CV, WINV) hipLaunchKernelGGL((dasp_spmv_kernel<T, NTV, CV, WINV>), dim3(grid), dim3(kWave * a.wpw), lds, s, a)
+        if (sizeof(T) == 8 && c16 && !p.windowed && p.cnt_reg8 > 0) {      // plans with one-byte ids: their own instantiation
+            if (nt) hipLaunchKernelGGL((dasp_spmv_kernel<double, true, true, false, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, a);
+            else hipLaunchKernelGGL((dasp_spmv_kernel<double, false, true, false, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, a);
+        } else
         DASP_FOR_EACH(DASP_LAUNCH)
 #undef DASP_LAUNCH
 #undef DASP_FOR_EACH
