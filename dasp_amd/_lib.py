@@ -24,7 +24,7 @@ class Options(C.Structure):
         ("host_threads", C.c_int), ("n_parts", C.c_int), ("part_bounds", C.POINTER(C.c_int)), ("part_stride", C.c_int),
         ("x_window", C.c_int), ("row_window", C.c_int), ("cid16", C.c_int), ("stream_policy", C.c_int),
         ("col_panels", C.c_int), ("slab_max_len", C.c_int), ("x_window_hybrid", C.c_int), ("piece_min_len", C.c_int),
-        ("chunk_pairs", C.c_int),
+        ("chunk_pairs", C.c_int), ("cid8", C.c_int),
     ]
 
 
@@ -38,7 +38,7 @@ class Stats(C.Structure):
         ("n_workgroups", C.c_int), ("pre_ms", C.c_double),
         ("x_window_on", C.c_int), ("n_windows", C.c_int), ("n_windows_lds", C.c_int), ("lds_bytes", C.c_int),
         ("row_window", C.c_int), ("window_nnz_frac", C.c_double), ("cid16_on", C.c_int),
-        ("n_col_panels", C.c_int), ("x_window_hybrid", C.c_int), ("med_rows_as_pieces", C.c_int), ("chunk_pairs", C.c_int)]
+        ("n_col_panels", C.c_int), ("x_window_hybrid", C.c_int), ("med_rows_as_pieces", C.c_int), ("chunk_pairs", C.c_int), ("cid8_chunks", C.c_int)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

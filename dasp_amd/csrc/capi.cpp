@@ -220,7 +220,7 @@ static long long host_array_impl(const dasp_plan_t *plan, const char *name, cons
     const Plan &p = plan->impl;
     // the nnz-sized arrays exist on the host only until dasp_plan_drop_host (never, for a plan packed on the device);
     // the O(rows) arrays and order_rid always do
-    static const char *const kBulk[] = {"long_val", "long_cid", "med_val", "med_cid", "med_cid16", "irr_val", "irr_cid", "short_val", "short_cid"};
+    static const char *const kBulk[] = {"long_val", "long_cid", "med_val", "med_cid", "med_cid16", "med_cid8", "irr_val", "irr_cid", "short_val", "short_cid"};
     if (p.host_dropped)
         for (const char *b : kBulk)
             if (std::strcmp(name, b) == 0) { set_error("host copy of this array was dropped (use dasp_plan_download_array)"); return DASP_ERR_STATE; }
@@ -244,6 +244,9 @@ static long long host_array_impl(const dasp_plan_t *plan, const char *name, cons
     if (n == "irr_val") return vals(p.irr_val);
     if (n == "irr_cid") return rints(p.irr_cid);
     if (n == "med_cid16") { *ptr = p.med_cid16.data(); *elem_bytes = 2; return (long long)p.med_cid16.size(); }
+    if (n == "med_cid8") { *ptr = p.med_cid8.data(); *elem_bytes = 1; return (long long)p.med_cid8.size(); }
+    if (n == "med_c8ptr") return ints(p.med_c8ptr);
+    if (n == "med_korig") return ints(p.med_korig);
     if (n == "med_base") {
         if (p.cid16 && p.med_base.empty() && p.med_ptr.back() > 0) { set_error("med_base lives on the device only (use dasp_plan_download_array)"); return DASP_ERR_STATE; }
         return ints(p.med_base);
@@ -281,7 +284,7 @@ int dasp_plan_drop_host(dasp_plan_t *plan)
     if (!p.dev) { set_error("upload the plan before dropping its host arrays"); return DASP_ERR_STATE; }
     auto dropc = [](raw_vector<char> &v) { raw_vector<char>().swap(v); };
     auto dropi = [](raw_vector<int> &v) { raw_vector<int>().swap(v); };
-    dropc(p.long_val); dropi(p.long_cid); dropc(p.med_val); dropi(p.med_cid); raw_vector<uint16_t>().swap(p.med_cid16);
+    dropc(p.long_val); dropi(p.long_cid); dropc(p.med_val); dropi(p.med_cid); raw_vector<uint16_t>().swap(p.med_cid16); raw_vector<uint8_t>().swap(p.med_cid8);
     dropc(p.irr_val); dropi(p.irr_cid); dropc(p.short_val); dropi(p.short_cid);
     p.host_dropped = true;
     for (auto &h : p.panels) if (int rc = dasp_plan_drop_host(h.get())) return rc;

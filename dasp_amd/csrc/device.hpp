@@ -24,6 +24,7 @@ struct DevArgs {
     int pair_mode;                                           // Plan::pair_mode (plan.hpp med_npair)
     const int *med_ptr; const void *med_val; const int *med_cid;
     const unsigned short *med_cid16; const int *med_base;   // cid16 mode: u16 offsets + per-chunk base column
+    const unsigned char *med_cid8; const int *med_c8ptr;     // ... and the one-byte offsets of the narrow chunks (plan.hpp med_cid8)
     const int *irr_ptr; const void *irr_val; const int *irr_cid;
     int n_blocks, row_block, row_long;
     // windowed mode (LDS-staged x)
@@ -44,7 +45,7 @@ struct DevArgs {
 
 // byte offsets of the nnz-sized arrays inside the arena (devpack.hip writes them, tests download them)
 struct ArenaMap {
-    size_t long_val = 0, long_cid = 0, med_val = 0, med_cid = 0, med_cid16 = 0, med_base = 0, irr_val = 0, irr_cid = 0,
+    size_t long_val = 0, long_cid = 0, med_val = 0, med_cid = 0, med_cid16 = 0, med_cid8 = 0, med_base = 0, irr_val = 0, irr_cid = 0,
            short_val = 0, short_cid = 0;
 };
 

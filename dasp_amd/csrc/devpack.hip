@@ -90,15 +90,17 @@ __global__ void k_row_coherence(const int *rp, const int *ci, const int *rows, i
     atomicAdd(out + 1, (unsigned long long)len);
 }
 
-// one wave per medium block: first chunk (of the nchunks[b] the fill rule keeps) whose columns span more than 65534
+// one wave per medium block: first chunk (of the nchunks[b] the fill rule keeps) whose columns span more than 65534, and which of the
+// chunks before it (< 64) span <= 254 columns (bit c of narrow[b]: one-byte ids, plan.cpp)
 template <int K>
 __global__ void k_chunk_spans(const int *rp, const int *ci, const int *ridM, const int *lenM, const int *nchunks, int nmed, int nb,
-                              RemapDev remap, int *k16)
+                              RemapDev remap, int *k16, unsigned long long *narrow)
 {
     const int lane = threadIdx.x & 63, b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= nb) return;
     const int r0 = b * kMedRows, k = nchunks[b];
     int out = k;
+    unsigned long long mask = 0;
     for (int c = 0; c < k; ++c) {
         int lo = 2147483647, hi = -1;
         // K columns x 16 rows = 16*K elements of the chunk, strided over the wave
@@ -108,8 +110,9 @@ __global__ void k_chunk_spans(const int *rp, const int *ci, const int *ridM, con
         }
         lo = wave_min(lo); hi = wave_max(hi);
         if (hi >= 0 && (long long)hi - lo > 65534) { out = c; break; }
+        if (c < 64 && hi >= 0 && hi - lo <= 254) mask |= 1ull << c;
     }
-    if (lane == 0) k16[b] = out;
+    if (lane == 0) { k16[b] = out; if (narrow) narrow[b] = mask; }
 }
 
 template <class T>
@@ -131,7 +134,7 @@ __global__ void k_pack_long(const int *rp, const int *ci, const T *val, const in
 template <class T, bool C16>
 __global__ void k_pack_medium(const int *rp, const int *ci, const T *val, const int *ridM, const int *lenM, const int *med_ptr,
                               const int *irr_ptr, int nmed, int nb, RemapDev remap, T *mv, int *mc, unsigned short *mc16, int *mbase,
-                              T *iv, int *ic, int pair_mode)
+                              T *iv, int *ic, int pair_mode, const int *c8ptr, unsigned char *mc8, int *korig)
 {
     constexpr int K = sizeof(T) == 8 ? 4 : 16, CH = kMedRows * K, VPL = CH / 64;
     const int lane = threadIdx.x & 63, b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -142,9 +145,12 @@ __global__ void k_pack_medium(const int *rp, const int *ci, const T *val, const 
     const int rr = lane & 15, kq = lane >> 4, r = r0 + rr;
     const bool row_ok = r < nmed;
     const int a0 = row_ok ? rp[ridM[r]] : 0, len = row_ok ? lenM[r] : 0;
+    // cid16 mode: n8 narrow chunks of the paired region go to its front (one-byte ids), the others follow in their order (plan.cpp packs the same)
+    int n8 = 0, a8 = 0, a16 = 0; size_t e8 = 0, e16 = (size_t)c0 * CH;
+    if constexpr (C16) { n8 = c8ptr[b + 1] - c8ptr[b]; e8 = (size_t)c8ptr[b] * CH; e16 = ((size_t)c0 - (size_t)c8ptr[b]) * CH; }
     for (int c = 0; c < nc; ++c) {
         int col[VPL]; T v[VPL];
-        int lo = 2147483647;
+        int lo = 2147483647, hi = -1;
 #pragma unroll
         for (int q = 0; q < VPL; ++q) {
             // f64: lane = kk*16 + rr holds entry kk of the chunk ; f16: lane = kq*16 + rr holds entries 4kq .. 4kq+3
@@ -152,16 +158,23 @@ __global__ void k_pack_medium(const int *rp, const int *ci, const T *val, const 
             const bool in = row_ok && i < len;
             v[q] = in ? val[a0 + i] : (T)0;
             col[q] = in ? remap(ci[a0 + i]) : -1;
-            if (in) lo = min(lo, col[q]);
+            if (in) { lo = min(lo, col[q]); hi = max(hi, col[q]); }
         }
-        const size_t at = (size_t)c0 * CH + med_elem_index(npair, c, lane, 0, VPL, CH);      // pipelined blocks: pairs of chunks interleaved per lane (plan.hpp)
         if constexpr (C16) {
-            lo = wave_min(lo);
+            lo = wave_min(lo); hi = wave_max(hi);
+            const bool narrow = c < npair && c < 64 && a8 < n8 && hi >= 0 && hi - lo <= 254;       // wave-uniform
             if (lo == 2147483647) lo = 0;
-            if (lane == 0) mbase[c0 + c] = lo;
+            const int pos = c >= npair ? c : narrow ? a8++ : n8 + a16++;
+            if (lane == 0) { mbase[c0 + pos] = lo; korig[c0 + pos] = c; }
+            const size_t at = (size_t)c0 * CH + med_elem_index(npair, pos, lane, 0, VPL, CH);     // pipelined blocks: pairs of chunks interleaved per lane (plan.hpp)
 #pragma unroll
-            for (int q = 0; q < VPL; ++q) { mv[at + q] = v[q]; mc16[at + q] = col[q] < 0 ? (unsigned short)0xFFFF : (unsigned short)(col[q] - lo); }
+            for (int q = 0; q < VPL; ++q) {
+                mv[at + q] = v[q];
+                if (pos < n8) mc8[e8 + med_cid8_index(pos, lane, CH)] = col[q] < 0 ? (unsigned char)0xFF : (unsigned char)(col[q] - lo);      // f64 only: VPL = 1
+                else mc16[e16 + med_elem_index(npair - n8, pos - n8, lane, q, VPL, CH)] = col[q] < 0 ? (unsigned short)0xFFFF : (unsigned short)(col[q] - lo);
+            }
         } else {
+            const size_t at = (size_t)c0 * CH + med_elem_index(npair, c, lane, 0, VPL, CH);
 #pragma unroll
             for (int q = 0; q < VPL; ++q) { mv[at + q] = v[q]; mc[at + q] = col[q]; }
         }
@@ -297,7 +310,7 @@ int devpack_row_coherence(const Plan &p, const DevCsr &d, const std::vector<int>
 }
 
 int devpack_chunk_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridM, const std::vector<int> &lenM,
-                        const std::vector<int> &nchunks, int *k16)
+                        const std::vector<int> &nchunks, int *k16, unsigned long long *narrow_mask)
 {
     const int nmed = (int)ridM.size(), nb = (nmed + kMedRows - 1) / kMedRows;
     if (nb == 0) return DASP_OK;
@@ -307,12 +320,14 @@ int devpack_chunk_spans(const Plan &p, const DevCsr &d, const std::vector<int> &
     if (int rc = dl.init(lenM)) return rc;
     if (int rc = dk.init(nchunks)) return rc;
     DevBuf<int> dout; if (int rc = dout.init((size_t)nb)) return rc;
+    DevBuf<unsigned long long> dmask; if (narrow_mask) if (int rc = dmask.init((size_t)nb)) return rc;
     if (p.precision == 64)
-        hipLaunchKernelGGL((k_chunk_spans<4>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, dr.d, dl.d, dk.d, nmed, nb, rm.r, dout.d);
+        hipLaunchKernelGGL((k_chunk_spans<4>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, dr.d, dl.d, dk.d, nmed, nb, rm.r, dout.d, narrow_mask ? dmask.d : nullptr);
     else
-        hipLaunchKernelGGL((k_chunk_spans<16>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, dr.d, dl.d, dk.d, nmed, nb, rm.r, dout.d);
+        hipLaunchKernelGGL((k_chunk_spans<16>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, dr.d, dl.d, dk.d, nmed, nb, rm.r, dout.d, narrow_mask ? dmask.d : nullptr);
     HIP_TRYP(hipGetLastError());
     HIP_TRYP(hipMemcpy(k16, dout.d, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost));
+    if (narrow_mask) HIP_TRYP(hipMemcpy(narrow_mask, dmask.d, sizeof(unsigned long long) * (size_t)nb, hipMemcpyDeviceToHost));
     return DASP_OK;
 }
 
@@ -341,14 +356,18 @@ static int pack_all_typed(Plan &p, const DevCsr &d, const PackMeta &m)
         int *mc = reinterpret_cast<int *>(base + dp.map.med_cid), *ic = reinterpret_cast<int *>(base + dp.map.irr_cid);
         unsigned short *mc16 = reinterpret_cast<unsigned short *>(base + dp.map.med_cid16);
         int *mb = reinterpret_cast<int *>(base + dp.map.med_base);
+        unsigned char *mc8 = reinterpret_cast<unsigned char *>(base + dp.map.med_cid8);
+        DevBuf<int> dko;                                    // which chunk of its block sits at each position: back to the host (plan files, decoders)
+        if (p.cid16) if (int rc = dko.init(std::max<size_t>(1, p.med_korig.size()))) return rc;
         if (p.cid16)
             hipLaunchKernelGGL((k_pack_medium<T, true>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, val, dr.d, dl.d, dp.args.med_ptr,
-                               dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic, p.pair_mode);
+                               dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic, p.pair_mode, dp.args.med_c8ptr, mc8, dko.d);
         else
             hipLaunchKernelGGL((k_pack_medium<T, false>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, val, dr.d, dl.d, dp.args.med_ptr,
-                               dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic, p.pair_mode);
+                               dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic, p.pair_mode, nullptr, nullptr, nullptr);
         HIP_TRYP(hipGetLastError());
         HIP_TRYP(hipDeviceSynchronize());
+        if (p.cid16 && !p.med_korig.empty()) HIP_TRYP(hipMemcpy(p.med_korig.data(), dko.d, p.med_korig.size() * sizeof(int), hipMemcpyDeviceToHost));
     }
     for (int g = 0; g < kNumShortGroups; ++g) {
         const ShortGroup &G = p.grp[g];
@@ -400,7 +419,7 @@ int download_array(Plan &p, const char *name, void *dst, size_t bytes)
     struct { const char *n; size_t off, len; } tab[] = {
         {"long_val", mp.long_val, p.cnt_long * vb}, {"long_cid", mp.long_cid, p.cnt_long * 4},
         {"med_val", mp.med_val, p.cnt_reg * vb}, {"med_cid", mp.med_cid, p.cid16 ? 0 : p.cnt_reg * 4},
-        {"med_cid16", mp.med_cid16, p.cid16 ? p.cnt_reg * 2 : 0}, {"med_base", mp.med_base, p.cid16 ? (size_t)p.med_ptr.back() * 4 : 0},
+        {"med_cid16", mp.med_cid16, p.cid16 ? (p.cnt_reg - p.cnt_reg8) * 2 : 0}, {"med_cid8", mp.med_cid8, p.cnt_reg8}, {"med_base", mp.med_base, p.cid16 ? (size_t)p.med_ptr.back() * 4 : 0},
         {"irr_val", mp.irr_val, p.cnt_irr * vb}, {"irr_cid", mp.irr_cid, p.cnt_irr * 4},
         {"short_val", mp.short_val, p.cnt_short * vb}, {"short_cid", mp.short_cid, p.cnt_short * 4},
     };

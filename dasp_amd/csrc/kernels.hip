@@ -48,6 +48,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(1))) unsigned char *gbyte_p;      // explicitly global: a select of two flat pointers is not inferred
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // ------------------------------------------------------------------ device helpers
@@ -206,16 +207,18 @@ __device__ __forceinline__ void frag_mfma(f32x4 &acc, const Frag<_Float16> &f)
 // lane-linear chunks only (long pieces)
 template <class T, bool NT>
 struct ChunkSrc {
-    static constexpr bool kPairs = false;
+    static constexpr bool kPairs = false, kQuadIds = false;
     const T *val; const int *cid; size_t e0; int lane;
     template <bool PAIRED_OK = true> __device__ __forceinline__ void load(Frag<T> &f, int i) const { frag_load<NT>(f, val, cid, e0 + (size_t)i * Tr<T>::CHUNK, lane); }
-    template <class XV> __device__ __forceinline__ void gather(Frag<T> &f, int, const XV &x) const { frag_gather(f, x); }
+    template <bool QUAD = false, class XV> __device__ __forceinline__ void gather(Frag<T> &f, int, const XV &x) const { frag_gather(f, x); }
 };
 
 // a medium block: nc lane-linear chunks, then the irregular tail as extra steps in which lane (row = l&15, kq = l>>4)
 // takes the next entries of its own row.  Out-of-range lanes read element 0 of the tail arrays (never empty: the
 // arena pads them) and are zeroed in gather(), so neither stage has a divergent branch.
-template <class T, bool NT, bool C16, bool PAIRS>
+// C8: the plan has one-byte ids (f64, 16-bit-id plans with narrow chunks): its own kernel instantiation, so that every other plan runs
+// exactly the code it ran before
+template <class T, bool NT, bool C16, bool PAIRS, bool C8>
 struct BlockSrc {
     static constexpr bool kPairs = PAIRS;          // false: the windowed kernel, whose plans keep every chunk lane-linear
     static constexpr int VPL = Tr<T>::CHUNK / kWave;           // values of one chunk per lane: 1 (f64) / 4 (f16)
@@ -225,7 +228,11 @@ struct BlockSrc {
     // (4 lanes per pass) -- half the tag lookups per streamed byte (profiles/r02_pairs.md).  npair is a multiple of BATCH, so a
     // pipeline batch is either all pairs or all lane-linear chunks / tail steps.
     int npair;                                                  // chunks [0, npair) are paired
-    const unsigned short *cid16; const int *base; int c0;      // C16: ids of the regular chunks as u16 offsets from base[chunk]
+    const unsigned short *cid16; const int *base; int c0;      // C16: ids of the regular chunks as u16 offsets from base[chunk] ...
+    // ... except the block's first n8 positions (f64: whole batches of a pipelined block's paired region): one-byte offsets, c8 = their
+    // plane at the block's first element.  w16 = the u16 plane rebased so that position i's ids sit where the block's own position i
+    // would be: w16 = cid16 + e16 - (e0 + n8 * CH), i.e. `w16 + at_of(i)` for i >= n8
+    const unsigned char *c8; const unsigned short *w16; int n8;
     const T *ival; const int *icid; int t0, t1, kq;
     // element index of this lane's first value (and id) of regular chunk i -- wave-uniform part + lane part
     template <bool PAIRED_OK> __device__ __forceinline__ size_t at_of(int i) const
@@ -246,7 +253,7 @@ struct BlockSrc {
             const f64x2 v = ldg<NT>(reinterpret_cast<const f64x2 *>(reg.val + at));
             f0.a = v[0]; f1.a = v[1];
             if constexpr (C16) {
-                const unsigned r = ldg<NT>(reinterpret_cast<const unsigned *>(cid16 + at));      // raw offsets; rebased in gather()
+                const unsigned r = ldg<NT>(reinterpret_cast<const unsigned *>((kQuadIds ? w16 : cid16) + at));      // raw offsets; rebased in gather() (one-shot blocks: n8 = 0)
                 f0.c = (int)(r & 0xFFFFu); f1.c = (int)(r >> 16);
             } else {
                 const i32x2 c = ldg<NT>(reinterpret_cast<const i32x2 *>(reg.cid + at));
@@ -264,6 +271,26 @@ struct BlockSrc {
             }
         }
     }
+    // f64 with 16-bit ids: the four chunks i .. i + 3 of one pipeline batch inside the paired region -- two 16-byte loads of values and two
+    // dword loads of ids, branch-free whether the batch is narrow (i + 4 <= n8: ONE dword per lane holds the four one-byte ids; the second
+    // load repeats the first address) or wide (two pairs of u16 offsets): the base pointer is a wave-uniform select.  The raw dword stays
+    // in the fragment; gather<true>() cuts the chunk's field out of it.
+    static constexpr bool kQuadIds = C8 && PAIRS && C16 && sizeof(T) == 8 && Tr<T>::BATCH == 4;
+    __device__ __forceinline__ void load4(Frag<T> *f, int i) const
+    {
+        constexpr int CH = Tr<T>::CHUNK;
+        const size_t at = reg.e0 + (size_t)i * CH + (size_t)2 * reg.lane;
+        const f64x2 v0 = ldg<NT>(reinterpret_cast<const f64x2 *>(reg.val + at));
+        const f64x2 v1 = ldg<NT>(reinterpret_cast<const f64x2 *>(reg.val + at + 2 * CH));
+        f[0].a = v0[0]; f[1].a = v0[1]; f[2].a = v1[0]; f[3].a = v1[1];
+        const bool narrow = i + 4 <= n8;                        // wave-uniform
+        const gbyte_p pa = narrow ? (gbyte_p)(c8 + (size_t)i * CH) : (gbyte_p)(w16 + reg.e0 + (size_t)i * CH);
+        const gbyte_p pb = narrow ? pa : pa + 4 * CH;           // the wide batch's second pair: 2 chunks x CH u16 further
+        const unsigned lo4 = 4u * (unsigned)reg.lane;
+        const unsigned ra = ldg<NT>((const __attribute__((address_space(1))) unsigned *)(pa + lo4));
+        const unsigned rb = ldg<NT>((const __attribute__((address_space(1))) unsigned *)(pb + lo4));
+        f[0].c = (int)ra; f[1].c = (int)ra; f[2].c = (int)rb; f[3].c = (int)rb;
+    }
     // PAIRED_OK = false: the caller knows the block has no paired chunks (the one-shot path)
     template <bool PAIRED_OK = true> __device__ __forceinline__ void load(Frag<T> &f, int i) const
     {
@@ -273,7 +300,7 @@ struct BlockSrc {
             else {
                 if constexpr (sizeof(T) == 8) {
                     f.a = ldg<NT>(reg.val + at);
-                    f.c = (int)ldg<NT>(cid16 + at);             // raw offset; rebased in gather()
+                    f.c = (int)ldg<NT>((kQuadIds ? w16 : cid16) + at);             // raw offset; rebased in gather() (single loads only see positions >= n8)
                 } else {
                     f.a = ldg<NT>(reinterpret_cast<const f16x4 *>(reg.val + at));
                     const i32x2 o = ldg<NT>(reinterpret_cast<const i32x2 *>(cid16 + at));      // raw u16 offsets, two per dword
@@ -300,7 +327,8 @@ struct BlockSrc {
             }
         }
     }
-    template <class XV> __device__ __forceinline__ void gather(Frag<T> &f, int i, const XV &x) const
+    // QUAD: the step may come from load4 (the pipelined path): inside the paired region its f.c is the batch's raw id dword
+    template <bool QUAD = false, class XV> __device__ __forceinline__ void gather(Frag<T> &f, int i, const XV &x) const
     {
         if (i >= nc) {
             const int j = i - nc;
@@ -318,7 +346,15 @@ struct BlockSrc {
             }
         } else if constexpr (C16) {
             const int b = base[c0 + i];                         // wave-uniform: one scalar load per chunk
-            if constexpr (sizeof(T) == 8) f.c = f.c == 0xFFFF ? -1 : b + f.c;
+            if constexpr (sizeof(T) == 8) {
+                unsigned o = (unsigned)f.c, pad = 0xFFFFu;
+                if constexpr (QUAD && kQuadIds) {                // this chunk's field of the raw dword: wave-uniform shift / mask
+                    const bool narrow = i < n8, paired = i < npair;
+                    pad = narrow ? 0xFFu : 0xFFFFu;
+                    o = (o >> (narrow ? 8u * (i & 3) : (paired ? 16u * (i & 1) : 0u))) & pad;
+                }
+                f.c = o == pad ? -1 : b + (int)o;
+            }
             else {
                 const unsigned lo = (unsigned)f.c[0], hi = (unsigned)f.c[1];
                 const unsigned o[4] = {lo & 0xFFFFu, lo >> 16, hi & 0xFFFFu, hi >> 16};
@@ -337,8 +373,11 @@ __device__ __forceinline__ void load_steps(const SRC &src, Frag<T> *f, int i0)
 {
     if constexpr (SRC::kPairs && N == Tr<T>::BATCH) {
         if (src.pairs_ok(i0, N)) {
+            if constexpr (SRC::kQuadIds) src.load4(f, i0);
+            else {
 #pragma unroll
-            for (int u = 0; u < N; u += 2) src.load2(f[u], f[u + 1], i0 + u);
+                for (int u = 0; u < N; u += 2) src.load2(f[u], f[u + 1], i0 + u);
+            }
             return;
         }
     }
@@ -397,12 +436,12 @@ struct FinishDispatch {
         if (rem == R) {
             Frag<T> r[R > 0 ? R : 1];
 #pragma unroll
-            for (int u = 0; u < U; ++u) src.gather(cur[u], ibase + u, x);
+            for (int u = 0; u < U; ++u) src.template gather<true>(cur[u], ibase + u, x);
             load_steps<R>(src, r, i);
 #pragma unroll
             for (int u = 0; u < U; ++u) frag_mfma(acc, cur[u]);
 #pragma unroll
-            for (int u = 0; u < R; ++u) src.gather(r[u], i + u, x);
+            for (int u = 0; u < R; ++u) src.template gather<true>(r[u], i + u, x);
 #pragma unroll
             for (int u = 0; u < R; ++u) frag_mfma(acc, r[u]);
         } else if constexpr (R > 0) FinishDispatch<T, U, R - 1, SRC, ACC, XV>::run(acc, src, cur, ibase, i, rem, x);
@@ -424,7 +463,7 @@ __device__ __forceinline__ void run_stream(ACC &acc, const SRC &src, int N, cons
     for (int it = 1; it < nfull; ++it, i += U) {
         Frag<T> nxt[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) src.gather(cur[u], i - U + u, x);
+        for (int u = 0; u < U; ++u) src.template gather<true>(cur[u], i - U + u, x);
         load_steps<U>(src, nxt, i);
 #pragma unroll
         for (int u = 0; u < U; ++u) frag_mfma(acc, cur[u]);
@@ -459,7 +498,7 @@ __device__ __forceinline__ bool diag_of(const f32x4 &acc, int lane, float &d)
 // ---- medium: one wave = one block of 16 sorted rows (reference: dasp_f64.h:145-279)
 // YM: where the 16 results go -- 0: the block's own slots (reference permutation), or order[slot] when the plan is
 // DASP_Y_NATURAL (a.order set); 2: med_dst[position] (windowed mode)
-template <class T, bool NT, bool C16, int YM, class XV>
+template <class T, bool NT, bool C16, int YM, bool C8 = false, class XV>
 __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, const XV &x)
 {
     using acc_t = typename Tr<T>::acc_t;
@@ -474,9 +513,14 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     if (r < a.row_block) { t0 = a.irr_ptr[r]; t1 = a.irr_ptr[r + 1]; }
     constexpr int TK = sizeof(T) == 8 ? 4 : 16;                      // tail entries of one row per MFMA step
     const int nt = (__builtin_amdgcn_readfirstlane(t1 - t0) + TK - 1) / TK;
-    BlockSrc<T, NT, C16, YM != 2> src;
+    BlockSrc<T, NT, C16, YM != 2, C8> src;
     src.reg.val = val; src.reg.cid = a.med_cid; src.reg.e0 = (size_t)c0 * CH; src.reg.lane = lane;
     src.nc = c1 - c0; src.npair = med_npair(c1 - c0, nt, (int)sizeof(T), YM == 2 ? 0 : a.pair_mode); src.cid16 = a.med_cid16; src.base = a.med_base; src.c0 = c0;
+    src.c8 = a.med_cid8; src.w16 = a.med_cid16; src.n8 = 0;
+    if constexpr (C8 && C16 && sizeof(T) == 8 && YM != 2) {
+        const int q0 = a.med_c8ptr[b], q1 = a.med_c8ptr[b + 1];
+        src.n8 = q1 - q0; src.c8 = a.med_cid8 + (size_t)q0 * CH; src.w16 = a.med_cid16 - (size_t)q1 * CH;      // e16 - (e0 + n8 CH) = -(q0 + n8) CH
+    }
     src.ival = static_cast<const T *>(a.irr_val); src.icid = a.irr_cid; src.t0 = t0; src.t1 = t1; src.kq = kq;
     run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, src.nc + nt, x);
 
@@ -638,7 +682,7 @@ constexpr int kMinWavesPlain = 1, kMinWavesWin = 8;
 // WIN: windowed mode.  A medium workgroup owns one window of row_window rows (blocks_per_win blocks, strided over its
 // 4 waves); if the window's x span fits, it is copied once into LDS with coalesced 16-byte loads and every gather of
 // the window reads LDS; otherwise that workgroup gathers from global memory like the non-windowed kernel.
-template <class T, bool NT, bool C16, bool WIN>
+template <class T, bool NT, bool C16, bool WIN, bool C8 = false>
 __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPlain) void dasp_spmv_kernel(DevArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -656,7 +700,7 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPla
             // grid-stride over the blocks: wg_med is capped (upload_plan) so the medium range is a persistent set of workgroups
 #pragma unroll 1
             for (int b = m * kWavesPerWG + wave; b < a.n_blocks; b += a.wg_med * kWavesPerWG)
-                medium_block<T, NT, C16, 0>(a, b, lane, x);
+                medium_block<T, NT, C16, 0, C8>(a, b, lane, x);
         } else {
             // one window per workgroup; its blocks_per_win blocks are dealt round-robin to the wpw waves
             const int w = wg - a.wg_long;
@@ -860,7 +904,9 @@ int upload_plan(Plan &p)
     const size_t o_mptr = add(p.med_ptr.data(), p.med_ptr.size() * 4);
     const size_t o_mv = add(src_of(p.med_val), p.cnt_reg * vbytes);
     const size_t o_mc = add(src_of(p.med_cid), p.cid16 ? 0 : p.cnt_reg * 4);
-    const size_t o_mc16 = add(src_of(p.med_cid16), p.cid16 ? p.cnt_reg * 2 : 0);
+    const size_t o_mc16 = add(src_of(p.med_cid16), p.cid16 ? (p.cnt_reg - p.cnt_reg8) * 2 : 0);
+    const size_t o_mc8 = add(src_of(p.med_cid8), p.cnt_reg8);
+    const size_t o_c8p = add(p.med_c8ptr.data(), p.med_c8ptr.size() * 4);
     const size_t o_mb = add(src_of(p.med_base), p.cid16 ? (size_t)p.med_ptr.back() * 4 : 0);
     const size_t o_ip = add(p.irr_ptr.data(), p.irr_ptr.size() * 4);
     const size_t o_iv = add(src_of(p.irr_val), p.cnt_irr * vbytes);
@@ -881,7 +927,7 @@ int upload_plan(Plan &p)
     for (const Item &it : items)
         if (it.src && it.bytes) HIP_TRY(hipMemcpy(base + it.off, it.src, it.bytes, hipMemcpyHostToDevice));
 
-    d->map.long_val = o_lv; d->map.long_cid = o_lc; d->map.med_val = o_mv; d->map.med_cid = o_mc; d->map.med_cid16 = o_mc16;
+    d->map.long_val = o_lv; d->map.long_cid = o_lc; d->map.med_val = o_mv; d->map.med_cid = o_mc; d->map.med_cid16 = o_mc16; d->map.med_cid8 = o_mc8;
     d->map.med_base = o_mb; d->map.irr_val = o_iv; d->map.irr_cid = o_ic; d->map.short_val = o_sv; d->map.short_cid = o_sc;
     DevArgs &a = d->args;
     a.long_val = base + o_lv; a.long_cid = (const int *)(base + o_lc);
@@ -899,6 +945,7 @@ int upload_plan(Plan &p)
     a.wpw = p.windowed ? std::min(16, p.row_window / kMedRows) : kWavesPerWG;
     a.wg_long = (a.n_pieces + a.wpw - 1) / a.wpw;
     a.med_cid16 = (const unsigned short *)(base + o_mc16); a.med_base = (const int *)(base + o_mb);
+    a.med_cid8 = (const unsigned char *)(base + o_mc8); a.med_c8ptr = (const int *)(base + o_c8p);
     a.med_dst = (const int *)(base + o_mdst); a.win_cmin = (const int *)(base + o_wc); a.win_len = (const int *)(base + o_wl);
     a.n_windows = (int)p.win_len.size(); a.blocks_per_win = p.windowed ? p.row_window / kMedRows : 0;
     a.win_hybrid = p.win_hybrid ? 1 : 0; a.pair_mode = p.pair_mode;
@@ -960,6 +1007,10 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
         else if (c16 && p.windowed) { M(false, true, true); } else if (c16) { M(false, true, false); } \
         else if (p.windowed) { M(false, false, true); } else { M(false, false, false); }
 #define DASP_LAUNCH(NTV, CV, WINV) hipLaunchKernelGGL((dasp_spmv_kernel<T, NTV, CV, WINV>), dim3(grid), dim3(kWave * a.wpw), lds, s, a)
+        if (sizeof(T) == 8 && c16 && !p.windowed && p.cnt_reg8 > 0) {      // plans with one-byte ids: their own instantiation
+            if (nt) hipLaunchKernelGGL((dasp_spmv_kernel<double, true, true, false, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, a);
+            else hipLaunchKernelGGL((dasp_spmv_kernel<double, false, true, false, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, a);
+        } else
         DASP_FOR_EACH(DASP_LAUNCH)
 #undef DASP_LAUNCH
 #undef DASP_FOR_EACH

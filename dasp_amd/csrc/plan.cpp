@@ -511,6 +511,10 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     // joins the irregular tail (32-bit ids).  opt.cid16: 0 = auto (on when that costs < 3 % of the regular elements).
     std::vector<int> nchunks16((size_t)nb + 1, 0);
     const bool try16 = p.opt.cid16 >= 0 && !meta_only;
+    // one-byte ids (plan.hpp med_cid8): bit c of narrow_mask[b] = chunk c (< 64) of block b spans <= 254 columns.  f64 only: the f16 kernels
+    // are not bound by bytes (profiles/r02_cid8.md)
+    const bool try8 = try16 && !f16 && p.opt.cid8 >= 0;
+    std::vector<unsigned long long> narrow_mask(try8 ? (size_t)nb : 0, 0ull);
     parallel_for(nb, threads, 256, [&](long long b0, long long b1) {
         for (long long b = b0; b < b1; ++b) {
             const int r0 = (int)b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
@@ -522,6 +526,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             }
             nchunks[b] = k;
             int k16 = k;
+            unsigned long long mask = 0;
             if (try16 && !dev) {
                 for (int c = 0; c < k; ++c) {
                     int lo = 2147483647, hi = -1;
@@ -530,12 +535,14 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                         for (int i = i0; i < i1; ++i) { const int col = remap(ci[a0 + i]); lo = std::min(lo, col); hi = std::max(hi, col); }
                     }
                     if (hi >= 0 && (long long)hi - lo > 65534) { k16 = c; break; }
+                    if (c < 64 && hi >= 0 && hi - lo <= 254) mask |= 1ull << c;
                 }
             }
             nchunks16[b] = k16;
+            if (try8 && !dev) narrow_mask[(size_t)b] = mask;
         }
     });
-    if (try16 && dev) { if (int rc = devpack_chunk_spans(p, *dev, ridM, lenM, nchunks, nchunks16.data())) return rc; }
+    if (try16 && dev) { if (int rc = devpack_chunk_spans(p, *dev, ridM, lenM, nchunks, nchunks16.data(), try8 ? narrow_mask.data() : nullptr)) return rc; }
     {
         long long e32 = 0, e16 = 0;
         for (int b = 0; b < nb; ++b) { e32 += nchunks[b]; e16 += nchunks16[b]; }
@@ -555,6 +562,14 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     // one-shot f64 blocks only when the plan is far beyond the 256 MiB Infinity Cache (nlpkkt160: 2.8 GB -7 % / -1.5 % by box; at 278 MB +4-8 %)
     p.pair_mode = p.windowed || p.opt.chunk_pairs < 0 ? 0 : p.opt.chunk_pairs > 0 ? std::min(2, p.opt.chunk_pairs)
                                                                      : ((long long)nnz * (geo.vbytes + 4) > 4 * kStreamBytes ? 2 : 1);
+    // narrow chunks per block: those of its pipelined paired region, in whole pipeline batches
+    std::vector<int> n8of((size_t)nb + 1, 0);
+    if (try8 && p.cid16 && p.pair_mode > 0)
+        for (int b = 0; b < nb; ++b) {
+            const int nt = (p.irr_ptr[(size_t)b * kMedRows] + K - 1) / K, npair = med_npair(nchunks[b], nt, geo.vbytes, p.pair_mode);
+            const unsigned long long in = npair >= 64 ? ~0ull : ((1ull << npair) - 1);
+            n8of[b] = med_n8(__builtin_popcountll(narrow_mask[(size_t)b] & in), nchunks[b], nt);
+        }
     lap("chunk split (+cid16 spans)");
     p.med_ptr.assign((size_t)nb + 1, 0);
     {
@@ -570,10 +585,18 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     const int nnz_irreg = p.irr_ptr[nmed];
     p.cnt_reg = (size_t)n_reg; p.cnt_irr = (size_t)nnz_irreg;
     p.med_base.assign(p.cid16 && pack ? (size_t)p.med_ptr[nb] : 0, 0);
+    p.med_c8ptr.clear(); p.med_korig.clear(); p.med_cid8.clear(); p.cnt_reg8 = 0;
+    if (p.cid16) {
+        p.med_c8ptr.assign((size_t)nb + 1, 0);
+        for (int b = 0; b < nb; ++b) p.med_c8ptr[(size_t)b + 1] = p.med_c8ptr[b] + n8of[b];
+        p.cnt_reg8 = (size_t)p.med_c8ptr[nb] * CH;
+        p.med_korig.assign((size_t)p.med_ptr[nb], 0);
+    }
     if (pack) {
     p.med_val.resize((size_t)n_reg * sizeof(T));               // not zero-filled: each block pads its own region first
     p.med_cid.resize(p.cid16 ? 0 : (size_t)n_reg);
-    p.med_cid16.resize(p.cid16 ? (size_t)n_reg : 0);
+    p.med_cid16.resize(p.cid16 ? (size_t)n_reg - p.cnt_reg8 : 0);
+    p.med_cid8.resize(p.cnt_reg8);
     p.irr_val.resize((size_t)nnz_irreg * sizeof(T));           // fully covered by the rows' tails
     p.irr_cid.resize((size_t)nnz_irreg);
     }
@@ -581,41 +604,59 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         T *mv = reinterpret_cast<T *>(p.med_val.data());
         T *iv = reinterpret_cast<T *>(p.irr_val.data());
         parallel_for(nb, threads, 64, [&](long long b0, long long b1) {
+            std::vector<int> pos_of, lo_of;
             for (long long b = b0; b < b1; ++b) {
                 const int nc = p.med_ptr[b + 1] - p.med_ptr[b];
                 const size_t base = (size_t)p.med_ptr[b] * CH;
                 const int r0 = (int)b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
                 // tail steps of the block = those of its first (longest) row; with them the kernel decides one shot / pipeline, hence the layout
                 const int npair = med_npair(nc, (p.irr_ptr[r0 + 1] - p.irr_ptr[r0] + K - 1) / K, geo.vbytes, p.pair_mode);
-                {   // pad the block's region (value 0, id -1 / 0xFFFF); real entries overwrite below
-                    const size_t n = (size_t)nc * CH;
-                    std::fill(mv + base, mv + base + n, (T)0);
-                    if (p.cid16) std::fill(p.med_cid16.begin() + base, p.med_cid16.begin() + base + n, (uint16_t)0xFFFF);
-                    else std::fill(p.med_cid.begin() + base, p.med_cid.begin() + base + n, -1);
-                }
-                if (p.cid16)   // per-chunk base = smallest column of the chunk
+                // cid16 mode: position q of the block holds the block's chunk korig[q]: n8 narrow chunks (columns span <= 254: one-byte ids) of
+                // the paired region first, everything else behind them in its original order
+                const int n8 = p.cid16 ? p.med_c8ptr[b + 1] - p.med_c8ptr[b] : 0;
+                const size_t e8 = p.cid16 ? (size_t)p.med_c8ptr[b] * CH : 0;                               // the block's narrow ids in med_cid8
+                const size_t e16 = p.cid16 ? ((size_t)p.med_ptr[b] - (size_t)p.med_c8ptr[b]) * CH : 0;      // its wide ids in med_cid16
+                pos_of.assign((size_t)nc + 1, 0); lo_of.assign((size_t)nc + 1, 0);
+                if (p.cid16) {
+                    int a8 = 0, a16 = 0;
                     for (int c = 0; c < nc; ++c) {
-                        int lo = 2147483647;
+                        int lo = 2147483647, hi = -1;
                         for (int r = r0; r < r1; ++r) {
                             const int a0 = rp[ridM[r]], i0 = c * K, i1 = std::min(lenM[r], i0 + K);
-                            for (int i = i0; i < i1; ++i) lo = std::min(lo, remap(ci[a0 + i]));
+                            for (int i = i0; i < i1; ++i) { const int col = remap(ci[a0 + i]); lo = std::min(lo, col); hi = std::max(hi, col); }
                         }
-                        p.med_base[(size_t)p.med_ptr[b] + c] = lo == 2147483647 ? 0 : lo;
+                        const bool narrow = c < npair && c < 64 && a8 < n8 && hi >= 0 && hi - lo <= 254;
+                        lo_of[c] = lo == 2147483647 ? 0 : lo;
+                        pos_of[c] = c >= npair ? c : narrow ? a8++ : n8 + a16++;
                     }
+                    for (int c = 0; c < nc; ++c) {
+                        p.med_base[(size_t)p.med_ptr[b] + pos_of[c]] = lo_of[c];
+                        p.med_korig[(size_t)p.med_ptr[b] + pos_of[c]] = c;
+                    }
+                } else for (int c = 0; c < nc; ++c) pos_of[c] = c;
+                {   // pad the block's region (value 0, id -1 / 0xFFFF / 0xFF); real entries overwrite below
+                    const size_t n = (size_t)nc * CH;
+                    std::fill(mv + base, mv + base + n, (T)0);
+                    if (p.cid16) {
+                        std::fill(p.med_cid8.begin() + e8, p.med_cid8.begin() + e8 + (size_t)n8 * CH, (uint8_t)0xFF);
+                        std::fill(p.med_cid16.begin() + e16, p.med_cid16.begin() + e16 + (size_t)(nc - n8) * CH, (uint16_t)0xFFFF);
+                    } else std::fill(p.med_cid.begin() + base, p.med_cid.begin() + base + n, -1);
+                }
                 for (int r = r0; r < r1; ++r) {
                     const int rr = r - r0, row = ridM[r], len = lenM[r], a0 = rp[row];
                     const int nreg = std::min(len, nc * K);
                     for (int i = 0; i < nreg; ++i) {
-                        const int c = i / K, kk = i % K;
+                        const int c = i / K, kk = i % K, q = pos_of[c];
                         // f64: lane = kk*16 + rr holds A[rr][kk]            (one value per lane)
                         // f16: lane = (kk/4)*16 + rr holds A[rr][4*(kk/4)..+3] (four values per lane)
                         // a pipelined block's leading chunks are stored in pairs, [pair][lane][2 chunks][VPL] (plan.hpp med_npair)
                         const int lane = f16 ? (kk / 4) * kMedRows + rr : kk * kMedRows + rr, j = f16 ? kk % 4 : 0;
-                        const size_t at = base + med_elem_index(npair, c, lane, j, VPL, CH);
+                        const size_t at = base + med_elem_index(npair, q, lane, j, VPL, CH);
                         mv[at] = val[a0 + i];
                         const int col = remap(ci[a0 + i]);
-                        if (p.cid16) p.med_cid16[at] = (uint16_t)(col - p.med_base[(size_t)p.med_ptr[b] + c]);
-                        else p.med_cid[at] = col;
+                        if (!p.cid16) p.med_cid[at] = col;
+                        else if (q < n8) p.med_cid8[e8 + med_cid8_index(q, lane, CH)] = (uint8_t)(col - lo_of[c]);
+                        else p.med_cid16[e16 + med_elem_index(npair - n8, q - n8, lane, j, VPL, CH)] = (uint16_t)(col - lo_of[c]);
                     }
                     const int t0 = p.irr_ptr[r], tl = p.irr_ptr[r + 1] - t0;
                     for (int j = 0; j < tl; ++j) {   // the LAST tl entries of the row (dasp_f64.h:1094-1106)
@@ -677,7 +718,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     std::memset(&s, 0, sizeof s);
     s.precision = p.precision; s.rowA = m; s.colA = p.n; s.nnzA = nnz;
     s.short_row_1 = n1; s.common_13 = c13; s.short_row_3 = n3; s.short_row_4 = n4; s.short_row_2 = n2;
-    s.row_long = nlong_cls; s.row_block = nmed_all; s.row_zero = nz0; s.med_rows_as_pieces = nsp; s.chunk_pairs = p.pair_mode;
+    s.row_long = nlong_cls; s.row_block = nmed_all; s.row_zero = nz0; s.med_rows_as_pieces = nsp; s.chunk_pairs = p.pair_mode; s.cid8_chunks = p.med_c8ptr.empty() ? 0 : p.med_c8ptr.back();
     s.nnz_short = nnz_short; s.nnz_long = (int)nnz_long; s.nnz_irreg = nnz_irreg;
     s.origin_nnz_reg = nnz - nnz_irreg - (int)nnz_long - nnz_short;
     s.rowloop = nmed < 59990 ? 1 : (nmed < 400000 ? 2 : 4);
@@ -688,7 +729,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     s.rate_fill0 = nnz > 0 ? (double)(stored - nnz) / nnz : 0.0;
     const long long sv = geo.vbytes;
     s.cid16_on = p.cid16 ? 1 : 0;
-    s.data_X = (long long)(m + p.n) * sv + stored * (sv + 4) - (p.cid16 ? 2 * n_reg - 4ll * p.med_ptr[nb] : 0) +
+    s.data_X = (long long)(m + p.n) * sv + stored * (sv + 4) - (p.cid16 ? 2 * n_reg - 4ll * p.med_ptr[nb] : 0) - (long long)p.cnt_reg8 +
                (long long)(p.piece_ptr.size() + p.piece_dst.size() + p.multi_ptr.size() + p.multi_dst.size()) * 4 +
                (long long)(p.med_ptr.size() + p.irr_ptr.size()) * 4 + (natural ? (long long)m * 4 : 0) +
                (long long)(p.med_dst.size() + 2 * p.win_len.size()) * 4;
@@ -874,7 +915,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     const int K = (int)p.panels.size();
     s.fill0_nnz_short = s.fill0_nnz_long = s.fill0_nnz_reg = 0;
     s.n_med_blocks = s.n_long_pieces = s.n_long_multi = s.n_short_tiles = s.n_workgroups = 0;
-    s.x_window_on = s.n_windows = s.n_windows_lds = s.lds_bytes = s.row_window = s.cid16_on = s.x_window_hybrid = s.chunk_pairs = 0;
+    s.x_window_on = s.n_windows = s.n_windows_lds = s.lds_bytes = s.row_window = s.cid16_on = s.x_window_hybrid = s.chunk_pairs = s.cid8_chunks = 0;
     s.window_nnz_frac = 0.0;
     long long stored = 0, dataX = 0;
     for (const auto &h : p.panels) {
@@ -886,7 +927,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
         s.n_short_tiles += t.n_short_tiles; s.n_workgroups += t.n_workgroups;
         s.x_window_on |= t.x_window_on; s.n_windows += t.n_windows; s.n_windows_lds += t.n_windows_lds;
         s.lds_bytes = std::max(s.lds_bytes, t.lds_bytes); s.row_window = std::max(s.row_window, t.row_window);
-        s.cid16_on |= t.cid16_on; s.x_window_hybrid |= t.x_window_hybrid; s.chunk_pairs = std::max(s.chunk_pairs, t.chunk_pairs);
+        s.cid16_on |= t.cid16_on; s.x_window_hybrid |= t.x_window_hybrid; s.chunk_pairs = std::max(s.chunk_pairs, t.chunk_pairs); s.cid8_chunks += t.cid8_chunks;
         s.window_nnz_frac += t.window_nnz_frac * (double)t.nnzA / (double)std::max(1, p.nnz);
     }
     s.rate_fill0 = p.nnz > 0 ? (double)(stored - p.nnz) / p.nnz : 0.0;

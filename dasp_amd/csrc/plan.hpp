@@ -58,6 +58,16 @@ inline int med_npair(int nc, int nt, int vbytes, int mode)
     // one-shot blocks: f16 pairs them (nlpkkt160 f16 0.2355 -> 0.2177 ms); f64 only as a whole (no tail steps: one test per block) and only in mode 2
     return nc + nt > shot ? nc / batch * batch : (vbytes == 2 || (mode == 2 && nt == 0) ? nc & ~1 : 0);
 }
+// where the one-byte id of lane `lane` of the narrow chunk at position q (< n8) sits inside its block's region of med_cid8
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline size_t med_cid8_index(int q, int lane, int ch) { return (size_t)(q & ~3) * ch + 4 * (size_t)lane + (q & 3); }
+// how many narrow chunks a block keeps: those of its PIPELINED paired region (one-shot blocks keep 16-bit ids), in whole batches (f64)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int med_n8(int narrow_in_paired_region, int nc, int nt) { return nc + nt > kMedShot64 ? narrow_in_paired_region / kMedBatch64 * kMedBatch64 : 0; }
 // where element j (< vpl) of lane `lane` of regular chunk c sits inside its block's region of med_val / med_cid / med_cid16 (in elements)
 #if defined(__HIPCC__)
 __host__ __device__
@@ -135,6 +145,15 @@ struct Plan {
     bool cid16 = false;
     raw_vector<uint16_t> med_cid16;  // u16 offsets from med_base[chunk], 0xFFFF = pad (cid16 on)
     std::vector<int> med_base;        // [chunks]
+    // one-byte ids (f64, cid16 on, pipelined paired chunks; r2): a chunk of the paired region whose columns span <= 254 stores its offsets in
+    // ONE byte (0xFF = pad), plane med_cid8, a pipeline batch of four chunks interleaved per lane: [batch][lane][4 chunks], one dword per
+    // lane.  A block's chunks are independent MFMA steps, so the packer moves n8 of them -- whole batches -- to the front of the paired
+    // region: position q of the block holds the block's chunk med_korig[q] (values, base and ids move together), positions [0, n8) are
+    // narrow.  med_c8ptr[b] = narrow chunks before block b; the block's wide ids start at (med_ptr[b] - med_c8ptr[b]) * CH in med_cid16.
+    raw_vector<uint8_t> med_cid8;
+    std::vector<int> med_c8ptr;       // [nb+1] (cid16 plans)
+    std::vector<int> med_korig;       // [chunks] (cid16 plans)
+    size_t cnt_reg8 = 0;              // elements of the narrow chunks (cnt_reg counts all regular elements)
     int n_mfma_rows = 0;            // medium rows handled as MFMA blocks (the shortest are slabs, see grp[5..]; the longest may be pieces)
     int med_slot0 = 0;              // slot of the first MFMA medium row: row_long + the medium rows stored as pieces (opt.piece_min_len)
     std::vector<int> irr_ptr;       // [n_mfma_rows+1]
@@ -186,7 +205,7 @@ int devpack_line_scatter(const Plan &p, const DevCsr &d, const std::vector<int> 
 // entry at the same position
 int devpack_row_coherence(const Plan &p, const DevCsr &d, const std::vector<int> &rows, long long *near, long long *entries);
 int devpack_chunk_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridM, const std::vector<int> &lenM,
-                        const std::vector<int> &nchunks, int *k16);
+                        const std::vector<int> &nchunks, int *k16, unsigned long long *narrow_mask);      // narrow_mask: nullptr or [blocks] (plan.cpp)
 int devpack_all(Plan &p, const DevCsr &d, const PackMeta &m);
 
 // builds every host array of `p` from CSR.  T = double or _Float16.  With `dev` set, rp is a host copy of the row pointer,

@@ -46,7 +46,7 @@ template <class IO> void arrays(IO &io, Plan &p)
 {
     io.vec(p.part_bounds); io.vec(p.order); io.vec(p.dst_map); io.vec(p.panel_bounds);
     io.vec(p.long_val); io.vec(p.long_cid); io.vec(p.piece_ptr); io.vec(p.piece_dst); io.vec(p.multi_ptr); io.vec(p.multi_dst);
-    io.vec(p.med_ptr); io.vec(p.med_val); io.vec(p.med_cid); io.vec(p.med_cid16); io.vec(p.med_base);
+    io.vec(p.med_ptr); io.vec(p.med_val); io.vec(p.med_cid); io.vec(p.med_cid16); io.vec(p.med_cid8); io.vec(p.med_c8ptr); io.vec(p.med_korig); io.vec(p.med_base);
     io.vec(p.irr_ptr); io.vec(p.irr_val); io.vec(p.irr_cid);
     io.vec(p.med_dst); io.vec(p.win_cmin); io.vec(p.win_len);
     io.vec(p.short_val); io.vec(p.short_cid);
@@ -101,20 +101,42 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
     const long long nb = (p.n_mfma_rows + kMedRows - 1) / kMedRows;
     if (p.med_ptr.size() != (size_t)nb + 1 || !mono(p.med_ptr) || p.stats.n_med_blocks != nb) return fail("med_ptr size / n_med_blocks");
     if ((size_t)p.med_ptr.back() * (size_t)CH != p.cnt_reg || p.med_val.size() != p.cnt_reg * (size_t)vb) return fail("regular tiles");
-    if (p.cid16 ? (p.med_cid16.size() != p.cnt_reg || !p.med_cid.empty() || p.med_base.size() != (size_t)p.med_ptr.back())
-                : (p.med_cid.size() != p.cnt_reg || !p.med_cid16.empty() || !p.med_base.empty())) return fail("medium column ids");
+    if (p.cid16 ? (p.med_cid16.size() + p.med_cid8.size() != p.cnt_reg || p.med_cid8.size() != p.cnt_reg8 || !p.med_cid.empty() ||
+                   p.med_base.size() != (size_t)p.med_ptr.back() || p.med_korig.size() != p.med_base.size() || p.med_c8ptr.size() != (size_t)nb + 1)
+                : (p.med_cid.size() != p.cnt_reg || !p.med_cid16.empty() || !p.med_cid8.empty() || !p.med_base.empty() || !p.med_c8ptr.empty() || !p.med_korig.empty()))
+        return fail("medium column ids");
+    // layout of block b (plan.hpp): npair chunks stored in pairs; in cid16 mode its first n8 positions carry one-byte ids and position q holds chunk korig[q]
+    auto npair_of = [&](long long b) {
+        const long long r0 = b * kMedRows, K = CH / kMedRows;
+        return med_npair((int)(p.med_ptr[(size_t)b + 1] - p.med_ptr[(size_t)b]), (int)((p.irr_ptr[(size_t)r0 + 1] - p.irr_ptr[(size_t)r0] + K - 1) / K), (int)vb, p.pair_mode);
+    };
     if (p.irr_ptr.size() != (size_t)p.n_mfma_rows + 1 || !mono(p.irr_ptr) || (size_t)p.irr_ptr.back() != p.cnt_irr) return fail("irr_ptr");
     if (p.irr_val.size() != p.cnt_irr * (size_t)vb || p.irr_cid.size() != p.cnt_irr) return fail("irregular arrays");
     if (!cid_ok(p.irr_cid) || !cid_ok(p.med_cid)) return fail("medium column id out of range");
-    // column id of element e (= lane * vpl + j) of chunk c of block b, -1 = pad: the block's chunks are stored in pairs (plan.hpp med_elem_index)
+    if (p.cid16) {
+        if (!mono(p.med_c8ptr) || (size_t)p.med_c8ptr.back() * (size_t)CH != p.cnt_reg8) return fail("med_c8ptr");
+        for (long long b = 0; b < nb; ++b) {
+            const int nc = p.med_ptr[(size_t)b + 1] - p.med_ptr[(size_t)b], n8 = p.med_c8ptr[(size_t)b + 1] - p.med_c8ptr[(size_t)b], npair = npair_of(b);
+            if (n8 < 0 || n8 > npair || n8 % kMedBatch64 || (n8 && (vb != 8 || nc + (p.irr_ptr[(size_t)b * kMedRows + 1] - p.irr_ptr[(size_t)b * kMedRows] + 3) / 4 <= kMedShot64)))
+                return fail("med_c8ptr: one-byte ids come in whole batches of a pipelined f64 block's paired region");
+            std::vector<char> seen((size_t)nc, 0);
+            for (int q = 0; q < nc; ++q) {
+                const unsigned k = (unsigned)p.med_korig[(size_t)p.med_ptr[(size_t)b] + (size_t)q];
+                if (k >= (unsigned)nc || seen[k] || (q >= npair && (int)k != q)) return fail("med_korig is not a permutation of its block's paired region");
+                seen[k] = 1;
+            }
+        }
+    }
+    // column id of element e (= lane * vpl + j) of the chunk at position c (absolute) of block b, -1 = pad
     const int vpl = (int)(CH / 64);
     auto cid_at = [&](long long b, long long c, long long e) -> long long {
         const long long c0 = p.med_ptr[(size_t)b];
-        const long long r0 = b * kMedRows, K = CH / kMedRows;      // tail steps of the block's first row decide its layout (plan.hpp med_npair)
-        const int npair = med_npair((int)(p.med_ptr[(size_t)b + 1] - c0), (int)((p.irr_ptr[(size_t)r0 + 1] - p.irr_ptr[(size_t)r0] + K - 1) / K), (int)vb, p.pair_mode);
-        const size_t at = (size_t)c0 * (size_t)CH + med_elem_index(npair, (int)(c - c0), (int)(e / vpl), (int)(e % vpl), vpl, (int)CH);
-        if (!p.cid16) return p.med_cid[at];
-        const unsigned o = p.med_cid16[at];
+        const int npair = npair_of(b), q = (int)(c - c0), lane = (int)(e / vpl), j = (int)(e % vpl);
+        if (!p.cid16) return p.med_cid[(size_t)c0 * (size_t)CH + med_elem_index(npair, q, lane, j, vpl, (int)CH)];
+        const long long c8 = p.med_c8ptr[(size_t)b];
+        const int n8 = (int)(p.med_c8ptr[(size_t)b + 1] - c8);
+        if (q < n8) { const unsigned o = p.med_cid8[(size_t)c8 * (size_t)CH + med_cid8_index(q, lane, (int)CH)]; return o == 0xFFu ? -1 : (long long)p.med_base[(size_t)c] + o; }
+        const unsigned o = p.med_cid16[(size_t)(c0 - c8) * (size_t)CH + med_elem_index(npair - n8, q - n8, lane, j, vpl, (int)CH)];
         return o == 0xFFFFu ? -1 : (long long)p.med_base[(size_t)c] + o;
     };
     if (p.cid16)
@@ -197,13 +219,14 @@ static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
                 (p.dst_map.empty() || p.dst_map.size() == (size_t)p.m) && p.panel_bounds.size() == 2 * (size_t)np &&
                 p.long_val.size() == p.long_cid.size() * vb && p.irr_val.size() == p.irr_cid.size() * vb &&
                 p.short_val.size() == p.short_cid.size() * vb &&
-                (p.cid16 ? p.med_val.size() == p.med_cid16.size() * vb : p.med_val.size() == p.med_cid.size() * vb);
+                (p.cid16 ? p.med_val.size() == (p.med_cid16.size() + p.med_cid8.size()) * vb : p.med_val.size() == p.med_cid.size() * vb);
     if (np == 0)   // a packed plan (a panel parent keeps none of the row-structure arrays)
         sane = sane && p.piece_ptr.size() == p.piece_dst.size() + 1 && p.irr_ptr.size() == (size_t)p.n_mfma_rows + 1 &&
                p.n_mfma_rows >= 0 && p.n_mfma_rows <= p.stats.row_block && (!p.windowed || p.med_dst.size() == (size_t)p.n_mfma_rows);
     if (!sane) return false;
     p.cnt_long = p.long_cid.size(); p.cnt_irr = p.irr_cid.size(); p.cnt_short = p.short_cid.size();
-    p.cnt_reg = p.cid16 ? p.med_cid16.size() : p.med_cid.size();
+    p.cnt_reg = p.cid16 ? p.med_cid16.size() + p.med_cid8.size() : p.med_cid.size();
+    p.cnt_reg8 = p.med_cid8.size();
     p.host_dropped = false;
     p.panel = depth > 0;
     if (!validate_plan(p, np, r_why)) return false;

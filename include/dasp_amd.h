@@ -151,6 +151,10 @@ typedef struct dasp_options {
      * -1 = off; 1 = the blocks long enough for the kernel's software pipeline and the one-shot f16 blocks; 2 = also the one-shot f64 blocks
      * that have no tail steps.  order_rid, the classifier counters and the arithmetic of a row do not depend on it. */
     int chunk_pairs;
+    /* one-byte column ids (f64, inside cid16 mode, pipelined paired chunks only): a chunk whose columns span <= 254 stores its offsets from
+     * the chunk's base column in one byte; such chunks are moved to the front of their block's paired region in whole pipeline batches
+     * (the order of a block's MFMA steps is free), a batch's ids being one dword per lane.  0 = auto (on wherever it applies); -1 = off. */
+    int cid8;
 } dasp_options_t;
 
 void dasp_options_default(dasp_options_t *opt);
@@ -179,6 +183,7 @@ typedef struct dasp_stats {
     int x_window_hybrid;       /* windows stage their densest span; window_nnz_frac = share of the medium gathers served from LDS */
     int med_rows_as_pieces;    /* medium rows (the longest ones: the first medium slots) stored as pieces (piece_min_len) */
     int chunk_pairs;           /* 0 / 1 / 2: which medium blocks store chunk pairs (options chunk_pairs; column panels: the largest) */
+    int cid8_chunks;           /* regular medium chunks with one-byte column ids (option cid8) */
 } dasp_stats_t;
 
 /* classifier + packers on the host (no GPU needed).  CSR arrays are read-only and may be

@@ -446,8 +446,8 @@ def test_bench_bare_multi_gpu_launch_needs_that_many_devices(torch_cuda):
     assert r.returncode == 4 and "need 2 devices" in r.stderr
 
 
-NNZ_ARRAYS = ("long_val long_cid med_val med_cid med_cid16 med_base irr_val irr_cid short_val short_cid").split()
-META_ARRAYS = ("piece_ptr piece_dst multi_ptr multi_dst med_ptr irr_ptr med_dst win_cmin win_len short_groups").split()
+NNZ_ARRAYS = ("long_val long_cid med_val med_cid med_cid16 med_cid8 med_base irr_val irr_cid short_val short_cid").split()
+META_ARRAYS = ("piece_ptr piece_dst multi_ptr multi_dst med_ptr med_c8ptr med_korig irr_ptr med_dst win_cmin win_len short_groups").split()
 
 
 @pytest.mark.parametrize("prec", [64, 16])
@@ -514,6 +514,35 @@ def test_device_built_plans_take_the_same_automatic_decisions(dasp, torch_cuda, 
     for name in NNZ_ARRAYS:
         h = host.host_array(name)
         assert np.array_equal(h, dev.device_array(name, h.size, h.dtype)), name
+
+
+def test_device_packed_one_byte_ids(oracle, dasp, torch_cuda):
+    """FEM-like rows, 16-bit ids forced: most chunks of the pipelined blocks are narrow (one-byte ids, moved to the front of their block).
+    The device packer produces the host packer's arrays bit for bit, and the product matches the oracle"""
+    torch = torch_cuda
+    rp, ci = dasp.synth_csr("HV15R", 0.004)
+    m, n = rp.size - 1, dasp.synth_dims("HV15R", 0.004)[1]
+    v = np.random.default_rng(2).uniform(0.5, 1.5, ci.size)
+    host = dasp.Plan(rp, ci, v, n, cid16=1)
+    st = host.stats
+    assert st["cid16_on"] == 1 and 0 < st["cid8_chunks"] < host.host_array("med_ptr")[-1]
+    d = [torch.from_numpy(a).cuda() for a in (rp, ci, v)]
+    dev = dasp.Plan.from_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), m, n, ci.size, cid16=1)
+    hs, ds = host.stats, dev.stats
+    hs.pop("pre_ms"), ds.pop("pre_ms")
+    assert hs == ds
+    for name in META_ARRAYS:
+        assert np.array_equal(host.host_array(name), dev.host_array(name)), name
+    for name in NNZ_ARRAYS:
+        h = host.host_array(name)
+        assert np.array_equal(h, dev.device_array(name, h.size, h.dtype)), name
+    x = np.random.default_rng(3).uniform(-1, 1, n)
+    y = run_spmv(torch, dev, x, m, 64)
+    order = dev.order_rid
+    ref = np.array([np.dot(v[rp[r]:rp[r + 1]], x[ci[rp[r]:rp[r + 1]]]) for r in order[:2000]])
+    mag = np.array([np.abs(v[rp[r]:rp[r + 1]] * x[ci[rp[r]:rp[r + 1]]]).sum() for r in order[:2000]])
+    assert (np.abs(y[:2000] - ref) <= 1e-12 * np.maximum(mag, 1e-300)).all()
+    assert np.array_equal(y, run_spmv(torch, host.upload(), x, m, 64))
 
 
 def test_device_plan_rejects_bad_columns(dasp, torch_cuda):
@@ -714,7 +743,7 @@ def test_random_option_combinations(oracle, dasp, torch_cuda, seed):
     else:
         rp, ci, v = util.csr_from_lengths(lens, n, int(rng.integers(1 << 30)), dtype=dt)
     kw = dict(col_panels=int(rng.choice([1, 1, 2, 3, 6])), cid16=int(rng.choice([-1, 0, 1])),
-              x_window=int(rng.choice([-1, 0, 0, 40000, 163840])), row_window=int(rng.choice([0, 64, 256, 1024])), x_window_hybrid=int(rng.choice([0, 0, 1, -1])), piece_min_len=int(rng.choice([0, 0, -1, 6, 40])), chunk_pairs=int(rng.choice([0, 0, -1, 1, 2])),
+              x_window=int(rng.choice([-1, 0, 0, 40000, 163840])), row_window=int(rng.choice([0, 64, 256, 1024])), x_window_hybrid=int(rng.choice([0, 0, 1, -1])), piece_min_len=int(rng.choice([0, 0, -1, 6, 40])), chunk_pairs=int(rng.choice([0, 0, -1, 1, 2])), cid8=int(rng.choice([0, 0, -1])),
               long_piece=int(rng.choice([0, 64, 300, 4096])), block_longest=int(rng.choice([256, 256, 32, 1000])),
               threshold=float(rng.choice([0.75, 0.75, 0.3, 1.0])), y_order=int(rng.choice([0, 1])),
               slab_max_len=int(rng.choice([0, 4, 7, 16, 32])))

@@ -235,6 +235,48 @@ def test_chunk_pairs_layout(dasp, prec):
     assert w["x_window_on"] == 1 and w["chunk_pairs"] == 0
 
 
+def test_cid8_narrow_chunks_layout(dasp, tmp_path):
+    """one-byte ids (f64, 16-bit-id plans, pipelined blocks): chunks whose columns span <= 254 go to the front of the block's paired region in
+    whole batches of four, ids [batch][lane][4]; values, base and ids move together (med_korig); the decoder, the plan file and cid8 = -1"""
+    K, CH = 4, 64
+    # 16 identical rows of 12 chunks: chunks 0..3 wide (columns 1000 apart), 4..9 narrow (adjacent columns), 10 spans exactly 254, 11 spans 255
+    cols = []
+    for c in range(12):
+        lo = 100000 * c
+        cols += [lo, lo + 1000, lo + 2000, lo + 3000] if c < 4 else [lo, lo + 1, lo + 2, lo + (254 if c == 10 else 255 if c == 11 else 3)]
+    ci = np.tile(np.array(cols, np.int32), 16)
+    rp = np.arange(0, 48 * 17, 48, dtype=np.int32)
+    v = np.arange(1, ci.size + 1, dtype=np.float64)
+    plan = dasp.Plan(rp, ci, v, 1300000, x_window=-1, cid16=1, slab_max_len=4, piece_min_len=-1)
+    st = plan.stats
+    assert st["cid16_on"] == 1 and st["chunk_pairs"] == 1 and plan.host_array("med_ptr").tolist() == [0, 12]
+    # 7 narrow chunks (4..10) -> one batch of four in front; the paired region is all 12 chunks
+    assert st["cid8_chunks"] == 4 and plan.host_array("med_c8ptr").tolist() == [0, 4]
+    assert plan.host_array("med_korig").tolist() == [4, 5, 6, 7, 0, 1, 2, 3, 8, 9, 10, 11]
+    assert plan.host_array("med_base").tolist() == [100000 * k for k in (4, 5, 6, 7, 0, 1, 2, 3, 8, 9, 10, 11)]
+    c8 = plan.host_array("med_cid8").reshape(64, 4)              # [lane][chunk of the batch]; lane = k * 16 + row
+    assert plan.host_array("med_cid8").size == 4 * CH and plan.host_array("med_cid16").size == 8 * CH
+    for q in range(4):
+        assert c8[:, q].reshape(4, 16)[:, 3].tolist() == [0, 1, 2, 3]
+    rows = util.decode_plan(plan)
+    order = plan.order_rid
+    for slot in range(16):
+        r = order[slot]
+        assert rows[slot][0] == cols and rows[slot][1] == v[rp[r]:rp[r + 1]].tolist()
+    f = str(tmp_path / "p.plan")
+    plan.save(f)
+    back = dasp.Plan.load(f)
+    assert util.decode_plan(back) == rows and back.stats["cid8_chunks"] == 4
+    off = dasp.Plan(rp, ci, v, 1300000, x_window=-1, cid16=1, slab_max_len=4, piece_min_len=-1, cid8=-1)
+    assert off.stats["cid8_chunks"] == 0 and off.host_array("med_cid8").size == 0 and off.host_array("med_korig").tolist() == list(range(12))
+    assert util.decode_plan(off) == rows
+    # one-shot blocks (<= 8 steps) and f16 plans keep 16-bit ids
+    short = dasp.Plan(np.arange(0, 32 * 17, 32, dtype=np.int32), np.tile(np.array(cols[16:48], np.int32), 16), np.ones(32 * 16), 1300000, x_window=-1, cid16=1, slab_max_len=4, piece_min_len=-1)
+    assert short.stats["cid8_chunks"] == 0
+    half = dasp.Plan(rp, ci, np.ones(ci.size, np.float16), 1300000, precision=16, x_window=-1, cid16=1, slab_max_len=4, piece_min_len=-1)
+    assert half.stats["cid8_chunks"] == 0
+
+
 @pytest.mark.parametrize("prec", [64, 16])
 def test_serialised_plan_round_trip(dasp, tmp_path, prec):
     dt = np.float64 if prec == 64 else np.float16
@@ -246,7 +288,7 @@ def test_serialised_plan_round_trip(dasp, tmp_path, prec):
         back = dasp.Plan.load(path)
         assert back.stats == plan.stats and (back.order_rid == plan.order_rid).all()
         assert (back.y_order, back.x_len, back.precision) == (plan.y_order, plan.x_len, prec)
-        for name in ("long_val long_cid piece_ptr piece_dst multi_ptr multi_dst med_ptr med_val med_cid med_cid16 med_base "
+        for name in ("long_val long_cid piece_ptr piece_dst multi_ptr multi_dst med_ptr med_val med_cid med_cid16 med_cid8 med_c8ptr med_korig med_base "
                      "irr_ptr irr_val irr_cid med_dst win_cmin win_len short_val short_cid short_groups").split():
             a, b = plan.host_array(name), back.host_array(name)
             assert a.dtype == b.dtype and np.array_equal(a, b), name

@@ -39,7 +39,7 @@ OPTS = st.fixed_dictionaries(dict(
     threshold=st.sampled_from([0.75, 0.75, 0.3, 1.0]), block_longest=st.sampled_from([256, 256, 64, 16, 700]),
     long_piece=st.sampled_from([0, 64, 256, 4096]), x_window=st.sampled_from([0, -1, 2048, 100000]), x_window_hybrid=st.sampled_from([0, 1, -1]),
     row_window=st.sampled_from([0, 64, 256, 1024]), cid16=st.sampled_from([0, -1, 1]), y_order=st.sampled_from([0, 1]),
-    slab_max_len=st.sampled_from([0, 0, 4, 9, 32]), piece_min_len=st.sampled_from([0, 0, -1, 7, 60]), chunk_pairs=st.sampled_from([0, 0, -1, 1, 2])))
+    slab_max_len=st.sampled_from([0, 0, 4, 9, 32]), piece_min_len=st.sampled_from([0, 0, -1, 7, 60]), chunk_pairs=st.sampled_from([0, 0, -1, 1, 2]), cid8=st.sampled_from([0, 0, -1])))
 
 
 @settings(max_examples=150, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])

@@ -83,28 +83,53 @@ def decode_plan(plan):
     ip_all = plan.host_array("irr_ptr")
     batch, shot = (4, 8) if prec == 64 else (2, 2)       # the kernel's pipeline batch / one-shot limit (plan.hpp med_npair)
 
-    def lane_linear(a):
+    def npair_of(b):
         """a block long enough for the kernel's pipeline (chunks + tail steps of its first row > shot) stores its leading
-        nc // batch * batch chunks in pairs, [pair][lane][2 chunks][VPL] (plan.hpp med_elem_index): back to chunk-major"""
-        a = a.copy()
-        for b in range(mptr.size - 1):
-            nc = int(mptr[b + 1] - mptr[b])
-            nt = -(-int(ip_all[b * 16 + 1] - ip_all[b * 16]) // K)
-            mode = st["chunk_pairs"]          # 0: nothing paired (windowed plans / option); 1: pipelined + one-shot f16; 2: + tail-less one-shot f64
-            npair = nc // batch * batch if nc + nt > shot else (nc & ~1 if prec == 16 or (nt == 0 and mode == 2) else 0)
-            if mode == 0:
-                npair = 0
-            if npair:
-                lo = int(mptr[b]) * CH
-                a[lo:lo + npair * CH] = a[lo:lo + npair * CH].reshape(npair // 2, 64, 2, VPL).transpose(0, 2, 1, 3).reshape(-1)
-        return a
-    mv = lane_linear(mv)
-    mc = lane_linear(mc) if mc.size else mc
-    if st.get("cid16_on"):       # u16 offsets from a per-chunk base column, 0xFFFF = pad
-        off = lane_linear(plan.host_array("med_cid16")).astype(np.int64)
-        base = np.repeat(plan.host_array("med_base").astype(np.int64), CH)
-        assert mc.size == 0 and off.size == base.size
-        mc = np.where(off == 0xFFFF, -1, base + off)
+        nc // batch * batch chunks in pairs (plan.hpp med_npair)"""
+        nc = int(mptr[b + 1] - mptr[b])
+        nt = -(-int(ip_all[b * 16 + 1] - ip_all[b * 16]) // K)
+        mode = st["chunk_pairs"]          # 0: nothing paired (windowed plans / option); 1: pipelined + one-shot f16; 2: + tail-less one-shot f64
+        if mode == 0:
+            return 0
+        return nc // batch * batch if nc + nt > shot else (nc & ~1 if prec == 16 or (nt == 0 and mode == 2) else 0)
+
+    def unpair(seg, npair):
+        """[pair][lane][2 chunks][VPL] for the first npair chunks of a block's segment (plan.hpp med_elem_index) -> chunk-major"""
+        seg = seg.copy()
+        if npair:
+            seg[:npair * CH] = seg[:npair * CH].reshape(npair // 2, 64, 2, VPL).transpose(0, 2, 1, 3).reshape(-1)
+        return seg
+
+    cid16 = bool(st.get("cid16_on"))
+    if cid16:
+        # u16 offsets from a per-chunk base column (0xFFFF = pad); the block's first n8 positions carry one-byte offsets instead (0xFF = pad,
+        # plane med_cid8, [batch][lane][4 chunks]); position q of a block holds its chunk med_korig[q]
+        off16, off8 = plan.host_array("med_cid16").astype(np.int64), plan.host_array("med_cid8").astype(np.int64)
+        c8p, korig, base = plan.host_array("med_c8ptr").astype(np.int64), plan.host_array("med_korig").astype(np.int64), plan.host_array("med_base").astype(np.int64)
+        assert mc.size == 0 and off16.size + off8.size == base.size * CH and korig.size == base.size and st["cid8_chunks"] == c8p[-1]
+    mv_out = np.empty_like(mv)
+    mc_out = np.full(mv.size, -1, np.int64)
+    for b in range(mptr.size - 1):
+        c0, nc, npair = int(mptr[b]), int(mptr[b + 1] - mptr[b]), npair_of(b)
+        vals = unpair(mv[c0 * CH:(c0 + nc) * CH], npair).reshape(nc, CH)             # by position
+        if not cid16:
+            cols = unpair(mc[c0 * CH:(c0 + nc) * CH], npair).reshape(nc, CH).astype(np.int64)
+            order = np.arange(nc)
+        else:
+            n8 = int(c8p[b + 1] - c8p[b])
+            assert n8 % 4 == 0 and n8 <= npair and (n8 == 0 or prec == 64)
+            narrow = off8[c8p[b] * CH:(c8p[b] + n8) * CH].reshape(n8 // 4, 64, 4).transpose(0, 2, 1).reshape(n8, CH) if n8 else np.zeros((0, CH), np.int64)
+            w0 = (c0 - int(c8p[b])) * CH
+            wide = unpair(off16[w0:w0 + (nc - n8) * CH], npair - n8).reshape(nc - n8, CH)
+            bs = base[c0:c0 + nc]
+            cols = np.concatenate([np.where(narrow == 0xFF, -1, bs[:n8, None] + narrow), np.where(wide == 0xFFFF, -1, bs[n8:, None] + wide)])
+            order = korig[c0:c0 + nc]
+            assert sorted(order.tolist()) == list(range(nc)) and (order[npair:] == np.arange(npair, nc)).all()
+        for q in range(nc):                                                            # position q -> the block's chunk order[q]
+            k = c0 + int(order[q])
+            mv_out[k * CH:(k + 1) * CH] = vals[q]
+            mc_out[k * CH:(k + 1) * CH] = cols[q]
+    mv, mc = mv_out, mc_out
     ip_, iv, ic = plan.host_array("irr_ptr"), plan.host_array("irr_val"), plan.host_array("irr_cid")
     nb = mptr.size - 1
     row_block, row_long = ip_.size - 1, st["row_long"] + st.get("med_rows_as_pieces", 0)   # MFMA-block rows only: shorter medium rows are slabs (short_groups), the longest may be pieces
