@@ -275,6 +275,34 @@ def generator_of(D, name):
 CHAIN_FACTOR = {64: 0.5, 16: 1.0}     # f16: 0.5^t would underflow after 24 steps (f64: after 1022, see main)
 
 
+class Watchdog:
+    """A rank that makes no progress for `limit_s` seconds (an RCCL bootstrap or a first collective that never returns, a peer that
+    died) prints ONE JSON error line (rank 0) and ends the process with code 5 -- the launcher then tears the job down -- instead of
+    sitting in a collective until the driver's own limit.  Never re-execs; `kick` is called after every completed phase."""
+
+    def __init__(self, rank, limit_s, args):
+        import threading
+        self.rank, self.limit, self.args = rank, limit_s, args
+        self.t, self.phase = time.time(), "start"
+        if limit_s > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def kick(self, phase):
+        self.t, self.phase = time.time(), phase
+
+    def _run(self):
+        while True:
+            time.sleep(1.0)
+            if time.time() - self.t > self.limit:
+                if self.rank == 0:
+                    print(json.dumps({"metric": "SpMV GFLOP/s (f64)", "value": None, "unit": "GFLOP/s", "n_gpus": self.args.gpus,
+                                      "steps": self.args.steps, "warmup": self.args.warmup, "error": "watchdog: no progress for %d s in phase '%s'"
+                                      % (self.limit, self.phase)}), flush=True)
+                sys.stderr.write("bench.py rank %d: watchdog fired in phase '%s'\n" % (self.rank, self.phase))
+                sys.stderr.flush()
+                os._exit(5)
+
+
 def setup_rank(torch, D, name, scale, prec, rank, world, multi=None, chain=None):
     """Everything one rank owns.  Single GPU: the plan of the whole matrix (A = 1, x = 1, the reference driver's mode).
     Partitioned: its row range (equal nonzeros) as a dasp_mg plan (C ABI) -- a plan over the rank's own columns and one over the
@@ -407,12 +435,15 @@ def main():
     # DASP_BENCH_FORCE_DIST=1 (test hook): run the partitioned + RCCL flow even at world size 1, which is all a one-GPU box
     # can offer RCCL (two ranks may not share a device)
     multi = world > 1 or os.environ.get("DASP_BENCH_FORCE_DIST") == "1"
+    # N > 1: no phase of a healthy run takes minutes (building a rank's plans: seconds; RCCL bootstrap on one node: seconds)
+    dog = Watchdog(rank, float(os.environ.get("DASP_BENCH_WATCHDOG_S", "240")) if multi else 0, args)
     dist = None
     if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=world)      # control plane only; the data path is RCCL inside libdasp_amd.so
+        dog.kick("control plane up")
 
     name, scale, prec = args.workload, args.scale, args.precision
     vb = prec // 8
@@ -424,12 +455,14 @@ def main():
     bounds, stride, r0, r1, x, y = R["bounds"], R["stride"], R["r0"], R["r1"], R["x"], R["y"]
     stream = torch.cuda.current_stream().cuda_stream
     mg = R["mg"]
+    dog.kick("plans built")
     host_exchange = multi and share_gpu
     if multi and not host_exchange:
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")          # one node: RCCL's bootstrap sockets need no NIC (and must not fail for lack of one)
         uid = torch.from_numpy(D.multi.unique_id() if rank == 0 else np.zeros(128, np.uint8))
         dist.broadcast(uid, 0)
         mg.comm_init(uid.numpy())                                 # ncclCommInitRank, one communicator per rank, on its own GPU
+        dog.kick("RCCL communicator up")
 
     def step():
         if mg is None:
@@ -453,6 +486,30 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    dog.kick("warm-up done")
+    step_form = None
+    if mg is not None:
+        # first contact: did an in-kernel wait of the fused step give up (it sets a flag instead of hanging)?  Then every rank drops
+        # to the two-launch form and the chain starts again -- a slower number instead of none.
+        step_form = "fused one-launch step" if mg.info["fused_step"] else "two launches (own, other) + stream hand-offs"
+        bad = 0
+        try:
+            mg.check()
+        except D.DaspError:
+            bad = 1
+        if dist is not None and world > 1:
+            bt = torch.tensor([bad])
+            dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+            bad = int(bt.item())
+        if bad:
+            step_form = "two launches (own, other) + stream hand-offs -- the fused step timed out during warm-up"
+            if mg.info["fused_step"]:
+                mg.set_fused(False)
+            mg.set_x(np.ones(cols, np.float64 if prec == 64 else np.float16))
+            for _ in range(args.warmup):
+                step()
+            fence()
+        dog.kick("first contact checked")
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
@@ -466,6 +523,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     region_event_ms = ev0.elapsed_time(ev1) / args.steps
+    dog.kick("timed region done")
+    if mg is not None:
+        mg.check()                                                # a time-out inside the timed region is an error, not a number
 
     from oracle import oracle as O          # checker / baseline only, after the timed region; never on the measured path
     rx = None
@@ -507,6 +567,7 @@ def main():
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
 
+    dog.kick("results verified")
     # ---- N > 1: what a step is made of, each part alone (events on the launch stream): own-column product, other-column product,
     # the all-gather by itself.  With the overlap a step costs ~ max(own, all-gather) + other; without it their sum.
     parts = None
@@ -536,6 +597,7 @@ def main():
         parts = {"allgather_alone_ms": round(float(tt[0]), 6), "other_column_product_ms": round(float(tt[1]), 6),
                  "allgather_bytes_per_rank": int(stride * vb), "note": "max over ranks; own-column product = roofline.kernel_ms (rank 0)"}
 
+    dog.kick("step parts timed")
     # ---- dominant kernel alone: HIP events on the launch stream around back-to-back launches
     k_iters = max(20, min(args.steps, 1000))
     if mg is None:
@@ -568,7 +630,9 @@ def main():
                     if mg.overlap else "row ranges by nnz + ncclAllGather(y) from libdasp_amd.so (dasp_mg_spmv); x_{t+1} = y_t"),
                    **({} if mg is None else {"rank0_nnz_own_columns": mg.nnz_local, "rank0_nnz_other_columns": mg.nnz_remote,
                                              "exchange": "host memory (test hook)" if host_exchange else "RCCL",
-                                             "stream_handoff": "hipStreamWriteValue64 / hipStreamWaitValue64" if mg.info["stream_memops"] else "events"}),
+                                             "step_form": step_form,
+                                             "stream_handoff": "in-kernel flags + one-lane kernels on the communication stream" if mg.info["fused_step"] else
+                                             ("hipStreamWriteValue64 / hipStreamWaitValue64" if mg.info["stream_memops"] else "events")}),
                    "row_long": st["row_long"], "row_block": st["row_block"], "rate_fill0": round(st["rate_fill0"], 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,

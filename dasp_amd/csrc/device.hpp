@@ -2,6 +2,7 @@
 #pragma once
 
 #include <cstddef>
+#include <vector>
 
 #include "plan.hpp"
 
@@ -62,5 +63,29 @@ struct DevicePlan {
 
 
 int upload_plan(Plan &p);
+
+// fused multi-GPU step (kernels.hip; driven by multigpu.cpp): all pointers are device pointers
+// the words of the fused step live in ONE zero-initialised device block of kMgWordBytes: sharded arrival counters first (marked
+// own-column workgroups at 0, all workgroups at 8192, their top counters at 16384 / +256), then the flags, each on a line of its own
+constexpr size_t kMgWordGathered = 20480, kMgWordOwnGo = 20480 + 4096, kMgWordReady = 20480 + 8192, kMgWordErr = 20480 + 12288, kMgWordBytes = 40960;
+struct MgStepCtl {
+    void *words;                                       // the block above
+    unsigned long long need;                           // the other-column product waits in the kernel for gathered >= need (0: no wait)
+    unsigned long long step;                           // published as "ready" by the last workgroup of the launch
+    const void *mark; const void *mark_members;        // device tables: [own workgroups] bytes, [64] marked workgroups per shard
+    const void *blk_order;                             // device table: [own medium blocks] dispatch order
+    int n_marked, n_mark_shards;
+    int max_pollers;                                   // bound on the persistent workgroups that wait
+    int poll_sleep;                                    // pause between two polls of a workgroup, in units of s_sleep(8) (~0.2 us)
+    long long timeout_ticks;                           // 100 MHz ticks a wait may take before it gives up and sets the error word
+};
+bool mg_step_supported(const Plan &own, const Plan *other);
+// host: which own-column workgroups of the step kernel store a row with has_other[row] != 0 (natural-order plan, before the
+// host arrays are dropped).  mark gets one byte per workgroup of the plan's launch grid; blk_order the dispatch order of the medium
+// blocks that the marks assume (blocks holding such rows first).
+void mg_step_marks(const Plan &own, const unsigned char *has_other, std::vector<unsigned char> &mark, std::vector<int> &blk_order);
+int launch_mg_step(Plan &own, Plan *other, const void *x_own, const void *x_gathered, void *y, const MgStepCtl &c, void *stream);
+int launch_mg_wait(const void *word, unsigned long long need, long long timeout_ticks, void *err, void *stream);
+int launch_mg_flag(void *word, unsigned long long value, void *stream);
 
 }  // namespace dasp

@@ -31,6 +31,7 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -100,6 +101,17 @@ __device__ __forceinline__ float wave_sum(float v)
     float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
     float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
     return (a + b) + (c + d);
+}
+
+// read-only plan tables indexed by wave-uniform values (block / piece / chunk numbers).  K = true (the fused multi-GPU step): read
+// through the CONSTANT address space, so that they stay scalar loads -- that kernel waits on flags in memory, and with an atomic
+// load or a fence anywhere in the function the compiler no longer proves global memory unclobbered and turns every such read into a
+// vector load (the own-column product of an 8-way HV15R slice: 61 -> 92 us).  The tables are never written while a plan exists.
+template <bool K, class U>
+__device__ __forceinline__ U tab(const U *p, int i)
+{
+    if constexpr (K) return reinterpret_cast<const __attribute__((address_space(4))) U *>(reinterpret_cast<uintptr_t>(p))[i];
+    else return p[i];
 }
 
 __device__ __forceinline__ int slot_of(const SlotMap &m, int t)
@@ -218,7 +230,7 @@ struct ChunkSrc {
 // arena pads them) and are zeroed in gather(), so neither stage has a divergent branch.
 // C8: the plan has one-byte ids (f64, 16-bit-id plans with narrow chunks): its own kernel instantiation, so that every other plan runs
 // exactly the code it ran before
-template <class T, bool NT, bool C16, bool PAIRS, bool C8>
+template <class T, bool NT, bool C16, bool PAIRS, bool C8, bool KT = false>
 struct BlockSrc {
     static constexpr bool kPairs = PAIRS;          // false: the windowed kernel, whose plans keep every chunk lane-linear
     static constexpr int VPL = Tr<T>::CHUNK / kWave;           // values of one chunk per lane: 1 (f64) / 4 (f16)
@@ -345,7 +357,7 @@ struct BlockSrc {
                 }
             }
         } else if constexpr (C16) {
-            const int b = base[c0 + i];                         // wave-uniform: one scalar load per chunk
+            const int b = tab<KT>(base, c0 + i);                // wave-uniform: one scalar load per chunk
             if constexpr (sizeof(T) == 8) {
                 unsigned o = (unsigned)f.c, pad = 0xFFFFu;
                 if constexpr (QUAD && kQuadIds) {                // this chunk's field of the raw dword: wave-uniform shift / mask
@@ -474,11 +486,24 @@ __device__ __forceinline__ void run_stream(ACC &acc, const SRC &src, int N, cons
 }
 
 // the one store of a row's result: y = v, or y += v in accumulate mode (wave-uniform flag; one writer per y index)
-template <class T, class P>
+// YS (the fused multi-GPU step only): how a row's result reaches y when the own-column and the other-column product share ONE launch.
+//   0: the ordinary store / read-modify-write (a.acc);
+//   1: own columns -- a write-through (sc1) store, so that the value is at the coherence point once the storing wave's vmcnt wait
+//      returns and the workgroup counts as done (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores + drained + counter);
+//   2: other columns, behind the in-kernel wait for ALL own-column workgroups -- sc1 load, add, sc1 store: y += v with exactly the
+//      arithmetic of the two-launch form (y = own; y += other), one writer per y index in each phase.
+template <class T, int YS = 0, class P>
 __device__ __forceinline__ void put_y(const DevArgs &a, int yi, P v)
 {
     T *y = static_cast<T *>(a.y) + yi;
-    *y = a.acc ? (T)((P)*y + v) : (T)v;
+    // volatile, not __hip_atomic_*: gfx950 gives a volatile access the system-scope cache bits (sc0 sc1: written through / read at the
+    // coherence point), and -- unlike ANY atomic store or inline asm in the kernel -- it leaves the compiler free to fetch the row
+    // tables and per-chunk bases with scalar loads (with an atomic store the own-column product of a slice runs 92 instead of 61 us)
+    if constexpr (YS == 1) *(volatile T *)y = (T)v;
+    else if constexpr (YS == 2) {
+        const T old = *(volatile T *)y;
+        *(volatile T *)y = (T)((P)old + v);
+    } else *y = a.acc ? (T)((P)*y + v) : (T)v;
 }
 
 // diagonal element D[row][row] held by this lane (valid only on the 16 "diagonal lanes")
@@ -498,13 +523,13 @@ __device__ __forceinline__ bool diag_of(const f32x4 &acc, int lane, float &d)
 // ---- medium: one wave = one block of 16 sorted rows (reference: dasp_f64.h:145-279)
 // YM: where the 16 results go -- 0: the block's own slots (reference permutation), or order[slot] when the plan is
 // DASP_Y_NATURAL (a.order set); 2: med_dst[position] (windowed mode)
-template <class T, bool NT, bool C16, int YM, bool C8 = false, class XV>
+template <class T, bool NT, bool C16, int YM, bool C8 = false, int YS = 0, class XV>
 __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, const XV &x)
 {
     using acc_t = typename Tr<T>::acc_t;
     constexpr int CH = Tr<T>::CHUNK;
     const T *val = static_cast<const T *>(a.med_val);
-    const int c0 = a.med_ptr[b], c1 = a.med_ptr[b + 1];
+    const int c0 = tab<YS != 0>(a.med_ptr, b), c1 = tab<YS != 0>(a.med_ptr, b + 1);
     acc_t acc = {0, 0, 0, 0};
     // the block's first row is its longest (rows are sorted), so its tail length bounds the number of tail steps
     const int row = lane & 15, kq = lane >> 4;
@@ -513,12 +538,12 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     if (r < a.row_block) { t0 = a.irr_ptr[r]; t1 = a.irr_ptr[r + 1]; }
     constexpr int TK = sizeof(T) == 8 ? 4 : 16;                      // tail entries of one row per MFMA step
     const int nt = (__builtin_amdgcn_readfirstlane(t1 - t0) + TK - 1) / TK;
-    BlockSrc<T, NT, C16, YM != 2, C8> src;
+    BlockSrc<T, NT, C16, YM != 2, C8, YS != 0> src;
     src.reg.val = val; src.reg.cid = a.med_cid; src.reg.e0 = (size_t)c0 * CH; src.reg.lane = lane;
     src.nc = c1 - c0; src.npair = med_npair(c1 - c0, nt, (int)sizeof(T), YM == 2 ? 0 : a.pair_mode); src.cid16 = a.med_cid16; src.base = a.med_base; src.c0 = c0;
     src.c8 = a.med_cid8; src.w16 = a.med_cid16; src.n8 = 0;
     if constexpr (C8 && C16 && sizeof(T) == 8 && YM != 2) {
-        const int q0 = a.med_c8ptr[b], q1 = a.med_c8ptr[b + 1];
+        const int q0 = tab<YS != 0>(a.med_c8ptr, b), q1 = tab<YS != 0>(a.med_c8ptr, b + 1);
         src.n8 = q1 - q0; src.c8 = a.med_cid8 + (size_t)q0 * CH; src.w16 = a.med_cid16 - (size_t)q1 * CH;      // e16 - (e0 + n8 CH) = -(q0 + n8) CH
     }
     src.ival = static_cast<const T *>(a.irr_val); src.icid = a.irr_cid; src.t0 = t0; src.t1 = t1; src.kq = kq;
@@ -528,12 +553,12 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     if (diag_of(acc, lane, d) && r < a.row_block) {
         const int slot = a.row_long + r;                 // row_long here = slot of the first MFMA medium row (Plan::med_slot0)
         const int yi = YM == 2 ? a.med_dst[r] : (a.order ? a.order[slot] : slot);
-        put_y<T>(a, yi, d);
+        put_y<T, YS>(a, yi, d);
     }
 }
 
 // ---- long: one wave = one piece (<= long_piece elements) of one long row (reference: dasp_f64.h:90-144)
-template <class T, bool NT>
+template <class T, bool NT, int YS = 0>
 __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
 {
     using acc_t = typename Tr<T>::acc_t;
@@ -542,7 +567,7 @@ __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
     constexpr int VPL = CH / kWave;          // values per lane per MFMA: 1 (f64) / 4 (f16)
     const XGlobal<T> x{static_cast<const T *>(a.x)};
     const T *val = static_cast<const T *>(a.long_val);
-    const int p0 = a.piece_ptr[p], p1 = a.piece_ptr[p + 1];
+    const int p0 = tab<YS != 0>(a.piece_ptr, p), p1 = tab<YS != 0>(a.piece_ptr, p + 1);
     acc_t acc = {0, 0, 0, 0};
     const int full = p0 + (p1 - p0) / CH * CH;
     ChunkSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane};
@@ -565,14 +590,14 @@ __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
     const bool on_diag = diag_of(acc, lane, d);
     const part_t total = wave_sum(on_diag ? d : (part_t)0);
     if (lane == 0) {
-        const int dst = a.piece_dst[p];
-        if (dst >= 0) put_y<T>(a, dst, total);
+        const int dst = tab<YS != 0>(a.piece_dst, p);
+        if (dst >= 0) put_y<T, YS>(a, dst, total);
         else static_cast<part_t *>(a.partial)[~dst] = total;
     }
 }
 
 // ---- short: one wave = one tile of SHORT_ROWS rows of equal length L; lane owns V consecutive rows
-template <class T, int L, bool NT>
+template <class T, int L, bool NT, int YS = 0>
 __device__ __forceinline__ void short_rows(const DevArgs &a, const ShortDev &g, int local_tile, int lane)
 {
     constexpr int SR = Tr<T>::SHORT_ROWS;
@@ -609,13 +634,13 @@ __device__ __forceinline__ void short_rows(const DevArgs &a, const ShortDev &g, 
         if (t < g.count) {
             const int slot = slot_of(g.map, t);
             const int yi = a.order ? a.order[slot] : slot;
-            put_y<T>(a, yi, s[v]);
+            put_y<T, YS>(a, yi, s[v]);
         }
     }
 }
 
 // the same for the medium rows stored as slabs (5 <= L <= kSlabMaxLen): L is a run-time value, four steps in flight
-template <class T, bool NT>
+template <class T, bool NT, int YS = 0>
 __device__ __forceinline__ void slab_rows(const DevArgs &a, const ShortDev &g, int local_tile, int lane)
 {
     constexpr int SR = Tr<T>::SHORT_ROWS;
@@ -653,25 +678,32 @@ __device__ __forceinline__ void slab_rows(const DevArgs &a, const ShortDev &g, i
         if (t < g.count) {
             const int slot = g.map.base[0] + t;                  // slab groups map linearly onto the medium slots
             const int yi = a.order ? a.order[slot] : slot;
-            put_y<T>(a, yi, s[v]);
+            put_y<T, YS>(a, yi, s[v]);
         }
     }
 }
 
-template <class T, bool NT>
+template <class T, bool NT, int YS = 0>
 __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
 {
     int gi = 0;
     for (int g = 1; g < kNumShortGroups; ++g) if (tile >= a.grp_tile0[g]) gi = g;     // kernel arguments: scalar compares
-    const ShortDev g = a.groups[gi];
+    ShortDev g;
+    if constexpr (YS != 0) {      // word by word through the constant address space (see tab)
+        static_assert(sizeof(ShortDev) % 4 == 0, "ShortDev is a whole number of words");
+        int w[sizeof(ShortDev) / 4];
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(ShortDev) / 4); ++i) w[i] = tab<true>(reinterpret_cast<const int *>(a.groups + gi), i);
+        __builtin_memcpy(&g, w, sizeof g);
+    } else g = a.groups[gi];
     const int local = tile - g.tile0;
     switch (g.len) {
-        case 0: short_rows<T, 0, NT>(a, g, local, lane); break;    // empty rows: y = 0
-        case 1: short_rows<T, 1, NT>(a, g, local, lane); break;
-        case 2: short_rows<T, 2, NT>(a, g, local, lane); break;
-        case 3: short_rows<T, 3, NT>(a, g, local, lane); break;
-        case 4: short_rows<T, 4, NT>(a, g, local, lane); break;
-        default: slab_rows<T, NT>(a, g, local, lane); break;
+        case 0: if constexpr (YS != 2) short_rows<T, 0, NT, YS>(a, g, local, lane); break;    // empty rows: y = 0 (y += 0: nothing to do)
+        case 1: short_rows<T, 1, NT, YS>(a, g, local, lane); break;
+        case 2: short_rows<T, 2, NT, YS>(a, g, local, lane); break;
+        case 3: short_rows<T, 3, NT, YS>(a, g, local, lane); break;
+        case 4: short_rows<T, 4, NT, YS>(a, g, local, lane); break;
+        default: slab_rows<T, NT, YS>(a, g, local, lane); break;
     }
 }
 
@@ -748,6 +780,140 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPla
         const int t = (wg - a.wg_long - a.wg_med) * wpw + wave;
         if (t < a.n_short_tiles) short_tile<T, NT>(a, t, lane);
     }
+}
+
+// ------------------------------------------------------------------ the fused multi-GPU step (dasp_mg_spmv, f64)
+// One launch = the whole product of one rank's step.  Grid order: the workgroups of the own-column plan `a` (y = own, written
+// through), then a bounded set of PERSISTENT workgroups that wait -- in the kernel -- for two flags and then stride over the
+// workgroups of the other-column plan `b` (y += other: exactly the arithmetic of the two-launch form):
+//   own_go   : every own-column workgroup that handles a row with other-column nonzeros ("marked", a host-built table) has stored
+//              its y.  The own plan's medium blocks are dispatched through a host-built order table -- the blocks holding such rows
+//              first, then the rest longest-first as ever (a plain reversal loses 20 us to the long blocks at the tail) -- so the
+//              marked workgroups run FIRST and the flag is up after a fraction of the own-column product;
+//   gathered : the exchange of the previous step has delivered the other ranks' x.
+// So the other-column product overlaps the rest of the own-column product instead of following it, neither a kernel boundary nor a
+// stream wait sits between the two, and the last workgroup to finish publishes "y ready" itself.  The waiting workgroups are at most
+// max_pollers (multigpu.cpp: one slot per CU is always left free), so they can never fill the device and keep the exchange's kernel
+// out; a wait longer than the time-out sets *err and skips the other-column product instead of hanging -- the host then falls back to
+// the two-launch form (dasp_mg_check).
+struct StepCtl {
+    const unsigned long long *gathered;   // device word: step number of the last completed exchange into the gather buffer
+    unsigned long long need;              // the other-column product may read the gather buffer once *gathered >= need (0: at once)
+    const unsigned char *mark;            // [grid_a] 1: that own-column workgroup stores a row the other-column plan adds to
+    const unsigned *mark_members;         // [64] marked workgroups per shard (wg & 63)
+    int n_marked, n_mark_shards;          // marked workgroups / non-empty shards among them
+    unsigned *mark_shards, *mark_top;     // arrival counters of the marked own-column workgroups (64 shards on lines of their own + top)
+    unsigned long long *own_go;           // set to `step` by the last marked workgroup: the other-column product may add into y
+    unsigned *all_shards, *all_top;       // arrival counters of ALL workgroups of the launch
+    unsigned long long *ready;            // word the exchange waits on: set to `step` when every workgroup of this launch is done
+    unsigned long long step;
+    int *err;                             // sticky: 1 = a wait timed out
+    int grid_a, grid_b, n_poll;           // workgroups of plan a / virtual workgroups of plan b / persistent workgroups serving them
+    const int *blk_order;                 // [medium blocks of plan a] dispatch order: the blocks of marked workgroups first
+    int sleep;                            // s_sleep(8) repetitions between two polls (~0.2 us each)
+    long long timeout;                    // 100 MHz ticks after which a waiting workgroup gives up
+};
+
+// arrival of a workgroup at a two-level counter: true for the one that arrives last.  64 sharded counters, each on a 128-byte line
+// of its own, then one top counter -- same-address atomics serialise at the memory side (one flat counter: ~50 ns per arrival,
+// 180 us for the 3800 workgroups of an 8-way HV15R slice).  `members` = arrivals expected at this shard, `nshards` = non-empty
+// shards.  Every counter returns to 0 with its last arrival.
+constexpr int kArriveShards = 64, kShardStride = 32;        // in 4-byte words
+__device__ __forceinline__ bool arrive_last(unsigned *shards, unsigned *top, int sh, unsigned members, unsigned nshards)
+{
+    if (__hip_atomic_fetch_add(shards + sh * kShardStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 != members) return false;
+    __hip_atomic_store(shards + sh * kShardStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 != nshards) return false;
+    __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+// members of shard `sh` among `total` consecutively numbered arrivals
+__device__ __forceinline__ unsigned shard_members(int total, int sh) { return (unsigned)((total - sh + kArriveShards - 1) / kArriveShards); }
+
+// one (virtual) workgroup `wg` of a non-windowed plan: dasp_spmv_kernel's body, parameterised by the workgroup id.  One medium block
+// per wave, no grid-stride loop (the f64 plans' medium range is never capped, upload_plan).  blk_order: the medium blocks'
+// dispatch order (null: as stored).
+template <class T, bool NT, bool C16, bool C8, int YS>
+__device__ __forceinline__ void plain_wg(const DevArgs &a, int wg, int wave, int lane, const int *blk_order)
+{
+    if (wg < a.wg_long) {
+        const int p = wg * kWavesPerWG + wave;
+        if (p < a.n_pieces) long_piece<T, NT, YS>(a, p, lane);
+    } else if (wg < a.wg_long + a.wg_med) {
+        const int q = (wg - a.wg_long) * kWavesPerWG + wave;
+        const XGlobal<T> x{static_cast<const T *>(a.x)};
+        if (q < a.n_blocks) medium_block<T, NT, C16, 0, C8, YS>(a, blk_order ? tab<true>(blk_order, q) : q, lane, x);
+    } else {
+        const int t = (wg - a.wg_long - a.wg_med) * kWavesPerWG + wave;
+        if (t < a.n_short_tiles) short_tile<T, NT, YS>(a, t, lane);
+    }
+}
+
+template <bool NT>
+__global__ __launch_bounds__(256, kMinWavesPlain) void dasp_mg_step_kernel(DevArgs a, DevArgs b, StepCtl c)
+{
+    __shared__ int go;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wg = blockIdx.x;
+    const int total = c.grid_a + c.n_poll;
+    if (wg < c.grid_a) {
+        plain_wg<double, NT, true, true, 1>(a, wg, wave, lane, c.blk_order);
+        // done: every wave's write-through stores acknowledged, then ONE lane counts the workgroup.  Relaxed atomics: the y values went
+        // out through sc0 sc1 stores, so an arrival needs no cache write-back or invalidate of its own (an acq_rel add costs every
+        // workgroup a buffer_wbl2 + buffer_inv: measured 300 instead of 70 us per step)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (c.n_marked > 0 && tab<true>(c.mark, wg) &&
+                arrive_last(c.mark_shards, c.mark_top, wg & (kArriveShards - 1), tab<true>(c.mark_members, wg & (kArriveShards - 1)), (unsigned)c.n_mark_shards))
+                __hip_atomic_store(c.own_go, c.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (arrive_last(c.all_shards, c.all_top, wg & (kArriveShards - 1), shard_members(total, wg & (kArriveShards - 1)),
+                            (unsigned)(total < kArriveShards ? total : kArriveShards)))
+                __hip_atomic_store(c.ready, c.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        const long long t0 = wall_clock64();
+        // relaxed polls (an acquire load would invalidate caches on every iteration, under the running product), ONE acquire at the end
+        while ((c.n_marked > 0 && __hip_atomic_load(c.own_go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.step) ||
+               (c.need && __hip_atomic_load(c.gathered, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < c.need)) {
+            for (int z = 0; z < c.sleep; ++z) __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > c.timeout) { ok = 0; __hip_atomic_store(c.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+        }
+        // the gather buffer was written by another kernel (this device's or, over xGMI, a peer's) while this one ran
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        go = ok;
+    }
+    __syncthreads();
+    if (go)
+        for (int v = wg - c.grid_a; v < c.grid_b; v += c.n_poll) plain_wg<double, NT, true, true, 2>(b, v, wave, lane, nullptr);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && arrive_last(c.all_shards, c.all_top, wg & (kArriveShards - 1), shard_members(total, wg & (kArriveShards - 1)),
+                                        (unsigned)(total < kArriveShards ? total : kArriveShards)))
+        __hip_atomic_store(c.ready, c.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// the exchange side of the fused step, on the communication stream: hold the stream until *p >= need (the product's "y ready"),
+// and publish a step number behind the exchange.  Plain kernels on plain device words: no stream memory operations (Beta API).
+__global__ void dasp_mg_wait_kernel(const unsigned long long *p, unsigned long long need, long long timeout, int *err)
+{
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    // relaxed polls (an acquire load invalidates the caches on every iteration, under the running product), ONE acquire at the end
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > timeout) { __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+__global__ void dasp_mg_flag_kernel(unsigned long long *p, unsigned long long v)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // stage 2 for long rows cut into several pieces (reference: longPart_sum, dasp_f64.h:53-75)
@@ -1063,6 +1229,96 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate
     a.x = dX; a.y = dY; a.acc = accumulate ? 1 : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.precision == 64 ? launch_typed<double>(p, a, s) : launch_typed<_Float16>(p, a, s);
+}
+
+// ---- fused multi-GPU step (multigpu.cpp).  Which plans qualify: f64, uploaded, no x windows, no column panels, 16-bit ids (the one
+// instantiation of the step kernel), no long row cut into several pieces (their stage 2 would run behind the launch that publishes
+// "y ready").  `other` may be null (no nonzero outside the rank's own columns).
+bool mg_step_supported(const Plan &own, const Plan *other)
+{
+    auto ok = [](const Plan &p) {
+        return p.precision == 64 && p.dev && p.dev->arena && p.panels.empty() && !p.windowed && p.cid16 && p.dev->args.n_multi == 0;
+    };
+    return ok(own) && (!other || ok(*other));
+}
+
+void mg_step_marks(const Plan &p, const unsigned char *has_other, std::vector<unsigned char> &mark, std::vector<int> &blk_order)
+{
+    // the launch grid of upload_plan / dasp_mg_step_kernel: [ long pieces | medium blocks through blk_order | short tiles ], 4 units per workgroup
+    const int n_pieces = (int)p.piece_dst.size(), n_blocks = p.stats.n_med_blocks, n_tiles = p.stats.n_short_tiles;
+    const int wg_long = (n_pieces + kWavesPerWG - 1) / kWavesPerWG, wg_med = (n_blocks + kWavesPerWG - 1) / kWavesPerWG,
+              wg_short = (n_tiles + kWavesPerWG - 1) / kWavesPerWG;
+    mark.assign((size_t)wg_long + wg_med + wg_short, 0);
+    for (int q = 0; q < n_pieces; ++q) {
+        const int dst = p.piece_dst[(size_t)q];
+        if (dst >= 0 && has_other[dst]) mark[(size_t)q / kWavesPerWG] = 1;
+    }
+    // medium blocks holding a row the other-column plan adds to go first, everything else keeps the stored (longest-first) order
+    std::vector<unsigned char> hot((size_t)n_blocks, 0);
+    for (int b = 0; b < n_blocks; ++b)
+        for (int i = 0; i < kMedRows && b * kMedRows + i < p.n_mfma_rows; ++i)
+            if (has_other[p.order[(size_t)p.med_slot0 + (size_t)b * kMedRows + i]]) { hot[(size_t)b] = 1; break; }
+    blk_order.clear(); blk_order.reserve((size_t)n_blocks);
+    for (int b = 0; b < n_blocks; ++b) if (hot[(size_t)b]) blk_order.push_back(b);
+    const int n_hot = (int)blk_order.size();
+    for (int b = 0; b < n_blocks; ++b) if (!hot[(size_t)b]) blk_order.push_back(b);
+    for (int q = 0; q < n_hot; ++q) mark[(size_t)wg_long + q / kWavesPerWG] = 1;
+    const int SR = p.geo.short_rows;
+    for (int g = 0; g < kNumShortGroups; ++g) {
+        const ShortGroup &G = p.grp[g];
+        for (int lt = 0; lt < G.tiles; ++lt) {
+            const int t = G.tile0 + lt;
+            for (int tt = lt * SR; tt < std::min(G.count, (lt + 1) * SR); ++tt) {
+                const int slot = g < 5 ? G.map.slot(tt) : G.map.base[0] + tt;      // short_rows / slab_rows
+                if (has_other[p.order[(size_t)slot]]) { mark[(size_t)wg_long + wg_med + t / kWavesPerWG] = 1; break; }
+            }
+        }
+    }
+}
+
+int launch_mg_step(Plan &own, Plan *other, const void *x_own, const void *x_gathered, void *y, const MgStepCtl &h, void *stream)
+{
+    if (!mg_step_supported(own, other)) { set_error("plans do not qualify for the fused multi-GPU step"); return DASP_ERR_STATE; }
+    DevArgs a = own.dev->args, b = other ? other->dev->args : own.dev->args;
+    a.x = x_own; a.y = y; a.acc = 0;
+    b.x = x_gathered; b.y = y; b.acc = 0;
+    StepCtl c{};
+    char *w = static_cast<char *>(h.words);
+    c.mark_shards = reinterpret_cast<unsigned *>(w); c.all_shards = reinterpret_cast<unsigned *>(w + 8192);
+    c.mark_top = reinterpret_cast<unsigned *>(w + 16384); c.all_top = reinterpret_cast<unsigned *>(w + 16384 + 256);
+    c.gathered = reinterpret_cast<const unsigned long long *>(w + kMgWordGathered); c.need = other ? h.need : 0;
+    c.own_go = reinterpret_cast<unsigned long long *>(w + kMgWordOwnGo);
+    c.ready = reinterpret_cast<unsigned long long *>(w + kMgWordReady); c.step = h.step; c.err = reinterpret_cast<int *>(w + kMgWordErr);
+    c.grid_a = a.wg_long + a.wg_med + a.wg_short;
+    c.grid_b = other ? b.wg_long + b.wg_med + b.wg_short : 0;
+    c.n_poll = std::min(c.grid_b, std::max(1, h.max_pollers));
+    c.mark = static_cast<const unsigned char *>(h.mark); c.mark_members = static_cast<const unsigned *>(h.mark_members);
+    c.n_marked = other ? h.n_marked : 0; c.n_mark_shards = h.n_mark_shards;
+    c.blk_order = static_cast<const int *>(h.blk_order);
+    c.sleep = std::max(1, h.poll_sleep); c.timeout = h.timeout_ticks;
+    const int grid = c.grid_a + c.n_poll;
+    if (grid <= 0) { set_error("empty step"); return DASP_ERR_STATE; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // the own-column plan decides the cache policy of the streamed tiles (the other-column plan is a few per cent of the bytes)
+    if (own.dev->nt) hipLaunchKernelGGL((dasp_mg_step_kernel<true>), dim3(grid), dim3(256), 0, s, a, b, c);
+    else hipLaunchKernelGGL((dasp_mg_step_kernel<false>), dim3(grid), dim3(256), 0, s, a, b, c);
+    HIP_TRY(hipGetLastError());
+    return DASP_OK;
+}
+
+int launch_mg_wait(const void *word, unsigned long long need, long long timeout_ticks, void *err, void *stream)
+{
+    hipLaunchKernelGGL(dasp_mg_wait_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<const unsigned long long *>(word), need,
+                       timeout_ticks, static_cast<int *>(err));
+    HIP_TRY(hipGetLastError());
+    return DASP_OK;
+}
+
+int launch_mg_flag(void *word, unsigned long long value, void *stream)
+{
+    hipLaunchKernelGGL(dasp_mg_flag_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<unsigned long long *>(word), value);
+    HIP_TRY(hipGetLastError());
+    return DASP_OK;
 }
 
 namespace {

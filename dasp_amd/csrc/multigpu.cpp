@@ -9,6 +9,16 @@
 // so that product t+1 over the own columns runs while all-gather t is still in flight on the communication stream and only
 // the (small, for banded matrices) other-column product waits for it.  RCCL is reached through dlopen: one copy per process
 // (the one PyTorch already mapped, if any), and libdasp_amd.so loads on machines without it.
+//
+// Fused step (r3, f64 plans that qualify: mg_step_supported): ONE launch per iteration on the caller's stream.  The own-column
+// workgroups come first in grid order; a bounded set of persistent workgroups waits IN THE KERNEL for the flag the exchange of the
+// previous iteration sets AND for the count of finished own-column workgroups, then runs the other-column plan (y += through sc1
+// loads / stores: the two-launch arithmetic); the last workgroup to finish publishes "y ready", on which a one-lane kernel at the
+// head of the communication stream spins.  So the caller's stream carries back-to-back kernels and nothing else -- no kernel
+// boundary between the two products, no stream wait / write packets -- and every hand-off is a plain kernel on a plain device word
+// (no Beta stream-memory-operation API).  A wait that times out sets a sticky error word instead of hanging; dasp_mg_check reports
+// it and drops the plan to the two-launch form.  (Tried first: both products adding into a zeroed slice with f64 atomics, fully
+// concurrent -- 125 us per step against 70: agent-scope atomics are performed at the memory side.)
 #include <hip/hip_runtime_api.h>
 #include <hip/hip_ext.h>
 #include <rccl/rccl.h>
@@ -27,6 +37,7 @@
 #include <vector>
 
 #include "plan.hpp"
+#include "device.hpp"
 
 using namespace dasp;
 
@@ -100,32 +111,54 @@ struct dasp_mg_plan {
     dasp_plan_t *other = nullptr;      // other ranks' columns (x = the gather buffer); may be absent
     // device state
     int device = -1;
-    void *ys[2] = {nullptr, nullptr};  // this rank's padded slice of y, ping-pong (the one last written is the next x slice)
+    void *ys[3] = {nullptr, nullptr, nullptr};  // this rank's padded slice of y, rotating: ys[cur] = the one last written = the next x slice
     void *yg = nullptr;                // world * stride: every rank's slice; for a square matrix also the x the products read
     void *xg = nullptr;                // what the products read: yg (square) or a plain colA vector (rectangular)
     int cur = 0;
     bool pending = false;              // an all-gather into yg is in flight on `cs`
+    bool pending_sig = false;          // ... and its completion was published by a stream memory operation (else: ev_g)
     hipStream_t cs = nullptr;          // communication stream
     hipEvent_t ev_y = nullptr, ev_g = nullptr;
-    // cross-stream hand-offs by stream memory operations where the device supports them (hipStreamWriteValue64 on the producing
-    // stream, hipStreamWaitValue64 on the consuming one, on two counters in device memory): the command processors poll a word
-    // instead of going through an event's signal + barrier packet (measured, world size 1: device time of a step 95 -> see DESIGN 5)
-    uint64_t *sig = nullptr;           // device words: [0] = products of step k done, [1] = all-gather of step k done
+    // two-launch form: cross-stream hand-offs through events (documented acquire / release semantics).  DASP_MG_SYNC=memops opts into
+    // stream memory operations (hipStreamWriteValue64 / hipStreamWaitValue64, a Beta API) on two words of SIGNAL memory, one
+    // allocation each as the API documents; a memory operation that fails falls back to the event for that hand-off.
+    uint64_t *sig[2] = {nullptr, nullptr};   // [0] = products of step k done, [1] = all-gather of step k done
     uint64_t step = 0, pending_step = 0;
     bool use_sig = false;
-    int fake_us = -1;                  // test hook DASP_MG_FAKE_ALLGATHER_US: world > 1 without a communicator, the exchange = local copy + a kernel of that duration
+    // fused step: one zeroed block of plain device words (device.hpp kMgWord*): sharded arrival counters, gathered (step of the last
+    // completed exchange), own_go, ready (step whose products are complete), error word
+    char *words = nullptr;
+    bool fused = false;                // dasp_mg_spmv / dasp_mg_product run the one-launch step
+    uint64_t gathered_step = 0;        // step number of the last exchange queued on the communication stream (0: none since set_x)
+    int max_pollers = 1024, poll_sleep = 1;
+    std::vector<unsigned char> mark;   // one byte per own-column workgroup of the step kernel: stores a row the other-column plan adds to
+    std::vector<unsigned> mark_members;
+    std::vector<int> blk_order;        // dispatch order of the own plan's medium blocks in the step kernel (marked ones first)
+    void *d_blk_order = nullptr;
+    int n_marked = 0, n_mark_shards = 0;
+    void *d_mark = nullptr;            // device copy: mark bytes, then (256-byte aligned) the 64 per-shard counts
+    long long timeout_ticks = 200ll * 100000;   // 200 ms at 100 MHz
+    // test hook (dasp_mg_set_fake_exchange): world > 1 without a communicator; the exchange = copies of the rank's slice into the
+    // given gather buffers (this rank's own and those of peers living on the same device) + a kernel of that duration
+    int fake_us = -1;
+    std::vector<void *> fake_peers;
     ncclComm_t comm = nullptr;
 
     size_t vb() const { return precision == 64 ? 8 : 2; }
     int rows() const { return bounds[(size_t)rank + 1] - bounds[(size_t)rank]; }
     ~dasp_mg_plan()
     {
+        if (device >= 0) (void)hipSetDevice(device);
+        if (cs) (void)hipStreamSynchronize(cs);
         if (comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(comm);
         if (ev_y) (void)hipEventDestroy(ev_y);
         if (ev_g) (void)hipEventDestroy(ev_g);
         if (cs) (void)hipStreamDestroy(cs);
-        if (sig) (void)hipFree(sig);
-        for (void *p : {ys[0], ys[1], yg}) if (p) (void)hipFree(p);
+        for (uint64_t *w : sig) if (w) (void)hipFree(w);
+        if (words) (void)hipFree(words);
+        if (d_mark) (void)hipFree(d_mark);
+        if (d_blk_order) (void)hipFree(d_blk_order);
+        for (void *p : {ys[0], ys[1], ys[2], yg}) if (p) (void)hipFree(p);
         if (xg && xg != yg) (void)hipFree(xg);
         if (own) dasp_plan_destroy(own);
         if (other) dasp_plan_destroy(other);
@@ -199,25 +232,76 @@ int create_impl(dasp_mg_plan &g, const int *rp, const int *ci, const T *val, con
     static const int zero = 0;
     if (int rc = dasp_plan_create(&g.own, g.precision, m, g.stride, rpO[(size_t)m], rpO.data(), ciO.empty() ? &zero : ciO.data(),
                                   vO.empty() ? static_cast<const void *>(&zero) : vO.data(), &opt)) return rc;
+    // the fused step runs ONE kernel instantiation for both plans (16-bit ids): where the own-column plan chose them, the small
+    // other-column plan follows (left to itself it would stay below the size from which 16-bit ids are automatic)
+    if (part.cid16 == 0 && g.precision == 64 && g.own->impl.cid16) part.cid16 = 1;
     if (g.nnz_other > 0)
         if (int rc = dasp_plan_create(&g.other, g.precision, m, g.colA, rpR[(size_t)m], rpR.data(), ciR.data(), vR.data(), &part)) return rc;
+    // fused step: which own-column workgroups store a row the other-column plan adds to (the only ones it has to wait for)
+    if (g.other && g.precision == 64 && g.own->impl.panels.empty() && !g.own->impl.windowed && g.own->impl.opt.y_order == DASP_Y_NATURAL) {
+        std::vector<unsigned char> has((size_t)std::max(m, 1), 0);
+        for (int i = 0; i < m; ++i) has[(size_t)i] = rpR[(size_t)i + 1] > rpR[(size_t)i];
+        mg_step_marks(g.own->impl, has.data(), g.mark, g.blk_order);
+        g.mark_members.assign(64, 0);
+        for (size_t w = 0; w < g.mark.size(); ++w) if (g.mark[w]) { ++g.mark_members[w & 63]; ++g.n_marked; }
+        for (unsigned c : g.mark_members) g.n_mark_shards += c > 0;
+    }
     return DASP_OK;
 }
 
-// consumer side of "the all-gather of the pending step is done" on stream s
+// hand-offs of the two-launch form: events, or -- opted in -- stream memory operations; an operation that fails is replaced by the
+// event (or, on the consumer side of a value that was already written by an operation, by a host wait for the communication stream).
+constexpr uint64_t kAllBits = 0xFFFFFFFFFFFFFFFFull;
+// "y ready": the communication stream continues once the products queued so far on `s` are done (both sides are queued here)
+int handoff_ready(dasp_mg_plan &g, hipStream_t s, uint64_t k)
+{
+    if (g.use_sig) {
+        if (hipStreamWriteValue64(s, g.sig[0], k, 0) == hipSuccess &&
+            hipStreamWaitValue64(g.cs, g.sig[0], k, hipStreamWaitValueGte, kAllBits) == hipSuccess) return DASP_OK;
+        (void)hipGetLastError(); g.use_sig = false;
+    }
+    MG_HIP(hipEventRecord(g.ev_y, s));
+    MG_HIP(hipStreamWaitEvent(g.cs, g.ev_y, 0));
+    return DASP_OK;
+}
+// "gathered", producer side (behind the exchange on the communication stream)
+int publish_gathered(dasp_mg_plan &g, uint64_t k)
+{
+    g.pending_sig = false;
+    if (g.use_sig) {
+        if (hipStreamWriteValue64(g.cs, g.sig[1], k, 0) == hipSuccess) { g.pending_sig = true; return DASP_OK; }
+        (void)hipGetLastError(); g.use_sig = false;
+    }
+    MG_HIP(hipEventRecord(g.ev_g, g.cs));
+    return DASP_OK;
+}
+// "gathered", consumer side on stream s.  One dasp_mg_plan is driven from ONE stream (header): the flag is cleared once that
+// stream has been ordered behind the exchange.
 int wait_gathered(dasp_mg_plan &g, hipStream_t s)
 {
     if (!g.pending) return DASP_OK;
-    if (g.use_sig) MG_HIP(hipStreamWaitValue64(s, &g.sig[1], g.pending_step, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
-    else MG_HIP(hipStreamWaitEvent(s, g.ev_g, 0));
+    if (g.pending_sig) {
+        if (hipStreamWaitValue64(s, g.sig[1], g.pending_step, hipStreamWaitValueGte, kAllBits) != hipSuccess) {
+            (void)hipGetLastError(); g.use_sig = false;
+            MG_HIP(hipStreamSynchronize(g.cs));          // no event was recorded for this exchange: wait for it on the host
+        }
+    } else MG_HIP(hipStreamWaitEvent(s, g.ev_g, 0));
     g.pending = false;
     return DASP_OK;
 }
 
 int product(dasp_mg_plan &g, hipStream_t s)
 {
-    const int cur = g.cur, nxt = 1 - g.cur;
-    if (g.overlap) {
+    const int cur = g.cur, nxt = (g.cur + 1) % 3;
+    if (g.fused) {
+        // one launch: own-column workgroups, then the persistent workgroups that wait in the kernel for exchange `gathered_step`
+        MgStepCtl c{};
+        c.words = g.words; c.need = g.gathered_step; c.step = g.step + 1;
+        c.mark = g.d_mark; c.mark_members = static_cast<char *>(g.d_mark) + ((g.mark.size() + 255) & ~size_t(255));
+        c.n_marked = g.n_marked; c.n_mark_shards = g.n_mark_shards; c.blk_order = g.d_blk_order;
+        c.max_pollers = g.max_pollers; c.timeout_ticks = g.timeout_ticks; c.poll_sleep = g.poll_sleep;
+        if (int rc = launch_mg_step(g.own->impl, g.other ? &g.other->impl : nullptr, g.ys[cur], g.yg, g.ys[nxt], c, s)) return rc;
+    } else if (g.overlap) {
         // own columns: needs only this rank's slice of x, i.e. its own previous y -- no communication
         if (int rc = dasp_plan_spmv(g.own, g.ys[cur], g.ys[nxt], s)) return rc;
         if (int rc = wait_gathered(g, s)) return rc;                                         // the other ranks' x has arrived
@@ -227,6 +311,23 @@ int product(dasp_mg_plan &g, hipStream_t s)
         if (int rc = dasp_plan_spmv(g.own, g.xg, g.ys[nxt], s)) return rc;
     }
     g.cur = nxt;
+    ++g.step;
+    return DASP_OK;
+}
+
+// the slice ys[cur] -> every rank's gather buffer on stream q (RCCL; one rank or the test hook: local copies)
+int exchange(dasp_mg_plan &g, hipStream_t q)
+{
+    if (g.comm) {
+        const ncclResult_t r = rccl()->AllGather(g.ys[g.cur], g.yg, (size_t)g.stride, g.precision == 64 ? ncclFloat64 : ncclFloat16, g.comm, q);
+        if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
+        return DASP_OK;
+    }
+    const size_t sl = (size_t)g.stride * g.vb();
+    MG_HIP(hipMemcpyAsync(static_cast<char *>(g.yg) + (size_t)g.rank * sl, g.ys[g.cur], sl, hipMemcpyDeviceToDevice, q));
+    for (void *peer : g.fake_peers)
+        if (peer && peer != g.yg) MG_HIP(hipMemcpyAsync(static_cast<char *>(peer) + (size_t)g.rank * sl, g.ys[g.cur], sl, hipMemcpyDeviceToDevice, q));
+    if (g.world > 1) if (int rc = devpack_spin(q, g.fake_us)) return rc;
     return DASP_OK;
 }
 
@@ -297,7 +398,7 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
     if (g.other) (void)dasp_plan_drop_host(g.other);
     MG_HIP(hipGetDevice(&g.device));
     const size_t vb = g.vb(), sl = (size_t)g.stride * vb, all = sl * (size_t)g.world;
-    for (int k = 0; k < 2; ++k) { MG_HIP(hipMalloc(&g.ys[k], sl)); MG_HIP(hipMemset(g.ys[k], 0, sl)); }
+    for (int k = 0; k < 3; ++k) { MG_HIP(hipMalloc(&g.ys[k], sl)); MG_HIP(hipMemset(g.ys[k], 0, sl)); }
     MG_HIP(hipMalloc(&g.yg, all)); MG_HIP(hipMemset(g.yg, 0, all));
     if (g.square) g.xg = g.yg;
     else { const size_t xb = std::max<size_t>((size_t)g.colA * vb, 16); MG_HIP(hipMalloc(&g.xg, xb)); MG_HIP(hipMemset(g.xg, 0, xb)); }
@@ -309,20 +410,55 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
     }
     MG_HIP(hipEventCreateWithFlags(&g.ev_y, hipEventDisableTiming));
     MG_HIP(hipEventCreateWithFlags(&g.ev_g, hipEventDisableTiming));
-    {
+    {   // two-launch form: events unless DASP_MG_SYNC=memops asks for stream memory operations on signal memory
         int can = 0;
-        const char *e = std::getenv("DASP_MG_SYNC");                        // "event" forces the event path (A/B, fallback)
-        if (!(e && std::strcmp(e, "event") == 0) && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, g.device) == hipSuccess && can) {
-            void *p = nullptr;
-            // plain device memory: signal memory (hipMallocSignalMemory) only comes in single 8-byte allocations and buys nothing here
-            // (tools/micro/memops.cpp: a hand-off through a plain word costs ~8 us, through an event ~16 us)
-            if (hipMalloc(&p, 2 * sizeof(uint64_t)) == hipSuccess && hipMemset(p, 0, 2 * sizeof(uint64_t)) == hipSuccess) {
-                g.sig = static_cast<uint64_t *>(p); g.use_sig = true;
-            } else if (p) (void)hipFree(p);
+        const char *e = std::getenv("DASP_MG_SYNC");
+        if (e && std::strcmp(e, "memops") == 0 && hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, g.device) == hipSuccess && can) {
+            bool ok = true;
+            for (int k = 0; k < 2 && ok; ++k) {
+                void *p = nullptr;
+                ok = hipExtMallocWithFlags(&p, sizeof(uint64_t), hipMallocSignalMemory) == hipSuccess && p;
+                if (ok) {
+                    const uint64_t zero = 0;
+                    g.sig[k] = static_cast<uint64_t *>(p);
+                    ok = hipMemcpy(p, &zero, sizeof zero, hipMemcpyHostToDevice) == hipSuccess;
+                }
+            }
+            g.use_sig = ok;
+            if (!ok) for (uint64_t *&w : g.sig) { if (w) (void)hipFree(w); w = nullptr; }
         }
         (void)hipGetLastError();
     }
-    if (const char *e = std::getenv("DASP_MG_FAKE_ALLGATHER_US")) g.fake_us = std::atoi(e);
+    {   // fused step: wherever the plans qualify (f64, square, split by columns), unless DASP_MG_FUSED=0
+        const char *e = std::getenv("DASP_MG_FUSED");
+        const bool want = !(e && std::strcmp(e, "0") == 0);
+        if (want && g.overlap && mg_step_supported(g.own->impl, g.other ? &g.other->impl : nullptr) && (!g.other || (int)g.mark.size() == g.own->impl.stats.n_workgroups)) {
+            void *p = nullptr;
+            MG_HIP(hipMalloc(&p, kMgWordBytes));
+            MG_HIP(hipMemset(p, 0, kMgWordBytes));
+            g.words = static_cast<char *>(p);
+            const size_t mb = (g.mark.size() + 255) & ~size_t(255);
+            MG_HIP(hipMalloc(&g.d_mark, mb + 256));
+            MG_HIP(hipMemset(g.d_mark, 0, mb + 256));
+            if (!g.mark.empty()) {
+                MG_HIP(hipMemcpy(g.d_mark, g.mark.data(), g.mark.size(), hipMemcpyHostToDevice));
+                MG_HIP(hipMemcpy(static_cast<char *>(g.d_mark) + mb, g.mark_members.data(), 64 * sizeof(unsigned), hipMemcpyHostToDevice));
+            }
+            if (!g.blk_order.empty()) {
+                MG_HIP(hipMalloc(&g.d_blk_order, g.blk_order.size() * sizeof(int)));
+                MG_HIP(hipMemcpy(g.d_blk_order, g.blk_order.data(), g.blk_order.size() * sizeof(int), hipMemcpyHostToDevice));
+            }
+            g.fused = true;
+            hipDeviceProp_t prop;
+            int cus = 256;
+            if (hipGetDeviceProperties(&prop, g.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+            int per_cu = 4;        // of the ~5 workgroups of the step kernel a CU holds: the rest stays free for the exchange's kernel
+            if (const char *q = std::getenv("DASP_MG_POLL_PER_CU")) per_cu = std::max(1, std::atoi(q));
+            g.max_pollers = cus * per_cu;
+            if (const char *q = std::getenv("DASP_MG_POLL_SLEEP")) g.poll_sleep = std::max(1, std::atoi(q));
+            if (const char *q = std::getenv("DASP_MG_TIMEOUT_MS")) g.timeout_ticks = std::max(1, std::atoi(q)) * 100000ll;
+        }
+    }
     MG_HIP(hipDeviceSynchronize());
     g.uploaded = true;
     return DASP_OK;
@@ -351,7 +487,7 @@ int dasp_mg_set_x(dasp_mg_plan_t *mg, const void *x_host)
     const size_t vb = g.vb();
     const char *x = static_cast<const char *>(x_host);
     MG_HIP(hipDeviceSynchronize());
-    g.pending = false;
+    g.pending = false; g.pending_sig = false; g.gathered_step = 0;
     if (!g.square) { MG_HIP(hipMemcpy(g.xg, x, (size_t)g.colA * vb, hipMemcpyHostToDevice)); return DASP_OK; }
     try {
         std::vector<char> lay((size_t)g.world * g.stride * vb, 0);
@@ -379,23 +515,19 @@ int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = product(g, s)) return rc;
     // y (this rank's padded slice) -> every rank's gather buffer, on the communication stream, behind the products
-    const uint64_t k = ++g.step;
-    if (g.use_sig) {
-        MG_HIP(hipStreamWriteValue64(s, &g.sig[0], k, 0));
-        MG_HIP(hipStreamWaitValue64(g.cs, &g.sig[0], k, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull));
+    const uint64_t k = g.step;
+    if (g.fused) {
+        // the communication stream spins (one lane) until the launch's last workgroup has published step k, exchanges, publishes k back
+        if (int rc = launch_mg_wait(g.words + kMgWordReady, k, g.timeout_ticks, g.words + kMgWordErr, g.cs)) return rc;
+        if (int rc = exchange(g, g.cs)) return rc;
+        if (int rc = launch_mg_flag(g.words + kMgWordGathered, k, g.cs)) return rc;
+        MG_HIP(hipEventRecord(g.ev_g, g.cs));          // for dasp_mg_wait / dasp_mg_allgather: consumers outside the step kernel
+        g.gathered_step = k; g.pending_sig = false;
     } else {
-        MG_HIP(hipEventRecord(g.ev_y, s));
-        MG_HIP(hipStreamWaitEvent(g.cs, g.ev_y, 0));
+        if (int rc = handoff_ready(g, s, k)) return rc;
+        if (int rc = exchange(g, g.cs)) return rc;
+        if (int rc = publish_gathered(g, k)) return rc;
     }
-    if (g.comm) {
-        const ncclResult_t r = rccl()->AllGather(g.ys[g.cur], g.yg, (size_t)g.stride, g.precision == 64 ? ncclFloat64 : ncclFloat16, g.comm, g.cs);
-        if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
-    } else {   // one rank (or the test hook): the gather is a copy of the own slice into its slot, plus the emulated duration
-        MG_HIP(hipMemcpyAsync(static_cast<char *>(g.yg) + (size_t)g.rank * g.stride * g.vb(), g.ys[g.cur], (size_t)g.stride * g.vb(), hipMemcpyDeviceToDevice, g.cs));
-        if (g.world > 1) if (int rc = devpack_spin(g.cs, g.fake_us)) return rc;
-    }
-    if (g.use_sig) MG_HIP(hipStreamWriteValue64(g.cs, &g.sig[1], k, 0));
-    else MG_HIP(hipEventRecord(g.ev_g, g.cs));
     g.pending = true; g.pending_step = k;
     return DASP_OK;
 }
@@ -407,15 +539,10 @@ int dasp_mg_allgather(dasp_mg_plan_t *mg, void *stream)
     if (!mg) return DASP_ERR_ARG;
     dasp_mg_plan &g = *mg;
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
-    if (!g.comm && g.world > 1) { set_error("dasp_mg_allgather needs dasp_mg_comm_init"); return DASP_ERR_STATE; }
+    if (!g.comm && g.world > 1 && g.fake_us < 0) { set_error("dasp_mg_allgather needs dasp_mg_comm_init"); return DASP_ERR_STATE; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = wait_gathered(g, s)) return rc;
-    if (g.comm) {
-        const ncclResult_t r = rccl()->AllGather(g.ys[g.cur], g.yg, (size_t)g.stride, g.precision == 64 ? ncclFloat64 : ncclFloat16, g.comm, s);
-        if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
-    } else {
-        MG_HIP(hipMemcpyAsync(g.yg, g.ys[g.cur], (size_t)g.stride * g.vb(), hipMemcpyDeviceToDevice, s));
-    }
+    if (int rc = exchange(g, s)) return rc;
     return DASP_OK;
 }
 
@@ -471,6 +598,47 @@ int dasp_mg_info(const dasp_mg_plan_t *mg, dasp_mg_info_t *out)
     out->nnz_own = mg->nnz_own; out->nnz_other = mg->nnz_other;
     out->overlap = mg->overlap ? 1 : 0; out->has_comm = mg->comm ? 1 : 0; out->square = mg->square ? 1 : 0;
     out->stream_memops = mg->use_sig ? 1 : 0;
+    out->fused_step = mg->fused ? 1 : 0;
+    return DASP_OK;
+}
+
+int dasp_mg_check(dasp_mg_plan_t *mg)
+{
+    if (!mg) return DASP_ERR_ARG;
+    dasp_mg_plan &g = *mg;
+    if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
+    MG_HIP(hipDeviceSynchronize());
+    g.pending = false;
+    if (!g.fused) return DASP_OK;
+    uint64_t err = 0;
+    MG_HIP(hipMemcpy(&err, g.words + kMgWordErr, sizeof err, hipMemcpyDeviceToHost));
+    if ((int)err == 0) return DASP_OK;
+    // a poll gave up: products since then lack other-column terms (1) or an exchange ran ahead of its product (2).  Drop to the
+    // two-launch form; the caller starts again from dasp_mg_set_x.
+    g.fused = false; g.gathered_step = 0;
+    MG_HIP(hipMemset(g.words, 0, kMgWordBytes));
+    set_error(std::string("fused multi-GPU step: ") + ((int)err == 1 ? "the wait for the previous exchange" : "the exchange's wait for the product") +
+              " timed out; the plan now runs the two-launch form -- call dasp_mg_set_x and start again");
+    return DASP_ERR_STATE;
+}
+
+int dasp_mg_set_fused(dasp_mg_plan_t *mg, int on)
+{
+    if (!mg) return DASP_ERR_ARG;
+    dasp_mg_plan &g = *mg;
+    if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
+    MG_HIP(hipDeviceSynchronize());
+    if (on && !g.words) { set_error("this plan does not qualify for the fused step (f64, square, column split, 16-bit ids, no windows / panels / multi-piece rows)"); return DASP_ERR_STATE; }
+    g.pending = false; g.gathered_step = 0;
+    g.fused = on != 0;
+    return DASP_OK;
+}
+
+int dasp_mg_set_fake_exchange(dasp_mg_plan_t *mg, int micros, int n_peers, void *const *peer_gathered)
+{
+    if (!mg || n_peers < 0 || (n_peers > 0 && !peer_gathered)) return DASP_ERR_ARG;
+    mg->fake_us = micros;
+    mg->fake_peers.assign(peer_gathered, peer_gathered + n_peers);
     return DASP_OK;
 }
 

@@ -18,7 +18,8 @@
 namespace dasp {
 
 namespace {
-const char kPlanMagic[8] = {'D', 'A', 'S', 'P', 'P', 'L', 'N', '4'};
+// bumped with EVERY change of the header, the array list or the element order inside an array (5: 18-int header, one-byte ids, chunk pairs)
+const char kPlanMagic[8] = {'D', 'A', 'S', 'P', 'P', 'L', 'N', '5'};
 
 struct Writer {
     FILE *f; bool ok = true;
@@ -71,7 +72,14 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
     const long long xlen = p.opt.n_parts > 0 ? (long long)p.opt.n_parts * p.opt.part_stride : (long long)p.n;
     if (xlen >= (1ll << 31)) return fail("x length");
     if (p.order.size() != (size_t)m) return fail("order size");
-    for (int v : p.order) if ((unsigned)v >= (unsigned)m) return fail("order_rid entry out of range");
+    {
+        std::vector<bool> seen((size_t)m, false);
+        for (int v : p.order) {
+            if ((unsigned)v >= (unsigned)m) return fail("order_rid entry out of range");
+            if (seen[(size_t)v]) return fail("order_rid is not a permutation: two writers for one y index in natural order");
+            seen[(size_t)v] = true;
+        }
+    }
     if (!p.dst_map.empty()) {
         if (p.dst_map.size() != (size_t)m) return fail("dst_map size");
         for (int v : p.dst_map) if ((unsigned)v >= (unsigned)m) return fail("dst_map entry out of range");
@@ -186,6 +194,27 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
             if (t >= 0 && t < G.count) { const long long sl = M.slot(t); if (sl < 0 || sl >= m) return fail("slot map leaves the permutation"); }
     }
     if ((size_t)off != p.cnt_short || p.stats.n_short_tiles != tile0) return fail("short segment size");
+    if (p.win_hybrid && !p.windowed) return fail("win_hybrid without windows");
+    // ---- one writer per y index: put_y is a plain store (or, in accumulate mode, a plain read-modify-write), so two units with the
+    // same destination would race / add twice.  Destinations exactly as the kernels form them (upload_plan: order / dst_map).
+    {
+        const bool natural = p.opt.y_order == DASP_Y_NATURAL;
+        std::vector<bool> hit((size_t)m, false);
+        auto claim = [&](long long yi) { if (yi < 0 || yi >= m || hit[(size_t)yi]) return false; hit[(size_t)yi] = true; return true; };
+        auto ydst = [&](long long slot) -> long long {
+            if (slot < 0 || slot >= m) return -1;
+            if (!natural) return slot;
+            const int r = p.order[(size_t)slot];
+            return p.dst_map.empty() ? r : p.dst_map[(size_t)r];
+        };
+        for (int d : p.piece_dst) if (d >= 0 && !claim(d)) return fail("two writers for one y index (piece_dst)");
+        for (int d : p.multi_dst) if (!claim(d)) return fail("two writers for one y index (multi_dst)");
+        for (long long r = 0; r < p.n_mfma_rows; ++r)
+            if (!claim(p.windowed ? (long long)p.med_dst[(size_t)r] : ydst((long long)p.med_slot0 + r))) return fail("two writers for one y index (medium rows)");
+        for (int g = 0; g < kNumShortGroups; ++g)
+            for (int t = 0; t < p.grp[g].count; ++t)
+                if (!claim(ydst(g < 5 ? (long long)p.grp[g].map.slot(t) : (long long)p.grp[g].map.base[0] + t))) return fail("two writers for one y index (short rows / slabs)");
+    }
     return true;
 }
 

@@ -92,6 +92,19 @@ class MgPlan:
         """the exchange alone (collective): current y slice -> every rank's gather buffer"""
         _lib.check(_lib.lib().dasp_mg_allgather(self._h, C.c_void_p(stream)))
 
+    def check(self):
+        """device sync + did a wait of the fused step time out?  Raises DaspError (and the plan drops to the two-launch form)."""
+        _lib.check(_lib.lib().dasp_mg_check(self._h))
+
+    def set_fused(self, on):
+        _lib.check(_lib.lib().dasp_mg_set_fused(self._h, 1 if on else 0))
+
+    def set_fake_exchange(self, micros, peers=()):
+        """TEST HOOK: n_gpus > 1 without RCCL; the exchange copies this rank's slice into its own gather buffer and into the
+        gather buffers of `peers` (MgPlans on the same device), then holds the communication stream for `micros` us."""
+        arr = (C.c_void_p * max(1, len(peers)))(*[p.gathered_ptr for p in peers])
+        _lib.check(_lib.lib().dasp_mg_set_fake_exchange(self._h, int(micros), len(peers), arr))
+
     def wait(self, stream=0):
         _lib.check(_lib.lib().dasp_mg_wait(self._h, C.c_void_p(stream)))
 

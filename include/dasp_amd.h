@@ -294,8 +294,9 @@ typedef struct dasp_mg_info {
     int stride;                    /* padded slice length in elements (multiple of 64) */
     long long nnz_own, nnz_other;  /* nonzeros in the rank's own column range / elsewhere (nnz_other = 0 without the split) */
     int overlap, has_comm, square;
-    int stream_memops;             /* (after dasp_mg_upload) 1: the two streams hand over through hipStreamWriteValue64 / hipStreamWaitValue64
-                                      on two device words; 0: through events (device without support, or DASP_MG_SYNC=event) */
+    int stream_memops;             /* (after dasp_mg_upload; two-launch form) 1: the two streams hand over through hipStreamWriteValue64 /
+                                      hipStreamWaitValue64 on two words of signal memory (DASP_MG_SYNC=memops; a Beta API); 0: through events */
+    int fused_step;                /* (after dasp_mg_upload) 1: dasp_mg_spmv / dasp_mg_product run the one-launch step (below) */
 } dasp_mg_info_t;
 
 /* contiguous row ranges with equal nonzero counts: bounds[0]=0 <= ... <= bounds[n_parts]=rowA */
@@ -319,8 +320,26 @@ int dasp_mg_comm_init(dasp_mg_plan_t *mg, const void *id);
 int dasp_mg_set_x(dasp_mg_plan_t *mg, const void *x_host);
 /* one iteration, asynchronous: own-column product | wait for the previous all-gather | other-column product (y +=) on
  * `stream`, then ncclAllGather(y slice -> gather buffer) on the communication stream behind them.  Square matrices: the
- * gathered y is the next call's x.  Rectangular: x stays what dasp_mg_set_x stored. */
+ * gathered y is the next call's x.  Rectangular: x stays what dasp_mg_set_x stored.
+ * ONE dasp_mg_plan is driven from ONE stream: pass the same `stream` to every dasp_mg_spmv / _product / _wait / _allgather of a plan.
+ * Fused step (f64, square, column split, plans with 16-bit ids and without x windows / column panels / multi-piece long rows;
+ * DASP_MG_FUSED=0 turns it off): the two products are ONE launch -- own-column workgroups first (y written through), then a
+ * bounded set of persistent workgroups that wait inside the kernel for the count of finished own-column workgroups and for the
+ * previous exchange's flag and run the other-column plan (y +=; the arithmetic of the two-launch form, bit-identical) -- and the
+ * launch's last workgroup publishes "y ready" to a one-lane kernel at the head of the communication stream: `stream` carries
+ * back-to-back kernels only.  In-kernel waits give up after 200 ms (DASP_MG_TIMEOUT_MS) and set a sticky error instead of
+ * hanging: see dasp_mg_check. */
 int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream);
+/* synchronises the device and reports whether a wait of the fused step timed out since the last check: DASP_OK, or DASP_ERR_STATE
+ * after switching the plan to the two-launch form (results since the time-out are invalid: dasp_mg_set_x and start again). */
+int dasp_mg_check(dasp_mg_plan_t *mg);
+/* choose the form explicitly (1 needs a plan that qualifies); synchronises the device, the current y slice stays valid */
+int dasp_mg_set_fused(dasp_mg_plan_t *mg, int on);
+/* TEST HOOK, never needed with RCCL: lets dasp_mg_spmv run at n_gpus > 1 without a communicator.  The exchange becomes a copy of
+ * the rank's slice into its own gather buffer and into `peer_gathered[0..n_peers)` (dasp_mg_gathered of other ranks' plans living on
+ * the same device; NULL entries are skipped), followed by a kernel that holds the communication stream for `micros` us.  There is no
+ * cross-rank synchronisation: the caller orders the ranks' steps itself. */
+int dasp_mg_set_fake_exchange(dasp_mg_plan_t *mg, int micros, int n_peers, void *const *peer_gathered);
 /* the products of one iteration only (no exchange): for callers that move dasp_mg_y_local into every rank's
  * dasp_mg_gathered themselves (tests; transports other than RCCL) */
 int dasp_mg_product(dasp_mg_plan_t *mg, void *stream);

@@ -66,3 +66,17 @@ def test_gather_roofline_arithmetic():
     assert abs(g["achieved_Ggathers_per_s"] - 153.0) < 0.1 and abs(g["frac_of_l1_miss_queue"] - 1.0) < 0.01
     assert abs(g["peak_ta_Glines_per_s"] - 614.4) < 0.1
     assert b.algorithmic_bytes(10, 20, 100, 8) == (100 + 20 + 10) * 8 + 100 * 4 + 11 * 4       # data_origin1, main_f64.cu:143
+
+
+def test_watchdog_ends_a_stuck_rank_with_a_json_error_line():
+    """bench.py's N > 1 watchdog: no progress for the limit -> rank 0 prints one JSON line carrying "error" and the process ends
+    with code 5 (never a re-exec)"""
+    import json
+    import subprocess
+    import sys
+    code = ("import sys, time, argparse; sys.path.insert(0, %r); import bench; "
+            "a = argparse.Namespace(gpus=8, steps=3, warmup=1); d = bench.Watchdog(0, 1.0, a); d.kick('RCCL communicator up'); time.sleep(30)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 5
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] is None and line["n_gpus"] == 8 and "RCCL communicator up" in line["error"]

@@ -404,6 +404,116 @@ def test_bench_rank_setup_assembles_full_y(dasp, torch_cuda):
             mg.close()
 
 
+def _hv_slices(dasp, world, scale=0.02):
+    import scipy.sparse as sp
+    rows, _ = dasp.synth_dims("HV15R", scale)
+    rp_all, ci_all = dasp.synth_csr("HV15R", scale)
+    lens = np.diff(rp_all)
+    val = np.repeat(0.5 / np.maximum(lens, 1), lens)
+    A = sp.csr_matrix((val, ci_all, rp_all), shape=(rows, rows))
+    bounds = dasp.partition_rows(rp_all, world)
+    sl = []
+    for r in range(world):
+        r0, r1 = int(bounds[r]), int(bounds[r + 1])
+        sl.append((rp_all[r0:r1 + 1] - rp_all[r0], ci_all[rp_all[r0]:rp_all[r1]], val[rp_all[r0]:rp_all[r1]]))
+    return rows, A, bounds, sl
+
+
+def test_fused_mg_step_three_ranks_on_one_device(dasp, torch_cuda):
+    """The one-launch step (own-column workgroups, other-column workgroups, atomics into a zeroed slice, three rotating slice
+    buffers) with three ranks' plans on ONE device and the test-hook exchange copying every slice into every rank's gather buffer:
+    six chained iterations == (A_s)^6 x_0 from scipy, every rank holds the same gathered y, and the result is BIT-IDENTICAL to the
+    two-launch form (y = own; y += other).  The in-kernel wait is exercised by the next test."""
+    from dasp_amd.multi import MgPlan
+    torch = torch_cuda
+    world = 3
+    rows, A, bounds, sl = _hv_slices(dasp, world)
+    x0 = np.random.default_rng(4).uniform(0.5, 1.5, rows)
+    res = {}
+    for fused in (True, False):
+        mgs = [MgPlan(rp, ci, v, rows, rows, bounds, r, cid16=1).upload() for r, (rp, ci, v) in enumerate(sl)]
+        streams = [torch.cuda.Stream() for _ in mgs]
+        for mg in mgs:
+            assert mg.info["fused_step"] == 1 and mg.overlap
+            if not fused:
+                mg.set_fused(False)
+                assert mg.info["fused_step"] == 0
+            mg.set_fake_exchange(20, peers=mgs)
+            mg.set_x(x0)
+        want = x0
+        for it in range(6):
+            # the hook has no cross-rank ordering of its own (RCCL's collective has): all products, then all exchanges
+            for mg, st in zip(mgs, streams):
+                mg.product(st.cuda_stream)
+            for mg in mgs:
+                mg.check()
+            for mg, st in zip(mgs, streams):
+                mg.allgather(st.cuda_stream)
+            torch.cuda.synchronize()
+            want = A @ want
+        ys = [mg.get_y() for mg in mgs]
+        for y in ys[1:]:
+            np.testing.assert_array_equal(y, ys[0])
+        assert np.abs(ys[0] - want).max() <= 1e-13 * np.abs(want).max()
+        np.testing.assert_array_equal(np.concatenate([mg.get_y_local() for mg in mgs]), ys[0])
+        res[fused] = ys[0]
+        for mg in mgs:
+            mg.close()
+    np.testing.assert_array_equal(res[True], res[False])
+
+
+def test_fused_mg_step_waits_in_the_kernel_and_times_out_cleanly(dasp, torch_cuda, monkeypatch):
+    """One rank of a 2-way partition, 30 chained steps with NO host synchronisation between them and an emulated exchange of
+    60 us: the other-column workgroups really wait inside the kernel for the previous exchange.  The peer's half of x never
+    changes (nobody sends it), so the expected chain is y <- A_own y + A_other x0, bit-identical between the two forms.  Then a
+    2 ms exchange against a 1 ms time-out: dasp_mg_check reports it, the plan drops to the two-launch form and works again."""
+    import scipy.sparse as sp
+    from dasp_amd.multi import MgPlan
+    torch = torch_cuda
+    rows, A, bounds, sl = _hv_slices(dasp, 2)
+    rank = 1
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    rp, ci, v = sl[rank]
+    Ar = sp.csr_matrix((v, ci, rp), shape=(r1 - r0, rows))
+    x0 = np.random.default_rng(5).uniform(0.5, 1.5, rows)
+    out = {}
+    for fused in (True, False):
+        mg = MgPlan(rp, ci, v, rows, rows, bounds, rank, cid16=1).upload()
+        mg.set_fused(fused)
+        mg.set_fake_exchange(60)
+        mg.set_x(x0)
+        s = torch.cuda.current_stream().cuda_stream
+        for _ in range(30):
+            mg.spmv(s)
+        mg.wait(s)
+        mg.check()
+        out[fused] = mg.get_y_local()
+        mg.close()
+    x = x0.copy()
+    for _ in range(30):
+        x[r0:r1] = Ar @ x
+    np.testing.assert_array_equal(out[True], out[False])
+    assert np.abs(out[True] - x[r0:r1]).max() <= 1e-12 * np.abs(x[r0:r1]).max()
+    monkeypatch.setenv("DASP_MG_TIMEOUT_MS", "1")
+    mg = MgPlan(rp, ci, v, rows, rows, bounds, rank, cid16=1).upload()
+    monkeypatch.delenv("DASP_MG_TIMEOUT_MS")
+    mg.set_fake_exchange(2000)
+    mg.set_x(x0)
+    for _ in range(3):
+        mg.spmv(0)
+    with pytest.raises(dasp.DaspError) as e:
+        mg.check()
+    assert "timed out" in str(e.value) and mg.info["fused_step"] == 0
+    mg.set_x(x0)
+    mg.spmv(0)
+    mg.wait(0)
+    mg.check()
+    x = x0.copy()
+    x[r0:r1] = Ar @ x
+    assert np.abs(mg.get_y_local() - x[r0:r1]).max() <= 1e-13 * np.abs(x).max()
+    mg.close()
+
+
 @pytest.mark.parametrize("prec", [64, 16])
 @pytest.mark.parametrize("square", [True, False])
 def test_mg_spmv_world_size_one_against_the_oracle(oracle, dasp, torch_cuda, prec, square):

@@ -385,12 +385,53 @@ def test_corrupt_plan_files_are_rejected_not_trusted(dasp, tmp_path):
                 assert e.status in (-2, -5, -11)
                 rejected += 1
         assert rejected >= 5
-    bad = bytearray(blob)
-    bad[7:8] = b"3"                                                    # an older layout's magic
-    open(good, "wb").write(bad)
-    with pytest.raises(dasp.DaspError) as e:
-        dasp.Plan.load(good)
-    assert e.value.status == -2
+    for old in (b"3", b"4"):                                           # older layouts' magics ('4': before the one-byte ids / 18-int header)
+        bad = bytearray(blob)
+        assert bytes(bad[:8]) == b"DASPPLN5"
+        bad[7:8] = old
+        open(good, "wb").write(bad)
+        with pytest.raises(dasp.DaspError) as e:
+            dasp.Plan.load(good)
+        assert e.value.status == -2
+
+
+def test_plan_files_with_two_writers_for_one_y_are_rejected(dasp, tmp_path):
+    """put_y assumes ONE writer per y index (a plain store; a plain read-modify-write in accumulate mode): a file whose destination
+    tables name a row twice -- or stage hybrid windows without windows -- is refused on load"""
+    rp, ci, v = util.mixed_matrix(2500, 2000, 13)
+    path = str(tmp_path / "p.plan")
+
+    def damaged(plan, name, mutate):
+        plan.save(path)
+        blob = bytearray(open(path, "rb").read())
+        arr = plan.host_array(name)
+        raw = arr.tobytes()
+        key = len(raw).to_bytes(8, "little") + raw                       # every array is stored behind its int64 byte count
+        at = bytes(blob).find(key)
+        assert at > 0 and bytes(blob).find(key, at + 1) < 0              # located unambiguously
+        at += 8
+        new = arr.copy()
+        mutate(new)
+        blob[at:at + len(raw)] = new.tobytes()
+        open(path, "wb").write(blob)
+        with pytest.raises(dasp.DaspError) as e:
+            dasp.Plan.load(path)
+        assert e.value.status in (-2, -5) and "writer" in str(e.value)
+
+    def dup(a):
+        a[1] = a[0]
+
+    plan = dasp.Plan(rp, ci, v, 2000, y_order=dasp.Y_NATURAL)            # natural order: destinations go through order_rid
+    damaged(plan, "order", dup)
+    plan.close()
+    plan = dasp.Plan(rp, ci, v, 2000, x_window=100000, row_window=128)   # windowed: med_dst
+    damaged(plan, "med_dst", dup)
+    plan.close()
+    lens = np.array([300, 400, 500] + [7] * 200)
+    rp2, ci2, v2 = util.csr_from_lengths(lens, 900, 3)
+    plan = dasp.Plan(rp2, ci2, v2, 900, y_order=dasp.Y_NATURAL)           # long rows: piece_dst
+    damaged(plan, "piece_dst", dup)
+    plan.close()
 
 
 def test_mg_plan_splits_a_row_slice_by_column_owner(dasp):

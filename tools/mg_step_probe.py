@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""tools/mg_step_probe.py [n_gpus=8] [workload=HV15R] [ranks=all] [balance=nnz|cost]: EVERY rank's share of an n-way row partition, one after the
+other on this box's single GPU, with the real plans and the real choreography of dasp_mg_spmv and an EMULATED exchange (dasp_mg_set_fake_exchange: local
+copy + a kernel holding the communication stream).  Per rank: the step time of the fused one-launch form and of the two-launch form for several exchange
+durations, the products alone, and -- last line -- the max over ranks against the 1-GPU step of the same box."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import dasp_amd as D
+from dasp_amd.multi import MgPlan
+
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+name = sys.argv[2] if len(sys.argv) > 2 else "HV15R"
+ranks = list(range(world)) if len(sys.argv) <= 3 or sys.argv[3] == "all" else [int(r) for r in sys.argv[3].split(",")]
+balance = sys.argv[4] if len(sys.argv) > 4 else "nnz"
+scale = float(os.environ.get("PROBE_SCALE", "1.0"))
+AG = [int(a) for a in os.environ.get("PROBE_AG_US", "0,40,60").split(",")]
+rows, cols = D.synth_dims(name, scale)
+lengths = D.synth_row_lengths(name, scale)
+rpf = np.zeros(rows + 1, np.int64); np.cumsum(lengths, out=rpf[1:])
+if balance == "cost":
+    bounds = D.partition_rows_cost(lengths, world, 64)
+else:
+    bounds = np.searchsorted(rpf, rpf[-1] * np.arange(world + 1) // world, side="left").astype(np.int32)
+    bounds[0], bounds[-1] = 0, rows
+s = torch.cuda.current_stream().cuda_stream
+
+HOST = {}
+def step_time(mg, n=300):
+    for _ in range(20): mg.spmv(s)
+    mg.wait(s); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); h0 = time.perf_counter()
+    for _ in range(n): mg.spmv(s)
+    h1 = time.perf_counter()
+    mg.wait(s); e1.record(); torch.cuda.synchronize()
+    mg.check()
+    HOST["us"] = (h1 - h0) / n * 1e6
+    return e0.elapsed_time(e1) / n * 1e3
+
+worst = {}
+for rank in ranks:
+    r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    rp, ci = D.synth_csr(name, scale, r0, r1, lengths=lengths[r0:r1])
+    val = np.repeat(0.5 / np.maximum(np.diff(rp), 1), np.diff(rp))
+    mg = MgPlan(rp, ci, val, rows, cols, bounds, rank).upload()
+    del ci, val
+    mg.set_x(np.ones(cols))
+    line = "rank %d rows %d nnz own %d other %d fused_ok %d |" % (rank, r1 - r0, mg.nnz_local, mg.nnz_remote, mg.info["fused_step"])
+    can_fuse = mg.info["fused_step"] == 1
+    for fused in ([] if os.environ.get("PROBE_KERNEL_ONLY") == "1" else [True, False] if can_fuse else [False]):
+        mg.set_fused(fused)
+        for us in AG:
+            mg.set_fake_exchange(us)
+            mg.set_x(np.ones(cols))
+            t = step_time(mg)
+            key = ("fused" if fused else "2launch", us)
+            worst[key] = max(worst.get(key, 0.0), t)
+            line += " %s/%dus %.1f (host %.1f)" % (key[0], us, t, HOST["us"])
+    if can_fuse:      # the step kernel alone, back to back (no exchange, no in-kernel wait)
+        mg.set_fused(True); mg.set_x(np.ones(cols))
+        for _ in range(10): mg.product(s)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); h0 = time.perf_counter()
+        for _ in range(100): mg.product(s)
+        h1 = time.perf_counter(); e1.record(); torch.cuda.synchronize()
+        line += " | step kernel alone %.1f (host enqueue %.1f)" % (e0.elapsed_time(e1) / 100 * 1e3, (h1 - h0) * 1e4)
+    own = mg.subplan(0); oth = mg.subplan(1)
+    x = torch.ones(own.x_len, dtype=torch.float64, device="cuda"); y = torch.zeros(mg.stride, dtype=torch.float64, device="cuda")
+    t_own = own.time(x.data_ptr(), y.data_ptr(), s, warmup=5, iters=100)[1] * 1e3
+    t_own2 = own.time(mg.y_local_ptr, y.data_ptr(), s, warmup=5, iters=100)[1] * 1e3
+    t_own3 = own.time(mg.y_local_ptr, mg.gathered_ptr, s, warmup=5, iters=100)[1] * 1e3
+    line += " | own alone with x=ys %.1f, and y=yg %.1f" % (t_own2, t_own3)
+    t_oth = 0.0
+    if oth is not None:
+        xo = torch.ones(oth.x_len, dtype=torch.float64, device="cuda")
+        t_oth = oth.time(xo.data_ptr(), y.data_ptr(), s, warmup=5, iters=100)[1] * 1e3
+        del xo
+    st = own.stats
+    print(line + " | own alone %.1f other alone %.1f us | own data_X %.1f MB blocks %d" % (t_own, t_oth, st["data_X"] / 1e6, st["n_med_blocks"]), flush=True)
+    mg.close(); del x, y
+    torch.cuda.empty_cache()
+if os.environ.get("PROBE_FULL", "1") == "1":
+    rp, ci = D.synth_csr(name, scale, 0, rows, lengths=lengths)
+    plan = D.Plan(rp, ci, np.ones(ci.size), cols).upload(); plan.drop_host()
+    del ci
+    x = torch.ones(cols, dtype=torch.float64, device="cuda"); y = torch.zeros(rows, dtype=torch.float64, device="cuda")
+    t1 = plan.time(x.data_ptr(), y.data_ptr(), s, warmup=10, iters=200)[1] * 1e3
+    print("1-GPU step %.1f us" % t1)
+    for k in sorted(worst):
+        print("max over ranks %-8s exchange %3d us: %.1f us  -> %.2fx" % (k[0], k[1], worst[k], t1 / worst[k]), flush=True)
