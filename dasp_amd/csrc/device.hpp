@@ -32,6 +32,8 @@ struct DevArgs {
     const int *med_dst; const int *win_cmin; const int *win_len;
     int n_windows, blocks_per_win;
     int win_hybrid;   // windows stage their densest span only: a gather outside [cmin, cmin + len) reads global memory
+    int win_xcd;      // windows dealt to the XCDs in contiguous eighths (kernel)
+    int win_rel16;    // 16-bit ids of an LDS-staged window are offsets from the window's first staged column (Plan::win_rel16)
     int acc;   // 1: y += A x (every y index has exactly one writer per launch, so a plain read-modify-write is exact)
     int wpw;   // waves per workgroup of this launch (4, or blocks_per_win in windowed mode)
     // short
@@ -56,6 +58,7 @@ struct DevicePlan {
     ArenaMap map{};
     DevArgs args{};
     bool nt = false;
+    bool win1 = false;      // windowed plan with at most one window workgroup per CU: launch dasp_spmv_win1_kernel
     int device = -1;
     // column-panel parent: arena = the panels' partial results, panel k at ypart + k * ypart_stride elements
     size_t ypart_stride = 0;

@@ -134,7 +134,8 @@ __global__ void k_pack_long(const int *rp, const int *ci, const T *val, const in
 template <class T, bool C16>
 __global__ void k_pack_medium(const int *rp, const int *ci, const T *val, const int *ridM, const int *lenM, const int *med_ptr,
                               const int *irr_ptr, int nmed, int nb, RemapDev remap, T *mv, int *mc, unsigned short *mc16, int *mbase,
-                              T *iv, int *ic, int pair_mode, const int *c8ptr, unsigned char *mc8, int *korig)
+                              T *iv, int *ic, int pair_mode, const int *c8ptr, unsigned char *mc8, int *korig,
+                              const int *win_cmin, const int *win_len, int bpw /* blocks per window; 0: per-chunk bases (Plan::win_rel16 off) */)
 {
     constexpr int K = sizeof(T) == 8 ? 4 : 16, CH = kMedRows * K, VPL = CH / 64;
     const int lane = threadIdx.x & 63, b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -164,6 +165,7 @@ __global__ void k_pack_medium(const int *rp, const int *ci, const T *val, const 
             lo = wave_min(lo); hi = wave_max(hi);
             const bool narrow = c < npair && c < 64 && a8 < n8 && hi >= 0 && hi - lo <= 254;       // wave-uniform
             if (lo == 2147483647) lo = 0;
+            if (bpw > 0 && win_len[b / bpw] > 0) lo = win_cmin[b / bpw];          // window-relative offsets (plan.cpp packs the same)
             const int pos = c >= npair ? c : narrow ? a8++ : n8 + a16++;
             if (lane == 0) { mbase[c0 + pos] = lo; korig[c0 + pos] = c; }
             const size_t at = (size_t)c0 * CH + med_elem_index(npair, pos, lane, 0, VPL, CH);     // pipelined blocks: pairs of chunks interleaved per lane (plan.hpp)
@@ -361,10 +363,11 @@ static int pack_all_typed(Plan &p, const DevCsr &d, const PackMeta &m)
         if (p.cid16) if (int rc = dko.init(std::max<size_t>(1, p.med_korig.size()))) return rc;
         if (p.cid16)
             hipLaunchKernelGGL((k_pack_medium<T, true>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, val, dr.d, dl.d, dp.args.med_ptr,
-                               dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic, p.pair_mode, dp.args.med_c8ptr, mc8, dko.d);
+                               dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic, p.pair_mode, dp.args.med_c8ptr, mc8, dko.d,
+                               dp.args.win_cmin, dp.args.win_len, p.win_rel16 ? p.row_window / kMedRows : 0);
         else
             hipLaunchKernelGGL((k_pack_medium<T, false>), dim3(waves_grid(nb)), dim3(256), 0, 0, d.rp, d.ci, val, dr.d, dl.d, dp.args.med_ptr,
-                               dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic, p.pair_mode, nullptr, nullptr, nullptr);
+                               dp.args.irr_ptr, nmed, nb, rm.r, mv, mc, mc16, mb, iv, ic, p.pair_mode, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
         HIP_TRYP(hipGetLastError());
         HIP_TRYP(hipDeviceSynchronize());
         if (p.cid16 && !p.med_korig.empty()) HIP_TRYP(hipMemcpy(p.med_korig.data(), dko.d, p.med_korig.size() * sizeof(int), hipMemcpyDeviceToHost));

@@ -230,7 +230,7 @@ struct ChunkSrc {
 // arena pads them) and are zeroed in gather(), so neither stage has a divergent branch.
 // C8: the plan has one-byte ids (f64, 16-bit-id plans with narrow chunks): its own kernel instantiation, so that every other plan runs
 // exactly the code it ran before
-template <class T, bool NT, bool C16, bool PAIRS, bool C8, bool KT = false>
+template <class T, bool NT, bool C16, bool PAIRS, bool C8, bool KT = false, bool REL = false>
 struct BlockSrc {
     static constexpr bool kPairs = PAIRS;          // false: the windowed kernel, whose plans keep every chunk lane-linear
     static constexpr int VPL = Tr<T>::CHUNK / kWave;           // values of one chunk per lane: 1 (f64) / 4 (f16)
@@ -241,6 +241,7 @@ struct BlockSrc {
     // pipeline batch is either all pairs or all lane-linear chunks / tail steps.
     int npair;                                                  // chunks [0, npair) are paired
     const unsigned short *cid16; const int *base; int c0;      // C16: ids of the regular chunks as u16 offsets from base[chunk] ...
+    int relb;                                                   // REL (LDS-staged window, Plan::win_rel16): every chunk's base is the window's first staged column
     // ... except the block's first n8 positions (f64: whole batches of a pipelined block's paired region): one-byte offsets, c8 = their
     // plane at the block's first element.  w16 = the u16 plane rebased so that position i's ids sit where the block's own position i
     // would be: w16 = cid16 + e16 - (e0 + n8 * CH), i.e. `w16 + at_of(i)` for i >= n8
@@ -357,7 +358,7 @@ struct BlockSrc {
                 }
             }
         } else if constexpr (C16) {
-            const int b = tab<KT>(base, c0 + i);                // wave-uniform: one scalar load per chunk
+            const int b = REL ? relb : tab<KT>(base, c0 + i);   // wave-uniform: one scalar load per chunk -- or none
             if constexpr (sizeof(T) == 8) {
                 unsigned o = (unsigned)f.c, pad = 0xFFFFu;
                 if constexpr (QUAD && kQuadIds) {                // this chunk's field of the raw dword: wave-uniform shift / mask
@@ -523,7 +524,7 @@ __device__ __forceinline__ bool diag_of(const f32x4 &acc, int lane, float &d)
 // ---- medium: one wave = one block of 16 sorted rows (reference: dasp_f64.h:145-279)
 // YM: where the 16 results go -- 0: the block's own slots (reference permutation), or order[slot] when the plan is
 // DASP_Y_NATURAL (a.order set); 2: med_dst[position] (windowed mode)
-template <class T, bool NT, bool C16, int YM, bool C8 = false, int YS = 0, class XV>
+template <class T, bool NT, bool C16, int YM, bool C8 = false, int YS = 0, bool REL = false, class XV>
 __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, const XV &x)
 {
     using acc_t = typename Tr<T>::acc_t;
@@ -538,7 +539,8 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     if (r < a.row_block) { t0 = a.irr_ptr[r]; t1 = a.irr_ptr[r + 1]; }
     constexpr int TK = sizeof(T) == 8 ? 4 : 16;                      // tail entries of one row per MFMA step
     const int nt = (__builtin_amdgcn_readfirstlane(t1 - t0) + TK - 1) / TK;
-    BlockSrc<T, NT, C16, YM != 2, C8, YS != 0> src;
+    BlockSrc<T, NT, C16, YM != 2, C8, YS != 0, REL> src;
+    if constexpr (REL) src.relb = x.cmin; else src.relb = 0;
     src.reg.val = val; src.reg.cid = a.med_cid; src.reg.e0 = (size_t)c0 * CH; src.reg.lane = lane;
     src.nc = c1 - c0; src.npair = med_npair(c1 - c0, nt, (int)sizeof(T), YM == 2 ? 0 : a.pair_mode); src.cid16 = a.med_cid16; src.base = a.med_base; src.c0 = c0;
     src.c8 = a.med_cid8; src.w16 = a.med_cid16; src.n8 = 0;
@@ -714,10 +716,9 @@ constexpr int kMinWavesPlain = 1, kMinWavesWin = 8;
 // WIN: windowed mode.  A medium workgroup owns one window of row_window rows (blocks_per_win blocks, strided over its
 // 4 waves); if the window's x span fits, it is copied once into LDS with coalesced 16-byte loads and every gather of
 // the window reads LDS; otherwise that workgroup gathers from global memory like the non-windowed kernel.
-template <class T, bool NT, bool C16, bool WIN, bool C8 = false>
-__global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPlain) void dasp_spmv_kernel(DevArgs a)
+template <class T, bool NT, bool C16, bool WIN, bool C8>
+__device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw)
 {
-    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wg = blockIdx.x;
@@ -734,8 +735,13 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPla
             for (int b = m * kWavesPerWG + wave; b < a.n_blocks; b += a.wg_med * kWavesPerWG)
                 medium_block<T, NT, C16, 0, C8>(a, b, lane, x);
         } else {
-            // one window per workgroup; its blocks_per_win blocks are dealt round-robin to the wpw waves
-            const int w = wg - a.wg_long;
+            // one window per workgroup; its blocks_per_win blocks are dealt round-robin to the wpw waves.  Workgroups are dealt to the 8
+            // XCDs round-robin, so workgroup m of the range takes window (m % 8) * per_xcd + m / 8: every XCD works on ONE contiguous
+            // eighth of the windows -- the same eighth in every launch, whose tiles and x (an eighth of x plus the band) can stay in
+            // that XCD's 4 MiB L2 from one SpMV to the next when the matrix is small enough (cop20k_A: 3.5 MB per XCD)
+            const int mw = wg - a.wg_long, per_xcd = a.wg_med >> 3;
+            const int w = a.win_xcd ? (mw & 7) * per_xcd + (mw >> 3) : mw;
+            if (w >= a.n_windows) return;
             const int len = a.win_len[w], cmin = a.win_cmin[w];
             const T *xg = static_cast<const T *>(a.x);
             T *xw = reinterpret_cast<T *>(lds_raw);
@@ -761,6 +767,12 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPla
                         const int b = w * a.blocks_per_win + q;
                         if (b < a.n_blocks) medium_block<T, NT, C16, 2>(a, b, lane, x);
                     }
+                } else if (C16 && a.win_rel16) {
+                    const XLds<T> x{xw, cmin};
+                    for (int q = wave; q < a.blocks_per_win; q += wpw) {
+                        const int b = w * a.blocks_per_win + q;
+                        if (b < a.n_blocks) medium_block<T, NT, C16, 2, false, 0, C16>(a, b, lane, x);
+                    }
                 } else {
                     const XLds<T> x{xw, cmin};
                     for (int q = wave; q < a.blocks_per_win; q += wpw) {
@@ -780,6 +792,25 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPla
         const int t = (wg - a.wg_long - a.wg_med) * wpw + wave;
         if (t < a.n_short_tiles) short_tile<T, NT>(a, t, lane);
     }
+}
+
+template <class T, bool NT, bool C16, bool WIN, bool C8 = false>
+__global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPlain) void dasp_spmv_kernel(DevArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    spmv_body<T, NT, C16, WIN, C8>(a, lds_raw);
+}
+
+// the windowed kernel for plans with at most one window workgroup per CU (n_windows <= CUs: cop20k_A's 212): nothing is gained by
+// holding it to 64 registers for a second resident workgroup that does not exist, and at 128 it needs no scratch.
+// (r3, measured and NOT kept: a wave requesting the row tables, tiles and tails of both its blocks BEFORE the x copy and the barrier,
+// so that only LDS gathers and MFMAs are left behind it -- cop20k_A 10.4 -> 10.9 us.  What bounds such a workgroup is not its chain
+// of latencies but its CU's memory-level parallelism: ~200 KB per CU through 64 outstanding L1 misses of ~740 cycles)
+template <class T, bool C16>
+__global__ __launch_bounds__(1024, 4) void dasp_spmv_win1_kernel(DevArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    spmv_body<T, false, C16, true, false>(a, lds_raw);
 }
 
 // ------------------------------------------------------------------ the fused multi-GPU step (dasp_mg_spmv, f64)
@@ -1114,8 +1145,18 @@ int upload_plan(Plan &p)
     a.med_cid8 = (const unsigned char *)(base + o_mc8); a.med_c8ptr = (const int *)(base + o_c8p);
     a.med_dst = (const int *)(base + o_mdst); a.win_cmin = (const int *)(base + o_wc); a.win_len = (const int *)(base + o_wl);
     a.n_windows = (int)p.win_len.size(); a.blocks_per_win = p.windowed ? p.row_window / kMedRows : 0;
-    a.win_hybrid = p.win_hybrid ? 1 : 0; a.pair_mode = p.pair_mode;
-    a.wg_med = p.windowed ? a.n_windows : (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG;
+    a.win_hybrid = p.win_hybrid ? 1 : 0; a.win_rel16 = p.win_rel16 ? 1 : 0; a.pair_mode = p.pair_mode;
+    a.win_xcd = 1;
+    if (const char *e = std::getenv("DASP_WIN_XCD")) a.win_xcd = std::atoi(e);      // A/B knob
+    d->win1 = false;
+    if (p.windowed) {
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        d->win1 = a.n_windows <= cus;
+        if (const char *e = std::getenv("DASP_WIN1")) d->win1 = d->win1 && std::atoi(e) != 0;
+    }
+    a.wg_med = p.windowed ? (a.n_windows + 7) / 8 * 8 : (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG;      // windows: a whole number per XCD (kernel)
     // f16 blocks of uniform length: a persistent set of 7 workgroups per CU striding over the blocks amortises the per-wave
     // set-up that weighs twice as much at 2 bytes per value (nlpkkt160 f16 0.675 -> 0.739 of the roofline, Queen_4147 f16
     // 0.873 -> 0.927).  Static striding needs equal blocks: with HV15R's 2 % of 3x longer rows it loses 10 %, and in f64 it
@@ -1155,6 +1196,10 @@ int upload_plan(Plan &p)
 #undef DASP_ATTR
         HIP_TRY(e1);
         HIP_TRY(e2);
+        if (p.precision == 64) HIP_TRY(c16 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_win1_kernel<double, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+                                           : hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_win1_kernel<double, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        else HIP_TRY(c16 ? hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_win1_kernel<_Float16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
+                         : hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_win1_kernel<_Float16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     }
     return DASP_OK;
 }
@@ -1173,7 +1218,10 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
         else if (c16 && p.windowed) { M(false, true, true); } else if (c16) { M(false, true, false); } \
         else if (p.windowed) { M(false, false, true); } else { M(false, false, false); }
 #define DASP_LAUNCH(NTV, CV, WINV) hipLaunchKernelGGL((dasp_spmv_kernel<T, NTV, CV, WINV>), dim3(grid), dim3(kWave * a.wpw), lds, s, a)
-        if (sizeof(T) == 8 && c16 && !p.windowed && p.cnt_reg8 > 0) {      // plans with one-byte ids: their own instantiation
+        if (p.windowed && p.dev->win1 && !nt) {                             // at most one window workgroup per CU: the 128-register build
+            if (c16) hipLaunchKernelGGL((dasp_spmv_win1_kernel<T, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, a);
+            else hipLaunchKernelGGL((dasp_spmv_win1_kernel<T, false>), dim3(grid), dim3(kWave * a.wpw), lds, s, a);
+        } else if (sizeof(T) == 8 && c16 && !p.windowed && p.cnt_reg8 > 0) {      // plans with one-byte ids: their own instantiation
             if (nt) hipLaunchKernelGGL((dasp_spmv_kernel<double, true, true, false, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, a);
             else hipLaunchKernelGGL((dasp_spmv_kernel<double, false, true, false, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, a);
         } else

@@ -239,7 +239,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     // medium rows globally by length, which scatters the 16 rows of a block over the matrix; here rows are sorted inside
     // windows of `row_window` consecutive medium rows only, one window per workgroup, so a workgroup's rows share a narrow
     // span of x that is staged once in LDS.  Output slots stay the reference's (order_rid untouched): y goes through med_dst.
-    p.windowed = false; p.win_hybrid = false; p.row_window = 0; p.lds_bytes = 0;
+    p.windowed = false; p.win_hybrid = false; p.win_rel16 = false; p.row_window = 0; p.lds_bytes = 0;
     p.med_dst.clear(); p.win_cmin.clear(); p.win_len.clear();
     double window_frac = 0.0;
     if ((p.opt.x_window >= 0 || p.opt.x_window == -2) && nmed > 0 && !meta_only) {
@@ -551,8 +551,14 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         // (nlpkkt160 x0.03 16.7 -> 15.5 us, Queen x0.05 31.2 -> 27.7, x0.08 56.8 -> 42.5: the packed matrix then fits the
         // Infinity Cache); windowed plans keep the old bound.
         const bool streams = (long long)nnz * (geo.vbytes + 4) > (p.windowed ? kStreamBytes : (64ll << 20));
-        p.cid16 = try16 && e32 > 0 && (p.opt.cid16 > 0 || (streams && (double)e16 >= 0.97 * (double)e32));
+        // r3: plans of at most 256 LDS windows (one window workgroup per CU: the 128-register kernel) whose ids can be window-relative
+        // (no per-chunk base load at all): cop20k_A 10.7 -> 10.4 us, 10.2 with the windows dealt to the XCDs in contiguous eighths
+        const bool rel1 = p.windowed && !p.win_hybrid && p.opt.x_window != -2 && p.win_len.size() <= 256 && p.lds_bytes / geo.vbytes <= 65534;
+        p.cid16 = try16 && e32 > 0 && (p.opt.cid16 > 0 || ((streams || rel1) && (double)e16 >= 0.97 * (double)e32));
         if (p.cid16) nchunks.swap(nchunks16);
+        // LDS-staged windows: offsets from the window's first staged column (every staged span is far below 65535 elements in f64;
+        // f16 spans beyond that -- the 160 KiB cap -- keep the per-chunk bases)
+        p.win_rel16 = p.cid16 && p.windowed && !p.win_hybrid && p.lds_bytes / geo.vbytes <= 65534;
     }
     for (int b = 0; b < nb; ++b) {
         const int r0 = b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
@@ -627,6 +633,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                         }
                         const bool narrow = c < npair && c < 64 && a8 < n8 && hi >= 0 && hi - lo <= 254;
                         lo_of[c] = lo == 2147483647 ? 0 : lo;
+                        if (p.win_rel16) { const size_t w = (size_t)b / (size_t)(p.row_window / kMedRows); if (p.win_len[w] > 0) lo_of[c] = p.win_cmin[w]; }
                         pos_of[c] = c >= npair ? c : narrow ? a8++ : n8 + a16++;
                     }
                     for (int c = 0; c < nc; ++c) {

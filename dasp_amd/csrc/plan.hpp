@@ -164,6 +164,9 @@ struct Plan {
     bool windowed = false;
     int pair_mode = 0;              // which medium blocks store their chunks in pairs (med_npair): decided before packing
     bool win_hybrid = false;        // windows stage their densest span only: gathers outside it read global memory
+    // 16-bit ids of an LDS-staged window are offsets from the WINDOW's first staged column (med_base[chunk] = win_cmin[window] for all its
+    // chunks), i.e. they index the staged span directly: the kernel needs neither the per-chunk base load nor the subtraction
+    bool win_rel16 = false;
     int row_window = 0, lds_bytes = 0;
     std::vector<int> med_dst, win_cmin, win_len;
 

@@ -2,7 +2,7 @@
 // A plan file holds every host array of a Plan, so a later run (or every rank of a multi-GPU job)
 // skips classification and packing: load -> upload -> spmv.
 // layout: "DASPPLN5" | int32 sizeof(dasp_stats_t), kNumShortGroups, sizeof(ShortGroup) | plan, where plan = int32 precision, m, n, nnz,
-//         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows, win_hybrid, med_slot0, pair_mode, 0 | dasp_stats_t |
+//         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows, win_hybrid, med_slot0, pair_mode, win_rel16 | dasp_stats_t |
 //         ShortGroup[kNumShortGroups] | for each array, in a fixed order: int64 byte count + bytes | the n_panels column panels, each
 //         a nested plan.
 // A file is not trusted more than a caller's CSR: after reading, every count, pointer array and column id the kernels index
@@ -195,6 +195,17 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
     }
     if ((size_t)off != p.cnt_short || p.stats.n_short_tiles != tile0) return fail("short segment size");
     if (p.win_hybrid && !p.windowed) return fail("win_hybrid without windows");
+    if (p.win_rel16) {       // the kernel then takes win_cmin as EVERY chunk's base in an LDS-staged window, without reading med_base
+        if (!p.windowed || !p.cid16 || p.win_hybrid) return fail("win_rel16 needs LDS windows with 16-bit ids");
+        const long long bpw = p.row_window / kMedRows;
+        for (long long b = 0; b < nb; ++b) {
+            const size_t w = (size_t)(b / bpw);
+            if (p.win_len[w] <= 0) continue;
+            if (p.win_len[w] > 65534) return fail("win_rel16: staged span beyond 16-bit offsets");
+            for (long long c = p.med_ptr[(size_t)b]; c < p.med_ptr[(size_t)b + 1]; ++c)
+                if (p.med_base[(size_t)c] != p.win_cmin[w]) return fail("win_rel16: a chunk base differs from its window's first staged column");
+        }
+    }
     // ---- one writer per y index: put_y is a plain store (or, in accumulate mode, a plain read-modify-write), so two units with the
     // same destination would race / add twice.  Destinations exactly as the kernels form them (upload_plan: order / dst_map).
     {
@@ -221,7 +232,7 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
 static void write_plan(Writer &w, Plan &p)
 {
     const int hdr[18] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
-                         p.opt.n_parts, p.opt.part_stride, p.opt.stream_policy, (int)p.panels.size(), p.n_mfma_rows, p.win_hybrid ? 1 : 0, p.med_slot0, p.pair_mode, 0};
+                         p.opt.n_parts, p.opt.part_stride, p.opt.stream_policy, (int)p.panels.size(), p.n_mfma_rows, p.win_hybrid ? 1 : 0, p.med_slot0, p.pair_mode, p.win_rel16 ? 1 : 0};
     w.raw(hdr, sizeof hdr); w.raw(&p.stats, sizeof p.stats); w.raw(p.grp, sizeof p.grp);
     arrays(w, p);
     for (auto &h : p.panels) write_plan(w, h->impl);
@@ -236,7 +247,7 @@ static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
     p.m = hdr[1]; p.n = hdr[2]; p.nnz = hdr[3];
     dasp_options_default(&p.opt);
     p.opt.y_order = hdr[4]; p.windowed = hdr[5] != 0; p.row_window = hdr[6]; p.lds_bytes = hdr[7]; p.cid16 = hdr[8] != 0;
-    p.opt.n_parts = hdr[9]; p.opt.part_stride = hdr[10]; p.opt.stream_policy = hdr[11]; p.n_mfma_rows = hdr[13]; p.win_hybrid = hdr[14] != 0; p.med_slot0 = hdr[15]; p.pair_mode = hdr[16];
+    p.opt.n_parts = hdr[9]; p.opt.part_stride = hdr[10]; p.opt.stream_policy = hdr[11]; p.n_mfma_rows = hdr[13]; p.win_hybrid = hdr[14] != 0; p.med_slot0 = hdr[15]; p.pair_mode = hdr[16]; p.win_rel16 = hdr[17] != 0;
     if (p.pair_mode < 0 || p.pair_mode > 2 || (p.windowed && p.pair_mode)) return false;
     r.raw(&p.stats, sizeof p.stats); r.raw(p.grp, sizeof p.grp);
     arrays(r, p);

@@ -26,7 +26,7 @@ out=sys.argv[1]
 agg=collections.defaultdict(list); dur=[]
 for f in glob.glob(out+"/g*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "dasp_spmv_kernel" in r["Kernel_Name"]:
+        if "dasp_spmv" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))
 print("dispatch duration under PMC: median %.1f us over %d" % (sorted(dur)[len(dur)//2]/1e3, len(dur)))
