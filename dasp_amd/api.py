@@ -236,6 +236,12 @@ class Plan:
         _lib.check(_lib.lib().dasp_plan_time(self._h, C.c_void_p(dX), C.c_void_p(dY), C.c_void_p(stream), warmup, iters, C.byref(w), C.byref(e)))
         return w.value, e.value
 
+    def time_each(self, dX, dY, stream=0, warmup=20, iters=200):
+        """ms of every one of `iters` back-to-back launches (an event between each two): numpy float32[iters]"""
+        out = np.zeros(iters, np.float32)
+        _lib.check(_lib.lib().dasp_plan_time_each(self._h, C.c_void_p(dX), C.c_void_p(dY), C.c_void_p(stream), warmup, iters, _vp(out)))
+        return out
+
     def time_graph(self, dX, dY, stream=0, warmup=100, iters=1000, batch=100):
         """Same protocol, `batch` SpMVs captured into one hipGraph and replayed: (wall_ms, event_ms) per SpMV."""
         w, e = C.c_double(), C.c_double()

@@ -18,6 +18,7 @@ namespace dasp {
 const char *last_error_cstr();
 int upload_plan(Plan &p);
 int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate);
+int time_spmv_each(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, float *ms_each);
 int time_spmv(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, double *wall_ms, double *event_ms);
 int time_spmv_graph(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, int batch, double *wall_ms, double *event_ms);
 int selftest_mfma();
@@ -321,6 +322,12 @@ int dasp_plan_time_graph(dasp_plan_t *plan, const void *dX, void *dY, void *stre
 {
     if (!plan || iters <= 0 || warmup < 0 || batch <= 0) return DASP_ERR_ARG;
     return guarded("dasp_plan_time_graph", [&] { return time_spmv_graph(plan->impl, dX, dY, stream, warmup, iters, batch, wall_ms, event_ms); });
+}
+
+int dasp_plan_time_each(dasp_plan_t *plan, const void *dX, void *dY, void *stream, int warmup, int iters, float *ms_each)
+{
+    if (!plan || iters <= 0 || warmup < 0 || !ms_each) return DASP_ERR_ARG;
+    return guarded("dasp_plan_time_each", [&] { return time_spmv_each(plan->impl, dX, dY, stream, warmup, iters, ms_each); });
 }
 
 int dasp_selftest_mfma(void) { return selftest_mfma(); }

@@ -9,6 +9,11 @@
 //   nlpkkt160     8345600 = 2 dof x 160x160x163 grid, symmetric, <= 28 per row (19-pt + 9-pt coupling)
 //   Queen_4147    4147110 rows, 3 dof x 27-point stencil (<= 81 per row), symmetric
 //   HV15R         2017169 rows, 5 dof x 27-point stencil (135) with 2% / 0.2% extended rows (375 / 484)
+//   HV15R-unstructured  the same dimensions and row lengths, but what an UNSTRUCTURED mesh leaves after a bandwidth-reducing
+//                 ordering: every node couples with itself and 26 / 74 / 95 nodes scattered over a band of +-6000 nodes (one draw per
+//                 stratum of the band, so a row is 27 / 75 / 96 runs of 5 adjacent columns at scattered positions) -- no grid
+//                 numbering, no plane structure, neighbouring rows share few columns.  Shows how much of the HV15R stand-in's
+//                 roofline fraction is owed to its structured-grid numbering.
 //   webbase-1M    1000005 rows, power-law lengths (mean ~3.1, max 4700); HOST-BLOCK columns: the pages of a host are contiguous
 //                 (a crawl in URL order), host sizes are power-law distributed, 85 % of a page's links stay inside its host
 //                 (half of them within +-32 pages, half skewed to the host's first pages), 3 % go to a neighbouring host, 12 %
@@ -44,7 +49,7 @@ inline uint64_t h2(uint64_t seed, uint64_t a, uint64_t b) { return mix(mix(seed 
 inline double u01(uint64_t h) { return ((h >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
 
 struct Synth {
-    enum Kind { GRID, BAND, POWER, RMAT, BLOCKS } kind;
+    enum Kind { GRID, BAND, POWER, RMAT, BLOCKS, UNSTR } kind;
     int rows = 0, cols = 0;
     uint64_t seed = 0;
     // GRID
@@ -78,6 +83,12 @@ bool make(const char *name, double scale, Synth &g)
     };
     if (n == "Queen_4147") { grid(113, 111, 111, 3, 4147110, 0, 20007); g.desc = "3 dof x 27-point stencil on a 113x111x111 grid"; return true; }
     if (n == "HV15R") { grid(74, 74, 74, 5, 2017169, 2, 20006); g.desc = "5 dof x 27-point stencil on a 74^3 grid, 2% / 0.2% extended rows (375 / 484)"; return true; }
+    if (n == "HV15R-unstructured") {
+        grid(74, 74, 74, 5, 2017169, 2, 20016);
+        g.kind = Synth::UNSTR; g.band = 6000;
+        g.desc = "5 dof per node, 27 / 75 (2%) / 96 (0.2%) coupled nodes drawn one per stratum of a +-6000-node band (unstructured mesh after RCM): HV15R's size and row lengths without grid numbering";
+        return true;
+    }
     if (n == "nlpkkt160") { grid(160, 160, 163, 2, 8345600, 1, 20002); g.desc = "2 dof on a 160x160x163 grid, 19-point + 9-point coupling"; return true; }
     if (n == "cop20k_A") {
         g.kind = Synth::BAND; g.seed = 20001; g.rows = g.cols = scaled(121192, scale);
@@ -182,6 +193,31 @@ int grid_row(const Synth &g, int row, int *out)
                     ++len;
                 }
             }
+        }
+    }
+    return len;
+}
+
+// ---- UNSTR rows (HV15R-unstructured): node `row / dof` couples with `deg` nodes, one per stratum of its band window; the stratum
+// holding the node itself yields the node, so the diagonal block is always present and a row has no duplicates and comes out sorted
+int unstr_row(const Synth &g, int row, int *out)
+{
+    const int dof = g.dof;
+    const long long nodes = ((long long)g.cols + dof - 1) / dof, node = row / dof;
+    const int cls = hv_class(g, node);
+    const long long W = std::min<long long>(nodes, 2ll * g.band + 1);
+    const int deg = (int)std::min<long long>(W, cls == 2 ? 96 : cls == 1 ? 75 : 27);
+    const long long start = std::min(std::max(0ll, node - g.band), nodes - W);
+    int len = 0;
+    for (int k = 0; k < deg; ++k) {
+        const long long lo = start + W * k / deg, hi = start + W * (k + 1) / deg;       // stratum k: [lo, hi), never empty (W >= deg)
+        long long nb = lo + (long long)(h2(g.seed, (uint64_t)node, (uint64_t)k + 1000) % (uint64_t)(hi - lo));
+        if (node >= lo && node < hi) nb = node;
+        for (int db = 0; db < dof; ++db) {
+            const long long col = nb * dof + db;
+            if (col >= g.cols) continue;
+            if (out) out[len] = (int)col;
+            ++len;
         }
     }
     return len;
@@ -317,6 +353,7 @@ inline int any_row(const Synth &g, int row, int *out, const float *tg, int tg0)
     switch (g.kind) {
         case Synth::RMAT: return rmat_row(g, row, out);
         case Synth::GRID: return grid_row(g, row, out);
+        case Synth::UNSTR: return unstr_row(g, row, out);
         case Synth::BAND: return band_row(g, row, out, tg, tg0);
         case Synth::BLOCKS: return blocks_row(g, row, out);
         default: return power_row(g, row, out);

@@ -1409,6 +1409,28 @@ int time_spmv(Plan &p, const void *dX, void *dY, void *stream, int warmup, int i
     return DASP_OK;
 }
 
+int time_spmv_each(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, float *ms_each)
+{
+    if (iters <= 0 || !ms_each) { set_error("time_each: iters > 0 and an output array"); return DASP_ERR_ARG; }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int i = 0; i < warmup; ++i) if (int rc = launch_spmv(p, dX, dY, stream, false)) return rc;
+    HIP_TRY(hipStreamSynchronize(s));
+    struct Events {
+        std::vector<hipEvent_t> e;
+        ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    } ev;
+    ev.e.assign((size_t)iters + 1, nullptr);
+    for (hipEvent_t &x : ev.e) HIP_TRY(hipEventCreate(&x));
+    HIP_TRY(hipEventRecord(ev.e[0], s));
+    for (int i = 0; i < iters; ++i) {
+        if (int rc = launch_spmv(p, dX, dY, stream, false)) return rc;
+        HIP_TRY(hipEventRecord(ev.e[(size_t)i + 1], s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int i = 0; i < iters; ++i) HIP_TRY(hipEventElapsedTime(&ms_each[i], ev.e[(size_t)i], ev.e[(size_t)i + 1]));
+    return DASP_OK;
+}
+
 // same protocol with the launches captured once into a hipGraph of `batch` SpMVs and replayed: removes the
 // per-launch host cost (3-4 us) that bounds back-to-back launches of small matrices; the kernels are unchanged.
 int time_spmv_graph(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, int batch, double *wall_ms, double *event_ms)

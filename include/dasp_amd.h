@@ -252,6 +252,10 @@ int dasp_plan_spmv_acc(dasp_plan_t *plan, const void *dX, void *dY, void *stream
 int dasp_plan_time(dasp_plan_t *plan, const void *dX, void *dY, void *stream, int warmup, int iters,
                    double *wall_ms_per_iter, double *event_ms_per_iter);
 
+/* `iters` back-to-back SpMVs with a hipEvent between every two of them: ms_each[i] = event i -> event i + 1, i.e. launch i's duration
+ * plus the gap to its successor (a few us).  For the spread of a kernel's duration inside one process (min / median / max). */
+int dasp_plan_time_each(dasp_plan_t *plan, const void *dX, void *dY, void *stream, int warmup, int iters, float *ms_each);
+
 /* the same protocol with `batch` SpMVs captured once into a hipGraph and replayed ceil(iters/batch) times:
  * removes the per-launch host cost that bounds back-to-back launches on small matrices (kernels unchanged).
  * stream NULL = a private capture stream. */
@@ -372,8 +376,9 @@ int dasp_selftest_mfma(void);
  * network on the build/bench machines).  Rows [row_begin,row_end) of the named matrix are
  * generated as CSR (global column ids, file-like order inside a row); every row can be
  * generated independently, so ranks of a multi-GPU run build only their slice.
- *   names: "cop20k_A" "nlpkkt160" "powerlaw_1M" "webbase-1M" "ljournal-2008" "HV15R" "Queen_4147" "rmat_2M", and the
- *          round-1 worst-case variants "webbase-1M-uniform" "ljournal-2008-uniform" (dasp_synth_generator describes each)
+ *   names: "cop20k_A" "nlpkkt160" "powerlaw_1M" "webbase-1M" "ljournal-2008" "HV15R" "Queen_4147" "rmat_2M", the
+ *          round-1 worst-case variants "webbase-1M-uniform" "ljournal-2008-uniform", and "HV15R-unstructured" (HV15R's size and
+ *          row lengths without the structured-grid numbering) -- dasp_synth_generator describes each
  *   scale: 1.0 = the collection's size; <1 shrinks the row count (tests). */
 int dasp_synth_dims(const char *name, double scale, int *rows, int *cols);
 /* one-line description of the generator behind `name` (seed, structure class, locality parameters); NULL for an unknown

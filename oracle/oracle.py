@@ -177,6 +177,36 @@ def csr_spmv(row_ptr, col_idx, val, x):
     return y
 
 
+_NATIVE = None
+
+
+def native_csr_spmv():
+    """The serial CSR loop compiled ON THIS HOST with -O3 -march=native (BASELINE.md section 3 asks the CPU baseline for both):
+    returns (callable like csr_spmv, build description).  Falls back to the portable liboracle.so when no compiler is around."""
+    global _NATIVE
+    if _NATIVE is None:
+        import tempfile
+        so = os.path.join(tempfile.gettempdir(), "liboracle_native_%d.so" % os.getuid())
+        src = os.path.join(_HERE, "dasp_oracle.c")
+        what = "gcc -O3 -march=native, built on this host"
+        try:
+            subprocess.check_call([os.environ.get("CC", "gcc"), "-O3", "-march=native", "-fPIC", "-std=c11", "-w", "-shared", "-o", so, src, "-lm"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            L = C.CDLL(so)
+            L.oracle_csr_spmv_f64.argtypes = [C.c_int] + [C.c_void_p] * 5
+        except Exception:
+            L, what = lib(), "portable liboracle.so (-O3 -march=x86-64-v2): no compiler on this host"
+        _NATIVE = (L, what)
+    L, what = _NATIVE
+
+    def run(row_ptr, col_idx, val, x):
+        m = row_ptr.size - 1
+        y = np.empty(m, np.float64)
+        L.oracle_csr_spmv_f64(m, _p(row_ptr), _p(col_idx), _p(val), _p(x), _p(y))
+        return y
+    return run, what
+
+
 def csr_absrow(row_ptr, col_idx, val, x):
     m = row_ptr.size - 1
     row_ptr = np.ascontiguousarray(row_ptr, np.int32)

@@ -117,7 +117,8 @@ def test_parity_synthetic_standins(oracle, dasp, torch_cuda, name, prec, scale):
     check(oracle, dasp, torch_cuda, rp, ci, v, cols, prec)
 
 
-@pytest.mark.parametrize("name,prec", [("HV15R", 64), ("ljournal-2008", 16)])
+@pytest.mark.parametrize("name,prec", [("HV15R", 64), ("ljournal-2008", 16), ("Queen_4147", 64), ("nlpkkt160", 64), ("webbase-1M", 16),
+                                       ("HV15R-unstructured", 64)])
 def test_full_size_random_x_parity(oracle, dasp, torch_cuda, name, prec):
     """BASELINE's full sizes (scale 1.0): seeded random values and x, >= 100 k sampled rows (the 4096 longest + a uniform sample)
     against the oracle at the north_star tolerance -- bench.py's verified_random_x, the check the all-ones mode cannot make"""

@@ -193,3 +193,25 @@ def test_handworked_classifier_and_order(oracle, dasp, case, prec):
     for k, val in want_c.items():
         assert st[k] == val, (k, "product")
     plan.close()
+
+
+@pytest.mark.parametrize("seed,m,n", [(1, 3000, 2500), (2, 500, 4000), (3, 1, 7), (4, 4000, 4000)])
+def test_csr_product_against_scipy(oracle, seed, m, n):
+    """The y oracle is the builder's own serial loop (the reference has no CPU SpMV): pin it to an INDEPENDENT implementation --
+    scipy.sparse's CSR product -- on seeded matrices with every row category, duplicates and unsorted columns included.  The loop
+    adds a row's products in storage order (as the reference's tail loop does, dasp_f64.h:189-192) and scipy's kernel adds them in
+    the same order, so the results agree exactly wherever no duplicate was summed beforehand; we demand 1e-15 of sum |a x|."""
+    import scipy.sparse as sp
+    rp, ci, v = util.mixed_matrix(m, n, seed)
+    x = np.random.default_rng(seed + 100).uniform(-1, 1, n)
+    A = sp.csr_matrix((v, ci, rp), shape=(m, n))                          # keeps duplicates and the storage order
+    want = A @ x
+    absA = sp.csr_matrix((np.abs(v), ci, rp), shape=(m, n))
+    scale = absA @ np.abs(x)
+    got = oracle.csr_spmv(rp, ci, v, x)
+    got_abs = oracle.csr_absrow(rp, ci, v, x)
+    assert np.all(np.abs(got - want) <= 1e-15 * np.maximum(scale, 1e-300))
+    assert np.all(np.abs(got_abs - scale) <= 1e-15 * np.maximum(scale, 1e-300))
+    assert np.array_equal(got == 0, want == 0) or np.all(scale[(got == 0) != (want == 0)] > 0)     # empty rows are exact zeros in both
+    e = np.diff(rp) == 0
+    assert np.all(got[e] == 0) and np.all(got_abs[e] == 0)
