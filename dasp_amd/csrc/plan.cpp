@@ -4,12 +4,15 @@
 #include "plan.hpp"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <thread>
 
 namespace dasp {
@@ -26,6 +29,80 @@ int resolve_threads(int requested)
     return (int)std::min(hc, 32u);
 }
 
+// ---- a small persistent worker pool: spawning 32 threads costs ~1 ms, and building a plan from a device-resident CSR is ~20
+// O(rows) loops of a few hundred microseconds each (HV15R: 38 ms of which half was thread creation).  Jobs are ranges handed out
+// through one atomic counter; the caller works too.  A call from inside a worker (column panels are built side by side, each
+// with loops of its own) or while another job runs falls back to plain threads -- never a nested wait on the pool.
+namespace {
+class Pool {
+public:
+    static Pool &get() { static Pool p; return p; }
+    // run job(part) for part in [0, parts) on up to `parts` threads; false = pool busy / nested: the caller must do it itself
+    bool run(long long parts, const std::function<void(long long)> &job)
+    {
+        if (in_worker_ || parts <= 1) return false;
+        std::unique_lock<std::mutex> own(busy_, std::try_to_lock);
+        if (!own.owns_lock()) return false;
+        ensure((int)std::min<long long>(parts - 1, 31));
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &job; parts_ = parts; next_.store(0); left_ = parts; ++epoch_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return left_ == 0; });
+        job_ = nullptr;
+        return true;
+    }
+private:
+    Pool() = default;
+    ~Pool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    void ensure(int n)
+    {
+        while ((int)th_.size() < n) th_.emplace_back([this] { in_worker_ = true; loop(); });
+    }
+    void work()
+    {
+        for (;;) {
+            const long long i = next_.fetch_add(1);
+            if (i >= parts_) break;
+            (*job_)(i);
+            std::lock_guard<std::mutex> lk(m_);
+            if (--left_ == 0) done_.notify_all();
+        }
+    }
+    void loop()
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || (epoch_ != seen && job_ != nullptr); });
+                if (stop_) return;
+                seen = epoch_;
+            }
+            work();
+        }
+    }
+    std::mutex m_, busy_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> th_;
+    const std::function<void(long long)> *job_ = nullptr;
+    long long parts_ = 0, left_ = 0;
+    std::atomic<long long> next_{0};
+    unsigned long long epoch_ = 0;
+    bool stop_ = false;
+    static thread_local bool in_worker_;
+};
+thread_local bool Pool::in_worker_ = false;
+}  // namespace
+
 // f(begin, end) over [0, n) in contiguous ranges
 template <class F>
 static void parallel_for(long long n, int threads, long long grain, F f)
@@ -33,6 +110,8 @@ static void parallel_for(long long n, int threads, long long grain, F f)
     if (n <= 0) return;
     long long parts = std::min<long long>(threads, (n + grain - 1) / grain);
     if (parts <= 1) { f(0LL, n); return; }
+    const std::function<void(long long)> job = [&](long long t) { f(n * t / parts, n * (t + 1) / parts); };
+    if (Pool::get().run(parts, job)) return;
     std::vector<std::thread> th;
     th.reserve((size_t)parts);
     for (long long t = 0; t < parts; ++t) {
@@ -107,23 +186,37 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         if (P < 0) return P;
         if (P >= 2) return build_panels<T>(p, rp, ci, val, P);
     }
-    // ---- classifier: same tests in the same order as dasp_f64.h:499-531
+    // ---- classifier: same tests in the same order as dasp_f64.h:499-531.  Two passes over row ranges (count, then fill from the
+    // ranges' prefix sums): every list comes out in row order, exactly what the reference's serial loop produces.
     int n1 = 0, n2 = 0, n3 = 0, n4 = 0, nz0 = 0, nlong = 0, nmed = 0;
-    for (int i = 0; i < m; ++i) {
-        const int len = rp[i + 1] - rp[i];
-        if (len == 1) n1++; else if (len == 3) n3++; else if (len == 2) n2++;
-        else if (len == 0) nz0++; else if (len == 4) n4++;
-        else if (len >= block_longest) nlong++; else nmed++;
-    }
+    // category of a row: 0 = len 1, 1 = len 3, 2 = len 2, 3 = empty, 4 = len 4, 5 = long, 6 = medium
+    auto cat_of = [block_longest](int len) { return len == 1 ? 0 : len == 3 ? 1 : len == 2 ? 2 : len == 0 ? 3 : len == 4 ? 4 : len >= block_longest ? 5 : 6; };
+    const int cparts = (int)std::max<long long>(1, std::min<long long>(threads, ((long long)m + (1 << 16) - 1) >> 16));
+    std::vector<std::array<int, 7>> ccnt((size_t)cparts + 1);
+    for (auto &c : ccnt) c.fill(0);
+    parallel_for(cparts, cparts, 1, [&](long long t0, long long t1) {
+        for (long long t = t0; t < t1; ++t) {
+            std::array<int, 7> c{};
+            c.fill(0);
+            for (long long i = (long long)m * t / cparts, e = (long long)m * (t + 1) / cparts; i < e; ++i) c[(size_t)cat_of(rp[i + 1] - rp[i])]++;
+            ccnt[(size_t)t + 1] = c;
+        }
+    });
+    for (int t = 0; t < cparts; ++t) for (int k = 0; k < 7; ++k) ccnt[(size_t)t + 1][(size_t)k] += ccnt[(size_t)t][(size_t)k];     // -> first index of part t
+    n1 = ccnt[(size_t)cparts][0]; n3 = ccnt[(size_t)cparts][1]; n2 = ccnt[(size_t)cparts][2]; nz0 = ccnt[(size_t)cparts][3];
+    n4 = ccnt[(size_t)cparts][4]; nlong = ccnt[(size_t)cparts][5]; nmed = ccnt[(size_t)cparts][6];
     std::vector<int> rid1(n1), rid2(n2), rid3(n3), rid4(n4), rid0(nz0), ridL(nlong), ridM_in(nmed);
     {
-        int a = 0, b = 0, c = 0, d = 0, z = 0, e = 0, g = 0;
-        for (int i = 0; i < m; ++i) {
-            const int len = rp[i + 1] - rp[i];
-            if (len == 1) rid1[a++] = i; else if (len == 3) rid3[c++] = i; else if (len == 2) rid2[b++] = i;
-            else if (len == 0) rid0[z++] = i; else if (len == 4) rid4[d++] = i;
-            else if (len >= block_longest) ridL[e++] = i; else ridM_in[g++] = i;
-        }
+        int *const lists[7] = {rid1.data(), rid3.data(), rid2.data(), rid0.data(), rid4.data(), ridL.data(), ridM_in.data()};
+        parallel_for(cparts, cparts, 1, [&](long long t0, long long t1) {
+            for (long long t = t0; t < t1; ++t) {
+                std::array<int, 7> at = ccnt[(size_t)t];
+                for (long long i = (long long)m * t / cparts, e = (long long)m * (t + 1) / cparts; i < e; ++i) {
+                    const int k = cat_of(rp[i + 1] - rp[i]);
+                    lists[k][at[(size_t)k]++] = (int)i;
+                }
+            }
+        });
     }
     const int n1_all = n1, n3_all = n3;
     const int nnz_short = n1 + 3 * n3 + 2 * n2 + 4 * n4;
@@ -141,11 +234,29 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     // lengths are < block_longest, so one counting pass does it.
     std::vector<int> ridM(nmed), lenM(nmed);
     {
-        std::vector<int> bucket((size_t)std::max(block_longest, 6) + 1, 0);
-        for (int r : ridM_in) bucket[rp[r + 1] - rp[r]]++;
+        // parallel counting sort: per-part histograms, then every (length, part) pair gets its start -- lengths descending, parts in
+        // row order inside a length: stable
+        const int nbk = std::max(block_longest, 6) + 1;
+        const int sparts = (int)std::max<long long>(1, std::min<long long>(threads, ((long long)nmed + (1 << 16) - 1) >> 16));
+        std::vector<int> hist((size_t)sparts * (size_t)nbk, 0);
+        parallel_for(sparts, sparts, 1, [&](long long t0, long long t1) {
+            for (long long t = t0; t < t1; ++t) {
+                int *h = hist.data() + (size_t)t * (size_t)nbk;
+                for (long long i = (long long)nmed * t / sparts, e = (long long)nmed * (t + 1) / sparts; i < e; ++i) { const int r = ridM_in[(size_t)i]; h[rp[r + 1] - rp[r]]++; }
+            }
+        });
         int run = 0;
-        for (int L = block_longest; L >= 0; --L) { int c = bucket[L]; bucket[L] = run; run += c; }
-        for (int r : ridM_in) { int L = rp[r + 1] - rp[r]; int at = bucket[L]++; ridM[at] = r; lenM[at] = L; }
+        for (int L = nbk - 1; L >= 0; --L)
+            for (int t = 0; t < sparts; ++t) { int &c = hist[(size_t)t * (size_t)nbk + (size_t)L]; const int n = c; c = run; run += n; }
+        parallel_for(sparts, sparts, 1, [&](long long t0, long long t1) {
+            for (long long t = t0; t < t1; ++t) {
+                int *h = hist.data() + (size_t)t * (size_t)nbk;
+                for (long long i = (long long)nmed * t / sparts, e = (long long)nmed * (t + 1) / sparts; i < e; ++i) {
+                    const int r = ridM_in[(size_t)i], L = rp[r + 1] - rp[r], at = h[L]++;
+                    ridM[(size_t)at] = r; lenM[(size_t)at] = L;
+                }
+            }
+        });
     }
 
     lap("sort medium");
@@ -216,9 +327,12 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     for (int g = 5; g < kNumShortGroups; ++g) glist[g] = &slab_rows[g];
     p.order.assign((size_t)m, -1);
     for (int i = 0; i < nlong; ++i) p.order[i] = ridL[i];
-    for (int i = 0; i < nmed; ++i) p.order[nlong + i] = ridM[i];
-    for (int g = 0; g < kNumShortGroups; ++g)
-        for (int t = 0; t < p.grp[g].count; ++t) p.order[p.grp[g].map.slot(t)] = (*glist[g])[t];
+    parallel_for(nmed, threads, 1 << 16, [&](long long b, long long e) { for (long long i = b; i < e; ++i) p.order[(size_t)nlong + (size_t)i] = ridM[(size_t)i]; });
+    for (int g = 0; g < kNumShortGroups; ++g) {
+        const ShortGroup &G = p.grp[g];
+        const std::vector<int> &list = *glist[g];
+        parallel_for(G.count, threads, 1 << 16, [&](long long b, long long e) { for (long long t = b; t < e; ++t) p.order[(size_t)G.map.slot((int)t)] = list[(size_t)t]; });
+    }
     // from here on "medium" means the MFMA part only
     if (nmf < nmed_all) {
         ridM.resize((size_t)nmf); lenM.resize((size_t)nmf);
@@ -280,19 +394,52 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         std::vector<int> cmin(nW), wlen(nW);
         std::vector<long long> wnnz(nW);
         std::vector<int> wlo(nW), whi(nW);
-        if (dev) { if (int rc = devpack_window_spans(p, *dev, ridW, R, wlo.data(), whi.data(), wnnz.data())) return rc; }
-        else parallel_for(nW, threads, 8, [&](long long w0, long long w1) {
-            for (long long w = w0; w < w1; ++w) {
-                const int a0 = (int)w * R, a1 = std::min(nmed, a0 + R);
-                int lo = 2147483647, hi = -1; long long k = 0;
-                for (int i = a0; i < a1; ++i) {
-                    const int r = ridW[i];
-                    for (int j = rp[r]; j < rp[r + 1]; ++j) { const int c = remap(ci[j]); lo = std::min(lo, c); hi = std::max(hi, c); }
-                    k += rp[r + 1] - rp[r];
+        // span [lo, hi] and nonzeros of the windows over rows list[0 .. n): one window per R rows
+        auto spans_of = [&](const std::vector<int> &list, int n, int *lo_out, int *hi_out, long long *nnz_out) -> int {
+            if (dev) return devpack_window_spans(p, *dev, list, R, lo_out, hi_out, nnz_out);
+            parallel_for(ceil_div(n, R), threads, 8, [&](long long w0, long long w1) {
+                for (long long w = w0; w < w1; ++w) {
+                    const int a0 = (int)w * R, a1 = std::min(n, a0 + R);
+                    int lo = 2147483647, hi = -1; long long k = 0;
+                    for (int i = a0; i < a1; ++i) {
+                        const int r = list[(size_t)i];
+                        for (int j = rp[r]; j < rp[r + 1]; ++j) { const int c = remap(ci[j]); lo = std::min(lo, c); hi = std::max(hi, c); }
+                        k += rp[r + 1] - rp[r];
+                    }
+                    lo_out[w] = lo; hi_out[w] = hi; nnz_out[w] = k;
                 }
-                wlo[w] = lo; whi[w] = hi; wnnz[w] = k;
+            });
+            return DASP_OK;
+        };
+        // auto mode on a large matrix: look at 64 evenly spaced windows first.  If under a quarter of THEIR nonzeros sit in windows
+        // that would fit even the whole 160 KiB of LDS, no strict window rule can reach its 50 % -- skip reading every column id of the
+        // matrix for nothing (HV15R: 332 ms of the host path's 659, 6 of the device path's 38)
+        bool scan_all = true;
+        if (p.opt.x_window == 0 && nW > 256) {
+            const int ns = 64;
+            std::vector<int> sample; sample.reserve((size_t)ns * (size_t)R);
+            for (int q = 0; q < ns; ++q) {
+                const int w = (int)((long long)q * (nW - 1) / ns);                 // never the (possibly partial) last window
+                sample.insert(sample.end(), ridW.begin() + (size_t)w * R, ridW.begin() + (size_t)(w + 1) * R);
             }
-        });
+            std::vector<int> slo(ns), shi(ns);
+            std::vector<long long> snz(ns);
+            if (int rc = spans_of(sample, ns * R, slo.data(), shi.data(), snz.data())) return rc;
+            long long fit_s = 0, all_s = 0;
+            for (int q = 0; q < ns; ++q) {
+                all_s += snz[q];
+                if (shi[q] >= 0 && ((long long)shi[q] - (slo[q] / A) * A + 1) * geo.vbytes <= 160 * 1024) fit_s += snz[q];
+            }
+            scan_all = 4 * fit_s >= all_s;
+        }
+        if (scan_all) { if (int rc = spans_of(ridW, nmed, wlo.data(), whi.data(), wnnz.data())) return rc; }
+        else
+            for (int w = 0; w < nW; ++w) {                                          // "does not fit": what the full scan would have concluded
+                wlo[w] = 2147483647; whi[w] = -1;
+                long long k = 0;
+                for (int i = w * R, e = std::min(nmed, (w + 1) * R); i < e; ++i) k += lenW[(size_t)i];
+                wnnz[w] = k;
+            }
         long long fit = 0, all = 0; int maxlen = 0;
         auto fit_windows = [&]() {
             fit = 0; all = 0; maxlen = 0;
@@ -328,9 +475,18 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             const long long xl = p.opt.n_parts > 0 ? (long long)p.opt.n_parts * p.opt.part_stride : (long long)p.n;
             std::vector<int> hmin(nW), hlen(nW);
             std::vector<long long> hin(nW);
-            parallel_for(nW, threads, 4, [&](long long w0, long long w1) {
+            // auto mode on a large matrix: the densest spans of 64 evenly spaced windows first -- when they hold under 45 % of those
+            // windows' gathers the whole will not reach 60 %, and sorting every window's columns is skipped (HV15R: 0.33 s of the host
+            // path; its three-plane rows give 33 %)
+            std::vector<int> wlist;
+            if (p.opt.x_window_hybrid == 0 && nW > 256) for (int q = 0; q < 64; ++q) wlist.push_back((int)((long long)q * (nW - 1) / 64));
+            bool sampled = !wlist.empty();
+            for (int pass = sampled ? 0 : 1; pass < 2; ++pass) {
+            if (pass == 1) { wlist.resize((size_t)nW); for (int w = 0; w < nW; ++w) wlist[(size_t)w] = w; }
+            parallel_for((long long)wlist.size(), threads, 4, [&](long long w0, long long w1) {
                 std::vector<int> cols;
-                for (long long w = w0; w < w1; ++w) {
+                for (long long wi = w0; wi < w1; ++wi) {
+                    const int w = wlist[(size_t)wi];
                     const int a0 = (int)w * R, a1 = std::min(nmed, a0 + R);
                     cols.clear();
                     for (int i = a0; i < a1; ++i) { const int r = ridW[i]; for (int j = rp[r]; j < rp[r + 1]; ++j) cols.push_back(remap(ci[j])); }
@@ -351,6 +507,12 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                     hlen[w] = (int)std::min<long long>(cap_cols, xl - bs);
                 }
             });
+            if (pass == 0) {
+                long long in_s = 0, all_s = 0;
+                for (int w : wlist) { in_s += hin[(size_t)w]; all_s += wnnz[(size_t)w]; }
+                if (100 * in_s < 45 * all_s) { std::fill(hin.begin(), hin.end(), 0); break; }     // cover stays 0: no hybrid windows
+            }
+            }
             long long in = 0;
             for (int w = 0; w < nW; ++w) in += hin[w];
             const double cover = all > 0 ? (double)in / (double)all : 0.0;
