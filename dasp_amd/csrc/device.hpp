@@ -44,6 +44,10 @@ struct DevArgs {
     const int *order;
     // workgroup ranges
     int wg_long, wg_med, wg_short;
+    // medium blocks dealt to the 8 XCDs in contiguous ranges of equal work (upload_plan): workgroup m of the medium range serves blocks
+    // xcd_blk[m % 8] + 4 * (m / 8) .. + 3 below xcd_blk[m % 8 + 1].  xcd_on = 0: block = workgroup * 4 + wave as ever.
+    int xcd_on;
+    int xcd_blk[9];
 };
 
 // byte offsets of the nnz-sized arrays inside the arena (devpack.hip writes them, tests download them)

@@ -730,10 +730,19 @@ __device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw)
         if constexpr (!WIN) {
             const int m = wg - a.wg_long;
             const XGlobal<T> x{static_cast<const T *>(a.x)};
+            if (a.xcd_on) {
+                // workgroups go to the XCDs round-robin, each XCD has an L2 of its own: with the blocks dealt round-robin too, every
+                // XCD gathers from ALL of x (nlpkkt160: 8 x 67 MB of x through the L2s against 2.4 GB of matrix).  Rows of equal length
+                // keep their row order in the sort, so a contiguous range of blocks is a contiguous part of the mesh: XCD k takes the
+                // k-th eighth of the blocks (eighths of equal work) and touches an eighth of x plus the halo.
+                const int k = m & 7, b = a.xcd_blk[k] + (m >> 3) * kWavesPerWG + wave;
+                if (b < a.xcd_blk[k + 1]) medium_block<T, NT, C16, 0, C8>(a, b, lane, x);
+            } else {
             // grid-stride over the blocks: wg_med is capped (upload_plan) so the medium range is a persistent set of workgroups
 #pragma unroll 1
             for (int b = m * kWavesPerWG + wave; b < a.n_blocks; b += a.wg_med * kWavesPerWG)
                 medium_block<T, NT, C16, 0, C8>(a, b, lane, x);
+            }
         } else {
             // one window per workgroup; its blocks_per_win blocks are dealt round-robin to the wpw waves.  Workgroups are dealt to the 8
             // XCDs round-robin, so workgroup m of the range takes window (m % 8) * per_xcd + m / 8: every XCD works on ONE contiguous
@@ -1178,6 +1187,33 @@ int upload_plan(Plan &p)
             a.wg_med = std::min(a.wg_med, cus * per_cu);
         }
     }
+    // XCD-contiguous block ranges (opt-in: DASP_XCD_BLOCKS=1) for plans of EVEN blocks (FEM / stencil rows: longest block <= 4 x the
+    // mean).  Work of a block = its chunks + 2 (row tables, tail); every XCD gets an eighth of it.  Measured r3 (profiles/r03_xcd_blocks.md):
+    // it removes exactly the traffic it was built for -- nlpkkt160's x pulled through eight L2s, FETCH 3.03 -> 2.54 GB per SpMV, 1.03 ->
+    // 0.86 x the CSR bytes -- but that traffic was Infinity-Cache hits, not HBM reads, and the time does not move (nlpkkt160 0.4051 ->
+    // 0.4105 ms, HV15R 0.4274 -> 0.4227, Queen 0.5089 -> 0.5083, f16 0-1.5 % slower), so it stays off by default.
+    a.xcd_on = 0;
+    for (int &v : a.xcd_blk) v = 0;
+    if (!p.windowed && a.wg_med == (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG && a.n_blocks >= 8 * 256 && (int)p.med_ptr.size() == a.n_blocks + 1) {
+        int longest = 0;
+        for (int b = 0; b < a.n_blocks; ++b) longest = std::max(longest, p.med_ptr[(size_t)b + 1] - p.med_ptr[(size_t)b]);
+        const double mean = (double)p.med_ptr[(size_t)a.n_blocks] / (double)a.n_blocks;
+        const char *e = std::getenv("DASP_XCD_BLOCKS");
+        const bool on = e && std::atoi(e) != 0 && (double)longest <= 4.0 * std::max(mean, 1.0);
+        if (on) {
+            auto work_before = [&](int b) { return (long long)p.med_ptr[(size_t)b] + 2ll * b; };
+            const long long total = work_before(a.n_blocks);
+            int most = 0;
+            for (int k = 0; k <= 8; ++k) {
+                int lo = 0, hi = a.n_blocks;                               // first block whose preceding work reaches k / 8 of the total
+                while (lo < hi) { const int mid = (lo + hi) / 2; if (work_before(mid) * 8 < total * k) lo = mid + 1; else hi = mid; }
+                a.xcd_blk[k] = k == 8 ? a.n_blocks : lo;
+            }
+            for (int k = 0; k < 8; ++k) most = std::max(most, a.xcd_blk[k + 1] - a.xcd_blk[k]);
+            a.xcd_on = 1;
+            a.wg_med = 8 * ((most + kWavesPerWG - 1) / kWavesPerWG);
+        }
+    }
     a.wg_short = (a.n_short_tiles + a.wpw - 1) / a.wpw;
     // streamed-once matrix data bypasses the caches (the reference's ld.global.cs, dasp_f64.h:34-51)
     // only when it cannot stay resident in the 256 MiB Infinity Cache between two SpMVs anyway.
@@ -1330,6 +1366,9 @@ int launch_mg_step(Plan &own, Plan *other, const void *x_own, const void *x_gath
     DevArgs a = own.dev->args, b = other ? other->dev->args : own.dev->args;
     a.x = x_own; a.y = y; a.acc = 0;
     b.x = x_gathered; b.y = y; b.acc = 0;
+    // the step kernel's own geometry: one medium block per wave in table order (mg_step_marks assumes it), whatever upload_plan chose
+    a.wg_med = (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG; a.xcd_on = 0;
+    b.wg_med = (b.n_blocks + kWavesPerWG - 1) / kWavesPerWG; b.xcd_on = 0;
     StepCtl c{};
     char *w = static_cast<char *>(h.words);
     c.mark_shards = reinterpret_cast<unsigned *>(w); c.all_shards = reinterpret_cast<unsigned *>(w + 8192);
