@@ -129,6 +129,7 @@ struct dasp_mg_plan {
     // completed exchange), own_go, ready (step whose products are complete), error word
     char *words = nullptr;
     bool fused = false;                // dasp_mg_spmv / dasp_mg_product run the one-launch step
+    bool gather_fine = false;          // yg is fine-grained device memory
     uint64_t gathered_step = 0;        // step number of the last exchange queued on the communication stream (0: none since set_x)
     int max_pollers = 1024, poll_sleep = 1;
     std::vector<unsigned char> mark;   // one byte per own-column workgroup of the step kernel: stores a row the other-column plan adds to
@@ -399,7 +400,19 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
     MG_HIP(hipGetDevice(&g.device));
     const size_t vb = g.vb(), sl = (size_t)g.stride * vb, all = sl * (size_t)g.world;
     for (int k = 0; k < 3; ++k) { MG_HIP(hipMalloc(&g.ys[k], sl)); MG_HIP(hipMemset(g.ys[k], 0, sl)); }
-    MG_HIP(hipMalloc(&g.yg, all)); MG_HIP(hipMemset(g.yg, 0, all));
+    {   // the gather buffer is written by the exchange -- this device's RCCL kernel or, over xGMI, a peer's stores -- WHILE the fused step's
+        // kernel is already running and about to read it behind an in-kernel acquire.  Coarse-grained memory only promises visibility at
+        // kernel boundaries; fine-grained memory is what the HSA memory model defines in-kernel cross-agent acquire / release on, so the
+        // buffer is allocated fine-grained wherever a plan may run the fused step (DASP_MG_GATHER_MEM=coarse: A/B knob).  Only the
+        // other-column product (a few per cent of the gathers) reads it.
+        const char *e = std::getenv("DASP_MG_GATHER_MEM");
+        const bool fine = g.overlap && g.precision == 64 && !(e && std::strcmp(e, "coarse") == 0);
+        if (!(fine && hipExtMallocWithFlags(&g.yg, all, hipDeviceMallocFinegrained) == hipSuccess && g.yg)) {
+            (void)hipGetLastError();
+            MG_HIP(hipMalloc(&g.yg, all));
+        } else g.gather_fine = true;
+        MG_HIP(hipMemset(g.yg, 0, all));
+    }
     if (g.square) g.xg = g.yg;
     else { const size_t xb = std::max<size_t>((size_t)g.colA * vb, 16); MG_HIP(hipMalloc(&g.xg, xb)); MG_HIP(hipMemset(g.xg, 0, xb)); }
     {   // the communication stream gets the highest priority: the all-gather's few workgroups must not queue behind the thousands of

@@ -23,6 +23,8 @@ SPMV_KERNELS = ("dasp_spmv_kernel", "dasp_long_reduce_kernel", "dasp_panel_sum_k
 
 def spmv_kernel(name):
     """which SpMV kernel a (possibly mangled: rocprofv3 does not demangle the _Float16 instantiations) name is, or None"""
+    if "dasp_spmv_win1_kernel" in name:          # the 128-register build of the windowed kernel (plans of <= 256 windows)
+        return "dasp_spmv_kernel"
     for k in SPMV_KERNELS:
         if k in name:
             return k
@@ -55,7 +57,7 @@ stats = list(csv.DictReader(open(max(glob.glob(d + "/trace/*/*kernel_stats.csv")
 sys.stderr.write("## rocprofv3 --kernel-trace --stats -- dasp_bench %s %g %d (tag %s)\n\n| kernel | calls | avg ns | %% |\n|---|---|---|---|\n" % (workload, scale, prec, tag))
 for r in stats[:5]:
     sys.stderr.write("| %s | %s | %.0f | %s |\n" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]), r["Percentage"]))
-g = [r for r in frows if "dasp_spmv_kernel" in r["Kernel_Name"]][0]
+g = [r for r in frows if "dasp_spmv" in r["Kernel_Name"]][0]
 sys.stderr.write("\nVGPR_Count=%s SGPR_Count=%s LDS=%s scratch=%s workgroup=%s; %d column panels; %.0f SpMVs profiled\n" %
                  (g["VGPR_Count"], g["SGPR_Count"], g["LDS_Block_Size"], g["Scratch_Size"], g["Workgroup_Size"], panels, n_spmv))
 sys.stderr.write("FETCH_SIZE (own pass) = %.4f GB raw per SpMV -> x2 = %.4f GB; WRITE_SIZE (own pass) = %.2f MB; traffic = %.4f GB per SpMV\n\n" %
@@ -69,4 +71,4 @@ print(json.dumps({"workload": workload, "precision": prec, "scale": scale, "kern
                   "fetch_size_bytes_raw": round(f_raw), "write_size_bytes": round(w), "traffic_bytes": round(2 * f_raw + w),
                   "kernel_avg_ns": avg, "column_panels": panels,
                   "correction": "2 x FETCH_SIZE (gfx950, MI355X_MICROARCH.md HBM section; calibrated for wide coalesced streams) + WRITE_SIZE, summed over the kernels of one SpMV",
-                  "source": "profiles/r02_traffic.md"}))
+                  "source": "profiles/r03_traffic.md"}))

@@ -16,4 +16,6 @@ wb16 webbase-1M 1 16 200
 lj16 ljournal-2008 1 16 20
 rmat16 rmat_2M 1 16 50
 lju16 ljournal-2008-uniform 1 16 20
+hvu64 HV15R-unstructured 1 64 20
+wbu16 webbase-1M-uniform 1 16 200
 LIST
