@@ -463,6 +463,59 @@ def test_fused_mg_step_three_ranks_on_one_device(dasp, torch_cuda):
     np.testing.assert_array_equal(res[True], res[False])
 
 
+@pytest.mark.parametrize("seed,kw", [(31, dict(x_window=-1)), (32, dict(x_window=-1, slab_max_len=12)), (33, dict(x_window=-1, long_piece=256, block_longest=64)),
+                                     (34, dict())])
+def test_fused_mg_step_every_row_category(dasp, torch_cuda, seed, kw):
+    """The one-launch step on a square matrix with EVERY row category in both the own-column and the other-column plan of each rank
+    (empty rows, lengths 1-4 with the 1&3 pairing, medium blocks with tails, slab-stored medium rows, long rows as single pieces):
+    three ranks on one device, chained, against scipy and BIT-IDENTICAL to the two-launch form.  A plan with a long row cut into
+    several pieces does not qualify for the fused step and must say so (and still be right)."""
+    import scipy.sparse as sp
+    from dasp_amd.multi import MgPlan
+    torch = torch_cuda
+    m, world = 9000, 3
+    rp, ci, v = util.mixed_matrix(m, m, seed, lengths=[0, 1, 2, 3, 4, 1, 3, 6, 9, 14, 27, 40, 90, 300, 700])
+    lens = np.diff(rp)
+    v = v / np.maximum(np.repeat(lens, lens), 1)                      # keeps the chain bounded
+    A = sp.csr_matrix((v.copy(), ci.copy(), rp.copy()), shape=(m, m))       # copies: abs() below sums duplicates IN PLACE, which would re-order the rows the second form packs
+    bounds = dasp.partition_rows(rp, world)
+    x0 = np.random.default_rng(seed).uniform(0.5, 1.5, m)
+    res = {}
+    for fused in (True, False):
+        mgs = []
+        for r in range(world):
+            r0, r1 = int(bounds[r]), int(bounds[r + 1])
+            mgs.append(MgPlan(rp[r0:r1 + 1] - rp[r0], ci[rp[r0]:rp[r1]], v[rp[r0]:rp[r1]], m, m, bounds, r, cid16=1, **kw).upload())
+        def qualifies(mg):      # no long row cut into several pieces, no x windows (a 9000-column x fits the LDS: auto turns them on)
+            subs = [mg.subplan(w) for w in (0, 1) if mg.subplan(w) is not None]
+            return all(sp_.stats["n_long_multi"] == 0 and sp_.stats["x_window_on"] == 0 for sp_ in subs)
+        for mg in mgs:
+            assert mg.info["fused_step"] == (1 if qualifies(mg) else 0)
+            if not fused and mg.info["fused_step"]:
+                mg.set_fused(False)
+            mg.set_fake_exchange(5, peers=mgs)
+            mg.set_x(x0)
+        want = x0
+        for it in range(4):
+            for mg in mgs:
+                mg.product(0)
+            for mg in mgs:
+                mg.check()
+            for mg in mgs:
+                mg.allgather(0)
+            torch.cuda.synchronize()
+            want = A @ want
+        y = mgs[0].get_y()
+        scale = np.abs(A) @ np.abs(x0) + 1e-300
+        assert np.abs(y - want).max() <= 1e-12 * max(np.abs(want).max(), scale.max())
+        for mg in mgs[1:]:
+            np.testing.assert_array_equal(mg.get_y(), y)
+        res[fused] = y
+        for mg in mgs:
+            mg.close()
+    np.testing.assert_array_equal(res[True], res[False])
+
+
 def test_fused_mg_step_waits_in_the_kernel_and_times_out_cleanly(dasp, torch_cuda, monkeypatch):
     """One rank of a 2-way partition, 30 chained steps with NO host synchronisation between them and an emulated exchange of
     60 us: the other-column workgroups really wait inside the kernel for the previous exchange.  The peer's half of x never
