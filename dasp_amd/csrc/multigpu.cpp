@@ -117,6 +117,7 @@ struct dasp_mg_plan {
     int cur = 0;
     bool pending = false;              // an all-gather into yg is in flight on `cs`
     bool pending_sig = false;          // ... and its completion was published by a stream memory operation (else: ev_g)
+    bool pending_lazy = false;         // ... fused step: ev_g not recorded yet (nobody but the step kernel has asked so far)
     hipStream_t cs = nullptr;          // communication stream
     hipEvent_t ev_y = nullptr, ev_g = nullptr;
     // two-launch form: cross-stream hand-offs through events (documented acquire / release semantics).  DASP_MG_SYNC=memops opts into
@@ -281,6 +282,7 @@ int publish_gathered(dasp_mg_plan &g, uint64_t k)
 int wait_gathered(dasp_mg_plan &g, hipStream_t s)
 {
     if (!g.pending) return DASP_OK;
+    if (g.pending_lazy) { MG_HIP(hipEventRecord(g.ev_g, g.cs)); g.pending_lazy = false; }      // the communication stream is in order: behind the exchange
     if (g.pending_sig) {
         if (hipStreamWaitValue64(s, g.sig[1], g.pending_step, hipStreamWaitValueGte, kAllBits) != hipSuccess) {
             (void)hipGetLastError(); g.use_sig = false;
@@ -500,7 +502,7 @@ int dasp_mg_set_x(dasp_mg_plan_t *mg, const void *x_host)
     const size_t vb = g.vb();
     const char *x = static_cast<const char *>(x_host);
     MG_HIP(hipDeviceSynchronize());
-    g.pending = false; g.pending_sig = false; g.gathered_step = 0;
+    g.pending = false; g.pending_sig = false; g.pending_lazy = false; g.gathered_step = 0;
     if (!g.square) { MG_HIP(hipMemcpy(g.xg, x, (size_t)g.colA * vb, hipMemcpyHostToDevice)); return DASP_OK; }
     try {
         std::vector<char> lay((size_t)g.world * g.stride * vb, 0);
@@ -534,8 +536,7 @@ int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream)
         if (int rc = launch_mg_wait(g.words + kMgWordReady, k, g.timeout_ticks, g.words + kMgWordErr, g.cs)) return rc;
         if (int rc = exchange(g, g.cs)) return rc;
         if (int rc = launch_mg_flag(g.words + kMgWordGathered, k, g.cs)) return rc;
-        MG_HIP(hipEventRecord(g.ev_g, g.cs));          // for dasp_mg_wait / dasp_mg_allgather: consumers outside the step kernel
-        g.gathered_step = k; g.pending_sig = false;
+        g.gathered_step = k; g.pending_sig = false; g.pending_lazy = true;      // consumers outside the step kernel: wait_gathered records the event when one shows up
     } else {
         if (int rc = handoff_ready(g, s, k)) return rc;
         if (int rc = exchange(g, g.cs)) return rc;
@@ -571,7 +572,7 @@ int dasp_mg_get_y(dasp_mg_plan_t *mg, void *y_host)
     dasp_mg_plan &g = *mg;
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
     MG_HIP(hipDeviceSynchronize());
-    g.pending = false;
+    g.pending = false; g.pending_lazy = false;
     const size_t vb = g.vb();
     try {
         std::vector<char> lay((size_t)g.world * g.stride * vb);
@@ -621,7 +622,7 @@ int dasp_mg_check(dasp_mg_plan_t *mg)
     dasp_mg_plan &g = *mg;
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
     MG_HIP(hipDeviceSynchronize());
-    g.pending = false;
+    g.pending = false; g.pending_lazy = false;
     if (!g.fused) return DASP_OK;
     uint64_t err = 0;
     MG_HIP(hipMemcpy(&err, g.words + kMgWordErr, sizeof err, hipMemcpyDeviceToHost));
@@ -642,7 +643,7 @@ int dasp_mg_set_fused(dasp_mg_plan_t *mg, int on)
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
     MG_HIP(hipDeviceSynchronize());
     if (on && !g.words) { set_error("this plan does not qualify for the fused step (f64, square, column split, 16-bit ids, no windows / panels / multi-piece rows)"); return DASP_ERR_STATE; }
-    g.pending = false; g.gathered_step = 0;
+    g.pending = false; g.pending_lazy = false; g.gathered_step = 0;
     g.fused = on != 0;
     return DASP_OK;
 }

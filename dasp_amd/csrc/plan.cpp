@@ -26,7 +26,10 @@ int resolve_threads(int requested)
     if (requested > 0) return requested;
     unsigned hc = std::thread::hardware_concurrency();
     if (hc == 0) hc = 1;
-    return (int)std::min(hc, 32u);
+    // DASP_HOST_THREADS_MAX: cap of the automatic choice (packing is a memory-bound copy: beyond the host's memory bandwidth more threads add nothing)
+    unsigned cap = 32u;     // measured on a 256-core host: HV15R 318 / 204 / 300 / 432 ms at 16 / 32 / 64 / 128 threads
+    if (const char *e = std::getenv("DASP_HOST_THREADS_MAX")) cap = (unsigned)std::max(1, std::atoi(e));
+    return (int)std::min(hc, cap);
 }
 
 // ---- a small persistent worker pool: spawning 32 threads costs ~1 ms, and building a plan from a device-resident CSR is ~20
@@ -43,7 +46,7 @@ public:
         if (in_worker_ || parts <= 1) return false;
         std::unique_lock<std::mutex> own(busy_, std::try_to_lock);
         if (!own.owns_lock()) return false;
-        ensure((int)std::min<long long>(parts - 1, 31));
+        ensure((int)std::min<long long>(parts - 1, 127));
         {
             std::lock_guard<std::mutex> lk(m_);
             job_ = &job; parts_ = parts; next_.store(0); left_ = parts; ++epoch_;
@@ -475,9 +478,9 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             const long long xl = p.opt.n_parts > 0 ? (long long)p.opt.n_parts * p.opt.part_stride : (long long)p.n;
             std::vector<int> hmin(nW), hlen(nW);
             std::vector<long long> hin(nW);
-            // auto mode on a large matrix: the densest spans of 64 evenly spaced windows first -- when they hold under 45 % of those
+            // auto mode on a large matrix: the densest spans of 64 evenly spaced windows first -- when they hold under 55 % of those
             // windows' gathers the whole will not reach 60 %, and sorting every window's columns is skipped (HV15R: 0.33 s of the host
-            // path; its three-plane rows give 33 %)
+            // path, its three-plane rows give 33 %; nlpkkt160: 0.45 s, ~50 %)
             std::vector<int> wlist;
             if (p.opt.x_window_hybrid == 0 && nW > 256) for (int q = 0; q < 64; ++q) wlist.push_back((int)((long long)q * (nW - 1) / 64));
             bool sampled = !wlist.empty();
@@ -510,7 +513,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             if (pass == 0) {
                 long long in_s = 0, all_s = 0;
                 for (int w : wlist) { in_s += hin[(size_t)w]; all_s += wnnz[(size_t)w]; }
-                if (100 * in_s < 45 * all_s) { std::fill(hin.begin(), hin.end(), 0); break; }     // cover stays 0: no hybrid windows
+                if (100 * in_s < 55 * all_s) { std::fill(hin.begin(), hin.end(), 0); break; }     // cover stays 0: no hybrid windows
             }
             }
             long long in = 0;
