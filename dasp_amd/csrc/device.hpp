@@ -48,6 +48,7 @@ struct DevArgs {
     // xcd_blk[m % 8] + 4 * (m / 8) .. + 3 below xcd_blk[m % 8 + 1].  xcd_on = 0: block = workgroup * 4 + wave as ever.
     int xcd_on;
     int xcd_blk[9];
+    int med_stride;   // 1: the medium workgroups stride over the blocks (capped, persistent range); 0: exactly one block per wave
 };
 
 // byte offsets of the nnz-sized arrays inside the arena (devpack.hip writes them, tests download them)

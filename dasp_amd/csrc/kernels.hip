@@ -737,6 +737,10 @@ __device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw)
                 // k-th eighth of the blocks (eighths of equal work) and touches an eighth of x plus the halo.
                 const int k = m & 7, b = a.xcd_blk[k] + (m >> 3) * kWavesPerWG + wave;
                 if (b < a.xcd_blk[k + 1]) medium_block<T, NT, C16, 0, C8>(a, b, lane, x);
+            } else if (sizeof(T) == 8 && !a.med_stride) {
+                // f64: the medium range is never capped (upload_plan), one block per wave -- no loop
+                const int b = m * kWavesPerWG + wave;
+                if (b < a.n_blocks) medium_block<T, NT, C16, 0, C8>(a, b, lane, x);
             } else {
             // grid-stride over the blocks: wg_med is capped (upload_plan) so the medium range is a persistent set of workgroups
 #pragma unroll 1
@@ -1194,6 +1198,8 @@ int upload_plan(Plan &p)
     // 0.4105 ms, HV15R 0.4274 -> 0.4227, Queen 0.5089 -> 0.5083, f16 0-1.5 % slower), so it stays off by default.
     a.xcd_on = 0;
     for (int &v : a.xcd_blk) v = 0;
+    a.med_stride = a.wg_med * kWavesPerWG < a.n_blocks ? 1 : 0;      // the medium range is a persistent, striding set of workgroups (f16 only today)
+    if (const char *e = std::getenv("DASP_MED_LOOP")) a.med_stride = a.med_stride || std::atoi(e) != 0;      // A/B knob
     if (!p.windowed && a.wg_med == (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG && a.n_blocks >= 8 * 256 && (int)p.med_ptr.size() == a.n_blocks + 1) {
         int longest = 0;
         for (int b = 0; b < a.n_blocks; ++b) longest = std::max(longest, p.med_ptr[(size_t)b + 1] - p.med_ptr[(size_t)b]);
