@@ -634,11 +634,10 @@ def main():
         tdt = torch.float64 if prec == 64 else torch.float16
         kx = torch.ones(plan.x_len, dtype=tdt, device="cuda")
         ky = torch.zeros(stride, dtype=tdt, device="cuda")
-    kw, ke = plan.time(kx.data_ptr(), ky.data_ptr(), stream, warmup=5, iters=k_iters)
-    # the spread inside this process: every one of >= 200 launches between its own pair of events (VERDICT r2 weak #8a)
+    kw, ke = plan.time(kx.data_ptr(), ky.data_ptr(), stream, warmup=5, iters=k_iters)      # one event pair around >= 200 back-to-back launches
+    # the spread inside this process: every one of >= 200 launches between its own pair of events (VERDICT r2 weak #8a); each interval
+    # carries the few microseconds an event between two kernels costs, so the headline kernel_ms stays the back-to-back mean above
     each = np.sort(plan.time_each(kx.data_ptr(), ky.data_ptr(), stream, warmup=5, iters=max(200, k_iters)).astype(np.float64))
-    plan_mean = ke
-    ke = float(np.median(each))                                   # the headline kernel time: the median launch
     # partitioned: the dominant kernel is the rank's own-column plan (its x is the rank's own slice)
     nnz_local = int(rp[-1]) if mg is None else mg.nnz_local
     b_alg_local = algorithmic_bytes(r1 - r0, cols if mg is None else (stride if mg.overlap else cols), nnz_local, vb)
@@ -670,12 +669,13 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "kernel": "dasp_spmv_kernel<%s>" % ("double" if prec == 64 else "_Float16"),
                      "algorithmic_bytes_per_launch": b_alg_local, "kernel_ms": round(ke, 6),
-                     "kernel_ms_min": round(float(each[0]), 6), "kernel_ms_max": round(float(each[-1]), 6),
-                     "kernel_ms_p10": round(float(each[len(each) // 10]), 6), "kernel_ms_p90": round(float(each[(len(each) * 9) // 10]), 6),
-                     "kernel_ms_mean_back_to_back": round(kw if False else float(plan_mean), 6),
-                     "frac_at_min": round(b_alg_local / (float(each[0]) * 1e6) / HBM_PEAK_GBPS, 4), "frac_at_max": round(b_alg_local / (float(each[-1]) * 1e6) / HBM_PEAK_GBPS, 4),
-                     "method": "median of %d back-to-back launches, a hipEvent between every two on the launch stream (rank 0 slice); "
-                               "kernel_ms_mean_back_to_back = one event pair around %d launches" % (len(each), k_iters)},
+                     "launch_ms_min": round(float(each[0]), 6), "launch_ms_p10": round(float(each[len(each) // 10]), 6),
+                     "launch_ms_median": round(float(np.median(each)), 6), "launch_ms_p90": round(float(each[(len(each) * 9) // 10]), 6),
+                     "launch_ms_max": round(float(each[-1]), 6),
+                     "frac_at_fastest_launch": round(b_alg_local / (float(each[0]) * 1e6) / HBM_PEAK_GBPS, 4),
+                     "frac_at_slowest_launch": round(b_alg_local / (float(each[-1]) * 1e6) / HBM_PEAK_GBPS, 4),
+                     "method": "kernel_ms: hipEvent pair on the launch stream around %d back-to-back launches (rank 0 slice); launch_ms_*: the same "
+                               "%d launches with a hipEvent between every two (each interval includes the few us an event between two kernels costs)" % (k_iters, len(each))},
         "achieved_GBps_whole_job": round(b_alg_total / (ms_per_step * 1e6), 1),
         "frac_hbm_roofline_whole_job": round(b_alg_total / (ms_per_step * 1e6) / (HBM_PEAK_GBPS * world), 4),
         "region_event_ms_per_step": round(region_event_ms, 6), "verified": ok, "preprocess_s": round(pre_s, 3),
