@@ -552,8 +552,12 @@ def main():
         elapsed = float(tt.item())
     region_event_ms = ev0.elapsed_time(ev1) / args.steps
     dog.kick("timed region done")
+    mg_err = None
     if mg is not None:
-        mg.check()                                                # a time-out inside the timed region is an error, not a number
+        try:
+            mg.check()                                            # a time-out inside the timed region invalidates the number: say so in the line
+        except D.DaspError as exc:
+            mg_err = str(exc)
 
     from oracle import oracle as O          # checker / baseline only, after the timed region; never on the measured path
     rx = None
@@ -682,6 +686,10 @@ def main():
     }
     if world == 1 and mg is None:
         out["roofline"].update(traffic_for(name, prec, scale, b_alg_local, kernel_revision()))
+    if mg_err is not None:
+        out["error"] = mg_err
+        out["verified"] = False
+        ok = False
     if rx is not None:
         out["verified_random_x"] = rx
     if parts is not None:
