@@ -261,6 +261,8 @@ def suite_entry(torch, D, O, name, precision, scale, budget_s=2.0):
     plan.close()
     del x, y
     torch.cuda.empty_cache()
+    if st["n_col_panels"] == 0:         # plans that split into column panels need a host CSR (panels are decided and cut on the host)
+        out.update(device_pre_ms(torch, D, rp, ci, rows, cols, precision))
     try:
         out["verified_random_x"] = verify_random_x(torch, D, O, rp, ci, cols, precision, time_iters=min(iters, 100))
         rv = out["verified_random_x"].get("random_values_ms")
@@ -269,6 +271,30 @@ def suite_entry(torch, D, O, name, precision, scale, budget_s=2.0):
     except Exception as exc:
         out["verified_random_x"] = {"ok": False, "error": repr(exc)}
     return out
+
+
+def device_pre_ms(torch, D, rp, ci, rows, cols, precision):
+    """wall time of dasp_plan_create_device: the same plan built from a CSR that already lives on the GPU (the nonzeros never visit the
+    host; SURVEY 8f-2, the reference's "dasp_pre" metric, dasp_f16.h:1444-1445).  Best of two builds: the first pays first-use costs."""
+    try:
+        nnz = int(rp[-1])
+        d_rp = torch.from_numpy(np.ascontiguousarray(rp, np.int32)).cuda()
+        d_ci = torch.from_numpy(np.ascontiguousarray(ci, np.int32)).cuda()
+        d_v = torch.ones(max(nnz, 1), dtype=torch.float64 if precision == 64 else torch.float16, device="cuda")
+        best = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dp = D.Plan.from_device(d_rp.data_ptr(), d_ci.data_ptr(), d_v.data_ptr(), rows, cols, nnz, precision=precision)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            dp.close()
+            best = (t1 - t0) if best is None else min(best, t1 - t0)
+        del d_rp, d_ci, d_v
+        torch.cuda.empty_cache()
+        return {"pre_ms_device_csr": round(best * 1e3, 1)}
+    except Exception as exc:
+        return {"pre_ms_device_csr": None, "pre_device_error": repr(exc)}
 
 
 def generator_of(D, name):
@@ -701,6 +727,8 @@ def main():
         plan.close()
     del x, y, kx, ky
     torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and mg is None and st["n_col_panels"] == 0:
+        out.update(device_pre_ms(torch, D, rp, ci, rows, cols, prec))
 
     if rank == 0 and world == 1 and mg is None and not args.no_random_x:
         try:
