@@ -209,7 +209,8 @@ __global__ void k_pack_short(const int *rp, const int *ci, const T *val, const i
 template <class U>
 struct DevVec {
     U *d = nullptr;
-    int init(const std::vector<U> &h)
+    template <class A>
+    int init(const std::vector<U, A> &h)
     {
         if (h.empty()) return DASP_OK;
         if (hipMalloc(&d, h.size() * sizeof(U)) != hipSuccess) { set_error("hipMalloc (device packing scratch)"); return DASP_ERR_HIP; }
@@ -260,7 +261,7 @@ int devpack_validate(const Plan &p, const DevCsr &d)
     return DASP_OK;
 }
 
-int devpack_window_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridW, int R, int *lo, int *hi, long long *wnnz)
+int devpack_window_spans(const Plan &p, const DevCsr &d, const raw_vector<int> &ridW, int R, int *lo, int *hi, long long *wnnz)
 {
     const int nmed = (int)ridW.size(), nW = (nmed + R - 1) / R;
     if (nW == 0) return DASP_OK;
@@ -311,7 +312,7 @@ int devpack_row_coherence(const Plan &p, const DevCsr &d, const std::vector<int>
     return DASP_OK;
 }
 
-int devpack_chunk_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridM, const std::vector<int> &lenM,
+int devpack_chunk_spans(const Plan &p, const DevCsr &d, const raw_vector<int> &ridM, const raw_vector<int> &lenM,
                         const std::vector<int> &nchunks, int *k16, unsigned long long *narrow_mask)
 {
     const int nmed = (int)ridM.size(), nb = (nmed + kMedRows - 1) / kMedRows;

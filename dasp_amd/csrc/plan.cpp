@@ -208,7 +208,8 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     for (int t = 0; t < cparts; ++t) for (int k = 0; k < 7; ++k) ccnt[(size_t)t + 1][(size_t)k] += ccnt[(size_t)t][(size_t)k];     // -> first index of part t
     n1 = ccnt[(size_t)cparts][0]; n3 = ccnt[(size_t)cparts][1]; n2 = ccnt[(size_t)cparts][2]; nz0 = ccnt[(size_t)cparts][3];
     n4 = ccnt[(size_t)cparts][4]; nlong = ccnt[(size_t)cparts][5]; nmed = ccnt[(size_t)cparts][6];
-    std::vector<int> rid1(n1), rid2(n2), rid3(n3), rid4(n4), rid0(nz0), ridL(nlong), ridM_in(nmed);
+    std::vector<int> rid1(n1), rid2(n2), rid3(n3), rid4(n4), rid0(nz0), ridL(nlong);
+    raw_vector<int> ridM_in((size_t)nmed);       // every element is written by the fill below; no 33 MB zero fill for 8 M rows
     {
         int *const lists[7] = {rid1.data(), rid3.data(), rid2.data(), rid0.data(), rid4.data(), ridL.data(), ridM_in.data()};
         parallel_for(cparts, cparts, 1, [&](long long t0, long long t1) {
@@ -235,7 +236,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     lap("classify");
     // ---- medium rows sorted by length, descending and stable (what utils.h:118-160,196-203 produce);
     // lengths are < block_longest, so one counting pass does it.
-    std::vector<int> ridM(nmed), lenM(nmed);
+    raw_vector<int> ridM((size_t)nmed), lenM((size_t)nmed);
     {
         // parallel counting sort: per-part histograms, then every (length, part) pair gets its start -- lengths descending, parts in
         // row order inside a length: stable
@@ -339,7 +340,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     // from here on "medium" means the MFMA part only
     if (nmf < nmed_all) {
         ridM.resize((size_t)nmf); lenM.resize((size_t)nmf);
-        std::vector<int> keep; keep.reserve((size_t)nmf);
+        raw_vector<int> keep; keep.reserve((size_t)nmf);
         for (int r : ridM_in) if (rp[r + 1] - rp[r] > slab_max) keep.push_back(r);
         ridM_in.swap(keep);
         nmed = nmf;
@@ -377,9 +378,9 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         int cap_bytes = order_only ? 0 : (p.opt.x_window > 0 ? std::min(p.opt.x_window, 160 * 1024) : 80 * 1024);
         const int A = 16 / geo.vbytes;                         // window base aligned for 16-byte copies
         // medium rows in row order, then a stable descending length sort inside each window
-        std::vector<int> ridW(nmed), lenW(nmed);
+        raw_vector<int> ridW((size_t)nmed), lenW((size_t)nmed);
         {
-            const std::vector<int> &rows = ridM_in;            // the medium rows in row order
+            const raw_vector<int> &rows = ridM_in;             // the medium rows in row order
             const int nW = ceil_div(nmed, R);
             parallel_for(nW, threads, 8, [&](long long w0, long long w1) {
                 std::vector<int> bucket;
@@ -398,7 +399,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         std::vector<long long> wnnz(nW);
         std::vector<int> wlo(nW), whi(nW);
         // span [lo, hi] and nonzeros of the windows over rows list[0 .. n): one window per R rows
-        auto spans_of = [&](const std::vector<int> &list, int n, int *lo_out, int *hi_out, long long *nnz_out) -> int {
+        auto spans_of = [&](const raw_vector<int> &list, int n, int *lo_out, int *hi_out, long long *nnz_out) -> int {
             if (dev) return devpack_window_spans(p, *dev, list, R, lo_out, hi_out, nnz_out);
             parallel_for(ceil_div(n, R), threads, 8, [&](long long w0, long long w1) {
                 for (long long w = w0; w < w1; ++w) {
@@ -420,7 +421,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         bool scan_all = true;
         if (p.opt.x_window == 0 && nW > 256) {
             const int ns = 64;
-            std::vector<int> sample; sample.reserve((size_t)ns * (size_t)R);
+            raw_vector<int> sample; sample.reserve((size_t)ns * (size_t)R);
             for (int q = 0; q < ns; ++q) {
                 const int w = (int)((long long)q * (nW - 1) / ns);                 // never the (possibly partial) last window
                 sample.insert(sample.end(), ridW.begin() + (size_t)w * R, ridW.begin() + (size_t)(w + 1) * R);
@@ -437,12 +438,14 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         }
         if (scan_all) { if (int rc = spans_of(ridW, nmed, wlo.data(), whi.data(), wnnz.data())) return rc; }
         else
-            for (int w = 0; w < nW; ++w) {                                          // "does not fit": what the full scan would have concluded
-                wlo[w] = 2147483647; whi[w] = -1;
-                long long k = 0;
-                for (int i = w * R, e = std::min(nmed, (w + 1) * R); i < e; ++i) k += lenW[(size_t)i];
-                wnnz[w] = k;
-            }
+            parallel_for(nW, threads, 64, [&](long long w0, long long w1) {
+                for (long long w = w0; w < w1; ++w) {                               // "does not fit": what the full scan would have concluded
+                    wlo[(size_t)w] = 2147483647; whi[(size_t)w] = -1;
+                    long long k = 0;
+                    for (long long i = w * R, e = std::min<long long>(nmed, (w + 1) * R); i < e; ++i) k += lenW[(size_t)i];
+                    wnnz[(size_t)w] = k;
+                }
+            });
         long long fit = 0, all = 0; int maxlen = 0;
         auto fit_windows = [&]() {
             fit = 0; all = 0; maxlen = 0;
@@ -602,7 +605,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         const int Tcut = lenM[nsp - 1];
         ridL.insert(ridL.end(), ridM.begin(), ridM.begin() + nsp);
         ridM.erase(ridM.begin(), ridM.begin() + nsp); lenM.erase(lenM.begin(), lenM.begin() + nsp);
-        std::vector<int> keep; keep.reserve(ridM_in.size());
+        raw_vector<int> keep; keep.reserve(ridM_in.size());
         for (int r : ridM_in) if (rp[r + 1] - rp[r] < Tcut) keep.push_back(r);
         ridM_in.swap(keep);
         nmf -= nsp; nmed = nmf; nlong += nsp;         // from here on nlong counts the rows STORED as pieces
@@ -725,10 +728,12 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         // f16 spans beyond that -- the 160 KiB cap -- keep the per-chunk bases)
         p.win_rel16 = p.cid16 && p.windowed && !p.win_hybrid && p.lds_bytes / geo.vbytes <= 65534;
     }
-    for (int b = 0; b < nb; ++b) {
-        const int r0 = b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
-        for (int r = r0; r < r1; ++r) p.irr_ptr[r] = std::max(0, lenM[r] - K * nchunks[b]);
-    }
+    parallel_for(nb, threads, 1 << 12, [&](long long b0, long long b1) {
+        for (long long b = b0; b < b1; ++b) {
+            const int r0 = (int)b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
+            for (int r = r0; r < r1; ++r) p.irr_ptr[(size_t)r] = std::max(0, lenM[(size_t)r] - K * nchunks[(size_t)b]);
+        }
+    });
     // which blocks store chunk pairs (plan.hpp med_npair): none in a windowed plan; pipelined blocks and one-shot f16 blocks otherwise;
     // one-shot f64 blocks only when the plan is far beyond the 256 MiB Infinity Cache (nlpkkt160: 2.8 GB -7 % / -1.5 % by box; at 278 MB +4-8 %)
     p.pair_mode = p.windowed || p.opt.chunk_pairs < 0 ? 0 : p.opt.chunk_pairs > 0 ? std::min(2, p.opt.chunk_pairs)
@@ -748,8 +753,24 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         for (int b = 0; b < nb; ++b) { p.med_ptr[b] = (int)run; run += nchunks[b]; }
         if (run >= (1LL << 31) / 1) { set_error("too many medium chunks"); return DASP_ERR_ARG; }
         p.med_ptr[nb] = (int)run;
-        long long t = 0;
-        for (int r = 0; r < nmed; ++r) { int v = p.irr_ptr[r]; p.irr_ptr[r] = (int)t; t += v; }
+        // exclusive scan of the tail lengths: per-range sums, their prefix, then every range scans itself
+        const int sparts = (int)std::max<long long>(1, std::min<long long>(threads, ((long long)nmed + (1 << 16) - 1) >> 16));
+        std::vector<long long> psum((size_t)sparts + 1, 0);
+        parallel_for(sparts, sparts, 1, [&](long long p0, long long p1) {
+            for (long long q = p0; q < p1; ++q) {
+                long long a = 0;
+                for (long long r = (long long)nmed * q / sparts, e = (long long)nmed * (q + 1) / sparts; r < e; ++r) a += p.irr_ptr[(size_t)r];
+                psum[(size_t)q + 1] = a;
+            }
+        });
+        for (int q = 0; q < sparts; ++q) psum[(size_t)q + 1] += psum[(size_t)q];
+        parallel_for(sparts, sparts, 1, [&](long long p0, long long p1) {
+            for (long long q = p0; q < p1; ++q) {
+                long long t = psum[(size_t)q];
+                for (long long r = (long long)nmed * q / sparts, e = (long long)nmed * (q + 1) / sparts; r < e; ++r) { const int v = p.irr_ptr[(size_t)r]; p.irr_ptr[(size_t)r] = (int)t; t += v; }
+            }
+        });
+        long long t = psum[(size_t)sparts];
         p.irr_ptr[nmed] = (int)t;
     }
     const long long n_reg = (long long)p.med_ptr[nb] * CH;

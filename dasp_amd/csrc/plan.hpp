@@ -197,17 +197,17 @@ struct Plan {
 struct DevCsr { const int *rp, *ci; const void *val; };      // device pointers
 struct PackMeta {                                             // what the device packers need, in packing order
     const std::vector<int> *ridL = nullptr; const std::vector<long long> *startL = nullptr;
-    const std::vector<int> *ridM = nullptr, *lenM = nullptr;
+    const raw_vector<int> *ridM = nullptr, *lenM = nullptr;      // (not zero-filled on construction: 33 MB each for 8 M rows)
     const std::vector<int> *glist[kNumShortGroups] = {};
 };
 int devpack_validate(const Plan &p, const DevCsr &d);
-int devpack_window_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridW, int R, int *lo, int *hi, long long *wnnz);
+int devpack_window_spans(const Plan &p, const DevCsr &d, const raw_vector<int> &ridW, int R, int *lo, int *hi, long long *wnnz);
 // over the sampled rows: nonzeros, and how many of them start a new 128-byte line of x relative to their predecessor in the row
 int devpack_line_scatter(const Plan &p, const DevCsr &d, const std::vector<int> &rows, long long *lines, long long *entries);
 // over pairs of equally long rows (rows[2i], rows[2i+1]): entries compared, and how many lie within 16 columns of the other row's
 // entry at the same position
 int devpack_row_coherence(const Plan &p, const DevCsr &d, const std::vector<int> &rows, long long *near, long long *entries);
-int devpack_chunk_spans(const Plan &p, const DevCsr &d, const std::vector<int> &ridM, const std::vector<int> &lenM,
+int devpack_chunk_spans(const Plan &p, const DevCsr &d, const raw_vector<int> &ridM, const raw_vector<int> &lenM,
                         const std::vector<int> &nchunks, int *k16, unsigned long long *narrow_mask);      // narrow_mask: nullptr or [blocks] (plan.cpp)
 int devpack_all(Plan &p, const DevCsr &d, const PackMeta &m);
 
