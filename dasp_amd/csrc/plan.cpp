@@ -481,6 +481,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             const long long xl = p.opt.n_parts > 0 ? (long long)p.opt.n_parts * p.opt.part_stride : (long long)p.n;
             std::vector<int> hmin(nW), hlen(nW);
             std::vector<long long> hin(nW);
+            const bool force_sort = std::getenv("DASP_HYBRID_SORT") != nullptr;       // test knob: the sort-based search (tests compare the two)
             // auto mode on a large matrix: the densest spans of 64 evenly spaced windows first -- when they hold under 55 % of those
             // windows' gathers the whole will not reach 60 %, and sorting every window's columns is skipped (HV15R: 0.33 s of the host
             // path, its three-plane rows give 33 %; nlpkkt160: 0.45 s, ~50 %)
@@ -490,15 +491,35 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             for (int pass = sampled ? 0 : 1; pass < 2; ++pass) {
             if (pass == 1) { wlist.resize((size_t)nW); for (int w = 0; w < nW; ++w) wlist[(size_t)w] = w; }
             parallel_for((long long)wlist.size(), threads, 4, [&](long long w0, long long w1) {
-                std::vector<int> cols;
+                std::vector<int> cols, hist;
                 for (long long wi = w0; wi < w1; ++wi) {
                     const int w = wlist[(size_t)wi];
                     const int a0 = (int)w * R, a1 = std::min(nmed, a0 + R);
                     cols.clear();
-                    for (int i = a0; i < a1; ++i) { const int r = ridW[i]; for (int j = rp[r]; j < rp[r + 1]; ++j) cols.push_back(remap(ci[j])); }
-                    std::sort(cols.begin(), cols.end());
-                    // best 16-byte-aligned start: for every distinct aligned start taken from an entry, count the entries in [s, s + cap_cols)
+                    int cmin_w = 2147483647, cmax_w = -1;
+                    for (int i = a0; i < a1; ++i) {
+                        const int r = ridW[i];
+                        for (int j = rp[r]; j < rp[r + 1]; ++j) { const int c = remap(ci[j]); cols.push_back(c); cmin_w = std::min(cmin_w, c); cmax_w = std::max(cmax_w, c); }
+                    }
+                    // best 16-byte-aligned start: for every aligned start that holds an entry, the entries in [start, start + cap_cols); the
+                    // first start with the largest count wins.  (An entry c that is not the smallest of its aligned group counts fewer entries
+                    // than the group's smallest one -- which is itself inside [group start, c) -- so only group starts compete.)
                     long long best = 0; int bs = 0;
+                    const long long g0 = cols.empty() ? 0 : cmin_w / A, ngrp = cols.empty() ? 0 : cmax_w / A - g0 + 1;
+                    if (!cols.empty() && ngrp <= 4 * (long long)cols.size() + 1024 && !force_sort) {
+                        // dense enough: a histogram over the aligned groups and a sliding sum -- O(entries + groups) instead of a sort
+                        hist.assign((size_t)ngrp + 1, 0);
+                        for (int c : cols) hist[(size_t)(c / A - g0)]++;
+                        const long long wg = cap_cols / A;                                  // groups per span
+                        long long run = 0;
+                        for (long long g = 0; g < std::min(wg, ngrp); ++g) run += hist[(size_t)g];
+                        for (long long g = 0; g < ngrp; ++g) {
+                            if (hist[(size_t)g] > 0 && run > best) { best = run; bs = (int)((g0 + g) * A); }
+                            run -= hist[(size_t)g];
+                            if (g + wg < ngrp) run += hist[(size_t)(g + wg)];
+                        }
+                    } else {
+                    std::sort(cols.begin(), cols.end());
                     size_t hi_i = 0;
                     for (size_t lo_i = 0; lo_i < cols.size(); ++lo_i) {
                         if (lo_i && cols[lo_i] == cols[lo_i - 1]) continue;
@@ -508,6 +529,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                         // entries between the aligned start and cols[lo_i] belong to the span too, but they are < A away: ignore them
                         const long long cnt = (long long)(hi_i - lo_i);
                         if (cnt > best) { best = cnt; bs = (int)st; }
+                    }
                     }
                     hmin[w] = bs; hin[w] = best;
                     hlen[w] = (int)std::min<long long>(cap_cols, xl - bs);

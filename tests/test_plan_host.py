@@ -328,6 +328,33 @@ def test_auto_hybrid_windows_need_even_rows_and_keep_the_format(dasp, prec):
     assert st2["x_window_hybrid"] == 0
 
 
+@pytest.mark.parametrize("prec", [64, 16])
+def test_densest_span_histogram_search_equals_the_sort_search(dasp, prec, monkeypatch):
+    """hybrid windows: the densest LDS-sized span of a window's columns is found by a histogram over the 16-byte-aligned column groups
+    and a sliding sum where the window's columns are dense enough (r3: it replaced a sort of every window's columns, 0.43 s of
+    nlpkkt160's preprocessing), by the sort otherwise -- both must pick the same span (first start with the largest count)"""
+    rng = np.random.default_rng(29)
+    m = n = 150000
+    dt = np.float64 if prec == 64 else np.float16
+    rows = np.repeat(np.arange(m), 14)
+    near = rng.random(rows.size) < 0.8
+    ci = np.clip(rows + np.where(near, rng.integers(-2500, 2501, rows.size), rng.integers(-14000, 14001, rows.size)), 0, n - 1).astype(np.int32)
+    rp = (np.arange(m + 1, dtype=np.int64) * 14).astype(np.int32)
+    out = {}
+    for mode in ("hist", "sort"):
+        if mode == "sort":
+            monkeypatch.setenv("DASP_HYBRID_SORT", "1")
+        plan = dasp.Plan(rp, ci, np.ones(ci.size, dt), n, precision=prec, x_window_hybrid=1)
+        st = plan.stats
+        assert st["x_window_on"] == 1 and st["x_window_hybrid"] == 1
+        out[mode] = (plan.host_array("win_cmin").copy(), plan.host_array("win_len").copy(), st["window_nnz_frac"], st["lds_bytes"])
+        plan.close()
+    monkeypatch.delenv("DASP_HYBRID_SORT")
+    np.testing.assert_array_equal(out["hist"][0], out["sort"][0])
+    np.testing.assert_array_equal(out["hist"][1], out["sort"][1])
+    assert out["hist"][2:] == out["sort"][2:] and 0.5 < out["hist"][2] <= 1.0
+
+
 def test_medium_rows_as_pieces_keep_slots_and_counters(dasp, oracle):
     """piece_min_len: the longest medium rows stored as wave-sized pieces -- order_rid and every classifier counter are still the
     oracle's, the packed arrays decode to the rows, the rows concerned sit in the first medium slots"""
