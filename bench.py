@@ -47,7 +47,9 @@ def gather_roofline(nnz, event_ms):
     return {"achieved_Ggathers_per_s": round(g, 1), "peak_ta_Glines_per_s": round(GATHER_PEAK_TA_G, 1),
             "peak_l1_miss_queue_Glines_per_s": round(GATHER_PEAK_L1MISS_G, 1), "frac_of_ta": round(g / GATHER_PEAK_TA_G, 4),
             "frac_of_l1_miss_queue": round(g / GATHER_PEAK_L1MISS_G, 4),
-            "note": "one gather per nonzero; > 1 of the miss-queue bound means gathers hit the L1 / LDS (FEM rows, staged windows)"}
+            "note": "DIAGNOSTIC, not an independent ceiling: the L1-miss-queue figure is Little's law on these kernels' own PMC counters "
+                    "(profiles/r02_gather_pmc.md); it bounds only matrices whose every gather misses the L1 (uniform-column graphs); "
+                    "a value > 1 means the gathers hit the L1 / LDS (FEM rows, staged windows) and the figure does not apply"}
 TOL = {64: 1e-12, 16: 1e-2}   # BASELINE.json north_star, relative to sum_j |a_ij x_j|
 
 
