@@ -263,8 +263,7 @@ def suite_entry(torch, D, O, name, precision, scale, budget_s=2.0):
     plan.close()
     del x, y
     torch.cuda.empty_cache()
-    if st["n_col_panels"] == 0:         # plans that split into column panels need a host CSR (panels are decided and cut on the host)
-        out.update(device_pre_ms(torch, D, rp, ci, rows, cols, precision))
+    out.update(device_pre_ms(torch, D, rp, ci, rows, cols, precision))
     try:
         out["verified_random_x"] = verify_random_x(torch, D, O, rp, ci, cols, precision, time_iters=min(iters, 100))
         rv = out["verified_random_x"].get("random_values_ms")
@@ -729,7 +728,7 @@ def main():
         plan.close()
     del x, y, kx, ky
     torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and mg is None and st["n_col_panels"] == 0:
+    if rank == 0 and world == 1 and mg is None:
         out.update(device_pre_ms(torch, D, rp, ci, rows, cols, prec))
 
     if rank == 0 and world == 1 and mg is None and not args.no_random_x:

@@ -6,6 +6,9 @@
 // the same bytes plan.cpp's host packers produce (tests compare them bit for bit).
 #include <hip/hip_runtime.h>
 
+#include <memory>
+#include <thread>
+
 #include <algorithm>
 #include <cstring>
 #include <string>
@@ -388,6 +391,141 @@ static int pack_all_typed(Plan &p, const DevCsr &d, const PackMeta &m)
     HIP_TRYP(hipGetLastError());
     return DASP_OK;
 }
+
+// ---- column panels of a device-resident CSR (plan.cpp build_panels): the split by column range as two kernels, one wave per row.
+// Lane k (k < P <= 64) holds panel k's counter / write cursor; a chunk of 64 entries is ranked per panel with ballots, so the entries of
+// a row keep their order inside every panel -- the sub-matrices are exactly those of the host split.
+__device__ __forceinline__ int panel_of_dev(const int *bnd, int P, int c)
+{
+    int lo = 0, hi = P;                        // last k with bnd[k] <= c
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (bnd[mid] <= c) lo = mid; else hi = mid; }
+    return lo;
+}
+__global__ void k_panel_count(const int *rp, const int *ci, int m, RemapDev remap, const int *bnd, int P, int *cnt /* [P][m + 1] */)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= m) return;
+    const int a0 = rp[i], a1 = rp[i + 1];
+    int mine = 0;
+    for (int j0 = a0; j0 < a1; j0 += 64) {
+        const int j = j0 + lane;
+        const int k = j < a1 ? panel_of_dev(bnd, P, remap(ci[j])) : -1;
+        for (int q = 0; q < P; ++q) {
+            const int tot = __popcll(__ballot(k == q));
+            if (lane == q) mine += tot;
+        }
+    }
+    if (lane < P) cnt[(size_t)lane * ((size_t)m + 1) + (size_t)i + 1] = mine;
+}
+template <class T>
+__global__ void k_panel_scatter(const int *rp, const int *ci, const T *val, int m, RemapDev remap, const int *bnd, int P,
+                                const int *rpP /* [P][m + 1], scanned */, int *const *ciP, T *const *valP)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= m) return;
+    const int a0 = rp[i], a1 = rp[i + 1];
+    int cursor = lane < P ? rpP[(size_t)lane * ((size_t)m + 1) + (size_t)i] : 0;
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int j0 = a0; j0 < a1; j0 += 64) {
+        const int j = j0 + lane;
+        const bool in = j < a1;
+        const int c = in ? remap(ci[j]) : 0;
+        const int k = in ? panel_of_dev(bnd, P, c) : -1;
+        int at = 0;
+        for (int q = 0; q < P; ++q) {
+            const unsigned long long mask = __ballot(k == q);
+            const int base = __shfl(cursor, q);
+            if (k == q) at = base + __popcll(mask & below);
+            if (lane == q) cursor += __popcll(mask);
+        }
+        if (in) { ciP[k][at] = c; valP[k][at] = val[j]; }
+    }
+}
+
+// splits the device CSR `d` of plan `p` into P column ranges [bnd[k], bnd[k + 1]).  rpP_host[k] = the panel's row pointer (host copy);
+// out[k] = its device CSR (columns already remapped).  The device arrays are owned by `keep` (freed with it).
+int devpack_panel_split(const Plan &p, const DevCsr &d, const std::vector<int> &bnd, int P, std::vector<std::vector<int>> &rpP_host,
+                        std::vector<DevCsr> &out, std::vector<std::shared_ptr<void>> &keep)
+{
+    const int m = p.m;
+    const size_t vb = (size_t)p.geo.vbytes, row = (size_t)m + 1;
+    auto dmalloc = [&](size_t bytes, void **ptr) -> int {
+        if (hipMalloc(ptr, std::max<size_t>(bytes, 16)) != hipSuccess) { set_error("hipMalloc (column-panel split)"); return DASP_ERR_HIP; }
+        keep.emplace_back(*ptr, [](void *q) { (void)hipFree(q); });
+        return DASP_OK;
+    };
+    RemapHolder rm; if (int rc = rm.init(p)) return rc;
+    DevVec<int> dbnd; if (int rc = dbnd.init(bnd)) return rc;
+    void *cnt = nullptr;
+    if (int rc = dmalloc(row * (size_t)P * sizeof(int), &cnt)) return rc;
+    HIP_TRYP(hipMemset(cnt, 0, row * (size_t)P * sizeof(int)));
+    if (m > 0) hipLaunchKernelGGL(k_panel_count, dim3(waves_grid(m)), dim3(256), 0, 0, d.rp, d.ci, m, rm.r, dbnd.d, P, static_cast<int *>(cnt));
+    HIP_TRYP(hipGetLastError());
+    std::vector<int> flat(row * (size_t)P);
+    HIP_TRYP(hipMemcpy(flat.data(), cnt, flat.size() * sizeof(int), hipMemcpyDeviceToHost));
+    rpP_host.assign((size_t)P, std::vector<int>());
+    {
+        std::vector<std::thread> th;
+        for (int k = 0; k < P; ++k)
+            th.emplace_back([&, k] {
+                int *q = flat.data() + (size_t)k * row;
+                for (int i = 0; i < m; ++i) q[i + 1] += q[i];
+                rpP_host[(size_t)k].assign(q, q + row);
+            });
+        for (auto &t : th) t.join();
+    }
+    HIP_TRYP(hipMemcpy(cnt, flat.data(), flat.size() * sizeof(int), hipMemcpyHostToDevice));         // the scanned row pointers, all panels
+    std::vector<int *> h_ci((size_t)P, nullptr);
+    std::vector<void *> h_val((size_t)P, nullptr);
+    out.assign((size_t)P, DevCsr{nullptr, nullptr, nullptr});
+    for (int k = 0; k < P; ++k) {
+        const size_t nk = (size_t)rpP_host[(size_t)k][(size_t)m];
+        void *a = nullptr, *b = nullptr;
+        if (int rc = dmalloc(nk * sizeof(int), &a)) return rc;
+        if (int rc = dmalloc(nk * vb, &b)) return rc;
+        h_ci[(size_t)k] = static_cast<int *>(a); h_val[(size_t)k] = b;
+        out[(size_t)k] = DevCsr{static_cast<const int *>(cnt) + (size_t)k * row, static_cast<const int *>(a), b};
+    }
+    void *pc = nullptr, *pv = nullptr;
+    if (int rc = dmalloc((size_t)P * sizeof(void *), &pc)) return rc;
+    if (int rc = dmalloc((size_t)P * sizeof(void *), &pv)) return rc;
+    HIP_TRYP(hipMemcpy(pc, h_ci.data(), (size_t)P * sizeof(void *), hipMemcpyHostToDevice));
+    HIP_TRYP(hipMemcpy(pv, h_val.data(), (size_t)P * sizeof(void *), hipMemcpyHostToDevice));
+    if (m > 0) {
+        if (p.precision == 64)
+            hipLaunchKernelGGL((k_panel_scatter<double>), dim3(waves_grid(m)), dim3(256), 0, 0, d.rp, d.ci, static_cast<const double *>(d.val), m, rm.r, dbnd.d, P,
+                               static_cast<const int *>(cnt), static_cast<int *const *>(pc), static_cast<double *const *>(pv));
+        else
+            hipLaunchKernelGGL((k_panel_scatter<_Float16>), dim3(waves_grid(m)), dim3(256), 0, 0, d.rp, d.ci, static_cast<const _Float16 *>(d.val), m, rm.r, dbnd.d, P,
+                               static_cast<const int *>(cnt), static_cast<int *const *>(pc), static_cast<_Float16 *const *>(pv));
+    }
+    HIP_TRYP(hipGetLastError());
+    HIP_TRYP(hipDeviceSynchronize());
+    return DASP_OK;
+}
+
+// remapped column ids at arbitrary nonzero positions, back on the host: the samples the automatic column-panel rule looks at
+__global__ void k_gather_cols(const int *ci, const long long *idx, long long n, long long start, long long stride, RemapDev remap, int *out)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = remap(ci[idx ? idx[i] : start + i * stride]);
+}
+int devpack_gather_columns(const Plan &p, const DevCsr &d, const std::vector<long long> *idx, long long start, long long stride, long long count, std::vector<int> &out)
+{
+    const long long n = idx ? (long long)idx->size() : count;
+    out.assign((size_t)std::max<long long>(n, 0), 0);
+    if (n <= 0) return DASP_OK;
+    RemapHolder rm; if (int rc = rm.init(p)) return rc;
+    DevVec<long long> di;
+    if (idx) { if (int rc = di.init(*idx)) return rc; }
+    DevBuf<int> dout; if (int rc = dout.init((size_t)n)) return rc;
+    hipLaunchKernelGGL(k_gather_cols, dim3((unsigned)std::min<long long>(4096, (n + 255) / 256)), dim3(256), 0, 0, d.ci, idx ? di.d : nullptr, n, start, stride, rm.r, dout.d);
+    HIP_TRYP(hipGetLastError());
+    HIP_TRYP(hipMemcpy(out.data(), dout.d, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    return DASP_OK;
+}
+
+int devpack_finish_panels(Plan &p) { return upload_plan(p); }
 
 int devpack_all(Plan &p, const DevCsr &d, const PackMeta &m)
 {

@@ -145,8 +145,8 @@ constexpr int kSlabDefaultF64 = 16, kSlabDefaultF16 = 24;
 
 enum BuildMode { kTop = 0, kMetaOnly = 1, kPanel = 2 };   // whole plan (may choose column panels) / order+stats only / one panel
 
-template <class T> static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int P);
-static int decide_panels(const Plan &p, const int *rp, const int *ci, const Remap &remap, bool dev);
+template <class T> static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int P, const DevCsr *dev);
+static int decide_panels(const Plan &p, const int *rp, const int *ci, const Remap &remap, const DevCsr *dev);
 
 template <class T>
 static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const DevCsr *dev, BuildMode mode = kTop)
@@ -185,9 +185,9 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
 
     lap("validate");
     if (mode == kTop) {
-        const int P = decide_panels(p, rp, ci, remap, dev != nullptr);
+        const int P = decide_panels(p, rp, ci, remap, dev);
         if (P < 0) return P;
-        if (P >= 2) return build_panels<T>(p, rp, ci, val, P);
+        if (P >= 2) return build_panels<T>(p, rp, ci, val, P, dev);
     }
     // ---- classifier: same tests in the same order as dasp_f64.h:499-531.  Two passes over row ranges (count, then fill from the
     // ranges' prefix sums): every list comes out in row order, exactly what the reference's serial loop produces.
@@ -961,7 +961,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     s.window_nnz_frac = window_frac;
     s.x_window_hybrid = p.win_hybrid ? 1 : 0;
     if (p.windowed) { const int wpw = std::min(16, p.row_window / kMedRows); s.n_workgroups = ceil_div(s.n_long_pieces, wpw) + s.n_windows + ceil_div(s.n_short_tiles, wpw); }
-    if (dev) {   // the O(nnz) copies happen on the GPU; the plan comes back uploaded
+    if (dev && !meta_only) {   // the O(nnz) copies happen on the GPU; the plan comes back uploaded
         PackMeta meta;
         meta.ridL = &ridL; meta.startL = &startL; meta.ridM = &ridM; meta.lenM = &lenM;
         for (int g = 0; g < kNumShortGroups; ++g) meta.glist[g] = glist[g];
@@ -981,15 +981,11 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
 // ---- column panels (opt.col_panels; DESIGN.md section 4 "column panels") -------------------------------------------------
 // auto rule: only matrices whose rows scatter over more x than an XCD's L2 holds gain from cache blocking; anything with
 // locality (FEM / stencil rows touch runs of neighbouring columns, banded rows stay inside a narrow span) is left alone.
-static int decide_panels(const Plan &p, const int *rp, const int *ci, const Remap &remap, bool dev)
+static int decide_panels(const Plan &p, const int *rp, const int *ci, const Remap &remap, const DevCsr *dev)
 {
     const int want = p.opt.col_panels;
     if (want == 1 || want < 0) return 1;
     if (want > 64) { set_error("col_panels must be <= 64"); return DASP_ERR_ARG; }
-    if (dev) {
-        if (want >= 2) { set_error("col_panels needs the CSR on the host (dasp_plan_create)"); return DASP_ERR_ARG; }
-        return 1;
-    }
     if (!p.dst_map.empty()) return 1;
     if (want >= 2) return p.nnz > 0 && p.m > 0 ? want : 1;
     const long long xlen = p.opt.n_parts > 0 ? (long long)p.opt.n_parts * p.opt.part_stride : (long long)p.n;
@@ -999,13 +995,26 @@ static int decide_panels(const Plan &p, const int *rp, const int *ci, const Rema
     const int S = 4096;
     long long entries = 0, lines = 0, wide = 0;
     std::vector<int> cols;
+    // device CSR (r3): the sampled rows' column ids are gathered by a kernel and copied over (<= 2 M ids), the rule itself is the same
+    std::vector<int> fetched;
+    if (dev) {
+        std::vector<long long> idx;
+        for (int s = 0; s < S; ++s) {
+            const int r = (int)((long long)p.m * s / S), len = rp[r + 1] - rp[r];
+            if (len < 4) continue;
+            for (int j = 0; j < std::min(len, 512); ++j) idx.push_back((long long)rp[r] + j);
+        }
+        if (int rc = devpack_gather_columns(p, *dev, &idx, 0, 0, 0, fetched)) return rc;
+    }
+    size_t fpos = 0;
     for (int s = 0; s < S; ++s) {
         const int r = (int)((long long)p.m * s / S);
         const int len = rp[r + 1] - rp[r];
         if (len < 4) continue;
         const int take = std::min(len, 512);
         cols.resize((size_t)take);
-        for (int j = 0; j < take; ++j) cols[j] = remap(ci[rp[r] + j]);
+        if (dev) { for (int j = 0; j < take; ++j) cols[j] = fetched[fpos + (size_t)j]; fpos += (size_t)take; }
+        else for (int j = 0; j < take; ++j) cols[j] = remap(ci[rp[r] + j]);
         std::sort(cols.begin(), cols.end());
         int distinct = 1;
         for (int j = 1; j < take; ++j) distinct += (cols[j] >> line_shift) != (cols[j - 1] >> line_shift);
@@ -1021,6 +1030,11 @@ static int decide_panels(const Plan &p, const int *rp, const int *ci, const Rema
         std::vector<int> hist((size_t)xlines, 0);
         const long long S2 = std::min<long long>(p.nnz, 1ll << 21), stride = std::max<long long>(1, p.nnz / S2);
         long long taken = 0;
+        if (dev) {
+            const long long cnt = (p.nnz + stride - 1) / stride;
+            if (int rc = devpack_gather_columns(p, *dev, nullptr, 0, stride, cnt, fetched)) return rc;
+            for (int c : fetched) { hist[(size_t)(c >> line_shift)]++; ++taken; }
+        } else
         for (long long j = 0; j < p.nnz; j += stride) { hist[(size_t)(remap(ci[j]) >> line_shift)]++; ++taken; }
         const size_t cap = (size_t)((3ll << 20) / 128);
         long long hot = 0;
@@ -1041,11 +1055,11 @@ static int decide_panels(const Plan &p, const int *rp, const int *ci, const Rema
 }
 
 template <class T>
-static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int P)
+static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int P, const DevCsr *dev)
 {
     using clk = std::chrono::steady_clock;
     const auto t_begin = clk::now();
-    // whole-matrix classification: order_rid and the reference's counters are those of the unsplit matrix
+    // whole-matrix classification: order_rid and the reference's counters are those of the unsplit matrix (row lengths only)
     if (int rc = build_impl<T>(p, rp, ci, val, nullptr, kMetaOnly)) return rc;
     const int m = p.m;
     const int threads = resolve_threads(p.opt.host_threads);
@@ -1059,6 +1073,12 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
 
     // split the CSR by column range: count, prefix, scatter (row-parallel; the rows' internal order is kept)
     std::vector<std::vector<int>> rpP((size_t)P);
+    std::vector<raw_vector<int>> ciP((size_t)P);
+    std::vector<raw_vector<T>> valP((size_t)P);
+    std::vector<DevCsr> devP;                          // device CSR: the same split by two kernels (devpack.hip), sub-matrices stay on the GPU
+    std::vector<std::shared_ptr<void>> dev_keep;
+    if (dev) { if (int rc = devpack_panel_split(p, *dev, bnd, P, rpP, devP, dev_keep)) return rc; }
+    else {
     for (auto &v : rpP) v.assign((size_t)m + 1, 0);
     parallel_for(m, threads, 1 << 12, [&](long long b, long long e) {
         for (long long i = b; i < e; ++i)
@@ -1067,8 +1087,6 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     parallel_for(P, threads, 1, [&](long long k0, long long k1) {
         for (long long k = k0; k < k1; ++k) { int *q = rpP[k].data(); for (int i = 0; i < m; ++i) q[i + 1] += q[i]; }
     });
-    std::vector<raw_vector<int>> ciP((size_t)P);
-    std::vector<raw_vector<T>> valP((size_t)P);
     for (int k = 0; k < P; ++k) { ciP[k].resize((size_t)rpP[k][m]); valP[k].resize((size_t)rpP[k][m]); }
     parallel_for(m, threads, 1 << 12, [&](long long b, long long e) {
         std::vector<int> cur((size_t)P);
@@ -1080,6 +1098,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
             }
         }
     });
+    }
 
     const bool natural = p.opt.y_order == DASP_Y_NATURAL;
     std::vector<int> slot_of_row;
@@ -1091,11 +1110,10 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     std::vector<int> rcs((size_t)P, DASP_OK);
     std::vector<std::string> errs((size_t)P);
     {
-        const int side = std::min(P, threads), each = std::max(1, threads / side);
+        const int side = dev ? 1 : std::min(P, threads), each = std::max(1, threads / side);       // device path: one panel at a time (its kernels fill the GPU)
         std::atomic<int> next{0};
         std::vector<std::thread> workers;
-        for (int t = 0; t < side; ++t)
-            workers.emplace_back([&] {
+        auto work = [&] {
                 for (int k = next++; k < P; k = next++) {
                     const int nnz_k = rpP[k][m];
                     if (nnz_k == 0) continue;                       // an empty panel adds nothing
@@ -1107,15 +1125,16 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
                     q.opt.col_panels = 1; q.opt.host_threads = each;
                     if (q.opt.stream_policy == 0) q.opt.stream_policy = streams ? 2 : 1;   // the policy follows the whole matrix, not one panel
                     q.dst_map = slot_of_row; q.panel = true;
-                    try { rcs[k] = build_impl<T>(q, rpP[k].data(), ciP[k].data(), valP[k].data(), nullptr, kPanel); }
+                    try { rcs[k] = build_impl<T>(q, rpP[k].data(), dev ? nullptr : ciP[k].data(), dev ? nullptr : valP[k].data(), dev ? &devP[(size_t)k] : nullptr, kPanel); }
                     catch (const std::bad_alloc &) { rcs[k] = DASP_ERR_NOMEM; set_error("out of host memory"); }
                     if (rcs[k] != DASP_OK) { errs[k] = last_error_cstr(); continue; }
                     q.opt.host_threads = p.opt.host_threads;
                     std::vector<int>().swap(rpP[k]); raw_vector<int>().swap(ciP[k]); raw_vector<T>().swap(valP[k]);
                     built[k] = std::move(h);
                 }
-            });
-        for (auto &w : workers) w.join();
+            };
+        if (dev) work();                                  // in the calling thread: it holds the caller's current HIP device
+        else { for (int t = 0; t < side; ++t) workers.emplace_back(work); for (auto &w : workers) w.join(); }
     }
     for (int k = 0; k < P; ++k) {
         if (rcs[k] != DASP_OK) { set_error(errs[k]); return rcs[k]; }
@@ -1149,6 +1168,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     // packed panels + x once + every panel's partial y written and read back + y
     s.data_X = dataX + xlen * vb + (long long)(2 * K + 1) * m * vb;
     s.n_col_panels = K;
+    if (dev) { if (int rc = devpack_finish_panels(p)) return rc; }      // a device-built plan comes back uploaded: the parent's partial-result buffers too
     s.pre_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
     return DASP_OK;
 }

@@ -210,6 +210,12 @@ int devpack_row_coherence(const Plan &p, const DevCsr &d, const std::vector<int>
 int devpack_chunk_spans(const Plan &p, const DevCsr &d, const raw_vector<int> &ridM, const raw_vector<int> &lenM,
                         const std::vector<int> &nchunks, int *k16, unsigned long long *narrow_mask);      // narrow_mask: nullptr or [blocks] (plan.cpp)
 int devpack_all(Plan &p, const DevCsr &d, const PackMeta &m);
+int devpack_finish_panels(Plan &p);
+// remapped column ids at the nonzero positions idx[] (or start + i * stride for i < count when idx is null), copied to the host
+int devpack_gather_columns(const Plan &p, const DevCsr &d, const std::vector<long long> *idx, long long start, long long stride, long long count, std::vector<int> &out);      // uploads the parent of device-built panels (its partial-result buffers)
+// column-panel split of a device CSR: P sub-matrices by column range (remapped columns, row order kept); `keep` owns the device arrays
+int devpack_panel_split(const Plan &p, const DevCsr &d, const std::vector<int> &bnd, int P, std::vector<std::vector<int>> &rpP_host,
+                        std::vector<DevCsr> &out, std::vector<std::shared_ptr<void>> &keep);
 
 // builds every host array of `p` from CSR.  T = double or _Float16.  With `dev` set, rp is a host copy of the row pointer,
 // ci / val are ignored and the nnz-sized arrays are produced on the device (the plan comes back uploaded).

@@ -121,7 +121,7 @@ typedef struct dasp_options {
      * kernel adds the panels' partial results.  order_rid and the classifier counters stay those of the whole matrix.
      *   0 = auto (on for matrices whose rows scatter over more x than the L2 holds: x > 4 MiB, >= 16 M nonzeros,
      *       > 75 % of a row's nonzeros on distinct 128-byte lines of x, rows spanning > x/4, and < 80 % of the gathers on the
-     *       hottest 3 MiB of x lines; host CSR only),
+     *       hottest 3 MiB of x lines; for a device-resident CSR the samples are gathered by a kernel and the split runs on the GPU),
      *   1 or -1 = off,  2..64 = that many panels.
      * f16: the per-panel partial results are rounded to binary16 before they are added (in f32). */
     int col_panels;
@@ -193,8 +193,9 @@ int dasp_plan_create(dasp_plan_t **plan, int precision, int rowA, int colA, int 
                      const int *csrRowPtr, const int *csrColIdx, const void *csrVal,
                      const dasp_options_t *opt /* NULL = defaults */);
 /* the same with the CSR already on the current HIP device (dRowPtr / dColIdx / dVal are device pointers): only the row
- * pointer visits the host; the nonzeros are range-checked, scanned and packed by kernels.  The plan comes
- * back uploaded and produces bit-identical packed arrays to dasp_plan_create. */
+ * pointer visits the host; the nonzeros are range-checked, scanned, split into column panels where the plan uses them, and packed by
+ * kernels.  The plan comes back uploaded and produces bit-identical packed arrays to dasp_plan_create, with the same
+ * automatic choices (only hybrid x windows are decided on a host CSR alone). */
 int dasp_plan_create_device(dasp_plan_t **plan, int precision, int rowA, int colA, int nnzA,
                             const int *dRowPtr, const int *dColIdx, const void *dVal, const dasp_options_t *opt);
 /* copy one nnz-sized packed array (names as dasp_plan_host_array) from the device arena to `dst` (tests, serialisation) */

@@ -869,12 +869,67 @@ def test_column_panels_multi_gpu_layout_and_file(oracle, dasp, torch_cuda, tmp_p
         pl.close()
 
 
-def test_column_panels_need_a_host_csr(dasp, torch_cuda):
+@pytest.mark.parametrize("name,prec", [("powerlaw_1M", 64), ("ljournal-2008", 16), ("rmat_2M", 16)])
+def test_device_csr_takes_the_same_automatic_panel_decision(dasp, torch_cuda, name, prec):
+    """the AUTOMATIC column-panel rule on a device-resident CSR (r3): the sampled rows' columns and the strided sample of column ids
+    are gathered by a kernel, the rule is the host's -- same number of panels, same counters, same y, at BASELINE's full size"""
     torch = torch_cuda
-    rp, ci, v = util.mixed_matrix(500, 400, 3)
-    d = [torch.from_numpy(a).cuda() for a in (rp, ci, v)]
-    with pytest.raises(dasp.DaspError):
-        dasp.Plan.from_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), 500, 400, ci.size, col_panels=2)
+    rows, cols = dasp.synth_dims(name, 1.0)
+    rp, ci = dasp.synth_csr(name, 1.0)
+    dt = np.float64 if prec == 64 else np.float16
+    v = np.ones(ci.size, dt)
+    host = dasp.Plan(rp, ci, v, cols, precision=prec)
+    d_rp, d_ci, d_v = torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(v).cuda()
+    dev = dasp.Plan.from_device(d_rp.data_ptr(), d_ci.data_ptr(), d_v.data_ptr(), rows, cols, int(rp[-1]), precision=prec)
+    hs, ds = host.stats, dev.stats
+    hs.pop("pre_ms"), ds.pop("pre_ms")
+    assert hs == ds and (hs["n_col_panels"] >= 2) == (name != "rmat_2M")
+    assert (host.order_rid == dev.order_rid).all()
+    x = np.ones(cols, dt)
+    y_d = run_spmv(torch, dev, x, rows, prec)
+    dev.close()
+    y_h = run_spmv(torch, host.upload(), x, rows, prec)
+    assert np.array_equal(y_h, y_d)
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("kw", [dict(col_panels=3), dict(col_panels=4, cid16=1, y_order=1), dict(col_panels=2, x_window=-1, long_piece=256)])
+def test_device_built_column_panels_are_bit_identical(oracle, dasp, torch_cuda, prec, kw):
+    """r3: explicit column panels from a CSR that lives on the GPU -- the split by column range runs as two kernels (one wave per
+    row, the entries of a row ranked per panel with ballots so they keep their order), every panel is packed on the device: the
+    same panels, array by array, as dasp_plan_create builds on the host, and the same y.  (The AUTOMATIC panel rule still samples a
+    host CSR.)"""
+    torch = torch_cuda
+    dt = np.float64 if prec == 64 else np.float16
+    m, n = 3000, 5000
+    rp, ci, v = util.mixed_matrix(m, n, 17, values="f16" if prec == 16 else "uniform", dtype=dt)
+    host = dasp.Plan(rp, ci, v, n, precision=prec, **kw)
+    d_rp, d_ci, d_v = torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(v).cuda()
+    dev = dasp.Plan.from_device(d_rp.data_ptr(), d_ci.data_ptr(), d_v.data_ptr(), m, n, int(rp[-1]), precision=prec, **kw)
+    hs, ds = host.stats, dev.stats
+    hs.pop("pre_ms"), ds.pop("pre_ms")
+    assert hs == ds and hs["n_col_panels"] == kw["col_panels"]
+    assert (host.order_rid == dev.order_rid).all()
+    for k in range(hs["n_col_panels"]):
+        (hp, hb, he), (dp, db, de) = host.panel(k), dev.panel(k)
+        assert (hb, he) == (db, de)
+        a, b = hp.stats, dp.stats
+        a.pop("pre_ms"), b.pop("pre_ms")
+        assert a == b
+        assert (hp.order_rid == dp.order_rid).all()
+        for name in META_ARRAYS:
+            assert np.array_equal(hp.host_array(name), dp.host_array(name)), (k, name)
+        for name in NNZ_ARRAYS:
+            h = hp.host_array(name)
+            assert np.array_equal(h, dp.device_array(name, h.size, h.dtype)), (k, name)
+    x = (np.random.default_rng(3).uniform(0.5, 1.5, dev.x_len)).astype(dt)
+    y_h = run_spmv(torch, host.upload(), x, m, prec)
+    y_d = run_spmv(torch, dev, x, m, prec)
+    assert np.array_equal(y_h, y_d)
+    ref = oracle.csr_spmv(rp, ci, v.astype(np.float64), x.astype(np.float64))
+    scale = np.maximum(oracle.csr_absrow(rp, ci, v.astype(np.float64), x.astype(np.float64)), 1e-300)
+    perm = np.arange(m) if kw.get("y_order") == 1 else dev.order_rid
+    assert (np.abs(y_d - ref[perm]) <= TOL[prec] * scale[perm]).all()
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("DASP_TEST_SEEDS", "24"))))      # DASP_TEST_SEEDS=2000 for a soak run
