@@ -318,7 +318,9 @@ class Watchdog:
 
     def __init__(self, rank, limit_s, args):
         import threading
-        self.rank, self.limit, self.args = rank, limit_s, args
+        # staggered: when one rank is stuck every rank stops making progress (they wait for it in a collective), and rank 0 -- the one that
+        # prints the line -- must be the first whose limit runs out, before the launcher tears the job down on another rank's exit
+        self.rank, self.limit, self.args = rank, limit_s + 3.0 * rank if limit_s > 0 else 0, args
         self.t, self.phase = time.time(), "start"
         if limit_s > 0:
             threading.Thread(target=self._run, daemon=True).start()
