@@ -516,6 +516,36 @@ def test_fused_mg_step_every_row_category(dasp, torch_cuda, seed, kw):
     np.testing.assert_array_equal(res[True], res[False])
 
 
+def test_fused_mg_step_without_other_column_nonzeros(dasp, torch_cuda):
+    """a block-diagonal matrix: a rank's rows touch its own columns only, so there is no other-column plan and no waiting workgroup --
+    the last own-column workgroup publishes "y ready" itself.  20 chained dasp_mg_spmv without host synchronisation (the exchange's
+    wait kernel must see every step's flag: no time-out), result == the rank's diagonal block applied 20 times."""
+    import scipy.sparse as sp
+    from dasp_amd.multi import MgPlan
+    m = 6000
+    bounds = np.array([0, 3000, 6000], np.int32)
+    rank = 1
+    rp, ci, v = util.mixed_matrix(3000, 3000, 41, lengths=[0, 1, 2, 3, 4, 7, 12, 30, 64, 300])
+    lens = np.diff(rp)
+    v = v / np.maximum(np.repeat(lens, lens), 1)
+    B = sp.csr_matrix((v.copy(), ci.copy(), rp.copy()), shape=(3000, 3000))
+    mg = MgPlan(rp, ci + 3000, v, m, m, bounds, rank, cid16=1, x_window=-1).upload()       # global column ids: all inside [3000, 6000)
+    assert mg.info["fused_step"] == 1 and mg.nnz_remote == 0 and mg.subplan(1) is None
+    mg.set_fake_exchange(10)
+    x0 = np.random.default_rng(6).uniform(0.5, 1.5, m)
+    mg.set_x(x0)
+    for _ in range(20):
+        mg.spmv(0)
+    mg.wait(0)
+    mg.check()
+    want = x0[3000:].copy()
+    for _ in range(20):
+        want = B @ want
+    got = mg.get_y_local()
+    assert np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), 1e-300)
+    mg.close()
+
+
 def test_fused_mg_step_waits_in_the_kernel_and_times_out_cleanly(dasp, torch_cuda, monkeypatch):
     """One rank of a 2-way partition, 30 chained steps with NO host synchronisation between them and an emulated exchange of
     60 us: the other-column workgroups really wait inside the kernel for the previous exchange.  The peer's half of x never
