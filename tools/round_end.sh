@@ -1,0 +1,11 @@
+#!/bin/bash
+# tools/round_end.sh -- the measurement batch behind profiles/r03_*: run through gpurun from the repo root, then `python tools/traffic_collect.py` here.
+#   full -m gpu suite | PMC traffic of every workload (tools/traffic_all.sh) | bench.py (full record) | rocprofv3 --kernel-trace --stats of the bench command | all-ranks multi-GPU step probe
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+python -m pytest tests -m gpu -x -q > gpurun_out/round_end_tests.log 2>&1; tail -2 gpurun_out/round_end_tests.log
+bash tools/traffic_all.sh > gpurun_out/round_end_traffic.log 2>&1
+python bench.py > gpurun_out/round_end_bench.json.log 2> gpurun_out/round_end_bench.err
+export TMPDIR=/tmp
+rm -rf gpurun_out/round_end_prof
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/round_end_prof -- python3 $GRAFT_REPO_ROOT/bench.py --no-suite --no-vendor --steps 20 > $GRAFT_REPO_ROOT/gpurun_out/round_end_prof.log 2>&1)
+PROBE_FULL=1 PROBE_AG_US=0,20,40,60 timeout 1500 python tools/mg_step_probe.py 8 HV15R all > gpurun_out/round_end_mg_allranks.log 2>&1; tail -9 gpurun_out/round_end_mg_allranks.log
