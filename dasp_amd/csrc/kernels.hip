@@ -944,20 +944,21 @@ __global__ __launch_bounds__(256, kMinWavesPlain) void dasp_mg_step_kernel(DevAr
 
 // the exchange side of the fused step, on the communication stream: hold the stream until *p >= need (the product's "y ready"),
 // and publish a step number behind the exchange.  Plain kernels on plain device words: no stream memory operations (Beta API).
+// Neither needs a fence of its own: what the wait kernel orders is the NEXT kernel on its stream (the exchange), which acquires at its
+// start like every kernel; what the flag kernel publishes was written by the PREVIOUS kernel on its stream, released at that kernel's
+// end -- a release fence in a one-lane kernel is a buffer_wbl2 under the running product (rocprofv3: 6.5 us per flag kernel with it).
 __global__ void dasp_mg_wait_kernel(const unsigned long long *p, unsigned long long need, long long timeout, int *err)
 {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
-    // relaxed polls (an acquire load invalidates the caches on every iteration, under the running product), ONE acquire at the end
     while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need) {
         __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > timeout) { __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 __global__ void dasp_mg_flag_kernel(unsigned long long *p, unsigned long long v)
 {
-    if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // stage 2 for long rows cut into several pieces (reference: longPart_sum, dasp_f64.h:53-75)
