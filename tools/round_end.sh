@@ -4,6 +4,8 @@
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 python -m pytest tests -m gpu -x -q > gpurun_out/round_end_tests.log 2>&1; tail -2 gpurun_out/round_end_tests.log
 bash tools/traffic_all.sh > gpurun_out/round_end_traffic.log 2>&1
+# profiles/traffic.json at this build's kernel revision BEFORE the bench runs (the bench attaches an entry only when the revisions match); copies travel back in gpurun_out/
+python tools/traffic_collect.py > gpurun_out/round_end_traffic_collect.log 2>&1 && cp profiles/traffic.json gpurun_out/round_end_traffic.json && cp profiles/r03_traffic.md gpurun_out/round_end_traffic.md
 python bench.py > gpurun_out/round_end_bench.json.log 2> gpurun_out/round_end_bench.err
 export TMPDIR=/tmp
 rm -rf gpurun_out/round_end_prof
