@@ -93,6 +93,7 @@ bool mg_step_supported(const Plan &own, const Plan *other);
 // blocks that the marks assume (blocks holding such rows first).
 void mg_step_marks(const Plan &own, const unsigned char *has_other, std::vector<unsigned char> &mark, std::vector<int> &blk_order);
 int launch_mg_step(Plan &own, Plan *other, const void *x_own, const void *x_gathered, void *y, const MgStepCtl &c, void *stream);
+int mg_step_resident_per_cu();
 int launch_mg_wait(const void *word, unsigned long long need, long long timeout_ticks, void *err, void *stream);
 int launch_mg_flag(void *word, unsigned long long value, void *stream);
 

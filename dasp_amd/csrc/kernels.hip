@@ -1400,6 +1400,16 @@ int launch_mg_step(Plan &own, Plan *other, const void *x_own, const void *x_gath
     return DASP_OK;
 }
 
+// workgroups of the step kernel one CU holds at a time (multigpu.cpp keeps one of them free of waiting workgroups)
+int mg_step_resident_per_cu()
+{
+    int a = 0, b = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void *>(&dasp_mg_step_kernel<true>), 256, 0) != hipSuccess) a = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void *>(&dasp_mg_step_kernel<false>), 256, 0) != hipSuccess) b = 0;
+    (void)hipGetLastError();
+    return std::min(a, b);
+}
+
 int launch_mg_wait(const void *word, unsigned long long need, long long timeout_ticks, void *err, void *stream)
 {
     hipLaunchKernelGGL(dasp_mg_wait_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<const unsigned long long *>(word), need,

@@ -467,7 +467,10 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
             hipDeviceProp_t prop;
             int cus = 256;
             if (hipGetDeviceProperties(&prop, g.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-            int per_cu = 4;        // of the ~5 workgroups of the step kernel a CU holds: the rest stays free for the exchange's kernel
+            // waiting workgroups per CU: one slot fewer than the step kernel's residency (5 at its 82 registers), so that the exchange's
+            // kernel always finds a free slot; never more than 4
+            const int resident = mg_step_resident_per_cu();
+            int per_cu = std::max(1, std::min(4, (resident > 0 ? resident : 5) - 1));
             if (const char *q = std::getenv("DASP_MG_POLL_PER_CU")) per_cu = std::max(1, std::atoi(q));
             g.max_pollers = cus * per_cu;
             if (const char *q = std::getenv("DASP_MG_POLL_SLEEP")) g.poll_sleep = std::max(1, std::atoi(q));
