@@ -1328,7 +1328,8 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate
 bool mg_step_supported(const Plan &own, const Plan *other)
 {
     auto ok = [](const Plan &p) {
-        return p.precision == 64 && p.dev && p.dev->arena && p.panels.empty() && !p.windowed && p.cid16 && p.dev->args.n_multi == 0;
+        // 16-bit ids -- or no MFMA block at all (every medium row stored as a slab: nothing reads the id planes)
+        return p.precision == 64 && p.dev && p.dev->arena && p.panels.empty() && !p.windowed && (p.cid16 || p.stats.n_med_blocks == 0) && p.dev->args.n_multi == 0;
     };
     return ok(own) && (!other || ok(*other));
 }

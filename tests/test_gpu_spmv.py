@@ -516,6 +516,49 @@ def test_fused_mg_step_every_row_category(dasp, torch_cuda, seed, kw):
     np.testing.assert_array_equal(res[True], res[False])
 
 
+@pytest.mark.parametrize("name,scale,world", [("cop20k_A", 1.0, 4), ("Queen_4147", 0.01, 5), ("webbase-1M", 0.05, 2), ("nlpkkt160", 0.01, 8)])
+def test_fused_mg_step_on_standins_matches_the_two_launch_form(dasp, torch_cuda, name, scale, world):
+    """banded / FEM / graph stand-ins cut into `world` ranks on one device: few or all of the own-column workgroups are "marked"
+    (store a row the other-column plan adds to), the dispatch-order table moves them to the front -- three chained iterations,
+    the fused step BIT-IDENTICAL to the two-launch form and equal to scipy's product"""
+    import scipy.sparse as sp
+    from dasp_amd.multi import MgPlan
+    torch = torch_cuda
+    rows, cols = dasp.synth_dims(name, scale)
+    rp, ci = dasp.synth_csr(name, scale)
+    lens = np.diff(rp)
+    v = np.random.default_rng(9).uniform(0.5, 1.5, ci.size) / np.maximum(np.repeat(lens, lens), 1)
+    A = sp.csr_matrix((v.copy(), ci.copy(), rp.copy()), shape=(rows, cols))
+    bounds = dasp.partition_rows(rp, world)
+    x0 = np.random.default_rng(10).uniform(0.5, 1.5, cols)
+    res = {}
+    for fused in (True, False):
+        mgs = []
+        for r in range(world):
+            r0, r1 = int(bounds[r]), int(bounds[r + 1])
+            mgs.append(MgPlan(rp[r0:r1 + 1] - rp[r0], ci[rp[r0]:rp[r1]], v[rp[r0]:rp[r1]], rows, cols, bounds, r, cid16=1, x_window=-1, col_panels=-1).upload())
+        for mg in mgs:
+            assert mg.info["fused_step"] == 1
+            mg.set_fused(fused)
+            mg.set_fake_exchange(3, peers=mgs)
+            mg.set_x(x0)
+        want = x0
+        for it in range(3):
+            for mg in mgs:
+                mg.product(0)
+            for mg in mgs:
+                mg.check()
+            for mg in mgs:
+                mg.allgather(0)
+            torch.cuda.synchronize()
+            want = A @ want
+        res[fused] = mgs[world - 1].get_y()
+        assert np.abs(res[fused] - want).max() <= 1e-12 * np.abs(want).max()
+        for mg in mgs:
+            mg.close()
+    np.testing.assert_array_equal(res[True], res[False])
+
+
 def test_fused_mg_step_without_other_column_nonzeros(dasp, torch_cuda):
     """a block-diagonal matrix: a rank's rows touch its own columns only, so there is no other-column plan and no waiting workgroup --
     the last own-column workgroup publishes "y ready" itself.  20 chained dasp_mg_spmv without host synchronisation (the exchange's
