@@ -46,7 +46,7 @@ class Stats(C.Structure):
 
 class MgInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in "precision n_gpus rank rowA colA row_begin row_end stride".split()] + [
-        ("nnz_own", C.c_longlong), ("nnz_other", C.c_longlong), ("overlap", C.c_int), ("has_comm", C.c_int), ("square", C.c_int), ("stream_memops", C.c_int), ("fused_step", C.c_int)]
+        ("nnz_own", C.c_longlong), ("nnz_other", C.c_longlong), ("overlap", C.c_int), ("has_comm", C.c_int), ("square", C.c_int), ("stream_memops", C.c_int), ("fused_step", C.c_int), ("exchange", C.c_int)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -159,6 +159,10 @@ def lib():
     L.dasp_mg_check.argtypes = [vp]
     L.dasp_mg_set_fused.argtypes = [vp, C.c_int]
     L.dasp_mg_set_fake_exchange.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.dasp_mg_push_export.argtypes = [vp, vp]
+    L.dasp_mg_push_connect.argtypes = [vp, vp]
+    L.dasp_mg_set_exchange.argtypes = [vp, C.c_int]
+    L.dasp_mg_push_loopback.argtypes = [vp]
     L.dasp_synth_dims.argtypes = [C.c_char_p, C.c_double, ip, ip]
     L.dasp_synth_generator.argtypes = [C.c_char_p]
     L.dasp_synth_generator.restype = C.c_char_p
@@ -179,4 +183,5 @@ EXPORTS = (
     "dasp_plan_drop_host dasp_plan_set_stream_policy dasp_plan_spmv dasp_plan_spmv_acc dasp_plan_time dasp_plan_time_each dasp_plan_time_graph dasp_spmv_all_f64 dasp_spmv_all_f16 dasp_partition_rows "
     "dasp_selftest_mfma dasp_synth_dims dasp_synth_generator dasp_synth_row_lengths dasp_synth_rows "
     "dasp_mg_unique_id dasp_mg_plan_create dasp_mg_destroy dasp_mg_upload dasp_mg_comm_init dasp_mg_set_x dasp_mg_spmv dasp_mg_product dasp_mg_allgather "
-    "dasp_mg_wait dasp_mg_get_y dasp_mg_get_y_local dasp_mg_y_local dasp_mg_gathered dasp_mg_x dasp_mg_subplan dasp_mg_info dasp_mg_check dasp_mg_set_fused dasp_mg_set_fake_exchange").split()
+    "dasp_mg_wait dasp_mg_get_y dasp_mg_get_y_local dasp_mg_y_local dasp_mg_gathered dasp_mg_x dasp_mg_subplan dasp_mg_info dasp_mg_check dasp_mg_set_fused dasp_mg_set_fake_exchange "
+    "dasp_mg_push_export dasp_mg_push_connect dasp_mg_set_exchange dasp_mg_push_loopback").split()

@@ -544,10 +544,24 @@ __global__ void k_spin_us(long long ticks)
     const long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
-int devpack_spin(void *stream, int micros)
+// the same with the footprint of RCCL's collective kernels on gfx950 (rcclGenericKernel<1|2|4> in this image's librccl.so: 256 threads,
+// .vgpr_count 261-280, 19 744 B of LDS, one workgroup per channel): what has to find room beside the product kernels for the exchange to
+// overlap them at all.  Every workgroup spins from ITS OWN start, so a late start ends the "exchange" late, as it would RCCL's.
+__global__ void __launch_bounds__(256) k_spin_fat(long long ticks, int *sink)
+{
+    __shared__ int pad[19744 / 4];
+    asm volatile("v_mov_b32 v255, 0" ::: "v255");
+    asm volatile("v_accvgpr_write_b32 a23, 0" ::: "a23");
+    pad[threadIdx.x] = (int)ticks;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (ticks < 0) sink[threadIdx.x] = pad[255 - threadIdx.x];
+}
+int devpack_spin(void *stream, int micros, int channels)
 {
     if (micros <= 0) return DASP_OK;
-    hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), (long long)micros * 100);
+    if (channels > 0) hipLaunchKernelGGL(k_spin_fat, dim3(channels), dim3(256), 0, static_cast<hipStream_t>(stream), (long long)micros * 100, (int *)nullptr);
+    else hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), (long long)micros * 100);
     HIP_TRYP(hipGetLastError());
     return DASP_OK;
 }

@@ -26,6 +26,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
@@ -36,12 +37,15 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 #include "plan.hpp"
 #include "device.hpp"
+#include "mgx.hpp"
 
 using namespace dasp;
 
-namespace dasp { int devpack_spin(void *stream, int micros); }
+namespace dasp { int devpack_spin(void *stream, int micros, int channels); }
 
 namespace {
 
@@ -142,17 +146,41 @@ struct dasp_mg_plan {
     long long timeout_ticks = 200ll * 100000;   // 200 ms at 100 MHz
     // test hook (dasp_mg_set_fake_exchange): world > 1 without a communicator; the exchange = copies of the rank's slice into the
     // given gather buffers (this rank's own and those of peers living on the same device) + a kernel of that duration
+    // direct exchange (dasp_mg_push_connect; mgx.hip): every rank stores its slice into every rank's gather buffer through peer-mapped
+    // pointers and then a sequence number into the receiver's arrived[sender] word.  The gather buffer is double: exchange n fills half
+    // n & 1, so that a peer's stores of exchange n + 1 never meet this rank's reads of exchange n - 1 ... n (a peer can only be one
+    // exchange ahead: its next product needs this rank's slice)
+    bool push = false;
+    bool push_loopback = false;        // test hook: the peers are scratch memory of this rank (timing on a one-GPU box)
+    void *xflags = nullptr;            // fine-grained: arrived[world] (u64), at kEpochOff: epoch_of[world] (u64)
+    std::vector<void *> peer_gather, peer_flags;   // [world] base pointers (own entry: this rank's)
+    std::vector<char> peer_opened;     // [world] 1: opened with hipIpcOpenMemHandle (closed in the destructor)
+    void *d_push_dst = nullptr;        // device: MgPushDst[2][world], one table per half
+    void *d_push_count = nullptr;      // device: unsigned[world]
+    void *push_scratch = nullptr;      // loopback only
+    uint64_t xseq = 0;                 // sequence number of the last exchange queued
+    uint64_t epoch = 0;                // dasp_mg_set_x / connect count: what this rank last published to its peers' epoch_of[rank]
+    bool peers_pending = false;        // the peers have not been seen at `epoch` yet (checked before the next exchange is queued)
+    int push_wgs = 32;                 // workgroups per destination (loopback, 40 us link time: 4 -> 132 us per step, 16 -> 85, 32 -> 79.5, 64 -> 84)
     int fake_us = -1;
+    int fake_channels = 0;             // > 0: the stand-in kernel has the footprint of RCCL's (devpack.hip k_spin_fat), that many workgroups
     std::vector<void *> fake_peers;
     ncclComm_t comm = nullptr;
 
     size_t vb() const { return precision == 64 ? 8 : 2; }
+    size_t all_bytes() const { return (size_t)stride * vb() * (size_t)world; }
+    // the half of the gather buffer the last exchange filled (push mode; RCCL and the test hook use half 0 only)
+    char *gcur() const { return static_cast<char *>(yg) + (push ? (size_t)(xseq & 1) * all_bytes() : 0); }
     int rows() const { return bounds[(size_t)rank + 1] - bounds[(size_t)rank]; }
     ~dasp_mg_plan()
     {
         if (device >= 0) (void)hipSetDevice(device);
         if (cs) (void)hipStreamSynchronize(cs);
+        if (device >= 0) (void)hipDeviceSynchronize();
         if (comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(comm);
+        for (size_t r = 0; r < peer_opened.size(); ++r)
+            if (peer_opened[r]) { if (peer_gather[r]) (void)hipIpcCloseMemHandle(peer_gather[r]); if (peer_flags[r]) (void)hipIpcCloseMemHandle(peer_flags[r]); }
+        for (void *p : {xflags, d_push_dst, d_push_count, push_scratch}) if (p) (void)hipFree(p);
         if (ev_y) (void)hipEventDestroy(ev_y);
         if (ev_g) (void)hipEventDestroy(ev_g);
         if (cs) (void)hipStreamDestroy(cs);
@@ -254,6 +282,7 @@ int create_impl(dasp_mg_plan &g, const int *rp, const int *ci, const T *val, con
 // hand-offs of the two-launch form: events, or -- opted in -- stream memory operations; an operation that fails is replaced by the
 // event (or, on the consumer side of a value that was already written by an operation, by a host wait for the communication stream).
 constexpr uint64_t kAllBits = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kExchangeKernelRegs = 288;      // registers per lane RCCL's collective kernels need on gfx950 (see dasp_mg_upload)
 // "y ready": the communication stream continues once the products queued so far on `s` are done (both sides are queued here)
 int handoff_ready(dasp_mg_plan &g, hipStream_t s, uint64_t k)
 {
@@ -303,24 +332,84 @@ int product(dasp_mg_plan &g, hipStream_t s)
         c.mark = g.d_mark; c.mark_members = static_cast<char *>(g.d_mark) + ((g.mark.size() + 255) & ~size_t(255));
         c.n_marked = g.n_marked; c.n_mark_shards = g.n_mark_shards; c.blk_order = g.d_blk_order;
         c.max_pollers = g.max_pollers; c.timeout_ticks = g.timeout_ticks; c.poll_sleep = g.poll_sleep;
-        if (int rc = launch_mg_step(g.own->impl, g.other ? &g.other->impl : nullptr, g.ys[cur], g.yg, g.ys[nxt], c, s)) return rc;
+        if (int rc = launch_mg_step(g.own->impl, g.other ? &g.other->impl : nullptr, g.ys[cur], g.gcur(), g.ys[nxt], c, s)) return rc;
     } else if (g.overlap) {
         // own columns: needs only this rank's slice of x, i.e. its own previous y -- no communication
         if (int rc = dasp_plan_spmv(g.own, g.ys[cur], g.ys[nxt], s)) return rc;
         if (int rc = wait_gathered(g, s)) return rc;                                         // the other ranks' x has arrived
-        if (g.other) if (int rc = dasp_plan_spmv_acc(g.other, g.yg, g.ys[nxt], s)) return rc;   // y += (other columns) * x
+        if (g.other) if (int rc = dasp_plan_spmv_acc(g.other, g.gcur(), g.ys[nxt], s)) return rc;   // y += (other columns) * x
     } else {
         if (int rc = wait_gathered(g, s)) return rc;
-        if (int rc = dasp_plan_spmv(g.own, g.xg, g.ys[nxt], s)) return rc;
+        if (int rc = dasp_plan_spmv(g.own, g.square ? g.gcur() : g.xg, g.ys[nxt], s)) return rc;
     }
     g.cur = nxt;
     ++g.step;
     return DASP_OK;
 }
 
-// the slice ys[cur] -> every rank's gather buffer on stream q (RCCL; one rank or the test hook: local copies)
+constexpr size_t kEpochOff = 2048, kFlagBytes = 4096;      // layout of xflags; at most 256 ranks
+
+// push mode: the peers must have passed the dasp_mg_set_x / connect this rank has passed before this rank stores into their buffers
+// (their earlier products are then complete, their x is in place).  Host-side: read this rank's epoch_of[] until every entry is there.
+int push_wait_peers(dasp_mg_plan &g)
+{
+    if (!g.peers_pending) return DASP_OK;
+    if (g.push_loopback) { g.peers_pending = false; return DASP_OK; }
+    double limit = 120.0;
+    if (const char *e = std::getenv("DASP_MG_BARRIER_TIMEOUT_S")) limit = std::max(0.01, std::atof(e));
+    std::vector<uint64_t> seen((size_t)g.world, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        MG_HIP(hipMemcpy(seen.data(), static_cast<char *>(g.xflags) + kEpochOff, seen.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        bool all = true;
+        for (int r = 0; r < g.world; ++r) all = all && seen[(size_t)r] >= g.epoch;
+        if (all) break;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            set_error("direct exchange: a peer did not reach this dasp_mg_set_x / dasp_mg_push_connect within " + std::to_string(limit) + " s (DASP_MG_BARRIER_TIMEOUT_S)");
+            return DASP_ERR_STATE;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    g.peers_pending = false;
+    return DASP_OK;
+}
+
+// publish "this rank has passed its n-th dasp_mg_set_x / connect" into every peer's epoch_of[rank] (plain copies: they also prove the
+// peer mappings before any kernel stores through them)
+int push_arrive(dasp_mg_plan &g)
+{
+    ++g.epoch;
+    g.peers_pending = true;
+    for (int r = 0; r < g.world; ++r) {
+        char *f = static_cast<char *>(g.push_loopback ? g.xflags : g.peer_flags[(size_t)r]);
+        const int slot = g.push_loopback ? r : g.rank;
+        MG_HIP(hipMemcpy(f + kEpochOff + (size_t)slot * sizeof(uint64_t), &g.epoch, sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+    return DASP_OK;
+}
+
+// the direct exchange on stream q: [wait for `ready` >= ready_need] stores into every rank's gather buffer + flags, then one wave waits
+// for every sender's flag [and sets `gathered` = step for the fused step's waiting workgroups]
+int push_exchange(dasp_mg_plan &g, hipStream_t q, uint64_t ready_need, bool set_gathered, uint64_t step)
+{
+    if (int rc = push_wait_peers(g)) return rc;
+    const uint64_t seq = ++g.xseq;
+    MgPushArgs a{};
+    a.src = g.ys[g.cur]; a.bytes = (size_t)g.stride * g.vb();
+    a.dst = static_cast<const MgPushDst *>(g.d_push_dst) + (size_t)(seq & 1) * (size_t)g.world;
+    a.count = static_cast<unsigned *>(g.d_push_count);
+    a.wgs = g.push_wgs; a.seq = seq;
+    a.ready = reinterpret_cast<const unsigned long long *>(g.words + kMgWordReady); a.ready_need = ready_need;
+    a.timeout = g.timeout_ticks; a.err = reinterpret_cast<int *>(g.words + kMgWordErr);
+    if (int rc = launch_mg_push(a, g.world, q)) return rc;
+    if (g.push_loopback && g.fake_us > 0) if (int rc = devpack_spin(q, g.fake_us, 0)) return rc;       // timing probe: the links' share of the exchange
+    return launch_mg_arrived(g.xflags, g.world, seq, set_gathered ? g.words + kMgWordGathered : nullptr, step, g.timeout_ticks, g.words + kMgWordErr, q);
+}
+
+// the slice ys[cur] -> every rank's gather buffer on stream q (direct stores; RCCL; one rank or the test hook: local copies)
 int exchange(dasp_mg_plan &g, hipStream_t q)
 {
+    if (g.push) return push_exchange(g, q, 0, false, 0);
     if (g.comm) {
         const ncclResult_t r = rccl()->AllGather(g.ys[g.cur], g.yg, (size_t)g.stride, g.precision == 64 ? ncclFloat64 : ncclFloat16, g.comm, q);
         if (r != ncclSuccess) return rccl_fail("ncclAllGather", r);
@@ -330,7 +419,71 @@ int exchange(dasp_mg_plan &g, hipStream_t q)
     MG_HIP(hipMemcpyAsync(static_cast<char *>(g.yg) + (size_t)g.rank * sl, g.ys[g.cur], sl, hipMemcpyDeviceToDevice, q));
     for (void *peer : g.fake_peers)
         if (peer && peer != g.yg) MG_HIP(hipMemcpyAsync(static_cast<char *>(peer) + (size_t)g.rank * sl, g.ys[g.cur], sl, hipMemcpyDeviceToDevice, q));
-    if (g.world > 1) if (int rc = devpack_spin(q, g.fake_us)) return rc;
+    if (g.world > 1) if (int rc = devpack_spin(q, g.fake_us, g.fake_channels)) return rc;
+    return DASP_OK;
+}
+
+// what dasp_mg_push_export writes and dasp_mg_push_connect reads: DASP_MG_IPC_BYTES per rank
+struct PushBlob {
+    uint64_t magic;
+    int32_t rank, world;
+    int64_t pid;
+    uint64_t gather, flags;            // the owner's device pointers (used as they are by peers inside the owner's process)
+    uint64_t gather_bytes;
+    hipIpcMemHandle_t hg, hf;
+};
+static_assert(sizeof(PushBlob) <= DASP_MG_IPC_BYTES, "DASP_MG_IPC_BYTES too small");
+constexpr uint64_t kPushMagic = 0x3158504D50534144ull;       // "DASPMPX1"
+
+// device tables + state of the push mode, once the peers' pointers are known
+int push_enable(dasp_mg_plan &g)
+{
+    const size_t sl = (size_t)g.stride * g.vb(), all = g.all_bytes();
+    std::vector<MgPushDst> tab((size_t)2 * g.world);
+    for (int half = 0; half < 2; ++half)
+        for (int r = 0; r < g.world; ++r) {
+            MgPushDst &d = tab[(size_t)half * g.world + r];
+            if (g.push_loopback) {
+                // every "peer" is scratch memory (except this rank itself); the flags are this rank's own arrived[r]
+                char *base = r == g.rank ? static_cast<char *>(g.yg) : static_cast<char *>(g.push_scratch);
+                d.data = base + (size_t)half * all + (size_t)g.rank * sl;
+                d.flag = reinterpret_cast<unsigned long long *>(g.xflags) + r;
+            } else {
+                d.data = static_cast<char *>(g.peer_gather[(size_t)r]) + (size_t)half * all + (size_t)g.rank * sl;
+                d.flag = reinterpret_cast<unsigned long long *>(g.peer_flags[(size_t)r]) + g.rank;
+            }
+        }
+    if (!g.d_push_dst) MG_HIP(hipMalloc(&g.d_push_dst, tab.size() * sizeof(MgPushDst)));
+    MG_HIP(hipMemcpy(g.d_push_dst, tab.data(), tab.size() * sizeof(MgPushDst), hipMemcpyHostToDevice));
+    if (!g.d_push_count) { MG_HIP(hipMalloc(&g.d_push_count, (size_t)g.world * sizeof(unsigned))); MG_HIP(hipMemset(g.d_push_count, 0, (size_t)g.world * sizeof(unsigned))); }
+    if (!g.words) {        // plans that do not qualify for the fused step still need the error word
+        void *p = nullptr;
+        MG_HIP(hipMalloc(&p, kMgWordBytes));
+        MG_HIP(hipMemset(p, 0, kMgWordBytes));
+        g.words = static_cast<char *>(p);
+    }
+    if (const char *e = std::getenv("DASP_MG_PUSH_WGS")) g.push_wgs = std::max(1, std::min(64, std::atoi(e)));
+    // the current x is in half 0 (RCCL and the test hook use no other): move it to where gcur() will look
+    MG_HIP(hipDeviceSynchronize());
+    if (g.xseq & 1) { MG_HIP(hipMemcpy(static_cast<char *>(g.yg) + all, g.yg, all, hipMemcpyDeviceToDevice)); MG_HIP(hipDeviceSynchronize()); }
+    g.push = true;
+    g.pending = false; g.pending_sig = false; g.pending_lazy = false; g.gathered_step = 0;
+    return push_arrive(g);
+}
+
+// 0: RCCL (or the test hook), 1: direct stores (needs a connected plan).  Synchronises the device; the current x stays valid.
+int set_exchange(dasp_mg_plan &g, int mode)
+{
+    MG_HIP(hipDeviceSynchronize());
+    g.pending = false; g.pending_sig = false; g.pending_lazy = false; g.gathered_step = 0;
+    if ((mode == 1) == g.push) return DASP_OK;
+    if (mode == 1) {
+        if (!g.d_push_dst) { set_error("dasp_mg_push_connect first"); return DASP_ERR_STATE; }
+        return push_enable(g);
+    }
+    const size_t all = g.all_bytes();
+    if (g.xseq & 1) { MG_HIP(hipMemcpy(g.yg, static_cast<char *>(g.yg) + all, all, hipMemcpyDeviceToDevice)); MG_HIP(hipDeviceSynchronize()); }
+    g.push = false;
     return DASP_OK;
 }
 
@@ -409,11 +562,12 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
         // other-column product (a few per cent of the gathers) reads it.
         const char *e = std::getenv("DASP_MG_GATHER_MEM");
         const bool fine = g.overlap && g.precision == 64 && !(e && std::strcmp(e, "coarse") == 0);
-        if (!(fine && hipExtMallocWithFlags(&g.yg, all, hipDeviceMallocFinegrained) == hipSuccess && g.yg)) {
+        // two halves: the direct exchange alternates between them (struct dasp_mg_plan); RCCL uses the first only
+        if (!(fine && hipExtMallocWithFlags(&g.yg, 2 * all, hipDeviceMallocFinegrained) == hipSuccess && g.yg)) {
             (void)hipGetLastError();
-            MG_HIP(hipMalloc(&g.yg, all));
+            MG_HIP(hipMalloc(&g.yg, 2 * all));
         } else g.gather_fine = true;
-        MG_HIP(hipMemset(g.yg, 0, all));
+        MG_HIP(hipMemset(g.yg, 0, 2 * all));
     }
     if (g.square) g.xg = g.yg;
     else { const size_t xb = std::max<size_t>((size_t)g.colA * vb, 16); MG_HIP(hipMalloc(&g.xg, xb)); MG_HIP(hipMemset(g.xg, 0, xb)); }
@@ -467,10 +621,13 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
             hipDeviceProp_t prop;
             int cus = 256;
             if (hipGetDeviceProperties(&prop, g.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-            // waiting workgroups per CU: one slot fewer than the step kernel's residency (5 at its 82 registers), so that the exchange's
-            // kernel always finds a free slot; never more than 4
-            const int resident = mg_step_resident_per_cu();
-            int per_cu = std::max(1, std::min(4, (resident > 0 ? resident : 5) - 1));
+            // waiting workgroups per CU: they hold their registers until the exchange has landed, so the exchange's own kernel must fit
+            // beside them on every CU or the step can only end by its timeout.  RCCL's kernels in this image (rcclGenericKernel<1|2|4>,
+            // gfx950 code object of librccl.so: .vgpr_count 261-280, 256 threads = one wave per SIMD, 19.7 KB of LDS) need 288 of a SIMD's
+            // 512 registers; a step-kernel wave holds at most 512 / residency of them (residency 5 at its 82 registers) -> 2 per CU.
+            // (1 / 2 / 4 waiting workgroups per CU: 76 / 75 / 74 us per step, profiles/r03_multi_gpu_step.md)
+            const int resident = std::max(1, mg_step_resident_per_cu() > 0 ? mg_step_resident_per_cu() : 5);
+            int per_cu = std::max(1, std::min(std::min(4, resident - 1), (512 - kExchangeKernelRegs) * resident / 512));
             if (const char *q = std::getenv("DASP_MG_POLL_PER_CU")) per_cu = std::max(1, std::atoi(q));
             g.max_pollers = cus * per_cu;
             if (const char *q = std::getenv("DASP_MG_POLL_SLEEP")) g.poll_sleep = std::max(1, std::atoi(q));
@@ -511,9 +668,10 @@ int dasp_mg_set_x(dasp_mg_plan_t *mg, const void *x_host)
         std::vector<char> lay((size_t)g.world * g.stride * vb, 0);
         for (int k = 0; k < g.world; ++k)
             std::memcpy(lay.data() + (size_t)k * g.stride * vb, x + (size_t)g.bounds[(size_t)k] * vb, (size_t)(g.bounds[(size_t)k + 1] - g.bounds[(size_t)k]) * vb);
-        MG_HIP(hipMemcpy(g.yg, lay.data(), lay.size(), hipMemcpyHostToDevice));
+        MG_HIP(hipMemcpy(g.gcur(), lay.data(), lay.size(), hipMemcpyHostToDevice));
         MG_HIP(hipMemcpy(g.ys[g.cur], lay.data() + (size_t)g.rank * g.stride * vb, (size_t)g.stride * vb, hipMemcpyHostToDevice));
     } catch (const std::bad_alloc &) { set_error("out of host memory"); return DASP_ERR_NOMEM; }
+    if (g.push) return push_arrive(g);       // direct exchange: the peers wait for this before they store into this rank's buffers again
     return DASP_OK;
 }
 
@@ -529,16 +687,21 @@ int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream)
     if (!mg) return DASP_ERR_ARG;
     dasp_mg_plan &g = *mg;
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
-    if (!g.comm && g.world > 1 && g.fake_us < 0) { set_error("dasp_mg_spmv needs dasp_mg_comm_init (or use dasp_mg_product with your own exchange)"); return DASP_ERR_STATE; }
+    if (!g.comm && !g.push && g.world > 1 && g.fake_us < 0) { set_error("dasp_mg_spmv needs dasp_mg_comm_init or dasp_mg_push_connect (or use dasp_mg_product with your own exchange)"); return DASP_ERR_STATE; }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (g.push) if (int rc = push_wait_peers(g)) return rc;
     if (int rc = product(g, s)) return rc;
     // y (this rank's padded slice) -> every rank's gather buffer, on the communication stream, behind the products
     const uint64_t k = g.step;
     if (g.fused) {
         // the communication stream spins (one lane) until the launch's last workgroup has published step k, exchanges, publishes k back
-        if (int rc = launch_mg_wait(g.words + kMgWordReady, k, g.timeout_ticks, g.words + kMgWordErr, g.cs)) return rc;
-        if (int rc = exchange(g, g.cs)) return rc;
-        if (int rc = launch_mg_flag(g.words + kMgWordGathered, k, g.cs)) return rc;
+        if (g.push) {          // both waits are inside the exchange's two kernels
+            if (int rc = push_exchange(g, g.cs, k, true, k)) return rc;
+        } else {
+            if (int rc = launch_mg_wait(g.words + kMgWordReady, k, g.timeout_ticks, g.words + kMgWordErr, g.cs)) return rc;
+            if (int rc = exchange(g, g.cs)) return rc;
+            if (int rc = launch_mg_flag(g.words + kMgWordGathered, k, g.cs)) return rc;
+        }
         g.gathered_step = k; g.pending_sig = false; g.pending_lazy = true;      // consumers outside the step kernel: wait_gathered records the event when one shows up
     } else {
         if (int rc = handoff_ready(g, s, k)) return rc;
@@ -556,7 +719,7 @@ int dasp_mg_allgather(dasp_mg_plan_t *mg, void *stream)
     if (!mg) return DASP_ERR_ARG;
     dasp_mg_plan &g = *mg;
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
-    if (!g.comm && g.world > 1 && g.fake_us < 0) { set_error("dasp_mg_allgather needs dasp_mg_comm_init"); return DASP_ERR_STATE; }
+    if (!g.comm && !g.push && g.world > 1 && g.fake_us < 0) { set_error("dasp_mg_allgather needs dasp_mg_comm_init or dasp_mg_push_connect"); return DASP_ERR_STATE; }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = wait_gathered(g, s)) return rc;
     if (int rc = exchange(g, s)) return rc;
@@ -579,7 +742,7 @@ int dasp_mg_get_y(dasp_mg_plan_t *mg, void *y_host)
     const size_t vb = g.vb();
     try {
         std::vector<char> lay((size_t)g.world * g.stride * vb);
-        MG_HIP(hipMemcpy(lay.data(), g.yg, lay.size(), hipMemcpyDeviceToHost));
+        MG_HIP(hipMemcpy(lay.data(), g.gcur(), lay.size(), hipMemcpyDeviceToHost));
         char *y = static_cast<char *>(y_host);
         for (int k = 0; k < g.world; ++k)
             std::memcpy(y + (size_t)g.bounds[(size_t)k] * vb, lay.data() + (size_t)k * g.stride * vb, (size_t)(g.bounds[(size_t)k + 1] - g.bounds[(size_t)k]) * vb);
@@ -597,8 +760,8 @@ int dasp_mg_get_y_local(dasp_mg_plan_t *mg, void *y_host)
 }
 
 void *dasp_mg_y_local(dasp_mg_plan_t *mg) { return mg && mg->uploaded ? mg->ys[mg->cur] : nullptr; }
-void *dasp_mg_gathered(dasp_mg_plan_t *mg) { return mg && mg->uploaded ? mg->yg : nullptr; }
-void *dasp_mg_x(dasp_mg_plan_t *mg) { return mg && mg->uploaded ? mg->xg : nullptr; }
+void *dasp_mg_gathered(dasp_mg_plan_t *mg) { return mg && mg->uploaded ? mg->gcur() : nullptr; }
+void *dasp_mg_x(dasp_mg_plan_t *mg) { return mg && mg->uploaded ? (mg->square ? static_cast<void *>(mg->gcur()) : mg->xg) : nullptr; }
 
 dasp_plan_t *dasp_mg_subplan(dasp_mg_plan_t *mg, int which)
 {
@@ -616,6 +779,7 @@ int dasp_mg_info(const dasp_mg_plan_t *mg, dasp_mg_info_t *out)
     out->overlap = mg->overlap ? 1 : 0; out->has_comm = mg->comm ? 1 : 0; out->square = mg->square ? 1 : 0;
     out->stream_memops = mg->use_sig ? 1 : 0;
     out->fused_step = mg->fused ? 1 : 0;
+    out->exchange = mg->push ? 1 : 0;
     return DASP_OK;
 }
 
@@ -626,14 +790,22 @@ int dasp_mg_check(dasp_mg_plan_t *mg)
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
     MG_HIP(hipDeviceSynchronize());
     g.pending = false; g.pending_lazy = false;
-    if (!g.fused) return DASP_OK;
+    if (!g.words) return DASP_OK;
     uint64_t err = 0;
     MG_HIP(hipMemcpy(&err, g.words + kMgWordErr, sizeof err, hipMemcpyDeviceToHost));
     if ((int)err == 0) return DASP_OK;
+    MG_HIP(hipMemset(g.words, 0, kMgWordBytes));
+    g.gathered_step = 0;
+    if ((int)err == 3) {
+        // direct exchange: a sender's flag did not arrive in time.  Results since then are invalid; the plan goes back to RCCL (if
+        // there is a communicator) and the caller starts again from dasp_mg_set_x
+        if (int rc = set_exchange(g, 0)) return rc;
+        set_error("direct exchange: a peer's slice did not arrive within the time-out; the plan now exchanges through RCCL -- call dasp_mg_set_x and start again");
+        return DASP_ERR_STATE;
+    }
     // a poll gave up: products since then lack other-column terms (1) or an exchange ran ahead of its product (2).  Drop to the
     // two-launch form; the caller starts again from dasp_mg_set_x.
-    g.fused = false; g.gathered_step = 0;
-    MG_HIP(hipMemset(g.words, 0, kMgWordBytes));
+    g.fused = false;
     set_error(std::string("fused multi-GPU step: ") + ((int)err == 1 ? "the wait for the previous exchange" : "the exchange's wait for the product") +
               " timed out; the plan now runs the two-launch form -- call dasp_mg_set_x and start again");
     return DASP_ERR_STATE;
@@ -655,8 +827,91 @@ int dasp_mg_set_fake_exchange(dasp_mg_plan_t *mg, int micros, int n_peers, void 
 {
     if (!mg || n_peers < 0 || (n_peers > 0 && !peer_gathered)) return DASP_ERR_ARG;
     mg->fake_us = micros;
+    if (const char *e = std::getenv("DASP_MG_FAKE_CHANNELS")) mg->fake_channels = std::max(0, std::atoi(e));
     mg->fake_peers.assign(peer_gathered, peer_gathered + n_peers);
     return DASP_OK;
+}
+
+int dasp_mg_push_export(dasp_mg_plan_t *mg, void *blob)
+{
+    if (!mg || !blob) return DASP_ERR_ARG;
+    dasp_mg_plan &g = *mg;
+    if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
+    if (!g.xflags) {
+        if (g.world > (int)(kEpochOff / sizeof(uint64_t))) { set_error("direct exchange: more than 256 ranks"); return DASP_ERR_ARG; }
+        MG_HIP(hipExtMallocWithFlags(&g.xflags, kFlagBytes, hipDeviceMallocFinegrained));
+        MG_HIP(hipMemset(g.xflags, 0, kFlagBytes));
+        MG_HIP(hipDeviceSynchronize());
+    }
+    PushBlob b{};
+    b.magic = kPushMagic; b.rank = g.rank; b.world = g.world; b.pid = (int64_t)getpid();
+    b.gather = reinterpret_cast<uint64_t>(g.yg); b.flags = reinterpret_cast<uint64_t>(g.xflags); b.gather_bytes = 2 * g.all_bytes();
+    MG_HIP(hipIpcGetMemHandle(&b.hg, g.yg));
+    MG_HIP(hipIpcGetMemHandle(&b.hf, g.xflags));
+    std::memset(blob, 0, DASP_MG_IPC_BYTES);
+    std::memcpy(blob, &b, sizeof b);
+    return DASP_OK;
+}
+
+int dasp_mg_push_connect(dasp_mg_plan_t *mg, const void *blobs)
+{
+    if (!mg || !blobs) return DASP_ERR_ARG;
+    dasp_mg_plan &g = *mg;
+    if (!g.uploaded || !g.xflags) { set_error("dasp_mg_push_export first"); return DASP_ERR_STATE; }
+    if (g.push) return DASP_OK;
+    MG_HIP(hipSetDevice(g.device));
+    std::vector<void *> pg((size_t)g.world, nullptr), pf((size_t)g.world, nullptr);
+    std::vector<char> opened((size_t)g.world, 0);
+    auto undo = [&] {
+        for (int r = 0; r < g.world; ++r)
+            if (opened[(size_t)r]) { if (pg[(size_t)r]) (void)hipIpcCloseMemHandle(pg[(size_t)r]); if (pf[(size_t)r]) (void)hipIpcCloseMemHandle(pf[(size_t)r]); }
+        (void)hipGetLastError();
+    };
+    for (int r = 0; r < g.world; ++r) {
+        PushBlob b;
+        std::memcpy(&b, static_cast<const char *>(blobs) + (size_t)r * DASP_MG_IPC_BYTES, sizeof b);
+        if (b.magic != kPushMagic || b.rank != r || b.world != g.world || b.gather_bytes != 2 * g.all_bytes()) {
+            undo(); set_error("dasp_mg_push_connect: entry " + std::to_string(r) + " is not rank " + std::to_string(r) + "'s dasp_mg_push_export of a plan with this partition");
+            return DASP_ERR_ARG;
+        }
+        if (r == g.rank) { pg[(size_t)r] = g.yg; pf[(size_t)r] = g.xflags; continue; }
+        if (b.pid == (int64_t)getpid()) {      // a peer inside this process (tests; one process driving several GPUs): its pointers as they are
+            pg[(size_t)r] = reinterpret_cast<void *>(b.gather); pf[(size_t)r] = reinterpret_cast<void *>(b.flags);
+            continue;
+        }
+        opened[(size_t)r] = 1;
+        hipError_t e = hipIpcOpenMemHandle(&pg[(size_t)r], b.hg, hipIpcMemLazyEnablePeerAccess);
+        if (e == hipSuccess) e = hipIpcOpenMemHandle(&pf[(size_t)r], b.hf, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            undo(); set_error(std::string("dasp_mg_push_connect: hipIpcOpenMemHandle (rank ") + std::to_string(r) + "): " + hipGetErrorString(e));
+            return DASP_ERR_HIP;
+        }
+    }
+    g.peer_gather = pg; g.peer_flags = pf; g.peer_opened = opened;
+    if (int rc = push_enable(g)) { g.push = false; return rc; }
+    return DASP_OK;
+}
+
+int dasp_mg_push_loopback(dasp_mg_plan_t *mg)
+{
+    if (!mg) return DASP_ERR_ARG;
+    dasp_mg_plan &g = *mg;
+    if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
+    if (g.push) return DASP_OK;
+    if (!g.xflags) {
+        MG_HIP(hipExtMallocWithFlags(&g.xflags, kFlagBytes, hipDeviceMallocFinegrained));
+        MG_HIP(hipMemset(g.xflags, 0, kFlagBytes));
+    }
+    if (!g.push_scratch) MG_HIP(hipMalloc(&g.push_scratch, 2 * g.all_bytes()));
+    g.push_loopback = true;
+    return push_enable(g);
+}
+
+int dasp_mg_set_exchange(dasp_mg_plan_t *mg, int mode)
+{
+    if (!mg || mode < 0 || mode > 1) return DASP_ERR_ARG;
+    if (!mg->uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
+    return set_exchange(*mg, mode);
 }
 
 }  // extern "C"

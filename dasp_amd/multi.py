@@ -105,6 +105,31 @@ class MgPlan:
         arr = (C.c_void_p * max(1, len(peers)))(*[p.gathered_ptr for p in peers])
         _lib.check(_lib.lib().dasp_mg_set_fake_exchange(self._h, int(micros), len(peers), arr))
 
+    # direct exchange (include/dasp_amd.h): stores into the peers' gather buffers instead of an RCCL collective
+    IPC_BYTES = 256
+
+    def push_export(self):
+        """this rank's DASP_MG_IPC_BYTES (bytes): all-gather them among the ranks, then push_connect"""
+        buf = np.zeros(self.IPC_BYTES, np.uint8)
+        _lib.check(_lib.lib().dasp_mg_push_export(self._h, _vp(buf)))
+        return buf.tobytes()
+
+    def push_connect(self, blobs):
+        """blobs: every rank's push_export in rank order (bytes or a list of bytes); maps the peers and switches the plan over"""
+        if not isinstance(blobs, (bytes, bytearray)):
+            blobs = b"".join(blobs)
+        buf = np.frombuffer(blobs, np.uint8).copy()
+        assert buf.size == self.IPC_BYTES * self.world
+        _lib.check(_lib.lib().dasp_mg_push_connect(self._h, _vp(buf)))
+
+    def set_exchange(self, mode):
+        """'rccl' / 'push' (after push_connect)"""
+        _lib.check(_lib.lib().dasp_mg_set_exchange(self._h, {"rccl": 0, "push": 1}[mode]))
+
+    def push_loopback(self):
+        """TEST HOOK: the direct exchange with scratch memory of this rank standing in for every peer (timing on a one-GPU box)"""
+        _lib.check(_lib.lib().dasp_mg_push_loopback(self._h))
+
     def wait(self, stream=0):
         _lib.check(_lib.lib().dasp_mg_wait(self._h, C.c_void_p(stream)))
 

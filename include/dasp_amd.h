@@ -302,6 +302,7 @@ typedef struct dasp_mg_info {
     int stream_memops;             /* (after dasp_mg_upload; two-launch form) 1: the two streams hand over through hipStreamWriteValue64 /
                                       hipStreamWaitValue64 on two words of signal memory (DASP_MG_SYNC=memops; a Beta API); 0: through events */
     int fused_step;                /* (after dasp_mg_upload) 1: dasp_mg_spmv / dasp_mg_product run the one-launch step (below) */
+    int exchange;                  /* 0: RCCL all-gather (or the test hook), 1: direct stores into the peers' gather buffers (dasp_mg_push_connect) */
 } dasp_mg_info_t;
 
 /* contiguous row ranges with equal nonzero counts: bounds[0]=0 <= ... <= bounds[n_parts]=rowA */
@@ -345,6 +346,26 @@ int dasp_mg_set_fused(dasp_mg_plan_t *mg, int on);
  * the same device; NULL entries are skipped), followed by a kernel that holds the communication stream for `micros` us.  There is no
  * cross-rank synchronisation: the caller orders the ranks' steps itself. */
 int dasp_mg_set_fake_exchange(dasp_mg_plan_t *mg, int micros, int n_peers, void *const *peer_gathered);
+/* ---- direct exchange (r3): instead of an RCCL collective every rank STORES its slice into every rank's gather buffer through
+ * peer-mapped pointers (hipIpc; xGMI: one hop, all links at once) and then a sequence number into the receiver's arrived[sender] word;
+ * a one-wave kernel on the receiver waits for all senders.  Why: RCCL's kernels on gfx950 need 261-280 registers per lane and do not
+ * start beside a product kernel that keeps every SIMD full -- the exchange then runs AFTER the product instead of under it
+ * (DESIGN.md 5.3); these kernels hold <= 32.  Single node.  Usage, after dasp_mg_upload on every rank:
+ *     dasp_mg_push_export(mg, blob)                    this rank's DASP_MG_IPC_BYTES
+ *     ... all-gather the blobs among the ranks by any means (MPI_Allgather, torch.distributed.all_gather, files) ...
+ *     dasp_mg_push_connect(mg, blobs)                  [n_gpus][DASP_MG_IPC_BYTES] in rank order; maps the peers and switches the plan over
+ *     dasp_mg_set_x(mg, x)                             with the direct exchange a COLLECTIVE point: every rank calls it (a rank's next
+ *                                                      exchange waits, on the host, until every peer has passed the same call;
+ *                                                      DASP_MG_BARRIER_TIMEOUT_S, default 120)
+ * Peers inside one process (one process driving several plans) are used through their plain pointers.  A sender that does not deliver
+ * within the time-out sets the sticky error: dasp_mg_check then returns DASP_ERR_STATE and puts the plan back on RCCL.
+ * dasp_mg_set_exchange: 0 = RCCL, 1 = direct (after a connect); synchronises the device, the current x stays valid. */
+enum { DASP_MG_IPC_BYTES = 256 };
+int dasp_mg_push_export(dasp_mg_plan_t *mg, void *blob);
+int dasp_mg_push_connect(dasp_mg_plan_t *mg, const void *blobs);
+int dasp_mg_set_exchange(dasp_mg_plan_t *mg, int mode);
+/* TEST HOOK (timing on a one-GPU box): the direct exchange with scratch memory of this rank standing in for every peer */
+int dasp_mg_push_loopback(dasp_mg_plan_t *mg);
 /* the products of one iteration only (no exchange): for callers that move dasp_mg_y_local into every rank's
  * dasp_mg_gathered themselves (tests; transports other than RCCL) */
 int dasp_mg_product(dasp_mg_plan_t *mg, void *stream);

@@ -6,6 +6,7 @@ against the CPU oracle on the same seeded inputs.
 """
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -461,6 +462,87 @@ def test_fused_mg_step_three_ranks_on_one_device(dasp, torch_cuda):
         for mg in mgs:
             mg.close()
     np.testing.assert_array_equal(res[True], res[False])
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_push_exchange_three_ranks_in_one_process(dasp, torch_cuda, fused):
+    """The direct exchange (dasp_mg_push_connect: every rank stores its slice into every rank's gather buffer and a sequence number into
+    the receiver's arrived[] word; mgx.hip) with three ranks' plans in ONE process on one device, each driven from its own stream with
+    plain dasp_mg_spmv calls -- the cross-rank ordering is the flags' own, unlike the copy hook's.  Chained iterations == (A_s)^n x_0
+    from scipy on every rank, across a second dasp_mg_set_x after an ODD number of exchanges (both halves of the double gather buffer),
+    the exchange alone (dasp_mg_allgather), and the way back: without a communicator dasp_mg_set_exchange('rccl') leaves nothing to
+    exchange with."""
+    from dasp_amd.multi import MgPlan
+    torch = torch_cuda
+    world = 3
+    rows, A, bounds, sl = _hv_slices(dasp, world)
+    x0 = np.random.default_rng(4).uniform(0.5, 1.5, rows)
+    mgs = [MgPlan(rp, ci, v, rows, rows, bounds, r, cid16=1).upload() for r, (rp, ci, v) in enumerate(sl)]
+    streams = [torch.cuda.Stream() for _ in mgs]
+    blobs = [mg.push_export() for mg in mgs]
+    for mg in mgs:
+        if not fused:
+            mg.set_fused(False)
+        mg.push_connect(blobs)
+        assert mg.info["exchange"] == 1 and mg.info["fused_step"] == (1 if fused else 0)
+    want = x0
+    for rnd, n in enumerate((5, 4)):
+        for mg in mgs:
+            mg.set_x(want)
+        for it in range(n):
+            for mg, st in zip(mgs, streams):
+                mg.spmv(st.cuda_stream)
+            want = A @ want
+        for mg in mgs:
+            mg.check()
+        ys = [mg.get_y() for mg in mgs]
+        for y in ys[1:]:
+            np.testing.assert_array_equal(y, ys[0])
+        assert np.abs(ys[0] - want).max() <= 1e-13 * np.abs(want).max()
+        np.testing.assert_array_equal(np.concatenate([mg.get_y_local() for mg in mgs]), ys[0])
+        want = ys[0]
+    # the exchange alone: the same slices again, into the other half
+    for mg, st in zip(mgs, streams):
+        mg.allgather(st.cuda_stream)
+    for mg in mgs:
+        mg.check()
+        np.testing.assert_array_equal(mg.get_y(), want)
+    mgs[0].set_exchange("rccl")
+    assert mgs[0].info["exchange"] == 0
+    np.testing.assert_array_equal(mgs[0].get_y(), want)           # the current x moved with the switch
+    with pytest.raises(dasp.DaspError, match="dasp_mg_comm_init"):
+        mgs[0].spmv(streams[0].cuda_stream)
+    for mg in mgs:
+        mg.close()
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_push_exchange_between_two_processes(dasp, torch_cuda, tmp_path, fused):
+    """The direct exchange across PROCESSES: two ranks, each in a process of its own on this box's one GPU, map each other's gather
+    buffer and flag words through hipIpcGetMemHandle / hipIpcOpenMemHandle (what eight processes on eight GPUs do) and run the chained
+    dasp_mg_spmv on their own: both end with (A_s)^(5+3) x_0."""
+    import subprocess
+    world, iters = 2, 5
+    rows, A, bounds, sl = _hv_slices(dasp, world)
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_push_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(tmp_path), str(r), str(world), str(iters), str(fused)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-2000:]
+    want = np.random.default_rng(4).uniform(0.5, 1.5, rows)
+    for _ in range(iters + 3):
+        want = A @ want
+    ys = [np.load(tmp_path / ("%d.out.npy" % r)) for r in range(world)]
+    np.testing.assert_array_equal(ys[0], ys[1])
+    assert np.abs(ys[0] - want).max() <= 1e-13 * np.abs(want).max()
 
 
 @pytest.mark.parametrize("seed,kw", [(31, dict(x_window=-1)), (32, dict(x_window=-1, slab_max_len=12)), (33, dict(x_window=-1, long_piece=256, block_longest=64)),

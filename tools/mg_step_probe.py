@@ -48,6 +48,8 @@ for rank in ranks:
     mg.set_x(np.ones(cols))
     line = "rank %d rows %d nnz own %d other %d fused_ok %d |" % (rank, r1 - r0, mg.nnz_local, mg.nnz_remote, mg.info["fused_step"])
     can_fuse = mg.info["fused_step"] == 1
+    if os.environ.get("PROBE_EXCHANGE") == "push":      # the direct exchange, scratch memory standing in for the peers (+ the emulated link time)
+        mg.push_loopback()
     for fused in ([] if os.environ.get("PROBE_KERNEL_ONLY") == "1" else [True, False] if can_fuse else [False]):
         mg.set_fused(fused)
         for us in AG:
