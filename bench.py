@@ -513,13 +513,61 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     mg = R["mg"]
     dog.kick("plans built")
-    host_exchange = multi and share_gpu
-    if multi and not host_exchange:
+    # how the ranks exchange their y slices (N > 1):
+    #   "direct" : every rank stores its slice into every rank's gather buffer through hipIpc peer mappings (dasp_mg_push_connect) -- first
+    #              choice: RCCL's kernels (261-280 registers per lane on gfx950) do not start beside the product kernel
+    #   "RCCL"   : ncclAllGather, with the products on the plan's CU-masked stream (32 CUs kept free for RCCL's kernels) -- the fallback
+    #   "host"   : test hook for ranks sharing one GPU without the direct exchange (DASP_BENCH_EXCHANGE=host)
+    want = os.environ.get("DASP_BENCH_EXCHANGE", "direct")
+    has_comm, exch, base_stream = False, None, stream
+
+    def all_ok(flag):
+        t = torch.tensor([1 if flag else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def use_rccl():
+        """RCCL as the exchange: the plan's compute stream that leaves 32 CUs to RCCL's kernels; without one, the two-launch form"""
+        rs = mg.reserved_stream(32) if world > 1 and os.environ.get("DASP_BENCH_RESERVE_CUS", "32") != "0" else None
+        if rs:
+            return rs
+        if world > 1 and mg.info["fused_step"]:
+            mg.set_fused(False)
+        return base_stream
+
+    if multi and not share_gpu:
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")          # one node: RCCL's bootstrap sockets need no NIC (and must not fail for lack of one)
         uid = torch.from_numpy(D.multi.unique_id() if rank == 0 else np.zeros(128, np.uint8))
         dist.broadcast(uid, 0)
         mg.comm_init(uid.numpy())                                 # ncclCommInitRank, one communicator per rank, on its own GPU
+        has_comm = True
         dog.kick("RCCL communicator up")
+    if multi and world > 1 and want == "direct":
+        good, blob = True, bytes(D.multi.MgPlan.IPC_BYTES)
+        try:
+            blob = mg.push_export()
+        except D.DaspError as exc:
+            good = False
+            sys.stderr.write("bench.py rank %d: dasp_mg_push_export: %s\n" % (rank, exc))
+        blobs = [None] * world
+        dist.all_gather_object(blobs, blob)
+        if all_ok(good):
+            try:
+                mg.push_connect(blobs)
+            except D.DaspError as exc:
+                good = False
+                sys.stderr.write("bench.py rank %d: dasp_mg_push_connect: %s\n" % (rank, exc))
+            if all_ok(good):
+                exch = "direct"
+            elif good:
+                mg.set_exchange("rccl")
+        dog.kick("direct exchange " + ("connected" if exch else "unavailable"))
+    if multi and exch is None:
+        if has_comm:
+            exch, stream = "RCCL", use_rccl()
+        else:
+            exch = "host"
+    host_exchange = exch == "host"
 
     def step():
         if mg is None:
@@ -544,42 +592,54 @@ def main():
         step()
     fence()
     dog.kick("warm-up done")
-    step_form = None
+    step_form, fell_back = None, []
     if mg is not None:
-        # first contact: did an in-kernel wait of the fused step give up (it sets a flag instead of hanging)?  Then every rank drops
-        # to the two-launch form and the chain starts again -- a slower number instead of none.
-        step_form = "fused one-launch step" if mg.info["fused_step"] else "two launches (own, other) + stream hand-offs"
-        bad = 0
-        try:
-            mg.check()
-        except D.DaspError:
-            bad = 1
-        if dist is not None and world > 1:
-            bt = torch.tensor([bad])
-            dist.all_reduce(bt, op=dist.ReduceOp.MAX)
-            bad = int(bt.item())
-        if bad:
-            step_form = "two launches (own, other) + stream hand-offs -- the fused step timed out during warm-up"
-            if mg.info["fused_step"]:
+        # first contact: did a wait inside a kernel give up (it sets a flag instead of hanging)?  Then every rank takes the next
+        # configuration down -- direct exchange -> RCCL on the CU-masked stream -> RCCL, two launches -- and the chain starts again: a
+        # slower number instead of none.
+        for _attempt in range(3):
+            bad = 0
+            try:
+                mg.check()
+            except D.DaspError as exc:
+                bad = 1
+                sys.stderr.write("bench.py rank %d: %s\n" % (rank, exc))
+            if dist is not None and world > 1:
+                bt = torch.tensor([bad])
+                dist.all_reduce(bt, op=dist.ReduceOp.MAX)
+                bad = int(bt.item())
+            if not bad:
+                break
+            fell_back.append("%s, %s" % (exch, "fused" if mg.info["fused_step"] else "two launches"))
+            if exch == "direct" and has_comm:
+                if mg.info["exchange"] == 1:
+                    mg.set_exchange("rccl")
+                exch, stream = "RCCL", use_rccl()
+            elif mg.info["fused_step"]:
                 mg.set_fused(False)
+                stream = base_stream
+            else:
+                break                                                 # nothing left to drop to: the line below will carry the error
             mg.set_x(np.ones(cols, np.float64 if prec == 64 else np.float16))
             for _ in range(args.warmup):
                 step()
             fence()
+        step_form = ("fused one-launch step" if mg.info["fused_step"] else "two launches (own, other) + stream hand-offs") + \
+                    ("" if not fell_back else " -- after a time-out during warm-up with: " + "; ".join(fell_back))
         dog.kick("first contact checked")
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    region = D.multi.StreamTimer(stream)                          # HIP events on the launch stream (not necessarily torch's current one)
     t0 = time.perf_counter()
-    ev0.record()
+    region.start()
     for _ in range(args.steps):
         step()
-    ev1.record()
+    region_ms = region.stop()
     fence()
     elapsed = time.perf_counter() - t0
     if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    region_event_ms = ev0.elapsed_time(ev1) / args.steps
+    region_event_ms = region_ms / args.steps
     dog.kick("timed region done")
     mg_err = None
     if mg is not None:
@@ -634,18 +694,17 @@ def main():
     parts = None
     if mg is not None and not host_exchange:
         tdt = torch.float64 if prec == 64 else torch.float16
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 20
         for _ in range(3):
             mg.allgather(stream)
         torch.cuda.synchronize()
         dist.barrier()
-        e0.record()
+        agt = D.multi.StreamTimer(stream)
+        agt.start()
         for _ in range(reps):
             mg.allgather(stream)
-        e1.record()
+        ag_ms = agt.stop() / reps
         torch.cuda.synchronize()
-        ag_ms = e0.elapsed_time(e1) / reps
         oth = mg.subplan(1)
         oth_ms = 0.0
         if oth is not None:
@@ -690,10 +749,12 @@ def main():
                    "generator": generator_of(D, name), "generator_rev": generator_revision(),
                    "rows": rows, "cols": cols, "nnz": nnz_total, "scale": scale,
                    "partition": "single GPU" if not multi else
-                   ("row ranges by nnz + ncclAllGather(y) from libdasp_amd.so (dasp_mg_spmv), overlapped with the product over the rank's own columns; x_{t+1} = y_t"
-                    if mg.overlap else "row ranges by nnz + ncclAllGather(y) from libdasp_amd.so (dasp_mg_spmv); x_{t+1} = y_t"),
+                   ("row ranges by nnz + all-gather of y (dasp_mg_spmv, libdasp_amd.so), overlapped with the product over the rank's own columns; x_{t+1} = y_t"
+                    if mg.overlap else "row ranges by nnz + all-gather of y (dasp_mg_spmv, libdasp_amd.so); x_{t+1} = y_t"),
                    **({} if mg is None else {"rank0_nnz_own_columns": mg.nnz_local, "rank0_nnz_other_columns": mg.nnz_remote,
-                                             "exchange": "host memory (test hook)" if host_exchange else "RCCL",
+                                             "exchange": {"host": "host memory (test hook)", "RCCL": "ncclAllGather" + (
+                                                 "; products on the plan's CU-masked stream (32 CUs left to RCCL's kernels)" if stream != base_stream else ""),
+                                                 "direct": "direct stores into the peers' gather buffers (hipIpc mappings) + flag words (dasp_mg_push_connect)"}[exch],
                                              "step_form": step_form,
                                              "stream_handoff": "in-kernel flags + one-lane kernels on the communication stream" if mg.info["fused_step"] else
                                              ("hipStreamWriteValue64 / hipStreamWaitValue64" if mg.info["stream_memops"] else "events")}),
@@ -748,6 +809,9 @@ def main():
                                              "note": "values, x ~ U(-1,1) seed 12345 instead of the reference driver's all-ones mode; 200 launches"}
     del ci
     if mg is not None:
+        torch.cuda.synchronize()
+        if dist is not None and world > 1:
+            dist.barrier()                                        # direct exchange: nobody frees a buffer a peer still has mapped and may be storing into
         mg.close()
 
     if rank == 0 and world == 1 and not multi and not args.no_vendor:

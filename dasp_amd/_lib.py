@@ -163,6 +163,8 @@ def lib():
     L.dasp_mg_push_connect.argtypes = [vp, vp]
     L.dasp_mg_set_exchange.argtypes = [vp, C.c_int]
     L.dasp_mg_push_loopback.argtypes = [vp]
+    L.dasp_mg_reserved_stream.argtypes = [vp, C.c_int]
+    L.dasp_mg_reserved_stream.restype = vp
     L.dasp_synth_dims.argtypes = [C.c_char_p, C.c_double, ip, ip]
     L.dasp_synth_generator.argtypes = [C.c_char_p]
     L.dasp_synth_generator.restype = C.c_char_p
@@ -184,4 +186,4 @@ EXPORTS = (
     "dasp_selftest_mfma dasp_synth_dims dasp_synth_generator dasp_synth_row_lengths dasp_synth_rows "
     "dasp_mg_unique_id dasp_mg_plan_create dasp_mg_destroy dasp_mg_upload dasp_mg_comm_init dasp_mg_set_x dasp_mg_spmv dasp_mg_product dasp_mg_allgather "
     "dasp_mg_wait dasp_mg_get_y dasp_mg_get_y_local dasp_mg_y_local dasp_mg_gathered dasp_mg_x dasp_mg_subplan dasp_mg_info dasp_mg_check dasp_mg_set_fused dasp_mg_set_fake_exchange "
-    "dasp_mg_push_export dasp_mg_push_connect dasp_mg_set_exchange dasp_mg_push_loopback").split()
+    "dasp_mg_push_export dasp_mg_push_connect dasp_mg_set_exchange dasp_mg_push_loopback dasp_mg_reserved_stream").split()

@@ -123,6 +123,8 @@ struct dasp_mg_plan {
     bool pending_sig = false;          // ... and its completion was published by a stream memory operation (else: ev_g)
     bool pending_lazy = false;         // ... fused step: ev_g not recorded yet (nobody but the step kernel has asked so far)
     hipStream_t cs = nullptr;          // communication stream
+    hipStream_t rs = nullptr;          // dasp_mg_reserved_stream: a compute stream that keeps off `rs_cus` CUs
+    int rs_cus = 0;
     hipEvent_t ev_y = nullptr, ev_g = nullptr;
     // two-launch form: cross-stream hand-offs through events (documented acquire / release semantics).  DASP_MG_SYNC=memops opts into
     // stream memory operations (hipStreamWriteValue64 / hipStreamWaitValue64, a Beta API) on two words of SIGNAL memory, one
@@ -184,6 +186,7 @@ struct dasp_mg_plan {
         if (ev_y) (void)hipEventDestroy(ev_y);
         if (ev_g) (void)hipEventDestroy(ev_g);
         if (cs) (void)hipStreamDestroy(cs);
+        if (rs) (void)hipStreamDestroy(rs);
         for (uint64_t *w : sig) if (w) (void)hipFree(w);
         if (words) (void)hipFree(words);
         if (d_mark) (void)hipFree(d_mark);
@@ -905,6 +908,30 @@ int dasp_mg_push_loopback(dasp_mg_plan_t *mg)
     if (!g.push_scratch) MG_HIP(hipMalloc(&g.push_scratch, 2 * g.all_bytes()));
     g.push_loopback = true;
     return push_enable(g);
+}
+
+void *dasp_mg_reserved_stream(dasp_mg_plan_t *mg, int reserve_cus)
+{
+    if (!mg || reserve_cus <= 0) { set_error("dasp_mg_reserved_stream: bad arguments"); return nullptr; }
+    dasp_mg_plan &g = *mg;
+    if (!g.uploaded) { set_error("dasp_mg_upload first"); return nullptr; }
+    if (g.rs) return g.rs;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(g.device) != hipSuccess || hipGetDeviceProperties(&prop, g.device) != hipSuccess) { (void)hipGetLastError(); set_error("dasp_mg_reserved_stream: no device"); return nullptr; }
+    // KFD deals the bits of a queue's CU mask to the XCDs in turn (bit i -> XCD i % 8) and, inside an XCD, to its four shader engines in
+    // turn (tools/micro/cumask.hip: the top 32 bits are one CU of every shader engine of every XCD).  A workgroup is bound to a shader
+    // engine before it looks for a CU, so the reserve has to be whole groups of 32: with the top 16 bits only, half of a 16-workgroup
+    // kernel of RCCL's footprint still started 100 us late.
+    const int cus = prop.multiProcessorCount, group = 32;
+    const int keep_off = (reserve_cus + group - 1) / group * group;
+    if (cus < 2 * group || keep_off * 2 > cus) { set_error("dasp_mg_reserved_stream: cannot keep " + std::to_string(keep_off) + " of " + std::to_string(cus) + " CUs free"); return nullptr; }
+    std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0xFFFFFFFFu);
+    for (int b = cus - keep_off; b < (int)mask.size() * 32; ++b) mask[(size_t)b / 32] &= ~(1u << (b % 32));
+    hipStream_t s = nullptr;
+    const hipError_t e = hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data());
+    if (e != hipSuccess) { (void)hipGetLastError(); set_error(std::string("hipExtStreamCreateWithCUMask: ") + hipGetErrorString(e)); return nullptr; }
+    g.rs = s; g.rs_cus = keep_off;
+    return s;
 }
 
 int dasp_mg_set_exchange(dasp_mg_plan_t *mg, int mode)

@@ -25,6 +25,35 @@ def unique_id():
     return buf
 
 
+class StreamTimer:
+    """HIP events on an arbitrary stream handle (ctypes; torch.cuda.Event only sees torch's current stream, and torch refuses a CU-masked
+    stream as its current one): t = StreamTimer(stream); t.start(); ...launches...; ms = t.stop() (synchronises the stop event)."""
+
+    def __init__(self, stream):
+        self._hip = C.CDLL("libamdhip64.so")
+        self._s = C.c_void_p(stream)
+        self._e = [C.c_void_p(), C.c_void_p()]
+        for e in self._e:
+            if self._hip.hipEventCreate(C.byref(e)) != 0:
+                raise RuntimeError("hipEventCreate failed")
+
+    def start(self):
+        if self._hip.hipEventRecord(self._e[0], self._s) != 0:
+            raise RuntimeError("hipEventRecord failed")
+
+    def stop(self):
+        ms = C.c_float()
+        if self._hip.hipEventRecord(self._e[1], self._s) != 0 or self._hip.hipEventSynchronize(self._e[1]) != 0 or \
+                self._hip.hipEventElapsedTime(C.byref(ms), self._e[0], self._e[1]) != 0:
+            raise RuntimeError("HIP event timing failed")
+        return float(ms.value)
+
+    def __del__(self):
+        for e in getattr(self, "_e", []):
+            if e:
+                self._hip.hipEventDestroy(e)
+
+
 class MgPlan:
     def __init__(self, rp, ci, val, n_rows, n_cols, bounds, rank, precision=64, overlap=True, threads=0, **opts):
         """rp / ci / val: this rank's CSR slice (local row pointer, GLOBAL column ids)."""
@@ -125,6 +154,12 @@ class MgPlan:
     def set_exchange(self, mode):
         """'rccl' / 'push' (after push_connect)"""
         _lib.check(_lib.lib().dasp_mg_set_exchange(self._h, {"rccl": 0, "push": 1}[mode]))
+
+    def reserved_stream(self, cus=32):
+        """a compute stream of the plan that keeps `cus` CUs free for RCCL's kernels (integer handle, as torch's cuda_stream); None if
+        the device cannot make one"""
+        h = _lib.lib().dasp_mg_reserved_stream(self._h, int(cus))
+        return int(h) if h else None
 
     def push_loopback(self):
         """TEST HOOK: the direct exchange with scratch memory of this rank standing in for every peer (timing on a one-GPU box)"""

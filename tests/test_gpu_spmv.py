@@ -918,13 +918,15 @@ def test_power_iteration_example_matches_scipy(dasp, torch_cuda, monkeypatch):
     assert abs(lam - ref) <= 1e-10 * ref
 
 
-def test_bench_multi_rank_flow_on_one_gpu(torch_cuda):
+@pytest.mark.parametrize("exchange", ["direct", "host"])
+def test_bench_multi_rank_flow_on_one_gpu(torch_cuda, exchange):
     """`python bench.py --gpus 2` end to end, launched bare (bench.py spawns its own two ranks as a child torch.distributed.run
     job): partition, per-rank dasp_mg plans, exchange, max-over-ranks timing, chained + random-x checks, JSON line -- both ranks
-    sharing this box's single GPU with the y slices moved through host memory: everything but RCCL itself"""
+    sharing this box's single GPU.  "direct": the bench's first choice as on a multi-GPU node -- the two processes map each other's gather
+    buffers through hipIpc and exchange with stores + flag words (fused step); "host": the y slices moved through host memory."""
     import json
     import sys
-    env = dict(os.environ, DASP_BENCH_SHARE_GPU="1")
+    env = dict(os.environ, DASP_BENCH_SHARE_GPU="1", DASP_BENCH_EXCHANGE=exchange)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
                         "--scale", "0.02"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -933,6 +935,9 @@ def test_bench_multi_rank_flow_on_one_gpu(torch_cuda):
     assert out["n_gpus"] == 2 and out["verified"] is True and out["scaling"] == "strong" and out["value"] > 0
     assert out["config"]["partition"].startswith("row ranges") and "roofline" in out and "suite" not in out
     assert out["verified_random_x"]["ok"] is True and out["verified_random_x"]["rows_checked"] > 1000
+    assert out["config"]["exchange"].startswith("direct stores" if exchange == "direct" else "host memory")
+    if exchange == "direct":
+        assert "time-out" not in out["config"]["step_form"] and "error" not in out
 
 
 def test_bench_rccl_calls_run_at_world_size_one(torch_cuda):
@@ -951,7 +956,7 @@ def test_bench_rccl_calls_run_at_world_size_one(torch_cuda):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 1 and out["verified"] is True and out["config"]["partition"].startswith("row ranges")
-    assert out["config"]["exchange"] == "RCCL" and out["verified_random_x"]["ok"] is True
+    assert out["config"]["exchange"] == "ncclAllGather" and out["verified_random_x"]["ok"] is True
 
 
 @pytest.mark.parametrize("prec", [64, 16])

@@ -7,7 +7,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dasp_amd as D
-from dasp_amd.multi import MgPlan
+from dasp_amd.multi import MgPlan, StreamTimer
 
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 name = sys.argv[2] if len(sys.argv) > 2 else "HV15R"
@@ -24,19 +24,20 @@ else:
     bounds = np.searchsorted(rpf, rpf[-1] * np.arange(world + 1) // world, side="left").astype(np.int32)
     bounds[0], bounds[-1] = 0, rows
 s = torch.cuda.current_stream().cuda_stream
+s0 = s
 
 HOST = {}
 def step_time(mg, n=300):
     for _ in range(20): mg.spmv(s)
     mg.wait(s); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); h0 = time.perf_counter()
+    t = StreamTimer(s)
+    t.start(); h0 = time.perf_counter()
     for _ in range(n): mg.spmv(s)
     h1 = time.perf_counter()
-    mg.wait(s); e1.record(); torch.cuda.synchronize()
+    mg.wait(s); ms = t.stop(); torch.cuda.synchronize()
     mg.check()
     HOST["us"] = (h1 - h0) / n * 1e6
-    return e0.elapsed_time(e1) / n * 1e3
+    return ms / n * 1e3
 
 worst = {}
 for rank in ranks:
@@ -48,6 +49,9 @@ for rank in ranks:
     mg.set_x(np.ones(cols))
     line = "rank %d rows %d nnz own %d other %d fused_ok %d |" % (rank, r1 - r0, mg.nnz_local, mg.nnz_remote, mg.info["fused_step"])
     can_fuse = mg.info["fused_step"] == 1
+    if os.environ.get("PROBE_RESERVE"):                  # the plan's CU-masked compute stream (what the RCCL exchange needs)
+        s = mg.reserved_stream(int(os.environ["PROBE_RESERVE"]))
+        assert s, "no reserved stream"
     if os.environ.get("PROBE_EXCHANGE") == "push":      # the direct exchange, scratch memory standing in for the peers (+ the emulated link time)
         mg.push_loopback()
     for fused in ([] if os.environ.get("PROBE_KERNEL_ONLY") == "1" else [True, False] if can_fuse else [False]):
@@ -63,11 +67,11 @@ for rank in ranks:
         mg.set_fused(True); mg.set_x(np.ones(cols))
         for _ in range(10): mg.product(s)
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); h0 = time.perf_counter()
+        t = StreamTimer(s)
+        t.start(); h0 = time.perf_counter()
         for _ in range(100): mg.product(s)
-        h1 = time.perf_counter(); e1.record(); torch.cuda.synchronize()
-        line += " | step kernel alone %.1f (host enqueue %.1f)" % (e0.elapsed_time(e1) / 100 * 1e3, (h1 - h0) * 1e4)
+        h1 = time.perf_counter(); ms = t.stop(); torch.cuda.synchronize()
+        line += " | step kernel alone %.1f (host enqueue %.1f)" % (ms / 100 * 1e3, (h1 - h0) * 1e4)
     own = mg.subplan(0); oth = mg.subplan(1)
     x = torch.ones(own.x_len, dtype=torch.float64, device="cuda"); y = torch.zeros(mg.stride, dtype=torch.float64, device="cuda")
     t_own = own.time(x.data_ptr(), y.data_ptr(), s, warmup=5, iters=100)[1] * 1e3
@@ -88,7 +92,7 @@ if os.environ.get("PROBE_FULL", "1") == "1":
     plan = D.Plan(rp, ci, np.ones(ci.size), cols).upload(); plan.drop_host()
     del ci
     x = torch.ones(cols, dtype=torch.float64, device="cuda"); y = torch.zeros(rows, dtype=torch.float64, device="cuda")
-    t1 = plan.time(x.data_ptr(), y.data_ptr(), s, warmup=10, iters=200)[1] * 1e3
+    t1 = plan.time(x.data_ptr(), y.data_ptr(), s0, warmup=10, iters=200)[1] * 1e3
     print("1-GPU step %.1f us" % t1)
     for k in sorted(worst):
         print("max over ranks %-8s exchange %3d us: %.1f us  -> %.2fx" % (k[0], k[1], worst[k], t1 / worst[k]), flush=True)
