@@ -526,14 +526,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
-    def use_rccl():
-        """RCCL as the exchange: the plan's compute stream that leaves 32 CUs to RCCL's kernels; without one, the two-launch form"""
-        rs = mg.reserved_stream(32) if world > 1 and os.environ.get("DASP_BENCH_RESERVE_CUS", "32") != "0" else None
-        if rs:
-            return rs
-        if world > 1 and mg.info["fused_step"]:
-            mg.set_fused(False)
-        return base_stream
+    def apply(cfg):
+        """put the plan into configuration (exchange, fused?) and return the stream its products go on"""
+        ex, fused = cfg
+        if ex != "host" and mg.info["exchange"] != (1 if ex == "direct" else 0):
+            mg.set_exchange("push" if ex == "direct" else "rccl")
+        if bool(mg.info["fused_step"]) != fused:
+            mg.set_fused(fused)
+        # RCCL: the plan's compute stream that leaves 32 CUs to RCCL's kernels (its kernels do not start beside the product otherwise)
+        rs = mg.reserved_stream(32) if ex == "RCCL" and world > 1 and os.environ.get("DASP_BENCH_RESERVE_CUS", "32") != "0" else None
+        return rs if rs else base_stream
 
     if multi and not share_gpu:
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")          # one node: RCCL's bootstrap sockets need no NIC (and must not fail for lack of one)
@@ -562,11 +564,19 @@ def main():
             elif good:
                 mg.set_exchange("rccl")
         dog.kick("direct exchange " + ("connected" if exch else "unavailable"))
-    if multi and exch is None:
+    # the configurations this run may use, best first; a time-out at first contact moves every rank one down
+    cfgs, cfg_i = [], 0
+    if multi:
+        can_fuse = bool(mg.info["fused_step"])
+        if exch == "direct":
+            cfgs += [("direct", True)] * can_fuse + [("direct", False)]
         if has_comm:
-            exch, stream = "RCCL", use_rccl()
-        else:
-            exch = "host"
+            rs_ok = world > 1 and os.environ.get("DASP_BENCH_RESERVE_CUS", "32") != "0" and mg.reserved_stream(32)
+            cfgs += [("RCCL", True)] * (can_fuse and (bool(rs_ok) or world == 1)) + [("RCCL", False)]
+        if not cfgs:
+            cfgs = [("host", False)]
+        exch = cfgs[0][0]
+        stream = apply(cfgs[0])
     host_exchange = exch == "host"
 
     def step():
@@ -595,9 +605,9 @@ def main():
     step_form, fell_back = None, []
     if mg is not None:
         # first contact: did a wait inside a kernel give up (it sets a flag instead of hanging)?  Then every rank takes the next
-        # configuration down -- direct exchange -> RCCL on the CU-masked stream -> RCCL, two launches -- and the chain starts again: a
+        # configuration down (cfgs: direct exchange fused / two launches -> RCCL on the CU-masked stream fused / two launches) and the chain starts again: a
         # slower number instead of none.
-        for _attempt in range(3):
+        for _attempt in range(4):
             bad = 0
             try:
                 mg.check()
@@ -610,16 +620,12 @@ def main():
                 bad = int(bt.item())
             if not bad:
                 break
-            fell_back.append("%s, %s" % (exch, "fused" if mg.info["fused_step"] else "two launches"))
-            if exch == "direct" and has_comm:
-                if mg.info["exchange"] == 1:
-                    mg.set_exchange("rccl")
-                exch, stream = "RCCL", use_rccl()
-            elif mg.info["fused_step"]:
-                mg.set_fused(False)
-                stream = base_stream
-            else:
+            fell_back.append("%s, %s" % (cfgs[cfg_i][0], "fused" if cfgs[cfg_i][1] else "two launches"))
+            if cfg_i + 1 >= len(cfgs):
                 break                                                 # nothing left to drop to: the line below will carry the error
+            cfg_i += 1
+            exch = cfgs[cfg_i][0]
+            stream = apply(cfgs[cfg_i])
             mg.set_x(np.ones(cols, np.float64 if prec == 64 else np.float16))
             for _ in range(args.warmup):
                 step()

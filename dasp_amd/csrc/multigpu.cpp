@@ -800,10 +800,9 @@ int dasp_mg_check(dasp_mg_plan_t *mg)
     MG_HIP(hipMemset(g.words, 0, kMgWordBytes));
     g.gathered_step = 0;
     if ((int)err == 3) {
-        // direct exchange: a sender's flag did not arrive in time.  Results since then are invalid; the plan goes back to RCCL (if
-        // there is a communicator) and the caller starts again from dasp_mg_set_x
-        if (int rc = set_exchange(g, 0)) return rc;
-        set_error("direct exchange: a peer's slice did not arrive within the time-out; the plan now exchanges through RCCL -- call dasp_mg_set_x and start again");
+        // direct exchange: a sender's flag did not arrive in time.  Results since then are invalid.  The exchange is NOT switched here:
+        // which exchange the ranks use is a collective decision (dasp_mg_set_exchange on every rank, then dasp_mg_set_x)
+        set_error("direct exchange: a peer's slice did not arrive within the time-out; results since then are invalid -- dasp_mg_set_exchange(0) on every rank for RCCL, then dasp_mg_set_x");
         return DASP_ERR_STATE;
     }
     // a poll gave up: products since then lack other-column terms (1) or an exchange ran ahead of its product (2).  Drop to the
