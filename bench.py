@@ -427,6 +427,18 @@ def cpu_baseline(O, rp, ci, n_cols, budget_s=20.0):
             "achieved_GBps": round(algorithmic_bytes(rp.size - 1, n_cols, nnz, 8) / med / 1e9, 2)}
 
 
+def exchange_configs(direct_ok, has_comm, can_fuse, reserved_ok, world):
+    """The (exchange, fused step?) configurations a multi-rank run may use, best first; a time-out at first contact moves every rank one down.
+    direct stores fit beside the product in either form; RCCL's kernels need the CU-masked stream to start at all while the fused step's
+    workgroups wait (world size 1 has no kernel to fit); with neither, the y slices go through host memory (test hook)."""
+    cfgs = []
+    if direct_ok:
+        cfgs += [("direct", True)] * can_fuse + [("direct", False)]
+    if has_comm:
+        cfgs += [("RCCL", True)] * (can_fuse and (reserved_ok or world == 1)) + [("RCCL", False)]
+    return cfgs or [("host", False)]
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child torch.distributed.run job (this parent never
     touches the GPU), relay the output, exit with the job's code.  Too few devices is an error of its own (rc 4), not a usage
@@ -564,17 +576,10 @@ def main():
             elif good:
                 mg.set_exchange("rccl")
         dog.kick("direct exchange " + ("connected" if exch else "unavailable"))
-    # the configurations this run may use, best first; a time-out at first contact moves every rank one down
     cfgs, cfg_i = [], 0
     if multi:
-        can_fuse = bool(mg.info["fused_step"])
-        if exch == "direct":
-            cfgs += [("direct", True)] * can_fuse + [("direct", False)]
-        if has_comm:
-            rs_ok = world > 1 and os.environ.get("DASP_BENCH_RESERVE_CUS", "32") != "0" and mg.reserved_stream(32)
-            cfgs += [("RCCL", True)] * (can_fuse and (bool(rs_ok) or world == 1)) + [("RCCL", False)]
-        if not cfgs:
-            cfgs = [("host", False)]
+        rs_ok = has_comm and world > 1 and os.environ.get("DASP_BENCH_RESERVE_CUS", "32") != "0" and bool(mg.reserved_stream(32))
+        cfgs = exchange_configs(exch == "direct", has_comm, bool(mg.info["fused_step"]), rs_ok, world)
         exch = cfgs[0][0]
         stream = apply(cfgs[0])
     host_exchange = exch == "host"

@@ -80,3 +80,14 @@ def test_watchdog_ends_a_stuck_rank_with_a_json_error_line():
     assert r.returncode == 5
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["value"] is None and line["n_gpus"] == 8 and "RCCL communicator up" in line["error"]
+
+
+def test_exchange_configurations_best_first():
+    """bench.py N > 1: direct exchange before RCCL, the fused step before two launches; RCCL + fused only where its kernel can start while
+    workgroups wait (CU-masked stream, or one rank); nothing at all -> the host-memory test hook"""
+    f = _bench().exchange_configs
+    assert f(True, True, True, True, 8) == [("direct", True), ("direct", False), ("RCCL", True), ("RCCL", False)]
+    assert f(True, True, True, False, 8) == [("direct", True), ("direct", False), ("RCCL", False)]
+    assert f(False, True, True, False, 1) == [("RCCL", True), ("RCCL", False)]
+    assert f(True, False, False, False, 2) == [("direct", False)]
+    assert f(False, False, True, False, 2) == [("host", False)]

@@ -11,3 +11,6 @@ export TMPDIR=/tmp
 rm -rf gpurun_out/round_end_prof
 (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/round_end_prof -- python3 $GRAFT_REPO_ROOT/bench.py --no-suite --no-vendor --steps 20 > $GRAFT_REPO_ROOT/gpurun_out/round_end_prof.log 2>&1)
 PROBE_FULL=1 PROBE_AG_US=0,20,40,60 timeout 1500 python tools/mg_step_probe.py 8 HV15R all > gpurun_out/round_end_mg_allranks.log 2>&1; tail -9 gpurun_out/round_end_mg_allranks.log
+# the same with the direct exchange (mgx.hip; loopback: scratch memory of this GPU as the peers, + N us for the links) and the exchange-footprint probes (profiles/r03_exchange_footprint.md)
+PROBE_FULL=1 PROBE_EXCHANGE=push PROBE_AG_US=0,40 timeout 1500 python tools/mg_step_probe.py 8 HV15R all > gpurun_out/round_end_mg_allranks_push.log 2>&1; tail -5 gpurun_out/round_end_mg_allranks_push.log
+bash tools/fat_exchange_probe.sh > gpurun_out/round_end_fat_exchange.log 2>&1
