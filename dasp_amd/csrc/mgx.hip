@@ -22,14 +22,15 @@ namespace dasp {
         if (e_ != hipSuccess) { set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); return DASP_ERR_HIP; } \
     } while (0)
 
-// grid = n_dst * wgs workgroups.  Workgroup (d, part): [optionally wait for `ready` >= ready_need: the products of this step are
-// complete] copy part `part` of the slice to destination d, count itself; the last of a destination's workgroups publishes `seq` in
-// that destination's flag word.  16-byte loads / stores, 4 in flight per lane.
+// grid = wgs workgroups.  Workgroup w: [optionally wait for `ready` >= ready_need: the products of this step are complete] load part w
+// of the slice ONCE and store it to every destination, then count itself at every destination's counter; the last arrival at a
+// destination's counter publishes `seq` in that destination's flag word.  16-byte loads / stores, up to 4 loads and 4 x n_dst stores in
+// flight per lane: with 256 workgroups a 2-MB slice is ONE round (first layout: a workgroup per (destination, part), the slice read
+// n_dst times in 4-8 dependent rounds -- 25 us under the running product instead of 9 alone).
 // No fences: a release fence is a write-back of the whole L2 (buffer_wbl2) and an acquire an invalidate, per wave, under the running
 // product (first version, 16 workgroups per destination: the step 108 us instead of 75; 32: 138 us).  Instead every access is
-// system-coherent by itself -- sc0 sc1 loads (the slice was written through by the product's sc0 sc1 stores, possibly from another XCD
-// whose L2 this one does not snoop) and sc0 sc1 write-through stores, complete when s_waitcnt vmcnt(0) returns -- and the counter and
-// the flag are relaxed atomics issued after that.
+// system-coherent by itself -- sc0 sc1 loads (the slice was written through by the product's sc0 sc1 stores) and sc0 sc1 write-through
+// stores, complete when s_waitcnt vmcnt(0) returns -- and the counters and the flags are relaxed atomics issued after that.
 // (as inline assembly: the compiler puts an s_waitcnt vmcnt(0) behind EVERY volatile access, one access in flight per wave)
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4u ld_sys(const v4u *p)
@@ -39,9 +40,9 @@ __device__ __forceinline__ v4u ld_sys(const v4u *p)
     return v;
 }
 __device__ __forceinline__ void st_sys(v4u *p, v4u v) { asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory"); }
+
 __global__ __launch_bounds__(256) void dasp_mg_push_kernel(MgPushArgs a)
 {
-    const int d = blockIdx.x / a.wgs, part = blockIdx.x % a.wgs;
     if (a.ready_need) {
         if (threadIdx.x == 0) {
             const long long t0 = wall_clock64();
@@ -52,28 +53,33 @@ __global__ __launch_bounds__(256) void dasp_mg_push_kernel(MgPushArgs a)
         }
         __syncthreads();
     }
-    const MgPushDst dst = a.dst[d];
     const size_t n16 = a.bytes >> 4;                                   // the slice is a multiple of 64 elements: of 16 bytes
-    const size_t per = (n16 + a.wgs - 1) / a.wgs, i0 = per * part, i1 = i0 + per < n16 ? i0 + per : n16;
+    const size_t per = (n16 + a.wgs - 1) / a.wgs, i0 = per * blockIdx.x, i1 = i0 + per < n16 ? i0 + per : n16;
     const v4u *src = reinterpret_cast<const v4u *>(a.src);
-    v4u *out = reinterpret_cast<v4u *>(dst.data);
+    // the destination table through the CONSTANT address space: scalar loads (lgkmcnt) -- a vector load of it would make the compiler wait
+    // for vmcnt(0), i.e. for the previous destination's stores to be acknowledged, before every destination
+    typedef const __attribute__((address_space(4))) MgPushDst *DstTab;
+    const DstTab dst = (DstTab)(uintptr_t)a.dst;
     size_t i = i0 + threadIdx.x;
     for (; i + 768 < i1; i += 1024) {                                  // the stores of one round are in flight under the loads of the next
         const v4u v0 = ld_sys(src + i), v1 = ld_sys(src + i + 256), v2 = ld_sys(src + i + 512), v3 = ld_sys(src + i + 768);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st_sys(out + i, v0); st_sys(out + i + 256, v1); st_sys(out + i + 512, v2); st_sys(out + i + 768, v3);
+        for (int d = 0; d < a.n_dst; ++d) {
+            v4u *out = reinterpret_cast<v4u *>(dst[d].data);
+            st_sys(out + i, v0); st_sys(out + i + 256, v1); st_sys(out + i + 512, v2); st_sys(out + i + 768, v3);
+        }
     }
     for (; i < i1; i += 256) {
         const v4u v = ld_sys(src + i);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st_sys(out + i, v);
+        for (int d = 0; d < a.n_dst; ++d) st_sys(reinterpret_cast<v4u *>(dst[d].data) + i, v);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's stores have been performed at the destination
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's stores have been performed at their destinations
     __syncthreads();
-    if (threadIdx.x == 0) {
+    for (int d = threadIdx.x; d < a.n_dst; d += 256) {
         const unsigned old = __hip_atomic_fetch_add(a.count + d, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((old + 1) % (unsigned)a.wgs == 0)                          // every part for this destination is out
-            __hip_atomic_store(dst.flag, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.dst[d].flag, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -101,10 +107,10 @@ __global__ void dasp_mg_arrived_kernel(const unsigned long long *arrived, int wo
     }
 }
 
-int launch_mg_push(const MgPushArgs &a, int n_dst, void *stream)
+int launch_mg_push(const MgPushArgs &a, void *stream)
 {
-    if (n_dst <= 0 || a.wgs <= 0) return DASP_OK;
-    hipLaunchKernelGGL(dasp_mg_push_kernel, dim3(n_dst * a.wgs), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (a.n_dst <= 0 || a.wgs <= 0) return DASP_OK;
+    hipLaunchKernelGGL(dasp_mg_push_kernel, dim3(a.wgs), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     HIP_TRYX(hipGetLastError());
     return DASP_OK;
 }

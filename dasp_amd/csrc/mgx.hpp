@@ -13,8 +13,9 @@ struct MgPushArgs {
     const void *src;                 // this rank's padded slice of y
     size_t bytes;                    // its size (a multiple of 16)
     const MgPushDst *dst;            // device table, one entry per destination
+    int n_dst;
     unsigned *count;                 // device, one zero-initialised counter per destination (never reset: counts modulo wgs)
-    int wgs;                         // workgroups per destination
+    int wgs;                         // workgroups of the launch: each moves one part of the slice to every destination
     unsigned long long seq;          // what the flags are set to
     const unsigned long long *ready; // fused step: wait for *ready >= ready_need first (ready_need 0: no wait)
     unsigned long long ready_need;
@@ -22,7 +23,7 @@ struct MgPushArgs {
     int *err;                        // sticky error word of the step (2: the wait for the product timed out)
 };
 
-int launch_mg_push(const MgPushArgs &a, int n_dst, void *stream);
+int launch_mg_push(const MgPushArgs &a, void *stream);
 // one wave waits for arrived[0..world) >= seq, then (gathered != nullptr) *gathered = step
 int launch_mg_arrived(const void *arrived, int world, unsigned long long seq, void *gathered, unsigned long long step, long long timeout_ticks,
                       void *err, void *stream);

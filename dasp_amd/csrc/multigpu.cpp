@@ -163,7 +163,7 @@ struct dasp_mg_plan {
     uint64_t xseq = 0;                 // sequence number of the last exchange queued
     uint64_t epoch = 0;                // dasp_mg_set_x / connect count: what this rank last published to its peers' epoch_of[rank]
     bool peers_pending = false;        // the peers have not been seen at `epoch` yet (checked before the next exchange is queued)
-    int push_wgs = 32;                 // workgroups per destination (loopback, 40 us link time: 4 -> 132 us per step, 16 -> 85, 32 -> 79.5, 64 -> 84)
+    int push_wgs = 256;                // workgroups of the push kernel (DASP_MG_PUSH_WGS)
     int fake_us = -1;
     int fake_channels = 0;             // > 0: the stand-in kernel has the footprint of RCCL's (devpack.hip k_spin_fat), that many workgroups
     std::vector<void *> fake_peers;
@@ -400,11 +400,12 @@ int push_exchange(dasp_mg_plan &g, hipStream_t q, uint64_t ready_need, bool set_
     MgPushArgs a{};
     a.src = g.ys[g.cur]; a.bytes = (size_t)g.stride * g.vb();
     a.dst = static_cast<const MgPushDst *>(g.d_push_dst) + (size_t)(seq & 1) * (size_t)g.world;
+    a.n_dst = g.world;
     a.count = static_cast<unsigned *>(g.d_push_count);
     a.wgs = g.push_wgs; a.seq = seq;
     a.ready = reinterpret_cast<const unsigned long long *>(g.words + kMgWordReady); a.ready_need = ready_need;
     a.timeout = g.timeout_ticks; a.err = reinterpret_cast<int *>(g.words + kMgWordErr);
-    if (int rc = launch_mg_push(a, g.world, q)) return rc;
+    if (int rc = launch_mg_push(a, q)) return rc;
     if (g.push_loopback && g.fake_us > 0) if (int rc = devpack_spin(q, g.fake_us, 0)) return rc;       // timing probe: the links' share of the exchange
     return launch_mg_arrived(g.xflags, g.world, seq, set_gathered ? g.words + kMgWordGathered : nullptr, step, g.timeout_ticks, g.words + kMgWordErr, q);
 }
@@ -465,7 +466,7 @@ int push_enable(dasp_mg_plan &g)
         MG_HIP(hipMemset(p, 0, kMgWordBytes));
         g.words = static_cast<char *>(p);
     }
-    if (const char *e = std::getenv("DASP_MG_PUSH_WGS")) g.push_wgs = std::max(1, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("DASP_MG_PUSH_WGS")) g.push_wgs = std::max(1, std::min(4096, std::atoi(e)));
     // the current x is in half 0 (RCCL and the test hook use no other): move it to where gcur() will look
     MG_HIP(hipDeviceSynchronize());
     if (g.xseq & 1) { MG_HIP(hipMemcpy(static_cast<char *>(g.yg) + all, g.yg, all, hipMemcpyDeviceToDevice)); MG_HIP(hipDeviceSynchronize()); }
