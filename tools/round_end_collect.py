@@ -61,3 +61,22 @@ a = s.index("| rank | rows | nnz own / other columns |")
 b = s.index("\nReading.  (1)")
 open(p, "w").write(s[:a] + "\n".join(tab) + "\n" + s[b:])
 print("\n".join(tab[-9:]))
+# all ranks with the direct exchange (loopback) -> profiles/r03_exchange_footprint.md, between the markers
+pl = "gpurun_out/round_end_mg_allranks_push.log"
+if os.path.exists(pl):
+    lines = [l.strip() for l in open(pl) if l.startswith(("rank", "max over", "1-GPU"))]
+    tab = ["<!-- allranks-push -->", "## 6. Every rank with the direct exchange (loopback), final batch (`tools/round_end.sh`; fused / two launches, exchange + 0 / 40 us for the links)\n",
+           "| rank | fused step 0 / 40 us | two launches 0 / 40 us |", "|---|---|---|"]
+    for l in lines:
+        if l.startswith("rank"):
+            tab.append("| %s | %s | %s |" % (re.match(r"rank (\d+)", l).group(1), " / ".join(re.findall(r"fused/\d+us ([\d.]+)", l)), " / ".join(re.findall(r"2launch/\d+us ([\d.]+)", l))))
+    tab.append("")
+    tab += ["    " + l for l in lines if not l.startswith("rank")]
+    tab.append("<!-- /allranks-push -->")
+    p = "profiles/r03_exchange_footprint.md"
+    s = open(p).read()
+    if "<!-- allranks-push -->" in s:
+        s = s[:s.index("<!-- allranks-push -->")] + "\n".join(tab) + s[s.index("<!-- /allranks-push -->") + len("<!-- /allranks-push -->"):]
+    else:
+        s = s.rstrip("\n") + "\n\n" + "\n".join(tab) + "\n"
+    open(p, "w").write(s)
