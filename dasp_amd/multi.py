@@ -29,8 +29,22 @@ class StreamTimer:
     """HIP events on an arbitrary stream handle (ctypes; torch.cuda.Event only sees torch's current stream, and torch refuses a CU-masked
     stream as its current one): t = StreamTimer(stream); t.start(); ...launches...; ms = t.stop() (synchronises the stop event)."""
 
+    @staticmethod
+    def _runtime():
+        """the HIP runtime ALREADY mapped into this process (the one libdasp_amd.so and torch use): a second copy found under another
+        name would know nothing of their streams"""
+        try:
+            for line in open("/proc/self/maps"):
+                path = line.split()[-1]
+                if "libamdhip64.so" in path:
+                    return C.CDLL(path)
+        except OSError:
+            pass
+        return C.CDLL("libamdhip64.so")
+
     def __init__(self, stream):
-        self._hip = C.CDLL("libamdhip64.so")
+        _lib.lib()                                   # maps libdasp_amd.so and with it the runtime
+        self._hip = self._runtime()
         self._s = C.c_void_p(stream)
         self._e = [C.c_void_p(), C.c_void_p()]
         for e in self._e:
