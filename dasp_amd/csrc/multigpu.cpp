@@ -160,7 +160,8 @@ struct dasp_mg_plan {
     void *d_push_dst = nullptr;        // device: MgPushDst[2][world], one table per half
     void *d_push_count = nullptr;      // device: unsigned[world]
     void *push_scratch = nullptr;      // loopback only
-    uint64_t xseq = 0;                 // sequence number of the last exchange queued
+    uint64_t xseq = 0;                 // exchanges queued since the last dasp_mg_set_x / connect; the flags carry (epoch << 32) + xseq, the same on every
+                                       // rank after that collective call, whatever a failed step left behind
     uint64_t epoch = 0;                // dasp_mg_set_x / connect count: what this rank last published to its peers' epoch_of[rank]
     bool peers_pending = false;        // the peers have not been seen at `epoch` yet (checked before the next exchange is queued)
     int push_wgs = 256;                // workgroups of the push kernel (DASP_MG_PUSH_WGS)
@@ -396,10 +397,10 @@ int push_arrive(dasp_mg_plan &g)
 int push_exchange(dasp_mg_plan &g, hipStream_t q, uint64_t ready_need, bool set_gathered, uint64_t step)
 {
     if (int rc = push_wait_peers(g)) return rc;
-    const uint64_t seq = ++g.xseq;
+    const uint64_t seq = (g.epoch << 32) + (++g.xseq);
     MgPushArgs a{};
     a.src = g.ys[g.cur]; a.bytes = (size_t)g.stride * g.vb();
-    a.dst = static_cast<const MgPushDst *>(g.d_push_dst) + (size_t)(seq & 1) * (size_t)g.world;
+    a.dst = static_cast<const MgPushDst *>(g.d_push_dst) + (size_t)(g.xseq & 1) * (size_t)g.world;
     a.n_dst = g.world;
     a.count = static_cast<unsigned *>(g.d_push_count);
     a.wgs = g.push_wgs; a.seq = seq;
@@ -467,9 +468,10 @@ int push_enable(dasp_mg_plan &g)
         g.words = static_cast<char *>(p);
     }
     if (const char *e = std::getenv("DASP_MG_PUSH_WGS")) g.push_wgs = std::max(1, std::min(4096, std::atoi(e)));
-    // the current x is in half 0 (RCCL and the test hook use no other): move it to where gcur() will look
+    // the current x is in half 0 (RCCL and the test hook use no other), where exchange count 0 looks for it
     MG_HIP(hipDeviceSynchronize());
-    if (g.xseq & 1) { MG_HIP(hipMemcpy(static_cast<char *>(g.yg) + all, g.yg, all, hipMemcpyDeviceToDevice)); MG_HIP(hipDeviceSynchronize()); }
+    (void)all;
+    g.xseq = 0;
     g.push = true;
     g.pending = false; g.pending_sig = false; g.pending_lazy = false; g.gathered_step = 0;
     return push_arrive(g);
@@ -487,7 +489,7 @@ int set_exchange(dasp_mg_plan &g, int mode)
     }
     const size_t all = g.all_bytes();
     if (g.xseq & 1) { MG_HIP(hipMemcpy(g.yg, static_cast<char *>(g.yg) + all, all, hipMemcpyDeviceToDevice)); MG_HIP(hipDeviceSynchronize()); }
-    g.push = false;
+    g.push = false; g.xseq = 0;
     return DASP_OK;
 }
 
@@ -635,9 +637,9 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
             if (const char *q = std::getenv("DASP_MG_POLL_PER_CU")) per_cu = std::max(1, std::atoi(q));
             g.max_pollers = cus * per_cu;
             if (const char *q = std::getenv("DASP_MG_POLL_SLEEP")) g.poll_sleep = std::max(1, std::atoi(q));
-            if (const char *q = std::getenv("DASP_MG_TIMEOUT_MS")) g.timeout_ticks = std::max(1, std::atoi(q)) * 100000ll;
         }
     }
+    if (const char *q = std::getenv("DASP_MG_TIMEOUT_MS")) g.timeout_ticks = std::max(1, std::atoi(q)) * 100000ll;      // every in-kernel wait (fused step, direct exchange)
     MG_HIP(hipDeviceSynchronize());
     g.uploaded = true;
     return DASP_OK;
@@ -667,7 +669,8 @@ int dasp_mg_set_x(dasp_mg_plan_t *mg, const void *x_host)
     const char *x = static_cast<const char *>(x_host);
     MG_HIP(hipDeviceSynchronize());
     g.pending = false; g.pending_sig = false; g.pending_lazy = false; g.gathered_step = 0;
-    if (!g.square) { MG_HIP(hipMemcpy(g.xg, x, (size_t)g.colA * vb, hipMemcpyHostToDevice)); return DASP_OK; }
+    g.xseq = 0;                             // direct exchange: x goes to half 0, the next exchange fills half 1 -- on every rank alike
+    if (!g.square) { MG_HIP(hipMemcpy(g.xg, x, (size_t)g.colA * vb, hipMemcpyHostToDevice)); return g.push ? push_arrive(g) : DASP_OK; }
     try {
         std::vector<char> lay((size_t)g.world * g.stride * vb, 0);
         for (int k = 0; k < g.world; ++k)

@@ -359,7 +359,9 @@ int dasp_mg_set_fake_exchange(dasp_mg_plan_t *mg, int micros, int n_peers, void 
  *                                                      DASP_MG_BARRIER_TIMEOUT_S, default 120)
  * Peers inside one process (one process driving several plans) are used through their plain pointers.  A sender that does not deliver
  * within the time-out sets the sticky error: dasp_mg_check then returns DASP_ERR_STATE (the exchange is not switched by it: that is a
- * collective decision -- dasp_mg_set_exchange(mg, 0) on every rank, then dasp_mg_set_x).
+ * collective decision -- dasp_mg_set_exchange(mg, 0) on every rank, then dasp_mg_set_x).  Starting again with dasp_mg_set_x on every
+ * rank is always possible: the flags carry (number of that collective call, exchanges since it), so ranks that stopped at different
+ * steps agree again.
  * dasp_mg_set_exchange: 0 = RCCL, 1 = direct (after a connect); synchronises the device, the current x stays valid.  Collective like
  * dasp_mg_set_x: every rank switches at the same point of its call sequence. */
 enum { DASP_MG_IPC_BYTES = 256 };

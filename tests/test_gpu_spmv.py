@@ -516,6 +516,43 @@ def test_push_exchange_three_ranks_in_one_process(dasp, torch_cuda, fused):
         mg.close()
 
 
+def test_push_exchange_reports_a_peer_that_does_not_deliver(dasp, torch_cuda, monkeypatch):
+    """Direct exchange, two ranks in one process, and only rank 0 steps: its arrival kernel gives up after the time-out (5 ms here), sets
+    the sticky error instead of hanging, and dasp_mg_check says whose fault it is -- without switching the exchange by itself (that is a
+    collective decision).  After both ranks start again from dasp_mg_set_x the chain is right."""
+    from dasp_amd.multi import MgPlan
+    torch = torch_cuda
+    monkeypatch.setenv("DASP_MG_TIMEOUT_MS", "5")
+    world = 2
+    rows, A, bounds, sl = _hv_slices(dasp, world)
+    x0 = np.random.default_rng(5).uniform(0.5, 1.5, rows)
+    mgs = [MgPlan(rp, ci, v, rows, rows, bounds, r, cid16=1).upload() for r, (rp, ci, v) in enumerate(sl)]
+    streams = [torch.cuda.Stream() for _ in mgs]
+    blobs = [mg.push_export() for mg in mgs]
+    for mg in mgs:
+        mg.set_fused(False)
+        mg.push_connect(blobs)
+        mg.set_x(x0)
+    mgs[0].spmv(streams[0].cuda_stream)
+    with pytest.raises(dasp.DaspError, match="did not arrive"):
+        mgs[0].check()
+    assert mgs[0].info["exchange"] == 1
+    mgs[1].check()
+    want = x0
+    for mg in mgs:
+        mg.set_x(x0)
+    for it in range(3):
+        for mg, st in zip(mgs, streams):
+            mg.spmv(st.cuda_stream)
+        want = A @ want
+    for mg in mgs:
+        mg.check()
+        y = mg.get_y()
+        assert np.abs(y - want).max() <= 1e-13 * np.abs(want).max()
+    for mg in mgs:
+        mg.close()
+
+
 @pytest.mark.parametrize("fused", [1, 0])
 def test_push_exchange_between_two_processes(dasp, torch_cuda, tmp_path, fused):
     """The direct exchange across PROCESSES: two ranks, each in a process of its own on this box's one GPU, map each other's gather
