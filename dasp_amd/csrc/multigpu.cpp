@@ -139,6 +139,7 @@ struct dasp_mg_plan {
     bool gather_fine = false;          // yg is fine-grained device memory
     uint64_t gathered_step = 0;        // step number of the last exchange queued on the communication stream (0: none since set_x)
     int max_pollers = 1024, poll_sleep = 1;
+    int max_pollers_thin = 1024;       // ... when the exchange's kernels are thin (direct exchange: 26 registers; they fit beside any number of waiting workgroups)
     std::vector<unsigned char> mark;   // one byte per own-column workgroup of the step kernel: stores a row the other-column plan adds to
     std::vector<unsigned> mark_members;
     std::vector<int> blk_order;        // dispatch order of the own plan's medium blocks in the step kernel (marked ones first)
@@ -335,7 +336,7 @@ int product(dasp_mg_plan &g, hipStream_t s)
         c.words = g.words; c.need = g.gathered_step; c.step = g.step + 1;
         c.mark = g.d_mark; c.mark_members = static_cast<char *>(g.d_mark) + ((g.mark.size() + 255) & ~size_t(255));
         c.n_marked = g.n_marked; c.n_mark_shards = g.n_mark_shards; c.blk_order = g.d_blk_order;
-        c.max_pollers = g.max_pollers; c.timeout_ticks = g.timeout_ticks; c.poll_sleep = g.poll_sleep;
+        c.max_pollers = g.push ? g.max_pollers_thin : g.max_pollers; c.timeout_ticks = g.timeout_ticks; c.poll_sleep = g.poll_sleep;
         if (int rc = launch_mg_step(g.own->impl, g.other ? &g.other->impl : nullptr, g.ys[cur], g.gcur(), g.ys[nxt], c, s)) return rc;
     } else if (g.overlap) {
         // own columns: needs only this rank's slice of x, i.e. its own previous y -- no communication
@@ -636,6 +637,7 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
             int per_cu = std::max(1, std::min(std::min(4, resident - 1), (512 - kExchangeKernelRegs) * resident / 512));
             if (const char *q = std::getenv("DASP_MG_POLL_PER_CU")) per_cu = std::max(1, std::atoi(q));
             g.max_pollers = cus * per_cu;
+            g.max_pollers_thin = std::getenv("DASP_MG_POLL_PER_CU") ? g.max_pollers : cus * std::max(1, std::min(4, resident - 1));      // 1 / 2 / 4 per CU: 76 / 75 / 74 us per step
             if (const char *q = std::getenv("DASP_MG_POLL_SLEEP")) g.poll_sleep = std::max(1, std::atoi(q));
         }
     }
