@@ -705,6 +705,7 @@ int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream)
     if (g.fused) {
         // the communication stream spins (one lane) until the launch's last workgroup has published step k, exchanges, publishes k back
         if (g.push) {          // both waits are inside the exchange's two kernels
+            // (a one-lane wait kernel ahead of the push instead of the wait inside it: 80.3 instead of 76.7 us at a 40-us exchange)
             if (int rc = push_exchange(g, g.cs, k, true, k)) return rc;
         } else {
             if (int rc = launch_mg_wait(g.words + kMgWordReady, k, g.timeout_ticks, g.words + kMgWordErr, g.cs)) return rc;
