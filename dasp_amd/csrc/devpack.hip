@@ -526,6 +526,8 @@ int devpack_gather_columns(const Plan &p, const DevCsr &d, const std::vector<lon
 }
 
 int devpack_finish_panels(Plan &p) { return upload_plan(p); }
+int devpack_current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; } return d; }
+void devpack_use_device(int device) { if (device >= 0) (void)hipSetDevice(device); }
 
 int devpack_all(Plan &p, const DevCsr &d, const PackMeta &m)
 {

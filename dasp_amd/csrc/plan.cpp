@@ -1059,8 +1059,12 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
 {
     using clk = std::chrono::steady_clock;
     const auto t_begin = clk::now();
+    const bool verbose = std::getenv("DASP_VERBOSE") != nullptr;
+    auto tick = t_begin;
+    auto lap = [&](const char *what) { if (verbose) { auto now = clk::now(); std::fprintf(stderr, "[dasp panels] %-26s %.3f s\n", what, std::chrono::duration<double>(now - tick).count()); tick = now; } };
     // whole-matrix classification: order_rid and the reference's counters are those of the unsplit matrix (row lengths only)
     if (int rc = build_impl<T>(p, rp, ci, val, nullptr, kMetaOnly)) return rc;
+    lap("whole-matrix meta");
     const int m = p.m;
     const int threads = resolve_threads(p.opt.host_threads);
     Remap remap;
@@ -1100,9 +1104,11 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     });
     }
 
+    lap("split by column range");
     const bool natural = p.opt.y_order == DASP_Y_NATURAL;
     std::vector<int> slot_of_row;
     if (!natural) { slot_of_row.resize((size_t)m); for (int i = 0; i < m; ++i) slot_of_row[p.order[i]] = i; }
+    lap("slot table");
     const bool streams = (long long)p.nnz * (p.geo.vbytes + 4) > kStreamBytes;
     p.panels.clear(); p.panel_bounds.clear();
     // the panels are built side by side (their O(rows) classifier passes are serial), each with its share of the threads
@@ -1110,10 +1116,13 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     std::vector<int> rcs((size_t)P, DASP_OK);
     std::vector<std::string> errs((size_t)P);
     {
-        const int side = dev ? 1 : std::min(P, threads), each = std::max(1, threads / side);       // device path: one panel at a time (its kernels fill the GPU)
+        // device path too: a panel's O(rows) host stages overlap another panel's kernels and copies (ljournal-2008, 4 panels: 4 x 26 ms one after the other)
+        const int side = dev ? std::min(P, std::min(4, threads)) : std::min(P, threads), each = std::max(1, threads / side);
+        const int hip_device = dev ? devpack_current_device() : -1;
         std::atomic<int> next{0};
         std::vector<std::thread> workers;
         auto work = [&] {
+                if (dev) devpack_use_device(hip_device);          // a new thread starts on device 0
                 for (int k = next++; k < P; k = next++) {
                     const int nnz_k = rpP[k][m];
                     if (nnz_k == 0) continue;                       // an empty panel adds nothing
@@ -1133,9 +1142,10 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
                     built[k] = std::move(h);
                 }
             };
-        if (dev) work();                                  // in the calling thread: it holds the caller's current HIP device
-        else { for (int t = 0; t < side; ++t) workers.emplace_back(work); for (auto &w : workers) w.join(); }
+        for (int t = 0; t < side; ++t) workers.emplace_back(work);
+        for (auto &w : workers) w.join();
     }
+    lap("panel plans");
     for (int k = 0; k < P; ++k) {
         if (rcs[k] != DASP_OK) { set_error(errs[k]); return rcs[k]; }
         if (!built[k]) continue;
@@ -1169,6 +1179,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     s.data_X = dataX + xlen * vb + (long long)(2 * K + 1) * m * vb;
     s.n_col_panels = K;
     if (dev) { if (int rc = devpack_finish_panels(p)) return rc; }      // a device-built plan comes back uploaded: the parent's partial-result buffers too
+    lap("parent upload");
     s.pre_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
     return DASP_OK;
 }

@@ -211,6 +211,9 @@ int devpack_chunk_spans(const Plan &p, const DevCsr &d, const raw_vector<int> &r
                         const std::vector<int> &nchunks, int *k16, unsigned long long *narrow_mask);      // narrow_mask: nullptr or [blocks] (plan.cpp)
 int devpack_all(Plan &p, const DevCsr &d, const PackMeta &m);
 int devpack_finish_panels(Plan &p);
+// the calling thread's HIP device / make `device` the calling thread's (panel workers of a device-built plan)
+int devpack_current_device();
+void devpack_use_device(int device);
 // remapped column ids at the nonzero positions idx[] (or start + i * stride for i < count when idx is null), copied to the host
 int devpack_gather_columns(const Plan &p, const DevCsr &d, const std::vector<long long> *idx, long long start, long long stride, long long count, std::vector<int> &out);      // uploads the parent of device-built panels (its partial-result buffers)
 // column-panel split of a device CSR: P sub-matrices by column range (remapped columns, row order kept); `keep` owns the device arrays
