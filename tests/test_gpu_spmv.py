@@ -516,6 +516,46 @@ def test_push_exchange_three_ranks_in_one_process(dasp, torch_cuda, fused):
         mg.close()
 
 
+@pytest.mark.parametrize("prec,overlap", [(16, True), (16, False), (64, False)])
+def test_push_exchange_other_plan_kinds(dasp, torch_cuda, prec, overlap):
+    """The direct exchange under the plans that do not run the fused step: f16 (two launches, coarse-grained gather buffer) and the
+    unsplit form (ONE plan per rank reading all of x from the gather buffer, whichever half the last exchange filled): three ranks in one
+    process, chained, against scipy on the same values."""
+    import scipy.sparse as sp
+    from dasp_amd.multi import MgPlan
+    torch = torch_cuda
+    world = 3
+    rows, A, bounds, sl = _hv_slices(dasp, world)
+    dt = np.float64 if prec == 64 else np.float16
+    if prec == 16:      # values exactly representable in f16, a chain that stays in range
+        sl = [(rp, ci, np.full(ci.size, 1.0 / 256.0)) for rp, ci, v in sl]
+        A = sp.csr_matrix((np.full(A.nnz, 1.0 / 256.0), A.indices, A.indptr), shape=A.shape)
+    x0 = np.random.default_rng(6).uniform(0.5, 1.5, rows).astype(dt)
+    mgs = [MgPlan(rp, ci, v, rows, rows, bounds, r, precision=prec, overlap=overlap).upload() for r, (rp, ci, v) in enumerate(sl)]
+    streams = [torch.cuda.Stream() for _ in mgs]
+    blobs = [mg.push_export() for mg in mgs]
+    for mg in mgs:
+        mg.push_connect(blobs)
+        assert mg.info["exchange"] == 1 and mg.info["fused_step"] == 0
+        mg.set_x(x0)
+    want = x0.astype(np.float64)
+    for it in range(3):
+        for mg, st in zip(mgs, streams):
+            mg.spmv(st.cuda_stream)
+        want = A @ want
+        if prec == 16:
+            want = want.astype(np.float16).astype(np.float64)       # every y is stored as f16
+    for mg in mgs:
+        mg.check()
+    ys = [mg.get_y().astype(np.float64) for mg in mgs]
+    for y in ys[1:]:
+        np.testing.assert_array_equal(y, ys[0])
+    tol = 1e-13 if prec == 64 else 2e-2
+    assert np.abs(ys[0] - want).max() <= tol * np.abs(want).max()
+    for mg in mgs:
+        mg.close()
+
+
 def test_push_exchange_reports_a_peer_that_does_not_deliver(dasp, torch_cuda, monkeypatch):
     """Direct exchange, two ranks in one process, and only rank 0 steps: its arrival kernel gives up after the time-out (5 ms here), sets
     the sticky error instead of hanging, and dasp_mg_check says whose fault it is -- without switching the exchange by itself (that is a
