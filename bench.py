@@ -619,6 +619,15 @@ def main():
             except D.DaspError as exc:
                 bad = 1
                 sys.stderr.write("bench.py rank %d: %s\n" % (rank, exc))
+            if not bad and prec == 64 and args.warmup > 0:
+                # ... or did the exchange deliver something else than it should (first contact of stores / flags across GPUs)?  The chain
+                # is x_t = c^t on every non-empty row: a stale or misplaced slice shows at once
+                got = mg.get_y()
+                wv = (R["chain"] ** args.warmup) * (lengths > 0)
+                if not bool((np.abs(got - wv) <= 1e-9 * wv).all()):
+                    bad = 1
+                    sys.stderr.write("bench.py rank %d: the gathered y after the warm-up is wrong with (%s, %s)\n"
+                                     % (rank, cfgs[cfg_i][0], "fused" if cfgs[cfg_i][1] else "two launches"))
             if dist is not None and world > 1:
                 bt = torch.tensor([bad])
                 dist.all_reduce(bt, op=dist.ReduceOp.MAX)
@@ -636,7 +645,7 @@ def main():
                 step()
             fence()
         step_form = ("fused one-launch step" if mg.info["fused_step"] else "two launches (own, other) + stream hand-offs") + \
-                    ("" if not fell_back else " -- after a time-out during warm-up with: " + "; ".join(fell_back))
+                    ("" if not fell_back else " -- after a time-out or a wrong result during warm-up with: " + "; ".join(fell_back))
         dog.kick("first contact checked")
     region = D.multi.StreamTimer(stream)                          # HIP events on the launch stream (not necessarily torch's current one)
     t0 = time.perf_counter()
