@@ -136,6 +136,7 @@ struct dasp_mg_plan {
     // completed exchange), own_go, ready (step whose products are complete), error word
     char *words = nullptr;
     bool fused = false;                // dasp_mg_spmv / dasp_mg_product run the one-launch step
+    bool fusable = false;              // the plans qualify for it (decided at upload)
     bool gather_fine = false;          // yg is fine-grained device memory
     uint64_t gathered_step = 0;        // step number of the last exchange queued on the communication stream (0: none since set_x)
     int max_pollers = 1024, poll_sleep = 1;
@@ -471,7 +472,6 @@ int push_enable(dasp_mg_plan &g)
     if (const char *e = std::getenv("DASP_MG_PUSH_WGS")) g.push_wgs = std::max(1, std::min(4096, std::atoi(e)));
     // the current x is in half 0 (RCCL and the test hook use no other), where exchange count 0 looks for it
     MG_HIP(hipDeviceSynchronize());
-    (void)all;
     g.xseq = 0;
     g.push = true;
     g.pending = false; g.pending_sig = false; g.pending_lazy = false; g.gathered_step = 0;
@@ -624,7 +624,7 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
                 MG_HIP(hipMalloc(&g.d_blk_order, g.blk_order.size() * sizeof(int)));
                 MG_HIP(hipMemcpy(g.d_blk_order, g.blk_order.data(), g.blk_order.size() * sizeof(int), hipMemcpyHostToDevice));
             }
-            g.fused = true;
+            g.fused = true; g.fusable = true;
             hipDeviceProp_t prop;
             int cus = 256;
             if (hipGetDeviceProperties(&prop, g.device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
@@ -826,7 +826,7 @@ int dasp_mg_set_fused(dasp_mg_plan_t *mg, int on)
     dasp_mg_plan &g = *mg;
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
     MG_HIP(hipDeviceSynchronize());
-    if (on && !g.words) { set_error("this plan does not qualify for the fused step (f64, square, column split, 16-bit ids, no windows / panels / multi-piece rows)"); return DASP_ERR_STATE; }
+    if (on && !g.fusable) { set_error("this plan does not qualify for the fused step (f64, square, column split, 16-bit ids, no windows / panels / multi-piece rows)"); return DASP_ERR_STATE; }
     g.pending = false; g.pending_lazy = false; g.gathered_step = 0;
     g.fused = on != 0;
     return DASP_OK;

@@ -537,6 +537,8 @@ def test_push_exchange_other_plan_kinds(dasp, torch_cuda, prec, overlap):
     for mg in mgs:
         mg.push_connect(blobs)
         assert mg.info["exchange"] == 1 and mg.info["fused_step"] == 0
+        with pytest.raises(dasp.DaspError, match="does not qualify"):
+            mg.set_fused(True)
         mg.set_x(x0)
     want = x0.astype(np.float64)
     for it in range(3):
