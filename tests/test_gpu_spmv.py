@@ -558,6 +558,49 @@ def test_push_exchange_other_plan_kinds(dasp, torch_cuda, prec, overlap):
         mg.close()
 
 
+def test_reserved_stream_runs_the_step_off_32_cus(dasp, torch_cuda):
+    """dasp_mg_reserved_stream: the plan's CU-masked compute stream (what RCCL as the exchange needs: its kernels do not start beside the
+    product otherwise).  Three ranks in one process drive their fused steps from their reserved streams (copy-hook exchange): same bits as
+    from plain streams; the handle is created once; a reserve of half the device or more is refused."""
+    from dasp_amd.multi import MgPlan
+    torch = torch_cuda
+    world = 3
+    rows, A, bounds, sl = _hv_slices(dasp, world)
+    x0 = np.random.default_rng(7).uniform(0.5, 1.5, rows)
+    res = {}
+    for reserved in (False, True):
+        mgs = [MgPlan(rp, ci, v, rows, rows, bounds, r, cid16=1).upload() for r, (rp, ci, v) in enumerate(sl)]
+        if reserved:
+            streams = [mg.reserved_stream(32) for mg in mgs]
+            assert all(streams) and streams[0] == mgs[0].reserved_stream(32)
+            assert mgs[0].reserved_stream(8) == streams[0]                      # one per plan
+        else:
+            keep = [torch.cuda.Stream() for _ in mgs]
+            streams = [st.cuda_stream for st in keep]
+        for mg in mgs:
+            mg.set_fake_exchange(5, peers=mgs)
+            mg.set_x(x0)
+        for it in range(4):
+            for mg, st in zip(mgs, streams):
+                mg.product(st)
+            for mg in mgs:
+                mg.check()
+            for mg, st in zip(mgs, streams):
+                mg.allgather(st)
+            torch.cuda.synchronize()
+        res[reserved] = mgs[0].get_y()
+        for mg in mgs:
+            mg.close()
+    np.testing.assert_array_equal(res[True], res[False])
+    want = x0
+    for it in range(4):
+        want = A @ want
+    assert np.abs(res[True] - want).max() <= 1e-13 * np.abs(want).max()
+    mg = MgPlan(*sl[0], rows, rows, bounds, 0, cid16=1).upload()
+    assert mg.reserved_stream(200) is None
+    mg.close()
+
+
 def test_push_exchange_reports_a_peer_that_does_not_deliver(dasp, torch_cuda, monkeypatch):
     """Direct exchange, two ranks in one process, and only rank 0 steps: its arrival kernel gives up after the time-out (5 ms here), sets
     the sticky error instead of hanging, and dasp_mg_check says whose fault it is -- without switching the exchange by itself (that is a
