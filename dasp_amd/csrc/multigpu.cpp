@@ -328,10 +328,17 @@ int wait_gathered(dasp_mg_plan &g, hipStream_t s)
     return DASP_OK;
 }
 
+// the one-launch step on stream s?  Not with RCCL between several ranks on a stream that leaves RCCL's kernels no room: they would
+// not start while workgroups wait for them -- such a call runs the two-launch form instead of timing out
+bool fuse_on(const dasp_mg_plan &g, hipStream_t s)
+{
+    return g.fused && (g.push || !g.comm || g.world == 1 || (g.rs && s == g.rs));
+}
+
 int product(dasp_mg_plan &g, hipStream_t s)
 {
     const int cur = g.cur, nxt = (g.cur + 1) % 3;
-    if (g.fused) {
+    if (fuse_on(g, s)) {
         // one launch: own-column workgroups, then the persistent workgroups that wait in the kernel for exchange `gathered_step`
         MgStepCtl c{};
         c.words = g.words; c.need = g.gathered_step; c.step = g.step + 1;
@@ -702,7 +709,7 @@ int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream)
     if (int rc = product(g, s)) return rc;
     // y (this rank's padded slice) -> every rank's gather buffer, on the communication stream, behind the products
     const uint64_t k = g.step;
-    if (g.fused) {
+    if (fuse_on(g, s)) {
         // the communication stream spins (one lane) until the launch's last workgroup has published step k, exchanges, publishes k back
         if (g.push) {          // both waits are inside the exchange's two kernels
             // (a one-lane wait kernel ahead of the push instead of the wait inside it: 80.3 instead of 76.7 us at a 40-us exchange)

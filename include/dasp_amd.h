@@ -371,7 +371,9 @@ int dasp_mg_set_exchange(dasp_mg_plan_t *mg, int mode);
 /* For RCCL as the exchange: a compute stream of the plan that keeps `reserve_cus` CUs (rounded up to whole groups of 32: one CU per shader
  * engine per XCD) free for RCCL's kernels (hipExtStreamCreateWithCUMask), or NULL.  Pass it as `stream` to dasp_mg_spmv & co.  Without it
  * RCCL's kernel waits for the product kernel to drain (and, in the fused step, for the waiting workgroups to time out: use the two-launch
- * form then); with it the product runs on the remaining CUs (HV15R, 224 of 256: +8 %, tools/cumask_product.py).  Owned by the plan. */
+ * form then); with it the product runs on the remaining CUs (HV15R, 224 of 256: +8 %, tools/cumask_product.py).  Owned by the plan.
+ * dasp_mg_spmv / dasp_mg_product with an RCCL communicator of several ranks run the fused step ONLY on this stream (two launches on any
+ * other); the direct exchange has no such restriction. */
 void *dasp_mg_reserved_stream(dasp_mg_plan_t *mg, int reserve_cus);
 /* TEST HOOK (timing on a one-GPU box): the direct exchange with scratch memory of this rank standing in for every peer */
 int dasp_mg_push_loopback(dasp_mg_plan_t *mg);
