@@ -47,12 +47,13 @@ public:
         std::unique_lock<std::mutex> own(busy_, std::try_to_lock);
         if (!own.owns_lock()) return false;
         ensure((int)std::min<long long>(parts - 1, 127));
+        unsigned long long e;
         {
             std::lock_guard<std::mutex> lk(m_);
-            job_ = &job; parts_ = parts; next_.store(0); left_ = parts; ++epoch_;
+            job_ = &job; parts_ = parts; next_ = 0; left_ = parts; e = ++epoch_;
         }
         cv_.notify_all();
-        work();
+        work(e);
         std::unique_lock<std::mutex> lk(m_);
         done_.wait(lk, [&] { return left_ == 0; });
         job_ = nullptr;
@@ -70,12 +71,22 @@ private:
     {
         while ((int)th_.size() < n) th_.emplace_back([this] { in_worker_ = true; loop(); });
     }
-    void work()
+    // parts of job `e` until none is left.  Every piece of job state is read and advanced under m_, and a part is only handed out while
+    // the pool is still on job e: a worker that wakes late (after its job is complete and the next one has been set up) must not take
+    // an index from the new job's counter on the strength of the old job's bounds -- with a lock-free counter that ran a part twice,
+    // counted the job complete one part early and let run() return under a worker still inside the caller's lambda (a rare hang in
+    // plan creation, seen twice in ~100 multi-plan probe runs).  A few dozen lock round-trips per job cost nothing next to the loops.
+    void work(unsigned long long e)
     {
         for (;;) {
-            const long long i = next_.fetch_add(1);
-            if (i >= parts_) break;
-            (*job_)(i);
+            const std::function<void(long long)> *job;
+            long long i;
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (epoch_ != e || job_ == nullptr || next_ >= parts_) return;
+                i = next_++; job = job_;
+            }
+            (*job)(i);
             std::lock_guard<std::mutex> lk(m_);
             if (--left_ == 0) done_.notify_all();
         }
@@ -90,15 +101,14 @@ private:
                 if (stop_) return;
                 seen = epoch_;
             }
-            work();
+            work(seen);
         }
     }
     std::mutex m_, busy_;
     std::condition_variable cv_, done_;
     std::vector<std::thread> th_;
     const std::function<void(long long)> *job_ = nullptr;
-    long long parts_ = 0, left_ = 0;
-    std::atomic<long long> next_{0};
+    long long parts_ = 0, left_ = 0, next_ = 0;
     unsigned long long epoch_ = 0;
     bool stop_ = false;
     static thread_local bool in_worker_;

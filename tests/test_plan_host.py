@@ -1,6 +1,8 @@
 """Host half of the plan (classifier + packers, no GPU): category counts and the output
 permutation are bit-identical to the oracle's restatement of the reference; the native packed
 arrays decode back to exactly the CSR rows (every nonzero once, in row order, pads only at row ends)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -548,3 +550,27 @@ def test_slab_layout_decodes_and_keeps_the_reference_slots(dasp, oracle, prec):
         for slot in range(2500):
             r = order[slot]
             assert rows[slot][0] == ci[rp[r]:rp[r + 1]].tolist()
+
+
+def test_many_plans_back_to_back_on_the_worker_pool(dasp):
+    """The persistent worker pool of the host packers (plan.cpp Pool) under its worst pattern: hundreds of plans one right after the other,
+    loops of very different part counts following each other within microseconds, more threads than cores.  (A worker that woke late used to
+    be able to take an index from the NEXT job's counter on the strength of the previous job's bounds: a part ran twice and the job was
+    counted complete early -- a rare hang.)  Every plan must come out identical to the single-threaded build."""
+    rng = np.random.default_rng(99)
+    cases = []
+    for rows in (70000, 150000, 40000, 300000):
+        lens = rng.integers(0, 12, rows)
+        rp = np.zeros(rows + 1, np.int32); np.cumsum(lens, out=rp[1:])
+        ci = rng.integers(0, rows, int(rp[-1])).astype(np.int32)
+        v = np.ones(int(rp[-1]))
+        ref = dasp.Plan(rp, ci, v, rows, host_threads=1)
+        cases.append((rp, ci, v, rows, ref.order_rid.copy(), dict(ref.stats)))
+        ref.close()
+    for it in range(int(os.environ.get("DASP_POOL_STRESS_ITERS", "60"))):
+        rp, ci, v, rows, order, stats = cases[it % len(cases)]
+        p = dasp.Plan(rp, ci, v, rows, host_threads=24)
+        assert np.array_equal(p.order_rid, order)
+        st = p.stats
+        assert all(st[k] == stats[k] for k in ("row_long", "row_block", "n_med_blocks", "nnz_irreg", "n_short_tiles", "data_X"))
+        p.close()

@@ -42,11 +42,18 @@ def step_time(mg, n=300):
 worst = {}
 for rank in ranks:
     r0, r1 = int(bounds[rank]), int(bounds[rank + 1])
+    TR = (lambda what: (sys.stderr.write("rank %d: %s\n" % (rank, what)), sys.stderr.flush())) if os.environ.get("PROBE_TRACE") else (lambda what: None)
+    TR("generate")
     rp, ci = D.synth_csr(name, scale, r0, r1, lengths=lengths[r0:r1])
     val = np.repeat(0.5 / np.maximum(np.diff(rp), 1), np.diff(rp))
-    mg = MgPlan(rp, ci, val, rows, cols, bounds, rank).upload()
+    TR("create")
+    mg = MgPlan(rp, ci, val, rows, cols, bounds, rank)
+    TR("upload")
+    mg.upload()
     del ci, val
+    TR("first set_x")
     mg.set_x(np.ones(cols))
+    TR("ready")
     line = "rank %d rows %d nnz own %d other %d fused_ok %d |" % (rank, r1 - r0, mg.nnz_local, mg.nnz_remote, mg.info["fused_step"])
     can_fuse = mg.info["fused_step"] == 1
     if os.environ.get("PROBE_RESERVE"):                  # the plan's CU-masked compute stream (what the RCCL exchange needs)
@@ -58,11 +65,14 @@ for rank in ranks:
         mg.set_fused(fused)
         for us in AG:
             mg.set_fake_exchange(us)
+            if os.environ.get("PROBE_TRACE"): sys.stderr.write("rank %d fused %d exchange %d us: set_x\n" % (rank, fused, us)); sys.stderr.flush()
             mg.set_x(np.ones(cols))
+            if os.environ.get("PROBE_TRACE"): sys.stderr.write("rank %d fused %d exchange %d us: steps\n" % (rank, fused, us)); sys.stderr.flush()
             t = step_time(mg)
             key = ("fused" if fused else "2launch", us)
             worst[key] = max(worst.get(key, 0.0), t)
             line += " %s/%dus %.1f (host %.1f)" % (key[0], us, t, HOST["us"])
+    if os.environ.get("PROBE_TRACE"): sys.stderr.write("rank %d: parts alone\n" % rank); sys.stderr.flush()
     if can_fuse:      # the step kernel alone, back to back (no exchange, no in-kernel wait)
         mg.set_fused(True); mg.set_x(np.ones(cols))
         for _ in range(10): mg.product(s)
@@ -85,8 +95,11 @@ for rank in ranks:
         del xo
     st = own.stats
     print(line + " | own alone %.1f other alone %.1f us | own data_X %.1f MB blocks %d" % (t_own, t_oth, st["data_X"] / 1e6, st["n_med_blocks"]), flush=True)
+    TR("close")
     mg.close(); del x, y
+    TR("empty_cache")
     torch.cuda.empty_cache()
+    TR("done")
 if os.environ.get("PROBE_FULL", "1") == "1":
     rp, ci = D.synth_csr(name, scale, 0, rows, lengths=lengths)
     plan = D.Plan(rp, ci, np.ones(ci.size), cols).upload(); plan.drop_host()
