@@ -322,6 +322,7 @@ class Watchdog:
         # prints the line -- must be the first whose limit runs out, before the launcher tears the job down on another rank's exit
         self.rank, self.limit, self.args = rank, limit_s + 3.0 * rank if limit_s > 0 else 0, args
         self.t, self.phase = time.time(), "start"
+        self.partial = None          # the headline record once it is complete: what rank 0 prints (with an "error" note) if an extra hangs after it
         if limit_s > 0:
             threading.Thread(target=self._run, daemon=True).start()
 
@@ -333,9 +334,11 @@ class Watchdog:
             time.sleep(1.0)
             if time.time() - self.t > self.limit:
                 if self.rank == 0:
-                    print(json.dumps({"metric": "SpMV GFLOP/s (f64)", "value": None, "unit": "GFLOP/s", "n_gpus": self.args.gpus,
-                                      "steps": self.args.steps, "warmup": self.args.warmup, "error": "watchdog: no progress for %d s in phase '%s'"
-                                      % (self.limit, self.phase)}), flush=True)
+                    note = "watchdog: no progress for %d s in phase '%s'" % (self.limit, self.phase)
+                    rec = dict(self.partial, error=note + " (the measurement above is complete; an extra after it did not finish)") if self.partial else \
+                        {"metric": "SpMV GFLOP/s (f64)", "value": None, "unit": "GFLOP/s", "n_gpus": self.args.gpus, "steps": self.args.steps,
+                         "warmup": self.args.warmup, "error": note}
+                    print(json.dumps(rec), flush=True)
                 sys.stderr.write("bench.py rank %d: watchdog fired in phase '%s'\n" % (self.rank, self.phase))
                 sys.stderr.flush()
                 os._exit(5)
@@ -505,7 +508,9 @@ def main():
     # can offer RCCL (two ranks may not share a device)
     multi = world > 1 or os.environ.get("DASP_BENCH_FORCE_DIST") == "1"
     # N > 1: no phase of a healthy run takes minutes (building a rank's plans: seconds; RCCL bootstrap on one node: seconds)
-    dog = Watchdog(rank, float(os.environ.get("DASP_BENCH_WATCHDOG_S", "240")) if multi else 0, args)
+    # N = 1: no phase takes long either (the largest: one suite entry, the CPU baseline: tens of seconds); a native call that never returns must not eat
+    # the driver's whole time limit without a line
+    dog = Watchdog(rank, float(os.environ.get("DASP_BENCH_WATCHDOG_S", "240" if multi else "900")), args)
     dist = None
     if multi:
         import torch.distributed as dist
@@ -834,6 +839,8 @@ def main():
             dist.barrier()                                        # direct exchange: nobody frees a buffer a peer still has mapped and may be storing into
         mg.close()
 
+    dog.partial = out
+    dog.kick("headline record complete")
     if rank == 0 and world == 1 and not multi and not args.no_vendor:
         # vendor comparator on the same box and matrix: rocSPARSE CSR SpMV (the reference's cuSPARSE column, main_f64.cu:18-100)
         exe = os.path.join(ROOT, "dasp_amd", "bin", "dasp_rocsparse")
@@ -856,6 +863,8 @@ def main():
                 suite.append(suite_entry(torch, D, O, nm, pr, args.suite_scale))
             except Exception as exc:   # a failing extra must not hide the headline line
                 suite.append({"workload": nm, "error": repr(exc)})
+            out["suite"] = suite
+            dog.kick("suite entry %s done" % nm)
         out["suite"] = suite
 
     if multi:

@@ -82,6 +82,21 @@ def test_watchdog_ends_a_stuck_rank_with_a_json_error_line():
     assert line["value"] is None and line["n_gpus"] == 8 and "RCCL communicator up" in line["error"]
 
 
+def test_watchdog_keeps_a_complete_headline_record():
+    """an extra that hangs AFTER the headline measurement (vendor comparator, a suite entry) must not cost the line: the watchdog prints
+    the complete record with an "error" note"""
+    import json
+    import subprocess
+    import sys
+    code = ("import sys, time, argparse; sys.path.insert(0, %r); import bench; "
+            "a = argparse.Namespace(gpus=1, steps=3, warmup=1); d = bench.Watchdog(0, 1.0, a); "
+            "d.partial = {'metric': 'SpMV GFLOP/s (f64)', 'value': 1234.5, 'n_gpus': 1}; d.kick('suite entry x done'); time.sleep(30)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 5
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] == 1234.5 and "suite entry x done" in line["error"]
+
+
 def test_exchange_configurations_best_first():
     """bench.py N > 1: direct exchange before RCCL, the fused step before two launches; RCCL + fused only where its kernel can start while
     workgroups wait (CU-masked stream, or one rank); nothing at all -> the host-memory test hook"""
