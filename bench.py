@@ -485,6 +485,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)                                         # does not return
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # before the runtime starts: this pool's hosts support dmabuf IPC only (RCCL, hipIpc mappings)
     import torch
     import dasp_amd as D
 

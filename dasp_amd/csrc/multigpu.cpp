@@ -444,6 +444,7 @@ struct PushBlob {
     int64_t pid;
     uint64_t gather, flags;            // the owner's device pointers (used as they are by peers inside the owner's process)
     uint64_t gather_bytes;
+    uint64_t has_ipc;                  // 0: hipIpcGetMemHandle failed on the owner (the blob still serves peers inside the owner's process)
     hipIpcMemHandle_t hg, hf;
 };
 static_assert(sizeof(PushBlob) <= DASP_MG_IPC_BYTES, "DASP_MG_IPC_BYTES too small");
@@ -862,8 +863,8 @@ int dasp_mg_push_export(dasp_mg_plan_t *mg, void *blob)
     PushBlob b{};
     b.magic = kPushMagic; b.rank = g.rank; b.world = g.world; b.pid = (int64_t)getpid();
     b.gather = reinterpret_cast<uint64_t>(g.yg); b.flags = reinterpret_cast<uint64_t>(g.xflags); b.gather_bytes = 2 * g.all_bytes();
-    MG_HIP(hipIpcGetMemHandle(&b.hg, g.yg));
-    MG_HIP(hipIpcGetMemHandle(&b.hf, g.xflags));
+    b.has_ipc = hipIpcGetMemHandle(&b.hg, g.yg) == hipSuccess && hipIpcGetMemHandle(&b.hf, g.xflags) == hipSuccess ? 1 : 0;
+    if (!b.has_ipc) (void)hipGetLastError();           // e.g. HSA_ENABLE_IPC_MODE_LEGACY unset on a host that only supports dmabuf IPC: peers in other processes will be told
     std::memset(blob, 0, DASP_MG_IPC_BYTES);
     std::memcpy(blob, &b, sizeof b);
     return DASP_OK;
@@ -894,6 +895,10 @@ int dasp_mg_push_connect(dasp_mg_plan_t *mg, const void *blobs)
         if (b.pid == (int64_t)getpid()) {      // a peer inside this process (tests; one process driving several GPUs): its pointers as they are
             pg[(size_t)r] = reinterpret_cast<void *>(b.gather); pf[(size_t)r] = reinterpret_cast<void *>(b.flags);
             continue;
+        }
+        if (!b.has_ipc) {
+            undo(); set_error("dasp_mg_push_connect: rank " + std::to_string(r) + " could not export IPC handles (hipIpcGetMemHandle failed there; HSA_ENABLE_IPC_MODE_LEGACY=0 set?)");
+            return DASP_ERR_HIP;
         }
         opened[(size_t)r] = 1;
         hipError_t e = hipIpcOpenMemHandle(&pg[(size_t)r], b.hg, hipIpcMemLazyEnablePeerAccess);

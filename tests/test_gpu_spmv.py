@@ -647,7 +647,8 @@ def test_push_exchange_between_two_processes(dasp, torch_cuda, tmp_path, fused):
     world, iters = 2, 5
     rows, A, bounds, sl = _hv_slices(dasp, world)
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_push_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(tmp_path), str(r), str(world), str(iters), str(fused)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")          # this pool's hosts support dmabuf IPC only
+    procs = [subprocess.Popen([sys.executable, worker, str(tmp_path), str(r), str(world), str(iters), str(fused)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
              for r in range(world)]
     outs = []
     for p in procs:
