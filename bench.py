@@ -562,6 +562,11 @@ def main():
         mg.comm_init(uid.numpy())                                 # ncclCommInitRank, one communicator per rank, on its own GPU
         has_comm = True
         dog.kick("RCCL communicator up")
+        # RCCL sets up its connections inside the FIRST collective (it can take longer than the step's in-kernel time-outs): pay that here.
+        # The slices hold x_0, so the gather buffer ends up as it was.
+        mg.allgather(stream)
+        torch.cuda.synchronize()
+        dog.kick("first RCCL collective done")
     if multi and world > 1 and want == "direct":
         good, blob = True, bytes(D.multi.MgPlan.IPC_BYTES)
         try:

@@ -357,7 +357,8 @@ int dasp_mg_set_fake_exchange(dasp_mg_plan_t *mg, int micros, int n_peers, void 
  *     dasp_mg_set_x(mg, x)                             with the direct exchange a COLLECTIVE point: every rank calls it (a rank's next
  *                                                      exchange waits, on the host, until every peer has passed the same call;
  *                                                      DASP_MG_BARRIER_TIMEOUT_S, default 120)
- * Peers inside one process (one process driving several plans) are used through their plain pointers.  A sender that does not deliver
+ * Peers inside one process (one process driving several plans) are used through their plain pointers (on different devices: the caller
+ * enables peer access between them).  A sender that does not deliver
  * within the time-out sets the sticky error: dasp_mg_check then returns DASP_ERR_STATE (the exchange is not switched by it: that is a
  * collective decision -- dasp_mg_set_exchange(mg, 0) on every rank, then dasp_mg_set_x).  Starting again with dasp_mg_set_x on every
  * rank is always possible: the flags carry (number of that collective call, exchanges since it), so ranks that stopped at different
