@@ -147,7 +147,7 @@ struct dasp_mg_plan {
     void *d_blk_order = nullptr;
     int n_marked = 0, n_mark_shards = 0;
     void *d_mark = nullptr;            // device copy: mark bytes, then (256-byte aligned) the 64 per-shard counts
-    long long timeout_ticks = 200ll * 100000;   // 200 ms at 100 MHz
+    long long timeout_ticks = 1000ll * 100000;  // 1 s at 100 MHz: far above any healthy wait (a first remote access may set up mappings), short against a hang
     // test hook (dasp_mg_set_fake_exchange): world > 1 without a communicator; the exchange = copies of the rank's slice into the
     // given gather buffers (this rank's own and those of peers living on the same device) + a kernel of that duration
     // direct exchange (dasp_mg_push_connect; mgx.hip): every rank stores its slice into every rank's gather buffer through peer-mapped

@@ -333,7 +333,7 @@ int dasp_mg_set_x(dasp_mg_plan_t *mg, const void *x_host);
  * bounded set of persistent workgroups that wait inside the kernel for the count of finished own-column workgroups and for the
  * previous exchange's flag and run the other-column plan (y +=; the arithmetic of the two-launch form, bit-identical) -- and the
  * launch's last workgroup publishes "y ready" to a one-lane kernel at the head of the communication stream: `stream` carries
- * back-to-back kernels only.  In-kernel waits give up after 200 ms (DASP_MG_TIMEOUT_MS) and set a sticky error instead of
+ * back-to-back kernels only.  In-kernel waits give up after 1 s (DASP_MG_TIMEOUT_MS) and set a sticky error instead of
  * hanging: see dasp_mg_check. */
 int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream);
 /* synchronises the device and reports whether a wait of the fused step timed out since the last check: DASP_OK, or DASP_ERR_STATE
