@@ -1134,6 +1134,7 @@ int upload_plan(Plan &p)
 
     HIP_TRY(hipMalloc(&d->arena, total));
     d->arena_bytes = total;
+    if (std::getenv("DASP_VERBOSE")) std::fprintf(stderr, "[dasp upload] arena %p + %zu bytes\n", d->arena, total);
     char *base = static_cast<char *>(d->arena);
     for (const Item &it : items)
         if (it.src && it.bytes) HIP_TRY(hipMemcpy(base + it.off, it.src, it.bytes, hipMemcpyHostToDevice));
