@@ -789,7 +789,9 @@ def main():
                                              "step_form": step_form,
                                              "stream_handoff": "in-kernel flags + one-lane kernels on the communication stream" if mg.info["fused_step"] else
                                              ("hipStreamWriteValue64 / hipStreamWaitValue64" if mg.info["stream_memops"] else "events")}),
-                   "row_long": st["row_long"], "row_block": st["row_block"], "rate_fill0": round(st["rate_fill0"], 4)},
+                   "row_long": st["row_long"], "row_block": st["row_block"], "rate_fill0": round(st["rate_fill0"], 4),
+                   "placement_trials": "dasp_plan_upload tries up to %s device allocations for the plan and keeps the fastest (DASP_PLACEMENT_TRIALS; profiles/r03_placement.md)"
+                                       % os.environ.get("DASP_PLACEMENT_TRIALS", "3")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "kernel": "dasp_spmv_kernel<%s>" % ("double" if prec == 64 else "_Float16"),

@@ -138,6 +138,7 @@ def lib():
     L.dasp_spmv_all_f16.argtypes = L.dasp_spmv_all_f64.argtypes
     L.dasp_partition_rows.argtypes = [C.c_int, vp, C.c_int, vp]
     L.dasp_selftest_mfma.argtypes = []
+    L.dasp_plan_tune_placement.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dasp_mg_unique_id.argtypes = [vp]
     L.dasp_mg_plan_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.POINTER(Options), C.c_int]
     L.dasp_mg_destroy.argtypes = [vp]
@@ -181,7 +182,7 @@ def check(rc):
 
 EXPORTS = (
     "dasp_last_error dasp_version dasp_mmio_allinone_f64 dasp_mmio_allinone_f16 dasp_free dasp_csr_save dasp_csr_load dasp_options_default "
-    "dasp_plan_create dasp_plan_create_device dasp_plan_download_array dasp_plan_destroy dasp_plan_save dasp_plan_load dasp_plan_order dasp_plan_stats dasp_plan_y_order dasp_plan_x_len dasp_plan_panel_count dasp_plan_panel dasp_plan_panel_range dasp_plan_host_array dasp_plan_upload "
+    "dasp_plan_create dasp_plan_create_device dasp_plan_download_array dasp_plan_destroy dasp_plan_save dasp_plan_load dasp_plan_order dasp_plan_stats dasp_plan_y_order dasp_plan_x_len dasp_plan_panel_count dasp_plan_panel dasp_plan_panel_range dasp_plan_host_array dasp_plan_upload dasp_plan_tune_placement "
     "dasp_plan_drop_host dasp_plan_set_stream_policy dasp_plan_spmv dasp_plan_spmv_acc dasp_plan_time dasp_plan_time_each dasp_plan_time_graph dasp_spmv_all_f64 dasp_spmv_all_f16 dasp_partition_rows "
     "dasp_selftest_mfma dasp_synth_dims dasp_synth_generator dasp_synth_row_lengths dasp_synth_rows "
     "dasp_mg_unique_id dasp_mg_plan_create dasp_mg_destroy dasp_mg_upload dasp_mg_comm_init dasp_mg_set_x dasp_mg_spmv dasp_mg_product dasp_mg_allgather "

@@ -549,7 +549,7 @@ void devpack_use_device(int device) { if (device >= 0) (void)hipSetDevice(device
 int devpack_all(Plan &p, const DevCsr &d, const PackMeta &m)
 {
     // arena + every O(rows) array through the normal upload path (the nnz-sized regions are left unwritten) ...
-    if (int rc = upload_plan(p)) return rc;
+    if (int rc = upload_plan_unpacked(p)) return rc;
     // ... then the kernels above fill those regions straight from the device CSR
     const int rc = p.precision == 64 ? pack_all_typed<double>(p, d, m) : pack_all_typed<_Float16>(p, d, m);
     if (rc == DASP_OK) p.host_dropped = true;       // no host copies of the packed nonzeros exist

@@ -1082,6 +1082,44 @@ def test_bench_rccl_calls_run_at_world_size_one(torch_cuda):
     assert out["config"]["exchange"] == "ncclAllGather" and out["verified_random_x"]["ok"] is True
 
 
+def test_placement_trials_keep_the_bytes_and_the_results(dasp, torch_cuda, monkeypatch):
+    """dasp_plan_tune_placement: the arena is copied into fresh allocations and the fastest kept -- products before and after are
+    bit-identical, the packed arrays read back the same, a plan below 256 MiB is left alone, dasp_plan_upload runs the trials by itself
+    for a host-built plan unless DASP_PLACEMENT_TRIALS=1, and a plan built from a device CSR only on request."""
+    torch = torch_cuda
+    rows, cols = dasp.synth_dims("HV15R", 0.12)
+    rp, ci = dasp.synth_csr("HV15R", 0.12)
+    v = np.random.default_rng(11).uniform(-1, 1, ci.size)
+    x = np.random.default_rng(12).uniform(0.5, 1.5, cols)
+    monkeypatch.setenv("DASP_PLACEMENT_TRIALS", "1")
+    plan = dasp.Plan(rp, ci, v, cols, y_order=dasp.Y_NATURAL).upload()
+    assert plan.stats["data_X"] > (256 << 20)
+    y0 = run_spmv(torch, plan, x, rows, 64)
+    before = plan.download_array("med_val") if hasattr(plan, "download_array") else None
+    first, kept = plan.tune_placement(4)
+    assert first > 0 and 0 < kept <= first
+    y1 = run_spmv(torch, plan, x, rows, 64)
+    np.testing.assert_array_equal(y0, y1)
+    if before is not None:
+        np.testing.assert_array_equal(before, plan.download_array("med_val"))
+    plan.close()
+    monkeypatch.delenv("DASP_PLACEMENT_TRIALS")
+    plan = dasp.Plan(rp, ci, v, cols, y_order=dasp.Y_NATURAL).upload()          # trials inside the upload
+    np.testing.assert_array_equal(run_spmv(torch, plan, x, rows, 64), y0)
+    plan.close()
+    d_rp, d_ci, d_v = (torch.from_numpy(a).cuda() for a in (rp, ci, v))
+    dplan = dasp.Plan.from_device(d_rp.data_ptr(), d_ci.data_ptr(), d_v.data_ptr(), rows, cols, ci.size, y_order=dasp.Y_NATURAL)
+    np.testing.assert_array_equal(run_spmv(torch, dplan, x, rows, 64), y0)
+    first, kept = dplan.tune_placement()
+    assert first > 0 and kept <= first
+    np.testing.assert_array_equal(run_spmv(torch, dplan, x, rows, 64), y0)
+    dplan.close()
+    rp2, ci2, v2 = util.mixed_matrix(3000, 2500, 5)
+    small = dasp.Plan(rp2, ci2, v2, 2500).upload()
+    assert small.tune_placement(3) == (0.0, 0.0)
+    small.close()
+
+
 @pytest.mark.parametrize("prec", [64, 16])
 def test_stream_policies_give_identical_results(dasp, torch_cuda, prec):
     """plain loads (reference dasp_spmv) vs non-temporal loads (reference "bypass" dasp_spmv2): same bits, switchable at run time"""

@@ -10,6 +10,8 @@ copies = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 prec = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 rows, cols = D.synth_dims(name, 1.0)
 rp, ci = D.synth_csr(name, 1.0)
+if os.environ.get("PROBE_ONE_COLUMN"):      # every gather reads x[0]: the stream of the arena alone
+    ci = np.zeros_like(ci)
 v = np.ones(ci.size, np.float64 if prec == 64 else np.float16)
 dt = torch.float64 if prec == 64 else torch.float16
 plans = []
