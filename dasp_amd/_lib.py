@@ -138,7 +138,7 @@ def lib():
     L.dasp_spmv_all_f16.argtypes = L.dasp_spmv_all_f64.argtypes
     L.dasp_partition_rows.argtypes = [C.c_int, vp, C.c_int, vp]
     L.dasp_selftest_mfma.argtypes = []
-    L.dasp_plan_tune_placement.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.dasp_plan_tune_placement.argtypes = [vp, C.c_int, vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dasp_mg_unique_id.argtypes = [vp]
     L.dasp_mg_plan_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.POINTER(Options), C.c_int]
     L.dasp_mg_destroy.argtypes = [vp]

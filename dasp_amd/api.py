@@ -217,11 +217,12 @@ class Plan:
         _lib.check(_lib.lib().dasp_plan_upload(self._h))
         return self
 
-    def tune_placement(self, trials=0):
-        """placement trials (include/dasp_amd.h): (ms of the first allocation, ms of the kept one) with scratch operands; (0, 0) if the plan
-        does not qualify.  upload() runs them by itself for host-built plans; a plan built from a device CSR calls this when it wants them."""
+    def tune_placement(self, trials=0, dX=0, dY=0):
+        """placement trials (include/dasp_amd.h): (ms of the first allocation, ms of the kept one); (0, 0) if the plan does not qualify.
+        dX / dY: the caller's own device vectors as integer addresses (dY is overwritten), 0 = scratch ones.  upload() runs the trials by
+        itself (scratch operands) for host-built plans; a plan built from a device CSR calls this when it wants them."""
         a, b = C.c_double(), C.c_double()
-        _lib.check(_lib.lib().dasp_plan_tune_placement(self._h, int(trials), C.byref(a), C.byref(b)))
+        _lib.check(_lib.lib().dasp_plan_tune_placement(self._h, int(trials), C.c_void_p(dX or None), C.c_void_p(dY or None), C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def drop_host(self):

@@ -17,7 +17,7 @@
 namespace dasp {
 const char *last_error_cstr();
 int upload_plan(Plan &p);
-int tune_placement(Plan &p, int trials, double *ms_first, double *ms_kept);
+int tune_placement(Plan &p, int trials, const void *dX, void *dY, double *ms_first, double *ms_kept);
 int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate);
 int time_spmv_each(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, float *ms_each);
 int time_spmv(Plan &p, const void *dX, void *dY, void *stream, int warmup, int iters, double *wall_ms, double *event_ms);
@@ -279,11 +279,11 @@ int dasp_plan_upload(dasp_plan_t *plan)
     return guarded("dasp_plan_upload", [&] { return upload_plan(plan->impl); });
 }
 
-int dasp_plan_tune_placement(dasp_plan_t *plan, int trials, double *ms_first, double *ms_kept)
+int dasp_plan_tune_placement(dasp_plan_t *plan, int trials, const void *dX, void *dY, double *ms_first, double *ms_kept)
 {
     if (!plan) return DASP_ERR_ARG;
     if (!plan->impl.dev) { set_error("plan not uploaded"); return DASP_ERR_STATE; }
-    return guarded("dasp_plan_tune_placement", [&] { return tune_placement(plan->impl, trials, ms_first, ms_kept); });
+    return guarded("dasp_plan_tune_placement", [&] { return tune_placement(plan->impl, trials, dX, dY, ms_first, ms_kept); });
 }
 
 int dasp_plan_drop_host(dasp_plan_t *plan)

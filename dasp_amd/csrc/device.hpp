@@ -72,7 +72,7 @@ struct DevicePlan {
 
 int upload_plan(Plan &p);
 int upload_plan_unpacked(Plan &p);     // for the device packers: arena + O(rows) arrays, no placement trials yet
-int tune_placement(Plan &p, int trials, double *ms_first, double *ms_kept);   // kernels.hip: placement trials of an uploaded, fully packed plan (trials <= 0: default)
+int tune_placement(Plan &p, int trials, const void *dX, void *dY, double *ms_first, double *ms_kept);   // kernels.hip: placement trials of an uploaded, fully packed plan (trials <= 0: default)
 
 // fused multi-GPU step (kernels.hip; driven by multigpu.cpp): all pointers are device pointers
 // the words of the fused step live in ONE zero-initialised device block of kMgWordBytes: sharded arrival counters first (marked

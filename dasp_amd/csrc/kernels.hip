@@ -1276,7 +1276,7 @@ static void rebase_args(DevArgs &a, const char *from, const char *to, size_t byt
     mv(a.short_val); mv(a.short_cid); mv(a.groups); mv(a.order);
 }
 
-int tune_placement(Plan &p, int trials, double *ms_first, double *ms_kept)
+int tune_placement(Plan &p, int trials, const void *dX, void *dY, double *ms_first, double *ms_kept)
 {
     DevicePlan *d = p.dev;
     if (ms_first) *ms_first = 0.0;
@@ -1289,7 +1289,8 @@ int tune_placement(Plan &p, int trials, double *ms_first, double *ms_kept)
     const bool verbose = std::getenv("DASP_VERBOSE") != nullptr;
     const size_t vb = (size_t)p.geo.vbytes, bytes = d->arena_bytes;
     const size_t xlen = p.opt.n_parts > 0 ? (size_t)p.opt.n_parts * (size_t)p.opt.part_stride : (size_t)p.n;
-    void *x = nullptr, *y = nullptr;
+    void *x = nullptr, *y = nullptr;                 // scratch operands unless the caller lends its own (whose placement takes part in the effect)
+    const void *ux = dX; void *uy = dY;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::vector<void *> losers;
     auto cleanup = [&] {
@@ -1301,13 +1302,14 @@ int tune_placement(Plan &p, int trials, double *ms_first, double *ms_kept)
         (void)hipGetLastError();
     };
     // scratch operands: zeros (the values do not matter to the stream); a failure anywhere below leaves the plan as it is
-    if (hipMalloc(&x, std::max<size_t>(xlen * vb, 256)) != hipSuccess || hipMalloc(&y, ((size_t)p.m + 64) * vb) != hipSuccess ||
-        hipMemset(x, 0, std::max<size_t>(xlen * vb, 256)) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { cleanup(); return DASP_OK; }
+    if (!ux) { if (hipMalloc(&x, std::max<size_t>(xlen * vb, 256)) != hipSuccess || hipMemset(x, 0, std::max<size_t>(xlen * vb, 256)) != hipSuccess) { cleanup(); return DASP_OK; } ux = x; }
+    if (!uy) { if (hipMalloc(&y, ((size_t)p.m + 64) * vb) != hipSuccess) { cleanup(); return DASP_OK; } uy = y; }
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { cleanup(); return DASP_OK; }
     auto time_it = [&](double *ms) -> bool {
-        for (int i = 0; i < 2; ++i) if (launch_spmv(p, x, y, nullptr, false) != DASP_OK) return false;
+        for (int i = 0; i < 2; ++i) if (launch_spmv(p, ux, uy, nullptr, false) != DASP_OK) return false;
         if (hipEventRecord(e0, nullptr) != hipSuccess) return false;
         const int reps = 6;
-        for (int i = 0; i < reps; ++i) if (launch_spmv(p, x, y, nullptr, false) != DASP_OK) return false;
+        for (int i = 0; i < reps; ++i) if (launch_spmv(p, ux, uy, nullptr, false) != DASP_OK) return false;
         float t = 0.f;
         if (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) return false;
         *ms = (double)t / reps;
@@ -1338,6 +1340,19 @@ int tune_placement(Plan &p, int trials, double *ms_first, double *ms_kept)
     }
     if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
     if (ms_kept) *ms_kept = best;
+    // the allocations that lost go back now -- and the driver wipes released VRAM in the background, which costs the kernels 1-3 % for the
+    // next 50-150 ms (seen as a slower timed region right behind the trials).  Let that pass here, at set-up, not under the caller's first
+    // products: launches until they run as fast as the kept allocation did, 250 ms at most.
+    const bool freed = !losers.empty();
+    for (void *q : losers) (void)hipFree(q);
+    losers.clear();
+    if (freed) {
+        const auto t0 = std::chrono::steady_clock::now();
+        double ms = 0.0;
+        int rounds = 0;
+        while (time_it(&ms) && ms > 1.004 * best && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 0.25) ++rounds;
+        if (verbose) std::fprintf(stderr, "[dasp placement] settled after %d more rounds (%.4f ms)\n", rounds, ms);
+    }
     cleanup();
     return DASP_OK;
 }
@@ -1348,7 +1363,7 @@ int upload_plan(Plan &p)
 {
     const bool fresh = !(p.host_dropped && p.dev);
     if (int rc = upload_plan_impl(p)) return rc;
-    return fresh ? tune_placement(p, 0, nullptr, nullptr) : DASP_OK;
+    return fresh ? tune_placement(p, 0, nullptr, nullptr, nullptr, nullptr) : DASP_OK;
 }
 // the arena with every O(rows) array, the nnz-sized regions left for the device packers (devpack.hip)
 int upload_plan_unpacked(Plan &p) { return upload_plan_impl(p); }
