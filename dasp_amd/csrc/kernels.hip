@@ -1096,14 +1096,11 @@ static int upload_plan_impl(Plan &p)
     struct Item { const void *src; size_t bytes; size_t off; };
     std::vector<Item> items;
     size_t total = 0;
-    size_t skew = 0;                                   // experiment (profiles/r03_placement.md): extra bytes behind every array of the arena
-    if (const char *e = std::getenv("DASP_ARENA_SKEW")) skew = ((size_t)std::max(0ll, std::atoll(e)) + 255) & ~size_t(255);
     auto add = [&](const void *src, size_t bytes) {
         size_t off = total;
         items.push_back({src, bytes, off});
         total += (bytes + 255) & ~size_t(255);
         if (bytes == 0) total += 256;
-        total += skew;
         return off;
     };
     // nnz-sized arrays: sized by their element counts; a plan packed on the device has no host copy (src = nullptr)
