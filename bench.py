@@ -240,7 +240,7 @@ def suite_entry(torch, D, O, name, precision, scale, budget_s=2.0):
     tdt = torch.float64 if precision == 64 else torch.float16
     x = torch.ones(cols, dtype=tdt, device="cuda")
     y = torch.zeros(rows, dtype=tdt, device="cuda")
-    if os.environ.get("DASP_PLACEMENT_TRIALS", "3") != "1":       # as the headline: placement trials against the vectors of this entry
+    if os.environ.get("DASP_PLACEMENT_TRIALS", "6") != "1":       # as the headline: placement trials against the vectors of this entry
         plan.tune_placement(0, x.data_ptr(), y.data_ptr())
     w, e = time_plan(torch, plan, x, y, 20, 10)
     iters = int(max(20, min(1000, budget_s * 1e3 / max(e, 1e-4))))
@@ -390,7 +390,7 @@ def setup_rank(torch, D, name, scale, prec, rank, world, multi=None, chain=None)
     x = torch.ones(plan.x_len, dtype=tdt, device="cuda")
     y = torch.zeros(r1 - r0, dtype=tdt, device="cuda")
     # placement trials once more, now against the vectors the products will really use (where x and y sit takes part: profiles/r03_placement.md)
-    if os.environ.get("DASP_PLACEMENT_TRIALS", "3") != "1":
+    if os.environ.get("DASP_PLACEMENT_TRIALS", "6") != "1":
         plan.tune_placement(0, x.data_ptr(), y.data_ptr())
     return dict(chain=None, mg=None, plan=plan, rp=rp, ci=ci, val=None, stats=plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total,
                 lengths=lengths, bounds=bounds, stride=0, r0=r0, r1=r1, x=x, y=y)
@@ -796,7 +796,7 @@ def main():
                                              ("hipStreamWriteValue64 / hipStreamWaitValue64" if mg.info["stream_memops"] else "events")}),
                    "row_long": st["row_long"], "row_block": st["row_block"], "rate_fill0": round(st["rate_fill0"], 4),
                    "placement_trials": "dasp_plan_upload, then dasp_plan_tune_placement with the run's own x / y, try up to %s device allocations for the plan and keep the fastest (DASP_PLACEMENT_TRIALS; profiles/r03_placement.md)"
-                                       % os.environ.get("DASP_PLACEMENT_TRIALS", "3")},
+                                       % os.environ.get("DASP_PLACEMENT_TRIALS", "6")},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "kernel": "dasp_spmv_kernel<%s>" % ("double" if prec == 64 else "_Float16"),

@@ -1255,8 +1255,8 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate
 // depending on WHERE the allocation landed (two uploads of one plan in one process, interleaved timing: 0.420 vs 0.453 ms; the skew
 // between the arena's arrays, the TLB and the history of the device do not matter; which allocation of a process is the fast one differs
 // from box to box).  A user-mode library cannot see the cause, but it can look: time a few launches, copy the arena into a fresh allocation
-// (the old one stays allocated meanwhile, so the new one lands elsewhere), time again, keep the faster, at most `trials` allocations
-// (DASP_PLACEMENT_TRIALS, default 3; 1 = off), stop as soon as one allocation is >= 4 % faster than another.  Only plans that stream
+// (the old one stays allocated meanwhile, so the new one lands elsewhere), time again, keep the faster, at most `trials` allocations alive at once
+// (DASP_PLACEMENT_TRIALS, default 6; 1 = off), stop as soon as one allocation is >= 4 % faster than another.  Only plans that stream
 // >= 256 MiB per SpMV and are not gather-bound by construction (column panels, LDS windows).  Costs ~5 ms per trial for HV15R.
 // Measured on the bench headline, six fresh processes each on one box: without 0.4343 0.4272 0.4595 0.4595 0.4603 0.4594 ms, with
 // 0.4508 0.4283 0.4285 0.4275 0.4332 0.4336 ms -- the caller's x / y take part in the effect (profiles/r03_placement.md), so the trials
@@ -1279,7 +1279,7 @@ int tune_placement(Plan &p, int trials, const void *dX, void *dY, double *ms_fir
     if (ms_first) *ms_first = 0.0;
     if (ms_kept) *ms_kept = 0.0;
     if (trials <= 0) {
-        trials = 3;
+        trials = 6;
         if (const char *e = std::getenv("DASP_PLACEMENT_TRIALS")) trials = std::max(1, std::min(8, std::atoi(e)));
     }
     if (!d || !d->arena || trials <= 1 || d->arena_bytes < (size_t(256) << 20) || !p.panels.empty() || p.panel || p.windowed) return DASP_OK;

@@ -200,7 +200,7 @@ int dasp_plan_create_device(dasp_plan_t **plan, int precision, int rowA, int col
                             const int *dRowPtr, const int *dColIdx, const void *dVal, const dasp_options_t *opt);
 /* Placement trials (r3): the same packed bytes run the HBM-bound kernels at one of two speeds ~8 % apart depending on where the plan's
  * device allocation landed (profiles/r03_placement.md).  Times a few launches with scratch operands, copies the arena into up to
- * `trials` - 1 fresh allocations (<= 0: DASP_PLACEMENT_TRIALS, default 3), keeps the fastest.  Only plans that stream >= 256 MiB and have
+ * `trials` - 1 fresh allocations (<= 0: DASP_PLACEMENT_TRIALS, default 6; they are all alive until the trials end), keeps the fastest.  Only plans that stream >= 256 MiB and have
  * no x windows / column panels; others return at once.  dasp_plan_upload runs it by itself for host-built plans (DASP_PLACEMENT_TRIALS=1
  * turns that off); a plan from dasp_plan_create_device leaves it to the caller (its creation time is a metric of its own).
  * dX / dY: the caller's own device vectors (x_len / rowA elements; dY is overwritten), or NULL for scratch ones -- where x and y sit takes
