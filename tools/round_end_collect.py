@@ -19,7 +19,8 @@ out = ["# Round 3 profile of the bench command -- HV15R stand-in (2 017 169 rows
        "Source: `cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-suite --no-vendor --steps 20` (kernel trace + stats only; the\n"
        "`--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes are separate runs of `dasp_bench HV15R 1 64 20 3`, `profiles/r03_traffic.md`), kernel sources at `kernel_rev %s`\n"
        "(= `profiles/traffic.json`); all of it one batch on one box (`tools/round_end.sh`, `tools/round_end_collect.py`).  The %s profiled launches include the 200 back-to-back\n"
-       "launches behind `roofline.kernel_ms`, the 200 timed one by one for the spread (`launch_ms_*`) and those of the random-values plan; the profiled average below (%.1f us over\n"
+       "launches behind `roofline.kernel_ms`, the 200 timed one by one for the spread (`launch_ms_*`), those of the random-values plan and those of the placement trials (other allocations,\n"
+       "some of them slower: `profiles/r03_placement.md`); the profiled average below (%.1f us over\n"
        "all of them) and the bench line's own `kernel_ms` of the same process (%.1f us; single launches min %.1f / p10 %.1f / median %.1f / p90 %.1f / max %.1f, each including the\n"
        "event between two kernels) agree.\n" % (hv["kernel_rev"], rows[0]["Calls"], float(rows[0]["AverageNs"]) / 1e3, r["kernel_ms"] * 1e3, r["launch_ms_min"] * 1e3,
                                             r["launch_ms_p10"] * 1e3, r["launch_ms_median"] * 1e3, r["launch_ms_p90"] * 1e3, r["launch_ms_max"] * 1e3),
