@@ -194,7 +194,7 @@ struct dasp_mg_plan {
         if (words) (void)hipFree(words);
         if (d_mark) (void)hipFree(d_mark);
         if (d_blk_order) (void)hipFree(d_blk_order);
-        for (void *p : {ys[0], ys[1], ys[2], yg}) if (p) (void)hipFree(p);
+        for (void *p : {ys[0], yg}) if (p) (void)hipFree(p);       // ys[1], ys[2] are parts of ys[0]'s allocation
         if (xg && xg != yg) (void)hipFree(xg);
         if (own) dasp_plan_destroy(own);
         if (other) dasp_plan_destroy(other);
@@ -569,7 +569,16 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
     if (g.other) (void)dasp_plan_drop_host(g.other);
     MG_HIP(hipGetDevice(&g.device));
     const size_t vb = g.vb(), sl = (size_t)g.stride * vb, all = sl * (size_t)g.world;
-    for (int k = 0; k < 3; ++k) { MG_HIP(hipMalloc(&g.ys[k], sl)); MG_HIP(hipMemset(g.ys[k], 0, sl)); }
+    {   // the three rotating slices as ONE allocation: where x and y live relative to a plan's arena decides between two speeds of the
+        // product (profiles/r03_placement.md), and three separate allocations could land in either group from one step to the next
+        const size_t sl_pad = (sl + 4095) & ~size_t(4095);
+        void *base = nullptr;
+        MG_HIP(hipMalloc(&base, 3 * sl_pad));
+        MG_HIP(hipMemset(base, 0, 3 * sl_pad));
+        for (int k = 0; k < 3; ++k) g.ys[k] = static_cast<char *>(base) + (size_t)k * sl_pad;
+    }
+    // ... and the own-column plan's placement trials once more against these slices (dasp_plan_upload ran them with scratch operands)
+    if (g.overlap) if (int rc = dasp_plan_tune_placement(g.own, 0, g.ys[0], g.ys[1], nullptr, nullptr)) return rc;
     {   // the gather buffer is written by the exchange -- this device's RCCL kernel or, over xGMI, a peer's stores -- WHILE the fused step's
         // kernel is already running and about to read it behind an in-kernel acquire.  Coarse-grained memory only promises visibility at
         // kernel boundaries; fine-grained memory is what the HSA memory model defines in-kernel cross-agent acquire / release on, so the
