@@ -29,6 +29,8 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <thread>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -1338,16 +1340,27 @@ int tune_placement(Plan &p, int trials, const void *dX, void *dY, double *ms_fir
     if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
     if (ms_kept) *ms_kept = best;
     // the allocations that lost go back now -- and the driver wipes released VRAM in the background, which costs the kernels 1-3 % for the
-    // next 50-150 ms (seen as a slower timed region right behind the trials).  Let that pass here, at set-up, not under the caller's first
-    // products: launches until they run as fast as the kept allocation did, 250 ms at most.
+    // next 50-500 ms, by how much was released (seen as a 2.8 % slower timed region right behind six trials on a box where none of them was
+    // faster).  Let that pass here, at set-up, not under the caller's first products: launches until they run as fast as the kept
+    // allocation did.
+    const size_t freed_bytes = losers.size() * bytes;
     const bool freed = !losers.empty();
     for (void *q : losers) (void)hipFree(q);
     losers.clear();
     if (freed) {
+        // ~35 GB/s of wiping was seen (5.3 GB: 0.15 s of slower launches); wait for 20 GB/s worth, then check with launches
+        std::this_thread::sleep_for(std::chrono::duration<double>(std::min(1.0, (double)freed_bytes / 20e9)));
         const auto t0 = std::chrono::steady_clock::now();
-        double ms = 0.0;
-        int rounds = 0;
-        while (time_it(&ms) && ms > 1.004 * best && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 0.25) ++rounds;
+        double ms = 0.0, prev = 0.0;
+        int rounds = 0, steady = 0;
+        // done when the kernel is back at the kept allocation's speed, or has stopped changing (three rounds within 0.3 % of each other)
+        while (time_it(&ms) && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 0.5) {
+            ++rounds;
+            if (ms <= 1.004 * best) break;
+            steady = prev > 0.0 && std::fabs(ms - prev) <= 0.003 * ms ? steady + 1 : 0;
+            if (steady >= 3) break;
+            prev = ms;
+        }
         if (verbose) std::fprintf(stderr, "[dasp placement] settled after %d more rounds (%.4f ms)\n", rounds, ms);
     }
     cleanup();

@@ -206,7 +206,7 @@ int dasp_plan_create_device(dasp_plan_t **plan, int precision, int rowA, int col
  * dX / dY: the caller's own device vectors (x_len / rowA elements; dY is overwritten), or NULL for scratch ones -- where x and y sit takes
  * part in the effect, so a solver that keeps its vectors should lend them.  ms_first / ms_kept (may be NULL): the time of the first and of
  * the kept allocation, 0 when nothing was tried.  Synchronises the device; results of later products are unchanged (same bytes).
- * Cost: ~5 ms per trial for a 2.6-GB plan plus up to 250 ms while the driver wipes the released allocations -- it pays for itself after a
+ * Cost: ~5 ms per trial for a 2.6-GB plan plus 0.1-1 s while the driver wipes the released allocations (waited for here, so that the caller's first products are not slowed) -- it pays for itself after a
  * few thousand products; DASP_PLACEMENT_TRIALS=1 for plans that live shorter. */
 int dasp_plan_tune_placement(dasp_plan_t *plan, int trials, const void *dX, void *dY, double *ms_first, double *ms_kept);
 /* copy one nnz-sized packed array (names as dasp_plan_host_array) from the device arena to `dst` (tests, serialisation) */
