@@ -223,7 +223,7 @@ def kernel_revision():
     """sha1 of the kernel + packer sources: a traffic.json entry is only attached to the build it was measured on"""
     import hashlib
     h = hashlib.sha1()
-    for f in ("kernels.hip", "plan.cpp", "device.hpp", "plan.hpp"):
+    for f in ("kernels.hip", "spmv_device.hpp", "upload.cpp", "plan.cpp", "device.hpp", "plan.hpp"):
         h.update(open(os.path.join(ROOT, "dasp_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:12]
 

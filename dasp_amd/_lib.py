@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "libdasp_amd.so")
+# DASP_AMD_SO: another build of the same library (tools/ A/B probes: dasp_amd/variants/<tag>/libdasp_amd.so); never a fallback
+SO_PATH = os.environ.get("DASP_AMD_SO") or os.path.join(_HERE, "libdasp_amd.so")
 
 
 class DaspError(RuntimeError):

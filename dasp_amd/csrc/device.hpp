@@ -48,6 +48,8 @@ struct DevArgs {
     // xcd_blk[m % 8] + 4 * (m / 8) .. + 3 below xcd_blk[m % 8 + 1].  xcd_on = 0: block = workgroup * 4 + wave as ever.
     int xcd_on;
     int xcd_blk[9];
+    int ymode;        // DASP_EXPERIMENT builds only: how y is written (spmv_device.hpp put_y / medium_block)
+    int ylog_rows;    // ... mode 5: rows of y (the log's counters sit behind them)
     int med_stride;   // 1: the medium workgroups stride over the blocks (capped, persistent range); 0: exactly one block per wave
 };
 
@@ -70,8 +72,13 @@ struct DevicePlan {
 };
 
 
+int require_device();                  // upload.cpp: DASP_OK, or DASP_ERR_NO_DEVICE with the error text set
 int upload_plan(Plan &p);
 int upload_plan_unpacked(Plan &p);     // for the device packers: arena + O(rows) arrays, no placement trials yet
+// kernels.hip: one SpMV of an uploaded plan (asynchronous); what upload.cpp asks the kernels
+int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate);
+int spmv_kernel_allow_full_lds(int precision, bool c16);
+int spmv_kernel_f16_resident(bool c16);
 int tune_placement(Plan &p, int trials, const void *dX, void *dY, double *ms_first, double *ms_kept);   // kernels.hip: placement trials of an uploaded, fully packed plan (trials <= 0: default)
 
 // fused multi-GPU step (kernels.hip; driven by multigpu.cpp): all pointers are device pointers
@@ -88,6 +95,7 @@ struct MgStepCtl {
     int max_pollers;                                   // bound on the persistent workgroups that wait
     int poll_sleep;                                    // pause between two polls of a workgroup, in units of s_sleep(8) (~0.2 us)
     long long timeout_ticks;                           // 100 MHz ticks a wait may take before it gives up and sets the error word
+    void *err;                                         // the sticky error word (host-mapped, so that the host reads it without a synchronisation); null: words + kMgWordErr
 };
 bool mg_step_supported(const Plan &own, const Plan *other);
 // host: which own-column workgroups of the step kernel store a row with has_other[row] != 0 (natural-order plan, before the

@@ -126,6 +126,13 @@ struct dasp_mg_plan {
     hipStream_t rs = nullptr;          // dasp_mg_reserved_stream: a compute stream that keeps off `rs_cus` CUs
     int rs_cus = 0;
     hipEvent_t ev_y = nullptr, ev_g = nullptr;
+    // fused step of a rank WITHOUT other-column nonzeros: nothing in its step kernel waits for the exchange, so the caller's stream is held
+    // back here instead -- ev_x[k % 3] is recorded behind exchange k, and step k + 3 (the next writer of the slice exchange k reads) waits
+    // for it.  ev_x_step[i] = the exchange the event stands for (0: none since the last synchronising call)
+    hipEvent_t ev_x[3] = {nullptr, nullptr, nullptr};
+    uint64_t ev_x_step[3] = {0, 0, 0};
+    // sticky error word of every in-kernel wait: host-mapped memory, so that every entry point can look at it without a synchronisation
+    int *err_word = nullptr;
     // two-launch form: cross-stream hand-offs through events (documented acquire / release semantics).  DASP_MG_SYNC=memops opts into
     // stream memory operations (hipStreamWriteValue64 / hipStreamWaitValue64, a Beta API) on two words of SIGNAL memory, one
     // allocation each as the API documents; a memory operation that fails falls back to the event for that hand-off.
@@ -138,6 +145,7 @@ struct dasp_mg_plan {
     bool fused = false;                // dasp_mg_spmv / dasp_mg_product run the one-launch step
     bool fusable = false;              // the plans qualify for it (decided at upload)
     bool gather_fine = false;          // yg is fine-grained device memory
+    bool gather_coarse_asked = false;  // DASP_MG_GATHER_MEM=coarse (A/B knob): the caller takes the coarse-grained buffer knowingly
     uint64_t gathered_step = 0;        // step number of the last exchange queued on the communication stream (0: none since set_x)
     int max_pollers = 1024, poll_sleep = 1;
     int max_pollers_thin = 1024;       // ... when the exchange's kernels are thin (direct exchange: 26 registers; they fit beside any number of waiting workgroups)
@@ -188,6 +196,8 @@ struct dasp_mg_plan {
         for (void *p : {xflags, d_push_dst, d_push_count, push_scratch}) if (p) (void)hipFree(p);
         if (ev_y) (void)hipEventDestroy(ev_y);
         if (ev_g) (void)hipEventDestroy(ev_g);
+        for (hipEvent_t e : ev_x) if (e) (void)hipEventDestroy(e);
+        if (err_word) (void)hipHostFree(err_word);
         if (cs) (void)hipStreamDestroy(cs);
         if (rs) (void)hipStreamDestroy(rs);
         for (uint64_t *w : sig) if (w) (void)hipFree(w);
@@ -328,6 +338,19 @@ int wait_gathered(dasp_mg_plan &g, hipStream_t s)
     return DASP_OK;
 }
 
+// a wait inside a kernel gave up since the last dasp_mg_check: whatever was computed since is invalid.  Read from host-mapped memory,
+// no synchronisation -- every entry point that hands out results or queues more work looks here first
+int sticky_error(const dasp_mg_plan &g)
+{
+    if (!g.err_word) return DASP_OK;
+    const int e = *static_cast<volatile int *>(g.err_word);
+    if (e == 0) return DASP_OK;
+    set_error(std::string("multi-GPU step: an in-kernel wait timed out (") + (e == 1 ? "the products' wait for the previous exchange" : e == 2 ? "the exchange's wait for the products" : "a peer's slice did not arrive") +
+              "); results since then are invalid -- dasp_mg_check, then dasp_mg_set_x");
+    return DASP_ERR_STATE;
+}
+void forget_exchange_events(dasp_mg_plan &g) { for (uint64_t &k : g.ev_x_step) k = 0; }
+
 // the one-launch step on stream s?  Not with RCCL between several ranks on a stream that leaves RCCL's kernels no room: they would
 // not start while workgroups wait for them -- such a call runs the two-launch form instead of timing out
 bool fuse_on(const dasp_mg_plan &g, hipStream_t s)
@@ -339,8 +362,16 @@ int product(dasp_mg_plan &g, hipStream_t s)
 {
     const int cur = g.cur, nxt = (g.cur + 1) % 3;
     if (fuse_on(g, s)) {
+        if (!g.other && g.world > 1) {
+            // no other-column plan: the step kernel has no waiting workgroups, i.e. nothing that orders this stream behind the exchange, while
+            // y rotates through three slices -- step k + 3 overwrites the slice exchange k sends.  Hold the stream until that exchange is done
+            // (two exchanges may still be in flight: the own-column product needs nothing from them)
+            const uint64_t j = g.step + 1;
+            if (j > 3 && g.ev_x_step[j % 3] == j - 3) MG_HIP(hipStreamWaitEvent(s, g.ev_x[j % 3], 0));
+        }
         // one launch: own-column workgroups, then the persistent workgroups that wait in the kernel for exchange `gathered_step`
         MgStepCtl c{};
+        c.err = g.err_word;
         c.words = g.words; c.need = g.gathered_step; c.step = g.step + 1;
         c.mark = g.d_mark; c.mark_members = static_cast<char *>(g.d_mark) + ((g.mark.size() + 255) & ~size_t(255));
         c.n_marked = g.n_marked; c.n_mark_shards = g.n_mark_shards; c.blk_order = g.d_blk_order;
@@ -414,10 +445,10 @@ int push_exchange(dasp_mg_plan &g, hipStream_t q, uint64_t ready_need, bool set_
     a.count = static_cast<unsigned *>(g.d_push_count);
     a.wgs = g.push_wgs; a.seq = seq;
     a.ready = reinterpret_cast<const unsigned long long *>(g.words + kMgWordReady); a.ready_need = ready_need;
-    a.timeout = g.timeout_ticks; a.err = reinterpret_cast<int *>(g.words + kMgWordErr);
+    a.timeout = g.timeout_ticks; a.err = g.err_word;
     if (int rc = launch_mg_push(a, q)) return rc;
     if (g.push_loopback && g.fake_us > 0) if (int rc = devpack_spin(q, g.fake_us, 0)) return rc;       // timing probe: the links' share of the exchange
-    return launch_mg_arrived(g.xflags, g.world, seq, set_gathered ? g.words + kMgWordGathered : nullptr, step, g.timeout_ticks, g.words + kMgWordErr, q);
+    return launch_mg_arrived(g.xflags, g.world, seq, set_gathered ? g.words + kMgWordGathered : nullptr, step, g.timeout_ticks, g.err_word, q);
 }
 
 // the slice ys[cur] -> every rank's gather buffer on stream q (direct stores; RCCL; one rank or the test hook: local copies)
@@ -477,12 +508,19 @@ int push_enable(dasp_mg_plan &g)
         MG_HIP(hipMemset(p, 0, kMgWordBytes));
         g.words = static_cast<char *>(p);
     }
-    if (const char *e = std::getenv("DASP_MG_PUSH_WGS")) g.push_wgs = std::max(1, std::min(4096, std::atoi(e)));
+    if (const char *e = std::getenv("DASP_MG_PUSH_WGS")) {
+        // a power of two: the per-destination counters are never reset and publish at (count % wgs == 0), which survives the wrap of an
+        // unsigned counter only when wgs divides 2^32
+        int w = std::max(1, std::min(4096, std::atoi(e))), p2 = 1;
+        while (p2 * 2 <= w) p2 *= 2;
+        g.push_wgs = p2;
+    }
     // the current x is in half 0 (RCCL and the test hook use no other), where exchange count 0 looks for it
     MG_HIP(hipDeviceSynchronize());
     g.xseq = 0;
     g.push = true;
     g.pending = false; g.pending_sig = false; g.pending_lazy = false; g.gathered_step = 0;
+    forget_exchange_events(g);
     return push_arrive(g);
 }
 
@@ -491,6 +529,7 @@ int set_exchange(dasp_mg_plan &g, int mode)
 {
     MG_HIP(hipDeviceSynchronize());
     g.pending = false; g.pending_sig = false; g.pending_lazy = false; g.gathered_step = 0;
+    forget_exchange_events(g);
     if ((mode == 1) == g.push) return DASP_OK;
     if (mode == 1) {
         if (!g.d_push_dst) { set_error("dasp_mg_push_connect first"); return DASP_ERR_STATE; }
@@ -585,7 +624,9 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
         // buffer is allocated fine-grained wherever a plan may run the fused step (DASP_MG_GATHER_MEM=coarse: A/B knob).  Only the
         // other-column product (a few per cent of the gathers) reads it.
         const char *e = std::getenv("DASP_MG_GATHER_MEM");
-        const bool fine = g.overlap && g.precision == 64 && !(e && std::strcmp(e, "coarse") == 0);
+        g.gather_coarse_asked = e && std::strcmp(e, "coarse") == 0;
+        // (every plan of a multi-GPU run: the direct exchange lets peers write this buffer whatever the precision or the step's form)
+        const bool fine = g.world > 1 && !g.gather_coarse_asked;
         // two halves: the direct exchange alternates between them (struct dasp_mg_plan); RCCL uses the first only
         if (!(fine && hipExtMallocWithFlags(&g.yg, 2 * all, hipDeviceMallocFinegrained) == hipSuccess && g.yg)) {
             (void)hipGetLastError();
@@ -603,6 +644,13 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
     }
     MG_HIP(hipEventCreateWithFlags(&g.ev_y, hipEventDisableTiming));
     MG_HIP(hipEventCreateWithFlags(&g.ev_g, hipEventDisableTiming));
+    for (hipEvent_t &e : g.ev_x) MG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    {   // the sticky error word of the in-kernel waits, where the host can read it at any time
+        void *p = nullptr;
+        MG_HIP(hipHostMalloc(&p, 64, hipHostMallocMapped));
+        std::memset(p, 0, 64);
+        g.err_word = static_cast<int *>(p);
+    }
     {   // two-launch form: events unless DASP_MG_SYNC=memops asks for stream memory operations on signal memory
         int can = 0;
         const char *e = std::getenv("DASP_MG_SYNC");
@@ -625,7 +673,8 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
     {   // fused step: wherever the plans qualify (f64, square, split by columns), unless DASP_MG_FUSED=0
         const char *e = std::getenv("DASP_MG_FUSED");
         const bool want = !(e && std::strcmp(e, "0") == 0);
-        if (want && g.overlap && mg_step_supported(g.own->impl, g.other ? &g.other->impl : nullptr) && (!g.other || (int)g.mark.size() == g.own->impl.stats.n_workgroups)) {
+        // (in-kernel acquire of data another agent / kernel writes meanwhile: fine-grained memory, or the caller's explicit A/B choice)
+        if (want && (g.gather_fine || g.gather_coarse_asked || g.world == 1) && g.overlap && mg_step_supported(g.own->impl, g.other ? &g.other->impl : nullptr) && (!g.other || (int)g.mark.size() == g.own->impl.stats.n_workgroups)) {
             void *p = nullptr;
             MG_HIP(hipMalloc(&p, kMgWordBytes));
             MG_HIP(hipMemset(p, 0, kMgWordBytes));
@@ -688,6 +737,7 @@ int dasp_mg_set_x(dasp_mg_plan_t *mg, const void *x_host)
     const char *x = static_cast<const char *>(x_host);
     MG_HIP(hipDeviceSynchronize());
     g.pending = false; g.pending_sig = false; g.pending_lazy = false; g.gathered_step = 0;
+    forget_exchange_events(g);
     g.xseq = 0;                             // direct exchange: x goes to half 0, the next exchange fills half 1 -- on every rank alike
     if (!g.square) { MG_HIP(hipMemcpy(g.xg, x, (size_t)g.colA * vb, hipMemcpyHostToDevice)); return g.push ? push_arrive(g) : DASP_OK; }
     try {
@@ -715,6 +765,7 @@ int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream)
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
     if (!g.comm && !g.push && g.world > 1 && g.fake_us < 0) { set_error("dasp_mg_spmv needs dasp_mg_comm_init or dasp_mg_push_connect (or use dasp_mg_product with your own exchange)"); return DASP_ERR_STATE; }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (int rc = sticky_error(g)) return rc;             // a wait timed out earlier: no more work on top of invalid data
     if (g.push) if (int rc = push_wait_peers(g)) return rc;
     if (int rc = product(g, s)) return rc;
     // y (this rank's padded slice) -> every rank's gather buffer, on the communication stream, behind the products
@@ -725,10 +776,11 @@ int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream)
             // (a one-lane wait kernel ahead of the push instead of the wait inside it: 80.3 instead of 76.7 us at a 40-us exchange)
             if (int rc = push_exchange(g, g.cs, k, true, k)) return rc;
         } else {
-            if (int rc = launch_mg_wait(g.words + kMgWordReady, k, g.timeout_ticks, g.words + kMgWordErr, g.cs)) return rc;
+            if (int rc = launch_mg_wait(g.words + kMgWordReady, k, g.timeout_ticks, g.err_word, g.cs)) return rc;
             if (int rc = exchange(g, g.cs)) return rc;
             if (int rc = launch_mg_flag(g.words + kMgWordGathered, k, g.cs)) return rc;
         }
+        if (!g.other && g.world > 1) { MG_HIP(hipEventRecord(g.ev_x[k % 3], g.cs)); g.ev_x_step[k % 3] = k; }      // product(): back-pressure of a rank without other-column nonzeros
         g.gathered_step = k; g.pending_sig = false; g.pending_lazy = true;      // consumers outside the step kernel: wait_gathered records the event when one shows up
     } else {
         if (int rc = handoff_ready(g, s, k)) return rc;
@@ -756,6 +808,7 @@ int dasp_mg_allgather(dasp_mg_plan_t *mg, void *stream)
 int dasp_mg_wait(dasp_mg_plan_t *mg, void *stream)
 {
     if (!mg) return DASP_ERR_ARG;
+    if (int rc = sticky_error(*mg)) return rc;
     return wait_gathered(*mg, static_cast<hipStream_t>(stream));
 }
 
@@ -766,6 +819,8 @@ int dasp_mg_get_y(dasp_mg_plan_t *mg, void *y_host)
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
     MG_HIP(hipDeviceSynchronize());
     g.pending = false; g.pending_lazy = false;
+    forget_exchange_events(g);
+    if (int rc = sticky_error(g)) return rc;
     const size_t vb = g.vb();
     try {
         std::vector<char> lay((size_t)g.world * g.stride * vb);
@@ -782,6 +837,7 @@ int dasp_mg_get_y_local(dasp_mg_plan_t *mg, void *y_host)
     if (!mg || !y_host) return DASP_ERR_ARG;
     if (!mg->uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
     MG_HIP(hipDeviceSynchronize());
+    if (int rc = sticky_error(*mg)) return rc;
     if (mg->rows() > 0) MG_HIP(hipMemcpy(y_host, mg->ys[mg->cur], (size_t)mg->rows() * mg->vb(), hipMemcpyDeviceToHost));
     return DASP_OK;
 }
@@ -817,11 +873,11 @@ int dasp_mg_check(dasp_mg_plan_t *mg)
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
     MG_HIP(hipDeviceSynchronize());
     g.pending = false; g.pending_lazy = false;
-    if (!g.words) return DASP_OK;
-    uint64_t err = 0;
-    MG_HIP(hipMemcpy(&err, g.words + kMgWordErr, sizeof err, hipMemcpyDeviceToHost));
-    if ((int)err == 0) return DASP_OK;
-    MG_HIP(hipMemset(g.words, 0, kMgWordBytes));
+    forget_exchange_events(g);
+    const int err = g.err_word ? *static_cast<volatile int *>(g.err_word) : 0;
+    if (err == 0) return DASP_OK;
+    *static_cast<volatile int *>(g.err_word) = 0;
+    if (g.words) MG_HIP(hipMemset(g.words, 0, kMgWordBytes));
     g.gathered_step = 0;
     if ((int)err == 3) {
         // direct exchange: a sender's flag did not arrive in time.  Results since then are invalid.  The exchange is NOT switched here:
@@ -845,6 +901,7 @@ int dasp_mg_set_fused(dasp_mg_plan_t *mg, int on)
     MG_HIP(hipDeviceSynchronize());
     if (on && !g.fusable) { set_error("this plan does not qualify for the fused step (f64, square, column split, 16-bit ids, no windows / panels / multi-piece rows)"); return DASP_ERR_STATE; }
     g.pending = false; g.pending_lazy = false; g.gathered_step = 0;
+    forget_exchange_events(g);
     g.fused = on != 0;
     return DASP_OK;
 }
@@ -885,6 +942,10 @@ int dasp_mg_push_connect(dasp_mg_plan_t *mg, const void *blobs)
     dasp_mg_plan &g = *mg;
     if (!g.uploaded || !g.xflags) { set_error("dasp_mg_push_export first"); return DASP_ERR_STATE; }
     if (g.push) return DASP_OK;
+    if (!g.gather_fine && !g.gather_coarse_asked && g.world > 1) {
+        set_error("dasp_mg_push_connect: the gather buffer is not fine-grained device memory (hipExtMallocWithFlags failed at upload); peers' stores into it are only defined at kernel boundaries -- use RCCL, or set DASP_MG_GATHER_MEM=coarse to accept that");
+        return DASP_ERR_STATE;
+    }
     MG_HIP(hipSetDevice(g.device));
     std::vector<void *> pg((size_t)g.world, nullptr), pf((size_t)g.world, nullptr);
     std::vector<char> opened((size_t)g.world, 0);

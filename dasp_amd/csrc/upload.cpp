@@ -1,0 +1,344 @@
+// upload.cpp -- a packed plan's way onto the device: one arena for every array (dasp_f64.h:1239-1278 does one cudaMalloc + cudaMemcpy per
+// array), the launch geometry that goes with it, and the placement trials (profiles/r03_placement.md).  Host code only; the kernels it
+// asks about live in kernels.hip (spmv_kernel_* below).
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <type_traits>
+#include <vector>
+
+#include "plan.hpp"
+#include "device.hpp"
+
+namespace dasp {
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                      \
+            return e_ == hipErrorNoDevice ? DASP_ERR_NO_DEVICE : DASP_ERR_HIP;                 \
+        }                                                                                      \
+    } while (0)
+
+Plan::~Plan()
+{
+    if (dev) {
+        if (dev->arena) (void)hipFree(dev->arena);
+        delete dev;
+    }
+}
+
+int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device visible (the DASP GPU path has no CPU fallback)");
+        return DASP_ERR_NO_DEVICE;
+    }
+    return DASP_OK;
+}
+
+int upload_plan(Plan &p);
+static int upload_plan_impl(Plan &p)
+{
+    if (int rc = require_device()) return rc;
+    if (p.host_dropped && p.dev) return DASP_OK;   // already on the device (packed there, or host copies released)
+    if (p.host_dropped) { set_error("host arrays were dropped"); return DASP_ERR_STATE; }
+    if (p.dev) { if (p.dev->arena) (void)hipFree(p.dev->arena); delete p.dev; p.dev = nullptr; }
+    auto *d = new DevicePlan();
+    p.dev = d;
+    HIP_TRY(hipGetDevice(&d->device));
+    if (!p.panels.empty()) {   // column panels: every panel is a plan of its own; this one only owns their partial results
+        for (auto &h : p.panels) if (int rc = upload_plan(h->impl)) return rc;
+        d->ypart_stride = ((size_t)std::max(p.m, 1) + 127) & ~size_t(127);
+        d->arena_bytes = d->ypart_stride * p.panels.size() * (size_t)p.geo.vbytes;
+        HIP_TRY(hipMalloc(&d->arena, d->arena_bytes));
+        return DASP_OK;
+    }
+
+    std::vector<ShortDev> groups(kNumShortGroups);
+    for (int g = 0; g < kNumShortGroups; ++g) {
+        groups[g].len = p.grp[g].len; groups[g].count = p.grp[g].count; groups[g].tiles = p.grp[g].tiles;
+        groups[g].tile0 = p.grp[g].tile0; groups[g].elem_off = p.grp[g].elem_off; groups[g].map = p.grp[g].map;
+    }
+    const bool natural = p.opt.y_order == DASP_Y_NATURAL;
+    const size_t part_bytes = (size_t)std::max<size_t>(1, p.multi_ptr.empty() ? 0 : (size_t)p.multi_ptr.back()) * 8;
+
+    struct Item { const void *src; size_t bytes; size_t off; };
+    std::vector<Item> items;
+    size_t total = 0;
+    auto add = [&](const void *src, size_t bytes) {
+        size_t off = total;
+        items.push_back({src, bytes, off});
+        total += (bytes + 255) & ~size_t(255);
+        if (bytes == 0) total += 256;
+        return off;
+    };
+    // nnz-sized arrays: sized by their element counts; a plan packed on the device has no host copy (src = nullptr)
+    auto src_of = [](const auto &v) -> const void * { return v.empty() ? nullptr : v.data(); };
+    const size_t vbytes = (size_t)p.geo.vbytes;
+    const size_t o_lv = add(src_of(p.long_val), p.cnt_long * vbytes);
+    const size_t o_lc = add(src_of(p.long_cid), p.cnt_long * 4);
+    const size_t o_pp = add(p.piece_ptr.data(), p.piece_ptr.size() * 4);
+    const size_t o_pd = add(p.piece_dst.data(), p.piece_dst.size() * 4);
+    const size_t o_mp = add(p.multi_ptr.data(), p.multi_ptr.size() * 4);
+    const size_t o_md = add(p.multi_dst.data(), p.multi_dst.size() * 4);
+    const size_t o_part = add(nullptr, part_bytes);
+    const size_t o_mptr = add(p.med_ptr.data(), p.med_ptr.size() * 4);
+    const size_t o_mv = add(src_of(p.med_val), p.cnt_reg * vbytes);
+    const size_t o_mc = add(src_of(p.med_cid), p.cid16 ? 0 : p.cnt_reg * 4);
+    const size_t o_mc16 = add(src_of(p.med_cid16), p.cid16 ? (p.cnt_reg - p.cnt_reg8) * 2 : 0);
+    const size_t o_mc8 = add(src_of(p.med_cid8), p.cnt_reg8);
+    const size_t o_c8p = add(p.med_c8ptr.data(), p.med_c8ptr.size() * 4);
+    const size_t o_mb = add(src_of(p.med_base), p.cid16 ? (size_t)p.med_ptr.back() * 4 : 0);
+    const size_t o_ip = add(p.irr_ptr.data(), p.irr_ptr.size() * 4);
+    const size_t o_iv = add(src_of(p.irr_val), p.cnt_irr * vbytes);
+    const size_t o_ic = add(src_of(p.irr_cid), p.cnt_irr * 4);
+    const size_t o_mdst = add(p.med_dst.data(), p.med_dst.size() * 4);
+    const size_t o_wc = add(p.win_cmin.data(), p.win_cmin.size() * 4);
+    const size_t o_wl = add(p.win_len.data(), p.win_len.size() * 4);
+    const size_t o_sv = add(src_of(p.short_val), p.cnt_short * vbytes);
+    const size_t o_sc = add(src_of(p.short_cid), p.cnt_short * 4);
+    const size_t o_g = add(groups.data(), groups.size() * sizeof(ShortDev));
+    std::vector<int> ord_mapped;   // a column panel writes row r to dst_map[r] (its parent's slot), not to r
+    if (natural && !p.dst_map.empty()) { ord_mapped.resize(p.order.size()); for (size_t i = 0; i < p.order.size(); ++i) ord_mapped[i] = p.dst_map[(size_t)p.order[i]]; }
+    const size_t o_ord = add(natural ? (ord_mapped.empty() ? p.order.data() : ord_mapped.data()) : nullptr, natural ? p.order.size() * 4 : 0);
+
+    HIP_TRY(hipMalloc(&d->arena, total));
+    d->arena_bytes = total;
+    if (std::getenv("DASP_VERBOSE")) std::fprintf(stderr, "[dasp upload] arena %p + %zu bytes\n", d->arena, total);
+    char *base = static_cast<char *>(d->arena);
+    for (const Item &it : items)
+        if (it.src && it.bytes) HIP_TRY(hipMemcpy(base + it.off, it.src, it.bytes, hipMemcpyHostToDevice));
+
+    d->map.long_val = o_lv; d->map.long_cid = o_lc; d->map.med_val = o_mv; d->map.med_cid = o_mc; d->map.med_cid16 = o_mc16; d->map.med_cid8 = o_mc8;
+    d->map.med_base = o_mb; d->map.irr_val = o_iv; d->map.irr_cid = o_ic; d->map.short_val = o_sv; d->map.short_cid = o_sc;
+    DevArgs &a = d->args;
+    a.long_val = base + o_lv; a.long_cid = (const int *)(base + o_lc);
+    a.piece_ptr = (const int *)(base + o_pp); a.piece_dst = (const int *)(base + o_pd);
+    a.multi_ptr = (const int *)(base + o_mp); a.multi_dst = (const int *)(base + o_md);
+    a.partial = base + o_part;
+    a.n_pieces = (int)p.piece_dst.size(); a.n_multi = (int)p.multi_dst.size();
+    a.med_ptr = (const int *)(base + o_mptr); a.med_val = base + o_mv; a.med_cid = (const int *)(base + o_mc);
+    a.irr_ptr = (const int *)(base + o_ip); a.irr_val = base + o_iv; a.irr_cid = (const int *)(base + o_ic);
+    a.n_blocks = p.stats.n_med_blocks; a.row_block = p.n_mfma_rows; a.row_long = p.med_slot0;
+    for (int g = 0; g < kNumShortGroups; ++g) a.grp_tile0[g] = p.grp[g].tile0;
+    a.short_val = base + o_sv; a.short_cid = (const int *)(base + o_sc); a.groups = (const ShortDev *)(base + o_g);
+    a.n_short_tiles = p.stats.n_short_tiles;
+    a.order = natural ? (const int *)(base + o_ord) : nullptr;
+    a.wpw = p.windowed ? std::min(16, p.row_window / kMedRows) : kWavesPerWG;
+    a.wg_long = (a.n_pieces + a.wpw - 1) / a.wpw;
+    a.med_cid16 = (const unsigned short *)(base + o_mc16); a.med_base = (const int *)(base + o_mb);
+    a.med_cid8 = (const unsigned char *)(base + o_mc8); a.med_c8ptr = (const int *)(base + o_c8p);
+    a.med_dst = (const int *)(base + o_mdst); a.win_cmin = (const int *)(base + o_wc); a.win_len = (const int *)(base + o_wl);
+    a.n_windows = (int)p.win_len.size(); a.blocks_per_win = p.windowed ? p.row_window / kMedRows : 0;
+    a.win_hybrid = p.win_hybrid ? 1 : 0; a.win_rel16 = p.win_rel16 ? 1 : 0; a.pair_mode = p.pair_mode;
+    a.win_xcd = 1;
+    if (const char *e = std::getenv("DASP_WIN_XCD")) a.win_xcd = std::atoi(e);      // A/B knob
+    d->win1 = false;
+    if (p.windowed) {
+        int cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        d->win1 = a.n_windows <= cus;
+        if (const char *e = std::getenv("DASP_WIN1")) d->win1 = d->win1 && std::atoi(e) != 0;
+    }
+    a.wg_med = p.windowed ? (a.n_windows + 7) / 8 * 8 : (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG;      // windows: a whole number per XCD (kernel)
+    // f16 blocks of uniform length: a persistent set of 7 workgroups per CU striding over the blocks amortises the per-wave
+    // set-up that weighs twice as much at 2 bytes per value (nlpkkt160 f16 0.675 -> 0.739 of the roofline, Queen_4147 f16
+    // 0.873 -> 0.927).  Static striding needs equal blocks: with HV15R's 2 % of 3x longer rows it loses 10 %, and in f64 it
+    // loses 3-9 % everywhere, so: f16 only, no windows, longest block <= 1.25 x the mean.
+    if (!p.windowed && p.precision == 16 && a.n_blocks > 256 * 7 * kWavesPerWG) {      // (the threshold: a full set on a 256-CU device)
+        int longest = 0;
+        for (int b = 0; b < a.n_blocks; ++b) longest = std::max(longest, p.med_ptr[(size_t)b + 1] - p.med_ptr[(size_t)b]);
+        const double mean = (double)p.med_ptr[(size_t)a.n_blocks] / (double)a.n_blocks;
+        if (p.cnt_irr * 8 <= p.cnt_reg && mean > 0 && (double)longest <= 1.25 * mean) {
+            // as many persistent workgroups per CU as the kernel's registers let reside at once (7 at <= 72 VGPRs), on every CU of the device
+            int per_cu = 7, cus = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+            const int fit = spmv_kernel_f16_resident(p.cid16);
+            if (fit > 0) per_cu = std::min(per_cu, fit);
+            (void)hipGetLastError();
+            a.wg_med = std::min(a.wg_med, cus * per_cu);
+        }
+    }
+    // XCD-contiguous block ranges (opt-in: DASP_XCD_BLOCKS=1) for plans of EVEN blocks (FEM / stencil rows: longest block <= 4 x the
+    // mean).  Work of a block = its chunks + 2 (row tables, tail); every XCD gets an eighth of it.  Measured r3 (profiles/r03_xcd_blocks.md):
+    // it removes exactly the traffic it was built for -- nlpkkt160's x pulled through eight L2s, FETCH 3.03 -> 2.54 GB per SpMV, 1.03 ->
+    // 0.86 x the CSR bytes -- but that traffic was Infinity-Cache hits, not HBM reads, and the time does not move (nlpkkt160 0.4051 ->
+    // 0.4105 ms, HV15R 0.4274 -> 0.4227, Queen 0.5089 -> 0.5083, f16 0-1.5 % slower), so it stays off by default.
+    a.xcd_on = 0;
+    for (int &v : a.xcd_blk) v = 0;
+    a.med_stride = a.wg_med * kWavesPerWG < a.n_blocks ? 1 : 0;      // the medium range is a persistent, striding set of workgroups (f16 only today)
+    if (const char *e = std::getenv("DASP_MED_LOOP")) a.med_stride = a.med_stride || std::atoi(e) != 0;      // A/B knob
+    if (!p.windowed && a.wg_med == (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG && a.n_blocks >= 8 * 256 && (int)p.med_ptr.size() == a.n_blocks + 1) {
+        int longest = 0;
+        for (int b = 0; b < a.n_blocks; ++b) longest = std::max(longest, p.med_ptr[(size_t)b + 1] - p.med_ptr[(size_t)b]);
+        const double mean = (double)p.med_ptr[(size_t)a.n_blocks] / (double)a.n_blocks;
+        const char *e = std::getenv("DASP_XCD_BLOCKS");
+        const bool on = e && std::atoi(e) != 0 && (double)longest <= 4.0 * std::max(mean, 1.0);
+        if (on) {
+            auto work_before = [&](int b) { return (long long)p.med_ptr[(size_t)b] + 2ll * b; };
+            const long long total = work_before(a.n_blocks);
+            int most = 0;
+            for (int k = 0; k <= 8; ++k) {
+                int lo = 0, hi = a.n_blocks;                               // first block whose preceding work reaches k / 8 of the total
+                while (lo < hi) { const int mid = (lo + hi) / 2; if (work_before(mid) * 8 < total * k) lo = mid + 1; else hi = mid; }
+                a.xcd_blk[k] = k == 8 ? a.n_blocks : lo;
+            }
+            for (int k = 0; k < 8; ++k) most = std::max(most, a.xcd_blk[k + 1] - a.xcd_blk[k]);
+            a.xcd_on = 1;
+            a.wg_med = 8 * ((most + kWavesPerWG - 1) / kWavesPerWG);
+        }
+    }
+    a.wg_short = (a.n_short_tiles + a.wpw - 1) / a.wpw;
+    // streamed-once matrix data bypasses the caches (the reference's ld.global.cs, dasp_f64.h:34-51)
+    // only when it cannot stay resident in the 256 MiB Infinity Cache between two SpMVs anyway.
+    d->nt = p.opt.stream_policy == 2 || (p.opt.stream_policy != 1 && p.stats.data_X > kStreamBytes);
+    if (p.windowed && p.lds_bytes > 65536) {
+        // more than the default 64 KiB of dynamic LDS must be requested per kernel; done here (for both cache-policy
+        // variants), not in the launch path, so that dasp_plan_spmv stays free of anything a stream capture would reject
+        // the attribute belongs to the kernel, not to the plan: always ask for the device maximum, or a later plan with narrower
+        // windows would lower the limit under an earlier one with wider windows
+        if (int rc = spmv_kernel_allow_full_lds(p.precision, p.cid16)) return rc;
+    }
+    return DASP_OK;
+}
+
+
+// ---- placement trials (r3, profiles/r03_placement.md).  The same arena bytes run the HBM-bound kernels at one of two speeds ~8 % apart
+// depending on WHERE the allocation landed (two uploads of one plan in one process, interleaved timing: 0.420 vs 0.453 ms; the skew
+// between the arena's arrays, the TLB and the history of the device do not matter; which allocation of a process is the fast one differs
+// from box to box).  A user-mode library cannot see the cause, but it can look: time a few launches, copy the arena into a fresh allocation
+// (the old one stays allocated meanwhile, so the new one lands elsewhere), time again, keep the faster, at most `trials` allocations alive at once
+// (DASP_PLACEMENT_TRIALS, default 6; 1 = off), stop as soon as one allocation is >= 4 % faster than another.  Only plans that stream
+// >= 256 MiB per SpMV and are not gather-bound by construction (column panels, LDS windows).  Costs ~5 ms per trial for HV15R.
+// Measured on the bench headline, six fresh processes each on one box: without 0.4343 0.4272 0.4595 0.4595 0.4603 0.4594 ms, with
+// 0.4508 0.4283 0.4285 0.4275 0.4332 0.4336 ms -- the caller's x / y take part in the effect (profiles/r03_placement.md), so the trials
+// with scratch operands shift the odds, they do not decide.
+static void rebase_args(DevArgs &a, const char *from, const char *to, size_t bytes)
+{
+    auto mv = [&](auto &ptr) {
+        const char *q = reinterpret_cast<const char *>(ptr);
+        if (q >= from && q < from + bytes) ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(const_cast<char *>(to + (q - from)));
+    };
+    mv(a.long_val); mv(a.long_cid); mv(a.piece_ptr); mv(a.piece_dst); mv(a.partial); mv(a.multi_ptr); mv(a.multi_dst);
+    mv(a.med_ptr); mv(a.med_val); mv(a.med_cid); mv(a.med_cid16); mv(a.med_base); mv(a.med_cid8); mv(a.med_c8ptr);
+    mv(a.irr_ptr); mv(a.irr_val); mv(a.irr_cid); mv(a.med_dst); mv(a.win_cmin); mv(a.win_len);
+    mv(a.short_val); mv(a.short_cid); mv(a.groups); mv(a.order);
+}
+
+int tune_placement(Plan &p, int trials, const void *dX, void *dY, double *ms_first, double *ms_kept)
+{
+    DevicePlan *d = p.dev;
+    if (ms_first) *ms_first = 0.0;
+    if (ms_kept) *ms_kept = 0.0;
+    if (trials <= 0) {
+        trials = 6;
+        if (const char *e = std::getenv("DASP_PLACEMENT_TRIALS")) trials = std::max(1, std::min(8, std::atoi(e)));
+    }
+    if (!d || !d->arena || trials <= 1 || d->arena_bytes < (size_t(256) << 20) || !p.panels.empty() || p.panel || p.windowed) return DASP_OK;
+    const bool verbose = std::getenv("DASP_VERBOSE") != nullptr;
+    const size_t vb = (size_t)p.geo.vbytes, bytes = d->arena_bytes;
+    const size_t xlen = p.opt.n_parts > 0 ? (size_t)p.opt.n_parts * (size_t)p.opt.part_stride : (size_t)p.n;
+    void *x = nullptr, *y = nullptr;                 // scratch operands unless the caller lends its own (whose placement takes part in the effect)
+    const void *ux = dX; void *uy = dY;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<void *> losers;
+    auto cleanup = [&] {
+        for (void *q : losers) (void)hipFree(q);
+        if (x) (void)hipFree(x);
+        if (y) (void)hipFree(y);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipGetLastError();
+    };
+    // scratch operands: zeros (the values do not matter to the stream); a failure anywhere below leaves the plan as it is
+    if (!ux) { if (hipMalloc(&x, std::max<size_t>(xlen * vb, 256)) != hipSuccess || hipMemset(x, 0, std::max<size_t>(xlen * vb, 256)) != hipSuccess) { cleanup(); return DASP_OK; } ux = x; }
+    if (!uy) { if (hipMalloc(&y, ((size_t)p.m + 64) * vb) != hipSuccess) { cleanup(); return DASP_OK; } uy = y; }
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { cleanup(); return DASP_OK; }
+    auto time_it = [&](double *ms) -> bool {
+        for (int i = 0; i < 2; ++i) if (launch_spmv(p, ux, uy, nullptr, false) != DASP_OK) return false;
+        if (hipEventRecord(e0, nullptr) != hipSuccess) return false;
+        const int reps = 6;
+        for (int i = 0; i < reps; ++i) if (launch_spmv(p, ux, uy, nullptr, false) != DASP_OK) return false;
+        float t = 0.f;
+        if (hipEventRecord(e1, nullptr) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&t, e0, e1) != hipSuccess) return false;
+        *ms = (double)t / reps;
+        return true;
+    };
+    double best = 0.0;
+    if (!time_it(&best)) { cleanup(); return DASP_OK; }
+    double lo = best, hi = best;
+    if (ms_first) *ms_first = best;
+    if (verbose) std::fprintf(stderr, "[dasp placement] allocation 0 at %p: %.4f ms\n", d->arena, best);
+    for (int t = 1; t < trials && hi < 1.04 * lo; ++t) {
+        void *na = nullptr;
+        if (hipMalloc(&na, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (hipMemcpy(na, d->arena, bytes, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(na); (void)hipGetLastError(); break; }
+        char *old = static_cast<char *>(d->arena);
+        rebase_args(d->args, old, static_cast<char *>(na), bytes);
+        d->arena = na;
+        double ms = 0.0;
+        const bool ok = time_it(&ms);
+        if (verbose) std::fprintf(stderr, "[dasp placement] allocation %d at %p: %.4f ms\n", t, na, ok ? ms : -1.0);
+        if (ok && ms < best) { best = ms; losers.push_back(old); }
+        else {                                        // back to the one that was faster
+            rebase_args(d->args, static_cast<char *>(na), old, bytes);
+            d->arena = old;
+            losers.push_back(na);
+        }
+        if (ok) { lo = std::min(lo, ms); hi = std::max(hi, ms); }
+    }
+    if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+    if (ms_kept) *ms_kept = best;
+    // the allocations that lost go back now -- and the driver wipes released VRAM in the background, which costs the kernels 1-3 % for the
+    // next 50-500 ms, by how much was released (seen as a 2.8 % slower timed region right behind six trials on a box where none of them was
+    // faster).  Let that pass here, at set-up, not under the caller's first products: launches until they run as fast as the kept
+    // allocation did.
+    const size_t freed_bytes = losers.size() * bytes;
+    const bool freed = !losers.empty();
+    for (void *q : losers) (void)hipFree(q);
+    losers.clear();
+    if (freed) {
+        // ~35 GB/s of wiping was seen (5.3 GB: 0.15 s of slower launches); wait for 20 GB/s worth, then check with launches
+        std::this_thread::sleep_for(std::chrono::duration<double>(std::min(1.0, (double)freed_bytes / 20e9)));
+        const auto t0 = std::chrono::steady_clock::now();
+        double ms = 0.0, prev = 0.0;
+        int rounds = 0, steady = 0;
+        // done when the kernel is back at the kept allocation's speed, or has stopped changing (three rounds within 0.3 % of each other)
+        while (time_it(&ms) && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 0.5) {
+            ++rounds;
+            if (ms <= 1.004 * best) break;
+            steady = prev > 0.0 && std::fabs(ms - prev) <= 0.003 * ms ? steady + 1 : 0;
+            if (steady >= 3) break;
+            prev = ms;
+        }
+        if (verbose) std::fprintf(stderr, "[dasp placement] settled after %d more rounds (%.4f ms)\n", rounds, ms);
+    }
+    cleanup();
+    return DASP_OK;
+}
+
+// host-built plans: the trials are part of the upload (a few ms next to the packing).  Plans packed on the device
+// (dasp_plan_create_device: creation time is the metric there) leave them to the caller: dasp_plan_tune_placement.
+int upload_plan(Plan &p)
+{
+    const bool fresh = !(p.host_dropped && p.dev);
+    if (int rc = upload_plan_impl(p)) return rc;
+    return fresh ? tune_placement(p, 0, nullptr, nullptr, nullptr, nullptr) : DASP_OK;
+}
+// the arena with every O(rows) array, the nnz-sized regions left for the device packers (devpack.hip)
+int upload_plan_unpacked(Plan &p) { return upload_plan_impl(p); }
+
+}  // namespace dasp

@@ -145,7 +145,7 @@ class MgPlan:
     def set_fake_exchange(self, micros, peers=()):
         """TEST HOOK: n_gpus > 1 without RCCL; the exchange copies this rank's slice into its own gather buffer and into the
         gather buffers of `peers` (MgPlans on the same device), then holds the communication stream for `micros` us."""
-        arr = (C.c_void_p * max(1, len(peers)))(*[p.gathered_ptr for p in peers])
+        arr = (C.c_void_p * max(1, len(peers)))(*[p if isinstance(p, int) else p.gathered_ptr for p in peers])      # MgPlans, or raw device addresses of gather-sized buffers
         _lib.check(_lib.lib().dasp_mg_set_fake_exchange(self._h, int(micros), len(peers), arr))
 
     # direct exchange (include/dasp_amd.h): stores into the peers' gather buffers instead of an RCCL collective

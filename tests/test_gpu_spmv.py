@@ -794,6 +794,43 @@ def test_fused_mg_step_without_other_column_nonzeros(dasp, torch_cuda):
     mg.close()
 
 
+def test_fused_mg_step_without_other_column_nonzeros_is_held_behind_a_slow_exchange(dasp, torch_cuda):
+    """a rank WITHOUT other-column nonzeros has no waiting workgroup in its step kernel, so nothing in the kernel
+    orders the caller's stream behind the exchange -- while y rotates through three slices.  With an exchange of 400 us against a product
+    of a few us and no host synchronisation, step k + 3 used to overwrite the slice exchange k had not sent yet.  Every step's exchange
+    copies the slice into a buffer of its own here (the hook's peer list is changed before every call), and each must hold exactly that
+    step's y."""
+    import scipy.sparse as sp
+    from dasp_amd.multi import MgPlan
+    torch = torch_cuda
+    m = 6000
+    bounds = np.array([0, 3000, 6000], np.int32)
+    rank = 1
+    rp, ci, v = util.mixed_matrix(3000, 3000, 43, lengths=[0, 1, 2, 3, 4, 7, 12, 30, 64])
+    lens = np.diff(rp)
+    v = v / np.maximum(np.repeat(lens, lens), 1)
+    B = sp.csr_matrix((v.copy(), ci.copy(), rp.copy()), shape=(3000, 3000))
+    mg = MgPlan(rp, ci + 3000, v, m, m, bounds, rank, cid16=1, x_window=-1).upload()
+    assert mg.info["fused_step"] == 1 and mg.nnz_remote == 0
+    steps = 9
+    stride = mg.stride
+    peers = [torch.zeros(2 * 2 * stride, dtype=torch.float64, device="cuda") for _ in range(steps)]      # gather-sized (two halves)
+    x0 = np.random.default_rng(7).uniform(0.5, 1.5, m)
+    mg.set_x(x0)
+    s = torch.cuda.current_stream().cuda_stream
+    for k in range(steps):
+        mg.set_fake_exchange(400, [peers[k].data_ptr()])
+        mg.spmv(s)
+    mg.wait(s)
+    mg.check()
+    want = x0[3000:].copy()
+    for k in range(steps):
+        want = B @ want
+        got = peers[k][rank * stride: rank * stride + 3000].cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max(), "exchange %d sent another step's slice" % (k + 1)
+    mg.close()
+
+
 def test_fused_mg_step_waits_in_the_kernel_and_times_out_cleanly(dasp, torch_cuda, monkeypatch):
     """One rank of a 2-way partition, 30 chained steps with NO host synchronisation between them and an emulated exchange of
     60 us: the other-column workgroups really wait inside the kernel for the previous exchange.  The peer's half of x never

@@ -87,7 +87,18 @@ for rank in ranks:
     t_own = own.time(x.data_ptr(), y.data_ptr(), s, warmup=5, iters=100)[1] * 1e3
     t_own2 = own.time(mg.y_local_ptr, y.data_ptr(), s, warmup=5, iters=100)[1] * 1e3
     t_own3 = own.time(mg.y_local_ptr, mg.gathered_ptr, s, warmup=5, iters=100)[1] * 1e3
-    line += " | own alone with x=ys %.1f, and y=yg %.1f" % (t_own2, t_own3)
+    t_own4 = own.time(mg.gathered_ptr, y.data_ptr(), s, warmup=5, iters=100)[1] * 1e3          # x read from the (fine-grained) gather buffer
+    line += " | own alone with x=ys %.1f, and y=yg %.1f, x=yg(fine-grained) %.1f" % (t_own2, t_own3, t_own4)
+    if can_fuse and "variants/exp" in os.environ.get("DASP_AMD_SO", ""):      # the own-column part inside the step kernel (no other-column product, no waiting workgroups)
+        os.environ["DASP_MG_STEP_NOOTHER"] = "1"
+        mg.set_fused(True); mg.set_x(np.ones(cols))
+        for _ in range(10): mg.product(s)
+        torch.cuda.synchronize()
+        t = StreamTimer(s); t.start()
+        for _ in range(100): mg.product(s)
+        ms = t.stop(); torch.cuda.synchronize()
+        os.environ["DASP_MG_STEP_NOOTHER"] = "0"
+        line += " | step kernel without the other-column part %.1f" % (ms / 100 * 1e3)
     t_oth = 0.0
     if oth is not None:
         xo = torch.ones(oth.x_len, dtype=torch.float64, device="cuda")

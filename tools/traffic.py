@@ -13,7 +13,7 @@ d = os.path.join(root, "gpurun_out", "prof_" + tag)
 
 def rev():
     h = hashlib.sha1()
-    for f in ("kernels.hip", "plan.cpp", "device.hpp", "plan.hpp"):
+    for f in ("kernels.hip", "spmv_device.hpp", "upload.cpp", "plan.cpp", "device.hpp", "plan.hpp"):
         h.update(open(os.path.join(root, "dasp_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:12]
 
