@@ -402,6 +402,8 @@ static int spmv_all_impl(int precision, const char *filename, const void *val, c
     dasp_plan_stats(plan, &s);
     const double t = wall;                                                  // ms per SpMV, dasp_f64.h:1394
     const double gflops = (double)((long long)nnzA * 2) / (t * 1e6);        // :1395
+    // the stdout line: what this run moved (the native packed bytes); the CSV row: the REFERENCE's geometry on this input, i.e. the values
+    // the CUDA reference writes for the same matrix, so that the two rows can be compared column by column (time / rate columns aside)
     const long long data_X2 = s.data_X + (long long)(nnzA - colA) * (long long)vb;  // x counted per gather, :1168-1172
     const double bw1 = (double)s.data_X / (t * 1e6), bw2 = (double)data_X2 / (t * 1e6);
     std::printf("SpMV_X:  %8.4lf ms, %8.4lf GFlop/s, %9.4lf GB/s, %9.4lf GB/s\n", t, gflops, bw1, bw2);     // dasp_f64.h:1398
@@ -412,16 +414,26 @@ static int spmv_all_impl(int precision, const char *filename, const void *val, c
     std::fflush(stdout);
     struct stat st;
     if (stat("data", &st) == 0 && S_ISDIR(st.st_mode)) {
+        const long long ref_X2 = s.ref_data_X + (long long)(nnzA - colA) * (long long)vb;
+        const double tb = precision == 16 ? t2 : t;                          // dasp_f16.h:1715-1716 rates its bandwidths on the bypass time
+        const double rbw1 = (double)s.ref_data_X / (tb * 1e6), rbw2 = (double)ref_X2 / (tb * 1e6);
         FILE *fo = std::fopen(precision == 64 ? "data/spmv_f64_record.csv" : "data/spmv_f16_record.csv", "a");
         if (fo) {   // column order of dasp_f64.h:1439-1441 (f16 adds dasp_pre after rate_fill0.. see dasp_f16.h:1756-1758)
             std::fprintf(fo, "%s,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%lld,%d,%lld,%d,%lld,%d,", filename ? filename : "", rowA, colA,
                          nnzA, s.short_row_1, s.common_13, s.short_row_3, s.short_row_4, s.short_row_2, s.row_long, s.row_block,
-                         s.nnz_short, s.fill0_nnz_short, s.nnz_long, s.fill0_nnz_long, s.origin_nnz_reg, s.fill0_nnz_reg, s.nnz_irreg);
+                         s.nnz_short, s.ref_fill0_nnz_short, s.nnz_long, s.ref_fill0_nnz_long, s.ref_origin_nnz_reg, s.ref_fill0_nnz_reg, s.ref_nnz_irreg);
             if (precision == 64)
-                std::fprintf(fo, "%lf,%d,%lld,%lf,%lf,%lf,%lf,", s.rate_fill0, block_longest, s.data_X, t, gflops, bw1, bw2);
+                std::fprintf(fo, "%lf,%d,%lld,%lf,%lf,%lf,%lf,", s.ref_rate_fill0, block_longest, s.ref_data_X, t, gflops, rbw1, rbw2);
             else   // dasp_f16.h:1757-1758: ..., dasp_pre, dasp_time, dasp_gflops, dasp_time_bypass, dasp_gflops_bypass, bandwidth1, bandwidth2
-                std::fprintf(fo, "%lf,%d,%lld,%lf,%lf,%lf,%lf,%lf,%lf,%lf,", s.rate_fill0, block_longest, s.data_X, s.pre_ms, t, gflops, t2,
-                             gflops2, bw1, bw2);
+                std::fprintf(fo, "%lf,%d,%lld,%lf,%lf,%lf,%lf,%lf,%lf,%lf,", s.ref_rate_fill0, block_longest, s.ref_data_X, s.pre_ms, t, gflops, t2,
+                             gflops2, rbw1, rbw2);
+            std::fclose(fo);
+        }
+        // this build's own geometry, one complete line per call: name, padded sizes, rate_fill0, packed bytes, the two rates on them
+        fo = std::fopen(precision == 64 ? "data/dasp_amd_native_f64.csv" : "data/dasp_amd_native_f16.csv", "a");
+        if (fo) {
+            std::fprintf(fo, "%s,%lld,%lld,%d,%lld,%d,%lf,%lld,%lf,%lf\n", filename ? filename : "", s.fill0_nnz_short, s.fill0_nnz_long, s.origin_nnz_reg,
+                         s.fill0_nnz_reg, s.nnz_irreg, s.rate_fill0, s.data_X, bw1, bw2);
             std::fclose(fo);
         }
     }

@@ -158,6 +158,60 @@ enum BuildMode { kTop = 0, kMetaOnly = 1, kPanel = 2 };   // whole plan (may cho
 template <class T> static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int P, const DevCsr *dev);
 static int decide_panels(const Plan &p, const int *rp, const int *ci, const Remap &remap, const DevCsr *dev);
 
+// ---- the REFERENCE's geometry on the same input (VERDICT r3 missing #5).  The native tiles are 16 x K on 64-lane waves, so the padded sizes
+// this library stores differ from the ones the CUDA reference computes (8-row blocks, 8 x 4 tiles, 32-lane warps) -- and a CSV row written
+// here could not be compared with a row the reference writes.  All of the reference's sizes are functions of the row lengths alone, so they
+// are computed next to the native ones: short tiles dasp_f64.h:609-629 / dasp_f16.h:1139-1156, long rows :1000-1014 / :1273-1288, the
+// regular / irregular split :1044-1091 / :1317-1365 (on the globally length-sorted medium rows), rate_fill0 and data_X :1159-1166 /
+// dasp_f16.h:1448-1455.  lenL: lengths of the long rows; lenM: medium lengths, descending.
+struct RefGeometry { long long fill0_short = 0, fill0_long = 0, fill0_reg = 0, data_X = 0; int nnz_irreg = 0, blocknum = 0, warp_number = 0; double rate_fill0 = 0; };
+static RefGeometry reference_geometry(bool f16, int m, int n, int nnz, int n1, int c13, int n3, int n4, int n2, const std::vector<int> &lenL,
+                                      const raw_vector<int> &lenM, double threshold, int threads)
+{
+    constexpr int BS = 8, MK = 4, TILE = BS * MK;           // BlockSize, MMA_K, MMA_M * MMA_K (common.h:29-33)
+    constexpr int warps = 4, loop_short = 4, loop_long = 2;  // warpNum_short = warpNum_long, loopNum_short, loopNum_long (dasp_f64.h:18-22)
+    RefGeometry g;
+    const int per13 = warps * (f16 ? 4 : 2), per22 = per13, per34 = warps * loop_short;      // blocks per thread block
+    const int tb13 = ceil_div(ceil_div(c13, BS), per13), tb22 = ceil_div(ceil_div((n2 + 1) / 2, BS), per22), tb34 = ceil_div(ceil_div(n3 + n4, BS), per34);
+    g.fill0_short = (f16 ? (long long)((n1 + 1) / 2) * 2 : (long long)n1) + (long long)(tb13 * per13 + tb34 * per34 + tb22 * per22) * TILE;
+    const int G = TILE * loop_long * (f16 ? 4 : 1);          // elements one warp takes of a long row: 64 / 256
+    long long w = 0;
+    for (int L : lenL) w += ceil_div(L, G);
+    const long long blocks_long = (w + warps - 1) / warps;
+    g.warp_number = (int)(blocks_long * warps);
+    g.fill0_long = blocks_long * warps * G;
+    const int row_block = (int)lenM.size();
+    const int rowloop = row_block < 59990 ? 1 : (row_block < 400000 ? 2 : 4);
+    const int nb_real = ceil_div(row_block, BS);
+    g.blocknum = ceil_div(nb_real, rowloop * 4) * rowloop * 4;
+    std::atomic<long long> reg{0}, irr{0};
+    parallel_for(nb_real, threads, 1 << 12, [&](long long b0, long long b1) {
+        long long r = 0, t = 0;
+        for (long long b = b0; b < b1; ++b) {
+            const int lo = (int)b * BS, hi = std::min(row_block, lo + BS);
+            long long kept = 0;      // elements of the block's regular part
+            for (int k = 1;; ++k) {
+                int fill = 0;
+                for (int i = lo; i < hi; ++i) { const int L = lenM[(size_t)i]; fill += L / MK >= k ? MK : (L / MK == k - 1 ? L % MK : 0); }
+                if ((double)fill >= threshold * TILE) { kept += TILE; continue; }
+                for (int i = lo; i < hi; ++i) t += std::max(lenM[(size_t)i] - (k - 1) * MK, 0);
+                break;
+            }
+            if (f16) kept = (kept + 4 * TILE - 1) / (4 * TILE) * (4 * TILE);      // dasp_f16.h:1356
+            r += kept;
+        }
+        reg += r; irr += t;
+    });
+    g.fill0_reg = reg; g.nnz_irreg = (int)irr;
+    const long long stored = g.fill0_short + g.fill0_long + g.nnz_irreg + g.fill0_reg;
+    g.rate_fill0 = nnz > 0 ? (double)(stored - nnz) / nnz : 0.0;
+    const long long sv = f16 ? 2 : 8;
+    g.data_X = (long long)(m + n) * sv + g.fill0_long * (sv + 4) + (long long)g.warp_number * sv + (long long)(lenL.size() + 1) * 4 + g.fill0_short * (sv + 4) +
+               g.fill0_reg * (sv + 4) + (long long)(g.blocknum + 1) * 4 + (long long)(f16 ? (g.nnz_irreg + 1) / 2 * 2 : g.nnz_irreg) * (sv + 4) +      // f16: fill0_nnz_irreg, dasp_f16.h:1368,1455
+               (long long)(row_block + 1) * 4;
+    return g;
+}
+
 template <class T>
 static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const DevCsr *dev, BuildMode mode = kTop)
 {
@@ -274,6 +328,13 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     }
 
     lap("sort medium");
+    RefGeometry refg;
+    {
+        std::vector<int> lenL(ridL.size());
+        for (size_t i = 0; i < ridL.size(); ++i) lenL[i] = rp[ridL[i] + 1] - rp[ridL[i]];
+        refg = reference_geometry(f16, m, p.n, nnz, n1, c13, n3, n4, n2, lenL, lenM, threshold, threads);
+    }
+    lap("reference geometry");
     // ---- output permutation (order_rid): dasp_f64.h:960-976 / dasp_f16.h:1253-1270
     const int base_s = nlong + nmed;   // (all medium rows: the slab split happens below)
     const int pg = f16 ? 32 : 8;
@@ -959,6 +1020,9 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                (long long)(p.med_ptr.size() + p.irr_ptr.size()) * 4 + (natural ? (long long)m * 4 : 0) +
                (long long)(p.med_dst.size() + 2 * p.win_len.size()) * 4;
     s.data_origin1 = (long long)(nnz + p.n + m) * sv + (long long)nnz * 4 + (long long)(m + 1) * 4;  // main_f64.cu:143
+    s.ref_fill0_nnz_short = refg.fill0_short; s.ref_fill0_nnz_long = refg.fill0_long; s.ref_fill0_nnz_reg = refg.fill0_reg; s.ref_data_X = refg.data_X;
+    s.ref_nnz_irreg = refg.nnz_irreg; s.ref_origin_nnz_reg = nnz - refg.nnz_irreg - (int)nnz_long - nnz_short; s.ref_blocknum = refg.blocknum;
+    s.ref_warp_number = refg.warp_number; s.ref_rate_fill0 = refg.rate_fill0;
     s.n_med_blocks = nb;
     s.n_long_pieces = (int)p.piece_dst.size();
     s.n_long_multi = (int)p.multi_dst.size();

@@ -184,6 +184,14 @@ typedef struct dasp_stats {
     int med_rows_as_pieces;    /* medium rows (the longest ones: the first medium slots) stored as pieces (piece_min_len) */
     int chunk_pairs;           /* 0 / 1 / 2: which medium blocks store chunk pairs (options chunk_pairs; column panels: the largest) */
     int cid8_chunks;           /* regular medium chunks with one-byte column ids (option cid8) */
+    /* the REFERENCE's geometry on the same input (8-row blocks, 8x4 tiles, 32-lane warps): the padded sizes the CUDA reference computes
+     * and writes into its CSV row for this matrix -- short tiles dasp_f64.h:609-629 / dasp_f16.h:1139-1156, long rows :1000-1014 /
+     * :1273-1288, regular / irregular split :1044-1091 / :1317-1365, rate_fill0 and data_X :1159-1166 / dasp_f16.h:1448-1455.  Functions
+     * of the row lengths alone; dasp_spmv_all_* writes THESE into the reference's CSV columns, so that a row written here can be diffed
+     * against a row the reference writes (the native sizes above go to data/dasp_amd_native_f64.csv / _f16.csv). */
+    long long ref_fill0_nnz_short, ref_fill0_nnz_long, ref_fill0_nnz_reg, ref_data_X;
+    int ref_nnz_irreg, ref_origin_nnz_reg, ref_blocknum, ref_warp_number;
+    double ref_rate_fill0;
 } dasp_stats_t;
 
 /* classifier + packers on the host (no GPU needed).  CSR arrays are read-only and may be

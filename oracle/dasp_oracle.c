@@ -587,6 +587,10 @@ int oracle_dasp_int(const oracle_dasp_t *d, const char *name)
     return -2147483647;
 }
 
+/* data_X (dasp_f64.h:1162-1166) and rate_fill0 (:1159-1160) do not fit oracle_dasp_int */
+long long oracle_dasp_data_X(const oracle_dasp_t *d) { return d->data_X; }
+double oracle_dasp_rate_fill0(const oracle_dasp_t *d) { return d->rate_fill0; }
+
 #define FIELD_ARR(n, l) if (strcmp(name, #n) == 0) { if (len) *len = (l); return d->n; }
 const void *oracle_dasp_arr(const oracle_dasp_t *d, const char *name, int *len)
 {

@@ -101,6 +101,8 @@ void oracle_dasp_eval(const oracle_dasp_t *d, const double *x, double *y_perm);
 /* accessors so ctypes users need not mirror the struct layout */
 int         oracle_dasp_int(const oracle_dasp_t *d, const char *name);
 const void *oracle_dasp_arr(const oracle_dasp_t *d, const char *name, int *len);
+long long   oracle_dasp_data_X(const oracle_dasp_t *d);
+double      oracle_dasp_rate_fill0(const oracle_dasp_t *d);
 oracle_dasp_t *oracle_dasp_new(void);
 
 /* FNV-1a 64 over an int array (fixture hashing) */

@@ -58,6 +58,8 @@ def lib():
         L.oracle_dasp_free.argtypes = [C.c_void_p]
         L.oracle_dasp_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_dasp_int.argtypes = [C.c_void_p, C.c_char_p]
+        L.oracle_dasp_data_X.argtypes = [C.c_void_p]; L.oracle_dasp_data_X.restype = C.c_longlong
+        L.oracle_dasp_rate_fill0.argtypes = [C.c_void_p]; L.oracle_dasp_rate_fill0.restype = C.c_double
         L.oracle_dasp_arr.argtypes = [C.c_void_p, C.c_char_p, ip]
         L.oracle_dasp_arr.restype = C.c_void_p
         L.oracle_fnv1a_i32.argtypes = [C.c_void_p, C.c_longlong]
@@ -238,6 +240,8 @@ class Packed:
             raise ValueError("oracle_dasp_pack rc=%d" % rc)
         for f in _INT_FIELDS:
             setattr(self, f, L.oracle_dasp_int(self._h, f.encode()))
+        self.data_X = int(L.oracle_dasp_data_X(self._h))
+        self.rate_fill0 = float(L.oracle_dasp_rate_fill0(self._h))
         for f, dt in _ARR_FIELDS.items():
             n = C.c_int()
             ptr = L.oracle_dasp_arr(self._h, f.encode(), C.byref(n))

@@ -198,7 +198,7 @@ def test_spmv_before_upload_is_an_error(dasp, torch_cuda):
 
 
 @pytest.mark.parametrize("exe,fixture", [("dasp_f64", "sym_real.mtx"), ("dasp_f16", "gen_real.mtx")])
-def test_cli_drivers(torch_cuda, exe, fixture, tmp_path):
+def test_cli_drivers(torch_cuda, oracle, exe, fixture, tmp_path):
     """spmv_double / spmv_half equivalents: load .mtx, all-ones, spmv_all, verify through order_rid; the CSV record is the
     reference's: spmv_all's partial row completed by the driver with the comparator columns and a newline (main_f64.cu:151-153,
     main_f16.cu:148-150), one row per run"""
@@ -216,6 +216,19 @@ def test_cli_drivers(torch_cuda, exe, fixture, tmp_path):
     for row in rows:
         assert row.startswith(os.path.join(ROOT, "tests", "golden", fixture) + ",")
         assert len(row.split(",")) == ncol and not row.endswith(",")
+    # the padded-size columns hold the REFERENCE's geometry (what the CUDA reference writes for this file: dasp_f64.h:1439-1441), i.e. the
+    # oracle's reference-geometry packer on the same CSR with the driver's all-ones values; the native sizes have a file of their own
+    prec = 64 if exe == "dasp_f64" else 16
+    rc, m, n, nnz, sym, rp, ci, v = oracle.mmio_allinone(os.path.join(ROOT, "tests", "golden", fixture))
+    assert rc == 0
+    P = oracle.Packed(prec, rp, ci, np.ones(ci.size), n)
+    c = rows[0].split(",")
+    assert [int(c[k]) for k in (1, 2, 3)] == [m, n, nnz]
+    assert [int(c[k]) for k in range(4, 18)] == [P.short_row_1, P.common_13, P.short_row_3, P.short_row_4, P.short_row_2, P.row_long, P.row_block,
+                                                  P.nnz_short, P.fill0_nnz_short, P.nnz_long, P.fill0_nnz_long, P.origin_nnz_reg, P.fill0_nnz_reg, P.nnz_irreg]
+    assert abs(float(c[18]) - P.rate_fill0) < 1e-6 and int(c[19]) == 256 and int(c[20]) == P.data_X
+    native = (tmp_path / "data" / ("dasp_amd_native_f%d.csv" % prec)).read_text().splitlines()
+    assert len(native) == 2 and len(native[0].split(",")) == 10
 
 
 @pytest.mark.parametrize("args", [("HV15R", "0.02", "64"), ("HV15R", "0.02", "16"), ("cop20k_A", "0.5", "64"), ("webbase-1M", "0.2", "16"),

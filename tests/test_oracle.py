@@ -192,6 +192,10 @@ def test_handworked_classifier_and_order(oracle, dasp, case, prec):
     st = plan.stats
     for k, val in want_c.items():
         assert st[k] == val, (k, "product")
+    # the product also reports the reference's padded sizes (dasp_stats_t::ref_*): the same hand-derived numbers
+    for k, val in h.get("packer_f%d" % prec, {}).items():
+        if not isinstance(val, list):
+            assert st["ref_" + k] == val, (k, "product, reference geometry")
     plan.close()
 
 

@@ -50,6 +50,28 @@ def test_native_format_decodes_to_csr(dasp, prec, tag, builder, m, n, seed, piec
     assert stored >= st["nnzA"] and abs(st["rate_fill0"] - (stored - st["nnzA"]) / max(st["nnzA"], 1)) < 1e-12
 
 
+REF_FIELDS = "fill0_nnz_short fill0_nnz_long fill0_nnz_reg nnz_irreg origin_nnz_reg blocknum warp_number data_X".split()
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("tag,builder,m,n,seed", CASES + [("pairs_big", util.pair_heavy_matrix, 70000, 5000, 13)])
+@pytest.mark.parametrize("opts", [{}, {"threshold": 0.5, "block_longest": 64}, {"x_window": 81920, "row_window": 128}, {"col_panels": 2}, {"slab_max_len": 12, "piece_min_len": 100}])
+def test_reference_geometry_stats_match_the_oracle(dasp, oracle, prec, tag, builder, m, n, seed, opts):
+    """dasp_stats_t::ref_* -- the padded sizes, rate_fill0 and data_X the CUDA reference computes for this input (8-row blocks, 8 x 4
+    tiles; dasp_f64.h:609-629,1000-1014,1044-1091,1159-1166 and their f16 counterparts) -- equal the oracle's reference-geometry packer
+    whatever native layout the plan itself chose (windows, column panels, slabs, pieces): they are what dasp_spmv_all_* writes into
+    the reference's CSV columns."""
+    dt = np.float64 if prec == 64 else np.float16
+    rp, ci, v = builder(m, n, seed, values="f16" if prec == 16 else "uniform", dtype=dt)
+    plan = dasp.Plan(rp, ci, v, n, precision=prec, **opts)
+    P = oracle.Packed(prec, rp, ci, v.astype(np.float64), n, threshold=opts.get("threshold", 0.75), block_longest=opts.get("block_longest", 256))
+    st = plan.stats
+    for f in REF_FIELDS:
+        assert st["ref_" + f] == getattr(P, f), f
+    assert abs(st["ref_rate_fill0"] - P.rate_fill0) < 1e-12
+    plan.close()
+
+
 def test_threshold_and_block_longest_change_the_split(dasp):
     rp, ci, v = util.mixed_matrix(2000, 1500, 9)
     a = dasp.Plan(rp, ci, v, 1500, threshold=0.75).stats
