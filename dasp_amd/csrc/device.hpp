@@ -49,7 +49,6 @@ struct DevArgs {
     int xcd_on;
     int xcd_blk[9];
     int ymode;        // DASP_EXPERIMENT builds only: how y is written (spmv_device.hpp put_y / medium_block)
-    int ylog_rows;    // ... mode 5: rows of y (the log's counters sit behind them)
     int med_stride;   // 1: the medium workgroups stride over the blocks (capped, persistent range); 0: exactly one block per wave
 };
 
@@ -101,9 +100,21 @@ bool mg_step_supported(const Plan &own, const Plan *other);
 // host: which own-column workgroups of the step kernel store a row with has_other[row] != 0 (natural-order plan, before the
 // host arrays are dropped).  mark gets one byte per workgroup of the plan's launch grid; blk_order the dispatch order of the medium
 // blocks that the marks assume (blocks holding such rows first).
-void mg_step_marks(const Plan &own, const unsigned char *has_other, std::vector<unsigned char> &mark, std::vector<int> &blk_order);
+void mg_step_marks(const Plan &own, const unsigned char *has_other, std::vector<unsigned char> &mark, std::vector<int> &blk_order, bool hot_first = true);
 int launch_mg_step(Plan &own, Plan *other, const void *x_own, const void *x_gathered, void *y, const MgStepCtl &c, void *stream);
 int mg_step_resident_per_cu();
+// the step on ONE stream (mgstep.hip dasp_mg_step2_kernel): ONE plan in the gather-buffer column layout; head workgroups send the previous
+// slice to the peers (push: mgx.hpp, n_dst may be 0), free workgroups run at once, a bounded set of persistent workgroups waits for every
+// peer's arrival flag and runs the workgroups holding boundary rows.  All pointers are device pointers.
+struct MgStep2Ctl {
+    const void *wg_list; const void *blk_order;      // device tables: [n_free + n_marked] virtual workgroups (free first), [medium blocks] dispatch order
+    int n_push, n_free, n_marked, max_pollers;
+    const void *arrived; int world, rank;            // this rank's arrival flags
+    unsigned long long need;                         // value the flags must reach (0: no wait)
+    void *err; long long timeout_ticks; int poll_sleep;
+};
+struct MgPushArgs;
+int launch_mg_step2(Plan &plan, const void *x, void *y, const MgStep2Ctl &c, const MgPushArgs &push, void *stream);
 int launch_mg_wait(const void *word, unsigned long long need, long long timeout_ticks, void *err, void *stream);
 int launch_mg_flag(void *word, unsigned long long value, void *stream);
 

@@ -248,7 +248,6 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate
     a.x = dX; a.y = dY; a.acc = accumulate ? 1 : 0;
 #ifdef DASP_EXPERIMENT
     if (const char *e = std::getenv("DASP_YSTORE")) a.ymode = std::atoi(e);
-    a.ylog_rows = p.m / 128 * 128;
 #endif
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.precision == 64 ? launch_typed<double>(p, a, s) : launch_typed<_Float16>(p, a, s);

@@ -3,10 +3,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
 #include "spmv_device.hpp"
+#include "mgx_device.hpp"
 
 namespace dasp {
 
@@ -126,6 +128,70 @@ __global__ void dasp_mg_flag_kernel(unsigned long long *p, unsigned long long v)
     if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ------------------------------------------------------------------ the step on ONE stream (r4: dasp_mg_step2_kernel)
+// The rank's slice is ONE plan whose column ids index the gather buffer (every rank's slice of x in equal padded slots).  One launch per
+// iteration and nothing else, on the caller's stream only:
+//   head workgroups       send the slice the PREVIOUS launch produced (this rank's own slot of the half of the gather buffer that holds
+//                         x) into every peer's gather buffer -- direct stores through peer mappings, then the peers' arrival flags
+//                         (mg_push_part).  The exchange of step k therefore runs under the product of step k + 1 without a
+//                         communication stream, a kernel of its own, or any word the product would have to publish;
+//   free workgroups       every workgroup of the plan whose rows read this rank's own columns only, in the plan's order;
+//   persistent workgroups (a bounded number, last in the grid) wait for the arrival flags of ALL peers and then stride over the
+//                         workgroups whose rows read other ranks' columns ("boundary rows": the host puts those blocks LAST in the
+//                         dispatch order, so that their turn comes when the peers' slices have long arrived).
+// y goes into this rank's slot of the OTHER half of the gather buffer: it is the next launch's x as it stands.  Every row is computed
+// once, by one workgroup, from one plan: no second product, no y +=, no counters, no write-through stores (compare dasp_mg_step_kernel:
+// its other-column product was a serial tail of ~10 us behind the own-column product, profiles/r04_multi_gpu_step.md).
+// Because every launch waits for all peers' slices of the previous step, no rank can run two steps ahead of another: a peer's stores of
+// step k + 1 go to the half this rank reads in step k + 2, never to the half it is reading.
+struct Step2Ctl {
+    const int *wg_list;                     // [n_free + n_marked] virtual workgroups of the plan: free ones first, boundary ones last
+    const int *blk_order;                   // [medium blocks] dispatch order: blocks with boundary rows last
+    int n_push, n_free, n_marked, n_poll;
+    const unsigned long long *arrived;      // [world] this rank's arrival flags (fine-grained memory, written by the peers)
+    int world, rank;
+    unsigned long long need;                // the flags must reach this value (0: x was put in place by the host, nothing to wait for)
+    int *err; long long timeout; int sleep;
+};
+
+template <bool NT>
+__global__ __launch_bounds__(256, kMinWavesPlain) void dasp_mg_step2_kernel(DevArgs a, MgPushArgs push, Step2Ctl c)
+{
+    __shared__ int go;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int wg = blockIdx.x;
+    if (wg < c.n_push) { mg_push_part(push, wg, c.n_push); return; }
+    wg -= c.n_push;
+    if (wg < c.n_free) { plain_wg<double, NT, true, true, 3>(a, tab<true>(c.wg_list, wg), wave, lane, c.blk_order); return; }
+    wg -= c.n_free;
+    if (wave == 0) {
+        bool late = false;
+        if (c.need) {
+            const long long t0 = wall_clock64();
+            for (int r0 = 0; r0 < c.world && !late; r0 += 64) {
+                const int r = r0 + lane;
+                for (;;) {       // relaxed polls; ONE acquire below
+                    const bool ok = r >= c.world || r == c.rank || __hip_atomic_load(c.arrived + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= c.need;
+                    if (__all(ok)) break;
+                    for (int z = 0; z < c.sleep; ++z) __builtin_amdgcn_s_sleep(8);
+                    if (wall_clock64() - t0 > c.timeout) { late = true; break; }
+                }
+            }
+        }
+        // the peers' slices were stored by other devices while this kernel ran
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            if (late) __hip_atomic_store(c.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            go = late ? 0 : 1;
+        }
+    }
+    __syncthreads();
+    if (go)
+        for (int v = wg; v < c.n_marked; v += c.n_poll) plain_wg<double, NT, true, true, 3>(a, tab<true>(c.wg_list, c.n_free + v), wave, lane, c.blk_order);
+}
+
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
@@ -134,52 +200,6 @@ __global__ void dasp_mg_flag_kernel(unsigned long long *p, unsigned long long v)
             return e_ == hipErrorNoDevice ? DASP_ERR_NO_DEVICE : DASP_ERR_HIP;                 \
         }                                                                                      \
     } while (0)
-
-// ---- fused multi-GPU step (multigpu.cpp).  Which plans qualify: f64, uploaded, no x windows, no column panels, 16-bit ids (the one
-// instantiation of the step kernel), no long row cut into several pieces (their stage 2 would run behind the launch that publishes
-// "y ready").  `other` may be null (no nonzero outside the rank's own columns).
-bool mg_step_supported(const Plan &own, const Plan *other)
-{
-    auto ok = [](const Plan &p) {
-        // 16-bit ids -- or no MFMA block at all (every medium row stored as a slab: nothing reads the id planes)
-        return p.precision == 64 && p.dev && p.dev->arena && p.panels.empty() && !p.windowed && (p.cid16 || p.stats.n_med_blocks == 0) && p.dev->args.n_multi == 0;
-    };
-    return ok(own) && (!other || ok(*other));
-}
-
-void mg_step_marks(const Plan &p, const unsigned char *has_other, std::vector<unsigned char> &mark, std::vector<int> &blk_order)
-{
-    // the launch grid of upload_plan / dasp_mg_step_kernel: [ long pieces | medium blocks through blk_order | short tiles ], 4 units per workgroup
-    const int n_pieces = (int)p.piece_dst.size(), n_blocks = p.stats.n_med_blocks, n_tiles = p.stats.n_short_tiles;
-    const int wg_long = (n_pieces + kWavesPerWG - 1) / kWavesPerWG, wg_med = (n_blocks + kWavesPerWG - 1) / kWavesPerWG,
-              wg_short = (n_tiles + kWavesPerWG - 1) / kWavesPerWG;
-    mark.assign((size_t)wg_long + wg_med + wg_short, 0);
-    for (int q = 0; q < n_pieces; ++q) {
-        const int dst = p.piece_dst[(size_t)q];
-        if (dst >= 0 && has_other[dst]) mark[(size_t)q / kWavesPerWG] = 1;
-    }
-    // medium blocks holding a row the other-column plan adds to go first, everything else keeps the stored (longest-first) order
-    std::vector<unsigned char> hot((size_t)n_blocks, 0);
-    for (int b = 0; b < n_blocks; ++b)
-        for (int i = 0; i < kMedRows && b * kMedRows + i < p.n_mfma_rows; ++i)
-            if (has_other[p.order[(size_t)p.med_slot0 + (size_t)b * kMedRows + i]]) { hot[(size_t)b] = 1; break; }
-    blk_order.clear(); blk_order.reserve((size_t)n_blocks);
-    for (int b = 0; b < n_blocks; ++b) if (hot[(size_t)b]) blk_order.push_back(b);
-    const int n_hot = (int)blk_order.size();
-    for (int b = 0; b < n_blocks; ++b) if (!hot[(size_t)b]) blk_order.push_back(b);
-    for (int q = 0; q < n_hot; ++q) mark[(size_t)wg_long + q / kWavesPerWG] = 1;
-    const int SR = p.geo.short_rows;
-    for (int g = 0; g < kNumShortGroups; ++g) {
-        const ShortGroup &G = p.grp[g];
-        for (int lt = 0; lt < G.tiles; ++lt) {
-            const int t = G.tile0 + lt;
-            for (int tt = lt * SR; tt < std::min(G.count, (lt + 1) * SR); ++tt) {
-                const int slot = g < 5 ? G.map.slot(tt) : G.map.base[0] + tt;      // short_rows / slab_rows
-                if (has_other[p.order[(size_t)slot]]) { mark[(size_t)wg_long + wg_med + t / kWavesPerWG] = 1; break; }
-            }
-        }
-    }
-}
 
 int launch_mg_step(Plan &own, Plan *other, const void *x_own, const void *x_gathered, void *y, const MgStepCtl &h, void *stream)
 {
@@ -223,8 +243,11 @@ int mg_step_resident_per_cu()
     int a = 0, b = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, reinterpret_cast<const void *>(&dasp_mg_step_kernel<true>), 256, 0) != hipSuccess) a = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, reinterpret_cast<const void *>(&dasp_mg_step_kernel<false>), 256, 0) != hipSuccess) b = 0;
+    int c2 = 0, d2 = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&c2, reinterpret_cast<const void *>(&dasp_mg_step2_kernel<true>), 256, 0) != hipSuccess) c2 = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&d2, reinterpret_cast<const void *>(&dasp_mg_step2_kernel<false>), 256, 0) != hipSuccess) d2 = 0;
     (void)hipGetLastError();
-    return std::min(a, b);
+    return std::min(std::min(a, b), std::min(c2, d2));
 }
 
 int launch_mg_wait(const void *word, unsigned long long need, long long timeout_ticks, void *err, void *stream)
@@ -238,6 +261,30 @@ int launch_mg_wait(const void *word, unsigned long long need, long long timeout_
 int launch_mg_flag(void *word, unsigned long long value, void *stream)
 {
     hipLaunchKernelGGL(dasp_mg_flag_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<unsigned long long *>(word), value);
+    HIP_TRY(hipGetLastError());
+    return DASP_OK;
+}
+
+int launch_mg_step2(Plan &plan, const void *x, void *y, const MgStep2Ctl &h, const MgPushArgs &push, void *stream)
+{
+    if (!mg_step_supported(plan, nullptr)) { set_error("plan does not qualify for the one-stream multi-GPU step"); return DASP_ERR_STATE; }
+    DevArgs a = plan.dev->args;
+    a.x = x; a.y = y; a.acc = 0;
+    a.wg_med = (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG; a.xcd_on = 0;      // one medium block per wave through the order table (mg_step_marks assumes it)
+    Step2Ctl c{};
+    c.wg_list = static_cast<const int *>(h.wg_list); c.blk_order = static_cast<const int *>(h.blk_order);
+    c.n_push = h.n_push; c.n_free = h.n_free; c.n_marked = h.n_marked;
+    c.n_poll = std::max(1, std::min(h.n_marked, std::max(1, h.max_pollers)));      // at least one: it is also what holds the launch until every peer's slice is in
+    c.arrived = static_cast<const unsigned long long *>(h.arrived); c.world = h.world; c.rank = h.rank; c.need = h.need;
+    c.err = static_cast<int *>(h.err); c.timeout = h.timeout_ticks; c.sleep = std::max(1, h.poll_sleep);
+#ifdef DASP_EXPERIMENT      // breakdown of the one-stream step (tools/mg_step_probe.py): without the head workgroups' stores / without the wait
+    if (const char *e = std::getenv("DASP_MG_STEP2_NOPUSH")) if (std::atoi(e)) { c.n_push = 0; c.need = 0; }
+#endif
+    if (c.n_free + c.n_marked != a.wg_long + a.wg_med + a.wg_short) { set_error("one-stream step: the workgroup list does not match the plan's grid"); return DASP_ERR_STATE; }
+    const int grid = c.n_push + c.n_free + c.n_poll;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (plan.dev->nt) hipLaunchKernelGGL((dasp_mg_step2_kernel<true>), dim3(grid), dim3(256), 0, s, a, push, c);
+    else hipLaunchKernelGGL((dasp_mg_step2_kernel<false>), dim3(grid), dim3(256), 0, s, a, push, c);
     HIP_TRY(hipGetLastError());
     return DASP_OK;
 }

@@ -26,6 +26,6 @@ struct MgPushArgs {
 int launch_mg_push(const MgPushArgs &a, void *stream);
 // one wave waits for arrived[0..world) >= seq, then (gathered != nullptr) *gathered = step
 int launch_mg_arrived(const void *arrived, int world, unsigned long long seq, void *gathered, unsigned long long step, long long timeout_ticks,
-                      void *err, void *stream);
+                      void *err, void *stream, int skip = -1);      // skip: a rank whose flag is not waited for (the one-stream step: this rank itself)
 
 }  // namespace dasp

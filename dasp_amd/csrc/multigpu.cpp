@@ -106,9 +106,65 @@ int rccl_fail(const char *what, ncclResult_t r)
 
 }  // namespace
 
+namespace dasp {
+// ---- fused multi-GPU step (multigpu.cpp).  Which plans qualify: f64, uploaded, no x windows, no column panels, 16-bit ids (the one
+// instantiation of the step kernel), no long row cut into several pieces (their stage 2 would run behind the launch that publishes
+// "y ready").  `other` may be null (no nonzero outside the rank's own columns).
+bool mg_step_supported(const Plan &own, const Plan *other)
+{
+    auto ok = [](const Plan &p) {
+        // 16-bit ids -- or no MFMA block at all (every medium row stored as a slab: nothing reads the id planes)
+        return p.precision == 64 && p.dev && p.dev->arena && p.panels.empty() && !p.windowed && (p.cid16 || p.stats.n_med_blocks == 0) && p.dev->args.n_multi == 0;
+    };
+    return ok(own) && (!other || ok(*other));
+}
+
+void mg_step_marks(const Plan &p, const unsigned char *has_other, std::vector<unsigned char> &mark, std::vector<int> &blk_order, bool hot_first)
+{
+    // the launch grid of upload_plan / dasp_mg_step_kernel: [ long pieces | medium blocks through blk_order | short tiles ], 4 units per workgroup
+    const int n_pieces = (int)p.piece_dst.size(), n_blocks = p.stats.n_med_blocks, n_tiles = p.stats.n_short_tiles;
+    const int wg_long = (n_pieces + kWavesPerWG - 1) / kWavesPerWG, wg_med = (n_blocks + kWavesPerWG - 1) / kWavesPerWG,
+              wg_short = (n_tiles + kWavesPerWG - 1) / kWavesPerWG;
+    mark.assign((size_t)wg_long + wg_med + wg_short, 0);
+    for (int q = 0; q < n_pieces; ++q) {
+        const int dst = p.piece_dst[(size_t)q];
+        if (dst >= 0 && has_other[dst]) mark[(size_t)q / kWavesPerWG] = 1;
+    }
+    // medium blocks holding a row the other-column plan adds to go first, everything else keeps the stored (longest-first) order
+    std::vector<unsigned char> hot((size_t)n_blocks, 0);
+    for (int b = 0; b < n_blocks; ++b)
+        for (int i = 0; i < kMedRows && b * kMedRows + i < p.n_mfma_rows; ++i)
+            if (has_other[p.order[(size_t)p.med_slot0 + (size_t)b * kMedRows + i]]) { hot[(size_t)b] = 1; break; }
+    blk_order.clear(); blk_order.reserve((size_t)n_blocks);
+    int n_hot = 0;
+    for (int b = 0; b < n_blocks; ++b) n_hot += hot[(size_t)b];
+    if (hot_first) {
+        for (int b = 0; b < n_blocks; ++b) if (hot[(size_t)b]) blk_order.push_back(b);
+        for (int b = 0; b < n_blocks; ++b) if (!hot[(size_t)b]) blk_order.push_back(b);
+        for (int q = 0; q < n_hot; ++q) mark[(size_t)wg_long + q / kWavesPerWG] = 1;
+    } else {      // the one-stream step: boundary blocks LAST (they wait for the peers' slices)
+        for (int b = 0; b < n_blocks; ++b) if (!hot[(size_t)b]) blk_order.push_back(b);
+        for (int b = 0; b < n_blocks; ++b) if (hot[(size_t)b]) blk_order.push_back(b);
+        for (int q = n_blocks - n_hot; q < n_blocks; ++q) mark[(size_t)wg_long + q / kWavesPerWG] = 1;
+    }
+    const int SR = p.geo.short_rows;
+    for (int g = 0; g < kNumShortGroups; ++g) {
+        const ShortGroup &G = p.grp[g];
+        for (int lt = 0; lt < G.tiles; ++lt) {
+            const int t = G.tile0 + lt;
+            for (int tt = lt * SR; tt < std::min(G.count, (lt + 1) * SR); ++tt) {
+                const int slot = g < 5 ? G.map.slot(tt) : G.map.base[0] + tt;      // short_rows / slab_rows
+                if (has_other[p.order[(size_t)slot]]) { mark[(size_t)wg_long + wg_med + t / kWavesPerWG] = 1; break; }
+            }
+        }
+    }
+}
+}  // namespace dasp
+
 struct dasp_mg_plan {
     int precision = 64, world = 1, rank = 0, rowA = 0, colA = 0, stride = 0;
     bool square = false, overlap = false, uploaded = false;
+    bool step2 = false;                // overlap mode 2: ONE plan in the gather-buffer layout, boundary rows last -- the step on one stream (mgstep.hip)
     std::vector<int> bounds;
     long long nnz_own = 0, nnz_other = 0;
     dasp_plan_t *own = nullptr;        // own columns (x = this rank's padded slice) -- or the whole slice when there is no split
@@ -175,6 +231,14 @@ struct dasp_mg_plan {
     uint64_t epoch = 0;                // dasp_mg_set_x / connect count: what this rank last published to its peers' epoch_of[rank]
     bool peers_pending = false;        // the peers have not been seen at `epoch` yet (checked before the next exchange is queued)
     int push_wgs = 256;                // workgroups of the push kernel (DASP_MG_PUSH_WGS)
+    // one-stream step (step2): the plan's virtual workgroups, those without boundary rows first; products since dasp_mg_set_x (x_k2 lives in
+    // half k2 & 1 of the gather buffer, this rank's y_k2 in its own slot there); the newest slice already sent to the peers
+    std::vector<int> wg_list;
+    int n_free2 = 0, n_marked2 = 0;
+    void *d_wg_list = nullptr;
+    void *d_push_dst2 = nullptr;       // device: MgPushDst[2][world - 1], the peers only (this rank's slot is written by its own product)
+    void *d_push_count2 = nullptr;
+    uint64_t k2 = 0, pushed_upto = 0;
     int fake_us = -1;
     int fake_channels = 0;             // > 0: the stand-in kernel has the footprint of RCCL's (devpack.hip k_spin_fat), that many workgroups
     std::vector<void *> fake_peers;
@@ -183,7 +247,8 @@ struct dasp_mg_plan {
     size_t vb() const { return precision == 64 ? 8 : 2; }
     size_t all_bytes() const { return (size_t)stride * vb() * (size_t)world; }
     // the half of the gather buffer the last exchange filled (push mode; RCCL and the test hook use half 0 only)
-    char *gcur() const { return static_cast<char *>(yg) + (push ? (size_t)(xseq & 1) * all_bytes() : 0); }
+    bool one_stream() const { return step2 && fused && push; }
+    char *gcur() const { return static_cast<char *>(yg) + (one_stream() ? (size_t)(k2 & 1) * all_bytes() : push ? (size_t)(xseq & 1) * all_bytes() : 0); }
     int rows() const { return bounds[(size_t)rank + 1] - bounds[(size_t)rank]; }
     ~dasp_mg_plan()
     {
@@ -193,7 +258,7 @@ struct dasp_mg_plan {
         if (comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(comm);
         for (size_t r = 0; r < peer_opened.size(); ++r)
             if (peer_opened[r]) { if (peer_gather[r]) (void)hipIpcCloseMemHandle(peer_gather[r]); if (peer_flags[r]) (void)hipIpcCloseMemHandle(peer_flags[r]); }
-        for (void *p : {xflags, d_push_dst, d_push_count, push_scratch}) if (p) (void)hipFree(p);
+        for (void *p : {xflags, d_push_dst, d_push_count, push_scratch, d_wg_list, d_push_dst2, d_push_count2}) if (p) (void)hipFree(p);
         if (ev_y) (void)hipEventDestroy(ev_y);
         if (ev_g) (void)hipEventDestroy(ev_g);
         for (hipEvent_t e : ev_x) if (e) (void)hipEventDestroy(e);
@@ -270,6 +335,28 @@ int create_impl(dasp_mg_plan &g, const int *rp, const int *ci, const T *val, con
     if (!g.overlap) {
         g.nnz_own = nnz; g.nnz_other = 0;
         return dasp_plan_create(&g.own, g.precision, m, g.colA, nnz, rp, ci, val, &part);
+    }
+    if (g.step2) {
+        // ONE plan over all columns in the gather-buffer layout; which rows read another rank's columns decides the dispatch order only
+        std::vector<unsigned char> has((size_t)std::max(m, 1), 0);
+        long long other = 0;
+        for (int i = 0; i < m; ++i) {
+            int o = 0;
+            for (int j = rp[i]; j < rp[i + 1]; ++j) o += !(ci[j] >= lo && ci[j] < hi);
+            has[(size_t)i] = o > 0; other += o;
+        }
+        g.nnz_own = nnz - other; g.nnz_other = other;
+        if (int rc = dasp_plan_create(&g.own, g.precision, m, g.colA, nnz, rp, ci, val, &part)) return rc;
+        const Plan &P = g.own->impl;
+        if (g.precision == 64 && P.panels.empty() && !P.windowed && P.opt.y_order == DASP_Y_NATURAL) {
+            mg_step_marks(P, has.data(), g.mark, g.blk_order, false);
+            g.wg_list.clear(); g.wg_list.reserve(g.mark.size());
+            for (size_t w = 0; w < g.mark.size(); ++w) if (!g.mark[w]) g.wg_list.push_back((int)w);
+            g.n_free2 = (int)g.wg_list.size();
+            for (size_t w = 0; w < g.mark.size(); ++w) if (g.mark[w]) g.wg_list.push_back((int)w);
+            g.n_marked2 = (int)g.wg_list.size() - g.n_free2;
+        }
+        return DASP_OK;
     }
     std::vector<int> rpO, ciO, rpR, ciR;
     std::vector<T> vO, vR;
@@ -355,12 +442,37 @@ void forget_exchange_events(dasp_mg_plan &g) { for (uint64_t &k : g.ev_x_step) k
 // not start while workgroups wait for them -- such a call runs the two-launch form instead of timing out
 bool fuse_on(const dasp_mg_plan &g, hipStream_t s)
 {
+    if (g.step2) return g.one_stream();
     return g.fused && (g.push || !g.comm || g.world == 1 || (g.rs && s == g.rs));
 }
 
 int product(dasp_mg_plan &g, hipStream_t s)
 {
     const int cur = g.cur, nxt = (g.cur + 1) % 3;
+    if (g.one_stream()) {
+        // ONE launch, on this stream only: head workgroups send y_k2 (this rank's slot of the half that holds x) to the peers, the plan's
+        // workgroups compute y_{k2+1} into this rank's slot of the other half, those with boundary rows behind the peers' arrival flags
+        const size_t sl = (size_t)g.stride * g.vb();
+        const bool send = g.world > 1 && g.k2 >= 1 && g.pushed_upto < g.k2;
+        MgPushArgs pa{};
+        if (send) {
+            pa.src = g.gcur() + (size_t)g.rank * sl; pa.bytes = sl;
+            pa.dst = static_cast<const MgPushDst *>(g.d_push_dst2) + (size_t)(g.k2 & 1) * (size_t)(g.world - 1);
+            pa.n_dst = g.world - 1; pa.count = static_cast<unsigned *>(g.d_push_count2); pa.wgs = g.push_wgs;
+            pa.seq = (g.epoch << 32) + g.k2; pa.timeout = g.timeout_ticks; pa.err = g.err_word;
+            g.pushed_upto = g.k2;
+        }
+        MgStep2Ctl c{};
+        c.wg_list = g.d_wg_list; c.blk_order = g.d_blk_order; c.n_push = send ? g.push_wgs : 0; c.n_free = g.n_free2; c.n_marked = g.n_marked2;
+        c.max_pollers = g.max_pollers_thin; c.arrived = g.xflags; c.world = g.world; c.rank = g.rank;
+        c.need = g.world > 1 && g.k2 >= 1 ? (g.epoch << 32) + g.k2 : 0;
+        c.err = g.err_word; c.timeout_ticks = g.timeout_ticks; c.poll_sleep = g.poll_sleep;
+        char *xin = g.gcur();
+        char *yout = static_cast<char *>(g.yg) + (size_t)((g.k2 + 1) & 1) * g.all_bytes() + (size_t)g.rank * sl;
+        if (int rc = launch_mg_step2(g.own->impl, xin, yout, c, pa, s)) return rc;
+        ++g.k2; ++g.step;
+        return DASP_OK;
+    }
     if (fuse_on(g, s)) {
         if (!g.other && g.world > 1) {
             // no other-column plan: the step kernel has no waiting workgroups, i.e. nothing that orders this stream behind the exchange, while
@@ -377,7 +489,7 @@ int product(dasp_mg_plan &g, hipStream_t s)
         c.n_marked = g.n_marked; c.n_mark_shards = g.n_mark_shards; c.blk_order = g.d_blk_order;
         c.max_pollers = g.push ? g.max_pollers_thin : g.max_pollers; c.timeout_ticks = g.timeout_ticks; c.poll_sleep = g.poll_sleep;
         if (int rc = launch_mg_step(g.own->impl, g.other ? &g.other->impl : nullptr, g.ys[cur], g.gcur(), g.ys[nxt], c, s)) return rc;
-    } else if (g.overlap) {
+    } else if (g.overlap && !g.step2) {
         // own columns: needs only this rank's slice of x, i.e. its own previous y -- no communication
         if (int rc = dasp_plan_spmv(g.own, g.ys[cur], g.ys[nxt], s)) return rc;
         if (int rc = wait_gathered(g, s)) return rc;                                         // the other ranks' x has arrived
@@ -451,9 +563,27 @@ int push_exchange(dasp_mg_plan &g, hipStream_t q, uint64_t ready_need, bool set_
     return launch_mg_arrived(g.xflags, g.world, seq, set_gathered ? g.words + kMgWordGathered : nullptr, step, g.timeout_ticks, g.err_word, q);
 }
 
+// one-stream step: the newest slice travels with the NEXT product; who wants the gathered y before that (dasp_mg_wait, dasp_mg_get_y) sends it
+// here -- the exchange as kernels of its own on stream q: stores + flags, then one wave that waits for every peer's flag
+int flush_step2(dasp_mg_plan &g, hipStream_t q, bool force)
+{
+    if (!g.one_stream() || g.world <= 1 || g.k2 < 1 || (!force && g.pushed_upto >= g.k2)) return DASP_OK;
+    if (int rc = push_wait_peers(g)) return rc;
+    const size_t sl = (size_t)g.stride * g.vb();
+    MgPushArgs a{};
+    a.src = g.gcur() + (size_t)g.rank * sl; a.bytes = sl;
+    a.dst = static_cast<const MgPushDst *>(g.d_push_dst2) + (size_t)(g.k2 & 1) * (size_t)(g.world - 1);
+    a.n_dst = g.world - 1; a.count = static_cast<unsigned *>(g.d_push_count2); a.wgs = g.push_wgs;
+    a.seq = (g.epoch << 32) + g.k2; a.timeout = g.timeout_ticks; a.err = g.err_word;
+    if (int rc = launch_mg_push(a, q)) return rc;
+    g.pushed_upto = g.k2;
+    return launch_mg_arrived(g.xflags, g.world, a.seq, nullptr, 0, g.timeout_ticks, g.err_word, q, g.rank);
+}
+
 // the slice ys[cur] -> every rank's gather buffer on stream q (direct stores; RCCL; one rank or the test hook: local copies)
 int exchange(dasp_mg_plan &g, hipStream_t q)
 {
+    if (g.one_stream()) return flush_step2(g, q, true);
     if (g.push) return push_exchange(g, q, 0, false, 0);
     if (g.comm) {
         const ncclResult_t r = rccl()->AllGather(g.ys[g.cur], g.yg, (size_t)g.stride, g.precision == 64 ? ncclFloat64 : ncclFloat16, g.comm, q);
@@ -502,6 +632,14 @@ int push_enable(dasp_mg_plan &g)
     if (!g.d_push_dst) MG_HIP(hipMalloc(&g.d_push_dst, tab.size() * sizeof(MgPushDst)));
     MG_HIP(hipMemcpy(g.d_push_dst, tab.data(), tab.size() * sizeof(MgPushDst), hipMemcpyHostToDevice));
     if (!g.d_push_count) { MG_HIP(hipMalloc(&g.d_push_count, (size_t)g.world * sizeof(unsigned))); MG_HIP(hipMemset(g.d_push_count, 0, (size_t)g.world * sizeof(unsigned))); }
+    if (g.step2 && g.world > 1) {      // the one-stream step sends to the peers only
+        std::vector<MgPushDst> t2;
+        for (int half = 0; half < 2; ++half)
+            for (int r = 0; r < g.world; ++r) if (r != g.rank) t2.push_back(tab[(size_t)half * g.world + r]);
+        if (!g.d_push_dst2) MG_HIP(hipMalloc(&g.d_push_dst2, t2.size() * sizeof(MgPushDst)));
+        MG_HIP(hipMemcpy(g.d_push_dst2, t2.data(), t2.size() * sizeof(MgPushDst), hipMemcpyHostToDevice));
+        if (!g.d_push_count2) { MG_HIP(hipMalloc(&g.d_push_count2, (size_t)g.world * sizeof(unsigned))); MG_HIP(hipMemset(g.d_push_count2, 0, (size_t)g.world * sizeof(unsigned))); }
+    }
     if (!g.words) {        // plans that do not qualify for the fused step still need the error word
         void *p = nullptr;
         MG_HIP(hipMalloc(&p, kMgWordBytes));
@@ -517,7 +655,7 @@ int push_enable(dasp_mg_plan &g)
     }
     // the current x is in half 0 (RCCL and the test hook use no other), where exchange count 0 looks for it
     MG_HIP(hipDeviceSynchronize());
-    g.xseq = 0;
+    g.xseq = 0; g.k2 = 0; g.pushed_upto = 0;
     g.push = true;
     g.pending = false; g.pending_sig = false; g.pending_lazy = false; g.gathered_step = 0;
     forget_exchange_events(g);
@@ -536,8 +674,8 @@ int set_exchange(dasp_mg_plan &g, int mode)
         return push_enable(g);
     }
     const size_t all = g.all_bytes();
-    if (g.xseq & 1) { MG_HIP(hipMemcpy(g.yg, static_cast<char *>(g.yg) + all, all, hipMemcpyDeviceToDevice)); MG_HIP(hipDeviceSynchronize()); }
-    g.push = false; g.xseq = 0;
+    if (g.gcur() != static_cast<char *>(g.yg)) { MG_HIP(hipMemcpy(g.yg, static_cast<char *>(g.yg) + all, all, hipMemcpyDeviceToDevice)); MG_HIP(hipDeviceSynchronize()); }
+    g.push = false; g.xseq = 0; g.k2 = 0; g.pushed_upto = 0;
     return DASP_OK;
 }
 
@@ -579,6 +717,7 @@ int dasp_mg_plan_create(dasp_mg_plan_t **out, int precision, int rowA, int colA,
         if ((long long)g->stride * n_gpus >= (1ll << 31)) { set_error("gathered vector exceeds 2^31 elements"); return DASP_ERR_ARG; }
         g->square = rowA == colA;
         g->overlap = g->square && overlap != 0 && n_gpus > 1;
+        g->step2 = g->overlap && overlap == 2;
         const int m = g->rows();
         const int nnz = csrRowPtr[m];
         if (csrRowPtr[0] != 0 || nnz < 0 || (nnz > 0 && (!csrColIdx || !csrVal))) { set_error("dasp_mg_plan_create: bad local CSR"); return DASP_ERR_ARG; }
@@ -617,7 +756,7 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
         for (int k = 0; k < 3; ++k) g.ys[k] = static_cast<char *>(base) + (size_t)k * sl_pad;
     }
     // ... and the own-column plan's placement trials once more against these slices (dasp_plan_upload ran them with scratch operands)
-    if (g.overlap) if (int rc = dasp_plan_tune_placement(g.own, 0, g.ys[0], g.ys[1], nullptr, nullptr)) return rc;
+    if (g.overlap && !g.step2) if (int rc = dasp_plan_tune_placement(g.own, 0, g.ys[0], g.ys[1], nullptr, nullptr)) return rc;
     {   // the gather buffer is written by the exchange -- this device's RCCL kernel or, over xGMI, a peer's stores -- WHILE the fused step's
         // kernel is already running and about to read it behind an in-kernel acquire.  Coarse-grained memory only promises visibility at
         // kernel boundaries; fine-grained memory is what the HSA memory model defines in-kernel cross-agent acquire / release on, so the
@@ -674,7 +813,8 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
         const char *e = std::getenv("DASP_MG_FUSED");
         const bool want = !(e && std::strcmp(e, "0") == 0);
         // (in-kernel acquire of data another agent / kernel writes meanwhile: fine-grained memory, or the caller's explicit A/B choice)
-        if (want && (g.gather_fine || g.gather_coarse_asked || g.world == 1) && g.overlap && mg_step_supported(g.own->impl, g.other ? &g.other->impl : nullptr) && (!g.other || (int)g.mark.size() == g.own->impl.stats.n_workgroups)) {
+        if (want && (g.gather_fine || g.gather_coarse_asked || g.world == 1) && g.overlap && mg_step_supported(g.own->impl, g.other ? &g.other->impl : nullptr) &&
+            (g.step2 ? (int)g.wg_list.size() == g.own->impl.stats.n_workgroups : (!g.other || (int)g.mark.size() == g.own->impl.stats.n_workgroups))) {
             void *p = nullptr;
             MG_HIP(hipMalloc(&p, kMgWordBytes));
             MG_HIP(hipMemset(p, 0, kMgWordBytes));
@@ -682,9 +822,13 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
             const size_t mb = (g.mark.size() + 255) & ~size_t(255);
             MG_HIP(hipMalloc(&g.d_mark, mb + 256));
             MG_HIP(hipMemset(g.d_mark, 0, mb + 256));
-            if (!g.mark.empty()) {
+            if (!g.mark.empty() && !g.step2) {      // (the one-stream step has its workgroup list instead)
                 MG_HIP(hipMemcpy(g.d_mark, g.mark.data(), g.mark.size(), hipMemcpyHostToDevice));
                 MG_HIP(hipMemcpy(static_cast<char *>(g.d_mark) + mb, g.mark_members.data(), 64 * sizeof(unsigned), hipMemcpyHostToDevice));
+            }
+            if (g.step2) {
+                MG_HIP(hipMalloc(&g.d_wg_list, std::max<size_t>(g.wg_list.size(), 1) * sizeof(int)));
+                if (!g.wg_list.empty()) MG_HIP(hipMemcpy(g.d_wg_list, g.wg_list.data(), g.wg_list.size() * sizeof(int), hipMemcpyHostToDevice));
             }
             if (!g.blk_order.empty()) {
                 MG_HIP(hipMalloc(&g.d_blk_order, g.blk_order.size() * sizeof(int)));
@@ -704,6 +848,12 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
             if (const char *q = std::getenv("DASP_MG_POLL_PER_CU")) per_cu = std::max(1, std::atoi(q));
             g.max_pollers = cus * per_cu;
             g.max_pollers_thin = std::getenv("DASP_MG_POLL_PER_CU") ? g.max_pollers : cus * std::max(1, std::min(4, resident - 1));      // 1 / 2 / 4 per CU: 76 / 75 / 74 us per step
+            // several ranks on ONE device (tests, a bench on a box with fewer GPUs than ranks): their waiting workgroups add up, and together
+            // they must never fill a CU -- the peer they wait for runs on the same CUs
+            if (const char *q = std::getenv("DASP_MG_SHARED_DEVICE_RANKS")) {
+                const int n = std::max(1, std::atoi(q));
+                g.max_pollers = std::max(1, g.max_pollers / n); g.max_pollers_thin = std::max(1, g.max_pollers_thin / n);
+            }
             if (const char *q = std::getenv("DASP_MG_POLL_SLEEP")) g.poll_sleep = std::max(1, std::atoi(q));
         }
     }
@@ -738,6 +888,7 @@ int dasp_mg_set_x(dasp_mg_plan_t *mg, const void *x_host)
     MG_HIP(hipDeviceSynchronize());
     g.pending = false; g.pending_sig = false; g.pending_lazy = false; g.gathered_step = 0;
     forget_exchange_events(g);
+    g.k2 = 0; g.pushed_upto = 0;
     g.xseq = 0;                             // direct exchange: x goes to half 0, the next exchange fills half 1 -- on every rank alike
     if (!g.square) { MG_HIP(hipMemcpy(g.xg, x, (size_t)g.colA * vb, hipMemcpyHostToDevice)); return g.push ? push_arrive(g) : DASP_OK; }
     try {
@@ -767,6 +918,7 @@ int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream)
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (int rc = sticky_error(g)) return rc;             // a wait timed out earlier: no more work on top of invalid data
     if (g.push) if (int rc = push_wait_peers(g)) return rc;
+    if (g.one_stream()) return product(g, s);      // the exchange of this step rides at the head of the next launch (or of dasp_mg_wait)
     if (int rc = product(g, s)) return rc;
     // y (this rank's padded slice) -> every rank's gather buffer, on the communication stream, behind the products
     const uint64_t k = g.step;
@@ -809,6 +961,7 @@ int dasp_mg_wait(dasp_mg_plan_t *mg, void *stream)
 {
     if (!mg) return DASP_ERR_ARG;
     if (int rc = sticky_error(*mg)) return rc;
+    if (mg->one_stream()) return flush_step2(*mg, static_cast<hipStream_t>(stream), false);
     return wait_gathered(*mg, static_cast<hipStream_t>(stream));
 }
 
@@ -817,6 +970,7 @@ int dasp_mg_get_y(dasp_mg_plan_t *mg, void *y_host)
     if (!mg || !y_host) return DASP_ERR_ARG;
     dasp_mg_plan &g = *mg;
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
+    if (int rc = flush_step2(g, nullptr, false)) return rc;
     MG_HIP(hipDeviceSynchronize());
     g.pending = false; g.pending_lazy = false;
     forget_exchange_events(g);
@@ -838,11 +992,16 @@ int dasp_mg_get_y_local(dasp_mg_plan_t *mg, void *y_host)
     if (!mg->uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
     MG_HIP(hipDeviceSynchronize());
     if (int rc = sticky_error(*mg)) return rc;
-    if (mg->rows() > 0) MG_HIP(hipMemcpy(y_host, mg->ys[mg->cur], (size_t)mg->rows() * mg->vb(), hipMemcpyDeviceToHost));
+    const void *src = mg->one_stream() ? static_cast<const void *>(mg->gcur() + (size_t)mg->rank * mg->stride * mg->vb()) : mg->ys[mg->cur];
+    if (mg->rows() > 0) MG_HIP(hipMemcpy(y_host, src, (size_t)mg->rows() * mg->vb(), hipMemcpyDeviceToHost));
     return DASP_OK;
 }
 
-void *dasp_mg_y_local(dasp_mg_plan_t *mg) { return mg && mg->uploaded ? mg->ys[mg->cur] : nullptr; }
+void *dasp_mg_y_local(dasp_mg_plan_t *mg)
+{
+    if (!mg || !mg->uploaded) return nullptr;
+    return mg->one_stream() ? static_cast<void *>(mg->gcur() + (size_t)mg->rank * mg->stride * mg->vb()) : mg->ys[mg->cur];
+}
 void *dasp_mg_gathered(dasp_mg_plan_t *mg) { return mg && mg->uploaded ? mg->gcur() : nullptr; }
 void *dasp_mg_x(dasp_mg_plan_t *mg) { return mg && mg->uploaded ? (mg->square ? static_cast<void *>(mg->gcur()) : mg->xg) : nullptr; }
 
@@ -861,7 +1020,7 @@ int dasp_mg_info(const dasp_mg_plan_t *mg, dasp_mg_info_t *out)
     out->nnz_own = mg->nnz_own; out->nnz_other = mg->nnz_other;
     out->overlap = mg->overlap ? 1 : 0; out->has_comm = mg->comm ? 1 : 0; out->square = mg->square ? 1 : 0;
     out->stream_memops = mg->use_sig ? 1 : 0;
-    out->fused_step = mg->fused ? 1 : 0;
+    out->fused_step = mg->fused ? (mg->step2 ? 2 : 1) : 0;
     out->exchange = mg->push ? 1 : 0;
     return DASP_OK;
 }

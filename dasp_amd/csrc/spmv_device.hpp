@@ -537,30 +537,6 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, src.nc + nt, x);
 
     typename Tr<T>::part_t d;
-#ifdef DASP_EXPERIMENT      // placement experiments: other shapes of the y write (results of modes 5 are NOT y; timing only)
-    if constexpr (YM == 0 && YS == 0 && sizeof(T) == 8) {
-        if (a.ymode == 5) {          // a sequential log per XCD: consecutive 128-byte lines written by one L2, in time order
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            xcc &= 7;
-            unsigned pos = 0;
-            unsigned *ctr = reinterpret_cast<unsigned *>(static_cast<T *>(a.y) + a.ylog_rows) + 16 * xcc;
-            if (lane == 0) pos = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            pos = __builtin_amdgcn_readfirstlane(pos);
-            const unsigned per = (unsigned)(a.ylog_rows / 16 / 8);
-            if (diag_of(acc, lane, d)) static_cast<T *>(a.y)[((size_t)xcc * per + pos % per) * 16 + row] = (T)d;
-            return;
-        }
-        if (a.ymode == 6 && (b | 3) < a.n_blocks && !a.order) {          // the workgroup's four blocks as ONE 512-byte store
-            __shared__ double ybuf[64];
-            const int wave = threadIdx.x >> 6;
-            if (diag_of(acc, lane, d)) ybuf[wave * 16 + row] = d;
-            __syncthreads();
-            if (wave == 0) static_cast<T *>(a.y)[a.row_long + (b & ~3) * kMedRows + lane] = ybuf[lane];
-            return;
-        }
-    }
-#endif
     if (diag_of(acc, lane, d) && r < a.row_block) {
         const int slot = a.row_long + r;                 // row_long here = slot of the first MFMA medium row (Plan::med_slot0)
         const int yi = YM == 2 ? a.med_dst[r] : (a.order ? a.order[slot] : slot);

@@ -85,7 +85,7 @@ class MgPlan:
             setattr(opt, k, x)
         self._h = C.c_void_p()
         _lib.check(L.dasp_mg_plan_create(C.byref(self._h), precision, int(n_rows), int(n_cols), b.size - 1, int(rank), _vp(b), _vp(rp),
-                                         _vp(ci), _vp(v), C.byref(opt), 1 if overlap else 0))
+                                         _vp(ci), _vp(v), C.byref(opt), int(overlap)))      # 0: one plan, no overlap; 1 / True: own / other column plans; 2: one plan, boundary rows last (the step on one stream)
         self.bounds, self.rank, self.world = b, int(rank), b.size - 1
         i = self.info
         self.stride, self.rows, self.overlap = i["stride"], i["row_end"] - i["row_begin"], bool(i["overlap"])

@@ -844,6 +844,50 @@ def test_fused_mg_step_without_other_column_nonzeros_is_held_behind_a_slow_excha
     mg.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_one_stream_mg_step_ranks_in_one_process(dasp, torch_cuda, monkeypatch, world):
+    """The step on ONE stream (overlap = 2, mgstep.hip dasp_mg_step2_kernel): `world` ranks of an HV15R-like partition as plans of one
+    process on one device, connected through the direct exchange (in-process peers use each other's pointers), every rank on a stream
+    of its own.  Each launch sends the previous slice from its head workgroups, computes the rows that read own columns at once and the
+    boundary rows behind the peers' arrival flags.  Seven chained steps without host synchronisation == (A^7) x0 from scipy on every
+    rank's gathered y; then dasp_mg_set_x and three more steps (the flags restart at the new epoch)."""
+    import scipy.sparse as sp
+    from dasp_amd.multi import MgPlan
+    torch = torch_cuda
+    monkeypatch.setenv("DASP_MG_SHARED_DEVICE_RANKS", str(world))
+    rows, A, bounds, sl = _hv_slices(dasp, world)
+    mgs = []
+    for r in range(world):
+        rp, ci, v = sl[r]
+        mgs.append(MgPlan(rp, ci, v, rows, rows, bounds, r, cid16=1, overlap=2).upload())
+    assert all(m.info["overlap"] == 1 and m.subplan(1) is None for m in mgs)
+    blobs = [m.push_export() for m in mgs]
+    for m in mgs:
+        m.push_connect(blobs)
+    assert all(m.info["fused_step"] == 2 and m.info["exchange"] == 1 for m in mgs)
+    streams = [torch.cuda.Stream() for _ in range(world)]
+    x0 = np.random.default_rng(11).uniform(0.5, 1.5, rows)
+    want = x0.copy()
+    for steps in (7, 3):
+        for m in mgs:
+            m.set_x(want)
+        for _ in range(steps):
+            for r, m in enumerate(mgs):
+                m.spmv(streams[r].cuda_stream)
+            want = A @ want
+        for r, m in enumerate(mgs):
+            m.wait(streams[r].cuda_stream)
+        for m in mgs:
+            m.check()
+        for r, m in enumerate(mgs):
+            got = m.get_y()
+            assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max(), (steps, r)
+            r0, r1 = int(bounds[r]), int(bounds[r + 1])
+            assert np.array_equal(m.get_y_local(), got[r0:r1])
+    for m in mgs:
+        m.close()
+
+
 def test_fused_mg_step_waits_in_the_kernel_and_times_out_cleanly(dasp, torch_cuda, monkeypatch):
     """One rank of a 2-way partition, 30 chained steps with NO host synchronisation between them and an emulated exchange of
     60 us: the other-column workgroups really wait inside the kernel for the previous exchange.  The peer's half of x never

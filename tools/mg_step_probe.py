@@ -47,7 +47,8 @@ for rank in ranks:
     rp, ci = D.synth_csr(name, scale, r0, r1, lengths=lengths[r0:r1])
     val = np.repeat(0.5 / np.maximum(np.diff(rp), 1), np.diff(rp))
     TR("create")
-    mg = MgPlan(rp, ci, val, rows, cols, bounds, rank)
+    OVL = int(os.environ.get("PROBE_OVERLAP", "1"))          # 2: ONE plan, the step on one stream (needs PROBE_EXCHANGE=push)
+    mg = MgPlan(rp, ci, val, rows, cols, bounds, rank, overlap=OVL)
     TR("upload")
     mg.upload()
     del ci, val
@@ -55,13 +56,14 @@ for rank in ranks:
     mg.set_x(np.ones(cols))
     TR("ready")
     line = "rank %d rows %d nnz own %d other %d fused_ok %d |" % (rank, r1 - r0, mg.nnz_local, mg.nnz_remote, mg.info["fused_step"])
-    can_fuse = mg.info["fused_step"] == 1
+    can_fuse = mg.info["fused_step"] >= 1
     if os.environ.get("PROBE_RESERVE"):                  # the plan's CU-masked compute stream (what the RCCL exchange needs)
         s = mg.reserved_stream(int(os.environ["PROBE_RESERVE"]))
         assert s, "no reserved stream"
     if os.environ.get("PROBE_EXCHANGE") == "push":      # the direct exchange, scratch memory standing in for the peers (+ the emulated link time)
         mg.push_loopback()
-    for fused in ([] if os.environ.get("PROBE_KERNEL_ONLY") == "1" else [True, False] if can_fuse else [False]):
+    if OVL == 2: can_fuse = mg.info["fused_step"] == 2
+    for fused in ([] if os.environ.get("PROBE_KERNEL_ONLY") == "1" else [True] if OVL == 2 else [True, False] if can_fuse else [False]):
         mg.set_fused(fused)
         for us in AG:
             mg.set_fake_exchange(us)
@@ -84,6 +86,21 @@ for rank in ranks:
         line += " | step kernel alone %.1f (host enqueue %.1f)" % (ms / 100 * 1e3, (h1 - h0) * 1e4)
     own = mg.subplan(0); oth = mg.subplan(1)
     x = torch.ones(own.x_len, dtype=torch.float64, device="cuda"); y = torch.zeros(mg.stride, dtype=torch.float64, device="cuda")
+    if OVL == 2:
+        if "variants/exp" in os.environ.get("DASP_AMD_SO", ""):
+            os.environ["DASP_MG_STEP2_NOPUSH"] = "1"
+            mg.set_x(np.ones(cols))
+            for _ in range(10): mg.product(s)
+            torch.cuda.synchronize()
+            t = StreamTimer(s); t.start()
+            for _ in range(100): mg.product(s)
+            ms = t.stop(); torch.cuda.synchronize()
+            os.environ["DASP_MG_STEP2_NOPUSH"] = "0"
+            line += " | step kernel without the stores to the peers and without the wait %.1f" % (ms / 100 * 1e3)
+        t_own = own.time(x.data_ptr(), y.data_ptr(), s, warmup=5, iters=100)[1] * 1e3
+        print(line + " | the plan alone (plain kernel, coarse x / y) %.1f us | data_X %.1f MB blocks %d" % (t_own, own.stats["data_X"] / 1e6, own.stats["n_med_blocks"]), flush=True)
+        mg.close(); del x, y; torch.cuda.empty_cache()
+        continue
     t_own = own.time(x.data_ptr(), y.data_ptr(), s, warmup=5, iters=100)[1] * 1e3
     t_own2 = own.time(mg.y_local_ptr, y.data_ptr(), s, warmup=5, iters=100)[1] * 1e3
     t_own3 = own.time(mg.y_local_ptr, mg.gathered_ptr, s, warmup=5, iters=100)[1] * 1e3
