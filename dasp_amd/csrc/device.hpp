@@ -83,7 +83,7 @@ int tune_placement(Plan &p, int trials, const void *dX, void *dY, double *ms_fir
 // fused multi-GPU step (kernels.hip; driven by multigpu.cpp): all pointers are device pointers
 // the words of the fused step live in ONE zero-initialised device block of kMgWordBytes: sharded arrival counters first (marked
 // own-column workgroups at 0, all workgroups at 8192, their top counters at 16384 / +256), then the flags, each on a line of its own
-constexpr size_t kMgWordGathered = 20480, kMgWordOwnGo = 20480 + 4096, kMgWordReady = 20480 + 8192, kMgWordErr = 20480 + 12288, kMgWordBytes = 40960;
+constexpr size_t kMgWordGathered = 20480, kMgWordOwnGo = 20480 + 4096, kMgWordReady = 20480 + 8192, kMgWordErr = 20480 + 12288, kMgWordXcd = 40960, kMgWordBytes = 40960 + 2048;      // (Xcd: 8 x 256 bytes, the per-XCD acquire words)
 struct MgStepCtl {
     void *words;                                       // the block above
     unsigned long long need;                           // the other-column product waits in the kernel for gathered >= need (0: no wait)
@@ -94,24 +94,28 @@ struct MgStepCtl {
     int max_pollers;                                   // bound on the persistent workgroups that wait
     int poll_sleep;                                    // pause between two polls of a workgroup, in units of s_sleep(8) (~0.2 us)
     long long timeout_ticks;                           // 100 MHz ticks a wait may take before it gives up and sets the error word
+    double poll_at;                                    // where the waiting workgroups stand in the grid, as a fraction of the own-column workgroups (1: last)
     void *err;                                         // the sticky error word (host-mapped, so that the host reads it without a synchronisation); null: words + kMgWordErr
 };
 bool mg_step_supported(const Plan &own, const Plan *other);
 // host: which own-column workgroups of the step kernel store a row with has_other[row] != 0 (natural-order plan, before the
 // host arrays are dropped).  mark gets one byte per workgroup of the plan's launch grid; blk_order the dispatch order of the medium
 // blocks that the marks assume (blocks holding such rows first).
-void mg_step_marks(const Plan &own, const unsigned char *has_other, std::vector<unsigned char> &mark, std::vector<int> &blk_order, bool hot_first = true);
+void mg_step_marks(const Plan &own, const unsigned char *has_other, std::vector<unsigned char> &mark, std::vector<int> &blk_order, double hot_at = -1.0);
 int launch_mg_step(Plan &own, Plan *other, const void *x_own, const void *x_gathered, void *y, const MgStepCtl &c, void *stream);
 int mg_step_resident_per_cu();
 // the step on ONE stream (mgstep.hip dasp_mg_step2_kernel): ONE plan in the gather-buffer column layout; head workgroups send the previous
-// slice to the peers (push: mgx.hpp, n_dst may be 0), free workgroups run at once, a bounded set of persistent workgroups waits for every
-// peer's arrival flag and runs the workgroups holding boundary rows.  All pointers are device pointers.
+// slice to the peers (push: mgx.hpp, n_dst may be 0), unmarked workgroups run at once, the marked ones (boundary rows) behind every peer's
+// arrival flag -- each by itself where it stands in the list, or (max_pollers > 0) through a bounded set of persistent workgroups at the end.
+// All pointers are device pointers.
 struct MgStep2Ctl {
     const void *wg_list; const void *blk_order;      // device tables: [n_free + n_marked] virtual workgroups (free first), [medium blocks] dispatch order
-    int n_push, n_free, n_marked, max_pollers;
+    int n_push, n_free, n_marked, n_total, max_pollers;   // list = n_free unmarked, n_marked marked, the remaining unmarked; max_pollers 0: marked workgroups wait in place
     const void *arrived; int world, rank;            // this rank's arrival flags
     unsigned long long need;                         // value the flags must reach (0: no wait)
     void *err; long long timeout_ticks; int poll_sleep;
+    int fence_mode;                                  // 0: every waiting workgroup acquires at system scope; 1: one per XCD (default)
+    void *xcd_fenced; unsigned long long step;       // device: 8 x 256 bytes, zeroed at upload; the launch's number (monotone)
 };
 struct MgPushArgs;
 int launch_mg_step2(Plan &plan, const void *x, void *y, const MgStep2Ctl &c, const MgPushArgs &push, void *stream);

@@ -39,6 +39,8 @@ struct StepCtl {
     unsigned long long step;
     int *err;                             // sticky: 1 = a wait timed out
     int grid_a, grid_b, n_poll;           // workgroups of plan a / virtual workgroups of plan b / persistent workgroups serving them
+    int poll_at;                          // grid position of the first waiting workgroup (<= grid_a)
+    unsigned long long *xcd_fenced;       // [8 x 32] per XCD: the step whose system-scope acquire is done; + 16: claimed
     const int *blk_order;                 // [medium blocks of plan a] dispatch order: the blocks of marked workgroups first
     int sleep;                            // s_sleep(8) repetitions between two polls (~0.2 us each)
     long long timeout;                    // 100 MHz ticks after which a waiting workgroup gives up
@@ -66,9 +68,13 @@ __global__ __launch_bounds__(256, kMinWavesPlain) void dasp_mg_step_kernel(DevAr
     __shared__ int go;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wg = blockIdx.x;
+    // the waiting workgroups stand at [poll_at, poll_at + n_poll) of the grid (poll_at = grid_a: last): early enough for the other-column
+    // product to run in the shadow of the own-column one instead of behind it
+    const int gi = blockIdx.x;
+    const bool own_wg = gi < c.poll_at || gi >= c.poll_at + c.n_poll;
+    const int wg = gi < c.poll_at ? gi : own_wg ? gi - c.n_poll : c.grid_a + (gi - c.poll_at);      // own-column workgroup number, or grid_a + waiting workgroup number
     const int total = c.grid_a + c.n_poll;
-    if (wg < c.grid_a) {
+    if (own_wg) {
         plain_wg<double, NT, true, true, 1>(a, wg, wave, lane, c.blk_order);
         // done: every wave's write-through stores acknowledged, then ONE lane counts the workgroup.  Relaxed atomics: the y values went
         // out through sc0 sc1 stores, so an arrival needs no cache write-back or invalidate of its own (an acq_rel add costs every
@@ -94,8 +100,25 @@ __global__ __launch_bounds__(256, kMinWavesPlain) void dasp_mg_step_kernel(DevAr
             for (int z = 0; z < c.sleep; ++z) __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > c.timeout) { ok = 0; __hip_atomic_store(c.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
         }
-        // the gather buffer was written by another kernel (this device's or, over xGMI, a peer's) while this one ran
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        // the gather buffer was written by another kernel (this device's or, over xGMI, a peer's) while this one ran: acquire at system
+        // scope -- ONE workgroup per XCD does it (a system-scope acquire drops what the XCD's L2 holds, under the running own-column product;
+        // r3 had every waiting workgroup do it), the others wait for that XCD's word.  No L1 holds a line of the gather buffer yet: only
+        // the other-column plan reads it, i.e. workgroups that have passed this point.
+        if (ok) {
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long *w = c.xcd_fenced + 32 * (xcc & 7);
+            if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.step) {
+                if (__hip_atomic_fetch_max(w + 16, c.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.step) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(w, c.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    const long long t1 = wall_clock64();
+                    while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.step && wall_clock64() - t1 < c.timeout) __builtin_amdgcn_s_sleep(2);
+                }
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         go = ok;
     }
@@ -147,12 +170,62 @@ __global__ void dasp_mg_flag_kernel(unsigned long long *p, unsigned long long v)
 struct Step2Ctl {
     const int *wg_list;                     // [n_free + n_marked] virtual workgroups of the plan: free ones first, boundary ones last
     const int *blk_order;                   // [medium blocks] dispatch order: blocks with boundary rows last
-    int n_push, n_free, n_marked, n_poll;
+    int n_push, n_free, n_marked, n_total, n_poll;     // list: n_free unmarked, n_marked marked, the other unmarked ones; n_poll 0: marked workgroups wait in place
     const unsigned long long *arrived;      // [world] this rank's arrival flags (fine-grained memory, written by the peers)
     int world, rank;
     unsigned long long need;                // the flags must reach this value (0: x was put in place by the host, nothing to wait for)
     int *err; long long timeout; int sleep;
+    int fence_mode;                         // 0: every waiting workgroup acquires at system scope; 1: one per XCD; 2: none (measurement only)
+    unsigned long long *xcd_fenced;         // [8 x 32] per XCD: the step whose fence is done; + 16: the step whose fence is claimed
+    unsigned long long step;
 };
+
+// lane 0 of the calling wave ends up knowing whether every peer's slice of the previous step has arrived (true) or the wait timed out
+__device__ __forceinline__ bool step2_wait(const Step2Ctl &c, int lane)
+{
+    bool late = false;
+    if (c.need) {
+        const long long t0 = wall_clock64();
+        for (int r0 = 0; r0 < c.world && !late; r0 += 64) {
+            const int r = r0 + lane;
+            for (;;) {       // relaxed polls
+                const bool ok = r >= c.world || r == c.rank || __hip_atomic_load(c.arrived + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= c.need;
+                if (__all(ok)) break;
+                for (int z = 0; z < c.sleep; ++z) __builtin_amdgcn_s_sleep(8);
+                if (wall_clock64() - t0 > c.timeout) { late = true; break; }
+            }
+        }
+    }
+    // The peers' slices were stored by other devices while this kernel ran: acquire at system scope.  A system-scope acquire throws away
+    // what the XCD's L2 holds (buffer_inv sc0 sc1) -- the x this rank's own rows are gathering from.  One per XCD is all the memory model
+    // asks for of the L2s: an L2 belongs to an XCD.  fence_mode 1: the first waiting workgroup of each XCD to get here claims
+    // the fence, performs it and raises that XCD's word to the step number; the others wait for the word (a few hundred cycles).
+    if (c.fence_mode == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    else if ((c.fence_mode == 1 || c.fence_mode == 3) && c.need && !late) {      // (3: measurement -- the per-XCD fence without the L1 invalidates)
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long *w = c.xcd_fenced + 32 * (xcc & 7);            // two 128-byte lines per XCD: fenced, claimed
+        if (lane == 0 && __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.step) {
+            if (__hip_atomic_fetch_max(w + 16, c.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.step) {      // this workgroup fences for its XCD
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(w, c.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const long long t1 = wall_clock64();
+                while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.step) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - t1 > c.timeout) break;          // (the fencing workgroup cannot get lost; a bound all the same)
+                }
+            }
+        }
+    }
+    // ... and every waiting workgroup drops its own CU's L1 (an agent-scope acquire: buffer_inv sc1, the L2 stays): a pad's clamped gather
+    // reads x[0] -- rank 0's slot -- whatever the row, so a line of a peer's slot CAN sit in an L1 from before the flags went up
+    if ((c.fence_mode == 1 || c.fence_mode == 0) && c.need) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0 && late) __hip_atomic_store(c.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return !late;
+}
 
 template <bool NT>
 __global__ __launch_bounds__(256, kMinWavesPlain) void dasp_mg_step2_kernel(DevArgs a, MgPushArgs push, Step2Ctl c)
@@ -163,30 +236,25 @@ __global__ __launch_bounds__(256, kMinWavesPlain) void dasp_mg_step2_kernel(DevA
     int wg = blockIdx.x;
     if (wg < c.n_push) { mg_push_part(push, wg, c.n_push); return; }
     wg -= c.n_push;
-    if (wg < c.n_free) { plain_wg<double, NT, true, true, 3>(a, tab<true>(c.wg_list, wg), wave, lane, c.blk_order); return; }
-    wg -= c.n_free;
-    if (wave == 0) {
-        bool late = false;
-        if (c.need) {
-            const long long t0 = wall_clock64();
-            for (int r0 = 0; r0 < c.world && !late; r0 += 64) {
-                const int r = r0 + lane;
-                for (;;) {       // relaxed polls; ONE acquire below
-                    const bool ok = r >= c.world || r == c.rank || __hip_atomic_load(c.arrived + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= c.need;
-                    if (__all(ok)) break;
-                    for (int z = 0; z < c.sleep; ++z) __builtin_amdgcn_s_sleep(8);
-                    if (wall_clock64() - t0 > c.timeout) { late = true; break; }
-                }
-            }
+#ifdef DASP_EXPERIMENT
+    if (c.fence_mode == 99) { plain_wg<double, NT, true, true, 3>(a, wg, wave, lane, nullptr); return; }          // no tables at all: the plan's own order
+    if (c.fence_mode == 98) { plain_wg<double, NT, true, true, 3>(a, wg, wave, lane, c.blk_order); return; }      // the block order table only
+#endif
+    if (c.n_poll == 0) {
+        // every workgroup of the list where it stands; the marked ones [n_free, n_free + n_marked) wait for the peers' slices by themselves
+        if (wg >= c.n_free && wg < c.n_free + c.n_marked) {
+            if (wave == 0) { const bool ok = step2_wait(c, lane); if (lane == 0) go = ok ? 1 : 0; }
+            __syncthreads();
+            if (!go) return;
         }
-        // the peers' slices were stored by other devices while this kernel ran
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) {
-            if (late) __hip_atomic_store(c.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            go = late ? 0 : 1;
-        }
+        plain_wg<double, NT, true, true, 3>(a, tab<true>(c.wg_list, wg), wave, lane, c.blk_order);
+        return;
     }
+    // several ranks on one device: the marked workgroups through a bounded set of persistent workgroups at the END of the grid
+    const int n_unmarked = c.n_total - c.n_marked;
+    if (wg < n_unmarked) { plain_wg<double, NT, true, true, 3>(a, tab<true>(c.wg_list, wg < c.n_free ? wg : wg + c.n_marked), wave, lane, c.blk_order); return; }
+    wg -= n_unmarked;
+    if (wave == 0) { const bool ok = step2_wait(c, lane); if (lane == 0) go = ok ? 1 : 0; }
     __syncthreads();
     if (go)
         for (int v = wg; v < c.n_marked; v += c.n_poll) plain_wg<double, NT, true, true, 3>(a, tab<true>(c.wg_list, c.n_free + v), wave, lane, c.blk_order);
@@ -223,6 +291,8 @@ int launch_mg_step(Plan &own, Plan *other, const void *x_own, const void *x_gath
     if (const char *e = std::getenv("DASP_MG_STEP_NOOTHER")) if (std::atoi(e)) { c.grid_b = 0; other = nullptr; }
 #endif
     c.n_poll = std::min(c.grid_b, std::max(1, h.max_pollers));
+    c.poll_at = std::max(0, std::min(c.grid_a, (int)((double)c.grid_a * h.poll_at)));
+    c.xcd_fenced = reinterpret_cast<unsigned long long *>(w + kMgWordXcd);
     c.mark = static_cast<const unsigned char *>(h.mark); c.mark_members = static_cast<const unsigned *>(h.mark_members);
     c.n_marked = other ? h.n_marked : 0; c.n_mark_shards = h.n_mark_shards;
     c.blk_order = static_cast<const int *>(h.blk_order);
@@ -273,15 +343,22 @@ int launch_mg_step2(Plan &plan, const void *x, void *y, const MgStep2Ctl &h, con
     a.wg_med = (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG; a.xcd_on = 0;      // one medium block per wave through the order table (mg_step_marks assumes it)
     Step2Ctl c{};
     c.wg_list = static_cast<const int *>(h.wg_list); c.blk_order = static_cast<const int *>(h.blk_order);
-    c.n_push = h.n_push; c.n_free = h.n_free; c.n_marked = h.n_marked;
-    c.n_poll = std::max(1, std::min(h.n_marked, std::max(1, h.max_pollers)));      // at least one: it is also what holds the launch until every peer's slice is in
+    c.n_push = h.n_push; c.n_free = h.n_free; c.n_marked = h.n_marked; c.n_total = h.n_total;
+    // bounded mode: at least one persistent workgroup -- it is also what holds the launch until every peer's slice is in
+    c.n_poll = h.max_pollers > 0 ? std::max(1, std::min(h.n_marked, h.max_pollers)) : 0;
     c.arrived = static_cast<const unsigned long long *>(h.arrived); c.world = h.world; c.rank = h.rank; c.need = h.need;
     c.err = static_cast<int *>(h.err); c.timeout = h.timeout_ticks; c.sleep = std::max(1, h.poll_sleep);
+    c.fence_mode = h.fence_mode; c.xcd_fenced = static_cast<unsigned long long *>(h.xcd_fenced); c.step = h.step;
 #ifdef DASP_EXPERIMENT      // breakdown of the one-stream step (tools/mg_step_probe.py): without the head workgroups' stores / without the wait
     if (const char *e = std::getenv("DASP_MG_STEP2_NOPUSH")) if (std::atoi(e)) { c.n_push = 0; c.need = 0; }
+    if (const char *e = std::getenv("DASP_MG_STEP2_FENCE")) c.fence_mode = std::atoi(e);
+    if (const char *e = std::getenv("DASP_MG_STEP2_ALLFREE")) if (std::atoi(e)) { c.n_free = c.n_total; c.n_marked = 0; c.n_poll = 0; c.need = 0; }      // every workgroup at once, in list order
 #endif
-    if (c.n_free + c.n_marked != a.wg_long + a.wg_med + a.wg_short) { set_error("one-stream step: the workgroup list does not match the plan's grid"); return DASP_ERR_STATE; }
-    const int grid = c.n_push + c.n_free + c.n_poll;
+    if (c.n_total != a.wg_long + a.wg_med + a.wg_short || c.n_free + c.n_marked > c.n_total) { set_error("one-stream step: the workgroup list does not match the plan's grid"); return DASP_ERR_STATE; }
+    // in-place mode with no marked workgroup at all (a rank without boundary rows): ONE extra workgroup still waits for every peer, so that
+    // no rank can run two steps ahead of another
+    if (c.n_poll == 0 && c.n_marked == 0 && c.need) c.n_poll = 1;
+    const int grid = c.n_push + (c.n_poll ? c.n_total - c.n_marked + c.n_poll : c.n_total);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (plan.dev->nt) hipLaunchKernelGGL((dasp_mg_step2_kernel<true>), dim3(grid), dim3(256), 0, s, a, push, c);
     else hipLaunchKernelGGL((dasp_mg_step2_kernel<false>), dim3(grid), dim3(256), 0, s, a, push, c);

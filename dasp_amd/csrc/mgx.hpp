@@ -21,6 +21,7 @@ struct MgPushArgs {
     unsigned long long ready_need;
     long long timeout;               // 100 MHz ticks
     int *err;                        // sticky error word of the step (2: the wait for the product timed out)
+    long long delay_ticks;           // TEST HOOK (loopback timing): the flags go up this long after the stores (0 in every real exchange)
 };
 
 int launch_mg_push(const MgPushArgs &a, void *stream);

@@ -57,8 +57,13 @@ __device__ __forceinline__ void mg_push_part(const MgPushArgs &a, int part, int 
     __syncthreads();
     for (int d = threadIdx.x; d < a.n_dst; d += 256) {
         const unsigned old = __hip_atomic_fetch_add(a.count + d, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((old + 1) % (unsigned)parts == 0)                          // every part for this destination is out
+        if ((old + 1) % (unsigned)parts == 0) {                        // every part for this destination is out
+            if (a.delay_ticks > 0) {                                   // loopback timing probes only: the links' share of the exchange (100 MHz ticks)
+                const long long t0 = wall_clock64();
+                while (wall_clock64() - t0 < a.delay_ticks) __builtin_amdgcn_s_sleep(8);
+            }
             __hip_atomic_store(a.dst[d].flag, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

@@ -119,7 +119,10 @@ bool mg_step_supported(const Plan &own, const Plan *other)
     return ok(own) && (!other || ok(*other));
 }
 
-void mg_step_marks(const Plan &p, const unsigned char *has_other, std::vector<unsigned char> &mark, std::vector<int> &blk_order, bool hot_first)
+// hot_at: where the medium blocks holding a marked row go in the dispatch order -- < 0: first (dasp_mg_step_kernel: the other-column product
+// waits for them); 0 .. 1: behind that fraction of the other blocks' work (dasp_mg_step2_kernel: they wait for the peers' slices, so late
+// enough for those to have arrived, but BEFORE the shortest blocks, which make the better tail); 1: last
+void mg_step_marks(const Plan &p, const unsigned char *has_other, std::vector<unsigned char> &mark, std::vector<int> &blk_order, double hot_at)
 {
     // the launch grid of upload_plan / dasp_mg_step_kernel: [ long pieces | medium blocks through blk_order | short tiles ], 4 units per workgroup
     const int n_pieces = (int)p.piece_dst.size(), n_blocks = p.stats.n_med_blocks, n_tiles = p.stats.n_short_tiles;
@@ -138,14 +141,27 @@ void mg_step_marks(const Plan &p, const unsigned char *has_other, std::vector<un
     blk_order.clear(); blk_order.reserve((size_t)n_blocks);
     int n_hot = 0;
     for (int b = 0; b < n_blocks; ++b) n_hot += hot[(size_t)b];
-    if (hot_first) {
+    if (hot_at < 0) {
         for (int b = 0; b < n_blocks; ++b) if (hot[(size_t)b]) blk_order.push_back(b);
         for (int b = 0; b < n_blocks; ++b) if (!hot[(size_t)b]) blk_order.push_back(b);
         for (int q = 0; q < n_hot; ++q) mark[(size_t)wg_long + q / kWavesPerWG] = 1;
-    } else {      // the one-stream step: boundary blocks LAST (they wait for the peers' slices)
-        for (int b = 0; b < n_blocks; ++b) if (!hot[(size_t)b]) blk_order.push_back(b);
+    } else {
+        // work of a block = its chunks + 2 (row tables, tail); the marked blocks go behind the first n0 unmarked ones (a whole number of workgroups)
+        auto work = [&](int b) { return (long long)(p.med_ptr[(size_t)b + 1] - p.med_ptr[(size_t)b]) + 2; };
+        long long cold_work = 0;
+        for (int b = 0; b < n_blocks; ++b) if (!hot[(size_t)b]) cold_work += work(b);
+        const long long before = (long long)(std::min(1.0, hot_at) * (double)cold_work);
+        int n0 = 0;
+        long long acc = 0;
+        std::vector<int> cold; cold.reserve((size_t)(n_blocks - n_hot));
+        for (int b = 0; b < n_blocks; ++b) if (!hot[(size_t)b]) cold.push_back(b);
+        while (n0 < (int)cold.size() && acc < before) acc += work(cold[(size_t)n0++]);
+        n0 = std::min((int)cold.size(), (n0 + kWavesPerWG - 1) / kWavesPerWG * kWavesPerWG);
+        if ((int)cold.size() - n0 < kWavesPerWG) n0 = (int)cold.size();
+        for (int i = 0; i < n0; ++i) blk_order.push_back(cold[(size_t)i]);
         for (int b = 0; b < n_blocks; ++b) if (hot[(size_t)b]) blk_order.push_back(b);
-        for (int q = n_blocks - n_hot; q < n_blocks; ++q) mark[(size_t)wg_long + q / kWavesPerWG] = 1;
+        for (int i = n0; i < (int)cold.size(); ++i) blk_order.push_back(cold[(size_t)i]);
+        for (int q = n0; q < n0 + n_hot; ++q) mark[(size_t)wg_long + q / kWavesPerWG] = 1;
     }
     const int SR = p.geo.short_rows;
     for (int g = 0; g < kNumShortGroups; ++g) {
@@ -239,6 +255,12 @@ struct dasp_mg_plan {
     void *d_push_dst2 = nullptr;       // device: MgPushDst[2][world - 1], the peers only (this rank's slot is written by its own product)
     void *d_push_count2 = nullptr;
     uint64_t k2 = 0, pushed_upto = 0;
+    // grid position of the two-plan fused step's waiting workgroups, as a fraction of the own-column workgroups (DASP_MG_POLL_AT).  At the very end (r3)
+    // the other-column product was a serial tail of ~10 us; at 0.8 it runs in the shadow of the own-column product: HV15R rank 3 of 8
+    // 76.2 -> 73.4 us, Queen_4147 93.2 -> 90.5 (2 waiting workgroups per CU; profiles/r04_multi_gpu_step.md)
+    double poll_at = 0.8;
+    bool step2_pollers = false;        // DASP_MG_STEP2_POLLERS=1 (A/B knob): the bounded persistent workgroups also with one rank per device
+    bool shared_device = false;        // DASP_MG_SHARED_DEVICE_RANKS: several ranks on this device (tests): the waiting workgroups are bounded
     int fake_us = -1;
     int fake_channels = 0;             // > 0: the stand-in kernel has the footprint of RCCL's (devpack.hip k_spin_fat), that many workgroups
     std::vector<void *> fake_peers;
@@ -349,12 +371,22 @@ int create_impl(dasp_mg_plan &g, const int *rp, const int *ci, const T *val, con
         if (int rc = dasp_plan_create(&g.own, g.precision, m, g.colA, nnz, rp, ci, val, &part)) return rc;
         const Plan &P = g.own->impl;
         if (g.precision == 64 && P.panels.empty() && !P.windowed && P.opt.y_order == DASP_Y_NATURAL) {
-            mg_step_marks(P, has.data(), g.mark, g.blk_order, false);
+            // grid order: the unmarked workgroups in the plan's order, with ALL marked ones (long pieces, medium blocks, short tiles) where the
+            // marked medium blocks stand -- behind `hot_at` of the other blocks' work (DASP_MG_HOT_AT; default 1.0 = last: measured with an
+            // emulated link time, an earlier place gains nothing when the slices are early and loses 9-14 us when they take 30-45 us: profiles/r04_multi_gpu_step.md)
+            double hot_at = 1.0;
+            if (const char *e = std::getenv("DASP_MG_HOT_AT")) hot_at = std::max(0.0, std::min(1.0, std::atof(e)));
+            mg_step_marks(P, has.data(), g.mark, g.blk_order, hot_at);
+            const int n_pieces = (int)P.piece_dst.size(), wg_long = (n_pieces + kWavesPerWG - 1) / kWavesPerWG;
+            const int wg_med = (P.stats.n_med_blocks + kWavesPerWG - 1) / kWavesPerWG;
+            int first_hot_med = wg_long + wg_med;                 // the first marked medium workgroup (none: marked ones go behind the medium range)
+            for (int w = wg_long; w < wg_long + wg_med; ++w) if (g.mark[(size_t)w]) { first_hot_med = w; break; }
             g.wg_list.clear(); g.wg_list.reserve(g.mark.size());
-            for (size_t w = 0; w < g.mark.size(); ++w) if (!g.mark[w]) g.wg_list.push_back((int)w);
-            g.n_free2 = (int)g.wg_list.size();
+            for (int w = 0; w < first_hot_med; ++w) if (!g.mark[(size_t)w]) g.wg_list.push_back(w);
+            g.n_free2 = (int)g.wg_list.size();                     // = the position of the first marked workgroup in the list
             for (size_t w = 0; w < g.mark.size(); ++w) if (g.mark[w]) g.wg_list.push_back((int)w);
             g.n_marked2 = (int)g.wg_list.size() - g.n_free2;
+            for (int w = first_hot_med; w < (int)g.mark.size(); ++w) if (!g.mark[(size_t)w]) g.wg_list.push_back(w);
         }
         return DASP_OK;
     }
@@ -460,13 +492,17 @@ int product(dasp_mg_plan &g, hipStream_t s)
             pa.dst = static_cast<const MgPushDst *>(g.d_push_dst2) + (size_t)(g.k2 & 1) * (size_t)(g.world - 1);
             pa.n_dst = g.world - 1; pa.count = static_cast<unsigned *>(g.d_push_count2); pa.wgs = g.push_wgs;
             pa.seq = (g.epoch << 32) + g.k2; pa.timeout = g.timeout_ticks; pa.err = g.err_word;
+            pa.delay_ticks = g.push_loopback && g.fake_us > 0 ? 100ll * g.fake_us : 0;      // timing probe: the links' share of the exchange
             g.pushed_upto = g.k2;
         }
         MgStep2Ctl c{};
         c.wg_list = g.d_wg_list; c.blk_order = g.d_blk_order; c.n_push = send ? g.push_wgs : 0; c.n_free = g.n_free2; c.n_marked = g.n_marked2;
-        c.max_pollers = g.max_pollers_thin; c.arrived = g.xflags; c.world = g.world; c.rank = g.rank;
+        c.n_total = (int)g.wg_list.size();
+        c.max_pollers = g.shared_device || g.step2_pollers ? g.max_pollers_thin : 0;      // 0: every marked workgroup waits by itself, in place
+        c.arrived = g.xflags; c.world = g.world; c.rank = g.rank;
         c.need = g.world > 1 && g.k2 >= 1 ? (g.epoch << 32) + g.k2 : 0;
         c.err = g.err_word; c.timeout_ticks = g.timeout_ticks; c.poll_sleep = g.poll_sleep;
+        c.fence_mode = 1; c.xcd_fenced = g.words + kMgWordXcd; c.step = g.step + 1;
         char *xin = g.gcur();
         char *yout = static_cast<char *>(g.yg) + (size_t)((g.k2 + 1) & 1) * g.all_bytes() + (size_t)g.rank * sl;
         if (int rc = launch_mg_step2(g.own->impl, xin, yout, c, pa, s)) return rc;
@@ -488,6 +524,7 @@ int product(dasp_mg_plan &g, hipStream_t s)
         c.mark = g.d_mark; c.mark_members = static_cast<char *>(g.d_mark) + ((g.mark.size() + 255) & ~size_t(255));
         c.n_marked = g.n_marked; c.n_mark_shards = g.n_mark_shards; c.blk_order = g.d_blk_order;
         c.max_pollers = g.push ? g.max_pollers_thin : g.max_pollers; c.timeout_ticks = g.timeout_ticks; c.poll_sleep = g.poll_sleep;
+        c.poll_at = g.poll_at;
         if (int rc = launch_mg_step(g.own->impl, g.other ? &g.other->impl : nullptr, g.ys[cur], g.gcur(), g.ys[nxt], c, s)) return rc;
     } else if (g.overlap && !g.step2) {
         // own columns: needs only this rank's slice of x, i.e. its own previous y -- no communication
@@ -847,13 +884,16 @@ int dasp_mg_upload(dasp_mg_plan_t *mg)
             int per_cu = std::max(1, std::min(std::min(4, resident - 1), (512 - kExchangeKernelRegs) * resident / 512));
             if (const char *q = std::getenv("DASP_MG_POLL_PER_CU")) per_cu = std::max(1, std::atoi(q));
             g.max_pollers = cus * per_cu;
-            g.max_pollers_thin = std::getenv("DASP_MG_POLL_PER_CU") ? g.max_pollers : cus * std::max(1, std::min(4, resident - 1));      // 1 / 2 / 4 per CU: 76 / 75 / 74 us per step
+            g.max_pollers_thin = std::getenv("DASP_MG_POLL_PER_CU") ? g.max_pollers : cus * std::max(1, std::min(2, resident - 1));      // standing at 0.8 of the grid (poll_at), 2 / 3 / 4 per CU: 74.2 / 76.2 / 78.4 us per step (HV15R rank 3 of 8; Queen_4147 alike within 0.5 us)
             // several ranks on ONE device (tests, a bench on a box with fewer GPUs than ranks): their waiting workgroups add up, and together
             // they must never fill a CU -- the peer they wait for runs on the same CUs
             if (const char *q = std::getenv("DASP_MG_SHARED_DEVICE_RANKS")) {
                 const int n = std::max(1, std::atoi(q));
+                g.shared_device = n > 1;
                 g.max_pollers = std::max(1, g.max_pollers / n); g.max_pollers_thin = std::max(1, g.max_pollers_thin / n);
             }
+            if (const char *q = std::getenv("DASP_MG_POLL_AT")) g.poll_at = std::max(0.0, std::min(1.0, std::atof(q)));
+            if (const char *q = std::getenv("DASP_MG_STEP2_POLLERS")) g.step2_pollers = std::atoi(q) != 0;
             if (const char *q = std::getenv("DASP_MG_POLL_SLEEP")) g.poll_sleep = std::max(1, std::atoi(q));
         }
     }

@@ -10,7 +10,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
-#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -216,16 +215,18 @@ static int upload_plan_impl(Plan &p)
 }
 
 
-// ---- placement trials (r3, profiles/r03_placement.md).  The same arena bytes run the HBM-bound kernels at one of two speeds ~8 % apart
-// depending on WHERE the allocation landed (two uploads of one plan in one process, interleaved timing: 0.420 vs 0.453 ms; the skew
-// between the arena's arrays, the TLB and the history of the device do not matter; which allocation of a process is the fast one differs
-// from box to box).  A user-mode library cannot see the cause, but it can look: time a few launches, copy the arena into a fresh allocation
-// (the old one stays allocated meanwhile, so the new one lands elsewhere), time again, keep the faster, at most `trials` allocations alive at once
-// (DASP_PLACEMENT_TRIALS, default 6; 1 = off), stop as soon as one allocation is >= 4 % faster than another.  Only plans that stream
-// >= 256 MiB per SpMV and are not gather-bound by construction (column panels, LDS windows).  Costs ~5 ms per trial for HV15R.
-// Measured on the bench headline, six fresh processes each on one box: without 0.4343 0.4272 0.4595 0.4595 0.4603 0.4594 ms, with
-// 0.4508 0.4283 0.4285 0.4275 0.4332 0.4336 ms -- the caller's x / y take part in the effect (profiles/r03_placement.md), so the trials
-// with scratch operands shift the odds, they do not decide.
+// ---- placement trials (r3; r4: profiles/r04_placement.md).  The same arena bytes run the HBM-bound kernels at one of two speeds ~8 % apart
+// depending on where the plan's allocation and the WRITTEN vector landed relative to each other (r4: it is y that decides -- the same plan is slow
+// with one y and fast with another, offsets inside an allocation change nothing, and with the y stores compiled out the kernel runs 10-19 %
+// faster on a slow pair: 16-67 MB of y written back under a 3-GB read stream cost 40-75 us; write-through / non-temporal stores, 512-byte
+// bursts, per-XCD sequential logs and XCD-contiguous block ranges do not cure it, and on some boxes no allocation is fast).  A user-mode library
+// cannot see the cause, but a caller who wants to can look: dasp_plan_tune_placement copies the arena into `trials` - 1 fresh allocations,
+// times each against the caller's own x / y and keeps the fastest.  OPT-IN since r4 (it was part of every dasp_plan_upload in r3): explicit
+// calls, or DASP_PLACEMENT_TRIALS=n > 1 for the upload of host-built plans.  The default of an explicit call is ONE extra allocation
+// (trials = 2); none is made unless the device has room for it beside 1 GiB of slack; nothing sleeps or launches behind the trials (the
+// driver wipes released VRAM in the background at ~35 GB/s and kernels run 1-3 % slower meanwhile: a caller that times right after a trial
+// warms up for that long -- bench.py does).  Cheaper, and usually enough, is to try a few y vectors instead: bench.py times the plan against
+// six candidates of its own and keeps the fastest (16 MB each instead of 2.9 GB).
 static void rebase_args(DevArgs &a, const char *from, const char *to, size_t bytes)
 {
     auto mv = [&](auto &ptr) {
@@ -243,10 +244,8 @@ int tune_placement(Plan &p, int trials, const void *dX, void *dY, double *ms_fir
     DevicePlan *d = p.dev;
     if (ms_first) *ms_first = 0.0;
     if (ms_kept) *ms_kept = 0.0;
-    if (trials <= 0) {
-        trials = 6;
-        if (const char *e = std::getenv("DASP_PLACEMENT_TRIALS")) trials = std::max(1, std::min(8, std::atoi(e)));
-    }
+    if (trials <= 0) trials = 2;      // one extra allocation
+    trials = std::min(trials, 8);
     if (!d || !d->arena || trials <= 1 || d->arena_bytes < (size_t(256) << 20) || !p.panels.empty() || p.panel || p.windowed) return DASP_OK;
     const bool verbose = std::getenv("DASP_VERBOSE") != nullptr;
     const size_t vb = (size_t)p.geo.vbytes, bytes = d->arena_bytes;
@@ -284,6 +283,8 @@ int tune_placement(Plan &p, int trials, const void *dX, void *dY, double *ms_fir
     if (verbose) std::fprintf(stderr, "[dasp placement] allocation 0 at %p: %.4f ms\n", d->arena, best);
     for (int t = 1; t < trials && hi < 1.04 * lo; ++t) {
         void *na = nullptr;
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess || mem_free < bytes + (size_t(1) << 30)) { (void)hipGetLastError(); break; }      // never squeeze a co-resident allocator
         if (hipMalloc(&na, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
         if (hipMemcpy(na, d->arena, bytes, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(na); (void)hipGetLastError(); break; }
         char *old = static_cast<char *>(d->arena);
@@ -302,41 +303,21 @@ int tune_placement(Plan &p, int trials, const void *dX, void *dY, double *ms_fir
     }
     if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
     if (ms_kept) *ms_kept = best;
-    // the allocations that lost go back now -- and the driver wipes released VRAM in the background, which costs the kernels 1-3 % for the
-    // next 50-500 ms, by how much was released (seen as a 2.8 % slower timed region right behind six trials on a box where none of them was
-    // faster).  Let that pass here, at set-up, not under the caller's first products: launches until they run as fast as the kept
-    // allocation did.
-    const size_t freed_bytes = losers.size() * bytes;
-    const bool freed = !losers.empty();
+    // the allocations that lost go back now (the driver wipes released VRAM in the background: see the note above)
     for (void *q : losers) (void)hipFree(q);
     losers.clear();
-    if (freed) {
-        // ~35 GB/s of wiping was seen (5.3 GB: 0.15 s of slower launches); wait for 20 GB/s worth, then check with launches
-        std::this_thread::sleep_for(std::chrono::duration<double>(std::min(1.0, (double)freed_bytes / 20e9)));
-        const auto t0 = std::chrono::steady_clock::now();
-        double ms = 0.0, prev = 0.0;
-        int rounds = 0, steady = 0;
-        // done when the kernel is back at the kept allocation's speed, or has stopped changing (three rounds within 0.3 % of each other)
-        while (time_it(&ms) && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 0.5) {
-            ++rounds;
-            if (ms <= 1.004 * best) break;
-            steady = prev > 0.0 && std::fabs(ms - prev) <= 0.003 * ms ? steady + 1 : 0;
-            if (steady >= 3) break;
-            prev = ms;
-        }
-        if (verbose) std::fprintf(stderr, "[dasp placement] settled after %d more rounds (%.4f ms)\n", rounds, ms);
-    }
     cleanup();
     return DASP_OK;
 }
 
-// host-built plans: the trials are part of the upload (a few ms next to the packing).  Plans packed on the device
-// (dasp_plan_create_device: creation time is the metric there) leave them to the caller: dasp_plan_tune_placement.
+// host-built plans: trials at upload only when asked for (DASP_PLACEMENT_TRIALS=n > 1); everybody else calls dasp_plan_tune_placement -- or nothing
 int upload_plan(Plan &p)
 {
     const bool fresh = !(p.host_dropped && p.dev);
     if (int rc = upload_plan_impl(p)) return rc;
-    return fresh ? tune_placement(p, 0, nullptr, nullptr, nullptr, nullptr) : DASP_OK;
+    int trials = 1;
+    if (const char *e = std::getenv("DASP_PLACEMENT_TRIALS")) trials = std::max(1, std::min(8, std::atoi(e)));
+    return fresh && trials > 1 ? tune_placement(p, trials, nullptr, nullptr, nullptr, nullptr) : DASP_OK;
 }
 // the arena with every O(rows) array, the nnz-sized regions left for the device packers (devpack.hip)
 int upload_plan_unpacked(Plan &p) { return upload_plan_impl(p); }

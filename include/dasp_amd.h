@@ -206,16 +206,17 @@ int dasp_plan_create(dasp_plan_t **plan, int precision, int rowA, int colA, int 
  * automatic choices (only hybrid x windows are decided on a host CSR alone). */
 int dasp_plan_create_device(dasp_plan_t **plan, int precision, int rowA, int colA, int nnzA,
                             const int *dRowPtr, const int *dColIdx, const void *dVal, const dasp_options_t *opt);
-/* Placement trials (r3): the same packed bytes run the HBM-bound kernels at one of two speeds ~8 % apart depending on where the plan's
- * device allocation landed (profiles/r03_placement.md).  Times a few launches with scratch operands, copies the arena into up to
- * `trials` - 1 fresh allocations (<= 0: DASP_PLACEMENT_TRIALS, default 6; they are all alive until the trials end), keeps the fastest.  Only plans that stream >= 256 MiB and have
- * no x windows / column panels; others return at once.  dasp_plan_upload runs it by itself for host-built plans (DASP_PLACEMENT_TRIALS=1
- * turns that off); a plan from dasp_plan_create_device leaves it to the caller (its creation time is a metric of its own).
- * dX / dY: the caller's own device vectors (x_len / rowA elements; dY is overwritten), or NULL for scratch ones -- where x and y sit takes
- * part in the effect, so a solver that keeps its vectors should lend them.  ms_first / ms_kept (may be NULL): the time of the first and of
- * the kept allocation, 0 when nothing was tried.  Synchronises the device; results of later products are unchanged (same bytes).
- * Cost: ~5 ms per trial for a 2.6-GB plan plus 0.1-1 s while the driver wipes the released allocations (waited for here, so that the caller's first products are not slowed) -- it pays for itself after a
- * few thousand products; DASP_PLACEMENT_TRIALS=1 for plans that live shorter. */
+/* Placement trials (r3; opt-in since r4): the same packed bytes run the HBM-bound kernels at one of two speeds ~8 % apart depending on where the
+ * plan's device allocation and the written vector y landed relative to each other (profiles/r03_placement.md, r04_placement.md).  Copies the arena
+ * into up to `trials` - 1 fresh allocations (<= 0: 2, i.e. ONE extra allocation; never when the device has less free memory than the arena + 1 GiB),
+ * times each with dX / dY and keeps the fastest; the others are freed before the call returns.  No sleeps, no launches behind the trials: the driver
+ * wipes released VRAM in the background (~35 GB/s) and kernels run 1-3 % slower meanwhile.  Only plans that stream >= 256 MiB and have no x windows
+ * / column panels; others return at once.  dasp_plan_upload does NOT run it (r3 did) unless DASP_PLACEMENT_TRIALS=n > 1 is set; the one-shot
+ * dasp_spmv_all_* never does.
+ * dX / dY: the caller's own device vectors (x_len / rowA elements; dY is overwritten), or NULL for scratch ones -- it is y's placement against the
+ * arena's that decides, so a solver that keeps its vectors should lend them (or simply try a few y allocations of its own: 16 MB each instead of a
+ * copy of the plan).  ms_first / ms_kept (may be NULL): the time of the first and of the kept allocation, 0 when nothing was tried.  Synchronises the
+ * device; results of later products are unchanged (same bytes). */
 int dasp_plan_tune_placement(dasp_plan_t *plan, int trials, const void *dX, void *dY, double *ms_first, double *ms_kept);
 /* copy one nnz-sized packed array (names as dasp_plan_host_array) from the device arena to `dst` (tests, serialisation) */
 int dasp_plan_download_array(dasp_plan_t *plan, const char *name, void *dst, size_t bytes);

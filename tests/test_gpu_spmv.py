@@ -1178,15 +1178,15 @@ def test_bench_rccl_calls_run_at_world_size_one(torch_cuda):
 
 def test_placement_trials_keep_the_bytes_and_the_results(dasp, torch_cuda, monkeypatch):
     """dasp_plan_tune_placement: the arena is copied into fresh allocations and the fastest kept -- products before and after are
-    bit-identical, the packed arrays read back the same, a plan below 256 MiB is left alone, dasp_plan_upload runs the trials by itself
-    for a host-built plan unless DASP_PLACEMENT_TRIALS=1, and a plan built from a device CSR only on request."""
+    bit-identical, the packed arrays read back the same, a plan below 256 MiB is left alone.  OPT-IN since r4: dasp_plan_upload runs no
+    trial unless DASP_PLACEMENT_TRIALS=n > 1 asks for it, a plan built from a device CSR only on request."""
     torch = torch_cuda
     rows, cols = dasp.synth_dims("HV15R", 0.12)
     rp, ci = dasp.synth_csr("HV15R", 0.12)
     v = np.random.default_rng(11).uniform(-1, 1, ci.size)
     x = np.random.default_rng(12).uniform(0.5, 1.5, cols)
-    monkeypatch.setenv("DASP_PLACEMENT_TRIALS", "1")
-    plan = dasp.Plan(rp, ci, v, cols, y_order=dasp.Y_NATURAL).upload()
+    monkeypatch.delenv("DASP_PLACEMENT_TRIALS", raising=False)
+    plan = dasp.Plan(rp, ci, v, cols, y_order=dasp.Y_NATURAL).upload()          # no trials inside the upload
     assert plan.stats["data_X"] > (256 << 20)
     y0 = run_spmv(torch, plan, x, rows, 64)
     before = plan.download_array("med_val") if hasattr(plan, "download_array") else None
@@ -1197,8 +1197,9 @@ def test_placement_trials_keep_the_bytes_and_the_results(dasp, torch_cuda, monke
     if before is not None:
         np.testing.assert_array_equal(before, plan.download_array("med_val"))
     plan.close()
+    monkeypatch.setenv("DASP_PLACEMENT_TRIALS", "3")
+    plan = dasp.Plan(rp, ci, v, cols, y_order=dasp.Y_NATURAL).upload()          # trials inside the upload, on request
     monkeypatch.delenv("DASP_PLACEMENT_TRIALS")
-    plan = dasp.Plan(rp, ci, v, cols, y_order=dasp.Y_NATURAL).upload()          # trials inside the upload
     np.testing.assert_array_equal(run_spmv(torch, plan, x, rows, 64), y0)
     plan.close()
     d_rp, d_ci, d_v = (torch.from_numpy(a).cuda() for a in (rp, ci, v))

@@ -95,9 +95,37 @@ for rank in ranks:
             t = StreamTimer(s); t.start()
             for _ in range(100): mg.product(s)
             ms = t.stop(); torch.cuda.synchronize()
+            os.environ["DASP_MG_STEP2_ALLFREE"] = "1"
+            for _ in range(10): mg.product(s)
+            torch.cuda.synchronize()
+            t = StreamTimer(s); t.start()
+            for _ in range(100): mg.product(s)
+            ms2 = t.stop(); torch.cuda.synchronize()
+            line += " | ... and every workgroup dispatched at once %.1f" % (ms2 / 100 * 1e3)
+            for fm, what in ((99, "the plan's own order, no tables"), (98, "block order table only")):
+                os.environ["DASP_MG_STEP2_FENCE"] = str(fm)
+                for _ in range(10): mg.product(s)
+                torch.cuda.synchronize()
+                t = StreamTimer(s); t.start()
+                for _ in range(100): mg.product(s)
+                ms3 = t.stop(); torch.cuda.synchronize()
+                line += " | %s %.1f" % (what, ms3 / 100 * 1e3)
+            os.environ.pop("DASP_MG_STEP2_FENCE")
+            os.environ["DASP_MG_STEP2_ALLFREE"] = "0"
             os.environ["DASP_MG_STEP2_NOPUSH"] = "0"
             line += " | step kernel without the stores to the peers and without the wait %.1f" % (ms / 100 * 1e3)
+            for fm in (0, 1, 3, 2):
+                os.environ["DASP_MG_STEP2_FENCE"] = str(fm)
+                mg.set_x(np.ones(cols))
+                line += " | fence mode %d: %.1f" % (fm, step_time(mg, 200))
+            os.environ.pop("DASP_MG_STEP2_FENCE")
         t_own = own.time(x.data_ptr(), y.data_ptr(), s, warmup=5, iters=100)[1] * 1e3
+        mg.set_x(np.ones(cols)); mg.product(s); torch.cuda.synchronize()          # k2 = 1: x in half 1, y_local = this rank's slot there
+        other_half = mg.gathered_ptr + (-1 if mg.gathered_ptr > mg.x_ptr else 1) * 0
+        t_fx = own.time(mg.gathered_ptr, y.data_ptr(), s, warmup=5, iters=100)[1] * 1e3
+        t_fy = own.time(x.data_ptr(), mg.y_local_ptr, s, warmup=5, iters=100)[1] * 1e3
+        t_fxy = own.time(mg.gathered_ptr, mg.y_local_ptr, s, warmup=5, iters=100)[1] * 1e3       # (x and y alias inside the same half: timing only)
+        line += " | plain kernel with fine-grained x %.1f, y %.1f, both %.1f" % (t_fx, t_fy, t_fxy)
         print(line + " | the plan alone (plain kernel, coarse x / y) %.1f us | data_X %.1f MB blocks %d" % (t_own, own.stats["data_X"] / 1e6, own.stats["n_med_blocks"]), flush=True)
         mg.close(); del x, y; torch.cuda.empty_cache()
         continue
