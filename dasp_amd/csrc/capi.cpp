@@ -258,14 +258,14 @@ static long long host_array_impl(const dasp_plan_t *plan, const char *name, cons
     if (n == "win_len") return ints(p.win_len);
     if (n == "short_val") return vals(p.short_val);
     if (n == "short_cid") return rints(p.short_cid);
-    if (n == "short_groups") {   // kNumShortGroups x {len,count,tiles,tile0,elem_off_lo,elem_off_hi,split,base0,base1,grp0,grp1,off0,off1}
+    if (n == "short_groups") {   // kNumShortGroups x {len,count,tiles,tile0,elem_off_lo,elem_off_hi,split,base0,base1,grp0,grp1,off0,off1,seg,rpt}
         static thread_local std::vector<int> flat;
         flat.clear();
         for (int g = 0; g < kNumShortGroups; ++g) {
             const ShortGroup &G = p.grp[g];
-            const int row[13] = {G.len, G.count, G.tiles, G.tile0, (int)(G.elem_off & 0xffffffffll), (int)(G.elem_off >> 32),
-                                 G.map.split, G.map.base[0], G.map.base[1], G.map.grp[0], G.map.grp[1], G.map.off[0], G.map.off[1]};
-            flat.insert(flat.end(), row, row + 13);
+            const int row[15] = {G.len, G.count, G.tiles, G.tile0, (int)(G.elem_off & 0xffffffffll), (int)(G.elem_off >> 32),
+                                 G.map.split, G.map.base[0], G.map.base[1], G.map.grp[0], G.map.grp[1], G.map.off[0], G.map.off[1], G.seg, G.rpt};
+            flat.insert(flat.end(), row, row + 15);
         }
         return ints(flat);
     }

@@ -12,6 +12,7 @@ struct ShortDev {
     int len, count, tiles, tile0;
     long long elem_off;
     SlotMap map;
+    int seg, rpt;        // ShortGroup::seg / rpt
 };
 
 struct DevArgs {

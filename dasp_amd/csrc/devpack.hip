@@ -195,14 +195,22 @@ __global__ void k_pack_medium(const int *rp, const int *ci, const T *val, const 
 // short slabs: one thread per (slab position, k); positions past the slab's row count are pads
 template <class T>
 __global__ void k_pack_short(const int *rp, const int *ci, const T *val, const int *list, int count, int tiles, int L, long long elem_off,
-                             int SR, RemapDev remap, T *sv, int *sc)
+                             int SR, int seg, RemapDev remap, T *sv, int *sc)
 {
-    const long long n = (long long)tiles * SR * L;
+    const long long n = (long long)tiles * short_tile_elems(seg != 0, L, SR);
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
-        const long long tile = e / ((long long)L * SR);
-        const int k = (int)((e / SR) % L), lr = (int)(e % SR);
-        const long long t = tile * SR + lr;
-        const bool in = t < count;
+        long long t; int k; bool in;
+        if (seg) {      // the inverse of plan.hpp short_elem_index: element e = tile * 64 + lane
+            const int lane = (int)(e & 63), sub = lane & 15, per16 = 16 / L, rloc = sub / L;
+            k = sub % L;
+            t = (e >> 6) * (4 * per16) + (lane >> 4) * per16 + rloc;
+            in = rloc < per16 && t < count;
+        } else {
+            const long long tile = e / ((long long)L * SR);
+            k = (int)((e / SR) % L);
+            t = tile * SR + (int)(e % SR);
+            in = t < count;
+        }
         const int a0 = in ? rp[list[t]] : 0;
         sv[elem_off + e] = in ? val[a0 + k] : (T)0;
         sc[elem_off + e] = in ? remap(ci[a0 + k]) : -1;
@@ -382,9 +390,9 @@ static int pack_all_typed(Plan &p, const DevCsr &d, const PackMeta &m)
         if (G.tiles == 0 || G.len == 0) continue;
         DevVec<int> dl;
         if (int rc = dl.init(*m.glist[g])) return rc;
-        const long long n = (long long)G.tiles * p.geo.short_rows * G.len;
+        const long long n = (long long)G.tiles * short_tile_elems(G.seg != 0, G.len, p.geo.short_rows);
         hipLaunchKernelGGL((k_pack_short<T>), dim3((unsigned)std::min<long long>((n + 255) / 256, 65535)), dim3(256), 0, 0, d.rp, d.ci, val,
-                           dl.d, G.count, G.tiles, G.len, G.elem_off, p.geo.short_rows, rm.r,
+                           dl.d, G.count, G.tiles, G.len, G.elem_off, p.geo.short_rows, G.seg, rm.r,
                            reinterpret_cast<T *>(base + dp.map.short_val), reinterpret_cast<int *>(base + dp.map.short_cid));
         HIP_TRYP(hipGetLastError());
         HIP_TRYP(hipDeviceSynchronize());

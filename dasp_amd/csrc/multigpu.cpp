@@ -163,9 +163,9 @@ void mg_step_marks(const Plan &p, const unsigned char *has_other, std::vector<un
         for (int i = n0; i < (int)cold.size(); ++i) blk_order.push_back(cold[(size_t)i]);
         for (int q = n0; q < n0 + n_hot; ++q) mark[(size_t)wg_long + q / kWavesPerWG] = 1;
     }
-    const int SR = p.geo.short_rows;
     for (int g = 0; g < kNumShortGroups; ++g) {
         const ShortGroup &G = p.grp[g];
+        const int SR = G.rpt > 0 ? G.rpt : p.geo.short_rows;          // rows of one tile of this group (slab or wave-segmented)
         for (int lt = 0; lt < G.tiles; ++lt) {
             const int t = G.tile0 + lt;
             for (int tt = lt * SR; tt < std::min(G.count, (lt + 1) * SR); ++tt) {

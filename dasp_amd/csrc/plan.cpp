@@ -955,16 +955,21 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     }
 
     lap("pack medium");
-    // ---- short rows: one slab per length, tile-major [tile][k][short_rows]
+    // ---- short rows: one slab per length, tile-major [tile][k][short_rows] -- or, for the rows of 1..4 nonzeros, the wave-segmented layout
+    // (opt.short_seg, plan.hpp short_elem_index): auto = f64 plans without x windows (the windowed kernels are held to 64 registers and
+    // spill more with the DPP path compiled in: cop20k_A 11.1 -> 12.0 us; f16 gains nothing: DESIGN.md section 3)
     {
         const int SR = geo.short_rows;
+        const bool seg = p.opt.short_seg > 0 || (p.opt.short_seg == 0 && !f16 && !p.windowed);
         long long off = 0; int tile0 = 0;
         for (int g = 0; g < kNumShortGroups; ++g) {
             ShortGroup &G = p.grp[g];
-            G.tiles = ceil_div(G.count, SR);
+            G.seg = seg && !p.windowed && G.len >= 1 && G.len <= 4 && g < 5 ? 1 : 0;
+            G.rpt = G.seg ? short_seg_rows(G.len) : SR;
+            G.tiles = ceil_div(G.count, G.rpt);
             G.tile0 = tile0; G.elem_off = off;
             tile0 += G.tiles;
-            off += (long long)G.tiles * SR * G.len;
+            off += (long long)G.tiles * short_tile_elems(G.seg != 0, G.len, SR);
         }
         if (off >= (1LL << 40)) { set_error("short segment too large"); return DASP_ERR_ARG; }
         p.cnt_short = (size_t)off;
@@ -975,7 +980,9 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         for (int g = 0; g < kNumShortGroups; ++g) {
             const ShortGroup &G = p.grp[g];
             if (G.tiles == 0 || G.len == 0) continue;
-            const size_t t0 = (size_t)G.elem_off + (size_t)(G.tiles - 1) * G.len * SR, t1 = t0 + (size_t)G.len * SR;
+            // pads: a slab's last tile only; a segmented group of 3 has an idle lane in every 16, so all of it is cleared first
+            const size_t te = (size_t)short_tile_elems(G.seg != 0, G.len, SR);
+            const size_t t0 = (size_t)G.elem_off + (G.seg && G.len == 3 ? 0 : (size_t)(G.tiles - 1) * te), t1 = (size_t)G.elem_off + (size_t)G.tiles * te;
             std::fill(sv + t0, sv + t1, (T)0);
             std::fill(p.short_cid.begin() + t0, p.short_cid.begin() + t1, -1);
         }
@@ -986,9 +993,8 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             parallel_for(G.count, threads, 1 << 14, [&](long long b, long long e) {
                 for (long long t = b; t < e; ++t) {
                     const int row = list[t], a0 = rp[row];
-                    const size_t tile = (size_t)(t / SR), lr = (size_t)(t % SR);
                     for (int k = 0; k < G.len; ++k) {
-                        const size_t at = (size_t)G.elem_off + (tile * G.len + k) * SR + lr;
+                        const size_t at = (size_t)G.elem_off + short_elem_index(G.seg != 0, G.len, SR, t, k);
                         sv[at] = val[a0 + k];
                         p.short_cid[at] = remap(ci[a0 + k]);
                     }
@@ -1004,6 +1010,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     std::memset(&s, 0, sizeof s);
     s.precision = p.precision; s.rowA = m; s.colA = p.n; s.nnzA = nnz;
     s.short_row_1 = n1; s.common_13 = c13; s.short_row_3 = n3; s.short_row_4 = n4; s.short_row_2 = n2;
+    s.short_seg = p.grp[0].seg | p.grp[1].seg | p.grp[2].seg | p.grp[3].seg;
     s.row_long = nlong_cls; s.row_block = nmed_all; s.row_zero = nz0; s.med_rows_as_pieces = nsp; s.chunk_pairs = p.pair_mode; s.cid8_chunks = p.med_c8ptr.empty() ? 0 : p.med_c8ptr.back();
     s.nnz_short = nnz_short; s.nnz_long = (int)nnz_long; s.nnz_irreg = nnz_irreg;
     s.origin_nnz_reg = nnz - nnz_irreg - (int)nnz_long - nnz_short;

@@ -109,11 +109,37 @@ struct SlotMap {
 struct ShortGroup {
     int len = 0;            // nonzeros per row (0..4)
     int count = 0;          // rows
-    int tiles = 0;          // ceil(count / short_rows)
+    int tiles = 0;          // ceil(count / rpt)
     int tile0 = 0;          // index of this group's first tile among all short tiles
     long long elem_off = 0; // first element in short_val / short_cid
     SlotMap map{};
+    int seg = 0;            // 1: wave-segmented layout (short_seg_*): one nonzero per lane, rows back to back, DPP row-shift sums
+    int rpt = 0;            // rows one wave handles: geo.short_rows for a slab, short_seg_rows(len) for a segmented group
 };
+
+// Wave-segmented short rows (opt.short_seg; the north_star's "wavefront-segmented dot product with DPP reductions", reference branches
+// dasp_f64.h:281-483).  A tile is 64 ELEMENTS = one per lane of one wave: every 16-lane DPP row holds 16 / L whole rows of L nonzeros back to
+// back (L = 3: five rows and one idle lane), so that a row is summed by two DPP row_shl steps inside its 16 lanes and the lanes that hold a
+// row's first nonzero store y.  Element (row t of the group, entry k) -> index inside the group's region; shared by the host packer, the
+// device packer, the plan validator and the test decoder (tests/util.py).
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int short_seg_rows(int L) { return 4 * (16 / L); }                        // rows per tile: 64, 32, 20, 16
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline size_t short_elem_index(bool seg, int L, int SR, long long t, int k)
+{
+    if (!seg) return ((size_t)(t / SR) * L + k) * SR + (size_t)(t % SR);                     // slab: [tile][k][SR]
+    const int per16 = 16 / L, rpw = 4 * per16, r = (int)(t % rpw);
+    return (size_t)(t / rpw) * kWave + (size_t)((r / per16) * 16 + (r % per16) * L + k);  // [tile][lane]
+}
+// elements of one tile of a group
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int short_tile_elems(bool seg, int L, int SR) { return seg ? kWave : L * SR; }
 
 struct DevicePlan;  // kernels.hip
 }  // namespace dasp

@@ -186,8 +186,10 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
     for (int g = 0; g < kNumShortGroups; ++g) {
         const ShortGroup &G = p.grp[g];
         if (G.len != (g < 5 ? kLen[g] : g) || G.count < 0 || G.count > m) return fail("short group length / count");
-        if (G.tiles != (G.count + SR - 1) / SR || G.tile0 != tile0 || G.elem_off != off) return fail("short group tiles / offsets");
-        tile0 += G.tiles; off += (long long)G.tiles * SR * G.len;
+        const bool seg_ok = G.seg == 0 || (G.seg == 1 && G.len >= 1 && G.len <= 4 && !p.windowed);
+        if (!seg_ok || G.rpt != (G.seg ? short_seg_rows(G.len) : (int)SR)) return fail("short group layout");
+        if (G.tiles != (G.count + G.rpt - 1) / G.rpt || G.tile0 != tile0 || G.elem_off != off) return fail("short group tiles / offsets");
+        tile0 += G.tiles; off += (long long)G.tiles * short_tile_elems(G.seg != 0, G.len, (int)SR);
         const SlotMap &M = G.map;
         if (M.split < 0 || M.grp[0] < 0 || M.grp[1] < 0) return fail("slot map");
         for (int t : {0, M.split - 1, M.split, G.count - 1})

@@ -626,6 +626,41 @@ __device__ __forceinline__ void short_rows(const DevArgs &a, const ShortDev &g, 
     }
 }
 
+// ---- short rows, wave-segmented (ShortGroup::seg; plan.hpp short_elem_index): one wave = one tile of 64 ELEMENTS, one nonzero per lane; every
+// 16-lane DPP row holds 16 / L whole rows back to back (L = 3: five rows, lane 15 idle).  The products of a row are summed towards its first
+// lane with two DPP row shifts -- lane i adds lane i + 1, then the head adds lane i + 2: (p0 + p1) + (p2 + p3) -- and the head lanes store y:
+// the north_star's "wavefront-segmented dot product with DPP reductions" (reference: the four short-row branches of dasp_spmv2,
+// dasp_f64.h:281-483, which fill 8x4 MMA tiles with pairs of short rows instead).
+template <class T, int L, bool NT, int YS = 0>
+__device__ __forceinline__ void short_rows_seg(const DevArgs &a, const ShortDev &g, int local_tile, int lane)
+{
+    constexpr int PER16 = 16 / L, RPW = 4 * PER16;
+    using part_t = typename Tr<T>::part_t;
+    const T *x = static_cast<const T *>(a.x);
+    const int sub = lane & 15, rloc = sub / L, k = sub - rloc * L;
+    const int t = local_tile * RPW + (lane >> 4) * PER16 + rloc;          // the row of the group this lane works for
+    const size_t e = (size_t)g.elem_off + (size_t)local_tile * kWave + (size_t)lane;
+    const T av = ldg<NT>(static_cast<const T *>(a.short_val) + e);
+    const int c = ldg<NT>(a.short_cid + e);
+    const T xv = x[c < 0 ? 0 : c];                                        // pads (idle lanes, the tile behind the last row): clamped gather, value dropped
+    part_t p = c < 0 ? (part_t)0 : (part_t)av * (part_t)xv;
+    if constexpr (L >= 2) {
+        part_t q;
+        if constexpr (sizeof(part_t) == 8) q = dpp_mov_f64<0x101>(p); else q = dpp_mov_f32<0x101>(p);      // row_shl:1 -- lane i reads lane i + 1
+        if (k + 1 < L) p += q;
+    }
+    if constexpr (L >= 3) {
+        part_t q;
+        if constexpr (sizeof(part_t) == 8) q = dpp_mov_f64<0x102>(p); else q = dpp_mov_f32<0x102>(p);      // row_shl:2
+        if (k == 0) p += q;
+    }
+    if (k == 0 && rloc < PER16 && t < g.count) {
+        const int slot = slot_of(g.map, t);
+        const int yi = a.order ? a.order[slot] : slot;
+        put_y<T, YS>(a, yi, p);
+    }
+}
+
 // the same for the medium rows stored as slabs (5 <= L <= kSlabMaxLen): L is a run-time value, four steps in flight
 template <class T, bool NT, int YS = 0>
 __device__ __forceinline__ void slab_rows(const DevArgs &a, const ShortDev &g, int local_tile, int lane)
@@ -670,7 +705,9 @@ __device__ __forceinline__ void slab_rows(const DevArgs &a, const ShortDev &g, i
     }
 }
 
-template <class T, bool NT, int YS = 0>
+// SEG: the wave-segmented short-row path is compiled in (not in the windowed kernels: they are held to 64 registers, and windowed plans never
+// store segmented groups)
+template <class T, bool NT, int YS = 0, bool SEG = true>
 __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
 {
     int gi = 0;
@@ -684,6 +721,17 @@ __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
         __builtin_memcpy(&g, w, sizeof g);
     } else g = a.groups[gi];
     const int local = tile - g.tile0;
+    if constexpr (SEG) {
+        if (g.seg) {
+            switch (g.len) {
+                case 1: short_rows_seg<T, 1, NT, YS>(a, g, local, lane); break;
+                case 2: short_rows_seg<T, 2, NT, YS>(a, g, local, lane); break;
+                case 3: short_rows_seg<T, 3, NT, YS>(a, g, local, lane); break;
+                default: short_rows_seg<T, 4, NT, YS>(a, g, local, lane); break;
+            }
+            return;
+        }
+    }
     switch (g.len) {
         case 0: if constexpr (YS != 2) short_rows<T, 0, NT, YS>(a, g, local, lane); break;    // empty rows: y = 0 (y += 0: nothing to do)
         case 1: short_rows<T, 1, NT, YS>(a, g, local, lane); break;
@@ -788,7 +836,7 @@ __device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw)
         }
     } else {
         const int t = (wg - a.wg_long - a.wg_med) * wpw + wave;
-        if (t < a.n_short_tiles) short_tile<T, NT>(a, t, lane);
+        if (t < a.n_short_tiles) short_tile<T, NT, 0, !WIN>(a, t, lane);
     }
 }
 

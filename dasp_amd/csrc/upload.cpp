@@ -68,6 +68,7 @@ static int upload_plan_impl(Plan &p)
     for (int g = 0; g < kNumShortGroups; ++g) {
         groups[g].len = p.grp[g].len; groups[g].count = p.grp[g].count; groups[g].tiles = p.grp[g].tiles;
         groups[g].tile0 = p.grp[g].tile0; groups[g].elem_off = p.grp[g].elem_off; groups[g].map = p.grp[g].map;
+        groups[g].seg = p.grp[g].seg; groups[g].rpt = p.grp[g].rpt;
     }
     const bool natural = p.opt.y_order == DASP_Y_NATURAL;
     const size_t part_bytes = (size_t)std::max<size_t>(1, p.multi_ptr.empty() ? 0 : (size_t)p.multi_ptr.back()) * 8;

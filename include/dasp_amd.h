@@ -155,6 +155,13 @@ typedef struct dasp_options {
      * the chunk's base column in one byte; such chunks are moved to the front of their block's paired region in whole pipeline batches
      * (the order of a block's MFMA steps is free), a batch's ids being one dword per lane.  0 = auto (on wherever it applies); -1 = off. */
     int cid8;
+    /* wave-segmented short rows (BASELINE north_star; reference branches dasp_f64.h:281-483): rows of 1..4 nonzeros stored back to back, ONE
+     * nonzero per lane, every 16-lane DPP row holding 16 / L whole rows; a row is summed with two DPP row_shl steps and the lane holding its
+     * first nonzero stores y -- instead of uniform-length slabs in which a lane owns whole rows (no cross-lane step, 16-byte loads, half to a
+     * quarter as many waves).  0 = auto: on for f64 plans without x windows (same-device A/B: webbase-1M f64 30.6 -> 28.4 us, powerlaw_1M
+     * 0.668 -> 0.662 ms; f16 and the windowed kernels lose); -1 = off (slabs); 1 = on.  order_rid, every counter
+     * and the order of a row's products are unchanged; the sum of a row of 4 is (p0 + p1) + (p2 + p3) instead of ((p0 + p1) + p2) + p3. */
+    int short_seg;
 } dasp_options_t;
 
 void dasp_options_default(dasp_options_t *opt);
@@ -184,6 +191,7 @@ typedef struct dasp_stats {
     int med_rows_as_pieces;    /* medium rows (the longest ones: the first medium slots) stored as pieces (piece_min_len) */
     int chunk_pairs;           /* 0 / 1 / 2: which medium blocks store chunk pairs (options chunk_pairs; column panels: the largest) */
     int cid8_chunks;           /* regular medium chunks with one-byte column ids (option cid8) */
+    int short_seg;             /* 1: the short rows (1..4 nonzeros) use the wave-segmented DPP layout */
     /* the REFERENCE's geometry on the same input (8-row blocks, 8x4 tiles, 32-lane warps): the padded sizes the CUDA reference computes
      * and writes into its CSV row for this matrix -- short tiles dasp_f64.h:609-629 / dasp_f16.h:1139-1156, long rows :1000-1014 /
      * :1273-1288, regular / irregular split :1044-1091 / :1317-1365, rate_fill0 and data_X :1159-1166 / dasp_f16.h:1448-1455.  Functions

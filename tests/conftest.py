@@ -24,3 +24,11 @@ def dasp():
     import dasp_amd
     dasp_amd._lib.lib()
     return dasp_amd
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU; there is no CPU fallback to hide behind"
+    torch.cuda.set_device(0)
+    return torch

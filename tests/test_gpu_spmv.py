@@ -18,14 +18,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = {64: 1e-12, 16: 1e-2}
 
 
-@pytest.fixture(scope="module")
-def torch_cuda():
-    import torch
-    assert torch.cuda.is_available(), "GPU tests need a GPU; there is no CPU fallback to hide behind"
-    torch.cuda.set_device(0)
-    return torch
-
-
 def tdtype(torch, prec):
     return torch.float64 if prec == 64 else torch.float16
 
@@ -982,13 +974,47 @@ def test_bench_bare_multi_gpu_launch_needs_that_many_devices(torch_cuda):
     assert r.returncode == 4 and "need 2 devices" in r.stderr
 
 
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("seg", [1, -1])
+@pytest.mark.parametrize("natural", [0, 1])
+def test_wave_segmented_short_rows_against_the_oracle(oracle, dasp, torch_cuda, prec, seg, natural):
+    """short_seg: rows of 1..4 nonzeros as one nonzero per lane with DPP row-shift sums (the north_star's short-row path) or as slabs --
+    same order_rid, same counters, y == the oracle's CSR product either way.  The matrix is short rows almost only (every length 0..4
+    many times over, counts that leave partial tiles in every group, 1&3 pairing active), plus a few medium / long rows."""
+    torch = torch_cuda
+    rng = np.random.default_rng(17)
+    m, n = 50011, 30000
+    lens = rng.choice([0, 1, 2, 3, 4, 9, 300], size=m, p=[0.05, 0.3, 0.2, 0.25, 0.19, 0.009, 0.001])
+    rp = np.zeros(m + 1, np.int32); rp[1:] = np.cumsum(lens)
+    ci = rng.integers(0, n, rp[-1]).astype(np.int32)
+    dt = np.float64 if prec == 64 else np.float16
+    v = rng.uniform(0.5, 1.5, rp[-1]).astype(dt)
+    x = rng.uniform(0.5, 1.5, n).astype(dt)
+    plan = dasp.Plan(rp, ci, v, n, precision=prec, short_seg=seg, x_window=-1, y_order=natural)
+    assert plan.stats["short_seg"] == (1 if seg == 1 else 0) and plan.stats["common_13"] > 0
+    P = oracle.Packed(prec, rp, ci, v.astype(np.float64), n)
+    assert (plan.order_rid == P.order_rid).all()
+    rows = util.decode_plan(plan)
+    for slot in rng.integers(0, m, 2000):
+        r = plan.order_rid[slot]
+        assert rows[int(slot)][0] == ci[rp[r]:rp[r + 1]].tolist()
+    got = run_spmv(torch, plan.upload(), x, m, prec)
+    ref = oracle.csr_spmv(rp, ci, v.astype(np.float64), x.astype(np.float64))
+    scale = oracle.csr_absrow(rp, ci, v.astype(np.float64), x.astype(np.float64))
+    if not natural:
+        ref, scale = ref[plan.order_rid], scale[plan.order_rid]
+    assert (np.abs(got - ref) <= TOL[prec] * np.maximum(scale, 1e-300)).all()
+    plan.close()
+
+
 NNZ_ARRAYS = ("long_val long_cid med_val med_cid med_cid16 med_cid8 med_base irr_val irr_cid short_val short_cid").split()
 META_ARRAYS = ("piece_ptr piece_dst multi_ptr multi_dst med_ptr med_c8ptr med_korig irr_ptr med_dst win_cmin win_len short_groups").split()
 
 
 @pytest.mark.parametrize("prec", [64, 16])
 @pytest.mark.parametrize("kw", [dict(), dict(cid16=1, chunk_pairs=2), dict(cid16=-1, x_window=-1, chunk_pairs=-1), dict(x_window=100000, y_order=1), dict(x_window=-1, chunk_pairs=2, slab_max_len=4),
-                                dict(part_bounds=np.array([0, 700, 2500], np.int32), part_stride=2048, y_order=1, cid16=1)])
+                                dict(part_bounds=np.array([0, 700, 2500], np.int32), part_stride=2048, y_order=1, cid16=1),
+                                dict(x_window=-1, short_seg=1), dict(x_window=-1, short_seg=-1, y_order=1)])
 @pytest.mark.parametrize("tag,builder,m,n,seed", [("mixed", util.mixed_matrix, 3000, 2500, 7), ("pairs", util.pair_heavy_matrix, 4000, 2500, 11)])
 def test_device_packed_plan_is_bit_identical(oracle, dasp, torch_cuda, prec, kw, tag, builder, m, n, seed):
     """dasp_plan_create_device (CSR on the GPU, packed by kernels) == dasp_plan_create (host packers), array by array,

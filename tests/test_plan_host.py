@@ -32,11 +32,11 @@ def test_counts_and_order_match_oracle(dasp, oracle, prec, tag, builder, m, n, s
 
 @pytest.mark.parametrize("prec", [64, 16])
 @pytest.mark.parametrize("tag,builder,m,n,seed", CASES)
-@pytest.mark.parametrize("piece", [0, 256])
-def test_native_format_decodes_to_csr(dasp, prec, tag, builder, m, n, seed, piece):
+@pytest.mark.parametrize("piece,seg", [(0, 0), (256, 0), (0, 1), (0, -1)])
+def test_native_format_decodes_to_csr(dasp, prec, tag, builder, m, n, seed, piece, seg):
     dt = np.float64 if prec == 64 else np.float16
     rp, ci, v = builder(m, n, seed, values="f16" if prec == 16 else "uniform", dtype=dt)
-    plan = dasp.Plan(rp, ci, v, n, precision=prec, long_piece=piece)
+    plan = dasp.Plan(rp, ci, v, n, precision=prec, long_piece=piece, short_seg=seg)      # short rows: slabs / wave-segmented (auto: f64 segmented, f16 slabs)
     rows = util.decode_plan(plan)
     order = plan.order_rid
     assert sorted(rows) == list(range(m))

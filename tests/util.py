@@ -37,7 +37,7 @@ def pair_heavy_matrix(m, n_cols, seed, values="uniform", dtype=np.float64):
 
 
 def slot_of(g, t):
-    """g = 13-int row of Plan.host_array('short_groups')"""
+    """g = 15-int row of Plan.host_array('short_groups')"""
     split, base, grp, off = g[6], (g[7], g[8]), (g[9], g[10]), (g[11], g[12])
     p = 0 if t < split else 1
     u = t - split if p else t
@@ -165,14 +165,20 @@ def decode_plan(plan):
             assert slot not in out
             out[slot] = (cs, vs)
     # short rows
-    sg = plan.host_array("short_groups").reshape(-1, 13)
+    sg = plan.host_array("short_groups").reshape(-1, 15)
     sv, sc = plan.host_array("short_val"), plan.host_array("short_cid")
     for g in sg:
         L, count, tiles, tile0 = int(g[0]), int(g[1]), int(g[2]), int(g[3])
         eoff = int(g[4]) & 0xFFFFFFFF | (int(g[5]) << 32)
+        seg = int(g[13])
         for t in range(count):
-            tile, lr = divmod(t, SR)
-            at = [eoff + (tile * L + k) * SR + lr for k in range(L)]
+            if seg:          # wave-segmented layout (plan.hpp short_elem_index): [tile][lane], 16 / L rows per 16 lanes
+                per16 = 16 // L
+                tile, r = divmod(t, 4 * per16)
+                at = [eoff + tile * 64 + (r // per16) * 16 + (r % per16) * L + k for k in range(L)]
+            else:
+                tile, lr = divmod(t, SR)
+                at = [eoff + (tile * L + k) * SR + lr for k in range(L)]
             slot = slot_of(g, t)
             assert slot not in out
             out[slot] = ([int(sc[a]) for a in at], [sv[a] for a in at])
