@@ -256,6 +256,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     // ---- classifier: same tests in the same order as dasp_f64.h:499-531.  Two passes over row ranges (count, then fill from the
     // ranges' prefix sums): every list comes out in row order, exactly what the reference's serial loop produces.
     int n1 = 0, n2 = 0, n3 = 0, n4 = 0, nz0 = 0, nlong = 0, nmed = 0;
+    const int *scan = p.scan_order;      // a column panel: the parent's slot order (Plan::scan_order); everybody else: row order, as the reference's serial loop
     // category of a row: 0 = len 1, 1 = len 3, 2 = len 2, 3 = empty, 4 = len 4, 5 = long, 6 = medium
     auto cat_of = [block_longest](int len) { return len == 1 ? 0 : len == 3 ? 1 : len == 2 ? 2 : len == 0 ? 3 : len == 4 ? 4 : len >= block_longest ? 5 : 6; };
     const int cparts = (int)std::max<long long>(1, std::min<long long>(threads, ((long long)m + (1 << 16) - 1) >> 16));
@@ -265,7 +266,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         for (long long t = t0; t < t1; ++t) {
             std::array<int, 7> c{};
             c.fill(0);
-            for (long long i = (long long)m * t / cparts, e = (long long)m * (t + 1) / cparts; i < e; ++i) c[(size_t)cat_of(rp[i + 1] - rp[i])]++;
+            for (long long i = (long long)m * t / cparts, e = (long long)m * (t + 1) / cparts; i < e; ++i) { const int r = scan ? scan[i] : (int)i; c[(size_t)cat_of(rp[r + 1] - rp[r])]++; }
             ccnt[(size_t)t + 1] = c;
         }
     });
@@ -280,8 +281,9 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             for (long long t = t0; t < t1; ++t) {
                 std::array<int, 7> at = ccnt[(size_t)t];
                 for (long long i = (long long)m * t / cparts, e = (long long)m * (t + 1) / cparts; i < e; ++i) {
-                    const int k = cat_of(rp[i + 1] - rp[i]);
-                    lists[k][at[(size_t)k]++] = (int)i;
+                    const int r = scan ? scan[i] : (int)i;
+                    const int k = cat_of(rp[r + 1] - rp[r]);
+                    lists[k][at[(size_t)k]++] = r;
                 }
             }
         });
@@ -1215,10 +1217,12 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
                     q.opt.col_panels = 1; q.opt.host_threads = each;
                     if (q.opt.stream_policy == 0) q.opt.stream_policy = streams ? 2 : 1;   // the policy follows the whole matrix, not one panel
                     q.dst_map = slot_of_row; q.panel = true;
+                    // f16 only: 2-byte stores are where the partial lines hurt (ljournal-2008-uniform 0.590 -> 0.559 ms, ljournal-2008 0.506 -> 0.503; powerlaw_1M f64 0.651 -> 0.654)
+                    if (!natural && p.precision == 16 && !std::getenv("DASP_PANEL_ROW_SCAN")) q.scan_order = p.order.data();      // (DASP_PANEL_ROW_SCAN: A/B knob, the r3 order)
                     try { rcs[k] = build_impl<T>(q, rpP[k].data(), dev ? nullptr : ciP[k].data(), dev ? nullptr : valP[k].data(), dev ? &devP[(size_t)k] : nullptr, kPanel); }
                     catch (const std::bad_alloc &) { rcs[k] = DASP_ERR_NOMEM; set_error("out of host memory"); }
                     if (rcs[k] != DASP_OK) { errs[k] = last_error_cstr(); continue; }
-                    q.opt.host_threads = p.opt.host_threads;
+                    q.opt.host_threads = p.opt.host_threads; q.scan_order = nullptr;
                     std::vector<int>().swap(rpP[k]); raw_vector<int>().swap(ciP[k]); raw_vector<T>().swap(valP[k]);
                     built[k] = std::move(h);
                 }

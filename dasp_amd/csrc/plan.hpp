@@ -210,6 +210,10 @@ struct Plan {
     std::vector<std::unique_ptr<dasp_plan>> panels;
     std::vector<int> panel_bounds;     // [panels.size()+1] pairs flattened: begin/end per kept panel (empty panels are dropped)
     bool panel = false;                // this plan is one column panel of another
+    // (building a panel only) the order in which the classifier walks the rows: the parent's slot order instead of the row order, so that rows
+    // of equal length in THIS panel follow each other in the parent's slots -- a workgroup's partial results then fall into a narrow range of
+    // the parent-ordered partial buffer instead of all over it (the panels' 2-byte stores were a quarter of ljournal-2008's time)
+    const int *scan_order = nullptr;
     std::vector<int> dst_map;          // [m] set on a panel: row -> y index (instead of the row id) in natural order
 
     bool host_dropped = false;

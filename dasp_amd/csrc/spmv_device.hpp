@@ -733,7 +733,9 @@ __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
         }
     }
     switch (g.len) {
-        case 0: if constexpr (YS != 2) short_rows<T, 0, NT, YS>(a, g, local, lane); break;    // empty rows: y = 0 (y += 0: nothing to do)
+        // empty rows: y = 0 -- nothing to do for y += 0, nor for a column panel, whose partial-result buffer is zeroed ONCE at upload and never
+        // written at the slots of the rows that are empty in that panel (a third to a half of all (row, panel) pairs of the graph stand-ins)
+        case 0: if constexpr (YS != 2) { if (!a.skip0 && !a.acc) short_rows<T, 0, NT, YS>(a, g, local, lane); } break;
         case 1: short_rows<T, 1, NT, YS>(a, g, local, lane); break;
         case 2: short_rows<T, 2, NT, YS>(a, g, local, lane); break;
         case 3: short_rows<T, 3, NT, YS>(a, g, local, lane); break;

@@ -61,6 +61,7 @@ static int upload_plan_impl(Plan &p)
         d->ypart_stride = ((size_t)std::max(p.m, 1) + 127) & ~size_t(127);
         d->arena_bytes = d->ypart_stride * p.panels.size() * (size_t)p.geo.vbytes;
         HIP_TRY(hipMalloc(&d->arena, d->arena_bytes));
+        HIP_TRY(hipMemset(d->arena, 0, d->arena_bytes));      // the panels never store the rows that are empty in them (DevArgs::skip0)
         return DASP_OK;
     }
 
@@ -143,6 +144,7 @@ static int upload_plan_impl(Plan &p)
     a.n_windows = (int)p.win_len.size(); a.blocks_per_win = p.windowed ? p.row_window / kMedRows : 0;
     a.win_hybrid = p.win_hybrid ? 1 : 0; a.win_rel16 = p.win_rel16 ? 1 : 0; a.pair_mode = p.pair_mode;
     a.win_xcd = 1;
+    a.skip0 = p.panel ? 1 : 0;
     if (const char *e = std::getenv("DASP_WIN_XCD")) a.win_xcd = std::atoi(e);      // A/B knob
     d->win1 = false;
     if (p.windowed) {
