@@ -35,6 +35,7 @@ struct DevArgs {
     int win_hybrid;   // windows stage their densest span only: a gather outside [cmin, cmin + len) reads global memory
     int win_xcd;      // windows dealt to the XCDs in contiguous eighths (kernel)
     int win_rel16;    // 16-bit ids of an LDS-staged window are offsets from the window's first staged column (Plan::win_rel16)
+    int ywt;   // 1: y stores written through (f64 plans whose tiles stream from HBM; put_y)
     int skip0; // 1: the rows without nonzeros are not stored at all (column panels: their slots of the partial-result buffer stay 0 from upload on)
     int acc;   // 1: y += A x (every y index has exactly one writer per launch, so a plain read-modify-write is exact)
     int wpw;   // waves per workgroup of this launch (4, or blocks_per_win in windowed mode)

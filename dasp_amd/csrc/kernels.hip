@@ -246,6 +246,9 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate
     }
     DevArgs a = p.dev->args;
     a.x = dX; a.y = dY; a.acc = accumulate ? 1 : 0;
+    // one block / tile / piece per wave and then the wave ends: f64 plans without x windows and without a striding medium range
+    a.ywt = p.dev->nt && p.precision == 64 && !p.windowed && !a.med_stride && !p.panel ? 1 : 0;
+    if (const char *e = std::getenv("DASP_Y_WT")) a.ywt = a.ywt && std::atoi(e) != 0;      // A/B knob
 #ifdef DASP_EXPERIMENT
     if (const char *e = std::getenv("DASP_YSTORE")) a.ymode = std::atoi(e);
 #endif
