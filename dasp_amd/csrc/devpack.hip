@@ -146,7 +146,9 @@ __global__ void k_pack_medium(const int *rp, const int *ci, const T *val, const 
     if (b >= nb) return;
     const int c0 = med_ptr[b], nc = med_ptr[b + 1] - c0;
     const int r0 = b * kMedRows;
-    const int npair = med_npair(nc, (irr_ptr[r0 + 1] - irr_ptr[r0] + K - 1) / K, (int)sizeof(T), pair_mode);      // r0 < nmed: a block has at least one row
+    const int nt_b = (irr_ptr[r0 + 1] - irr_ptr[r0] + K - 1) / K;
+    const int npair = med_npair(nc, nt_b, (int)sizeof(T), pair_mode);      // r0 < nmed: a block has at least one row
+    const bool oneshot = med_oneshot64(nc, nt_b);
     const int rr = lane & 15, kq = lane >> 4, r = r0 + rr;
     const bool row_ok = r < nmed;
     const int a0 = row_ok ? rp[ridM[r]] : 0, len = row_ok ? lenM[r] : 0;
@@ -176,7 +178,7 @@ __global__ void k_pack_medium(const int *rp, const int *ci, const T *val, const 
 #pragma unroll
             for (int q = 0; q < VPL; ++q) {
                 mv[at + q] = v[q];
-                if (pos < n8) mc8[e8 + med_cid8_index(pos, lane, CH)] = col[q] < 0 ? (unsigned char)0xFF : (unsigned char)(col[q] - lo);      // f64 only: VPL = 1
+                if (pos < n8) mc8[e8 + med_cid8_index(pos, lane, CH, oneshot)] = col[q] < 0 ? (unsigned char)0xFF : (unsigned char)(col[q] - lo);      // f64 only: VPL = 1
                 else mc16[e16 + med_elem_index(npair - n8, pos - n8, lane, q, VPL, CH)] = col[q] < 0 ? (unsigned short)0xFFFF : (unsigned short)(col[q] - lo);
             }
         } else {

@@ -897,7 +897,9 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                 const size_t base = (size_t)p.med_ptr[b] * CH;
                 const int r0 = (int)b * kMedRows, r1 = std::min(nmed, r0 + kMedRows);
                 // tail steps of the block = those of its first (longest) row; with them the kernel decides one shot / pipeline, hence the layout
-                const int npair = med_npair(nc, (p.irr_ptr[r0 + 1] - p.irr_ptr[r0] + K - 1) / K, geo.vbytes, p.pair_mode);
+                const int nt_b = (p.irr_ptr[r0 + 1] - p.irr_ptr[r0] + K - 1) / K;
+                const int npair = med_npair(nc, nt_b, geo.vbytes, p.pair_mode);
+                const bool oneshot = med_oneshot64(nc, nt_b);          // (f64: the layout of the block's one-byte ids)
                 // cid16 mode: position q of the block holds the block's chunk korig[q]: n8 narrow chunks (columns span <= 254: one-byte ids) of
                 // the paired region first, everything else behind them in its original order
                 const int n8 = p.cid16 ? p.med_c8ptr[b + 1] - p.med_c8ptr[b] : 0;
@@ -943,7 +945,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                         mv[at] = val[a0 + i];
                         const int col = remap(ci[a0 + i]);
                         if (!p.cid16) p.med_cid[at] = col;
-                        else if (q < n8) p.med_cid8[e8 + med_cid8_index(q, lane, CH)] = (uint8_t)(col - lo_of[c]);
+                        else if (q < n8) p.med_cid8[e8 + med_cid8_index(q, lane, CH, oneshot)] = (uint8_t)(col - lo_of[c]);
                         else p.med_cid16[e16 + med_elem_index(npair - n8, q - n8, lane, j, VPL, CH)] = (uint16_t)(col - lo_of[c]);
                     }
                     const int t0 = p.irr_ptr[r], tl = p.irr_ptr[r + 1] - t0;

@@ -62,12 +62,24 @@ inline int med_npair(int nc, int nt, int vbytes, int mode)
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline size_t med_cid8_index(int q, int lane, int ch) { return (size_t)(q & ~3) * ch + 4 * (size_t)lane + (q & 3); }
-// how many narrow chunks a block keeps: those of its PIPELINED paired region (one-shot blocks keep 16-bit ids), in whole batches (f64)
+// (a pipelined block: its batch of four chunks interleaved per lane, one dword per lane and batch; a ONE-SHOT block (r4): its pair of
+// chunks interleaved per lane, one 16-bit word per lane and pair)
+inline size_t med_cid8_index(int q, int lane, int ch, bool oneshot = false)
+{
+    return oneshot ? (size_t)(q & ~1) * ch + 2 * (size_t)lane + (q & 1) : (size_t)(q & ~3) * ch + 4 * (size_t)lane + (q & 3);
+}
+// is a block of nc regular chunks and nt tail steps issued in one shot by the f64 kernel (no software pipeline)?
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline int med_n8(int narrow_in_paired_region, int nc, int nt) { return nc + nt > kMedShot64 ? narrow_in_paired_region / kMedBatch64 * kMedBatch64 : 0; }
+inline bool med_oneshot64(int nc, int nt) { return nc + nt <= kMedShot64; }
+// how many narrow chunks a block keeps: those of its paired region -- in whole batches of four in a pipelined block, in whole pairs in a
+// one-shot block (r4: nlpkkt160's rows of 5-28 nonzeros are one-shot blocks, 68 % of their chunks span <= 254 columns; a one-shot f64 block
+// has a paired region only in pair_mode 2, i.e. in plans far beyond the Infinity Cache)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int med_n8(int narrow_in_paired_region, int nc, int nt) { return nc + nt > kMedShot64 ? narrow_in_paired_region / kMedBatch64 * kMedBatch64 : narrow_in_paired_region / 2 * 2; }
 // where element j (< vpl) of lane `lane` of regular chunk c sits inside its block's region of med_val / med_cid / med_cid16 (in elements)
 #if defined(__HIPCC__)
 __host__ __device__

@@ -118,6 +118,10 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
         const long long r0 = b * kMedRows, K = CH / kMedRows;
         return med_npair((int)(p.med_ptr[(size_t)b + 1] - p.med_ptr[(size_t)b]), (int)((p.irr_ptr[(size_t)r0 + 1] - p.irr_ptr[(size_t)r0] + K - 1) / K), (int)vb, p.pair_mode);
     };
+    auto oneshot_of = [&](long long b) {
+        const long long r0 = b * kMedRows, K = CH / kMedRows;
+        return vb == 8 && med_oneshot64((int)(p.med_ptr[(size_t)b + 1] - p.med_ptr[(size_t)b]), (int)((p.irr_ptr[(size_t)r0 + 1] - p.irr_ptr[(size_t)r0] + K - 1) / K));
+    };
     if (p.irr_ptr.size() != (size_t)p.n_mfma_rows + 1 || !mono(p.irr_ptr) || (size_t)p.irr_ptr.back() != p.cnt_irr) return fail("irr_ptr");
     if (p.irr_val.size() != p.cnt_irr * (size_t)vb || p.irr_cid.size() != p.cnt_irr) return fail("irregular arrays");
     if (!cid_ok(p.irr_cid) || !cid_ok(p.med_cid)) return fail("medium column id out of range");
@@ -125,8 +129,9 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
         if (!mono(p.med_c8ptr) || (size_t)p.med_c8ptr.back() * (size_t)CH != p.cnt_reg8) return fail("med_c8ptr");
         for (long long b = 0; b < nb; ++b) {
             const int nc = p.med_ptr[(size_t)b + 1] - p.med_ptr[(size_t)b], n8 = p.med_c8ptr[(size_t)b + 1] - p.med_c8ptr[(size_t)b], npair = npair_of(b);
-            if (n8 < 0 || n8 > npair || n8 % kMedBatch64 || (n8 && (vb != 8 || nc + (p.irr_ptr[(size_t)b * kMedRows + 1] - p.irr_ptr[(size_t)b * kMedRows] + 3) / 4 <= kMedShot64)))
-                return fail("med_c8ptr: one-byte ids come in whole batches of a pipelined f64 block's paired region");
+            const bool one = med_oneshot64(nc, (p.irr_ptr[(size_t)b * kMedRows + 1] - p.irr_ptr[(size_t)b * kMedRows] + 3) / 4);
+            if (n8 < 0 || n8 > npair || n8 % (one ? 2 : kMedBatch64) || (n8 && vb != 8))
+                return fail("med_c8ptr: one-byte ids come in whole batches (pipelined) / pairs (one-shot) of an f64 block's paired region");
             std::vector<char> seen((size_t)nc, 0);
             for (int q = 0; q < nc; ++q) {
                 const unsigned k = (unsigned)p.med_korig[(size_t)p.med_ptr[(size_t)b] + (size_t)q];
@@ -143,7 +148,7 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
         if (!p.cid16) return p.med_cid[(size_t)c0 * (size_t)CH + med_elem_index(npair, q, lane, j, vpl, (int)CH)];
         const long long c8 = p.med_c8ptr[(size_t)b];
         const int n8 = (int)(p.med_c8ptr[(size_t)b + 1] - c8);
-        if (q < n8) { const unsigned o = p.med_cid8[(size_t)c8 * (size_t)CH + med_cid8_index(q, lane, (int)CH)]; return o == 0xFFu ? -1 : (long long)p.med_base[(size_t)c] + o; }
+        if (q < n8) { const unsigned o = p.med_cid8[(size_t)c8 * (size_t)CH + med_cid8_index(q, lane, (int)CH, oneshot_of(b))]; return o == 0xFFu ? -1 : (long long)p.med_base[(size_t)c] + o; }
         const unsigned o = p.med_cid16[(size_t)(c0 - c8) * (size_t)CH + med_elem_index(npair - n8, q - n8, lane, j, vpl, (int)CH)];
         return o == 0xFFFFu ? -1 : (long long)p.med_base[(size_t)c] + o;
     };

@@ -244,7 +244,17 @@ struct BlockSrc {
             const f64x2 v = ldg<NT>(reinterpret_cast<const f64x2 *>(reg.val + at));
             f0.a = v[0]; f1.a = v[1];
             if constexpr (C16) {
-                const unsigned r = ldg<NT>(reinterpret_cast<const unsigned *>((kQuadIds ? w16 : cid16) + at));      // raw offsets; rebased in gather() (one-shot blocks: n8 = 0)
+                if constexpr (kQuadIds) {
+                    // (load2 of this instantiation serves the ONE-SHOT blocks only: the pipeline uses load4.)  A narrow pair (i < n8, r4) keeps its
+                    // ids as one 16-bit word per lane, [pair][lane][2 bytes]; the pad 0xFF becomes the wide pad, so that gather() needs no second form
+                    if (i < n8) {              // wave-uniform
+                        const unsigned r = ldg<NT>(reinterpret_cast<const unsigned short *>(c8 + (size_t)i * CH) + reg.lane);
+                        const unsigned b0 = r & 0xFFu, b1 = r >> 8;
+                        f0.c = (int)(b0 == 0xFFu ? 0xFFFFu : b0); f1.c = (int)(b1 == 0xFFu ? 0xFFFFu : b1);
+                        return;
+                    }
+                }
+                const unsigned r = ldg<NT>(reinterpret_cast<const unsigned *>((kQuadIds ? w16 : cid16) + at));      // raw offsets; rebased in gather()
                 f0.c = (int)(r & 0xFFFFu); f1.c = (int)(r >> 16);
             } else {
                 const i32x2 c = ldg<NT>(reinterpret_cast<const i32x2 *>(reg.cid + at));

@@ -1107,6 +1107,41 @@ def test_device_packed_one_byte_ids(oracle, dasp, torch_cuda):
     assert np.array_equal(y, run_spmv(torch, host.upload(), x, m, 64))
 
 
+def test_one_byte_ids_in_one_shot_blocks(oracle, dasp, torch_cuda):
+    """r4: nlpkkt160-like rows of 5-28 nonzeros are ONE-SHOT blocks; in a plan whose one-shot f64 blocks are paired as a
+    whole (chunk_pairs = 2: automatic beyond 1 GiB of CSR) their narrow chunks carry one-byte ids too, in whole pairs.  Host and device packer
+    agree bit for bit, the product matches the oracle, and cid8 = -1 gives the same y."""
+    torch = torch_cuda
+    rp, ci = dasp.synth_csr("nlpkkt160", 0.01)
+    m, n = rp.size - 1, dasp.synth_dims("nlpkkt160", 0.01)[1]
+    v = np.random.default_rng(5).uniform(0.5, 1.5, ci.size)
+    kw = dict(cid16=1, chunk_pairs=2, x_window=-1, slab_max_len=4)
+    host = dasp.Plan(rp, ci, v, n, **kw)
+    st = host.stats
+    nchunks = int(host.host_array("med_ptr")[-1])
+    assert st["cid16_on"] == 1 and st["chunk_pairs"] == 2 and 0.3 * nchunks < st["cid8_chunks"] < nchunks
+    d = [torch.from_numpy(a).cuda() for a in (rp, ci, v)]
+    dev = dasp.Plan.from_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), m, n, ci.size, **kw)
+    hs, ds = host.stats, dev.stats
+    hs.pop("pre_ms"), ds.pop("pre_ms")
+    assert hs == ds
+    for name in META_ARRAYS:
+        assert np.array_equal(host.host_array(name), dev.host_array(name)), name
+    for name in NNZ_ARRAYS:
+        h = host.host_array(name)
+        assert np.array_equal(h, dev.device_array(name, h.size, h.dtype)), name
+    x = np.random.default_rng(6).uniform(-1, 1, n)
+    y = run_spmv(torch, dev, x, m, 64)
+    ref = oracle.csr_spmv(rp, ci, v, x)[dev.order_rid]
+    mag = oracle.csr_absrow(rp, ci, v, x)[dev.order_rid]
+    assert (np.abs(y - ref) <= 1e-12 * np.maximum(mag, 1e-300)).all()
+    wide = dasp.Plan(rp, ci, v, n, cid8=-1, **kw).upload()
+    assert wide.stats["cid8_chunks"] == 0
+    # (the narrow chunks move to the front of their block: another order of the block's MFMA steps, so the last bits may differ)
+    assert (np.abs(y - run_spmv(torch, wide, x, m, 64)) <= 1e-12 * np.maximum(mag, 1e-300)).all()
+    assert np.array_equal(y, run_spmv(torch, host.upload(), x, m, 64))
+
+
 def test_device_plan_rejects_bad_columns(dasp, torch_cuda):
     torch = torch_cuda
     rp = torch.tensor([0, 2, 3], dtype=torch.int32, device="cuda")

@@ -294,9 +294,27 @@ def test_cid8_narrow_chunks_layout(dasp, tmp_path):
     off = dasp.Plan(rp, ci, v, 1300000, x_window=-1, cid16=1, slab_max_len=4, piece_min_len=-1, cid8=-1)
     assert off.stats["cid8_chunks"] == 0 and off.host_array("med_cid8").size == 0 and off.host_array("med_korig").tolist() == list(range(12))
     assert util.decode_plan(off) == rows
-    # one-shot blocks (<= 8 steps) and f16 plans keep 16-bit ids
-    short = dasp.Plan(np.arange(0, 32 * 17, 32, dtype=np.int32), np.tile(np.array(cols[16:48], np.int32), 16), np.ones(32 * 16), 1300000, x_window=-1, cid16=1, slab_max_len=4, piece_min_len=-1)
-    assert short.stats["cid8_chunks"] == 0
+    # one-shot blocks (<= 8 steps) keep 16-bit ids unless they are paired as a whole (chunk_pairs = 2: plans far beyond the Infinity Cache; r4),
+    # f16 plans always
+    rp8, ci8 = np.arange(0, 32 * 17, 32, dtype=np.int32), np.tile(np.array(cols[16:48], np.int32), 16)      # 8 chunks: the narrow 4..9, then 10 (254) and 11 (255)
+    short = dasp.Plan(rp8, ci8, np.ones(32 * 16), 1300000, x_window=-1, cid16=1, slab_max_len=4, piece_min_len=-1)
+    assert short.stats["cid8_chunks"] == 0 and short.stats["chunk_pairs"] == 1
+    v8 = np.arange(1, ci8.size + 1, dtype=np.float64)
+    one = dasp.Plan(rp8, ci8, v8, 1300000, x_window=-1, cid16=1, slab_max_len=4, piece_min_len=-1, chunk_pairs=2)
+    # 7 of its 8 chunks are narrow -> three whole PAIRS in front; ids [pair][lane][2 bytes]
+    assert one.stats["chunk_pairs"] == 2 and one.stats["cid8_chunks"] == 6 and one.host_array("med_c8ptr").tolist() == [0, 6]
+    assert one.host_array("med_korig").tolist() == [0, 1, 2, 3, 4, 5, 6, 7] and one.host_array("med_cid8").size == 6 * CH and one.host_array("med_cid16").size == 2 * CH
+    c8 = one.host_array("med_cid8").reshape(3, 64, 2)             # [pair][lane][chunk of the pair]; lane = k * 16 + row
+    for pr in range(3):
+        for h in range(2):
+            assert c8[pr, :, h].reshape(4, 16)[:, 5].tolist() == [0, 1, 2, 254 if 2 * pr + h == 6 else 3]
+    rows8 = util.decode_plan(one)
+    for slot in range(16):
+        r = one.order_rid[slot]
+        assert rows8[slot][0] == cols[16:48] and rows8[slot][1] == v8[rp8[r]:rp8[r + 1]].tolist()
+    f8 = str(tmp_path / "p8.plan")
+    one.save(f8)
+    assert util.decode_plan(dasp.Plan.load(f8)) == rows8
     half = dasp.Plan(rp, ci, np.ones(ci.size, np.float16), 1300000, precision=16, x_window=-1, cid16=1, slab_max_len=4, piece_min_len=-1)
     assert half.stats["cid8_chunks"] == 0
 

@@ -117,8 +117,10 @@ def decode_plan(plan):
             order = np.arange(nc)
         else:
             n8 = int(c8p[b + 1] - c8p[b])
-            assert n8 % 4 == 0 and n8 <= npair and (n8 == 0 or prec == 64)
-            narrow = off8[c8p[b] * CH:(c8p[b] + n8) * CH].reshape(n8 // 4, 64, 4).transpose(0, 2, 1).reshape(n8, CH) if n8 else np.zeros((0, CH), np.int64)
+            oneshot = prec == 64 and nc + (int(ip_all[b * 16 + 1] - ip_all[b * 16]) + 3) // 4 <= 8          # plan.hpp med_oneshot64: pairs instead of batches of four
+            G = 2 if oneshot else 4
+            assert n8 % G == 0 and n8 <= npair and (n8 == 0 or prec == 64)
+            narrow = off8[c8p[b] * CH:(c8p[b] + n8) * CH].reshape(n8 // G, 64, G).transpose(0, 2, 1).reshape(n8, CH) if n8 else np.zeros((0, CH), np.int64)
             w0 = (c0 - int(c8p[b])) * CH
             wide = unpair(off16[w0:w0 + (nc - n8) * CH], npair - n8).reshape(nc - n8, CH)
             bs = base[c0:c0 + nc]
