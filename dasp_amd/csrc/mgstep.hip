@@ -63,7 +63,7 @@ __device__ __forceinline__ bool arrive_last(unsigned *shards, unsigned *top, int
 __device__ __forceinline__ unsigned shard_members(int total, int sh) { return (unsigned)((total - sh + kArriveShards - 1) / kArriveShards); }
 
 template <bool NT>
-__global__ __launch_bounds__(256, kMinWavesPlain) void dasp_mg_step_kernel(DevArgs a, DevArgs b, StepCtl c)
+__global__ __launch_bounds__(256, 6) void dasp_mg_step_kernel(DevArgs a, DevArgs b, StepCtl c)
 {
     __shared__ int go;
     const int lane = threadIdx.x & 63;
@@ -228,7 +228,7 @@ __device__ __forceinline__ bool step2_wait(const Step2Ctl &c, int lane)
 }
 
 template <bool NT>
-__global__ __launch_bounds__(256, kMinWavesPlain) void dasp_mg_step2_kernel(DevArgs a, MgPushArgs push, Step2Ctl c)
+__global__ __launch_bounds__(256, 6) void dasp_mg_step2_kernel(DevArgs a, MgPushArgs push, Step2Ctl c)
 {
     __shared__ int go;
     const int lane = threadIdx.x & 63;

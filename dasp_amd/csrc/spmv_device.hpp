@@ -903,7 +903,9 @@ __device__ __forceinline__ void plain_wg(const DevArgs &a, int wg, int wave, int
         if (q < a.n_blocks) medium_block<T, NT, C16, 0, C8, YS>(a, blk_order ? tab<true>(blk_order, q) : q, lane, x);
     } else {
         const int t = (wg - a.wg_long - a.wg_med) * kWavesPerWG + wave;
-        if (t < a.n_short_tiles) short_tile<T, NT, YS>(a, t, lane);
+        // (the multi-GPU step kernels, YS != 0, do without the wave-segmented short rows: with them they need 83-85 registers, one wave per SIMD less;
+        // multigpu.cpp builds its plans with short_seg off)
+        if (t < a.n_short_tiles) short_tile<T, NT, YS, YS == 0>(a, t, lane);
     }
 }
 
