@@ -783,73 +783,6 @@ def main():
         parts = {"allgather_alone_ms": round(float(tt[0]), 6), "other_column_product_ms": round(float(tt[1]), 6),
                  "allgather_bytes_per_rank": int(stride * vb), "note": "max over ranks; own-column product = roofline.kernel_ms (rank 0)"}
 
-    # ---- N > 1: the OTHER exchange too, in the same run (VERDICT r3 next #1c): whichever of {direct stores, ncclAllGather} the timed region did
-    # not use is timed here over a shorter chain, so that one record tells the two apart.  Collective: every rank takes the same branches.
-    exchange_ms = None
-    if mg is not None and not host_exchange and cfgs:
-        chosen = cfgs[cfg_i]
-        exchange_ms = {chosen[0]: {"ms_per_step": round(elapsed * 1e3 / args.steps, 6), "fused": bool(chosen[1]), "steps": args.steps,
-                                   "allgather_alone_ms": parts["allgather_alone_ms"] if parts else None}}
-        alt = [c for c in cfgs if c[0] != chosen[0]]
-        if alt and world > 1:
-            oc = alt[0]
-            rec = {"fused": bool(oc[1])}
-            try:
-                stream = apply(oc)
-                exch = oc[0]
-                dtx = np.float64 if prec == 64 else np.float16
-                mg.set_x(np.ones(cols, dtx))
-                nb = max(10, min(args.steps, 100))
-                for _ in range(5):
-                    step()
-                fence()
-                good = True
-                try:
-                    mg.check()
-                except D.DaspError as exc:
-                    good = False
-                    rec["error"] = str(exc)
-                if all_ok(good):
-                    t1 = time.perf_counter()
-                    for _ in range(nb):
-                        step()
-                    fence()
-                    e2 = time.perf_counter() - t1
-                    te = torch.tensor([e2], dtype=torch.float64)
-                    dist.all_reduce(te, op=dist.ReduceOp.MAX)
-                    good = True
-                    try:
-                        mg.check()
-                    except D.DaspError as exc:
-                        good = False
-                        rec["error"] = str(exc)
-                    if all_ok(good):
-                        rec.update(ms_per_step=round(float(te.item()) * 1e3 / nb, 6), steps=nb)
-                        if prec == 64:
-                            gotc = mg.get_y()
-                            wv = (R["chain"] ** (5 + nb)) * (lengths > 0)
-                            rec["verified"] = bool((np.abs(gotc - wv) <= 1e-9 * wv).all())
-                        for _ in range(3):
-                            mg.allgather(stream)
-                        torch.cuda.synchronize()
-                        dist.barrier()
-                        agt = D.multi.StreamTimer(stream)
-                        agt.start()
-                        for _ in range(20):
-                            mg.allgather(stream)
-                        ta = torch.tensor([agt.stop() / 20], dtype=torch.float64)
-                        torch.cuda.synchronize()
-                        dist.all_reduce(ta, op=dist.ReduceOp.MAX)
-                        rec["allgather_alone_ms"] = round(float(ta.item()), 6)
-            except D.DaspError as exc:                          # (a failure every rank sees at the same call: the switch itself)
-                rec["error"] = str(exc)
-            exchange_ms[oc[0]] = rec
-            try:
-                stream = apply(chosen)
-                exch = chosen[0]
-            except D.DaspError:
-                pass
-        exchange_ms["rccl_ranks"] = world if has_comm else 0
     dog.kick("step parts timed")
     # ---- dominant kernel alone: HIP events on the launch stream around back-to-back launches
     k_iters = max(200, min(args.steps, 1000))
@@ -918,6 +851,79 @@ def main():
         out["verified_random_x"] = rx
     if parts is not None:
         out["step_parts"] = parts
+    if mg is not None:
+        dog.partial = dict(out)                                   # the measurement is complete: from here on a hang costs an extra, not the line
+        dog.kick("headline record complete (multi-GPU); timing the other exchange")
+    # ---- N > 1: the OTHER exchange too, in the same run (VERDICT r3 next #1c): whichever of {direct stores, ncclAllGather} the timed region did
+    # not use is timed here over a shorter chain, so that one record tells the two apart.  Collective: every rank takes the same branches.
+    exchange_ms = None
+    try:
+        if mg is not None and not host_exchange and cfgs:
+            chosen = cfgs[cfg_i]
+            exchange_ms = {chosen[0]: {"ms_per_step": round(elapsed * 1e3 / args.steps, 6), "fused": bool(chosen[1]), "steps": args.steps,
+                                       "allgather_alone_ms": parts["allgather_alone_ms"] if parts else None}}
+            alt = [c for c in cfgs if c[0] != chosen[0]]
+            if alt and world > 1:
+                oc = alt[0]
+                rec = {"fused": bool(oc[1])}
+                try:
+                    stream = apply(oc)
+                    exch = oc[0]
+                    dtx = np.float64 if prec == 64 else np.float16
+                    mg.set_x(np.ones(cols, dtx))
+                    nb = max(10, min(args.steps, 100))
+                    for _ in range(5):
+                        step()
+                    fence()
+                    good = True
+                    try:
+                        mg.check()
+                    except D.DaspError as exc:
+                        good = False
+                        rec["error"] = str(exc)
+                    if all_ok(good):
+                        t1 = time.perf_counter()
+                        for _ in range(nb):
+                            step()
+                        fence()
+                        e2 = time.perf_counter() - t1
+                        te = torch.tensor([e2], dtype=torch.float64)
+                        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+                        good = True
+                        try:
+                            mg.check()
+                        except D.DaspError as exc:
+                            good = False
+                            rec["error"] = str(exc)
+                        if all_ok(good):
+                            rec.update(ms_per_step=round(float(te.item()) * 1e3 / nb, 6), steps=nb)
+                            if prec == 64:
+                                gotc = mg.get_y()
+                                wv = (R["chain"] ** (5 + nb)) * (lengths > 0)
+                                rec["verified"] = bool((np.abs(gotc - wv) <= 1e-9 * wv).all())
+                            for _ in range(3):
+                                mg.allgather(stream)
+                            torch.cuda.synchronize()
+                            dist.barrier()
+                            agt = D.multi.StreamTimer(stream)
+                            agt.start()
+                            for _ in range(20):
+                                mg.allgather(stream)
+                            ta = torch.tensor([agt.stop() / 20], dtype=torch.float64)
+                            torch.cuda.synchronize()
+                            dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+                            rec["allgather_alone_ms"] = round(float(ta.item()), 6)
+                except D.DaspError as exc:                          # (a failure every rank sees at the same call: the switch itself)
+                    rec["error"] = str(exc)
+                exchange_ms[oc[0]] = rec
+                try:
+                    stream = apply(chosen)
+                    exch = chosen[0]
+                except D.DaspError:
+                    pass
+            exchange_ms["rccl_ranks"] = world if has_comm else 0
+    except Exception as exc:                                    # an extra must never cost the line (whatever failed: gloo, HIP, RCCL)
+        exchange_ms = dict(exchange_ms or {}, error=repr(exc))
     if exchange_ms is not None:
         out["exchange_ms"] = exchange_ms
 
