@@ -5,6 +5,7 @@ kernel trace + stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes: the t
 HBM bytes per SpMV = sum over every dasp_* kernel of one SpMV (column panels: P fused kernels + the panel sum; long rows: + stage 2) of
 2 x FETCH_SIZE (gfx950 tallies the 128-byte requests of wide streaming reads at 64 B: MI355X_MICROARCH.md, HBM) + WRITE_SIZE.
 The x2 is calibrated for wide coalesced streams only: for gather-bound kernels the entry says so and also carries the raw sum."""
+import os
 import csv, glob, hashlib, json, os, sys
 tag, workload, prec, scale = sys.argv[1], sys.argv[2], int(sys.argv[3]), float(sys.argv[4])
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -71,4 +72,4 @@ print(json.dumps({"workload": workload, "precision": prec, "scale": scale, "kern
                   "fetch_size_bytes_raw": round(f_raw), "write_size_bytes": round(w), "traffic_bytes": round(2 * f_raw + w),
                   "kernel_avg_ns": avg, "column_panels": panels,
                   "correction": "2 x FETCH_SIZE (gfx950, MI355X_MICROARCH.md HBM section; calibrated for wide coalesced streams) + WRITE_SIZE, summed over the kernels of one SpMV",
-                  "source": "profiles/r03_traffic.md"}))
+                  "source": "profiles/%s_traffic.md" % os.environ.get("ROUND", "r04")}))

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """tools/traffic_collect.py -- after tools/traffic_all.sh ran on the GPU box: turn every gpurun_out/prof_<tag>/ into profiles/traffic.json
-(one entry per workload, stamped with the kernel revision) and profiles/r03_traffic.md (summary table + the per-workload rocprofv3 summaries)."""
+(one entry per workload, stamped with the kernel revision) and profiles/<ROUND>_traffic.md (summary table + the per-workload rocprofv3 summaries)."""
 import json, os, subprocess, sys
+ROUND = os.environ.get("ROUND", "r04")
 import numpy as np
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
@@ -16,7 +17,7 @@ for tag, w, prec in LIST:
         sys.exit("traffic.py failed for %s:\n%s" % (tag, r.stderr[-2000:]))
     entries.append(json.loads(r.stdout)); mds.append(r.stderr)
 json.dump(entries, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
-out = ["# r03: HBM traffic per SpMV from rocprofv3 PMC passes (kernels of this round, kernel_rev %s)\n" % entries[0]["kernel_rev"],
+out = ["# " + ROUND + ": HBM traffic per SpMV from rocprofv3 PMC passes (kernels of this round, kernel_rev %s)\n" % entries[0]["kernel_rev"],
        "Collected with `tools/traffic_all.sh` on the GPU box (per workload: `tools/prof.sh <tag> -- dasp_amd/bin/dasp_bench <workload> 1 <precision> <iters> 3`: "
        "kernel trace + stats, `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` in separate passes), turned into `profiles/traffic.json` and this file by "
        "`tools/traffic_collect.py`.  traffic = 2 x FETCH_SIZE + WRITE_SIZE summed over the kernels of one SpMV (the x2: gfx950 tallies the 128-byte requests of wide "
@@ -33,5 +34,5 @@ for (tag, w, prec), e in zip(LIST, entries):
     us = sum(e["kernel_avg_ns"].values()) / 1e3
     out.append("| %s | f%d | %.4f | %.4f | %.2f | %.4f | %.3f | %.1f | %.2f |" % (w, prec, balg / 1e9, e["fetch_size_bytes_raw"] / 1e9, e["write_size_bytes"] / 1e6,
                e["traffic_bytes"] / 1e9, e["traffic_bytes"] / balg, us, e["traffic_bytes"] / us / 1e6))
-open(os.path.join(root, "profiles", "r03_traffic.md"), "w").write("\n".join(out) + "\n\n" + "\n".join(mds))
+open(os.path.join(root, "profiles", ROUND + "_traffic.md"), "w").write("\n".join(out) + "\n\n" + "\n".join(mds))
 print("\n".join(out[2:]))
