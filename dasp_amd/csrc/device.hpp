@@ -71,6 +71,7 @@ struct DevicePlan {
     int device = -1;
     // column-panel parent: arena = the panels' partial results, panel k at ypart + k * ypart_stride elements
     size_t ypart_stride = 0;
+    size_t exp_y_off = 0, exp_x_off = 0;      // DASP_EXPERIMENT builds: scratch y / x inside the arena allocation
 };
 
 

@@ -249,6 +249,18 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate
     // one block / tile / piece per wave and then the wave ends: f64 plans without x windows and without a striding medium range
     a.ywt = p.dev->nt && p.precision == 64 && !p.windowed && !a.med_stride && !p.panel ? 1 : 0;
     if (const char *e = std::getenv("DASP_Y_WT")) a.ywt = a.ywt && std::atoi(e) != 0;      // A/B knob
+#ifdef DASP_EXPERIMENT_HOST      // host-side experiment switches only: the device code of such a build is the product's
+    if (const char *e = std::getenv("DASP_Y_IN_ARENA")) {      // 1: y inside the plan's allocation; 2: x too (copied once per call: timing only)
+        const int v = std::atoi(e);
+        if (v >= 1 && p.dev->exp_y_off) a.y = static_cast<char *>(p.dev->arena) + p.dev->exp_y_off;
+        if (v >= 2 && p.dev->exp_x_off) {
+            void *xi = static_cast<char *>(p.dev->arena) + p.dev->exp_x_off;
+            static const void *last_x = nullptr; static void *last_arena = nullptr;
+            if (last_x != dX || last_arena != p.dev->arena) { (void)hipMemcpyAsync(xi, dX, (size_t)p.n * p.geo.vbytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)); last_x = dX; last_arena = p.dev->arena; }
+            a.x = xi;
+        }
+    }
+#endif
 #ifdef DASP_EXPERIMENT
     if (const char *e = std::getenv("DASP_YSTORE")) a.ymode = std::atoi(e);
 #endif

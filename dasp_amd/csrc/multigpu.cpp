@@ -1011,7 +1011,10 @@ int dasp_mg_get_y(dasp_mg_plan_t *mg, void *y_host)
     if (!mg || !y_host) return DASP_ERR_ARG;
     dasp_mg_plan &g = *mg;
     if (!g.uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
-    if (int rc = flush_step2(g, nullptr, false)) return rc;
+    if (g.one_stream() && g.pushed_upto < g.k2) {      // the newest slice has not travelled yet: behind everything queued so far (the products may be on a non-blocking stream)
+        MG_HIP(hipDeviceSynchronize());
+        if (int rc = flush_step2(g, nullptr, false)) return rc;
+    }
     MG_HIP(hipDeviceSynchronize());
     g.pending = false; g.pending_lazy = false;
     forget_exchange_events(g);

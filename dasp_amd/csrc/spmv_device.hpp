@@ -553,36 +553,6 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, src.nc + nt, x);
 
     typename Tr<T>::part_t d;
-#ifdef DASP_EXPERIMENT      // placement experiments: the 16 results moved to 16 CONSECUTIVE lanes first -- one store of 4 full quads instead of 16 lanes in 16 quads
-    if constexpr (YM == 0 && YS == 0 && sizeof(T) == 8) {
-        if (a.ymode == 7 && !a.order) {
-            (void)diag_of(acc, lane, d);
-            const int src = 16 * (lane & 3) + (lane & 15);           // the diagonal lane of row (lane & 15)
-            const int lo = __builtin_amdgcn_ds_bpermute(4 * src, __double2loint(d)), hi = __builtin_amdgcn_ds_bpermute(4 * src, __double2hiint(d));
-            if (lane < 16 && b * kMedRows + lane < a.row_block) static_cast<T *>(a.y)[a.row_long + b * kMedRows + lane] = __hiloint2double(hi, lo);
-            return;
-        }
-        if ((a.ymode == 8 || a.ymode == 9) && !a.order && (b + 1) * kMedRows <= a.row_block) {      // the same, written through (8: 16 lanes x 8 bytes; 9: 8 lanes x 16 bytes)
-            (void)diag_of(acc, lane, d);
-            if (a.ymode == 8) {
-                const int src = 16 * (lane & 3) + (lane & 15);
-                const int lo = __builtin_amdgcn_ds_bpermute(4 * src, __double2loint(d)), hi = __builtin_amdgcn_ds_bpermute(4 * src, __double2hiint(d));
-                if (lane < 16) *(volatile T *)(static_cast<T *>(a.y) + a.row_long + b * kMedRows + lane) = __hiloint2double(hi, lo);
-            } else {
-                const int r0 = 2 * (lane & 7), r1 = r0 + 1, s0 = 16 * (r0 & 3) + r0, s1 = 16 * (r1 & 3) + r1;
-                const int lo0 = __builtin_amdgcn_ds_bpermute(4 * s0, __double2loint(d)), hi0 = __builtin_amdgcn_ds_bpermute(4 * s0, __double2hiint(d));
-                const int lo1 = __builtin_amdgcn_ds_bpermute(4 * s1, __double2loint(d)), hi1 = __builtin_amdgcn_ds_bpermute(4 * s1, __double2hiint(d));
-                if (lane < 8) {
-                    typedef int i4 __attribute__((ext_vector_type(4)));
-                    i4 v = {lo0, hi0, lo1, hi1};
-                    i4 *dst = reinterpret_cast<i4 *>(static_cast<T *>(a.y) + a.row_long + b * kMedRows) + lane;
-                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(v) : "memory");
-                }
-            }
-            return;
-        }
-    }
-#endif
     if (diag_of(acc, lane, d) && r < a.row_block) {
         const int slot = a.row_long + r;                 // row_long here = slot of the first MFMA medium row (Plan::med_slot0)
         const int yi = YM == 2 ? a.med_dst[r] : (a.order ? a.order[slot] : slot);

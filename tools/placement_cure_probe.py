@@ -42,7 +42,7 @@ if "variants/exp" in os.environ.get("DASP_AMD_SO", ""):
     for which, k in (("slow", slow), ("fast", fast)) + ((("xcd-contiguous", copies - 1),) if os.environ.get("PROBE_XCD_LAST") else ()):
         for j in range(2):
             line = "%s plan %d pair %d:" % (which, k, j)
-            for mode, label in ((0, "plain"), (1, "nt"), (2, "write-through"), (3, "no y store"), (4, "y into 4 KiB"), (7, "16 consecutive lanes"), (8, "16 consecutive lanes written through"), (9, "8 lanes x 16 B written through"), (0, "plain again")):
+            for mode, label in ((0, "plain"), (1, "nt"), (2, "write-through"), (3, "no y store"), (4, "y into 4 KiB"), (0, "plain again")):
                 os.environ["DASP_YSTORE"] = str(mode)
                 line += "  %s %.4f" % (label, t(plans[k], xs[j].data_ptr(), ys[j].data_ptr()))
             print(line, flush=True)
