@@ -880,6 +880,47 @@ def test_one_stream_mg_step_ranks_in_one_process(dasp, torch_cuda, monkeypatch, 
         m.close()
 
 
+def test_one_stream_mg_step_rank_without_boundary_rows(dasp, torch_cuda, monkeypatch):
+    """A block-diagonal matrix in the one-stream form: neither rank has a boundary row, so no workgroup of the plan waits -- ONE extra workgroup
+    still does, for every peer's slice of the previous step (no rank may run two steps ahead of another: a peer's stores would meet the half
+    this rank reads).  Two ranks in one process, twelve chained steps without host synchronisation == the blocks applied twelve times."""
+    import scipy.sparse as sp
+    from dasp_amd.multi import MgPlan
+    torch = torch_cuda
+    monkeypatch.setenv("DASP_MG_SHARED_DEVICE_RANKS", "2")
+    m = 6000
+    bounds = np.array([0, 3000, 6000], np.int32)
+    blocks, mgs = [], []
+    for r in range(2):
+        rp, ci, v = util.mixed_matrix(3000, 3000, 51 + r, lengths=[0, 1, 2, 3, 4, 7, 12, 30, 64])
+        lens = np.diff(rp)
+        v = v / np.maximum(np.repeat(lens, lens), 1)
+        blocks.append(sp.csr_matrix((v.copy(), ci.copy(), rp.copy()), shape=(3000, 3000)))
+        mgs.append(MgPlan(rp, ci + 3000 * r, v, m, m, bounds, r, cid16=1, x_window=-1, overlap=2).upload())
+    assert all(g.nnz_remote == 0 for g in mgs)
+    blobs = [g.push_export() for g in mgs]
+    for g in mgs:
+        g.push_connect(blobs)
+    assert all(g.info["fused_step"] == 2 for g in mgs)
+    streams = [torch.cuda.Stream() for _ in mgs]
+    x0 = np.random.default_rng(9).uniform(0.5, 1.5, m)
+    for g in mgs:
+        g.set_x(x0)
+    for _ in range(12):
+        for r, g in enumerate(mgs):
+            g.spmv(streams[r].cuda_stream)
+    for r, g in enumerate(mgs):
+        g.wait(streams[r].cuda_stream)
+    for g in mgs:
+        g.check()
+    want = x0.copy()
+    for _ in range(12):
+        want = np.concatenate([blocks[0] @ want[:3000], blocks[1] @ want[3000:]])
+    for g in mgs:
+        assert np.abs(g.get_y() - want).max() <= 1e-12 * np.abs(want).max()
+        g.close()
+
+
 def test_fused_mg_step_waits_in_the_kernel_and_times_out_cleanly(dasp, torch_cuda, monkeypatch):
     """One rank of a 2-way partition, 30 chained steps with NO host synchronisation between them and an emulated exchange of
     60 us: the other-column workgroups really wait inside the kernel for the previous exchange.  The peer's half of x never

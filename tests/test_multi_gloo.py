@@ -57,6 +57,15 @@ def _worker(rank, world, port, q):
             for slot, (cs, vs) in util.decode_plan(sub).items():
                 if cs:
                     y_local[order[slot]] += float(np.dot(np.asarray(vs, np.float64), xv[np.asarray(cs, np.int64)]))
+        # the one-plan layout of the one-stream step (overlap = 2): ONE plan over all columns in the gathered layout, every row once
+        mg2 = MgPlan(rp[r0:r1 + 1] - rp[r0], ci[sl], v[sl], m, n, bounds, rank, overlap=2)
+        assert mg2.subplan(1) is None and mg2.nnz_local + mg2.nnz_remote == rp[r1] - rp[r0] and mg2.nnz_local == mg.nnz_local
+        sub2 = mg2.subplan(0)
+        y2 = np.zeros(stride)
+        for slot, (cs, vs) in util.decode_plan(sub2).items():
+            if cs:
+                y2[sub2.order_rid[slot]] = float(np.dot(np.asarray(vs, np.float64), xg[np.asarray(cs, np.int64)]))
+        assert np.abs(y2 - y_local).max() <= 1e-12 * max(np.abs(y_local).max(), 1e-300)
         gathered = torch.zeros(world * stride, dtype=torch.float64)
         dist.all_gather_into_tensor(gathered, torch.from_numpy(y_local))
         full = np.concatenate([gathered.numpy()[g * stride: g * stride + bounds[g + 1] - bounds[g]] for g in range(world)])
