@@ -489,6 +489,22 @@ __device__ __forceinline__ void put_y(const DevArgs &a, int yi, P v)
     // coherence point), and -- unlike ANY atomic store or inline asm in the kernel -- it leaves the compiler free to fetch the row
     // tables and per-chunk bases with scalar loads (with an atomic store the own-column product of a slice runs 92 instead of 61 us)
     if constexpr (YS == 1) *(volatile T *)y = (T)v;
+#ifdef DASP_EXPERIMENT      // store-policy experiment (dasp_spmv_kt_kernel only: its tables do not depend on the compiler's alias analysis)
+    else if constexpr (YS == 3 && sizeof(T) == 8) {
+        const T w = (T)v;
+        switch (a.ymode) {
+            case 10: asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(y), "v"(w) : "memory"); break;
+            case 11: asm volatile("global_store_dwordx2 %0, %1, off sc0" : : "v"(y), "v"(w) : "memory"); break;
+            case 12: asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(y), "v"(w) : "memory"); break;
+            case 13: asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(y), "v"(w) : "memory"); break;
+            case 14: asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" : : "v"(y), "v"(w) : "memory"); break;
+            case 15: asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" : : "v"(y), "v"(w) : "memory"); break;
+            case 16: asm volatile("global_store_dwordx2 %0, %1, off sc0 nt" : : "v"(y), "v"(w) : "memory"); break;
+            case 3: break;
+            default: *y = w; break;
+        }
+    }
+#endif
     else if constexpr (YS == 2) {
         const T old = *(volatile T *)y;
         *(volatile T *)y = (T)((P)old + v);
