@@ -37,15 +37,6 @@
 
 namespace dasp {
 
-#ifdef DASP_EXPERIMENT
-// experiment build only (tools/store_policy_probe.py): the non-windowed f64 16-bit-id kernel with its tables read through the CONSTANT address space (YS = 3),
-// so that put_y may try store instructions written in assembly without turning the table reads into vector loads
-__global__ __launch_bounds__(256, 6) void dasp_spmv_kt_kernel(DevArgs a)
-{
-    plain_wg<double, true, true, true, 3>(a, (int)blockIdx.x, __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), (int)(threadIdx.x & 63), nullptr);
-}
-#endif
-
 template <class T, bool NT, bool C16, bool WIN, bool C8 = false>
 __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPlain) void dasp_spmv_kernel(DevArgs a)
 {
@@ -152,6 +143,10 @@ __global__ void selftest_f16_kernel(float *D)
         }                                                                                      \
     } while (0)
 
+#ifdef DASP_EXPERIMENT
+#include "spmv_experiments.hpp"      // kernels of the experiment build only (store policies, resident waves)
+#endif
+
 // ---- what upload.cpp needs to know about the kernels (it is host code and never names a kernel itself)
 // windowed plans with more than the default 64 KiB of dynamic LDS: the limit must be raised per kernel.  Done at upload (for both
 // cache-policy variants), not in the launch path, so that dasp_plan_spmv stays free of anything a stream capture would reject; the
@@ -193,12 +188,7 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
         const size_t lds = p.windowed ? (size_t)p.lds_bytes : 0;
         const bool c16 = p.cid16;
 #ifdef DASP_EXPERIMENT
-        if (sizeof(T) == 8 && nt && c16 && !p.windowed && a.n_multi == 0 && std::getenv("DASP_KT_KERNEL") && std::atoi(std::getenv("DASP_KT_KERNEL"))) {
-            DevArgs b = a; b.wg_med = (b.n_blocks + kWavesPerWG - 1) / kWavesPerWG; b.xcd_on = 0;
-            hipLaunchKernelGGL(dasp_spmv_kt_kernel, dim3(b.wg_long + b.wg_med + b.wg_short), dim3(256), 0, s, b);
-            HIP_TRY(hipGetLastError());
-            return DASP_OK;
-        }
+        if (sizeof(T) == 8 && nt && c16 && !p.windowed && a.n_multi == 0) { const int rc = launch_experiment(a, s); if (rc != 1) return rc; }
 #endif
 #define DASP_FOR_EACH(M) \
         if (nt && c16 && p.windowed) { M(true, true, true); } else if (nt && c16) { M(true, true, false); } \

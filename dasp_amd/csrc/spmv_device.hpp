@@ -147,6 +147,14 @@ struct XGlobal {
     const T *x;
     __device__ __forceinline__ T at(int c) const { return x[c < 0 ? 0 : c]; }       // pads read x[0], dropped below
 };
+#ifdef DASP_EXPERIMENT
+// experiment (dasp_spmv_persist_kernel): x from global memory, the block's 16 results into the wave's LDS slot instead of y
+template <class T>
+struct XGlobalY {
+    const T *x; T *ybuf;
+    __device__ __forceinline__ T at(int c) const { return x[c < 0 ? 0 : c]; }
+};
+#endif
 template <class T>
 struct XLds {
     const T *xw; int cmin;
@@ -572,6 +580,9 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     if (diag_of(acc, lane, d) && r < a.row_block) {
         const int slot = a.row_long + r;                 // row_long here = slot of the first MFMA medium row (Plan::med_slot0)
         const int yi = YM == 2 ? a.med_dst[r] : (a.order ? a.order[slot] : slot);
+#ifdef DASP_EXPERIMENT
+        if constexpr (YS == 5) x.ybuf[lane & 15] = (T)d; else
+#endif
         put_y<T, YS>(a, yi, d);
     }
 }
