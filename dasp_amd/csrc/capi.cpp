@@ -222,7 +222,7 @@ static long long host_array_impl(const dasp_plan_t *plan, const char *name, cons
     const Plan &p = plan->impl;
     // the nnz-sized arrays exist on the host only until dasp_plan_drop_host (never, for a plan packed on the device);
     // the O(rows) arrays and order_rid always do
-    static const char *const kBulk[] = {"long_val", "long_cid", "med_val", "med_cid", "med_cid16", "med_cid8", "irr_val", "irr_cid", "short_val", "short_cid"};
+    static const char *const kBulk[] = {"long_val", "long_cid", "med_val", "med_cid", "med_cid16", "med_cid8", "irr_val", "irr_cid", "short_val", "short_cid", "rt_val", "rt_cid"};
     if (p.host_dropped)
         for (const char *b : kBulk)
             if (std::strcmp(name, b) == 0) { set_error("host copy of this array was dropped (use dasp_plan_download_array)"); return DASP_ERR_STATE; }
@@ -258,6 +258,11 @@ static long long host_array_impl(const dasp_plan_t *plan, const char *name, cons
     if (n == "win_len") return ints(p.win_len);
     if (n == "short_val") return vals(p.short_val);
     if (n == "short_cid") return rints(p.short_cid);
+    if (n == "rt_val") return vals(p.rt_val);
+    if (n == "rt_cid") return rints(p.rt_cid);
+    if (n == "rt_ptr") return ints(p.rt_ptr);
+    if (n == "rt_start") { *ptr = p.rt_start.data(); *elem_bytes = 2; return (long long)p.rt_start.size(); }
+    if (n == "rt_mask") { *ptr = p.rt_mask.data(); *elem_bytes = 8; return (long long)p.rt_mask.size(); }
     if (n == "short_groups") {   // kNumShortGroups x {len,count,tiles,tile0,elem_off_lo,elem_off_hi,split,base0,base1,grp0,grp1,off0,off1,seg,rpt}
         static thread_local std::vector<int> flat;
         flat.clear();
@@ -294,7 +299,7 @@ int dasp_plan_drop_host(dasp_plan_t *plan)
     auto dropc = [](raw_vector<char> &v) { raw_vector<char>().swap(v); };
     auto dropi = [](raw_vector<int> &v) { raw_vector<int>().swap(v); };
     dropc(p.long_val); dropi(p.long_cid); dropc(p.med_val); dropi(p.med_cid); raw_vector<uint16_t>().swap(p.med_cid16); raw_vector<uint8_t>().swap(p.med_cid8);
-    dropc(p.irr_val); dropi(p.irr_cid); dropc(p.short_val); dropi(p.short_cid);
+    dropc(p.irr_val); dropi(p.irr_cid); dropc(p.short_val); dropi(p.short_cid); dropc(p.rt_val); dropi(p.rt_cid);
     p.host_dropped = true;
     for (auto &h : p.panels) if (int rc = dasp_plan_drop_host(h.get())) return rc;
     return DASP_OK;

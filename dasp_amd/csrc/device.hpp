@@ -53,12 +53,15 @@ struct DevArgs {
     int xcd_blk[9];
     int ymode;        // DASP_EXPERIMENT builds only: how y is written (spmv_device.hpp put_y / medium_block)
     int med_stride;   // 1: the medium workgroups stride over the blocks (capped, persistent range); 0: exactly one block per wave
+    // row tiles of a column panel (Plan::rt_*): workgroups [wg_long + wg_med + wg_short, + wg_rt), one tile per wave
+    const void *rt_val; const int *rt_cid; const int *rt_ptr; const unsigned short *rt_start; const unsigned long long *rt_mask;
+    int n_rt_tiles, wg_rt, rt_max;
 };
 
 // byte offsets of the nnz-sized arrays inside the arena (devpack.hip writes them, tests download them)
 struct ArenaMap {
     size_t long_val = 0, long_cid = 0, med_val = 0, med_cid = 0, med_cid16 = 0, med_cid8 = 0, med_base = 0, irr_val = 0, irr_cid = 0,
-           short_val = 0, short_cid = 0;
+           short_val = 0, short_cid = 0, rt_val = 0, rt_cid = 0;
 };
 
 struct DevicePlan {

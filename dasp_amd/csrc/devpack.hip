@@ -531,6 +531,60 @@ int devpack_panel_split(const Plan &p, const DevCsr &d, const std::vector<int> &
     return DASP_OK;
 }
 
+// ---- row tiles of a column panel (plan.cpp build_panels): one wave per row moves the row either into the tiles' arrays or into the
+// sub-matrix of the rows that stay with the panel's plan; a row's elements keep their order
+template <class T>
+__global__ void k_row_tiles_move(const int *rp, const int *ci, const T *val, int m, const int *rp_rest, const int *at, int *rest_ci, T *rest_val, int *rt_cid, T *rt_val)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= m) return;
+    const int a0 = rp[i], n = rp[i + 1] - a0, t = at[i];
+    int *dc = t >= 0 ? rt_cid + t : rest_ci + rp_rest[i];
+    T *dv = t >= 0 ? rt_val + t : rest_val + rp_rest[i];
+    for (int j = lane; j < n; j += 64) { dc[j] = ci[a0 + j]; dv[j] = val[a0 + j]; }
+}
+int devpack_row_tiles(const Plan &p, DevCsr &panel, const std::vector<int> &rp_rest, const std::vector<int> &at, size_t cnt,
+                      std::vector<std::shared_ptr<void>> &keep, DevRowTiles *out)
+{
+    const int m = p.m;
+    const size_t vb = (size_t)p.geo.vbytes, n_rest = (size_t)rp_rest[(size_t)m];
+    auto dmalloc = [&](size_t bytes, void **ptr) -> int {
+        if (hipMalloc(ptr, std::max<size_t>(bytes, 16)) != hipSuccess) { set_error("hipMalloc (row tiles)"); return DASP_ERR_HIP; }
+        keep.emplace_back(*ptr, [](void *q) { (void)hipFree(q); });
+        return DASP_OK;
+    };
+    void *d_rp = nullptr, *d_at = nullptr, *r_ci = nullptr, *r_val = nullptr, *t_ci = nullptr, *t_val = nullptr;
+    if (int rc = dmalloc(((size_t)m + 1) * 4, &d_rp)) return rc;
+    if (int rc = dmalloc((size_t)m * 4, &d_at)) return rc;
+    if (int rc = dmalloc(n_rest * 4, &r_ci)) return rc;
+    if (int rc = dmalloc(n_rest * vb, &r_val)) return rc;
+    if (int rc = dmalloc(cnt * 4, &t_ci)) return rc;
+    if (int rc = dmalloc(cnt * vb, &t_val)) return rc;
+    HIP_TRYP(hipMemcpy(d_rp, rp_rest.data(), ((size_t)m + 1) * 4, hipMemcpyHostToDevice));
+    if (m > 0) {
+        HIP_TRYP(hipMemcpy(d_at, at.data(), (size_t)m * 4, hipMemcpyHostToDevice));
+        if (p.precision == 64)
+            hipLaunchKernelGGL((k_row_tiles_move<double>), dim3(waves_grid(m)), dim3(256), 0, 0, panel.rp, panel.ci, static_cast<const double *>(panel.val), m, static_cast<const int *>(d_rp),
+                               static_cast<const int *>(d_at), static_cast<int *>(r_ci), static_cast<double *>(r_val), static_cast<int *>(t_ci), static_cast<double *>(t_val));
+        else
+            hipLaunchKernelGGL((k_row_tiles_move<_Float16>), dim3(waves_grid(m)), dim3(256), 0, 0, panel.rp, panel.ci, static_cast<const _Float16 *>(panel.val), m, static_cast<const int *>(d_rp),
+                               static_cast<const int *>(d_at), static_cast<int *>(r_ci), static_cast<_Float16 *>(r_val), static_cast<int *>(t_ci), static_cast<_Float16 *>(t_val));
+        HIP_TRYP(hipGetLastError());
+        HIP_TRYP(hipDeviceSynchronize());
+    }
+    panel = DevCsr{static_cast<const int *>(d_rp), static_cast<const int *>(r_ci), r_val};
+    out->val = t_val; out->cid = static_cast<int *>(t_ci);
+    return DASP_OK;
+}
+int devpack_place_row_tiles(Plan &q, const DevRowTiles &src)
+{
+    if (!q.dev || !q.dev->arena) { set_error("panel plan not on the device"); return DASP_ERR_STATE; }
+    char *base = static_cast<char *>(q.dev->arena);
+    HIP_TRYP(hipMemcpy(base + q.dev->map.rt_val, src.val, q.cnt_rt * (size_t)q.geo.vbytes, hipMemcpyDeviceToDevice));
+    HIP_TRYP(hipMemcpy(base + q.dev->map.rt_cid, src.cid, q.cnt_rt * 4, hipMemcpyDeviceToDevice));
+    return DASP_OK;
+}
+
 // remapped column ids at arbitrary nonzero positions, back on the host: the samples the automatic column-panel rule looks at
 __global__ void k_gather_cols(const int *ci, const long long *idx, long long n, long long start, long long stride, RemapDev remap, int *out)
 {
@@ -607,6 +661,7 @@ int download_array(Plan &p, const char *name, void *dst, size_t bytes)
         {"med_cid16", mp.med_cid16, p.cid16 ? (p.cnt_reg - p.cnt_reg8) * 2 : 0}, {"med_cid8", mp.med_cid8, p.cnt_reg8}, {"med_base", mp.med_base, p.cid16 ? (size_t)p.med_ptr.back() * 4 : 0},
         {"irr_val", mp.irr_val, p.cnt_irr * vb}, {"irr_cid", mp.irr_cid, p.cnt_irr * 4},
         {"short_val", mp.short_val, p.cnt_short * vb}, {"short_cid", mp.short_cid, p.cnt_short * 4},
+        {"rt_val", mp.rt_val, p.cnt_rt * vb}, {"rt_cid", mp.rt_cid, p.cnt_rt * 4},
     };
     for (auto &t : tab)
         if (std::strcmp(t.n, name) == 0) {

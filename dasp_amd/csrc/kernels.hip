@@ -44,6 +44,15 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPla
     spmv_body<T, NT, C16, WIN, C8>(a, lds_raw);
 }
 
+// a column panel with row tiles (Plan::rt_*): the non-windowed kernel + the tiles' workgroup range, dynamic LDS = 4 waves x 64 x rt_max products
+// (f16: held to 72 registers = 7 waves per SIMD like the kernel without tiles -- 75 otherwise; ljournal-2008 0.4522 -> 0.4443 ms)
+template <class T, bool NT, bool C16>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 7 : kMinWavesPlain) void dasp_spmv_rt_kernel(DevArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    spmv_body<T, NT, C16, false, false, true>(a, lds_raw);
+}
+
 // the windowed kernel for plans with at most one window workgroup per CU (n_windows <= CUs: cop20k_A's 212): nothing is gained by
 // holding it to 64 registers for a second resident workgroup that does not exist, and at 128 it needs no scratch.
 // (r3, measured and NOT kept: a wave requesting the row tables, tiles and tails of both its blocks BEFORE the x copy and the barrier,
@@ -182,9 +191,15 @@ int spmv_kernel_f16_resident(bool c16)
 template <class T>
 static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
 {
-    const int grid = a.wg_long + a.wg_med + a.wg_short;
+    const int grid = a.wg_long + a.wg_med + a.wg_short + a.wg_rt;
     const bool nt = p.dev->nt;
-    if (grid > 0) {
+    if (a.wg_rt > 0) {      // a column panel with row tiles (never windowed, never with one-byte ids: plan.cpp build_panels)
+        const size_t lds = (size_t)kWavesPerWG * kRowTile * (size_t)a.rt_max * sizeof(typename Tr<T>::part_t);
+        if (nt && p.cid16) hipLaunchKernelGGL((dasp_spmv_rt_kernel<T, true, true>), dim3(grid), dim3(256), lds, s, a);
+        else if (nt) hipLaunchKernelGGL((dasp_spmv_rt_kernel<T, true, false>), dim3(grid), dim3(256), lds, s, a);
+        else if (p.cid16) hipLaunchKernelGGL((dasp_spmv_rt_kernel<T, false, true>), dim3(grid), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((dasp_spmv_rt_kernel<T, false, false>), dim3(grid), dim3(256), lds, s, a);
+    } else if (grid > 0) {
         const size_t lds = p.windowed ? (size_t)p.lds_bytes : 0;
         const bool c16 = p.cid16;
 #ifdef DASP_EXPERIMENT

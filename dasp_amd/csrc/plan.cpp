@@ -1166,34 +1166,83 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     std::vector<raw_vector<T>> valP((size_t)P);
     std::vector<DevCsr> devP;                          // device CSR: the same split by two kernels (devpack.hip), sub-matrices stay on the GPU
     std::vector<std::shared_ptr<void>> dev_keep;
-    if (dev) { if (int rc = devpack_panel_split(p, *dev, bnd, P, rpP, devP, dev_keep)) return rc; }
-    else {
+    std::vector<DevRowTiles> rt_dev((size_t)P);        // device path: the tiles' elements, moved into the panel plan's arena once it exists
+    const bool natural = p.opt.y_order == DASP_Y_NATURAL;
+    std::vector<int> slot_of_row;
+    if (!natural) { slot_of_row.resize((size_t)m); for (int i = 0; i < m; ++i) slot_of_row[p.order[i]] = i; }
+    lap("slot table");
+    // row tiles (opt.row_tile_max, Plan::rt_*): panel k keeps its rows of <= rt_max nonzeros in the parent's output order; rt[k] holds their
+    // tables, rt_at[k][row] = the row's first element in the tiles' arrays (-1: the row stays with the panel's own plan)
+    int rt_max = p.opt.row_tile_max == 0 ? kRowTileAuto : std::max(0, p.opt.row_tile_max);
+    if (rt_max > kRowTileMax) { set_error("row_tile_max must be <= 32"); return DASP_ERR_ARG; }
+    if (const char *e = std::getenv("DASP_ROW_TILE_MAX")) rt_max = std::min(kRowTileMax, std::max(0, std::atoi(e)));      // A/B knob
+    struct RowTiles { std::vector<int> ptr; std::vector<uint16_t> start; std::vector<uint64_t> mask; raw_vector<char> val; raw_vector<int> cid; std::vector<int> at; size_t cnt = 0; };
+    std::vector<RowTiles> rt((size_t)P);
+    // from a panel's row LENGTHS in len[1 .. m] (len[i + 1] = row i): the tiles' tables; the rows taken get length 0 in len
+    auto cut_row_tiles = [&](RowTiles &R, int *len) {
+        const int tiles = ceil_div(m, kRowTile);
+        R.ptr.assign((size_t)tiles + 1, 0); R.start.assign((size_t)tiles * kRowTile, 0); R.mask.assign((size_t)tiles, 0); R.at.assign((size_t)m, -1);
+        long long run = 0;
+        for (int t = 0; t < tiles; ++t) {
+            int in_tile = 0;
+            for (int i = 0; i < kRowTile; ++i) {
+                const int j = t * kRowTile + i;
+                R.start[(size_t)j] = (uint16_t)in_tile;
+                if (j >= m) continue;
+                const int r = natural ? j : p.order[(size_t)j], L = len[(size_t)r + 1];
+                if (L > rt_max) continue;
+                R.mask[(size_t)t] |= uint64_t(1) << i;
+                if (L > 0) { R.at[(size_t)r] = (int)(run + in_tile); in_tile += L; len[(size_t)r + 1] = 0; }
+            }
+            run += in_tile;
+            R.ptr[(size_t)t + 1] = (int)run;
+        }
+        R.cnt = (size_t)run;
+    };
+    if (dev) {
+        if (int rc = devpack_panel_split(p, *dev, bnd, P, rpP, devP, dev_keep)) return rc;
+        if (rt_max > 0) {
+            // the split's row pointers -> lengths, cut, -> the pointers of what is left; the device moves the elements (devpack.hip)
+            parallel_for(P, threads, 1, [&](long long k0, long long k1) {
+                for (long long k = k0; k < k1; ++k) {
+                    int *q = rpP[k].data();
+                    for (int i = m; i > 0; --i) q[i] -= q[i - 1];
+                    cut_row_tiles(rt[(size_t)k], q);
+                    for (int i = 0; i < m; ++i) q[i + 1] += q[i];
+                }
+            });
+            for (int k = 0; k < P; ++k) if (int rc = devpack_row_tiles(p, devP[(size_t)k], rpP[(size_t)k], rt[(size_t)k].at, rt[(size_t)k].cnt, dev_keep, &rt_dev[(size_t)k])) return rc;
+        }
+    } else {
     for (auto &v : rpP) v.assign((size_t)m + 1, 0);
     parallel_for(m, threads, 1 << 12, [&](long long b, long long e) {
         for (long long i = b; i < e; ++i)
             for (int j = rp[i]; j < rp[i + 1]; ++j) rpP[panel_of(remap(ci[j]))][i + 1]++;
     });
     parallel_for(P, threads, 1, [&](long long k0, long long k1) {
-        for (long long k = k0; k < k1; ++k) { int *q = rpP[k].data(); for (int i = 0; i < m; ++i) q[i + 1] += q[i]; }
+        for (long long k = k0; k < k1; ++k) {
+            int *q = rpP[k].data();
+            if (rt_max > 0) cut_row_tiles(rt[(size_t)k], q);
+            for (int i = 0; i < m; ++i) q[i + 1] += q[i];
+        }
     });
-    for (int k = 0; k < P; ++k) { ciP[k].resize((size_t)rpP[k][m]); valP[k].resize((size_t)rpP[k][m]); }
+    const size_t vb = (size_t)p.geo.vbytes;
+    for (int k = 0; k < P; ++k) { ciP[k].resize((size_t)rpP[k][m]); valP[k].resize((size_t)rpP[k][m]); rt[(size_t)k].cid.resize(rt[(size_t)k].cnt); rt[(size_t)k].val.resize(rt[(size_t)k].cnt * vb); }
     parallel_for(m, threads, 1 << 12, [&](long long b, long long e) {
         std::vector<int> cur((size_t)P);
+        std::vector<char> tiled((size_t)P);
         for (long long i = b; i < e; ++i) {
-            for (int k = 0; k < P; ++k) cur[k] = rpP[k][i];
+            for (int k = 0; k < P; ++k) { const int at = rt_max > 0 ? rt[(size_t)k].at[(size_t)i] : -1; tiled[k] = at >= 0; cur[k] = at >= 0 ? at : rpP[k][i]; }
             for (int j = rp[i]; j < rp[i + 1]; ++j) {
                 const int c = remap(ci[j]), k = panel_of(c), at = cur[k]++;
-                ciP[k][at] = c; valP[k][at] = val[j];
+                if (tiled[k]) { rt[(size_t)k].cid[(size_t)at] = c; reinterpret_cast<T *>(rt[(size_t)k].val.data())[at] = val[j]; }
+                else { ciP[k][at] = c; valP[k][at] = val[j]; }
             }
         }
     });
     }
 
     lap("split by column range");
-    const bool natural = p.opt.y_order == DASP_Y_NATURAL;
-    std::vector<int> slot_of_row;
-    if (!natural) { slot_of_row.resize((size_t)m); for (int i = 0; i < m; ++i) slot_of_row[p.order[i]] = i; }
-    lap("slot table");
     const bool streams = (long long)p.nnz * (p.geo.vbytes + 4) > kStreamBytes;
     p.panels.clear(); p.panel_bounds.clear();
     // the panels are built side by side (their O(rows) classifier passes are serial), each with its share of the threads
@@ -1210,7 +1259,8 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
                 if (dev) devpack_use_device(hip_device);          // a new thread starts on device 0
                 for (int k = next++; k < P; k = next++) {
                     const int nnz_k = rpP[k][m];
-                    if (nnz_k == 0) continue;                       // an empty panel adds nothing
+                    RowTiles &R = rt[(size_t)k];
+                    if (nnz_k == 0 && R.cnt == 0) continue;         // an empty panel adds nothing
                     std::unique_ptr<dasp_plan> h(new dasp_plan());
                     Plan &q = h->impl;
                     q.precision = p.precision; q.geo = p.geo; q.m = m; q.n = (int)xlen; q.nnz = nnz_k;
@@ -1219,12 +1269,24 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
                     q.opt.col_panels = 1; q.opt.host_threads = each;
                     if (q.opt.stream_policy == 0) q.opt.stream_policy = streams ? 2 : 1;   // the policy follows the whole matrix, not one panel
                     q.dst_map = slot_of_row; q.panel = true;
+                    if (R.cnt > 0) {      // (a panel none of whose rows is short enough keeps no tiles at all)
+                        q.rt_max = rt_max; q.cnt_rt = R.cnt;
+                        q.rt_ptr.swap(R.ptr); q.rt_start.swap(R.start); q.rt_mask.swap(R.mask); q.rt_val.swap(R.val); q.rt_cid.swap(R.cid);
+                        q.opt.x_window = -1; q.opt.cid8 = -1;      // the tiles ride in the non-windowed kernel without one-byte ids (dasp_spmv_rt_kernel)
+                    }
                     // f16 only: 2-byte stores are where the partial lines hurt (ljournal-2008-uniform 0.590 -> 0.559 ms, ljournal-2008 0.506 -> 0.503; powerlaw_1M f64 0.651 -> 0.654)
                     if (!natural && p.precision == 16 && !std::getenv("DASP_PANEL_ROW_SCAN")) q.scan_order = p.order.data();      // (DASP_PANEL_ROW_SCAN: A/B knob, the r3 order)
                     try { rcs[k] = build_impl<T>(q, rpP[k].data(), dev ? nullptr : ciP[k].data(), dev ? nullptr : valP[k].data(), dev ? &devP[(size_t)k] : nullptr, kPanel); }
                     catch (const std::bad_alloc &) { rcs[k] = DASP_ERR_NOMEM; set_error("out of host memory"); }
+                    if (rcs[k] == DASP_OK && dev && q.cnt_rt > 0) rcs[k] = devpack_place_row_tiles(q, rt_dev[(size_t)k]);
                     if (rcs[k] != DASP_OK) { errs[k] = last_error_cstr(); continue; }
                     q.opt.host_threads = p.opt.host_threads; q.scan_order = nullptr;
+                    {   // the tiles in the panel's counters
+                        dasp_stats_t &t = q.stats;
+                        t.row_tile_max = q.rt_max; t.n_row_tiles = (int)q.rt_mask.size(); t.row_tile_nnz = (long long)q.cnt_rt;
+                        t.n_workgroups += ceil_div(t.n_row_tiles, kWavesPerWG);
+                        t.data_X += (long long)q.cnt_rt * (p.geo.vbytes + 4) + (long long)t.n_row_tiles * (4 + 2 * kRowTile + 8);
+                    }
                     std::vector<int>().swap(rpP[k]); raw_vector<int>().swap(ciP[k]); raw_vector<T>().swap(valP[k]);
                     built[k] = std::move(h);
                 }
@@ -1247,6 +1309,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     s.fill0_nnz_short = s.fill0_nnz_long = s.fill0_nnz_reg = 0;
     s.n_med_blocks = s.n_long_pieces = s.n_long_multi = s.n_short_tiles = s.n_workgroups = 0;
     s.x_window_on = s.n_windows = s.n_windows_lds = s.lds_bytes = s.row_window = s.cid16_on = s.x_window_hybrid = s.chunk_pairs = s.cid8_chunks = 0;
+    s.row_tile_max = s.n_row_tiles = 0; s.row_tile_nnz = 0;
     s.window_nnz_frac = 0.0;
     long long stored = 0, dataX = 0;
     for (const auto &h : p.panels) {
@@ -1260,6 +1323,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
         s.lds_bytes = std::max(s.lds_bytes, t.lds_bytes); s.row_window = std::max(s.row_window, t.row_window);
         s.cid16_on |= t.cid16_on; s.x_window_hybrid |= t.x_window_hybrid; s.chunk_pairs = std::max(s.chunk_pairs, t.chunk_pairs); s.cid8_chunks += t.cid8_chunks;
         s.window_nnz_frac += t.window_nnz_frac * (double)t.nnzA / (double)std::max(1, p.nnz);
+        s.row_tile_max = std::max(s.row_tile_max, t.row_tile_max); s.n_row_tiles += t.n_row_tiles; s.row_tile_nnz += t.row_tile_nnz; stored += t.row_tile_nnz;
     }
     s.rate_fill0 = p.nnz > 0 ? (double)(stored - p.nnz) / p.nnz : 0.0;
     // packed panels + x once + every panel's partial y written and read back + y

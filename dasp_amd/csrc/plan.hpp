@@ -153,6 +153,10 @@ __host__ __device__
 #endif
 inline int short_tile_elems(bool seg, int L, int SR) { return seg ? kWave : L * SR; }
 
+constexpr int kRowTile = 64;        // output positions per row tile: one wave, one lane per position
+constexpr int kRowTileAuto = 16;    // opt.row_tile_max = 0 (tools/row_tile_ab.py: ljournal-2008 f16 0.483 / 0.469 / 0.460 / 0.452 / 0.451 / 0.451 / 0.496 ms at 6 / 8 / 12 / 16 / 20 / 24 / 32, 0.507-0.511 without)
+constexpr int kRowTileMax = 32;     // longest row a tile may take (LDS: 4 waves x 64 x bound products per workgroup)
+
 struct DevicePlan;  // kernels.hip
 }  // namespace dasp
 struct dasp_plan;      // the C handle (defined at the end of this file): one Plan
@@ -228,6 +232,18 @@ struct Plan {
     const int *scan_order = nullptr;
     std::vector<int> dst_map;          // [m] set on a panel: row -> y index (instead of the row id) in natural order
 
+    // row tiles (a column panel only, opt.row_tile_max): the panel's rows of <= rt_max nonzeros, in the PARENT's output order (position j =
+    // the parent's slot j, or row j when the parent writes in row order), tiles of kRowTile positions.  rt_ptr[t]: first element of tile t;
+    // rt_start[j]: first element of position j relative to its tile; rt_mask[t] bit i: position 64 t + i is stored by the tile (it belongs to a
+    // row of <= rt_max nonzeros, empty rows included) -- the other positions belong to this panel's blocks / pieces / slabs.  Elements in CSR order.
+    int rt_max = 0;
+    std::vector<int> rt_ptr;           // [tiles + 1]
+    std::vector<uint16_t> rt_start;    // [tiles * 64]
+    std::vector<uint64_t> rt_mask;     // [tiles]
+    raw_vector<char> rt_val;           // vbytes per element
+    raw_vector<int> rt_cid;
+    size_t cnt_rt = 0;
+
     bool host_dropped = false;
     DevicePlan *dev = nullptr;
 
@@ -261,6 +277,15 @@ int devpack_gather_columns(const Plan &p, const DevCsr &d, const std::vector<lon
 // column-panel split of a device CSR: P sub-matrices by column range (remapped columns, row order kept); `keep` owns the device arrays
 int devpack_panel_split(const Plan &p, const DevCsr &d, const std::vector<int> &bnd, int P, std::vector<std::vector<int>> &rpP_host,
                         std::vector<DevCsr> &out, std::vector<std::shared_ptr<void>> &keep);
+
+// row tiles of a device-built column panel (plan.cpp build_panels): `panel` = the split's sub-matrix, rp_rest = the row pointer of the rows that
+// stay with the panel's plan (host), at[row] = first element of a tiled row in the tiles' arrays (-1: not tiled), cnt = their elements.
+// On return `panel` is the sub-matrix of the remaining rows only and `out` holds the tiles' elements (device, owned by `keep`).
+struct DevRowTiles { void *val = nullptr; int *cid = nullptr; };
+int devpack_row_tiles(const Plan &p, DevCsr &panel, const std::vector<int> &rp_rest, const std::vector<int> &at, size_t cnt,
+                      std::vector<std::shared_ptr<void>> &keep, DevRowTiles *out);
+// ... and their copy into the uploaded panel plan's arena (ArenaMap::rt_val / rt_cid)
+int devpack_place_row_tiles(Plan &q, const DevRowTiles &src);
 
 // builds every host array of `p` from CSR.  T = double or _Float16.  With `dev` set, rp is a host copy of the row pointer,
 // ci / val are ignored and the nnz-sized arrays are produced on the device (the plan comes back uploaded).

@@ -1,8 +1,8 @@
 // planio.cpp -- serialised plans (the reference never stores its packed format).
 // A plan file holds every host array of a Plan, so a later run (or every rank of a multi-GPU job)
 // skips classification and packing: load -> upload -> spmv.
-// layout: "DASPPLN5" | int32 sizeof(dasp_stats_t), kNumShortGroups, sizeof(ShortGroup) | plan, where plan = int32 precision, m, n, nnz,
-//         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows, win_hybrid, med_slot0, pair_mode, win_rel16 | dasp_stats_t |
+// layout: "DASPPLN6" | int32 sizeof(dasp_stats_t), kNumShortGroups, sizeof(ShortGroup) | plan, where plan = int32 precision, m, n, nnz,
+//         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows, win_hybrid, med_slot0, pair_mode, win_rel16, rt_max | dasp_stats_t |
 //         ShortGroup[kNumShortGroups] | for each array, in a fixed order: int64 byte count + bytes | the n_panels column panels, each
 //         a nested plan.
 // A file is not trusted more than a caller's CSR: after reading, every count, pointer array and column id the kernels index
@@ -18,8 +18,8 @@
 namespace dasp {
 
 namespace {
-// bumped with EVERY change of the header, the array list or the element order inside an array (5: 18-int header, one-byte ids, chunk pairs)
-const char kPlanMagic[8] = {'D', 'A', 'S', 'P', 'P', 'L', 'N', '5'};
+// bumped with EVERY change of the header, the array list or the element order inside an array (5: 18-int header, one-byte ids, chunk pairs; 6: 19-int header, row tiles)
+const char kPlanMagic[8] = {'D', 'A', 'S', 'P', 'P', 'L', 'N', '6'};
 
 struct Writer {
     FILE *f; bool ok = true;
@@ -51,11 +51,12 @@ template <class IO> void arrays(IO &io, Plan &p)
     io.vec(p.irr_ptr); io.vec(p.irr_val); io.vec(p.irr_cid);
     io.vec(p.med_dst); io.vec(p.win_cmin); io.vec(p.win_len);
     io.vec(p.short_val); io.vec(p.short_cid);
+    io.vec(p.rt_ptr); io.vec(p.rt_start); io.vec(p.rt_mask); io.vec(p.rt_val); io.vec(p.rt_cid);
 }
 }  // namespace
 
 // Everything upload_plan and the kernels rely on, re-derived from the arrays themselves.  `why` names the first violation.
-static bool validate_plan(const Plan &p, int n_panels, std::string &why)
+static bool validate_plan(const Plan &p, int n_panels, bool is_panel, std::string &why)
 {
     auto fail = [&](const char *w) { why = w; return false; };
     const Geometry geo = p.geo;
@@ -201,6 +202,24 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
             if (t >= 0 && t < G.count) { const long long sl = M.slot(t); if (sl < 0 || sl >= m) return fail("slot map leaves the permutation"); }
     }
     if ((size_t)off != p.cnt_short || p.stats.n_short_tiles != tile0) return fail("short segment size");
+    // ---- row tiles (a column panel only): what row_tile() indexes with
+    if (p.rt_max == 0) { if (!p.rt_ptr.empty() || !p.rt_start.empty() || !p.rt_mask.empty() || p.cnt_rt) return fail("row tiles without rt_max"); }
+    else {
+        const size_t tiles = (size_t)((m + kRowTile - 1) / kRowTile);
+        if (p.rt_max < 0 || p.rt_max > kRowTileMax || !is_panel || p.windowed || p.cnt_reg8) return fail("row tiles: bound / not a plain column panel");
+        if (p.rt_mask.size() != tiles || p.rt_ptr.size() != tiles + 1 || p.rt_start.size() != tiles * kRowTile || !mono(p.rt_ptr) || (size_t)p.rt_ptr.back() != p.cnt_rt)
+            return fail("row tile tables");
+        if (p.rt_val.size() != p.cnt_rt * (size_t)vb || p.rt_cid.size() != p.cnt_rt) return fail("row tile arrays");
+        for (int v : p.rt_cid) if (v < 0 || v >= xlen) return fail("row tile column id out of range");
+        for (size_t t = 0; t < tiles; ++t) {
+            const int n = p.rt_ptr[t + 1] - p.rt_ptr[t];
+            for (int i = 0; i < kRowTile; ++i) {
+                const int s = p.rt_start[t * kRowTile + (size_t)i], e = i + 1 < kRowTile ? p.rt_start[t * kRowTile + (size_t)i + 1] : n;
+                const bool on = (p.rt_mask[t] >> i) & 1;
+                if ((i == 0 && s != 0) || e < s || e > n || e - s > p.rt_max || (!on && e != s) || (on && (long long)t * kRowTile + i >= m)) return fail("row tile row table");
+            }
+        }
+    }
     if (p.win_hybrid && !p.windowed) return fail("win_hybrid without windows");
     if (p.win_rel16) {       // the kernel then takes win_cmin as EVERY chunk's base in an LDS-staged window, without reading med_base
         if (!p.windowed || !p.cid16 || p.win_hybrid) return fail("win_rel16 needs LDS windows with 16-bit ids");
@@ -225,21 +244,25 @@ static bool validate_plan(const Plan &p, int n_panels, std::string &why)
             const int r = p.order[(size_t)slot];
             return p.dst_map.empty() ? r : p.dst_map[(size_t)r];
         };
+        for (size_t t = 0; t < p.rt_mask.size(); ++t)      // a row tile stores its positions of the output order directly
+            for (int i = 0; i < kRowTile; ++i) if (((p.rt_mask[t] >> i) & 1) && !claim((long long)t * kRowTile + i)) return fail("two writers for one y index (row tiles)");
         for (int d : p.piece_dst) if (d >= 0 && !claim(d)) return fail("two writers for one y index (piece_dst)");
         for (int d : p.multi_dst) if (!claim(d)) return fail("two writers for one y index (multi_dst)");
         for (long long r = 0; r < p.n_mfma_rows; ++r)
             if (!claim(p.windowed ? (long long)p.med_dst[(size_t)r] : ydst((long long)p.med_slot0 + r))) return fail("two writers for one y index (medium rows)");
-        for (int g = 0; g < kNumShortGroups; ++g)
+        for (int g = 0; g < kNumShortGroups; ++g) {
+            if (is_panel && p.grp[g].len == 0) continue;       // a panel never stores its empty rows (DevArgs::skip0; the tiled rows are among them)
             for (int t = 0; t < p.grp[g].count; ++t)
                 if (!claim(ydst(g < 5 ? (long long)p.grp[g].map.slot(t) : (long long)p.grp[g].map.base[0] + t))) return fail("two writers for one y index (short rows / slabs)");
+        }
     }
     return true;
 }
 
 static void write_plan(Writer &w, Plan &p)
 {
-    const int hdr[18] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
-                         p.opt.n_parts, p.opt.part_stride, p.opt.stream_policy, (int)p.panels.size(), p.n_mfma_rows, p.win_hybrid ? 1 : 0, p.med_slot0, p.pair_mode, p.win_rel16 ? 1 : 0};
+    const int hdr[19] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
+                         p.opt.n_parts, p.opt.part_stride, p.opt.stream_policy, (int)p.panels.size(), p.n_mfma_rows, p.win_hybrid ? 1 : 0, p.med_slot0, p.pair_mode, p.win_rel16 ? 1 : 0, p.rt_max};
     w.raw(hdr, sizeof hdr); w.raw(&p.stats, sizeof p.stats); w.raw(p.grp, sizeof p.grp);
     arrays(w, p);
     for (auto &h : p.panels) write_plan(w, h->impl);
@@ -247,14 +270,14 @@ static void write_plan(Writer &w, Plan &p)
 
 static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
 {
-    int hdr[18];
+    int hdr[19];
     r.raw(hdr, sizeof hdr);
     if (!r.ok || (hdr[0] != 64 && hdr[0] != 16) || hdr[12] < 0 || hdr[12] > 64 || (depth > 0 && hdr[12] != 0)) return false;
     p.precision = hdr[0]; p.geo = geometry_for(p.precision);
     p.m = hdr[1]; p.n = hdr[2]; p.nnz = hdr[3];
     dasp_options_default(&p.opt);
     p.opt.y_order = hdr[4]; p.windowed = hdr[5] != 0; p.row_window = hdr[6]; p.lds_bytes = hdr[7]; p.cid16 = hdr[8] != 0;
-    p.opt.n_parts = hdr[9]; p.opt.part_stride = hdr[10]; p.opt.stream_policy = hdr[11]; p.n_mfma_rows = hdr[13]; p.win_hybrid = hdr[14] != 0; p.med_slot0 = hdr[15]; p.pair_mode = hdr[16]; p.win_rel16 = hdr[17] != 0;
+    p.opt.n_parts = hdr[9]; p.opt.part_stride = hdr[10]; p.opt.stream_policy = hdr[11]; p.n_mfma_rows = hdr[13]; p.win_hybrid = hdr[14] != 0; p.med_slot0 = hdr[15]; p.pair_mode = hdr[16]; p.win_rel16 = hdr[17] != 0; p.rt_max = hdr[18];
     if (p.pair_mode < 0 || p.pair_mode > 2 || (p.windowed && p.pair_mode)) return false;
     r.raw(&p.stats, sizeof p.stats); r.raw(p.grp, sizeof p.grp);
     arrays(r, p);
@@ -274,9 +297,10 @@ static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
     p.cnt_long = p.long_cid.size(); p.cnt_irr = p.irr_cid.size(); p.cnt_short = p.short_cid.size();
     p.cnt_reg = p.cid16 ? p.med_cid16.size() + p.med_cid8.size() : p.med_cid.size();
     p.cnt_reg8 = p.med_cid8.size();
+    p.cnt_rt = p.rt_cid.size();
     p.host_dropped = false;
     p.panel = depth > 0;
-    if (!validate_plan(p, np, r_why)) return false;
+    if (!validate_plan(p, np, depth > 0, r_why)) return false;
     p.opt.col_panels = np > 0 ? np : 1;
     for (int k = 0; k < np; ++k) {
         std::unique_ptr<dasp_plan> h(new dasp_plan());
@@ -316,7 +340,7 @@ int load_plan(Plan &p, const char *path)
     r.raw(magic, 8);
     r.raw(abi, sizeof abi);
     if (!r.ok || std::memcmp(magic, kPlanMagic, 8) != 0 || abi[0] != (int)sizeof(dasp_stats_t) || abi[1] != kNumShortGroups || abi[2] != (int)sizeof(ShortGroup)) {
-        std::fclose(f); set_error("not a DASPPLN5 plan file of this build (magic / struct sizes differ)"); return DASP_ERR_BANNER;
+        std::fclose(f); set_error("not a DASPPLN6 plan file of this build (magic / struct sizes differ)"); return DASP_ERR_BANNER;
     }
     std::string why;
     bool ok = false;

@@ -790,11 +790,34 @@ __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
 // launch bounds: the windowed kernel is held to 64 registers so that two 1024-thread window workgroups share a CU
 // (A/B: 12.9 vs 15.0 us on cop20k_A); blocks are dealt to workgroups in the default round-robin order (length-sorted
 // blocks in XCD-contiguous ranges put all the long ones on one XCD: DESIGN.md 4.4)
+//
+// ---- row tile of a column panel (Plan::rt_*, no reference counterpart): 64 consecutive positions of the parent's output order, the rows of
+// at most rt_max nonzeros among them.  The wave streams the tile's elements (CSR order, one per lane and step), parks the products in its
+// LDS slice, then lane r adds row r's products in their CSR order and the wave stores one complete line (f16) / two lines (f64) of the
+// panel's partial result -- the positions of longer rows (mask bit 0) are left to the panel's blocks.  prod: this wave's 64 * rt_max sums.
+template <class T, bool NT>
+__device__ __forceinline__ void row_tile(const DevArgs &a, int t, int lane, typename Tr<T>::part_t *prod)
+{
+    using part_t = typename Tr<T>::part_t;
+    const T *x = static_cast<const T *>(a.x), *val = static_cast<const T *>(a.rt_val);
+    const int e0 = a.rt_ptr[t], n = a.rt_ptr[t + 1] - e0;
+    const int s = a.rt_start[(size_t)t * kRowTile + lane];
+#pragma unroll 4
+    for (int i = lane; i < n; i += kWave) prod[i] = (part_t)ldg<NT>(val + e0 + i) * (part_t)x[ldg<NT>(a.rt_cid + e0 + i)];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // this wave's LDS writes before its LDS reads (another lane's)
+    __builtin_amdgcn_wave_barrier();
+    int e = __shfl_down(s, 1);
+    if (lane == kWave - 1) e = n;
+    part_t sum = 0;
+    for (int j = s; j < e; ++j) sum += prod[j];
+    if ((a.rt_mask[t] >> lane) & 1) put_y<T>(a, t * kRowTile + lane, sum);
+}
+
 constexpr int kMinWavesPlain = 1, kMinWavesWin = 8;
 // WIN: windowed mode.  A medium workgroup owns one window of row_window rows (blocks_per_win blocks, strided over its
 // 4 waves); if the window's x span fits, it is copied once into LDS with coalesced 16-byte loads and every gather of
 // the window reads LDS; otherwise that workgroup gathers from global memory like the non-windowed kernel.
-template <class T, bool NT, bool C16, bool WIN, bool C8>
+template <class T, bool NT, bool C16, bool WIN, bool C8, bool RT = false>
 __device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw)
 {
     const int lane = threadIdx.x & 63;
@@ -879,9 +902,12 @@ __device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw)
                 }
             }
         }
-    } else {
+    } else if (!RT || wg < a.wg_long + a.wg_med + a.wg_short) {
         const int t = (wg - a.wg_long - a.wg_med) * wpw + wave;
         if (t < a.n_short_tiles) short_tile<T, NT, 0, !WIN>(a, t, lane);
+    } else if constexpr (RT) {
+        const int t = (wg - a.wg_long - a.wg_med - a.wg_short) * kWavesPerWG + wave;
+        if (t < a.n_rt_tiles) row_tile<T, NT>(a, t, lane, reinterpret_cast<typename Tr<T>::part_t *>(lds_raw) + (size_t)wave * kRowTile * a.rt_max);
     }
 }
 

@@ -110,6 +110,11 @@ static int upload_plan_impl(Plan &p)
     const size_t o_sv = add(src_of(p.short_val), p.cnt_short * vbytes);
     const size_t o_sc = add(src_of(p.short_cid), p.cnt_short * 4);
     const size_t o_g = add(groups.data(), groups.size() * sizeof(ShortDev));
+    const size_t o_rv = add(src_of(p.rt_val), p.cnt_rt * vbytes);
+    const size_t o_rc = add(src_of(p.rt_cid), p.cnt_rt * 4);
+    const size_t o_rp = add(p.rt_ptr.data(), p.rt_ptr.size() * 4);
+    const size_t o_rs = add(p.rt_start.data(), p.rt_start.size() * 2);
+    const size_t o_rm = add(p.rt_mask.data(), p.rt_mask.size() * 8);
     std::vector<int> ord_mapped;   // a column panel writes row r to dst_map[r] (its parent's slot), not to r
     if (natural && !p.dst_map.empty()) { ord_mapped.resize(p.order.size()); for (size_t i = 0; i < p.order.size(); ++i) ord_mapped[i] = p.dst_map[(size_t)p.order[i]]; }
     const size_t o_ord = add(natural ? (ord_mapped.empty() ? p.order.data() : ord_mapped.data()) : nullptr, natural ? p.order.size() * 4 : 0);
@@ -127,6 +132,7 @@ static int upload_plan_impl(Plan &p)
 
     d->map.long_val = o_lv; d->map.long_cid = o_lc; d->map.med_val = o_mv; d->map.med_cid = o_mc; d->map.med_cid16 = o_mc16; d->map.med_cid8 = o_mc8;
     d->map.med_base = o_mb; d->map.irr_val = o_iv; d->map.irr_cid = o_ic; d->map.short_val = o_sv; d->map.short_cid = o_sc;
+    d->map.rt_val = o_rv; d->map.rt_cid = o_rc;
     DevArgs &a = d->args;
     a.long_val = base + o_lv; a.long_cid = (const int *)(base + o_lc);
     a.piece_ptr = (const int *)(base + o_pp); a.piece_dst = (const int *)(base + o_pd);
@@ -208,6 +214,9 @@ static int upload_plan_impl(Plan &p)
         }
     }
     a.wg_short = (a.n_short_tiles + a.wpw - 1) / a.wpw;
+    a.rt_val = base + o_rv; a.rt_cid = (const int *)(base + o_rc); a.rt_ptr = (const int *)(base + o_rp);
+    a.rt_start = (const unsigned short *)(base + o_rs); a.rt_mask = (const unsigned long long *)(base + o_rm);
+    a.n_rt_tiles = (int)p.rt_mask.size(); a.wg_rt = (a.n_rt_tiles + kWavesPerWG - 1) / kWavesPerWG; a.rt_max = p.rt_max;
     // streamed-once matrix data bypasses the caches (the reference's ld.global.cs, dasp_f64.h:34-51)
     // only when it cannot stay resident in the 256 MiB Infinity Cache between two SpMVs anyway.
     d->nt = p.opt.stream_policy == 2 || (p.opt.stream_policy != 1 && p.stats.data_X > kStreamBytes);

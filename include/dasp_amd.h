@@ -162,6 +162,15 @@ typedef struct dasp_options {
      * 0.668 -> 0.662 ms; f16 and the windowed kernels lose); -1 = off (slabs); 1 = on.  order_rid, every counter
      * and the order of a row's products are unchanged; the sum of a row of 4 is (p0 + p1) + (p2 + p3) instead of ((p0 + p1) + p2) + p3. */
     int short_seg;
+    /* row tiles of the column panels (no reference counterpart): a panel's rows of at most `row_tile_max` nonzeros IN THAT
+     * PANEL are not classified and sorted by the panel but kept in the parent's output order, in tiles of 64 consecutive output positions: one
+     * wave streams a tile's (value, column) pairs in CSR order, parks the products in LDS, lane r sums row r's products in their CSR order and
+     * the wave stores ONE complete 128-byte line of the panel's partial result (f16; two lines in f64) -- instead of 2-byte pieces of lines
+     * that other workgroups complete (ljournal-2008 f16: 333 MB written per SpMV for 54 MB of partial results).  The rows above the bound stay
+     * with the panel's own blocks / pieces.  0 = auto (16: ljournal-2008 f16 0.507 -> 0.444 ms, 333 -> ~100 MB written; powerlaw_1M f64 0.653 ->
+     * 0.646); -1 = off; 1..32 = that bound (LDS: 256 x bound products per workgroup).  Plans without column panels ignore it.  order_rid, the
+     * classifier counters and the order of a row's products are unchanged (a tiled row is summed in CSR order, as the oracle does). */
+    int row_tile_max;
 } dasp_options_t;
 
 void dasp_options_default(dasp_options_t *opt);
@@ -192,6 +201,9 @@ typedef struct dasp_stats {
     int chunk_pairs;           /* 0 / 1 / 2: which medium blocks store chunk pairs (options chunk_pairs; column panels: the largest) */
     int cid8_chunks;           /* regular medium chunks with one-byte column ids (option cid8) */
     int short_seg;             /* 1: the short rows (1..4 nonzeros) use the wave-segmented DPP layout */
+    int row_tile_max;          /* column panels: rows of at most this many nonzeros per panel are stored as row tiles (0: none) */
+    int n_row_tiles;           /* row tiles over all panels */
+    long long row_tile_nnz;    /* nonzeros stored in row tiles */
     /* the REFERENCE's geometry on the same input (8-row blocks, 8x4 tiles, 32-lane warps): the padded sizes the CUDA reference computes
      * and writes into its CSV row for this matrix -- short tiles dasp_f64.h:609-629 / dasp_f16.h:1139-1156, long rows :1000-1014 /
      * :1273-1288, regular / irregular split :1044-1091 / :1317-1365, rate_fill0 and data_X :1159-1166 / dasp_f16.h:1448-1455.  Functions

@@ -1048,8 +1048,8 @@ def test_wave_segmented_short_rows_against_the_oracle(oracle, dasp, torch_cuda, 
     plan.close()
 
 
-NNZ_ARRAYS = ("long_val long_cid med_val med_cid med_cid16 med_cid8 med_base irr_val irr_cid short_val short_cid").split()
-META_ARRAYS = ("piece_ptr piece_dst multi_ptr multi_dst med_ptr med_c8ptr med_korig irr_ptr med_dst win_cmin win_len short_groups").split()
+NNZ_ARRAYS = ("long_val long_cid med_val med_cid med_cid16 med_cid8 med_base irr_val irr_cid short_val short_cid rt_val rt_cid").split()
+META_ARRAYS = ("piece_ptr piece_dst multi_ptr multi_dst med_ptr med_c8ptr med_korig irr_ptr med_dst win_cmin win_len short_groups rt_ptr rt_start rt_mask").split()
 
 
 @pytest.mark.parametrize("prec", [64, 16])
@@ -1337,7 +1337,7 @@ def test_stream_policies_give_identical_results(dasp, torch_cuda, prec):
 # ---- column panels (dasp_options_t::col_panels): P natural-order plans over column ranges + a streaming sum
 @pytest.mark.parametrize("prec", [64, 16])
 @pytest.mark.parametrize("kw", [dict(col_panels=2), dict(col_panels=3, cid16=1), dict(col_panels=8, x_window=-1), dict(col_panels=5, long_piece=256),
-                                dict(col_panels=64)])
+                                dict(col_panels=64), dict(col_panels=3, row_tile_max=16), dict(col_panels=2, row_tile_max=3), dict(col_panels=4, row_tile_max=-1)])
 @pytest.mark.parametrize("tag,builder,m,n,seed", [("mixed", util.mixed_matrix, 3000, 2500, 7), ("pairs", util.pair_heavy_matrix, 4000, 2500, 11)])
 def test_column_panels_parity(oracle, dasp, torch_cuda, prec, kw, tag, builder, m, n, seed):
     rp, ci, v = builder(m, n, seed)
@@ -1411,7 +1411,8 @@ def test_device_csr_takes_the_same_automatic_panel_decision(dasp, torch_cuda, na
 
 
 @pytest.mark.parametrize("prec", [64, 16])
-@pytest.mark.parametrize("kw", [dict(col_panels=3), dict(col_panels=4, cid16=1, y_order=1), dict(col_panels=2, x_window=-1, long_piece=256)])
+@pytest.mark.parametrize("kw", [dict(col_panels=3), dict(col_panels=4, cid16=1, y_order=1), dict(col_panels=2, x_window=-1, long_piece=256), dict(col_panels=3, row_tile_max=7),
+                                dict(col_panels=2, row_tile_max=16, y_order=1)])
 def test_device_built_column_panels_are_bit_identical(oracle, dasp, torch_cuda, prec, kw):
     """r3: explicit column panels from a CSR that lives on the GPU -- the split by column range runs as two kernels (one wave per
     row, the entries of a row ranked per panel with ballots so they keep their order), every panel is packed on the device: the

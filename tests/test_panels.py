@@ -21,14 +21,14 @@ def rows_of(plan, m):
 
 @pytest.mark.parametrize("prec", [64, 16])
 @pytest.mark.parametrize("y_order", [0, 1])
-@pytest.mark.parametrize("P", [2, 3, 7])
-def test_panels_partition_the_matrix(dasp, prec, y_order, P):
+@pytest.mark.parametrize("P,tile", [(2, 0), (3, -1), (7, 5), (3, 32)])
+def test_panels_partition_the_matrix(dasp, prec, y_order, P, tile):
     dt = np.float64 if prec == 64 else np.float16
     m, n = 1500, 5000
     lens = np.random.default_rng(3).choice([0, 1, 2, 3, 4, 9, 40, 300, 700], size=m, p=[.05, .15, .1, .15, .1, .2, .15, .07, .03])
     rp, ci, v = util.csr_from_lengths(lens, n, 5, dtype=dt)
     single = dasp.Plan(rp, ci, v, n, precision=prec, y_order=y_order, col_panels=1)
-    plan = dasp.Plan(rp, ci, v, n, precision=prec, y_order=y_order, col_panels=P)
+    plan = dasp.Plan(rp, ci, v, n, precision=prec, y_order=y_order, col_panels=P, row_tile_max=tile)      # 0 = auto: 16
     assert single.n_panels == 0 and single.stats["n_col_panels"] == 0
     assert plan.n_panels == P and plan.stats["n_col_panels"] == P
     np.testing.assert_array_equal(plan.order_rid, single.order_rid)
@@ -53,10 +53,12 @@ def test_panels_partition_the_matrix(dasp, prec, y_order, P):
             assert all(cb <= c < ce for c, _ in ent)
             got[r] += ent
             nnz_k += len(ent)
-        assert nnz_k == sub.stats["nnzA"]
+        assert nnz_k == sub.stats["nnzA"] + sub.stats["row_tile_nnz"]      # (the panels keep their short rows in row tiles)
+        assert (sub.stats["row_tile_nnz"] > 0) == (tile >= 0) and sub.stats["row_tile_max"] == (0 if tile < 0 else tile or 16) and sub.stats["n_row_tiles"] == (-(-m // 64) if tile >= 0 else 0)
     assert prev_end == n
     assert [sorted(g) for g in got] == want
-    assert sum(plan.panel(k)[0].stats["nnzA"] for k in range(P)) == ci.size
+    assert sum(plan.panel(k)[0].stats["nnzA"] + plan.panel(k)[0].stats["row_tile_nnz"] for k in range(P)) == ci.size
+    assert plan.stats["row_tile_nnz"] == sum(plan.panel(k)[0].stats["row_tile_nnz"] for k in range(P))
 
 
 def test_empty_panels_are_dropped_and_auto_stays_off_for_small_inputs(dasp):

@@ -184,4 +184,25 @@ def decode_plan(plan):
             slot = slot_of(g, t)
             assert slot not in out
             out[slot] = ([int(sc[a]) for a in at], [sv[a] for a in at])
+    # row tiles of a column panel: position j of the parent's output order (its slot, or the row id when it writes in row order) -> the row;
+    # the row sits among this panel's empty rows, at the slot its own order_rid gives it
+    rt_ptr = plan.host_array("rt_ptr")
+    if rt_ptr.size:
+        rt_start, rt_mask = plan.host_array("rt_start").astype(np.int64), plan.host_array("rt_mask")
+        rt_val, rt_cid = plan.host_array("rt_val"), plan.host_array("rt_cid")
+        T = st["row_tile_max"]
+        assert 0 < T <= 32 and rt_mask.size == rt_ptr.size - 1 == -(-plan.order_rid.size // 64) and rt_start.size == 64 * rt_mask.size and rt_cid.size == rt_val.size == rt_ptr[-1] == st["row_tile_nnz"]
+        row_of_pos = np.argsort(dmap) if dmap.size else np.arange(plan.order_rid.size)
+        own_slot = np.argsort(plan.order_rid)
+        for t in range(rt_mask.size):
+            n = int(rt_ptr[t + 1] - rt_ptr[t])
+            for i in range(64):
+                s0 = int(rt_start[t * 64 + i]); s1 = int(rt_start[t * 64 + i + 1]) if i < 63 else n
+                on = (int(rt_mask[t]) >> i) & 1
+                assert 0 <= s1 - s0 <= T and (on or s1 == s0) and (i or s0 == 0)
+                if s1 > s0:
+                    slot = int(own_slot[row_of_pos[t * 64 + i]])
+                    assert out.get(slot, ([], [])) == ([], [])        # (the row is one of the panel plan's own empty rows)
+                    a = int(rt_ptr[t]) + s0
+                    out[slot] = (rt_cid[a:a + s1 - s0].tolist(), rt_val[a:a + s1 - s0].tolist())
     return out
