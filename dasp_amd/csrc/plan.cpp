@@ -712,12 +712,14 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     // ---- long rows: compact, padded to kLongAlign; one wave per piece
     std::vector<long long> startL;
     int piece = p.opt.long_piece > 0 ? p.opt.long_piece : 1024;
-    if (p.opt.long_piece <= 0 && nnz_pieces <= 2000000) {
-        // few long nonzeros (launch-bound matrices): one piece per row, so that the second launch (long_reduce) disappears;
-        // it costs ~2.7 us per SpMV on the webbase-1M stand-in (19.7 -> 17.0 us)
+    if (p.opt.long_piece <= 0) {
+        // one piece per row, so that the second launch (long_reduce) disappears, when that leaves no wave with a long tail of its own: few
+        // long nonzeros in rows of <= 16384 (launch-bound matrices: the launch costs ~2.7 us per SpMV on the webbase-1M stand-in, 19.7 ->
+        // 17.0 us), or no row beyond 4096 at all (r4: the four panels of ljournal-2008 each paid a ~5 us launch for ~540 rows of 1025..2469)
         int longest = 0;
         for (int r : ridL) longest = std::max(longest, rp[r + 1] - rp[r]);
-        if (longest <= 16384) piece = std::max(piece, longest);
+        const int one_piece = std::getenv("DASP_ONE_PIECE_MAX") ? std::atoi(std::getenv("DASP_ONE_PIECE_MAX")) : 4096;      // (A/B knob)
+        if ((nnz_pieces <= 2000000 && longest <= 16384) || longest <= one_piece) piece = std::max(piece, longest);
     }
     piece = std::max(geo.chunk, ceil_div(piece, geo.chunk) * geo.chunk);
     {

@@ -84,7 +84,7 @@ typedef struct dasp_options {
     int block_longest;     /* rows with >= this many nonzeros are "long"; reference: 256 (main_f64.cu:124) */
     int y_order;           /* dasp_y_order */
     int long_piece;        /* nonzeros of a long row given to one wave; 0 = default (1024; the longest row when the long
-                              rows hold <= 2 M nonzeros in rows of <= 16384, so that no second launch is needed) */
+                              rows hold <= 2 M nonzeros in rows of <= 16384, or when no row is longer than 4096, so that no second launch is needed) */
     int host_threads;      /* preprocessing threads; 0 = hardware concurrency */
     /* column remap for the row-partitioned multi-GPU layout (0/NULL = identity):
      * column c owned by part g (part_bounds[g] <= c < part_bounds[g+1]) is read from
