@@ -470,10 +470,10 @@ def test_plan_files_with_two_writers_for_one_y_are_rejected(dasp, tmp_path):
     rp, ci, v = util.mixed_matrix(2500, 2000, 13)
     path = str(tmp_path / "p.plan")
 
-    def damaged(plan, name, mutate):
+    def damaged(plan, name, mutate, holder=None):
         plan.save(path)
         blob = bytearray(open(path, "rb").read())
-        arr = plan.host_array(name)
+        arr = (holder or plan).host_array(name)
         raw = arr.tobytes()
         key = len(raw).to_bytes(8, "little") + raw                       # every array is stored behind its int64 byte count
         at = bytes(blob).find(key)
@@ -500,6 +500,15 @@ def test_plan_files_with_two_writers_for_one_y_are_rejected(dasp, tmp_path):
     rp2, ci2, v2 = util.csr_from_lengths(lens, 900, 3)
     plan = dasp.Plan(rp2, ci2, v2, 900, y_order=dasp.Y_NATURAL)           # long rows: piece_dst
     damaged(plan, "piece_dst", dup)
+    plan.close()
+    plan = dasp.Plan(rp, ci, v, 2000, col_panels=2, row_tile_max=4)       # a panel's row tiles claiming the positions of its blocks' rows too
+    sub = plan.panel(0)[0]
+    assert sub.stats["row_tile_nnz"] > 0 and sub.stats["row_block"] > 0
+
+    def all_on(a):
+        a[:-1] = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    damaged(plan, "rt_mask", all_on, holder=sub)
     plan.close()
 
 
