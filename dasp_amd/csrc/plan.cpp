@@ -1169,6 +1169,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     std::vector<DevCsr> devP;                          // device CSR: the same split by two kernels (devpack.hip), sub-matrices stay on the GPU
     std::vector<std::shared_ptr<void>> dev_keep;
     std::vector<DevRowTiles> rt_dev((size_t)P);        // device path: the tiles' elements, moved into the panel plan's arena once it exists
+    std::vector<std::vector<std::shared_ptr<void>>> rt_keep((size_t)P);
     const bool natural = p.opt.y_order == DASP_Y_NATURAL;
     std::vector<int> slot_of_row;
     if (!natural) { slot_of_row.resize((size_t)m); for (int i = 0; i < m; ++i) slot_of_row[p.order[i]] = i; }
@@ -1213,7 +1214,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
                     for (int i = 0; i < m; ++i) q[i + 1] += q[i];
                 }
             });
-            for (int k = 0; k < P; ++k) if (int rc = devpack_row_tiles(p, devP[(size_t)k], rpP[(size_t)k], rt[(size_t)k].at, rt[(size_t)k].cnt, dev_keep, &rt_dev[(size_t)k])) return rc;
+            // (the device moves each panel's elements in that panel's worker below, beside the other panels' builds)
         }
     } else {
     for (auto &v : rpP) v.assign((size_t)m + 1, 0);
@@ -1263,6 +1264,10 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
                     const int nnz_k = rpP[k][m];
                     RowTiles &R = rt[(size_t)k];
                     if (nnz_k == 0 && R.cnt == 0) continue;         // an empty panel adds nothing
+                    if (dev && rt_max > 0) {
+                        rcs[k] = devpack_row_tiles(p, devP[(size_t)k], rpP[(size_t)k], R.at, R.cnt, rt_keep[(size_t)k], &rt_dev[(size_t)k]);
+                        if (rcs[k] != DASP_OK) { errs[k] = last_error_cstr(); continue; }
+                    }
                     std::unique_ptr<dasp_plan> h(new dasp_plan());
                     Plan &q = h->impl;
                     q.precision = p.precision; q.geo = p.geo; q.m = m; q.n = (int)xlen; q.nnz = nnz_k;

@@ -24,7 +24,7 @@ SPMV_KERNELS = ("dasp_spmv_kernel", "dasp_long_reduce_kernel", "dasp_panel_sum_k
 
 def spmv_kernel(name):
     """which SpMV kernel a (possibly mangled: rocprofv3 does not demangle the _Float16 instantiations) name is, or None"""
-    if "dasp_spmv_win1_kernel" in name:          # the 128-register build of the windowed kernel (plans of <= 256 windows)
+    if "dasp_spmv_win1_kernel" in name or "dasp_spmv_rt_kernel" in name:      # the 128-register build of the windowed kernel (plans of <= 256 windows) / a column panel with row tiles
         return "dasp_spmv_kernel"
     for k in SPMV_KERNELS:
         if k in name:
