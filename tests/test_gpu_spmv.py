@@ -1337,7 +1337,7 @@ def test_stream_policies_give_identical_results(dasp, torch_cuda, prec):
 # ---- column panels (dasp_options_t::col_panels): P natural-order plans over column ranges + a streaming sum
 @pytest.mark.parametrize("prec", [64, 16])
 @pytest.mark.parametrize("kw", [dict(col_panels=2), dict(col_panels=3, cid16=1), dict(col_panels=8, x_window=-1), dict(col_panels=5, long_piece=256),
-                                dict(col_panels=64), dict(col_panels=3, row_tile_max=16), dict(col_panels=2, row_tile_max=3), dict(col_panels=4, row_tile_max=-1)])
+                                dict(col_panels=64), dict(col_panels=3, row_tile_max=32), dict(col_panels=2, row_tile_max=3), dict(col_panels=4, row_tile_max=-1)])
 @pytest.mark.parametrize("tag,builder,m,n,seed", [("mixed", util.mixed_matrix, 3000, 2500, 7), ("pairs", util.pair_heavy_matrix, 4000, 2500, 11)])
 def test_column_panels_parity(oracle, dasp, torch_cuda, prec, kw, tag, builder, m, n, seed):
     rp, ci, v = builder(m, n, seed)
