@@ -1484,7 +1484,8 @@ def test_random_option_combinations(oracle, dasp, torch_cuda, seed):
               x_window=int(rng.choice([-1, 0, 0, 40000, 163840])), row_window=int(rng.choice([0, 64, 256, 1024])), x_window_hybrid=int(rng.choice([0, 0, 1, -1])), piece_min_len=int(rng.choice([0, 0, -1, 6, 40])), chunk_pairs=int(rng.choice([0, 0, -1, 1, 2])), cid8=int(rng.choice([0, 0, -1])),
               long_piece=int(rng.choice([0, 64, 300, 4096])), block_longest=int(rng.choice([256, 256, 32, 1000])),
               threshold=float(rng.choice([0.75, 0.75, 0.3, 1.0])), y_order=int(rng.choice([0, 1])),
-              slab_max_len=int(rng.choice([0, 4, 7, 16, 32])))
+              slab_max_len=int(rng.choice([0, 4, 7, 16, 32])),
+              row_tile_max=int(np.random.default_rng(5000 + seed).choice([0, 0, -1, 1, 5, 32])))      # (its own generator: the other draws stay what they were)
     part = None
     if rng.random() < 0.4 and n >= 3:
         cuts = np.sort(rng.choice(np.arange(1, n), size=min(2, n - 1), replace=False))
