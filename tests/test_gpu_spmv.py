@@ -1345,6 +1345,26 @@ def test_column_panels_parity(oracle, dasp, torch_cuda, prec, kw, tag, builder, 
 
 
 @pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("m,n,lens_set", [(1000, 500, [1, 2, 3]), (130, 400, [0, 1]), (64, 128, [2]), (1, 64, [1]), (4097, 9000, [0, 5, 16, 17, 40])])
+def test_column_panels_whose_rows_all_sit_in_row_tiles(oracle, dasp, torch_cuda, tmp_path, prec, m, n, lens_set):
+    """row tiles at their edges: panels with NO row left for their own blocks (every row <= the bound: the panel plan is empty but for its tiles), a last tile
+    of one position, bounds that cut through the lengths -- against the oracle, and again after a round trip through a plan file"""
+    dt = np.float64 if prec == 64 else np.float16
+    lens = np.random.default_rng(m).choice(lens_set, size=m)
+    rp, ci, v = util.csr_from_lengths(lens, n, 3, values="f16" if prec == 16 else "uniform", dtype=dt)
+    for T in (0, 16 if max(lens_set) > 16 else 2):
+        check(oracle, dasp, torch_cuda, rp, ci, v, n, prec, col_panels=2, row_tile_max=T)
+    plan = dasp.Plan(rp, ci, v, n, precision=prec, col_panels=2)
+    assert plan.stats["row_tile_nnz"] == (ci.size if max(lens_set) <= 16 else plan.stats["row_tile_nnz"]) and plan.stats["n_row_tiles"] == plan.n_panels * -(-m // 64)
+    path = str(tmp_path / "tiles.plan")
+    plan.save(path)
+    x = np.random.default_rng(5).uniform(0.5, 1.5, n).astype(dt)
+    y0 = run_spmv(torch_cuda, plan.upload(), x, m, prec)
+    y1 = run_spmv(torch_cuda, dasp.Plan.load(path).upload(), x, m, prec)
+    assert np.array_equal(y0, y1)
+
+
+@pytest.mark.parametrize("prec", [64, 16])
 def test_column_panels_with_long_rows_and_unaligned_y(oracle, dasp, torch_cuda, prec):
     torch = torch_cuda
     dt = np.float64 if prec == 64 else np.float16
