@@ -103,6 +103,7 @@ struct MgStepCtl {
     long long timeout_ticks;                           // 100 MHz ticks a wait may take before it gives up and sets the error word
     double poll_at;                                    // where the waiting workgroups stand in the grid, as a fraction of the own-column workgroups (1: last)
     void *err;                                         // the sticky error word (host-mapped, so that the host reads it without a synchronisation); null: words + kMgWordErr
+    int ready_by_event;                                // 1: the kernel does not publish "ready"; the caller does, behind the launch on the same stream (multigpu.cpp ready_by_kernel)
 };
 bool mg_step_supported(const Plan &own, const Plan *other);
 // host: which own-column workgroups of the step kernel store a row with has_other[row] != 0 (natural-order plan, before the

@@ -44,6 +44,7 @@ struct StepCtl {
     const int *blk_order;                 // [medium blocks of plan a] dispatch order: the blocks of marked workgroups first
     int sleep;                            // s_sleep(8) repetitions between two polls (~0.2 us each)
     long long timeout;                    // 100 MHz ticks after which a waiting workgroup gives up
+    int count_all;                        // 1: every workgroup arrives at the `ready` counter; 0: the caller publishes "y ready" behind the launch (stream order)
 };
 
 // arrival of a workgroup at a two-level counter: true for the one that arrives last.  64 sharded counters, each on a 128-byte line
@@ -76,6 +77,8 @@ __global__ __launch_bounds__(256, 6) void dasp_mg_step_kernel(DevArgs a, DevArgs
     const int total = c.grid_a + c.n_poll;
     if (own_wg) {
         plain_wg<double, NT, true, true, 1>(a, wg, wave, lane, c.blk_order);
+        // ("ready" published behind the launch: a workgroup nobody waits for just ends -- no wait for its stores, no barrier, no atomic)
+        if (!c.count_all && !(c.n_marked > 0 && tab<true>(c.mark, wg))) return;
         // done: every wave's write-through stores acknowledged, then ONE lane counts the workgroup.  Relaxed atomics: the y values went
         // out through sc0 sc1 stores, so an arrival needs no cache write-back or invalidate of its own (an acq_rel add costs every
         // workgroup a buffer_wbl2 + buffer_inv: measured 300 instead of 70 us per step)
@@ -85,8 +88,8 @@ __global__ __launch_bounds__(256, 6) void dasp_mg_step_kernel(DevArgs a, DevArgs
             if (c.n_marked > 0 && tab<true>(c.mark, wg) &&
                 arrive_last(c.mark_shards, c.mark_top, wg & (kArriveShards - 1), tab<true>(c.mark_members, wg & (kArriveShards - 1)), (unsigned)c.n_mark_shards))
                 __hip_atomic_store(c.own_go, c.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (arrive_last(c.all_shards, c.all_top, wg & (kArriveShards - 1), shard_members(total, wg & (kArriveShards - 1)),
-                            (unsigned)(total < kArriveShards ? total : kArriveShards)))
+            if (c.count_all && arrive_last(c.all_shards, c.all_top, wg & (kArriveShards - 1), shard_members(total, wg & (kArriveShards - 1)),
+                                           (unsigned)(total < kArriveShards ? total : kArriveShards)))
                 __hip_atomic_store(c.ready, c.step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
@@ -125,6 +128,7 @@ __global__ __launch_bounds__(256, 6) void dasp_mg_step_kernel(DevArgs a, DevArgs
     __syncthreads();
     if (go)
         for (int v = wg - c.grid_a; v < c.grid_b; v += c.n_poll) plain_wg<double, NT, true, true, 2>(b, v, wave, lane, nullptr);
+    if (!c.count_all) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0 && arrive_last(c.all_shards, c.all_top, wg & (kArriveShards - 1), shard_members(total, wg & (kArriveShards - 1)),
@@ -297,6 +301,7 @@ int launch_mg_step(Plan &own, Plan *other, const void *x_own, const void *x_gath
     c.n_marked = other ? h.n_marked : 0; c.n_mark_shards = h.n_mark_shards;
     c.blk_order = static_cast<const int *>(h.blk_order);
     c.sleep = std::max(1, h.poll_sleep); c.timeout = h.timeout_ticks;
+    c.count_all = h.ready_by_event ? 0 : 1;
     const int grid = c.grid_a + c.n_poll;
     if (grid <= 0) { set_error("empty step"); return DASP_ERR_STATE; }
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -247,6 +247,12 @@ struct dasp_mg_plan {
     uint64_t epoch = 0;                // dasp_mg_set_x / connect count: what this rank last published to its peers' epoch_of[rank]
     bool peers_pending = false;        // the peers have not been seen at `epoch` yet (checked before the next exchange is queued)
     int push_wgs = 256;                // workgroups of the push kernel (DASP_MG_PUSH_WGS)
+    // fused step + direct exchange: "y ready" is published by a one-lane kernel BEHIND the step kernel on the caller's stream (stream order = every workgroup
+    // done) instead of by the last of the step's workgroups to arrive at a counter -- the workgroups nobody waits for then simply end: no wait for their
+    // stores, no barrier, no atomic.  HV15R rank 1 of 8: 78.4 / 76.6 / 82.0 -> 76.9 / 76.9 / 80.9 us at a 0 / 30 / 45-us exchange, Queen_4147 95.7 / 94.9 / 94.3 ->
+    // 94.1 / 92.8 / 92.5 (tools/ready_event_ab.sh; an EVENT to the communication stream instead: 80.8 / 88.6 / 100.5, its latency sits on the exchange's
+    // critical path).  DASP_MG_READY_KERNEL=0: the in-kernel counter (A/B knob).
+    bool ready_by_kernel = true;
     // one-stream step (step2): the plan's virtual workgroups, those without boundary rows first; products since dasp_mg_set_x (x_k2 lives in
     // half k2 & 1 of the gather buffer, this rank's y_k2 in its own slot there); the newest slice already sent to the peers
     std::vector<int> wg_list;
@@ -526,6 +532,7 @@ int product(dasp_mg_plan &g, hipStream_t s)
         c.n_marked = g.n_marked; c.n_mark_shards = g.n_mark_shards; c.blk_order = g.d_blk_order;
         c.max_pollers = g.push ? g.max_pollers_thin : g.max_pollers; c.timeout_ticks = g.timeout_ticks; c.poll_sleep = g.poll_sleep;
         c.poll_at = g.poll_at;
+        c.ready_by_event = g.ready_by_kernel && g.push ? 1 : 0;
         if (int rc = launch_mg_step(g.own->impl, g.other ? &g.other->impl : nullptr, g.ys[cur], g.gcur(), g.ys[nxt], c, s)) return rc;
     } else if (g.overlap && !g.step2) {
         // own columns: needs only this rank's slice of x, i.e. its own previous y -- no communication
@@ -684,6 +691,7 @@ int push_enable(dasp_mg_plan &g)
         MG_HIP(hipMemset(p, 0, kMgWordBytes));
         g.words = static_cast<char *>(p);
     }
+    if (const char *e = std::getenv("DASP_MG_READY_KERNEL")) g.ready_by_kernel = std::atoi(e) != 0;
     if (const char *e = std::getenv("DASP_MG_PUSH_WGS")) {
         // a power of two: the per-destination counters are never reset and publish at (count % wgs == 0), which survives the wrap of an
         // unsigned counter only when wgs divides 2^32
@@ -967,6 +975,7 @@ int dasp_mg_spmv(dasp_mg_plan_t *mg, void *stream)
         // the communication stream spins (one lane) until the launch's last workgroup has published step k, exchanges, publishes k back
         if (g.push) {          // both waits are inside the exchange's two kernels
             // (a one-lane wait kernel ahead of the push instead of the wait inside it: 80.3 instead of 76.7 us at a 40-us exchange)
+            if (g.ready_by_kernel) if (int rc = launch_mg_flag(g.words + kMgWordReady, k, s)) return rc;      // "y ready" = everything before it on this stream is done
             if (int rc = push_exchange(g, g.cs, k, true, k)) return rc;
         } else {
             if (int rc = launch_mg_wait(g.words + kMgWordReady, k, g.timeout_ticks, g.err_word, g.cs)) return rc;
