@@ -1176,7 +1176,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     lap("slot table");
     // row tiles (opt.row_tile_max, Plan::rt_*): panel k keeps its rows of <= rt_max nonzeros in the parent's output order; rt[k] holds their
     // tables, rt_at[k][row] = the row's first element in the tiles' arrays (-1: the row stays with the panel's own plan)
-    int rt_max = p.opt.row_tile_max == 0 ? kRowTileAuto : std::max(0, p.opt.row_tile_max);
+    int rt_max = p.opt.row_tile_max == 0 ? (p.precision == 16 ? kRowTileAuto : kRowTileAuto64) : std::max(0, p.opt.row_tile_max);
     if (rt_max > kRowTileMax) { set_error("row_tile_max must be <= 32"); return DASP_ERR_ARG; }
     if (const char *e = std::getenv("DASP_ROW_TILE_MAX")) rt_max = std::min(kRowTileMax, std::max(0, std::atoi(e)));      // A/B knob
     struct RowTiles { std::vector<int> ptr; std::vector<uint16_t> start; std::vector<uint64_t> mask; raw_vector<char> val; raw_vector<int> cid; std::vector<int> at; size_t cnt = 0; };

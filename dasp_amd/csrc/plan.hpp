@@ -154,7 +154,8 @@ __host__ __device__
 inline int short_tile_elems(bool seg, int L, int SR) { return seg ? kWave : L * SR; }
 
 constexpr int kRowTile = 64;        // output positions per row tile: one wave, one lane per position
-constexpr int kRowTileAuto = 16;    // opt.row_tile_max = 0 (tools/row_tile_ab.py: ljournal-2008 f16 0.483 / 0.469 / 0.460 / 0.452 / 0.451 / 0.451 / 0.496 ms at 6 / 8 / 12 / 16 / 20 / 24 / 32, 0.507-0.511 without)
+constexpr int kRowTileAuto64 = 8;    // opt.row_tile_max = 0, f64: 16 KB of LDS per workgroup -- at 16 (32 KB) a CU holds 5 instead of 6 workgroups of the f64 kernel, which costs an HBM-bound panel 7 % (HV15R-unstructured in two forced panels 0.554 -> 0.592 ms) and gains powerlaw_1M 0.6 %
+constexpr int kRowTileAuto = 16;    // opt.row_tile_max = 0, f16 (tools/row_tile_ab.py: ljournal-2008 f16 0.483 / 0.469 / 0.460 / 0.452 / 0.451 / 0.451 / 0.496 ms at 6 / 8 / 12 / 16 / 20 / 24 / 32, 0.507-0.511 without)
 constexpr int kRowTileMax = 32;     // longest row a tile may take (LDS: 4 waves x 64 x bound products per workgroup)
 
 struct DevicePlan;  // kernels.hip

@@ -555,7 +555,10 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     using acc_t = typename Tr<T>::acc_t;
     constexpr int CH = Tr<T>::CHUNK;
     const T *val = static_cast<const T *>(a.med_val);
-    const int c0 = tab<YS != 0>(a.med_ptr, b), c1 = tab<YS != 0>(a.med_ptr, b + 1);
+    // tables through the CONSTANT address space (tab<>) wherever the compiler could not prove them unclobbered: the step kernels (YS != 0) and the windowed
+    // kernels, whose blocks sit behind the barrier of the x copy (r4: cop20k_A x16, 1695 windows, 124.4 -> 111.1 us; the 212-window size is unchanged)
+    constexpr bool KT = YS != 0 || YM == 2;
+    const int c0 = tab<KT>(a.med_ptr, b), c1 = tab<KT>(a.med_ptr, b + 1);
     acc_t acc = {0, 0, 0, 0};
     // the block's first row is its longest (rows are sorted), so its tail length bounds the number of tail steps
     const int row = lane & 15, kq = lane >> 4;
@@ -564,7 +567,7 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     if (r < a.row_block) { t0 = a.irr_ptr[r]; t1 = a.irr_ptr[r + 1]; }
     constexpr int TK = sizeof(T) == 8 ? 4 : 16;                      // tail entries of one row per MFMA step
     const int nt = (__builtin_amdgcn_readfirstlane(t1 - t0) + TK - 1) / TK;
-    BlockSrc<T, NT, C16, YM != 2, C8, YS != 0, REL> src;
+    BlockSrc<T, NT, C16, YM != 2, C8, KT, REL> src;
     if constexpr (REL) src.relb = x.cmin; else src.relb = 0;
     src.reg.val = val; src.reg.cid = a.med_cid; src.reg.e0 = (size_t)c0 * CH; src.reg.lane = lane;
     src.nc = c1 - c0; src.npair = med_npair(c1 - c0, nt, (int)sizeof(T), YM == 2 ? 0 : a.pair_mode); src.cid16 = a.med_cid16; src.base = a.med_base; src.c0 = c0;
@@ -804,8 +807,10 @@ __device__ __forceinline__ void row_tile(const DevArgs &a, int t, int lane, type
     const int s = a.rt_start[(size_t)t * kRowTile + lane];
 #pragma unroll 4
     for (int i = lane; i < n; i += kWave) prod[i] = (part_t)ldg<NT>(val + e0 + i) * (part_t)x[ldg<NT>(a.rt_cid + e0 + i)];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // this wave's LDS writes before its LDS reads (another lane's)
-    __builtin_amdgcn_wave_barrier();
+    // this wave's LDS writes before its LDS reads (another lane's): one wave's LDS operations execute in issue order, and the compiler keeps a store before a
+    // load of the same array.  NO fence and NO __builtin_amdgcn_wave_barrier() here: either makes the compiler read the row tables of the panel's blocks with
+    // vector instead of scalar loads in the f64 kernel (the cliff of DESIGN.md 5.1: 302 -> 119 s_load instructions; HV15R-unstructured in two forced panels
+    // 0.555 -> 0.884 ms with 0.05 % of its nonzeros in tiles)
     int e = __shfl_down(s, 1);
     if (lane == kWave - 1) e = n;
     part_t sum = 0;

@@ -167,8 +167,8 @@ typedef struct dasp_options {
      * wave streams a tile's (value, column) pairs in CSR order, parks the products in LDS, lane r sums row r's products in their CSR order and
      * the wave stores ONE complete 128-byte line of the panel's partial result (f16; two lines in f64) -- instead of 2-byte pieces of lines
      * that other workgroups complete (ljournal-2008 f16: 333 MB written per SpMV for 54 MB of partial results).  The rows above the bound stay
-     * with the panel's own blocks / pieces.  0 = auto (16: ljournal-2008 f16 0.507 -> 0.444 ms, 333 -> ~100 MB written; powerlaw_1M f64 0.653 ->
-     * 0.646); -1 = off; 1..32 = that bound (LDS: 256 x bound products per workgroup).  Plans without column panels ignore it.  order_rid, the
+     * with the panel's own blocks / pieces.  0 = auto (f16: 16 -- ljournal-2008 0.507 -> 0.436 ms, 333 -> 69 MB written; f64: 8 -- powerlaw_1M 0.653 -> 0.648,
+     * 16 KB of LDS per workgroup so that a CU still holds six of them); -1 = off; 1..32 = that bound (LDS: 256 x bound products per workgroup).  Plans without column panels ignore it.  order_rid, the
      * classifier counters and the order of a row's products are unchanged (a tiled row is summed in CSR order, as the oracle does). */
     int row_tile_max;
 } dasp_options_t;

@@ -28,7 +28,7 @@ def test_panels_partition_the_matrix(dasp, prec, y_order, P, tile):
     lens = np.random.default_rng(3).choice([0, 1, 2, 3, 4, 9, 40, 300, 700], size=m, p=[.05, .15, .1, .15, .1, .2, .15, .07, .03])
     rp, ci, v = util.csr_from_lengths(lens, n, 5, dtype=dt)
     single = dasp.Plan(rp, ci, v, n, precision=prec, y_order=y_order, col_panels=1)
-    plan = dasp.Plan(rp, ci, v, n, precision=prec, y_order=y_order, col_panels=P, row_tile_max=tile)      # 0 = auto: 16
+    plan = dasp.Plan(rp, ci, v, n, precision=prec, y_order=y_order, col_panels=P, row_tile_max=tile)      # 0 = auto: 16 (f16) / 8 (f64)
     assert single.n_panels == 0 and single.stats["n_col_panels"] == 0
     assert plan.n_panels == P and plan.stats["n_col_panels"] == P
     np.testing.assert_array_equal(plan.order_rid, single.order_rid)
@@ -54,7 +54,7 @@ def test_panels_partition_the_matrix(dasp, prec, y_order, P, tile):
             got[r] += ent
             nnz_k += len(ent)
         assert nnz_k == sub.stats["nnzA"] + sub.stats["row_tile_nnz"]      # (the panels keep their short rows in row tiles)
-        assert (sub.stats["row_tile_nnz"] > 0) == (tile >= 0) and sub.stats["row_tile_max"] == (0 if tile < 0 else tile or 16) and sub.stats["n_row_tiles"] == (-(-m // 64) if tile >= 0 else 0)
+        assert (sub.stats["row_tile_nnz"] > 0) == (tile >= 0) and sub.stats["row_tile_max"] == (0 if tile < 0 else tile or (16 if prec == 16 else 8)) and sub.stats["n_row_tiles"] == (-(-m // 64) if tile >= 0 else 0)
     assert prev_end == n
     assert [sorted(g) for g in got] == want
     assert sum(plan.panel(k)[0].stats["nnzA"] + plan.panel(k)[0].stats["row_tile_nnz"] for k in range(P)) == ci.size
