@@ -48,16 +48,17 @@ def main():
           f"fill0={st['rate_fill0']:.4f} pre={st['pre_ms']:.0f} ms")
     rows = []
     for xw, c16, cp, pol in itertools.product((-1, 81920), (-1, 1), (1, 2, 4), (1, 2)):
-        try:
-            e, st = run(x_window=xw, cid16=c16, col_panels=cp, stream_policy=pol)
-        except D.DaspError as exc:
-            print("skip", xw, c16, cp, pol, exc)
-            continue
-        rows.append((e, xw, c16, cp, pol, st))
+        for rt in ((0,) if cp == 1 else (0, -1)):          # column panels: with their row tiles (auto bound) and without
+            try:
+                e, st = run(x_window=xw, cid16=c16, col_panels=cp, stream_policy=pol, row_tile_max=rt)
+            except D.DaspError as exc:
+                print("skip", xw, c16, cp, pol, rt, exc)
+                continue
+            rows.append((e, xw, c16, cp, pol, rt, st))
     rows.sort(key=lambda r: r[0])
-    for e, xw, c16, cp, pol, st in rows[:8]:
-        print(f"      {e*1e3:9.2f} us   x_window={xw:6d} cid16={c16:2d} col_panels={cp} stream_policy={pol}   "
-              f"(windows {st['n_windows_lds']}/{st['n_windows']}, cid16 {st['cid16_on']}, panels {st['n_col_panels']})  {e/base:5.2f} x auto")
+    for e, xw, c16, cp, pol, rt, st in rows[:8]:
+        print(f"      {e*1e3:9.2f} us   x_window={xw:6d} cid16={c16:2d} col_panels={cp} stream_policy={pol} row_tile_max={rt:2d}   "
+              f"(windows {st['n_windows_lds']}/{st['n_windows']}, cid16 {st['cid16_on']}, panels {st['n_col_panels']}, tiles {st['n_row_tiles']})  {e/base:5.2f} x auto")
 
 
 if __name__ == "__main__":
