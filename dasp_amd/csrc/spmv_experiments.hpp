@@ -37,6 +37,37 @@ __global__ __launch_bounds__(256, 6) void dasp_spmv_persist_kernel(DevArgs a)
         if (q < a.n_blocks && r < a.row_block) put_y<double, 3>(a, a.row_long + r, ybuf[(j * kWavesPerWG + wave) * 16 + (lane & 15)]);
     }
 }
+// experiment: a hybrid grid.  The first R workgroups are resident ones that share the HEAD of the medium blocks (the first H virtual workgroups: the longest blocks)
+// with the grid's stride, their results parked in LDS and written in one burst; the workgroups behind them are ordinary ones -- long pieces, the TAIL of the medium
+// blocks (one block per wave, direct stores), short tiles -- which the hardware hands out as the resident ones finish: the dispatcher levels what the static
+// shares left uneven.
+__global__ __launch_bounds__(256, 6) void dasp_spmv_hybrid_kernel(DevArgs a, int R, int H)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+    const int wg = (int)blockIdx.x;
+    if (wg < R) {
+        double *ybuf = reinterpret_cast<double *>(lds_raw);
+        int k = 0;
+        for (int v = wg; v < H; v += R, ++k) {
+            const int q = v * kWavesPerWG + wave;
+            if (q < a.n_blocks) {
+                const XGlobalY<double> x{static_cast<const double *>(a.x), ybuf + (k * kWavesPerWG + wave) * 16};
+                medium_block<double, true, true, 0, true, 5>(a, q, lane, x);
+            }
+        }
+        for (int j = lane >> 4; j < k; j += 4) {
+            const int q = (wg + j * R) * kWavesPerWG + wave;
+            const int r = q * kMedRows + (lane & 15);
+            if (q < a.n_blocks && r < a.row_block) put_y<double, 3>(a, a.row_long + r, ybuf[(j * kWavesPerWG + wave) * 16 + (lane & 15)]);
+        }
+        return;
+    }
+    // ordinary workgroups: virtual id v over [long | medium tail | short]
+    int v = wg - R;
+    if (v >= a.wg_long) v += H;          // skip the head of the medium range
+    plain_wg<double, true, true, true, 3>(a, v, wave, lane, nullptr);
+}
 constexpr int kCtrStride = (4096 + 256) / 4;      // counters on different memory channels
 // experiment: `reps` virtual workgroups per workgroup (grid-strided), stores as they come: between one block per wave and resident waves
 __global__ __launch_bounds__(256, 6) void dasp_spmv_ktr_kernel(DevArgs a, int total)
@@ -108,6 +139,20 @@ static int launch_experiment(const DevArgs &a, hipStream_t s)
             static bool once = false;
             if (!once) { once = true; HIP_TRY(hipFuncSetAttribute((const void *)dasp_spmv_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); }
             hipLaunchKernelGGL(dasp_spmv_persist_kernel, dim3(G), dim3(256), need, s, b);
+            HIP_TRY(hipGetLastError());
+            return DASP_OK;
+        }
+    }
+    if (!a.order && on("DASP_HYBRID")) {      // DASP_HYBRID = percent of the medium virtual workgroups in the resident head; DASP_HYBRID_PER_CU resident workgroups per CU (6)
+        DevArgs b = a; b.wg_med = (b.n_blocks + kWavesPerWG - 1) / kWavesPerWG; b.xcd_on = 0;
+        const int per_cu = on("DASP_HYBRID_PER_CU") > 0 ? on("DASP_HYBRID_PER_CU") : 6, R = 256 * per_cu;
+        const int H = std::min(b.wg_med, (int)((long long)b.wg_med * on("DASP_HYBRID") / 100));
+        const int kmax = (H + R - 1) / R + 1;
+        const size_t need = (size_t)kmax * kWavesPerWG * 16 * sizeof(double);
+        if (need <= (size_t)160 * 1024 / 6 - 512) {
+            static bool once = false;
+            if (!once) { once = true; HIP_TRY(hipFuncSetAttribute((const void *)dasp_spmv_hybrid_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); }
+            hipLaunchKernelGGL(dasp_spmv_hybrid_kernel, dim3(R + b.wg_long + (b.wg_med - H) + b.wg_short), dim3(256), need, s, b, R, H);
             HIP_TRY(hipGetLastError());
             return DASP_OK;
         }
