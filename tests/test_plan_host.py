@@ -426,6 +426,22 @@ def test_medium_rows_as_pieces_keep_slots_and_counters(dasp, oracle):
             plan.close()
 
 
+def test_long_rows_stay_one_piece_when_none_is_very_long(dasp):
+    """long_piece = 0 (default): one piece per long row -- no stage-2 launch -- when the long rows hold <= 2 M nonzeros in rows of <= 16384, or when no
+    row exceeds 4096 whatever their number; beyond that, pieces of 1024 and a partial sum per piece"""
+    def multi(lens, n_cols):
+        rp, ci, v = util.csr_from_lengths(np.asarray(lens), n_cols, 3, values="ones")
+        p = dasp.Plan(rp, ci, v, n_cols)
+        st = p.stats
+        p.close()
+        return st["n_long_multi"], st["n_long_pieces"], st["row_long"]
+    assert multi([3000] * 20 + [7] * 100, 6000) == (0, 20, 20)                    # few long nonzeros
+    assert multi([4000] * 600 + [7] * 100, 8000) == (0, 600, 600)                 # 2.4 M long nonzeros, but no row beyond 4096
+    m, pieces, rl = multi([5000] * 450 + [7] * 100, 8000)                         # 2.25 M long nonzeros in rows of 5000: pieces of 1024
+    assert m == 450 and pieces == 450 * 5 and rl == 450
+    assert multi([20000] * 3 + [7] * 100, 30000)[0] == 3                          # rows beyond 16384 are always cut
+
+
 def test_corrupt_plan_files_are_rejected_not_trusted(dasp, tmp_path):
     """dasp_plan_load re-derives what the kernels index with: a plan file with one damaged table / column id / header field comes
     back as an error (never an exception through the C ABI, never a plan that would read out of bounds on upload)"""
