@@ -55,8 +55,8 @@ int main(int argc, char **argv)
     int *idx; float *x, *out;
     hipMalloc(&idx, N * 4); hipMalloc(&x, (size_t)X * 4); hipMalloc(&out, 64);
     hipMemcpy(idx, h.data(), N * 4, hipMemcpyHostToDevice); hipMemset(x, 0, (size_t)X * 4);
-    const int grid = 256 * 8;
-    printf("x of %d floats (%.2f MiB), %zu M gathers\n", X, X * 4.0 / (1 << 20), N >> 20);
+    const int grid = 256 * (argc > 2 ? atoi(argv[2]) : 8);      // resident workgroups (of 4 waves) per CU
+    printf("x of %d floats (%.2f MiB), %zu M gathers, %d workgroups per CU\n", X, X * 4.0 / (1 << 20), N >> 20, grid / 256);
 #define RUN(SV) { const double ms = ms_of([&] { hipLaunchKernelGGL(gather<SV>, dim3(grid), dim3(256), 0, 0, idx, N / 64, x, out); }); \
                   printf("%2d of 64 through the scalar path: %.3f ms = %.1f G gathers/s\n", SV, ms, N / ms / 1e6); }
     RUN(0) RUN(4) RUN(8) RUN(16) RUN(32) RUN(64) RUN(0)
