@@ -38,8 +38,10 @@ HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-lev
 #   L1 miss queue    : 256 CUs x 64 misses in flight per CU / 257 cycles L2-hit round trip    = 153 G lines/s
 #     (Little's law on the PMC counters of the uniform-column stand-ins, profiles/r02_gather_pmc.md: TCP_TCC_READ_REQ x
 #      TCP_TCC_READ_REQ_LATENCY / busy cycles = 61-64 requests in flight per CU whatever the kernel does)
+#   bare gather loop : tools/micro/sgather.hip (r4): 64 M random 4-byte gathers from an L2-resident x, two steps in flight per wave = 190 G lines/s (85 in flight per CU)
 GATHER_PEAK_TA_G = 256 * 2.4
 GATHER_PEAK_L1MISS_G = 256 * 64 * 2.4 / 257.0
+GATHER_LOOP_G = 190.0
 
 
 def gather_roofline(nnz, event_ms):
@@ -47,8 +49,10 @@ def gather_roofline(nnz, event_ms):
     return {"achieved_Ggathers_per_s": round(g, 1), "peak_ta_Glines_per_s": round(GATHER_PEAK_TA_G, 1),
             "peak_l1_miss_queue_Glines_per_s": round(GATHER_PEAK_L1MISS_G, 1), "frac_of_ta": round(g / GATHER_PEAK_TA_G, 4),
             "frac_of_l1_miss_queue": round(g / GATHER_PEAK_L1MISS_G, 4),
+            "bare_gather_loop_Glines_per_s": GATHER_LOOP_G, "frac_of_bare_gather_loop": round(g / GATHER_LOOP_G, 4),
             "note": "DIAGNOSTIC, not an independent ceiling: the L1-miss-queue figure is Little's law on these kernels' own PMC counters "
-                    "(profiles/r02_gather_pmc.md); it bounds only matrices whose every gather misses the L1 (uniform-column graphs); "
+                    "(profiles/r02_gather_pmc.md), the bare loop is a measured rate of nothing but random L2-hit gathers (tools/micro/sgather.hip); both bound "
+                    "only matrices whose every gather misses the L1 (uniform-column graphs); "
                     "a value > 1 means the gathers hit the L1 / LDS (FEM rows, staged windows) and the figure does not apply"}
 TOL = {64: 1e-12, 16: 1e-2}   # BASELINE.json north_star, relative to sum_j |a_ij x_j|
 
