@@ -348,16 +348,23 @@ int rmat_row(const Synth &g, int i, int *out)
     return len;
 }
 
+// the graph generators draw a row's columns one by one: they come out in random order.  A SuiteSparse .mtx lists its entries column by column, and mmio_allinone's
+// COO -> CSR keeps the file order inside a row (src/mmio_highlevel.h), so a row of a general matrix (webbase-1M, ljournal-2008: directed graphs) arrives with ascending
+// columns -- r4: the stand-ins do too (until then powerlaw_1M ran 16 %, rmat_2M 13 %, ljournal-2008 3 % slower than the same kernels on the sorted rows:
+// tools/hot_cols_probe.py).  Duplicate columns stay separate entries (the plan takes them as they come), nnz is unchanged.
 inline int any_row(const Synth &g, int row, int *out, const float *tg, int tg0)
 {
+    int len;
     switch (g.kind) {
-        case Synth::RMAT: return rmat_row(g, row, out);
         case Synth::GRID: return grid_row(g, row, out);
         case Synth::UNSTR: return unstr_row(g, row, out);
         case Synth::BAND: return band_row(g, row, out, tg, tg0);
-        case Synth::BLOCKS: return blocks_row(g, row, out);
-        default: return power_row(g, row, out);
+        case Synth::RMAT: len = rmat_row(g, row, out); break;
+        case Synth::BLOCKS: len = blocks_row(g, row, out); break;
+        default: len = power_row(g, row, out); break;
     }
+    if (out && len > 1) std::sort(out, out + len);
+    return len;
 }
 
 // per-call cache of band targets for rows [r0 - band, r1 + band)
@@ -415,6 +422,7 @@ extern "C" const char *dasp_synth_generator(const char *name)
     Synth g;
     if (!make(name, 1.0, g)) { set_error("unknown synthetic matrix name"); return nullptr; }
     text = std::string("dasp_amd/csrc/gen.cpp seed ") + std::to_string((unsigned long long)g.seed) + ": " + g.desc;
+    if (g.kind != Synth::GRID && g.kind != Synth::UNSTR && g.kind != Synth::BAND) text += "; columns ascending inside a row (as mmio_allinone reads a general .mtx)";
     return text.c_str();
 }
 
