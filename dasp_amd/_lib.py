@@ -25,7 +25,7 @@ class Options(C.Structure):
         ("host_threads", C.c_int), ("n_parts", C.c_int), ("part_bounds", C.POINTER(C.c_int)), ("part_stride", C.c_int),
         ("x_window", C.c_int), ("row_window", C.c_int), ("cid16", C.c_int), ("stream_policy", C.c_int),
         ("col_panels", C.c_int), ("slab_max_len", C.c_int), ("x_window_hybrid", C.c_int), ("piece_min_len", C.c_int),
-        ("chunk_pairs", C.c_int), ("cid8", C.c_int), ("short_seg", C.c_int), ("row_tile_max", C.c_int),
+        ("chunk_pairs", C.c_int), ("cid8", C.c_int), ("short_seg", C.c_int), ("row_tile_max", C.c_int), ("sort_columns", C.c_int),
     ]
 
 

@@ -531,6 +531,54 @@ int devpack_panel_split(const Plan &p, const DevCsr &d, const std::vector<int> &
     return DASP_OK;
 }
 
+// ---- opt.sort_columns on a device CSR
+__global__ void k_rows_unsorted(const int *rp, const int *ci, int m, int *flag)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= m) return;
+    const int a0 = rp[i], a1 = rp[i + 1];
+    bool bad = false;
+    for (int j = a0 + 1 + lane; j < a1; j += 64) bad = bad || ci[j] < ci[j - 1];
+    if (__any(bad) && lane == 0) *flag = 1;
+}
+int devpack_sort_columns(const Plan &p, const DevCsr &d, std::vector<std::shared_ptr<void>> &keep, DevCsr *out, int *did)
+{
+    *did = 0;
+    const int m = p.m, nnz = p.nnz;
+    if (m <= 0 || nnz <= 0) return DASP_OK;
+    auto dmalloc = [&](size_t bytes, void **ptr) -> int {
+        if (hipMalloc(ptr, std::max<size_t>(bytes, 16)) != hipSuccess) { set_error("hipMalloc (sort_columns)"); return DASP_ERR_HIP; }
+        keep.emplace_back(*ptr, [](void *q) { (void)hipFree(q); });
+        return DASP_OK;
+    };
+    void *flag = nullptr;
+    if (int rc = dmalloc(16, &flag)) return rc;
+    HIP_TRYP(hipMemset(flag, 0, 16));
+    hipLaunchKernelGGL(k_rows_unsorted, dim3(waves_grid(m)), dim3(256), 0, 0, d.rp, d.ci, m, static_cast<int *>(flag));
+    HIP_TRYP(hipGetLastError());
+    int h = 0;
+    HIP_TRYP(hipMemcpy(&h, flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (!h) return DASP_OK;
+    const size_t vb = (size_t)p.geo.vbytes;
+    void *ci2 = nullptr, *val2 = nullptr, *tmp = nullptr;
+    if (int rc = dmalloc((size_t)nnz * 4, &ci2)) return rc;
+    if (int rc = dmalloc((size_t)nnz * vb, &val2)) return rc;
+    size_t tmp_bytes = 0;
+    hipError_t e;
+    // the values ride along as plain bit patterns
+    if (vb == 8) e = hipcub::DeviceSegmentedSort::StableSortPairs(nullptr, tmp_bytes, d.ci, static_cast<int *>(ci2), static_cast<const unsigned long long *>(d.val), static_cast<unsigned long long *>(val2), nnz, m, d.rp, d.rp + 1);
+    else e = hipcub::DeviceSegmentedSort::StableSortPairs(nullptr, tmp_bytes, d.ci, static_cast<int *>(ci2), static_cast<const unsigned short *>(d.val), static_cast<unsigned short *>(val2), nnz, m, d.rp, d.rp + 1);
+    if (e != hipSuccess) { set_error("hipcub segmented sort (sort_columns)"); return DASP_ERR_HIP; }
+    if (int rc = dmalloc(tmp_bytes, &tmp)) return rc;
+    if (vb == 8) e = hipcub::DeviceSegmentedSort::StableSortPairs(tmp, tmp_bytes, d.ci, static_cast<int *>(ci2), static_cast<const unsigned long long *>(d.val), static_cast<unsigned long long *>(val2), nnz, m, d.rp, d.rp + 1);
+    else e = hipcub::DeviceSegmentedSort::StableSortPairs(tmp, tmp_bytes, d.ci, static_cast<int *>(ci2), static_cast<const unsigned short *>(d.val), static_cast<unsigned short *>(val2), nnz, m, d.rp, d.rp + 1);
+    if (e != hipSuccess) { set_error("hipcub segmented sort (sort_columns)"); return DASP_ERR_HIP; }
+    HIP_TRYP(hipDeviceSynchronize());
+    *out = DevCsr{d.rp, static_cast<const int *>(ci2), val2};
+    *did = 1;
+    return DASP_OK;
+}
+
 // ---- row tiles of a column panel (plan.cpp build_panels): one wave per row moves the row either into the tiles' arrays or into the
 // sub-matrix of the rows that stay with the panel's plan; a row's elements keep their order
 template <class T>

@@ -248,6 +248,42 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     }
 
     lap("validate");
+    // opt.sort_columns: rows whose columns do not ascend get their (column, value) pairs sorted by column (stable) -- copies; the caller's arrays stay as they are
+    raw_vector<int> ci_sorted;
+    raw_vector<T> val_sorted;
+    DevCsr dev_sorted{nullptr, nullptr, nullptr};
+    std::vector<std::shared_ptr<void>> sort_keep;
+    if (mode == kTop && p.opt.sort_columns > 0 && nnz > 0) {
+        if (dev) {
+            int did = 0;
+            if (int rc = devpack_sort_columns(p, *dev, sort_keep, &dev_sorted, &did)) return rc;
+            if (did) dev = &dev_sorted;
+        } else {
+            std::atomic<int> unsorted{0};
+            parallel_for(m, threads, 1 << 14, [&](long long b, long long e) {
+                for (long long i = b; i < e && !unsorted; ++i)
+                    for (int j = rp[i] + 1; j < rp[i + 1]; ++j) if (ci[j] < ci[j - 1]) { unsorted = 1; break; }
+            });
+            if (unsorted) {
+                ci_sorted.resize((size_t)nnz); val_sorted.resize((size_t)nnz);
+                parallel_for(m, threads, 1 << 12, [&](long long b, long long e) {
+                    std::vector<std::pair<int, T>> row;
+                    for (long long i = b; i < e; ++i) {
+                        const int a0 = rp[i], a1 = rp[i + 1];
+                        bool ok = true;
+                        for (int j = a0 + 1; j < a1; ++j) if (ci[j] < ci[j - 1]) { ok = false; break; }
+                        if (ok) { for (int j = a0; j < a1; ++j) { ci_sorted[(size_t)j] = ci[j]; val_sorted[(size_t)j] = val[j]; } continue; }
+                        row.resize((size_t)(a1 - a0));
+                        for (int j = a0; j < a1; ++j) row[(size_t)(j - a0)] = {ci[j], val[j]};
+                        std::stable_sort(row.begin(), row.end(), [](const std::pair<int, T> &x, const std::pair<int, T> &y) { return x.first < y.first; });
+                        for (int j = a0; j < a1; ++j) { ci_sorted[(size_t)j] = row[(size_t)(j - a0)].first; val_sorted[(size_t)j] = row[(size_t)(j - a0)].second; }
+                    }
+                });
+                ci = ci_sorted.data(); val = val_sorted.data();
+            }
+        }
+        lap("sort columns");
+    }
     if (mode == kTop) {
         const int P = decide_panels(p, rp, ci, remap, dev);
         if (P < 0) return P;

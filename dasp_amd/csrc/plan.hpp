@@ -288,6 +288,10 @@ int devpack_row_tiles(const Plan &p, DevCsr &panel, const std::vector<int> &rp_r
 // ... and their copy into the uploaded panel plan's arena (ArenaMap::rt_val / rt_cid)
 int devpack_place_row_tiles(Plan &q, const DevRowTiles &src);
 
+// opt.sort_columns on a device CSR: when a row's columns do not ascend, `out` = the same matrix with every row's (column, value) pairs sorted by column (stable segmented
+// sort; new device arrays owned by `keep`) and *did = 1; otherwise *did = 0
+int devpack_sort_columns(const Plan &p, const DevCsr &d, std::vector<std::shared_ptr<void>> &keep, DevCsr *out, int *did);
+
 // builds every host array of `p` from CSR.  T = double or _Float16.  With `dev` set, rp is a host copy of the row pointer,
 // ci / val are ignored and the nnz-sized arrays are produced on the device (the plan comes back uploaded).
 int build_plan(Plan &p, const int *rp, const int *ci, const void *val, const DevCsr *dev = nullptr);

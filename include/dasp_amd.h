@@ -171,6 +171,11 @@ typedef struct dasp_options {
      * 16 KB of LDS per workgroup so that a CU still holds six of them); -1 = off; 1..32 = that bound (LDS: 256 x bound products per workgroup).  Plans without column panels ignore it.  order_rid, the
      * classifier counters and the order of a row's products are unchanged (a tiled row is summed in CSR order, as the oracle does). */
     int row_tile_max;
+    /* rows whose column ids do not ascend (a CSR assembled from unsorted coordinates): the packers keep the order of a row's entries, as the reference does, and the
+     * gathers of such rows touch more lines of x (graph-like rows: 13-16 % slower, profiles/r04_row_tiles.md 14).  1 = sort every such row's (column, value) pairs by
+     * column before packing -- stable, on the host or (dasp_plan_create_device) with a segmented sort on the GPU, bit-identical either way; the caller's arrays are not
+     * touched.  The sum of a row then runs in column order instead of CSR order (same products).  0 / -1 = keep the CSR order (default: what the reference does). */
+    int sort_columns;
 } dasp_options_t;
 
 void dasp_options_default(dasp_options_t *opt);

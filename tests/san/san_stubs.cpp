@@ -37,6 +37,7 @@ int devpack_gather_columns(const Plan &, const DevCsr &, const std::vector<long 
 int devpack_panel_split(const Plan &, const DevCsr &, const std::vector<int> &, int, std::vector<std::vector<int>> &, std::vector<DevCsr> &, std::vector<std::shared_ptr<void>> &) { return nodev(); }
 int devpack_row_tiles(const Plan &, DevCsr &, const std::vector<int> &, const std::vector<int> &, size_t, std::vector<std::shared_ptr<void>> &, DevRowTiles *) { return nodev(); }
 int devpack_place_row_tiles(Plan &, const DevRowTiles &) { return nodev(); }
+int devpack_sort_columns(const Plan &, const DevCsr &, std::vector<std::shared_ptr<void>> &, DevCsr *, int *) { return nodev(); }
 int devpack_spin(void *, int, int) { return nodev(); }
 int launch_mg_step(Plan &, Plan *, const void *, const void *, void *, const MgStepCtl &, void *) { return nodev(); }
 int launch_mg_step2(Plan &, const void *, void *, const MgStep2Ctl &, const MgPushArgs &, void *) { return nodev(); }

@@ -1055,7 +1055,7 @@ META_ARRAYS = ("piece_ptr piece_dst multi_ptr multi_dst med_ptr med_c8ptr med_ko
 @pytest.mark.parametrize("prec", [64, 16])
 @pytest.mark.parametrize("kw", [dict(), dict(cid16=1, chunk_pairs=2), dict(cid16=-1, x_window=-1, chunk_pairs=-1), dict(x_window=100000, y_order=1), dict(x_window=-1, chunk_pairs=2, slab_max_len=4),
                                 dict(part_bounds=np.array([0, 700, 2500], np.int32), part_stride=2048, y_order=1, cid16=1),
-                                dict(x_window=-1, short_seg=1), dict(x_window=-1, short_seg=-1, y_order=1)])
+                                dict(x_window=-1, short_seg=1), dict(x_window=-1, short_seg=-1, y_order=1), dict(sort_columns=1), dict(sort_columns=1, col_panels=2, y_order=1)])
 @pytest.mark.parametrize("tag,builder,m,n,seed", [("mixed", util.mixed_matrix, 3000, 2500, 7), ("pairs", util.pair_heavy_matrix, 4000, 2500, 11)])
 def test_device_packed_plan_is_bit_identical(oracle, dasp, torch_cuda, prec, kw, tag, builder, m, n, seed):
     """dasp_plan_create_device (CSR on the GPU, packed by kernels) == dasp_plan_create (host packers), array by array,
@@ -1505,7 +1505,8 @@ def test_random_option_combinations(oracle, dasp, torch_cuda, seed):
               long_piece=int(rng.choice([0, 64, 300, 4096])), block_longest=int(rng.choice([256, 256, 32, 1000])),
               threshold=float(rng.choice([0.75, 0.75, 0.3, 1.0])), y_order=int(rng.choice([0, 1])),
               slab_max_len=int(rng.choice([0, 4, 7, 16, 32])),
-              row_tile_max=int(np.random.default_rng(5000 + seed).choice([0, 0, -1, 1, 5, 32])))      # (its own generator: the other draws stay what they were)
+              row_tile_max=int(np.random.default_rng(5000 + seed).choice([0, 0, -1, 1, 5, 32])),      # (its own generator: the other draws stay what they were)
+              sort_columns=int(np.random.default_rng(7000 + seed).choice([0, 0, 1])))
     part = None
     if rng.random() < 0.4 and n >= 3:
         cuts = np.sort(rng.choice(np.arange(1, n), size=min(2, n - 1), replace=False))

@@ -426,6 +426,38 @@ def test_medium_rows_as_pieces_keep_slots_and_counters(dasp, oracle):
             plan.close()
 
 
+@pytest.mark.parametrize("prec", [64, 16])
+def test_sort_columns_sorts_the_rows_stably_and_only_when_asked(dasp, prec):
+    """sort_columns = 1: every row whose columns do not ascend is packed with its (column, value) pairs in column order -- stable, duplicates keep their CSR order --,
+    order_rid and the counters unchanged; 0: the CSR order, as ever; rows that ascend already give the same plan either way"""
+    dt = np.float64 if prec == 64 else np.float16
+    rp, ci, v = util.mixed_matrix(1500, 300, 5, values="f16" if prec == 16 else "uniform", dtype=dt)     # 300 columns: duplicates inside the longer rows
+    assert any(len(set(ci[rp[r]:rp[r + 1]].tolist())) < rp[r + 1] - rp[r] for r in range(1500))
+    for kw in (dict(), dict(y_order=1), dict(x_window=-1, cid16=1, chunk_pairs=2)):
+        plain = dasp.Plan(rp, ci, v, 300, precision=prec, **kw)
+        srt = dasp.Plan(rp, ci, v, 300, precision=prec, sort_columns=1, **kw)
+        assert (plain.order_rid == srt.order_rid).all()
+        a, b = plain.stats, srt.stats
+        a.pop("pre_ms"), b.pop("pre_ms")
+        for k in ("short_row_1", "row_long", "row_block", "row_zero", "nnz_short", "nnz_long", "common_13"):
+            assert a[k] == b[k], k
+        order = srt.order_rid
+        for slot, (cs, vs) in util.decode_plan(srt).items():
+            r = int(order[slot])
+            pairs = sorted(zip(ci[rp[r]:rp[r + 1]].tolist(), v[rp[r]:rp[r + 1]].tolist()), key=lambda t: t[0])      # Python's sort is stable
+            assert cs == [c for c, _ in pairs] and list(vs) == [x for _, x in pairs], r
+        for slot, (cs, vs) in util.decode_plan(plain).items():
+            r = int(plain.order_rid[slot])
+            assert cs == ci[rp[r]:rp[r + 1]].tolist()
+        plain.close(); srt.close()
+    # ascending rows: nothing to do, the same arrays
+    rowid = np.repeat(np.arange(1500), np.diff(rp))
+    o = np.lexsort((ci, rowid))
+    p0, p1 = dasp.Plan(rp, ci[o], v[o], 300, precision=prec), dasp.Plan(rp, ci[o], v[o], 300, precision=prec, sort_columns=1)
+    for name in ("med_val", "med_cid", "med_cid16", "irr_cid", "irr_val", "short_cid", "short_val", "long_cid", "long_val"):
+        assert np.array_equal(p0.host_array(name), p1.host_array(name)), name
+
+
 def test_long_rows_stay_one_piece_when_none_is_very_long(dasp):
     """long_piece = 0 (default): one piece per long row -- no stage-2 launch -- when the long rows hold <= 2 M nonzeros in rows of <= 16384, or when no
     row exceeds 4096 whatever their number; beyond that, pieces of 1024 and a partial sum per piece"""
