@@ -48,6 +48,7 @@ static void plans_of(const Csr &c, const std::string &scratch, int tag)
             opt.x_window = o.x_window; opt.row_window = o.row_window; opt.cid16 = o.cid16; opt.col_panels = o.col_panels; opt.slab_max_len = o.slab;
             opt.x_window_hybrid = o.hybrid; opt.piece_min_len = o.piece; opt.chunk_pairs = o.pairs; opt.cid8 = o.cid8; opt.y_order = o.natural;
             opt.threshold = o.thr; opt.block_longest = o.longest; opt.host_threads = 1 + (k % 5);
+            opt.sort_columns = k % 3 == 0 ? 1 : 0;
             dasp_plan_t *p = nullptr;
             const void *val = prec == 64 ? (const void *)c.v64.data() : (const void *)c.v16.data();
             const int rc = dasp_plan_create(&p, prec, c.m, c.n, c.nnz, c.rp.data(), c.ci.data(), val, &opt);
