@@ -49,12 +49,95 @@ def gather_roofline(nnz, event_ms):
     return {"achieved_Ggathers_per_s": round(g, 1), "peak_ta_Glines_per_s": round(GATHER_PEAK_TA_G, 1),
             "peak_l1_miss_queue_Glines_per_s": round(GATHER_PEAK_L1MISS_G, 1), "frac_of_ta": round(g / GATHER_PEAK_TA_G, 4),
             "frac_of_l1_miss_queue": round(g / GATHER_PEAK_L1MISS_G, 4),
-            "bare_gather_loop_Glines_per_s": GATHER_LOOP_G, "frac_of_bare_gather_loop": round(g / GATHER_LOOP_G, 4),
-            "note": "DIAGNOSTIC, not an independent ceiling: the L1-miss-queue figure is Little's law on these kernels' own PMC counters "
-                    "(profiles/r02_gather_pmc.md), the bare loop is a measured rate of nothing but random L2-hit gathers (tools/micro/sgather.hip); both bound "
-                    "only matrices whose every gather misses the L1 (uniform-column graphs); "
-                    "a value > 1 means the gathers hit the L1 / LDS (FEM rows, staged windows) and the figure does not apply"}
+            "bare_gather_loop_Glines_per_s": GATHER_LOOP_G, "frac_of_bare_gather_loop": round(g / GATHER_LOOP_G, 4)}
+
+
+# what the gather_roofline figures are (said once, in the full record): DIAGNOSTIC, not an independent ceiling -- the
+# L1-miss-queue figure is Little's law on these kernels' own PMC counters, the bare loop a measured rate of nothing but random L2-hit
+# gathers; both bound only matrices whose every gather misses the L1; > 1 means the gathers hit the L1 / LDS and the figure does not apply
+GATHER_NOTE = "diagnostic only (DESIGN.md 4.6): bounds matrices whose every gather misses the L1; > 1 = the gathers hit L1 / LDS"
 TOL = {64: 1e-12, 16: 1e-2}   # BASELINE.json north_star, relative to sum_j |a_ij x_j|
+
+LINE_LIMIT = 4096     # the driver keeps an 8 KB tail of stdout and parses its last line: r04's 22 KB line was lost
+
+
+def _short(v, n):
+    v = str(v)
+    return v if len(v) <= n else v[: n - 3] + "..."
+
+
+def driver_line(out):
+    """The ONE stdout line the driver parses: the contract's keys + config + roofline + cpu_baseline, <= LINE_LIMIT bytes whatever the run
+    did (reference: one short result line, dasp_f64.h:1394-1398).  Everything else (suite entries, placement notes, the vendor
+    comparator, per-launch spread) lives in the full record `bench_suite.json` next to this file."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    rec = {k: out.get(k) for k in keep}
+    c = out.get("config", {})
+    rec["config"] = {k: c[k] for k in ("workload", "rows", "cols", "nnz", "scale", "partition", "generator_rev", "exchange", "step_form",
+                                       "rank0_nnz_own_columns", "rank0_nnz_other_columns") if k in c}
+    for k, n in (("workload", 120), ("partition", 100), ("exchange", 80), ("step_form", 240)):
+        if k in rec["config"]:
+            rec["config"][k] = _short(rec["config"][k], n)
+    r = out.get("roofline", {})
+    rec["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel", "kernel_ms",
+                                         "algorithmic_bytes_per_launch", "frac_single_y", "frac_random_values", "launch_ms_median",
+                                         "f64_share_at_or_above_0.6", "suite_frac", "suite_frac_random_values") if k in r}
+    if "traffic_reason" in r:
+        rec["roofline"]["traffic_reason"] = _short(r["traffic_reason"], 120)
+    cb = out.get("cpu_baseline")
+    if cb:
+        rec["cpu_baseline"] = {k: (_short(cb[k], 140) if k == "sample" else cb[k]) for k in ("value", "unit", "cores", "kind", "sample", "ms", "host_cores_available") if k in cb}
+    for k in ("verified", "region_event_ms_per_step", "achieved_GBps_whole_job", "frac_hbm_roofline_whole_job", "preprocess_s", "pre_ms_device_csr"):
+        if k in out:
+            rec[k] = out[k]
+    vr = out.get("verified_random_x")
+    if vr:
+        rec["verified_random_x"] = {k: vr[k] for k in ("ok", "rows_checked", "max_rel_err", "tol") if k in vr}
+        if "error" in vr:
+            rec["verified_random_x"]["error"] = _short(vr["error"], 120)
+    if "rocsparse_csr" in out and "ms" in out["rocsparse_csr"]:
+        rec["rocsparse_csr_ms"] = out["rocsparse_csr"]["ms"]
+    sp = out.get("step_parts")
+    if sp:
+        rec["step_parts"] = {k: sp[k] for k in ("allgather_alone_ms", "other_column_product_ms", "allgather_bytes_per_rank") if k in sp}
+    ex = out.get("exchange_ms")
+    if ex:
+        rec["exchange_ms"] = {k: ({kk: (_short(vv, 100) if kk == "error" else vv) for kk, vv in v.items()} if isinstance(v, dict) else
+                                  (_short(v, 100) if k == "error" else v)) for k, v in ex.items()}
+    if "error" in out:
+        rec["error"] = _short(out["error"], 300)
+    if "suite" in out:
+        rec["suite_errors"] = [e["workload"] for e in out["suite"] if "error" in e or not e.get("verified", False)
+                               or not e.get("verified_random_x", {}).get("ok", False)]
+    rec["full_record"] = "bench_suite.json"
+    line = json.dumps(rec, separators=(",", ":"))
+    # the limit holds by construction for every run of this file; should a future key break it, shed the optional ones rather than the line
+    for k in ("suite_frac_random_values", "suite_frac"):
+        if len(line) <= LINE_LIMIT:
+            break
+        rec["roofline"].pop(k, None)
+        line = json.dumps(rec, separators=(",", ":"))
+    for k in ("exchange_ms", "step_parts", "verified_random_x", "suite_errors"):
+        if len(line) <= LINE_LIMIT:
+            break
+        rec.pop(k, None)
+        line = json.dumps(rec, separators=(",", ":"))
+    return line
+
+
+def emit(out):
+    """full record -> bench_suite.json (+ gpurun_out/ when that exists: it travels back from a gpurun box); compact line -> stdout, LAST"""
+    full = json.dumps(out, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_suite.json"), "w") as f:
+                    f.write(full + "\n")
+            except OSError as exc:
+                sys.stderr.write("bench.py: could not write %s/bench_suite.json: %s\n" % (d, exc))
+    sys.stdout.flush()
+    print(driver_line(out), flush=True)
+
 
 
 def algorithmic_bytes(m, n, nnz, vbytes):
@@ -232,6 +315,9 @@ def kernel_revision():
     return h.hexdigest()[:12]
 
 
+_FIRST_Y = {}
+
+
 def choose_y(torch, plan, x, rows, tdt, stats):
     """The written vector's placement decides between the two speeds of the HBM-bound kernels (profiles/r04_placement.md): instead of copying the
     2.9-GB plan into fresh allocations until one is fast (r3's trials inside dasp_plan_upload), time the plan against a few y vectors of
@@ -245,6 +331,7 @@ def choose_y(torch, plan, x, rows, tdt, stats):
     ms = [plan.time(x.data_ptr(), yk.data_ptr(), 0, 2, 6)[1] for yk in ys]
     k = int(np.argmin(ms))
     y = ys[k]
+    _FIRST_Y["y"] = ys[0]          # what a caller with ONE y gets: timed beside the kept one (roofline.frac_single_y)
     del ys
     return y, {"y_candidates": n, "ms_each": [round(float(v), 4) for v in ms], "kept": k,
                "note": "the plan timed against n y vectors of the run's own (2 + 6 launches each), the fastest kept; no copy of the plan, no trial inside the library"}
@@ -262,10 +349,13 @@ def suite_entry(torch, D, O, name, precision, scale, budget_s=2.0):
     tdt = torch.float64 if precision == 64 else torch.float16
     x = torch.ones(cols, dtype=tdt, device="cuda")
     y, placement = choose_y(torch, plan, x, rows, tdt, plan.stats)      # as the headline
+    y_first = _FIRST_Y.pop("y", None)
     w, e = time_plan(torch, plan, x, y, 20, 10)
     iters = int(max(20, min(1000, budget_s * 1e3 / max(e, 1e-4))))
     w, e = time_plan(torch, plan, x, y, iters, min(100, iters))
     gw, ge = plan.time_graph(x.data_ptr(), y.data_ptr(), 0, warmup=min(100, iters), iters=iters, batch=min(50, iters))
+    e1 = e if y_first is None or y_first is y else time_plan(torch, plan, x, y_first, min(iters, 200), 10)[1]
+    del y_first
     order = torch.from_numpy(plan.order_rid.astype(np.int64)).cuda()
     want = torch.from_numpy(np.diff(rp).astype(np.float64)).cuda()[order]
     ok = bool((y.double() == want).all().item()) if precision == 64 or int(np.diff(rp).max()) <= 2048 else \
@@ -276,6 +366,7 @@ def suite_entry(torch, D, O, name, precision, scale, budget_s=2.0):
            "ms": round(w, 6), "event_ms": round(e, 6), "graph_event_ms": round(ge, 6), "iters": iters, "gflops": round(2.0 * nnz / (w * 1e6), 2),
            "achieved_GBps": round(b_alg / (e * 1e6), 1), "frac_hbm_roofline": round(b_alg / (e * 1e6) / HBM_PEAK_GBPS, 4),
            "frac_hbm_roofline_graph": round(b_alg / (ge * 1e6) / HBM_PEAK_GBPS, 4),
+           "frac_single_y": round(b_alg / (e1 * 1e6) / HBM_PEAK_GBPS, 4),
            "rate_fill0": round(st["rate_fill0"], 4), "pre_ms": round(st["pre_ms"], 1), "verified": ok,
            "col_panels": st["n_col_panels"], "row_long": st["row_long"], "row_block": st["row_block"],
            "row_short": rows - st["row_long"] - st["row_block"] - st["row_zero"], "generator": generator_of(D, name),
@@ -360,7 +451,7 @@ class Watchdog:
                     rec = dict(self.partial, error=note + " (the measurement above is complete; an extra after it did not finish)") if self.partial else \
                         {"metric": "SpMV GFLOP/s (f64)", "value": None, "unit": "GFLOP/s", "n_gpus": self.args.gpus, "steps": self.args.steps,
                          "warmup": self.args.warmup, "error": note}
-                    print(json.dumps(rec), flush=True)
+                    emit(rec)
                 sys.stderr.write("bench.py rank %d: watchdog fired in phase '%s'\n" % (self.rank, self.phase))
                 sys.stderr.flush()
                 os._exit(5)
@@ -413,6 +504,7 @@ def setup_rank(torch, D, name, scale, prec, rank, world, multi=None, chain=None)
     tdt = torch.float64 if prec == 64 else torch.float16
     x = torch.ones(plan.x_len, dtype=tdt, device="cuda")
     y, placement = choose_y(torch, plan, x, r1 - r0, tdt, plan.stats)
+    y_first = _FIRST_Y.pop("y", None)
     arena_trials = int(os.environ.get("DASP_BENCH_ARENA_TRIALS", "0"))          # r3's trials (copies of the whole plan): off unless asked for
     if arena_trials > 1:
         first, kept = plan.tune_placement(arena_trials, x.data_ptr(), y.data_ptr())
@@ -423,7 +515,7 @@ def setup_rank(torch, D, name, scale, prec, rank, world, multi=None, chain=None)
     placement["upload_ms"] = round(upload_ms, 1)
     placement["device_bytes_plan_and_vectors"] = int(free0 - torch.cuda.mem_get_info()[0])
     return dict(chain=None, mg=None, placement=placement, plan=plan, rp=rp, ci=ci, val=None, stats=plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total,
-                lengths=lengths, bounds=bounds, stride=0, r0=r0, r1=r1, x=x, y=y)
+                lengths=lengths, bounds=bounds, stride=0, r0=r0, r1=r1, x=x, y=y, y_first=y_first)
 
 
 def cpu_baseline(O, rp, ci, n_cols, budget_s=20.0):
@@ -800,6 +892,10 @@ def main():
     # the spread inside this process: every one of >= 200 launches between its own pair of events (VERDICT r2 weak #8a); each interval
     # carries the few microseconds an event between two kernels costs, so the headline kernel_ms stays the back-to-back mean above
     each = np.sort(plan.time_each(kx.data_ptr(), ky.data_ptr(), stream, warmup=5, iters=max(200, k_iters)).astype(np.float64))
+    # the same plan against the FIRST y this run allocated (no choice among candidates): what a solver with one y vector gets
+    y1 = R.get("y_first")
+    ke1 = ke if (mg is not None or y1 is None or y1 is y) else plan.time(x.data_ptr(), y1.data_ptr(), stream, warmup=5, iters=k_iters)[1]
+    R["y_first"] = y1 = None
     # partitioned: the dominant kernel is the rank's own-column plan (its x is the rank's own slice)
     nnz_local = int(rp[-1]) if mg is None else mg.nnz_local
     b_alg_local = algorithmic_bytes(r1 - r0, cols if mg is None else (stride if mg.overlap else cols), nnz_local, vb)
@@ -834,6 +930,7 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "kernel": "dasp_spmv_kernel<%s>" % ("double" if prec == 64 else "_Float16"),
                      "algorithmic_bytes_per_launch": b_alg_local, "kernel_ms": round(ke, 6),
+                     "frac_single_y": round(b_alg_local / (ke1 * 1e6) / HBM_PEAK_GBPS, 4), "kernel_ms_single_y": round(ke1, 6),
                      "launch_ms_min": round(float(each[0]), 6), "launch_ms_p10": round(float(each[len(each) // 10]), 6),
                      "launch_ms_median": round(float(np.median(each)), 6), "launch_ms_p90": round(float(each[(len(each) * 9) // 10]), 6),
                      "launch_ms_max": round(float(each[-1]), 6),
@@ -987,6 +1084,7 @@ def main():
             out["suite"] = suite
             dog.kick("suite entry %s done" % nm)
         out["suite"] = suite
+        out["gather_roofline_note"] = GATHER_NOTE
         # where the driver's record keeps it: every BASELINE configuration's fraction of the HBM roofline inside the roofline object
         sf = {"%s %s" % (name, "f64" if prec == 64 else "f16"): out["roofline"]["frac"]}
         sfr = {}
@@ -1006,7 +1104,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if not ok:
         sys.exit(3)
 

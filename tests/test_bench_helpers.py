@@ -106,3 +106,72 @@ def test_exchange_configurations_best_first():
     assert f(False, True, True, False, 1) == [("RCCL", True), ("RCCL", False)]
     assert f(True, False, False, False, 2) == [("direct", False)]
     assert f(False, False, True, False, 2) == [("host", False)]
+
+
+def _worst_case_record(b, multi):
+    """a canned full record with every optional key present and every free-text field long (what a run with fall-backs, errors and
+    all eleven suite rows produces)"""
+    names = ["HV15R", "cop20k_A", "nlpkkt160", "powerlaw_1M", "Queen_4147", "HV15R-unstructured", "webbase-1M", "ljournal-2008", "rmat_2M",
+             "ljournal-2008-uniform", "webbase-1M-uniform"]
+    sf = {"%s %s" % (n, "f64" if i < 6 else "f16"): 0.1234 for i, n in enumerate(names)}
+    out = {"metric": "SpMV GFLOP/s (f64)", "value": 1236.27, "unit": "GFLOP/s", "n_gpus": 8 if multi else 1, "steps": 20, "warmup": 5,
+           "ms_per_step": 0.445621, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "HV15R synthetic stand-in " + "x" * 400, "generator": "g" * 600, "generator_rev": "26e32ff958e7", "rows": 2017169,
+                      "cols": 2017169, "nnz": 275454726, "scale": 1.0, "partition": "p" * 400, "placement": {"note": "n" * 900},
+                      "exchange": "e" * 300, "step_form": "s" * 700, "rank0_nnz_own_columns": 1, "rank0_nnz_other_columns": 2},
+           "roofline": {"bound": "hbm", "achieved": 7500.7, "peak": 8000.0, "unit": "GB/s", "frac": 0.9376, "traffic": 2913962942,
+                        "traffic_over_algorithmic": 0.8709, "traffic_reason": "r" * 500, "kernel": "dasp_spmv_kernel<double>", "kernel_ms": 0.446063,
+                        "algorithmic_bytes_per_launch": 3345800096, "frac_single_y": 0.91, "frac_random_values": 0.9194, "launch_ms_median": 0.447,
+                        "method": "m" * 900, "f64_share_at_or_above_0.6": 0.667, "suite_frac": sf, "suite_frac_random_values": dict(sf)},
+           "cpu_baseline": {"value": 5.343, "unit": "GFLOP/s", "cores": 1, "kind": "port", "sample": "c" * 500, "ms": 103.1, "host_cores_available": 256,
+                            "build": "b" * 300},
+           "verified": True, "region_event_ms_per_step": 0.445, "achieved_GBps_whole_job": 7508.2, "frac_hbm_roofline_whole_job": 0.9385,
+           "preprocess_s": 0.322, "pre_ms_device_csr": 28.8,
+           "verified_random_x": {"ok": True, "rows_checked": 103878, "max_rel_err": 4.2e-16, "tol": 1e-12, "inputs": "i" * 300, "error": "E" * 900},
+           "rocsparse_csr": {"ms": 0.68, "gflops": 800.0}, "error": "X" * 2000,
+           "suite": [{"workload": n, "verified": True, "verified_random_x": {"ok": True}, "gather_roofline": b.gather_roofline(10 ** 8, 0.4),
+                      "note": "z" * 2000} for n in names[1:]] + [{"workload": "broken", "error": "y" * 3000}]}
+    if multi:
+        out["step_parts"] = {"allgather_alone_ms": 0.03, "other_column_product_ms": 0.01, "allgather_bytes_per_rank": 2017176, "note": "n" * 300}
+        out["exchange_ms"] = {"direct": {"ms_per_step": 0.08, "fused": True, "steps": 20, "allgather_alone_ms": 0.03},
+                              "RCCL": {"fused": False, "error": "q" * 1500}, "rccl_ranks": 8, "error": "w" * 1500}
+    return out
+
+
+def test_driver_line_is_short_and_complete(tmp_path, capsys):
+    """the driver keeps an 8 KB tail of stdout and parses its LAST line -- r04's 22 KB line was lost.  Whatever the run did,
+    the last stdout line is one JSON object < 4096 bytes with the contract's keys, roofline and cpu_baseline; the suite goes to bench_suite.json"""
+    import json
+    b = _bench()
+    for multi in (False, True):
+        out = _worst_case_record(b, multi)
+        assert len(json.dumps(out)) > 20000                            # the full record is as fat as r04's
+        line = b.driver_line(out)
+        assert len(line) < b.LINE_LIMIT == 4096 and "\n" not in line
+        rec = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+            assert rec[k] == out[k], k
+        assert rec["config"]["workload"].startswith("HV15R") and rec["config"]["nnz"] == 275454726 and "partition" in rec["config"]
+        assert "model" not in rec["config"]
+        r = rec["roofline"]
+        assert (r["bound"], r["frac"], r["achieved"], r["peak"], r["unit"], r["traffic"]) == ("hbm", 0.9376, 7500.7, 8000.0, "GB/s", 2913962942)
+        assert r["frac_single_y"] == 0.91 and r["frac_random_values"] == 0.9194 and len(r["suite_frac"]) == 11 and len(r["suite_frac_random_values"]) == 11
+        c = rec["cpu_baseline"]
+        assert (c["value"], c["cores"], c["kind"], c["unit"]) == (5.343, 1, "port", "GFLOP/s") and c["sample"]
+        assert rec["suite_errors"] == ["broken"] and "suite" not in rec and rec["full_record"] == "bench_suite.json"
+        if multi:
+            assert rec["exchange_ms"]["rccl_ranks"] == 8 and rec["exchange_ms"]["direct"]["ms_per_step"] == 0.08
+            assert rec["step_parts"]["allgather_alone_ms"] == 0.03
+    # the canned record of the run the driver could not parse: its own keys survive
+    logp = os.path.join(ROOT, "profiles", "r04_bench_full.json.log")
+    out = json.loads(open(logp).read().strip().splitlines()[-1])
+    rec = json.loads(b.driver_line(out))
+    assert rec["ms_per_step"] == out["ms_per_step"] and rec["roofline"]["frac"] == out["roofline"]["frac"]
+    assert rec["cpu_baseline"]["value"] == out["cpu_baseline"]["value"] and len(b.driver_line(out)) < 4096
+    # emit(): full record to the side file, the short line LAST on stdout
+    b.ROOT = str(tmp_path)
+    b.emit(out)
+    printed = capsys.readouterr().out.strip().splitlines()
+    assert json.loads(printed[-1])["value"] == out["value"] and len(printed[-1]) < 4096
+    side = json.load(open(tmp_path / "bench_suite.json"))
+    assert len(side["suite"]) == len(out["suite"]) and side["roofline"] == out["roofline"]
