@@ -114,7 +114,10 @@ bool mg_step_supported(const Plan &own, const Plan *other)
 {
     auto ok = [](const Plan &p) {
         // 16-bit ids -- or no MFMA block at all (every medium row stored as a slab: nothing reads the id planes)
-        return p.precision == 64 && p.dev && p.dev->arena && p.panels.empty() && !p.windowed && (p.cid16 || p.stats.n_med_blocks == 0) && p.dev->args.n_multi == 0;
+        // the step kernels decode short groups as slabs only (plain_wg -> short_tile<.., SEG = YS==0> without the wave-segmented form): a plan
+        // with a segmented group -- a caller's short_seg, a loaded plan file -- takes the two-launch form instead of wrong results
+        return p.precision == 64 && p.dev && p.dev->arena && p.panels.empty() && !p.windowed && (p.cid16 || p.stats.n_med_blocks == 0) && p.dev->args.n_multi == 0 &&
+               p.stats.short_seg == 0;
     };
     return ok(own) && (!other || ok(*other));
 }
@@ -955,6 +958,12 @@ int dasp_mg_product(dasp_mg_plan_t *mg, void *stream)
 {
     if (!mg) return DASP_ERR_ARG;
     if (!mg->uploaded) { set_error("dasp_mg_upload first"); return DASP_ERR_STATE; }
+    if (mg->one_stream()) {
+        // one-stream step: this launch's head workgroups store the previous slice into every peer's gather buffer and its boundary workgroups
+        // wait on the peers' flags -- "products only" does not exist in this mode, so the same gates as dasp_mg_spmv apply
+        if (int rc = sticky_error(*mg)) return rc;
+        if (int rc = push_wait_peers(*mg)) return rc;
+    }
     return product(*mg, static_cast<hipStream_t>(stream));
 }
 

@@ -32,6 +32,25 @@ int resolve_threads(int requested)
     return (int)std::min(hc, cap);
 }
 
+// A/B knobs of the packers (tools/*_ab.py): read ONCE per process, before any worker thread exists, and only ever applied over an option
+// left at "auto" -- a plan file or a saved number never depends on the environment behind an explicit option.
+//   DASP_ONE_PIECE_MAX (longest row kept as one piece, default 4096), DASP_ROW_TILE_MAX (bound of the column panels' row tiles over
+//   row_tile_max = 0), DASP_PANEL_ROW_SCAN (the r3 scan order of the f16 panels)
+namespace {
+struct AbKnobs { int one_piece_max = 4096, row_tile_max = -1; bool panel_row_scan = false; };
+const AbKnobs &ab_knobs()
+{
+    static const AbKnobs k = [] {
+        AbKnobs v;
+        if (const char *e = std::getenv("DASP_ONE_PIECE_MAX")) v.one_piece_max = std::atoi(e);
+        if (const char *e = std::getenv("DASP_ROW_TILE_MAX")) v.row_tile_max = std::max(0, std::atoi(e));
+        v.panel_row_scan = std::getenv("DASP_PANEL_ROW_SCAN") != nullptr;
+        return v;
+    }();
+    return k;
+}
+}  // namespace
+
 // ---- a small persistent worker pool: spawning 32 threads costs ~1 ms, and building a plan from a device-resident CSR is ~20
 // O(rows) loops of a few hundred microseconds each (HV15R: 38 ms of which half was thread creation).  Jobs are ranges handed out
 // through one atomic counter; the caller works too.  A call from inside a worker (column panels are built side by side, each
@@ -754,7 +773,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         // 17.0 us), or no row beyond 4096 at all (r4: the four panels of ljournal-2008 each paid a ~5 us launch for ~540 rows of 1025..2469)
         int longest = 0;
         for (int r : ridL) longest = std::max(longest, rp[r + 1] - rp[r]);
-        const int one_piece = std::getenv("DASP_ONE_PIECE_MAX") ? std::atoi(std::getenv("DASP_ONE_PIECE_MAX")) : 4096;      // (A/B knob)
+        const int one_piece = ab_knobs().one_piece_max;
         if ((nnz_pieces <= 2000000 && longest <= 16384) || longest <= one_piece) piece = std::max(piece, longest);
     }
     piece = std::max(geo.chunk, ceil_div(piece, geo.chunk) * geo.chunk);
@@ -1052,7 +1071,8 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     std::memset(&s, 0, sizeof s);
     s.precision = p.precision; s.rowA = m; s.colA = p.n; s.nnzA = nnz;
     s.short_row_1 = n1; s.common_13 = c13; s.short_row_3 = n3; s.short_row_4 = n4; s.short_row_2 = n2;
-    s.short_seg = p.grp[0].seg | p.grp[1].seg | p.grp[2].seg | p.grp[3].seg;
+    s.short_seg = 0;
+    for (int g = 0; g < kNumShortGroups; ++g) s.short_seg |= p.grp[g].seg;
     s.row_long = nlong_cls; s.row_block = nmed_all; s.row_zero = nz0; s.med_rows_as_pieces = nsp; s.chunk_pairs = p.pair_mode; s.cid8_chunks = p.med_c8ptr.empty() ? 0 : p.med_c8ptr.back();
     s.nnz_short = nnz_short; s.nnz_long = (int)nnz_long; s.nnz_irreg = nnz_irreg;
     s.origin_nnz_reg = nnz - nnz_irreg - (int)nnz_long - nnz_short;
@@ -1214,7 +1234,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     // tables, rt_at[k][row] = the row's first element in the tiles' arrays (-1: the row stays with the panel's own plan)
     int rt_max = p.opt.row_tile_max == 0 ? (p.precision == 16 ? kRowTileAuto : kRowTileAuto64) : std::max(0, p.opt.row_tile_max);
     if (rt_max > kRowTileMax) { set_error("row_tile_max must be <= 32"); return DASP_ERR_ARG; }
-    if (const char *e = std::getenv("DASP_ROW_TILE_MAX")) rt_max = std::min(kRowTileMax, std::max(0, std::atoi(e)));      // A/B knob
+    if (p.opt.row_tile_max == 0 && ab_knobs().row_tile_max >= 0) rt_max = std::min(kRowTileMax, ab_knobs().row_tile_max);      // A/B knob: only over "auto", never over a caller's choice
     struct RowTiles { std::vector<int> ptr; std::vector<uint16_t> start; std::vector<uint64_t> mask; raw_vector<char> val; raw_vector<int> cid; std::vector<int> at; size_t cnt = 0; };
     std::vector<RowTiles> rt((size_t)P);
     // from a panel's row LENGTHS in len[1 .. m] (len[i + 1] = row i): the tiles' tables; the rows taken get length 0 in len
@@ -1318,7 +1338,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
                         q.opt.x_window = -1; q.opt.cid8 = -1;      // the tiles ride in the non-windowed kernel without one-byte ids (dasp_spmv_rt_kernel)
                     }
                     // f16 only: 2-byte stores are where the partial lines hurt (ljournal-2008-uniform 0.590 -> 0.559 ms, ljournal-2008 0.506 -> 0.503; powerlaw_1M f64 0.651 -> 0.654)
-                    if (!natural && p.precision == 16 && !std::getenv("DASP_PANEL_ROW_SCAN")) q.scan_order = p.order.data();      // (DASP_PANEL_ROW_SCAN: A/B knob, the r3 order)
+                    if (!natural && p.precision == 16 && !ab_knobs().panel_row_scan) q.scan_order = p.order.data();      // (DASP_PANEL_ROW_SCAN: A/B knob, the r3 order)
                     try { rcs[k] = build_impl<T>(q, rpP[k].data(), dev ? nullptr : ciP[k].data(), dev ? nullptr : valP[k].data(), dev ? &devP[(size_t)k] : nullptr, kPanel); }
                     catch (const std::bad_alloc &) { rcs[k] = DASP_ERR_NOMEM; set_error("out of host memory"); }
                     if (rcs[k] == DASP_OK && dev && q.cnt_rt > 0) rcs[k] = devpack_place_row_tiles(q, rt_dev[(size_t)k]);

@@ -424,7 +424,9 @@ void *dasp_mg_reserved_stream(dasp_mg_plan_t *mg, int reserve_cus);
 /* TEST HOOK (timing on a one-GPU box): the direct exchange with scratch memory of this rank standing in for every peer */
 int dasp_mg_push_loopback(dasp_mg_plan_t *mg);
 /* the products of one iteration only (no exchange): for callers that move dasp_mg_y_local into every rank's
- * dasp_mg_gathered themselves (tests; transports other than RCCL) */
+ * dasp_mg_gathered themselves (tests; transports other than RCCL).  EXCEPT in the one-stream step (overlap = 2 with the direct exchange):
+ * there the launch itself sends the previous slice to the peers and waits for theirs, so the call is dasp_mg_spmv under another name -- it
+ * waits for the peers' epoch (dasp_mg_set_x) and refuses after a timed-out wait exactly as dasp_mg_spmv does. */
 int dasp_mg_product(dasp_mg_plan_t *mg, void *stream);
 /* the exchange alone, on `stream` (no product): the current y slice -> every rank's gather buffer; collective.  For timing the
  * all-gather by itself next to the products. */

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """tools/one_piece_ab.py -- long rows of up to 4096 nonzeros as ONE piece (no dasp_long_reduce launch) against pieces of 1024: DASP_ONE_PIECE_MAX=0 / default."""
+# NOTE (r5): the packers read their A/B environment knobs once per process now -- run one process per setting.
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """tools/panel_scan_ab.py: column panels whose classifier walks the rows in the parent's slot order (r4) against row order (r3, DASP_PANEL_ROW_SCAN=1)."""
+# NOTE (r5): the packers read their A/B environment knobs once per process now -- run one process per setting.
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
