@@ -1,6 +1,7 @@
 /*
  * oracle/dasp_oracle.c -- TEST INFRASTRUCTURE ONLY (see dasp_oracle.h for the
- * pinning status: "parity unpinned" except mmio.h banner/size parsing and radix_sort).
+ * pinning status: "parity unpinned" except the mmio.h parse layer, radix_sort and the survey-recorded
+ * classifier / padded sizes / order_rid hash of one 3000-row matrix).
  *
  * Plain-C restatement of the reference's host algorithm for the DASP SpMV path.
  * Every function cites the reference lines it follows (paths relative to

@@ -16,6 +16,14 @@
  *     size-line parsing of this file (tests/test_oracle_ref.py).
  *   - radix_sort is pinned by the known-answer vector the survey recorded from a
  *     run of the real code.
+ *   - (r5) Classifier tuple, padded sizes (fill0_nnz_short/_long/_reg, nnz_irreg,
+ *     blocknum, warp_number; f64 and f16) and the f64 order_rid (by hash) are pinned
+ *     on ONE 3000-row matrix with every category by the outputs of the reference's
+ *     own host code that the survey recorded:
+ *     tests/golden/survey_g3000.{mtx.gz,json}, tests/test_oracle.py::
+ *     test_survey_recorded_reference_outputs.  Recorded by the survey, not re-run
+ *     by this build; the packed value / column arrays themselves and y have no
+ *     reference-run pin (tools/ref_dump.cu.txt is the recipe for a CUDA box).
  *   - Everything else is pinned only through the reference's own identities:
  *     y[i] == nnz(row order_rid[i]) when A == 1 and x == 1 (src/utils.h:93-100,
  *     src/main_f64.cu:131-132) and

@@ -111,7 +111,8 @@ def test_parity_synthetic_standins(oracle, dasp, torch_cuda, name, prec, scale):
 
 
 @pytest.mark.parametrize("name,prec", [("HV15R", 64), ("ljournal-2008", 16), ("Queen_4147", 64), ("nlpkkt160", 64), ("webbase-1M", 16),
-                                       ("HV15R-unstructured", 64)])
+                                       ("HV15R-unstructured", 64), ("cop20k_A", 64), ("powerlaw_1M", 64), ("rmat_2M", 64), ("rmat_2M", 16),
+                                       ("ljournal-2008-uniform", 16), ("webbase-1M-uniform", 16)])
 def test_full_size_random_x_parity(oracle, dasp, torch_cuda, name, prec):
     """BASELINE's full sizes (scale 1.0): seeded random values and x, >= 100 k sampled rows (the 4096 longest + a uniform sample)
     against the oracle at the north_star tolerance -- bench.py's verified_random_x, the check the all-ones mode cannot make"""
@@ -123,6 +124,21 @@ def test_full_size_random_x_parity(oracle, dasp, torch_cuda, name, prec):
     rp, ci = dasp.synth_csr(name, 1.0)
     res = bench.verify_random_x(torch_cuda, dasp, oracle, rp, ci, cols, prec)
     assert res["ok"] and res["rows_checked"] >= 100000 and res["max_rel_err"] <= TOL[prec], res
+
+
+@pytest.mark.parametrize("name,scale", [("cop20k_A", 1.0), ("HV15R", 0.02), ("powerlaw_1M", 0.05), ("webbase-1M", 0.2), ("nlpkkt160", 0.01)])
+def test_vendor_comparator_agrees_with_dasp(torch_cuda, name, scale):
+    """the reference's comparator check (src/main_f64.cu:3-16 verify_new: y_cusparse[order_rid[i]] against y_dasp[i]) with rocSPARSE's CSR SpMV
+    in cuSPARSE's place: seeded random values and x, every row, 1e-12 relative to sum |a_ij x_j| (the reference: 1e-5 absolute)"""
+    import re
+    exe = os.path.join(ROOT, "dasp_amd", "bin", "dasp_rocsparse")
+    if not os.path.exists(exe):
+        pytest.skip("dasp_rocsparse was not built (no librocsparse at build time)")
+    r = subprocess.run([exe, name, repr(scale), "3", "1", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "mismatches=0 (vs dasp_plan_spmv through order_rid" in r.stdout
+    m = re.search(r"compare: rows=(\d+) max_rel_err=([0-9.e+-]+)", r.stdout)
+    assert m and int(m.group(1)) > 1000 and float(m.group(2)) <= 1e-12
 
 
 def test_padded_slots_do_not_read_x0(oracle, dasp, torch_cuda):

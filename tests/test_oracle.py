@@ -219,3 +219,50 @@ def test_csr_product_against_scipy(oracle, seed, m, n):
     assert np.array_equal(got == 0, want == 0) or np.all(scale[(got == 0) != (want == 0)] > 0)     # empty rows are exact zeros in both
     e = np.diff(rp) == 0
     assert np.all(got[e] == 0) and np.all(got_abs[e] == 0)
+
+
+def _fnv_words(a):
+    """the survey's hash of order_rid: FNV-1a constants over the int WORDS (h ^= (unsigned)order_rid[i]; h *= prime)"""
+    h = 1469598103934665603
+    for w in np.asarray(a).astype(np.uint32).tolist():
+        h = ((h ^ w) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+def test_survey_recorded_reference_outputs(oracle, dasp, tmp_path, prec):
+    """The one place where numbers produced BY THE REFERENCE'S OWN HOST CODE exist for the hot path: SURVEY.md section 8(c) / App. D.3 record what
+    the reference's classifier and packers (dasp_f64.h:486-1157, dasp_f16.h:1015-1449) printed for a 3000 x 3000 pattern matrix -- the
+    classifier tuple, the padded sizes and (f64) a hash of order_rid.  The matrix is committed as data (survey_g3000.mtx.gz), the numbers are
+    copied from the survey.  The oracle's restatement, the product's loader + classifier and the product's reference-geometry sizes
+    (dasp_stats_t::ref_*) must all reproduce them: a pin of rows a4-a11 to an execution of the reference, recorded by the survey."""
+    import gzip
+    want_all = json.load(open(os.path.join(GOLD, "survey_g3000.json")))
+    path = tmp_path / "survey_g3000.mtx"
+    path.write_bytes(gzip.open(os.path.join(GOLD, "survey_g3000.mtx.gz")).read())
+    rc, m, n, nnz, sym, rp, ci, v = oracle.mmio_allinone(str(path))
+    assert (rc, m, n, nnz, sym) == (0, want_all["rows"], want_all["cols"], want_all["nnz"], 0)
+    want = dict(want_all["f%d" % prec])
+    fnv = want.pop("order_rid_fnv", None)
+    rate = want.pop("rate_fill0_3dp", None)
+    P = oracle.Packed(prec, rp, ci, np.ones(nnz), n)
+    for k, val in want.items():
+        assert int(getattr(P, k)) == val, (k, "oracle")
+    if fnv:
+        assert _fnv_words(P.order_rid) == fnv
+    if rate is not None:
+        assert round(P.rate_fill0, 3) == rate
+    # the product: its own loader on the same file, its classifier, its order_rid, and the reference-geometry sizes it reports
+    m2, n2, nnz2, sym2, rp2, ci2, v2 = dasp.mmio_allinone(str(path), prec)
+    assert (m2, n2, nnz2) == (m, n, nnz) and np.array_equal(rp2, rp) and np.array_equal(ci2, ci)
+    plan = dasp.Plan(rp2, ci2, v2, n2, precision=prec)
+    st = plan.stats
+    for k, val in want.items():
+        key = k if k in st and not k.startswith("fill0") and k not in ("nnz_irreg", "blocknum", "warp_number") else "ref_" + k
+        assert st[key] == val, (k, "product")
+    if fnv:
+        assert _fnv_words(plan.order_rid) == fnv
+    if rate is not None:
+        assert round(st["ref_rate_fill0"], 3) == rate
+    assert np.array_equal(plan.order_rid, P.order_rid)
+    plan.close()
