@@ -51,7 +51,6 @@ struct DevArgs {
     // xcd_blk[m % 8] + 4 * (m / 8) .. + 3 below xcd_blk[m % 8 + 1].  xcd_on = 0: block = workgroup * 4 + wave as ever.
     int xcd_on;
     int xcd_blk[9];
-    int ymode;        // DASP_EXPERIMENT builds only: how y is written (spmv_device.hpp put_y / medium_block)
     int med_stride;   // 1: the medium workgroups stride over the blocks (capped, persistent range); 0: exactly one block per wave
     // row tiles of a column panel (Plan::rt_*): workgroups [wg_long + wg_med + wg_short, + wg_rt), one tile per wave
     const void *rt_val; const int *rt_cid; const int *rt_ptr; const unsigned short *rt_start; const unsigned long long *rt_mask;
@@ -74,7 +73,6 @@ struct DevicePlan {
     int device = -1;
     // column-panel parent: arena = the panels' partial results, panel k at ypart + k * ypart_stride elements
     size_t ypart_stride = 0;
-    size_t exp_y_off = 0, exp_x_off = 0;      // DASP_EXPERIMENT builds: scratch y / x inside the arena allocation
 };
 
 

@@ -152,9 +152,6 @@ __global__ void selftest_f16_kernel(float *D)
         }                                                                                      \
     } while (0)
 
-#ifdef DASP_EXPERIMENT
-#include "spmv_experiments.hpp"      // kernels of the experiment build only (store policies, resident waves)
-#endif
 
 // ---- what upload.cpp needs to know about the kernels (it is host code and never names a kernel itself)
 // windowed plans with more than the default 64 KiB of dynamic LDS: the limit must be raised per kernel.  Done at upload (for both
@@ -202,9 +199,6 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
     } else if (grid > 0) {
         const size_t lds = p.windowed ? (size_t)p.lds_bytes : 0;
         const bool c16 = p.cid16;
-#ifdef DASP_EXPERIMENT
-        if (sizeof(T) == 8 && nt && c16 && !p.windowed && a.n_multi == 0) { const int rc = launch_experiment(a, s); if (rc != 1) return rc; }
-#endif
 #define DASP_FOR_EACH(M) \
         if (nt && c16 && p.windowed) { M(true, true, true); } else if (nt && c16) { M(true, true, false); } \
         else if (nt && p.windowed) { M(true, false, true); } else if (nt) { M(true, false, false); } \
@@ -271,21 +265,6 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate
     // one block / tile / piece per wave and then the wave ends: f64 plans without x windows and without a striding medium range
     a.ywt = p.dev->nt && p.precision == 64 && !p.windowed && !a.med_stride && !p.panel ? 1 : 0;
     if (const char *e = std::getenv("DASP_Y_WT")) a.ywt = a.ywt && std::atoi(e) != 0;      // A/B knob
-#ifdef DASP_EXPERIMENT_HOST      // host-side experiment switches only: the device code of such a build is the product's
-    if (const char *e = std::getenv("DASP_Y_IN_ARENA")) {      // 1: y inside the plan's allocation; 2: x too (copied once per call: timing only)
-        const int v = std::atoi(e);
-        if (v >= 1 && p.dev->exp_y_off) a.y = static_cast<char *>(p.dev->arena) + p.dev->exp_y_off;
-        if (v >= 2 && p.dev->exp_x_off) {
-            void *xi = static_cast<char *>(p.dev->arena) + p.dev->exp_x_off;
-            static const void *last_x = nullptr; static void *last_arena = nullptr;
-            if (last_x != dX || last_arena != p.dev->arena) { (void)hipMemcpyAsync(xi, dX, (size_t)p.n * p.geo.vbytes, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)); last_x = dX; last_arena = p.dev->arena; }
-            a.x = xi;
-        }
-    }
-#endif
-#ifdef DASP_EXPERIMENT
-    if (const char *e = std::getenv("DASP_YSTORE")) a.ymode = std::atoi(e);
-#endif
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.precision == 64 ? launch_typed<double>(p, a, s) : launch_typed<_Float16>(p, a, s);
 }

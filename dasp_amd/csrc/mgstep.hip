@@ -240,10 +240,6 @@ __global__ __launch_bounds__(256, 6) void dasp_mg_step2_kernel(DevArgs a, MgPush
     int wg = blockIdx.x;
     if (wg < c.n_push) { mg_push_part(push, wg, c.n_push); return; }
     wg -= c.n_push;
-#ifdef DASP_EXPERIMENT
-    if (c.fence_mode == 99) { plain_wg<double, NT, true, true, 3>(a, wg, wave, lane, nullptr); return; }          // no tables at all: the plan's own order
-    if (c.fence_mode == 98) { plain_wg<double, NT, true, true, 3>(a, wg, wave, lane, c.blk_order); return; }      // the block order table only
-#endif
     if (c.n_poll == 0) {
         // every workgroup of the list where it stands; the marked ones [n_free, n_free + n_marked) wait for the peers' slices by themselves
         if (wg >= c.n_free && wg < c.n_free + c.n_marked) {
@@ -291,9 +287,6 @@ int launch_mg_step(Plan &own, Plan *other, const void *x_own, const void *x_gath
     c.ready = reinterpret_cast<unsigned long long *>(w + kMgWordReady); c.step = h.step; c.err = h.err ? static_cast<int *>(h.err) : reinterpret_cast<int *>(w + kMgWordErr);
     c.grid_a = a.wg_long + a.wg_med + a.wg_short;
     c.grid_b = other ? b.wg_long + b.wg_med + b.wg_short : 0;
-#ifdef DASP_EXPERIMENT      // breakdown of the step kernel (tools/mg_step_probe.py): the own-column part alone, inside the step kernel
-    if (const char *e = std::getenv("DASP_MG_STEP_NOOTHER")) if (std::atoi(e)) { c.grid_b = 0; other = nullptr; }
-#endif
     c.n_poll = std::min(c.grid_b, std::max(1, h.max_pollers));
     c.poll_at = std::max(0, std::min(c.grid_a, (int)((double)c.grid_a * h.poll_at)));
     c.xcd_fenced = reinterpret_cast<unsigned long long *>(w + kMgWordXcd);
@@ -354,11 +347,6 @@ int launch_mg_step2(Plan &plan, const void *x, void *y, const MgStep2Ctl &h, con
     c.arrived = static_cast<const unsigned long long *>(h.arrived); c.world = h.world; c.rank = h.rank; c.need = h.need;
     c.err = static_cast<int *>(h.err); c.timeout = h.timeout_ticks; c.sleep = std::max(1, h.poll_sleep);
     c.fence_mode = h.fence_mode; c.xcd_fenced = static_cast<unsigned long long *>(h.xcd_fenced); c.step = h.step;
-#ifdef DASP_EXPERIMENT      // breakdown of the one-stream step (tools/mg_step_probe.py): without the head workgroups' stores / without the wait
-    if (const char *e = std::getenv("DASP_MG_STEP2_NOPUSH")) if (std::atoi(e)) { c.n_push = 0; c.need = 0; }
-    if (const char *e = std::getenv("DASP_MG_STEP2_FENCE")) c.fence_mode = std::atoi(e);
-    if (const char *e = std::getenv("DASP_MG_STEP2_ALLFREE")) if (std::atoi(e)) { c.n_free = c.n_total; c.n_marked = 0; c.n_poll = 0; c.need = 0; }      // every workgroup at once, in list order
-#endif
     if (c.n_total != a.wg_long + a.wg_med + a.wg_short || c.n_free + c.n_marked > c.n_total) { set_error("one-stream step: the workgroup list does not match the plan's grid"); return DASP_ERR_STATE; }
     // in-place mode with no marked workgroup at all (a rank without boundary rows): ONE extra workgroup still waits for every peer, so that
     // no rank can run two steps ahead of another

@@ -147,14 +147,6 @@ struct XGlobal {
     const T *x;
     __device__ __forceinline__ T at(int c) const { return x[c < 0 ? 0 : c]; }       // pads read x[0], dropped below
 };
-#ifdef DASP_EXPERIMENT
-// experiment (dasp_spmv_persist_kernel): x from global memory, the block's 16 results into the wave's LDS slot instead of y
-template <class T>
-struct XGlobalY {
-    const T *x; T *ybuf;
-    __device__ __forceinline__ T at(int c) const { return x[c < 0 ? 0 : c]; }
-};
-#endif
 template <class T>
 struct XLds {
     const T *xw; int cmin;
@@ -497,32 +489,10 @@ __device__ __forceinline__ void put_y(const DevArgs &a, int yi, P v)
     // coherence point), and -- unlike ANY atomic store or inline asm in the kernel -- it leaves the compiler free to fetch the row
     // tables and per-chunk bases with scalar loads (with an atomic store the own-column product of a slice runs 92 instead of 61 us)
     if constexpr (YS == 1) *(volatile T *)y = (T)v;
-#ifdef DASP_EXPERIMENT      // store-policy experiment (dasp_spmv_kt_kernel only: its tables do not depend on the compiler's alias analysis)
-    else if constexpr (YS == 3 && sizeof(T) == 8) {
-        const T w = (T)v;
-        switch (a.ymode) {
-            case 10: asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(y), "v"(w) : "memory"); break;
-            case 11: asm volatile("global_store_dwordx2 %0, %1, off sc0" : : "v"(y), "v"(w) : "memory"); break;
-            case 12: asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(y), "v"(w) : "memory"); break;
-            case 13: asm volatile("global_store_dwordx2 %0, %1, off nt" : : "v"(y), "v"(w) : "memory"); break;
-            case 14: asm volatile("global_store_dwordx2 %0, %1, off sc1 nt" : : "v"(y), "v"(w) : "memory"); break;
-            case 15: asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1 nt" : : "v"(y), "v"(w) : "memory"); break;
-            case 16: asm volatile("global_store_dwordx2 %0, %1, off sc0 nt" : : "v"(y), "v"(w) : "memory"); break;
-            case 3: break;
-            default: *y = w; break;
-        }
-    }
-#endif
     else if constexpr (YS == 2) {
         const T old = *(volatile T *)y;
         *(volatile T *)y = (T)((P)old + v);
     }
-#ifdef DASP_EXPERIMENT      // placement experiments only (tools/placement_cure_probe.py): how y is stored, switchable per launch
-    else if (a.ymode == 1) __builtin_nontemporal_store((T)v, y);
-    else if (a.ymode == 2) *(volatile T *)y = (T)v;
-    else if (a.ymode == 3) { if (v == (P)1.2345e300) *y = (T)v; }                                  // no store at all (the compiler cannot drop the sum)
-    else if (a.ymode == 4) static_cast<T *>(a.y)[yi & 511] = (T)v;                                 // every store into one 4-KiB window: stays in the L2s, (almost) no DRAM write
-#endif
     else if (a.acc) *y = (T)((P)*y + v);
     // written through (sc0 sc1) where the plan streams from HBM (DevArgs::ywt, f64): the y lines then leave the XCD's L2 at once instead of as
     // dirty evictions under the read stream.  Same-device A/B on three boxes (profiles/r04_placement.md): HV15R 0.4750 -> 0.4590, 0.4597 ->
@@ -583,9 +553,6 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     if (diag_of(acc, lane, d) && r < a.row_block) {
         const int slot = a.row_long + r;                 // row_long here = slot of the first MFMA medium row (Plan::med_slot0)
         const int yi = YM == 2 ? a.med_dst[r] : (a.order ? a.order[slot] : slot);
-#ifdef DASP_EXPERIMENT
-        if constexpr (YS == 5) x.ybuf[lane & 15] = (T)d; else
-#endif
         put_y<T, YS>(a, yi, d);
     }
 }

@@ -119,10 +119,6 @@ static int upload_plan_impl(Plan &p)
     if (natural && !p.dst_map.empty()) { ord_mapped.resize(p.order.size()); for (size_t i = 0; i < p.order.size(); ++i) ord_mapped[i] = p.dst_map[(size_t)p.order[i]]; }
     const size_t o_ord = add(natural ? (ord_mapped.empty() ? p.order.data() : ord_mapped.data()) : nullptr, natural ? p.order.size() * 4 : 0);
 
-#ifdef DASP_EXPERIMENT_HOST      // placement experiment: room for a y (and an x) INSIDE the plan's allocation, behind the arrays (tools/y_in_arena_probe.py)
-    d->exp_y_off = total; total += ((size_t)p.m * p.geo.vbytes + 4095) & ~size_t(4095);
-    d->exp_x_off = total; total += ((size_t)(p.opt.n_parts > 0 ? (size_t)p.opt.n_parts * p.opt.part_stride : (size_t)p.n) * p.geo.vbytes + 4095) & ~size_t(4095);
-#endif
     HIP_TRY(hipMalloc(&d->arena, total));
     d->arena_bytes = total;
     if (std::getenv("DASP_VERBOSE")) std::fprintf(stderr, "[dasp upload] arena %p + %zu bytes\n", d->arena, total);

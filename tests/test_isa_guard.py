@@ -1,0 +1,123 @@
+"""Performance cliffs that DESIGN.md states in terms of the compiled code, turned into a guard: the invariants
+below were found by reading listings by hand; an innocent edit (a fence, an atomic, a wave barrier in the wrong place) or a compiler bump flips
+them without any test noticing -- HV15R-unstructured in two forced panels 0.555 -> 0.884 ms when __builtin_amdgcn_wave_barrier() sits in
+row_tile (302 -> 119 s_load), the own-column product of an 8-way HV15R slice 61 -> 92 us with an atomic store in put_y.
+
+Compile-only: reads the gfx950 code objects inside dasp_amd/csrc/build/*.o (tools/isa_report.py: metadata note + disassembly), no GPU."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def isa():
+    import __graft_entry__ as g
+    g.build()                                                   # the objects of THIS tree (no-op when they are up to date)
+    spec = importlib.util.spec_from_file_location("isa_report", os.path.join(ROOT, "tools", "isa_report.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rows = m.report()
+    assert len(rows) >= 40, sorted(rows)
+    return rows
+
+
+PLAIN64 = ["dasp_spmv_kernel<double,%d,%d,0,%d>" % (nt, c16, c8) for nt in (0, 1) for c16, c8 in ((0, 0), (1, 0), (1, 1))]
+PLAIN16 = ["dasp_spmv_kernel<half,%d,%d,0,0>" % (nt, c16) for nt in (0, 1) for c16 in (0, 1)]
+RT64 = ["dasp_spmv_rt_kernel<double,%d,%d>" % (nt, c16) for nt in (0, 1) for c16 in (0, 1)]
+RT16 = ["dasp_spmv_rt_kernel<half,%d,%d>" % (nt, c16) for nt in (0, 1) for c16 in (0, 1)]
+WIN = ["dasp_spmv_kernel<%s,%d,%d,1,0>" % (t, nt, c16) for t in ("double", "half") for nt in (0, 1) for c16 in (0, 1)]
+WIN1 = ["dasp_spmv_win1_kernel<%s,%d>" % (t, c16) for t in ("double", "half") for c16 in (0, 1)]
+STEP = ["dasp_mg_step_kernel<0>", "dasp_mg_step_kernel<1>", "dasp_mg_step2_kernel<0>", "dasp_mg_step2_kernel<1>"]
+
+
+def test_every_kernel_of_the_hot_path_is_there(isa):
+    for k in PLAIN64 + PLAIN16 + RT64 + RT16 + WIN + WIN1 + STEP + ["dasp_long_reduce_kernel<double>", "dasp_long_reduce_kernel<half>",
+                                                                    "dasp_panel_sum_kernel<double,2>", "dasp_panel_sum_kernel<half,8>"]:
+        assert k in isa, k
+    # the MFMA kernels issue MFMAs, and agree on wave64 geometry: 4 waves of 64 (256) or a window workgroup (1024)
+    for k in PLAIN64 + PLAIN16 + RT64 + RT16 + WIN + WIN1 + STEP:
+        assert isa[k]["mfma"] > 0 and isa[k].get("agpr_count", 0) == 0, (k, isa[k])      # -amdgpu-mfma-vgpr-form: accumulators stay in VGPRs
+
+
+def test_plain_kernels_have_no_scratch_and_keep_their_occupancy(isa):
+    """DESIGN.md 4.4 / kernels.hip: the non-windowed kernels never spill; f64 <= 80 VGPRs (6 waves per SIMD), f16 <= 72 (7 waves; the row-tile
+    build is held there by its launch bound)"""
+    for k in PLAIN64 + RT64:
+        r = isa[k]
+        assert r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0 and r["scratch"] == 0, (k, r)
+        assert r["vgpr_count"] <= 80, (k, r["vgpr_count"])
+    for k in PLAIN16 + RT16:
+        r = isa[k]
+        assert r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0 and r["scratch"] == 0, (k, r)
+        assert r["vgpr_count"] <= 72, (k, r["vgpr_count"])
+
+
+def test_row_tables_stay_scalar_loads(isa):
+    """spmv_device.hpp tab<> / row_tile / put_y: the per-block tables (med_ptr, med_base per chunk, med_c8ptr, piece_ptr ...) are fetched with
+    s_load.  With a fence, a wave barrier or an atomic anywhere in the function the compiler turns every one of them into a vector load:
+    the 16-bit-id f64 kernels then drop from ~300 to ~120 s_load instructions (and HV15R-class matrices lose a third of their speed)."""
+    for k in PLAIN64 + RT64:
+        c16 = k.split(",")[2][0] == "1"
+        assert isa[k]["s_load"] >= (280 if c16 else 100), (k, isa[k]["s_load"])
+    # the row-tile build must not lose scalar loads against the kernel without tiles (the f64 panel kernel is the one the cliff was found on)
+    for nt in (0, 1):
+        for c16 in (0, 1):
+            assert isa["dasp_spmv_rt_kernel<double,%d,%d>" % (nt, c16)]["s_load"] >= isa["dasp_spmv_kernel<double,%d,%d,0,0>" % (nt, c16)]["s_load"]
+            assert isa["dasp_spmv_rt_kernel<half,%d,%d>" % (nt, c16)]["s_load"] >= isa["dasp_spmv_kernel<half,%d,%d,0,0>" % (nt, c16)]["s_load"] - 8
+    for k in PLAIN16 + RT16:
+        assert isa[k]["s_load"] >= 100, (k, isa[k]["s_load"])
+    # the multi-GPU step kernels wait on flags in memory; their tables go through the constant address space (tab<true>) and must stay scalar
+    assert isa["dasp_mg_step_kernel<1>"]["s_load"] >= 200 and isa["dasp_mg_step2_kernel<1>"]["s_load"] >= 700, [isa[k]["s_load"] for k in STEP]
+
+
+def test_windowed_kernels_keep_their_register_cap_and_known_scratch(isa):
+    """the windowed kernel is held to 64 VGPRs so that two 1024-thread window workgroups share a CU (12.9 vs 15.0 us on cop20k_A); what that
+    costs in scratch is an accepted, recorded figure -- growth is a regression.  The one-window-per-CU build (win1) has no cap and no scratch."""
+    accepted = {"dasp_spmv_kernel<double,0,0,1,0>": 60, "dasp_spmv_kernel<double,0,1,1,0>": 68, "dasp_spmv_kernel<half,0,0,1,0>": 12, "dasp_spmv_kernel<half,0,1,1,0>": 0}
+    for k in WIN:
+        r = isa[k]
+        assert r["vgpr_count"] <= 64, (k, r["vgpr_count"])
+        assert r["private_segment_fixed_size"] <= accepted[k.replace(",1,", ",0,", 1) if k.split(",")[1] == "1" else k], (k, r["private_segment_fixed_size"])
+        assert r["s_barrier"] == 1 and r["ds"] > 0                                          # ONE barrier: behind the x copy
+    for k in WIN1:
+        r = isa[k]
+        assert r["private_segment_fixed_size"] == 0 and r["vgpr_count"] <= 128 and r["s_barrier"] == 1, (k, r)
+
+
+def test_step_kernels_fit_their_occupancy(isa):
+    """mgstep.hip: <= 80 VGPRs (6 waves per SIMD; 83-85 with the wave-segmented short rows compiled in, which is why they are not), no scratch"""
+    for k in STEP:
+        r = isa[k]
+        assert r["vgpr_count"] <= 80 and r["private_segment_fixed_size"] == 0 and r["scratch"] == 0, (k, r)
+
+
+def test_row_tile_lds_ops_are_in_program_order(isa):
+    """ADVICE r4 (spmv_device.hpp row_tile): lane i parks products in LDS, other lanes sum them, with NO fence / wave barrier between (either costs
+    the scalar loads above).  Correct because one wave's LDS operations execute in issue order -- as long as the compiler emits every ds_write of
+    the store loop BEFORE the first ds_read of the sum loop.  Checked on the listing: in the tile section of every row-tile kernel the writes
+    precede the reads."""
+    import re
+    import subprocess
+    import tempfile
+    spec = importlib.util.spec_from_file_location("isa_report", os.path.join(ROOT, "tools", "isa_report.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    with tempfile.TemporaryDirectory() as work:
+        co = m.code_object(os.path.join(ROOT, "dasp_amd", "csrc", "build", "kernels.o"), work)
+        txt = subprocess.run([os.path.join(m.LLVM, "llvm-objdump"), "-d", co], capture_output=True, text=True, check=True).stdout
+    seen = 0
+    for sec in re.split(r"\n(?=[0-9a-f]+ <)", txt):
+        head = sec.split("\n", 1)[0]
+        if "dasp_spmv_rt_kernel" not in head:
+            continue
+        ops = [(i, l) for i, l in enumerate(sec.splitlines()) if re.search(r"\tds_(write|read|store|load)", l)]
+        writes = [i for i, l in ops if re.search(r"ds_(write|store)", l)]
+        reads = [i for i, l in ops if re.search(r"ds_(read|load)", l)]
+        assert writes and reads, head
+        # the store loop is unrolled by 4 (+ remainder): every write of the LAST store-loop body lies before the first read
+        assert max(writes) < min(reads), (head, writes, reads)
+        seen += 1
+    assert seen == 8

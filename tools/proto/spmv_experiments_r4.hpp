@@ -1,3 +1,6 @@
+// MOVED OUT OF THE PRODUCT TREE in r5: the r4 experiment kernels, kept as a record of what profiles/experiments_r1_r3.md and
+// profiles/r04_*.md measured.  They were compiled into kernels.hip under -DDASP_EXPERIMENT together with switchable store policies inside put_y
+// (DevArgs::ymode); those hooks no longer exist in dasp_amd/csrc -- to rebuild an experiment, check out revision 056d623 (tools/build_rev.sh).
 // Kernels of the experiment build (-DDASP_EXPERIMENT, tools/build_variant.sh) -- never part of the product library.  All of them are the
 // non-windowed f64 16-bit-id kernel with its tables read through the CONSTANT address space (YS = 3 / 5), so that assembly stores and
 // atomics do not turn the table reads into vector loads.  Results: profiles/r04_placement.md (store policies) and
