@@ -128,7 +128,8 @@ def driver_line(out):
 def emit(out):
     """full record -> bench_suite.json (+ gpurun_out/ when that exists: it travels back from a gpurun box); compact line -> stdout, LAST"""
     full = json.dumps(out, indent=1)
-    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+    dirs = os.environ.get("DASP_BENCH_RECORD_DIRS")           # (tests point this somewhere else)
+    for d in (dirs.split(os.pathsep) if dirs else (ROOT, os.path.join(ROOT, "gpurun_out"))):
         if os.path.isdir(d):
             try:
                 with open(os.path.join(d, "bench_suite.json"), "w") as f:

@@ -76,7 +76,7 @@ def test_watchdog_ends_a_stuck_rank_with_a_json_error_line():
     import sys
     code = ("import sys, time, argparse; sys.path.insert(0, %r); import bench; "
             "a = argparse.Namespace(gpus=8, steps=3, warmup=1); d = bench.Watchdog(0, 1.0, a); d.kick('RCCL communicator up'); time.sleep(30)" % ROOT)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=dict(os.environ, DASP_BENCH_RECORD_DIRS="/nonexistent"))
     assert r.returncode == 5
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["value"] is None and line["n_gpus"] == 8 and "RCCL communicator up" in line["error"]
@@ -91,7 +91,7 @@ def test_watchdog_keeps_a_complete_headline_record():
     code = ("import sys, time, argparse; sys.path.insert(0, %r); import bench; "
             "a = argparse.Namespace(gpus=1, steps=3, warmup=1); d = bench.Watchdog(0, 1.0, a); "
             "d.partial = {'metric': 'SpMV GFLOP/s (f64)', 'value': 1234.5, 'n_gpus': 1}; d.kick('suite entry x done'); time.sleep(30)" % ROOT)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=dict(os.environ, DASP_BENCH_RECORD_DIRS="/nonexistent"))
     assert r.returncode == 5
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["value"] == 1234.5 and "suite entry x done" in line["error"]
