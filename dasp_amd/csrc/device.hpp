@@ -64,6 +64,12 @@ struct ArenaMap {
 };
 
 struct DevicePlan {
+    // the plan's DevArgs as the kernels read it: a device-resident copy (x / y / acc / ywt unset -- those four travel in the kernarg segment), read
+    // through the constant address space with scalar loads.  A 528-byte by-value block costs a small launch ~0.7 us more than a pointer to it
+    // (tools/micro/launch_floor2.hip: 212 x 1024 threads, 3.8-3.95 vs 3.07-3.14 us per launch).  args_sent = what dargs currently holds:
+    // launch_spmv re-sends the block when `args` was changed behind it (placement trials, the device packers).
+    void *dargs = nullptr;
+    void *args_sent = nullptr;      // host copy, sizeof(DevArgs)
     void *arena = nullptr;
     size_t arena_bytes = 0;
     ArenaMap map{};
@@ -78,6 +84,7 @@ struct DevicePlan {
 
 int require_device();                  // upload.cpp: DASP_OK, or DASP_ERR_NO_DEVICE with the error text set
 int upload_plan(Plan &p);
+int sync_dev_args(Plan &p);            // upload.cpp: DevicePlan::dargs = DevicePlan::args (a memcmp when nothing changed; a blocking copy otherwise -- never inside a stream capture: upload and the placement trials leave it in sync)
 int upload_plan_unpacked(Plan &p);     // for the device packers: arena + O(rows) arrays, no placement trials yet
 // kernels.hip: one SpMV of an uploaded plan (asynchronous); what upload.cpp asks the kernels
 int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate);

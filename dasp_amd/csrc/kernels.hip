@@ -38,18 +38,20 @@
 namespace dasp {
 
 template <class T, bool NT, bool C16, bool WIN, bool C8 = false>
-__global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPlain) void dasp_spmv_kernel(DevArgs a)
+__global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPlain) void dasp_spmv_kernel(CallArgs c)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const DevArgs a = load_args(c);
     spmv_body<T, NT, C16, WIN, C8>(a, lds_raw);
 }
 
 // a column panel with row tiles (Plan::rt_*): the non-windowed kernel + the tiles' workgroup range, dynamic LDS = 4 waves x 64 x rt_max products
 // (f16: held to 72 registers = 7 waves per SIMD like the kernel without tiles -- 75 otherwise; ljournal-2008 0.4522 -> 0.4443 ms)
 template <class T, bool NT, bool C16>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 7 : kMinWavesPlain) void dasp_spmv_rt_kernel(DevArgs a)
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 7 : kMinWavesPlain) void dasp_spmv_rt_kernel(CallArgs c)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const DevArgs a = load_args(c);
     spmv_body<T, NT, C16, false, false, true>(a, lds_raw);
 }
 
@@ -59,16 +61,18 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 7 : kMinWavesPlain) void dasp
 // so that only LDS gathers and MFMAs are left behind it -- cop20k_A 10.4 -> 10.9 us.  What bounds such a workgroup is not its chain
 // of latencies but its CU's memory-level parallelism: ~200 KB per CU through 64 outstanding L1 misses of ~740 cycles)
 template <class T, bool C16>
-__global__ __launch_bounds__(1024, 4) void dasp_spmv_win1_kernel(DevArgs a)
+__global__ __launch_bounds__(1024, 4) void dasp_spmv_win1_kernel(CallArgs c)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    const DevArgs a = load_args(c);
     spmv_body<T, false, C16, true, false>(a, lds_raw);
 }
 
 // stage 2 for long rows cut into several pieces (reference: longPart_sum, dasp_f64.h:53-75)
 template <class T>
-__global__ __launch_bounds__(256) void dasp_long_reduce_kernel(DevArgs a)
+__global__ __launch_bounds__(256) void dasp_long_reduce_kernel(CallArgs c)
 {
+    const DevArgs a = load_args(c);
     using part_t = typename Tr<T>::part_t;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * kWavesPerWG + (threadIdx.x >> 6);
@@ -190,12 +194,14 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
 {
     const int grid = a.wg_long + a.wg_med + a.wg_short + a.wg_rt;
     const bool nt = p.dev->nt;
+    if (int rc = sync_dev_args(p)) return rc;          // (a memcmp: the device copy follows DevicePlan::args)
+    const CallArgs c{static_cast<const DevArgs *>(p.dev->dargs), a.x, a.y, a.acc, a.ywt};
     if (a.wg_rt > 0) {      // a column panel with row tiles (never windowed, never with one-byte ids: plan.cpp build_panels)
         const size_t lds = (size_t)kWavesPerWG * kRowTile * (size_t)a.rt_max * sizeof(typename Tr<T>::part_t);
-        if (nt && p.cid16) hipLaunchKernelGGL((dasp_spmv_rt_kernel<T, true, true>), dim3(grid), dim3(256), lds, s, a);
-        else if (nt) hipLaunchKernelGGL((dasp_spmv_rt_kernel<T, true, false>), dim3(grid), dim3(256), lds, s, a);
-        else if (p.cid16) hipLaunchKernelGGL((dasp_spmv_rt_kernel<T, false, true>), dim3(grid), dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((dasp_spmv_rt_kernel<T, false, false>), dim3(grid), dim3(256), lds, s, a);
+        if (nt && p.cid16) hipLaunchKernelGGL((dasp_spmv_rt_kernel<T, true, true>), dim3(grid), dim3(256), lds, s, c);
+        else if (nt) hipLaunchKernelGGL((dasp_spmv_rt_kernel<T, true, false>), dim3(grid), dim3(256), lds, s, c);
+        else if (p.cid16) hipLaunchKernelGGL((dasp_spmv_rt_kernel<T, false, true>), dim3(grid), dim3(256), lds, s, c);
+        else hipLaunchKernelGGL((dasp_spmv_rt_kernel<T, false, false>), dim3(grid), dim3(256), lds, s, c);
     } else if (grid > 0) {
         const size_t lds = p.windowed ? (size_t)p.lds_bytes : 0;
         const bool c16 = p.cid16;
@@ -204,20 +210,20 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
         else if (nt && p.windowed) { M(true, false, true); } else if (nt) { M(true, false, false); } \
         else if (c16 && p.windowed) { M(false, true, true); } else if (c16) { M(false, true, false); } \
         else if (p.windowed) { M(false, false, true); } else { M(false, false, false); }
-#define DASP_LAUNCH(NTV, CV, WINV) hipLaunchKernelGGL((dasp_spmv_kernel<T, NTV, CV, WINV>), dim3(grid), dim3(kWave * a.wpw), lds, s, a)
+#define DASP_LAUNCH(NTV, CV, WINV) hipLaunchKernelGGL((dasp_spmv_kernel<T, NTV, CV, WINV>), dim3(grid), dim3(kWave * a.wpw), lds, s, c)
         if (p.windowed && p.dev->win1 && !nt) {                             // at most one window workgroup per CU: the 128-register build
-            if (c16) hipLaunchKernelGGL((dasp_spmv_win1_kernel<T, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, a);
-            else hipLaunchKernelGGL((dasp_spmv_win1_kernel<T, false>), dim3(grid), dim3(kWave * a.wpw), lds, s, a);
+            if (c16) hipLaunchKernelGGL((dasp_spmv_win1_kernel<T, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
+            else hipLaunchKernelGGL((dasp_spmv_win1_kernel<T, false>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
         } else if (sizeof(T) == 8 && c16 && !p.windowed && p.cnt_reg8 > 0) {      // plans with one-byte ids: their own instantiation
-            if (nt) hipLaunchKernelGGL((dasp_spmv_kernel<double, true, true, false, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, a);
-            else hipLaunchKernelGGL((dasp_spmv_kernel<double, false, true, false, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, a);
+            if (nt) hipLaunchKernelGGL((dasp_spmv_kernel<double, true, true, false, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
+            else hipLaunchKernelGGL((dasp_spmv_kernel<double, false, true, false, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
         } else
         DASP_FOR_EACH(DASP_LAUNCH)
 #undef DASP_LAUNCH
 #undef DASP_FOR_EACH
     }
     if (a.n_multi > 0)
-        hipLaunchKernelGGL((dasp_long_reduce_kernel<T>), dim3((a.n_multi + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((dasp_long_reduce_kernel<T>), dim3((a.n_multi + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, s, c);
     HIP_TRY(hipGetLastError());
     return DASP_OK;
 }

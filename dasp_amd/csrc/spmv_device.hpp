@@ -92,6 +92,37 @@ __device__ __forceinline__ U tab(const U *p, int i)
     else return p[i];
 }
 
+// The kernels' arguments: the plan's DevArgs lives on the device (DevicePlan::dargs) and is read word by word through the constant address space --
+// scalar loads the compiler sinks to their uses and drops where a field is unused, exactly as it treats a by-value kernarg block -- and the four
+// per-call values travel in the kernarg segment (device.hpp: ~0.7 us per small launch against the 528-byte by-value block).
+struct CallArgs { const DevArgs *plan; const void *x; void *y; int acc, ywt; };
+// a pointer field of the device-resident block, loaded AS a global pointer (address space 1) through the constant address space: a pointer that arrives in
+// the kernarg segment is known to be global, one loaded from memory as a generic pointer is flat (flat_load instead of global_load, and no scalar
+// loads through it -- the plain f64 kernels fell from 302 to 19 s_load that way)
+template <class U> __device__ __forceinline__ U *ldp(U *const *field)
+{
+    typedef __attribute__((address_space(1))) U *gptr;
+    return (U *)*reinterpret_cast<const __attribute__((address_space(4))) gptr *>(reinterpret_cast<uintptr_t>(field));
+}
+__device__ __forceinline__ DevArgs load_args(const CallArgs &c)
+{
+    static_assert(sizeof(DevArgs) % 4 == 0, "DevArgs is a whole number of words");
+    int w[sizeof(DevArgs) / 4];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(DevArgs) / 4); ++i) w[i] = tab<true>(reinterpret_cast<const int *>(c.plan), i);
+    DevArgs a;
+    __builtin_memcpy(&a, w, sizeof a);
+#define DASP_G(f) a.f = ldp(&c.plan->f)
+    DASP_G(long_val); DASP_G(long_cid); DASP_G(piece_ptr); DASP_G(piece_dst); DASP_G(partial); DASP_G(multi_ptr); DASP_G(multi_dst);
+    DASP_G(med_ptr); DASP_G(med_val); DASP_G(med_cid); DASP_G(med_cid16); DASP_G(med_base); DASP_G(med_cid8); DASP_G(med_c8ptr);
+    DASP_G(irr_ptr); DASP_G(irr_val); DASP_G(irr_cid); DASP_G(med_dst); DASP_G(win_cmin); DASP_G(win_len);
+    DASP_G(short_val); DASP_G(short_cid); DASP_G(groups); DASP_G(order);
+    DASP_G(rt_val); DASP_G(rt_cid); DASP_G(rt_ptr); DASP_G(rt_start); DASP_G(rt_mask);
+#undef DASP_G
+    a.x = c.x; a.y = c.y; a.acc = c.acc; a.ywt = c.ywt;
+    return a;
+}
+
 __device__ __forceinline__ int slot_of(const SlotMap &m, int t)
 {
     const int p = t < m.split ? 0 : 1;
@@ -808,8 +839,13 @@ __device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw)
                 // XCD gathers from ALL of x (nlpkkt160: 8 x 67 MB of x through the L2s against 2.4 GB of matrix).  Rows of equal length
                 // keep their row order in the sort, so a contiguous range of blocks is a contiguous part of the mesh: XCD k takes the
                 // k-th eighth of the blocks (eighths of equal work) and touches an eighth of x plus the halo.
-                const int k = m & 7, b = a.xcd_blk[k] + (m >> 3) * kWavesPerWG + wave;
-                if (b < a.xcd_blk[k + 1]) medium_block<T, NT, C16, 0, C8>(a, b, lane, x);
+                // (constant indices + scalar selects instead of xcd_blk[k]: a run-time index into DevArgs would pin the whole block in scratch, load_args)
+                const int k = m & 7;
+                int lo = a.xcd_blk[0], hi = a.xcd_blk[1];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) { lo = k == i ? a.xcd_blk[i] : lo; hi = k == i ? a.xcd_blk[i + 1] : hi; }
+                const int b = lo + (m >> 3) * kWavesPerWG + wave;
+                if (b < hi) medium_block<T, NT, C16, 0, C8>(a, b, lane, x);
             } else if (sizeof(T) == 8 && !a.med_stride) {
                 // f64: the medium range is never capped (upload_plan), one block per wave -- no loop
                 const int b = m * kWavesPerWG + wave;

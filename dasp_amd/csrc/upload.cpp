@@ -31,6 +31,8 @@ Plan::~Plan()
 {
     if (dev) {
         if (dev->arena) (void)hipFree(dev->arena);
+        if (dev->dargs) (void)hipFree(dev->dargs);
+        std::free(dev->args_sent);
         delete dev;
     }
 }
@@ -46,13 +48,25 @@ int require_device()
     return DASP_OK;
 }
 
+int sync_dev_args(Plan &p)
+{
+    DevicePlan *d = p.dev;
+    if (!d) { set_error("plan not uploaded"); return DASP_ERR_STATE; }
+    if (d->dargs && d->args_sent && std::memcmp(d->args_sent, &d->args, sizeof(DevArgs)) == 0) return DASP_OK;
+    if (!d->dargs) HIP_TRY(hipMalloc(&d->dargs, (sizeof(DevArgs) + 255) & ~size_t(255)));
+    if (!d->args_sent) { d->args_sent = std::malloc(sizeof(DevArgs)); if (!d->args_sent) { set_error("out of host memory"); return DASP_ERR_NOMEM; } }
+    HIP_TRY(hipMemcpy(d->dargs, &d->args, sizeof(DevArgs), hipMemcpyHostToDevice));
+    std::memcpy(d->args_sent, &d->args, sizeof(DevArgs));
+    return DASP_OK;
+}
+
 int upload_plan(Plan &p);
 static int upload_plan_impl(Plan &p)
 {
     if (int rc = require_device()) return rc;
     if (p.host_dropped && p.dev) return DASP_OK;   // already on the device (packed there, or host copies released)
     if (p.host_dropped) { set_error("host arrays were dropped"); return DASP_ERR_STATE; }
-    if (p.dev) { if (p.dev->arena) (void)hipFree(p.dev->arena); delete p.dev; p.dev = nullptr; }
+    if (p.dev) { if (p.dev->arena) (void)hipFree(p.dev->arena); if (p.dev->dargs) (void)hipFree(p.dev->dargs); std::free(p.dev->args_sent); delete p.dev; p.dev = nullptr; }
     auto *d = new DevicePlan();
     p.dev = d;
     HIP_TRY(hipGetDevice(&d->device));
@@ -223,7 +237,7 @@ static int upload_plan_impl(Plan &p)
         // windows would lower the limit under an earlier one with wider windows
         if (int rc = spmv_kernel_allow_full_lds(p.precision, p.cid16)) return rc;
     }
-    return DASP_OK;
+    return sync_dev_args(p);
 }
 
 

@@ -61,14 +61,21 @@ def test_row_tables_stay_scalar_loads(isa):
     the 16-bit-id f64 kernels then drop from ~300 to ~120 s_load instructions (and HV15R-class matrices lose a third of their speed)."""
     for k in PLAIN64 + RT64:
         c16 = k.split(",")[2][0] == "1"
-        assert isa[k]["s_load"] >= (280 if c16 else 100), (k, isa[k]["s_load"])
+        # (r5: the plan's arguments come from a device-resident block loaded once, not from kernarg fields re-read at every use -- ~85 fewer s_load
+        # than the by-value builds of r4: 302 -> 217 / 116 -> 31.  What is left in a 16-bit-id build are the per-chunk table loads the cliff is about.)
+        assert isa[k]["s_load"] >= (200 if c16 else 25), (k, isa[k]["s_load"])
     # the row-tile build must not lose scalar loads against the kernel without tiles (the f64 panel kernel is the one the cliff was found on)
     for nt in (0, 1):
         for c16 in (0, 1):
             assert isa["dasp_spmv_rt_kernel<double,%d,%d>" % (nt, c16)]["s_load"] >= isa["dasp_spmv_kernel<double,%d,%d,0,0>" % (nt, c16)]["s_load"]
             assert isa["dasp_spmv_rt_kernel<half,%d,%d>" % (nt, c16)]["s_load"] >= isa["dasp_spmv_kernel<half,%d,%d,0,0>" % (nt, c16)]["s_load"] - 8
     for k in PLAIN16 + RT16:
-        assert isa[k]["s_load"] >= 100, (k, isa[k]["s_load"])
+        assert isa[k]["s_load"] >= 25, (k, isa[k]["s_load"])
+    # pointers of the device-resident argument block must be known to be GLOBAL (ldp in load_args): as flat pointers every table and tile load becomes
+    # flat_load and none of them scalar (f64 16-bit-id kernel: 1056 global_load + 20 flat stores -> 297 + 972)
+    for k in PLAIN64 + RT64 + PLAIN16 + RT16 + WIN + WIN1:
+        assert isa[k]["flat"] <= 80 and isa[k]["global_load"] >= 400, (k, isa[k]["flat"], isa[k]["global_load"])
+        assert isa[k]["kernarg_segment_size"] <= 64, (k, isa[k]["kernarg_segment_size"])
     # the multi-GPU step kernels wait on flags in memory; their tables go through the constant address space (tab<true>) and must stay scalar
     assert isa["dasp_mg_step_kernel<1>"]["s_load"] >= 200 and isa["dasp_mg_step2_kernel<1>"]["s_load"] >= 700, [isa[k]["s_load"] for k in STEP]
 
@@ -76,7 +83,7 @@ def test_row_tables_stay_scalar_loads(isa):
 def test_windowed_kernels_keep_their_register_cap_and_known_scratch(isa):
     """the windowed kernel is held to 64 VGPRs so that two 1024-thread window workgroups share a CU (12.9 vs 15.0 us on cop20k_A); what that
     costs in scratch is an accepted, recorded figure -- growth is a regression.  The one-window-per-CU build (win1) has no cap and no scratch."""
-    accepted = {"dasp_spmv_kernel<double,0,0,1,0>": 60, "dasp_spmv_kernel<double,0,1,1,0>": 68, "dasp_spmv_kernel<half,0,0,1,0>": 12, "dasp_spmv_kernel<half,0,1,1,0>": 0}
+    accepted = {"dasp_spmv_kernel<double,0,0,1,0>": 60, "dasp_spmv_kernel<double,0,1,1,0>": 40, "dasp_spmv_kernel<half,0,0,1,0>": 12, "dasp_spmv_kernel<half,0,1,1,0>": 0}
     for k in WIN:
         r = isa[k]
         assert r["vgpr_count"] <= 64, (k, r["vgpr_count"])
