@@ -222,7 +222,8 @@ static long long host_array_impl(const dasp_plan_t *plan, const char *name, cons
     const Plan &p = plan->impl;
     // the nnz-sized arrays exist on the host only until dasp_plan_drop_host (never, for a plan packed on the device);
     // the O(rows) arrays and order_rid always do
-    static const char *const kBulk[] = {"long_val", "long_cid", "med_val", "med_cid", "med_cid16", "med_cid8", "irr_val", "irr_cid", "short_val", "short_cid", "rt_val", "rt_cid"};
+    static const char *const kBulk[] = {"long_val", "long_cid", "med_val", "med_cid", "med_cid16", "med_cid8", "irr_val", "irr_cid", "short_val", "short_cid", "rt_val", "rt_cid",
+                                        "tp_val", "tp_lrow", "tp_lcol", "tp_dst"};
     if (p.host_dropped)
         for (const char *b : kBulk)
             if (std::strcmp(name, b) == 0) { set_error("host copy of this array was dropped (use dasp_plan_download_array)"); return DASP_ERR_STATE; }
@@ -263,6 +264,13 @@ static long long host_array_impl(const dasp_plan_t *plan, const char *name, cons
     if (n == "rt_ptr") return ints(p.rt_ptr);
     if (n == "rt_start") { *ptr = p.rt_start.data(); *elem_bytes = 2; return (long long)p.rt_start.size(); }
     if (n == "rt_mask") { *ptr = p.rt_mask.data(); *elem_bytes = 8; return (long long)p.rt_mask.size(); }
+    if (n == "tp_rb_row0") return ints(p.tp.rb_row0);
+    if (n == "tp_rb_seg0") return ints(p.tp.rb_seg0);
+    if (n == "tp_unit") return ints(p.tp.unit);
+    if (n == "tp_dst") return ints(p.tp.dst);
+    if (n == "tp_val") return vals(p.tp.val);
+    if (n == "tp_lrow") { *ptr = p.tp.lrow.data(); *elem_bytes = 2; return (long long)p.tp.lrow.size(); }
+    if (n == "tp_lcol") { *ptr = p.tp.lcol.data(); *elem_bytes = 2; return (long long)p.tp.lcol.size(); }
     if (n == "short_groups") {   // kNumShortGroups x {len,count,tiles,tile0,elem_off_lo,elem_off_hi,split,base0,base1,grp0,grp1,off0,off1,seg,rpt}
         static thread_local std::vector<int> flat;
         flat.clear();
@@ -300,6 +308,7 @@ int dasp_plan_drop_host(dasp_plan_t *plan)
     auto dropi = [](raw_vector<int> &v) { raw_vector<int>().swap(v); };
     dropc(p.long_val); dropi(p.long_cid); dropc(p.med_val); dropi(p.med_cid); raw_vector<uint16_t>().swap(p.med_cid16); raw_vector<uint8_t>().swap(p.med_cid8);
     dropc(p.irr_val); dropi(p.irr_cid); dropc(p.short_val); dropi(p.short_cid); dropc(p.rt_val); dropi(p.rt_cid);
+    dropc(p.tp.val); raw_vector<uint16_t>().swap(p.tp.lrow); raw_vector<uint16_t>().swap(p.tp.lcol); std::vector<int>().swap(p.tp.dst);
     p.host_dropped = true;
     for (auto &h : p.panels) if (int rc = dasp_plan_drop_host(h.get())) return rc;
     return DASP_OK;

@@ -57,6 +57,15 @@ struct DevArgs {
     int n_rt_tiles, wg_rt, rt_max;
 };
 
+// two-phase form (plan.hpp struct TwoPhase): what its two kernels read.  All device pointers into the plan's arena; xs is the stream phase 1
+// writes and phase 2 reads (one x value per stored element)
+struct TpDev {
+    const unsigned short *lcol; const int *dst; const int *unit;
+    const void *val; const unsigned short *lrow; void *xs;
+    const int *rb_row0; const int *rb_seg0;
+    int n_units, n_rb, cb, rb_max, xlen, m;
+};
+
 // byte offsets of the nnz-sized arrays inside the arena (devpack.hip writes them, tests download them)
 struct ArenaMap {
     size_t long_val = 0, long_cid = 0, med_val = 0, med_cid = 0, med_cid16 = 0, med_cid8 = 0, med_base = 0, irr_val = 0, irr_cid = 0,
@@ -74,6 +83,7 @@ struct DevicePlan {
     size_t arena_bytes = 0;
     ArenaMap map{};
     DevArgs args{};
+    TpDev tp{};             // Plan::two_phase: the arena holds the tile streams, `args` is unused
     bool nt = false;
     bool win1 = false;      // windowed plan with at most one window workgroup per CU: launch dasp_spmv_win1_kernel
     int device = -1;
@@ -89,6 +99,7 @@ int upload_plan_unpacked(Plan &p);     // for the device packers: arena + O(rows
 // kernels.hip: one SpMV of an uploaded plan (asynchronous); what upload.cpp asks the kernels
 int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate);
 int spmv_kernel_allow_full_lds(int precision, bool c16);
+int tp_kernels_allow_lds();             // kernels.hip: the two-phase kernels may use up to 160 KiB of dynamic LDS (called at upload)
 int spmv_kernel_f16_resident(bool c16);
 int tune_placement(Plan &p, int trials, const void *dX, void *dY, double *ms_first, double *ms_kept);   // kernels.hip: placement trials of an uploaded, fully packed plan (trials <= 0: default)
 

@@ -655,6 +655,15 @@ int devpack_gather_columns(const Plan &p, const DevCsr &d, const std::vector<lon
 }
 
 int devpack_finish_panels(Plan &p) { return upload_plan(p); }
+// the two-phase form of a device-resident CSR: its tile sort runs on the host for now (preprocessing, not the hot path) -- the column ids and values
+// are copied over once, the plan is packed by build_two_phase and uploaded like any host-built plan
+int devpack_fetch_csr(const Plan &p, const DevCsr &d, int *ci, void *val)
+{
+    if (p.nnz <= 0) return DASP_OK;
+    HIP_TRYP(hipMemcpy(ci, d.ci, (size_t)p.nnz * sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRYP(hipMemcpy(val, d.val, (size_t)p.nnz * (size_t)p.geo.vbytes, hipMemcpyDeviceToHost));
+    return DASP_OK;
+}
 int devpack_current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; } return d; }
 void devpack_use_device(int device) { if (device >= 0) (void)hipSetDevice(device); }
 
@@ -703,6 +712,20 @@ int download_array(Plan &p, const char *name, void *dst, size_t bytes)
     if (!p.dev || !p.dev->arena) { set_error("plan not on the device"); return DASP_ERR_STATE; }
     const ArenaMap &mp = p.dev->map;
     const size_t vb = (size_t)p.geo.vbytes;
+    if (p.two_phase) {      // the tile streams of a two-phase plan (tp_xs: what phase 1 wrote in the last product)
+        const TpDev &q = p.dev->tp;
+        const size_t S = p.tp.segments;
+        struct { const char *n; const void *ptr; size_t len; } tt[] = {
+            {"tp_lcol", q.lcol, S * kTpSeg * 2}, {"tp_dst", q.dst, S * 4}, {"tp_val", q.val, S * kTpSeg * vb}, {"tp_lrow", q.lrow, S * kTpSeg * 2}, {"tp_xs", q.xs, S * kTpSeg * vb}};
+        for (auto &t : tt)
+            if (std::strcmp(t.n, name) == 0) {
+                if (bytes != t.len) { set_error(std::string("size mismatch for ") + name); return DASP_ERR_ARG; }
+                if (t.len) HIP_TRYP(hipMemcpy(dst, t.ptr, t.len, hipMemcpyDeviceToHost));
+                return DASP_OK;
+            }
+        set_error(std::string("unknown device array of a two-phase plan: ") + name);
+        return DASP_ERR_ARG;
+    }
     struct { const char *n; size_t off, len; } tab[] = {
         {"long_val", mp.long_val, p.cnt_long * vb}, {"long_cid", mp.long_cid, p.cnt_long * 4},
         {"med_val", mp.med_val, p.cnt_reg * vb}, {"med_cid", mp.med_cid, p.cid16 ? 0 : p.cnt_reg * 4},

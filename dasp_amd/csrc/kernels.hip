@@ -121,6 +121,81 @@ __global__ __launch_bounds__(256) void dasp_panel_sum_kernel(const T *__restrict
     }
 }
 
+
+// ------------------------------------------------------------------ two-phase (gather-free) form: plan.hpp struct TwoPhase, DESIGN.md section 4.7
+// Phase 1: one workgroup per unit (<= kTpUnitSegs segments of ONE column block, CB-major).  The block's slice of x is staged in LDS with
+// coalesced 16-byte loads; then every lane takes 8 consecutive local column ids (one 16-byte load), reads their x values from LDS and stores
+// them (one 16-byte store) where phase 2 will stream them.  8 lanes = one 128-byte segment; dst[] maps a CB-major segment to its RB-major place.
+typedef unsigned short tp_u16x8 __attribute__((ext_vector_type(8)));
+template <class T>
+__global__ __launch_bounds__(512) void dasp_tp_expand_kernel(TpDev a, const T *__restrict__ x)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    typedef T vec8 __attribute__((ext_vector_type(8)));
+    T *xl = reinterpret_cast<T *>(lds_raw);
+    const int u = blockIdx.x;
+    const int c = a.unit[3 * u], s0 = a.unit[3 * u + 1], s1 = a.unit[3 * u + 2];
+    const int c0 = c * a.cb, len = min(a.cb, a.xlen - c0);
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {          // (c0 is a multiple of 8 elements)
+        for (int i = threadIdx.x * 8; i < len; i += 512 * 8) {
+            if (i + 8 <= len) *reinterpret_cast<vec8 *>(xl + i) = *reinterpret_cast<const vec8 *>(x + c0 + i);
+            else for (int j = i; j < len; ++j) xl[j] = x[c0 + j];
+        }
+    } else for (int i = threadIdx.x; i < len; i += 512) xl[i] = x[c0 + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 3, off = (lane & 7) * 8;
+    T *xs = static_cast<T *>(a.xs);
+#pragma unroll 2
+    for (int g = s0 + wave * 8; g < s1; g += 8 * 8) {
+        const int seg = g + sub;
+        if (seg < s1) {
+            const tp_u16x8 lc = __builtin_nontemporal_load(reinterpret_cast<const tp_u16x8 *>(a.lcol + (size_t)seg * kTpSeg + off));
+            const int d = a.dst[seg];
+            vec8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = xl[lc[j]];
+            *reinterpret_cast<vec8 *>(xs + (size_t)d * kTpSeg + off) = o;
+        }
+    }
+}
+
+// Phase 2: one workgroup per row block.  Its <= rb_max output positions are f64 accumulators in LDS; the block's (value, local row, xs) triples are
+// three contiguous streams read with 16-byte loads; every product (f16 x f16, exact in f32) is added with ds_add_f64 -- on gfx950 LDS f64 atomics
+// run ~4x the rate of f32 ones (profiles/r05_two_phase.md: 0.153 against 0.559 ms for ljournal-2008), and the sum is exact to well below the f16
+// result's rounding.  Then y is stored once, coalesced (acc: y += sum).
+template <class T>
+__global__ __launch_bounds__(512) void dasp_tp_reduce_kernel(TpDev a, T *__restrict__ y, int acc)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    typedef T vec8 __attribute__((ext_vector_type(8)));
+    double *yl = reinterpret_cast<double *>(lds_raw);
+    const int r = blockIdx.x;
+    const int p0 = a.rb_row0[r], rows = a.rb_row0[r + 1] - p0;
+    for (int i = threadIdx.x; i < rows; i += 512) yl[i] = 0.0;
+    __syncthreads();
+    const int s0 = a.rb_seg0[r], s1 = a.rb_seg0[r + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 3, off = (lane & 7) * 8;
+    const T *val = static_cast<const T *>(a.val), *xs = static_cast<const T *>(a.xs);
+#pragma unroll 2
+    for (int g = s0 + wave * 8; g < s1; g += 8 * 8) {
+        const int seg = g + sub;
+        if (seg < s1) {
+            const size_t at = (size_t)seg * kTpSeg + off;
+            const vec8 v = __builtin_nontemporal_load(reinterpret_cast<const vec8 *>(val + at));
+            const tp_u16x8 lr = __builtin_nontemporal_load(reinterpret_cast<const tp_u16x8 *>(a.lrow + at));
+            const vec8 xv = __builtin_nontemporal_load(reinterpret_cast<const vec8 *>(xs + at));
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (lr[j] != kTpPadRow) __hip_atomic_fetch_add(yl + lr[j], (double)((float)v[j] * (float)xv[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    if (acc) { for (int i = threadIdx.x; i < rows; i += 512) y[p0 + i] = (T)((float)y[p0 + i] + (float)yl[i]); }
+    else for (int i = threadIdx.x; i < rows; i += 512) y[p0 + i] = (T)(float)yl[i];
+}
+
 // ------------------------------------------------------------------ MFMA lane-map self test
 __global__ void selftest_f64_kernel(double *D)
 {
@@ -239,10 +314,27 @@ int set_stream_policy(Plan &p, int policy)
     return DASP_OK;
 }
 
+int tp_kernels_allow_lds()
+{
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_tp_expand_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_tp_reduce_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return DASP_OK;
+}
+
 int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate)
 {
     if (!p.dev || !p.dev->arena) { set_error("plan not uploaded"); return DASP_ERR_STATE; }
     if (!dX || !dY) { set_error("null device pointer"); return DASP_ERR_ARG; }
+    if (p.two_phase) {
+        const TpDev &a = p.dev->tp;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        if (a.n_units > 0)
+            hipLaunchKernelGGL((dasp_tp_expand_kernel<_Float16>), dim3(a.n_units), dim3(512), (size_t)a.cb * 2, s, a, static_cast<const _Float16 *>(dX));
+        if (a.n_rb > 0)
+            hipLaunchKernelGGL((dasp_tp_reduce_kernel<_Float16>), dim3(a.n_rb), dim3(512), (size_t)a.rb_max * 8, s, a, static_cast<_Float16 *>(dY), accumulate ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+        return DASP_OK;
+    }
     if (!p.panels.empty()) {
         const size_t vb = (size_t)p.geo.vbytes, stride = p.dev->ypart_stride;
         char *part = static_cast<char *>(p.dev->arena);

@@ -355,6 +355,7 @@ int create_impl(dasp_mg_plan &g, const int *rp, const int *ci, const T *val, con
     if (user) opt = *user; else dasp_options_default(&opt);
     opt.y_order = DASP_Y_NATURAL;              // the padded y slice is what the all-gather sends: un-permute fused into the stores
     opt.short_seg = -1;                        // short rows as slabs: the step kernels are compiled without the wave-segmented path (registers)
+    opt.two_phase = -1;                        // (the two-phase form has no column remap and no accumulate-into-the-step: DASP kernels only)
     opt.n_parts = 0; opt.part_bounds = nullptr; opt.part_stride = 0;
     const int nnz = rp[m];
     if (!g.square) {

@@ -306,6 +306,18 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     if (mode == kTop) {
         const int P = decide_panels(p, rp, ci, remap, dev);
         if (P < 0) return P;
+        if (decide_two_phase(p, rp, P)) {
+            // the two-phase (gather-free) form: order_rid and the classifier counters of the whole matrix (row lengths only), then the tile streams
+            if (int rc = build_impl<T>(p, rp, ci, val, nullptr, kMetaOnly)) return rc;
+            lap("whole-matrix meta");
+            if (!dev) { const int rc = build_two_phase(p, rp, ci, val); lap("two-phase streams"); return rc; }
+            raw_vector<int> hci((size_t)nnz);
+            raw_vector<T> hval((size_t)nnz);
+            if (int rc = devpack_fetch_csr(p, *dev, hci.data(), hval.data())) return rc;
+            if (int rc = build_two_phase(p, rp, hci.data(), hval.data())) return rc;
+            lap("two-phase streams (device CSR fetched)");
+            return devpack_finish_panels(p);       // a device-built plan comes back uploaded
+        }
         if (P >= 2) return build_panels<T>(p, rp, ci, val, P, dev);
     }
     // ---- classifier: same tests in the same order as dasp_f64.h:499-531.  Two passes over row ranges (count, then fill from the

@@ -158,6 +158,36 @@ constexpr int kRowTileAuto64 = 8;    // opt.row_tile_max = 0, f64: 16 KB of LDS 
 constexpr int kRowTileAuto = 16;    // opt.row_tile_max = 0, f16 (tools/row_tile_ab.py: ljournal-2008 f16 0.483 / 0.469 / 0.460 / 0.452 / 0.451 / 0.451 / 0.496 ms at 6 / 8 / 12 / 16 / 20 / 24 / 32, 0.507-0.511 without)
 constexpr int kRowTileMax = 32;     // longest row a tile may take (LDS: 4 waves x 64 x bound products per workgroup)
 
+// ---- two-phase (gather-free) form of a plan: opt.two_phase, f16 (no reference counterpart).
+// Every kernel that gathers x per nonzero pays ~0.8 L1 misses per nonzero on graph matrices whose rows scatter over all of x; here no gather
+// leaves the CU.  The nonzeros are cut into TILES (row block r, column block c): row blocks are ranges of at most rb_max consecutive OUTPUT
+// positions (slots of order_rid, or rows in DASP_Y_NATURAL) holding about the same number of nonzeros, column blocks are ranges of `cb`
+// columns.  A tile's nonzeros keep their CSR order (rows in output order) and are padded to whole SEGMENTS of kTpSeg elements.
+//   phase 1 (dasp_tp_expand_kernel): one workgroup per UNIT (a run of <= kTpUnitSegs segments of one column block, CB-major order): stages
+//       x[c * cb, (c + 1) * cb) in LDS and writes xs[dst[s] * kTpSeg + i] = x[c * cb + lcol[s * kTpSeg + i]]: the x value of every nonzero,
+//       as a stream in RB-major order.
+//   phase 2 (dasp_tp_reduce_kernel): one workgroup per row block: y slice in LDS as f64, streams (val, lrow, xs) -- all contiguous -- and
+//       adds val * xs to position lrow with LDS f64 atomics (ds_add_f64: ~4x the rate of ds_add_f32 on gfx950), then stores y once.
+// Pads: val 0, lrow kTpPadRow (skipped), lcol 0.
+constexpr int kTpSeg = 64;            // elements per segment: 128 bytes of f16 / u16
+constexpr int kTpUnitSegs = 1024;     // segments per phase-1 workgroup (64 Ki elements against the 64-KiB x slice it stages)
+constexpr int kTpColBlock = 32768;    // default cb: 64 KiB of LDS, two phase-1 workgroups per CU
+constexpr int kTpRowBlock = 4096;     // default rb_max: 32 KiB of f64 accumulators, five phase-2 workgroups per CU
+constexpr unsigned short kTpPadRow = 0xFFFFu;
+struct TwoPhase {
+    int cb = 0, rb_max = 0;
+    std::vector<int> rb_row0;         // [n_rb + 1] first output position of every row block
+    std::vector<int> rb_seg0;         // [n_rb + 1] first segment (RB-major) of every row block
+    std::vector<int> unit;            // [n_units * 3] column block, first segment, end segment (CB-major)
+    std::vector<int> dst;             // [segments] CB-major segment -> RB-major segment
+    raw_vector<uint16_t> lcol;        // [segments * kTpSeg] CB-major: column - c * cb
+    raw_vector<uint16_t> lrow;        // [segments * kTpSeg] RB-major: output position - rb_row0[r]
+    raw_vector<char> val;             // [segments * kTpSeg * vbytes] RB-major
+    size_t segments = 0;
+    int n_rb() const { return rb_row0.empty() ? 0 : (int)rb_row0.size() - 1; }
+    int n_units() const { return (int)(unit.size() / 3); }
+};
+
 struct DevicePlan;  // kernels.hip
 }  // namespace dasp
 struct dasp_plan;      // the C handle (defined at the end of this file): one Plan
@@ -245,6 +275,10 @@ struct Plan {
     raw_vector<int> rt_cid;
     size_t cnt_rt = 0;
 
+    // two-phase form (TwoPhase above): the plan then holds order / stats of the whole matrix and the tile streams, nothing else
+    bool two_phase = false;
+    TwoPhase tp;
+
     bool host_dropped = false;
     DevicePlan *dev = nullptr;
 
@@ -270,6 +304,7 @@ int devpack_chunk_spans(const Plan &p, const DevCsr &d, const raw_vector<int> &r
                         const std::vector<int> &nchunks, int *k16, unsigned long long *narrow_mask);      // narrow_mask: nullptr or [blocks] (plan.cpp)
 int devpack_all(Plan &p, const DevCsr &d, const PackMeta &m);
 int devpack_finish_panels(Plan &p);
+int devpack_fetch_csr(const Plan &p, const DevCsr &d, int *ci, void *val);      // column ids and values of a device CSR -> host arrays of nnz elements
 // the calling thread's HIP device / make `device` the calling thread's (panel workers of a device-built plan)
 int devpack_current_device();
 void devpack_use_device(int device);
@@ -295,6 +330,12 @@ int devpack_sort_columns(const Plan &p, const DevCsr &d, std::vector<std::shared
 // builds every host array of `p` from CSR.  T = double or _Float16.  With `dev` set, rp is a host copy of the row pointer,
 // ci / val are ignored and the nnz-sized arrays are produced on the device (the plan comes back uploaded).
 int build_plan(Plan &p, const int *rp, const int *ci, const void *val, const DevCsr *dev = nullptr);
+
+// two-phase form (twophase.cpp): the automatic rule (1: use it), the packer (after build_impl's meta pass: p.order / p.stats are set) and the
+// checks a loaded plan file must pass
+int decide_two_phase(const Plan &p, const int *rp, int panels_wanted);
+int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val);
+bool validate_two_phase(const Plan &p, std::string &why);
 
 // loader (mmio.cpp).  val_out: malloc'd array of double or binary16.
 int load_mtx(const char *path, int precision, int *m, int *n, int *nnz, int *sym, int **rp, int **ci, void **val);

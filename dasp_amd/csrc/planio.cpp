@@ -1,8 +1,8 @@
 // planio.cpp -- serialised plans (the reference never stores its packed format).
 // A plan file holds every host array of a Plan, so a later run (or every rank of a multi-GPU job)
 // skips classification and packing: load -> upload -> spmv.
-// layout: "DASPPLN6" | int32 sizeof(dasp_stats_t), kNumShortGroups, sizeof(ShortGroup) | plan, where plan = int32 precision, m, n, nnz,
-//         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows, win_hybrid, med_slot0, pair_mode, win_rel16, rt_max | dasp_stats_t |
+// layout: "DASPPLN7" | int32 sizeof(dasp_stats_t), kNumShortGroups, sizeof(ShortGroup) | plan, where plan = int32 precision, m, n, nnz,
+//         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows, win_hybrid, med_slot0, pair_mode, win_rel16, rt_max, two_phase, tp.cb, tp.rb_max | dasp_stats_t |
 //         ShortGroup[kNumShortGroups] | for each array, in a fixed order: int64 byte count + bytes | the n_panels column panels, each
 //         a nested plan.
 // A file is not trusted more than a caller's CSR: after reading, every count, pointer array and column id the kernels index
@@ -18,8 +18,8 @@
 namespace dasp {
 
 namespace {
-// bumped with EVERY change of the header, the array list or the element order inside an array (5: 18-int header, one-byte ids, chunk pairs; 6: 19-int header, row tiles)
-const char kPlanMagic[8] = {'D', 'A', 'S', 'P', 'P', 'L', 'N', '6'};
+// bumped with EVERY change of the header, the array list or the element order inside an array (5: 18-int header, one-byte ids, chunk pairs; 6: 19-int header, row tiles; 7: 22-int header, the two-phase streams)
+const char kPlanMagic[8] = {'D', 'A', 'S', 'P', 'P', 'L', 'N', '7'};
 
 struct Writer {
     FILE *f; bool ok = true;
@@ -52,6 +52,7 @@ template <class IO> void arrays(IO &io, Plan &p)
     io.vec(p.med_dst); io.vec(p.win_cmin); io.vec(p.win_len);
     io.vec(p.short_val); io.vec(p.short_cid);
     io.vec(p.rt_ptr); io.vec(p.rt_start); io.vec(p.rt_mask); io.vec(p.rt_val); io.vec(p.rt_cid);
+    io.vec(p.tp.rb_row0); io.vec(p.tp.rb_seg0); io.vec(p.tp.unit); io.vec(p.tp.dst); io.vec(p.tp.lcol); io.vec(p.tp.lrow); io.vec(p.tp.val);
 }
 }  // namespace
 
@@ -89,6 +90,12 @@ static bool validate_plan(const Plan &p, int n_panels, bool is_panel, std::strin
     if (p.stats.row_long < 0 || p.n_mfma_rows < 0 || p.n_mfma_rows > p.stats.row_block || (long long)p.stats.row_long + p.stats.row_block > m) return fail("category counters");
     if (n_panels == 0 && (p.med_slot0 < p.stats.row_long || (long long)p.med_slot0 + p.n_mfma_rows > (long long)p.stats.row_long + p.stats.row_block)) return fail("med_slot0");
     if (p.panel_bounds.size() != 2 * (size_t)n_panels) return fail("panel_bounds size");
+    if (p.two_phase) {    // order + stats + the tile streams (twophase.cpp)
+        if (n_panels > 0 || is_panel) return fail("two-phase plan with column panels");
+        if (p.cnt_long || p.cnt_reg || p.cnt_irr || p.cnt_short || p.cnt_rt || !p.med_ptr.empty() || !p.irr_ptr.empty() || !p.piece_ptr.empty()) return fail("two-phase plan holds packed DASP arrays");
+        return validate_two_phase(p, why);
+    }
+    if (!p.tp.dst.empty() || !p.tp.lcol.empty() || !p.tp.lrow.empty() || !p.tp.val.empty() || !p.tp.unit.empty() || !p.tp.rb_row0.empty() || !p.tp.rb_seg0.empty()) return fail("two-phase streams in a plan that is not two-phase");
     if (n_panels > 0) {   // a panel parent keeps order + stats only
         if (p.cnt_long || p.cnt_reg || p.cnt_irr || p.cnt_short || !p.med_ptr.empty() || !p.irr_ptr.empty() || !p.piece_ptr.empty()) return fail("panel parent holds packed arrays");
         for (int k = 0; k < n_panels; ++k)
@@ -261,8 +268,9 @@ static bool validate_plan(const Plan &p, int n_panels, bool is_panel, std::strin
 
 static void write_plan(Writer &w, Plan &p)
 {
-    const int hdr[19] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
-                         p.opt.n_parts, p.opt.part_stride, p.opt.stream_policy, (int)p.panels.size(), p.n_mfma_rows, p.win_hybrid ? 1 : 0, p.med_slot0, p.pair_mode, p.win_rel16 ? 1 : 0, p.rt_max};
+    const int hdr[22] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
+                         p.opt.n_parts, p.opt.part_stride, p.opt.stream_policy, (int)p.panels.size(), p.n_mfma_rows, p.win_hybrid ? 1 : 0, p.med_slot0, p.pair_mode, p.win_rel16 ? 1 : 0, p.rt_max,
+                         p.two_phase ? 1 : 0, p.tp.cb, p.tp.rb_max};
     w.raw(hdr, sizeof hdr); w.raw(&p.stats, sizeof p.stats); w.raw(p.grp, sizeof p.grp);
     arrays(w, p);
     for (auto &h : p.panels) write_plan(w, h->impl);
@@ -270,7 +278,7 @@ static void write_plan(Writer &w, Plan &p)
 
 static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
 {
-    int hdr[19];
+    int hdr[22];
     r.raw(hdr, sizeof hdr);
     if (!r.ok || (hdr[0] != 64 && hdr[0] != 16) || hdr[12] < 0 || hdr[12] > 64 || (depth > 0 && hdr[12] != 0)) return false;
     p.precision = hdr[0]; p.geo = geometry_for(p.precision);
@@ -279,9 +287,13 @@ static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
     p.opt.y_order = hdr[4]; p.windowed = hdr[5] != 0; p.row_window = hdr[6]; p.lds_bytes = hdr[7]; p.cid16 = hdr[8] != 0;
     p.opt.n_parts = hdr[9]; p.opt.part_stride = hdr[10]; p.opt.stream_policy = hdr[11]; p.n_mfma_rows = hdr[13]; p.win_hybrid = hdr[14] != 0; p.med_slot0 = hdr[15]; p.pair_mode = hdr[16]; p.win_rel16 = hdr[17] != 0; p.rt_max = hdr[18];
     if (p.pair_mode < 0 || p.pair_mode > 2 || (p.windowed && p.pair_mode)) return false;
+    p.two_phase = hdr[19] != 0; p.tp.cb = hdr[20]; p.tp.rb_max = hdr[21];
+    if (p.two_phase && (depth > 0 || hdr[12] != 0)) return false;
     r.raw(&p.stats, sizeof p.stats); r.raw(p.grp, sizeof p.grp);
     arrays(r, p);
     if (!r.ok) return false;
+    p.tp.segments = p.tp.dst.size();
+    p.opt.two_phase = p.two_phase ? 1 : -1; p.opt.tp_col_block = p.tp.cb; p.opt.tp_row_block = p.tp.rb_max;
     p.opt.part_bounds = p.part_bounds.empty() ? nullptr : p.part_bounds.data();
     const size_t vb = (size_t)p.geo.vbytes;
     const int np = hdr[12];
@@ -290,7 +302,7 @@ static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
                 p.long_val.size() == p.long_cid.size() * vb && p.irr_val.size() == p.irr_cid.size() * vb &&
                 p.short_val.size() == p.short_cid.size() * vb &&
                 (p.cid16 ? p.med_val.size() == (p.med_cid16.size() + p.med_cid8.size()) * vb : p.med_val.size() == p.med_cid.size() * vb);
-    if (np == 0)   // a packed plan (a panel parent keeps none of the row-structure arrays)
+    if (np == 0 && !p.two_phase)   // a packed plan (a panel parent and a two-phase plan keep none of the row-structure arrays)
         sane = sane && p.piece_ptr.size() == p.piece_dst.size() + 1 && p.irr_ptr.size() == (size_t)p.n_mfma_rows + 1 &&
                p.n_mfma_rows >= 0 && p.n_mfma_rows <= p.stats.row_block && (!p.windowed || p.med_dst.size() == (size_t)p.n_mfma_rows);
     if (!sane) return false;
@@ -340,7 +352,7 @@ int load_plan(Plan &p, const char *path)
     r.raw(magic, 8);
     r.raw(abi, sizeof abi);
     if (!r.ok || std::memcmp(magic, kPlanMagic, 8) != 0 || abi[0] != (int)sizeof(dasp_stats_t) || abi[1] != kNumShortGroups || abi[2] != (int)sizeof(ShortGroup)) {
-        std::fclose(f); set_error("not a DASPPLN6 plan file of this build (magic / struct sizes differ)"); return DASP_ERR_BANNER;
+        std::fclose(f); set_error("not a DASPPLN7 plan file of this build (magic / struct sizes differ)"); return DASP_ERR_BANNER;
     }
     std::string why;
     bool ok = false;

@@ -79,6 +79,32 @@ static int upload_plan_impl(Plan &p)
         return DASP_OK;
     }
 
+    if (p.two_phase) {
+        // two-phase form: the tile streams + the xs stream between the two kernels, one allocation
+        const TwoPhase &t = p.tp;
+        const size_t S = t.segments, vbytes = (size_t)p.geo.vbytes;
+        struct Item { const void *src; size_t bytes; size_t off; };
+        std::vector<Item> items;
+        size_t total = 0;
+        auto add = [&](const void *src, size_t bytes) { const size_t off = total; items.push_back({src, bytes, off}); total += (std::max<size_t>(bytes, 16) + 255) & ~size_t(255); return off; };
+        const size_t o_lc = add(t.lcol.data(), S * kTpSeg * 2), o_dst = add(t.dst.data(), S * 4), o_un = add(t.unit.data(), t.unit.size() * 4);
+        const size_t o_v = add(t.val.data(), S * kTpSeg * vbytes), o_lr = add(t.lrow.data(), S * kTpSeg * 2), o_xs = add(nullptr, S * kTpSeg * vbytes);
+        const size_t o_r0 = add(t.rb_row0.data(), t.rb_row0.size() * 4), o_s0 = add(t.rb_seg0.data(), t.rb_seg0.size() * 4);
+        HIP_TRY(hipMalloc(&d->arena, total));
+        d->arena_bytes = total;
+        char *base = static_cast<char *>(d->arena);
+        for (const Item &it : items)
+            if (it.src && it.bytes) HIP_TRY(hipMemcpy(base + it.off, it.src, it.bytes, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(base + o_xs, 0, std::max<size_t>(S * kTpSeg * vbytes, 16)));
+        TpDev &q = d->tp;
+        q.lcol = (const unsigned short *)(base + o_lc); q.dst = (const int *)(base + o_dst); q.unit = (const int *)(base + o_un);
+        q.val = base + o_v; q.lrow = (const unsigned short *)(base + o_lr); q.xs = base + o_xs;
+        q.rb_row0 = (const int *)(base + o_r0); q.rb_seg0 = (const int *)(base + o_s0);
+        q.n_units = t.n_units(); q.n_rb = t.n_rb(); q.cb = t.cb; q.rb_max = t.rb_max; q.xlen = p.n; q.m = p.m;
+        d->nt = true;
+        return tp_kernels_allow_lds();
+    }
+
     std::vector<ShortDev> groups(kNumShortGroups);
     for (int g = 0; g < kNumShortGroups; ++g) {
         groups[g].len = p.grp[g].len; groups[g].count = p.grp[g].count; groups[g].tiles = p.grp[g].tiles;
@@ -272,7 +298,7 @@ int tune_placement(Plan &p, int trials, const void *dX, void *dY, double *ms_fir
     if (ms_kept) *ms_kept = 0.0;
     if (trials <= 0) trials = 2;      // one extra allocation
     trials = std::min(trials, 8);
-    if (!d || !d->arena || trials <= 1 || d->arena_bytes < (size_t(256) << 20) || !p.panels.empty() || p.panel || p.windowed) return DASP_OK;
+    if (!d || !d->arena || trials <= 1 || d->arena_bytes < (size_t(256) << 20) || !p.panels.empty() || p.panel || p.windowed || p.two_phase) return DASP_OK;
     const bool verbose = std::getenv("DASP_VERBOSE") != nullptr;
     const size_t vb = (size_t)p.geo.vbytes, bytes = d->arena_bytes;
     const size_t xlen = p.opt.n_parts > 0 ? (size_t)p.opt.n_parts * (size_t)p.opt.part_stride : (size_t)p.n;

@@ -176,6 +176,16 @@ typedef struct dasp_options {
      * column before packing -- stable, on the host or (dasp_plan_create_device) with a segmented sort on the GPU, bit-identical either way; the caller's arrays are not
      * touched.  The sum of a row then runs in column order instead of CSR order (same products).  0 / -1 = keep the CSR order (default: what the reference does). */
     int sort_columns;
+    /* two-phase (gather-free) form, f16 plans only (no reference counterpart).  For matrices whose rows scatter over all of x every
+     * gathering kernel pays ~0.8 L1 misses per nonzero.  Here the nonzeros are cut into (row block, column block) tiles; phase 1 stages a column block's
+     * slice of x in LDS and expands it into a stream xs of one x value per nonzero, phase 2 keeps a row block's slice of y in LDS (f64 accumulators) and
+     * streams (value, local row, xs): every byte is streamed, 10 B per nonzero against the 6 of B_alg, nothing gathers from global memory
+     * (ljournal-2008 f16: 0.43 -> 0.22 ms, the uniform-column variant 0.51 -> 0.18).  All rows take this path; order_rid and the classifier counters
+     * stay those of the whole matrix; products are f16 x f16 accumulated in f64 (the order of a row's additions is not fixed: LDS atomics).
+     *   0 = auto: f16, no column remap, where the column-panel rule fires (col_panels) and no row is longer than 8192; 1 = force; -1 = off.
+     *   tp_col_block: columns per column block (multiple of 8, <= 65536; 0 = 32768); tp_row_block: most output positions per row block (<= 8192; 0 = 4096). */
+    int two_phase;
+    int tp_col_block, tp_row_block;
 } dasp_options_t;
 
 void dasp_options_default(dasp_options_t *opt);
@@ -209,6 +219,9 @@ typedef struct dasp_stats {
     int row_tile_max;          /* column panels: rows of at most this many nonzeros per panel are stored as row tiles (0: none) */
     int n_row_tiles;           /* row tiles over all panels */
     long long row_tile_nnz;    /* nonzeros stored in row tiles */
+    int two_phase;             /* 1: the plan is in the two-phase (gather-free) form (option two_phase) */
+    int tp_col_block, tp_row_blocks, tp_units;   /* its columns per column block, row blocks (phase-2 workgroups) and phase-1 workgroups */
+    long long tp_segments;     /* its 64-element segments (padded nonzeros / 64) */
     /* the REFERENCE's geometry on the same input (8-row blocks, 8x4 tiles, 32-lane warps): the padded sizes the CUDA reference computes
      * and writes into its CSV row for this matrix -- short tiles dasp_f64.h:609-629 / dasp_f16.h:1139-1156, long rows :1000-1014 /
      * :1273-1288, regular / irregular split :1044-1091 / :1317-1365, rate_fill0 and data_X :1159-1166 / dasp_f16.h:1448-1455.  Functions

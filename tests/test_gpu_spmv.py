@@ -1649,3 +1649,97 @@ def test_plans_with_different_window_sizes_coexist(oracle, dasp, torch_cuda):
         ref = oracle.csr_spmv(rp, ci, v, xh)[plan.order_rid]
         scale = np.maximum(oracle.csr_absrow(rp, ci, v, xh)[plan.order_rid], 1e-300)
         assert (np.abs(got - ref) / scale).max() <= TOL[64]
+
+
+# ---- the two-phase (gather-free) form of an f16 plan (opt.two_phase; kernels dasp_tp_expand_kernel / dasp_tp_reduce_kernel)
+@pytest.mark.parametrize("tag,builder,m,n,seed,kw", [
+    ("mixed", util.mixed_matrix, 3000, 2500, 7, dict()),
+    ("mixed_small_blocks", util.mixed_matrix, 3000, 2500, 8, dict(tp_col_block=64, tp_row_block=16)),
+    ("pairs", util.pair_heavy_matrix, 4000, 3000, 11, dict(tp_col_block=1024, tp_row_block=500)),
+    ("wide", util.mixed_matrix, 900, 150000, 12, dict()),
+    ("big_blocks", util.mixed_matrix, 20000, 70000, 13, dict(tp_col_block=65536, tp_row_block=8192)),
+    ("tiny", util.mixed_matrix, 37, 50, 3, dict()),
+    ("one_row", util.mixed_matrix, 1, 10, 5, dict()),
+])
+def test_two_phase_parity(oracle, dasp, torch_cuda, tag, builder, m, n, seed, kw):
+    """every row category through the two kernels, both y orders, random values / x at the f16 tolerance and the exact all-ones mode"""
+    rp, ci, v = builder(m, n, seed, values="f16")
+    check(oracle, dasp, torch_cuda, rp, ci, v, n, 16, two_phase=1, **kw)
+
+
+@pytest.mark.parametrize("lens", [[5] * 100, [255] * 33, [4] * 1000, [1] * 300 + [3] * 300, [0] * 70, [6, 0, 6, 0, 1], [5000, 256, 1023, 20000, 0, 700, 2]])
+def test_two_phase_edges(oracle, dasp, torch_cuda, lens):
+    rp, ci, v = util.csr_from_lengths(lens, 30011, 13, values="f16")
+    check(oracle, dasp, torch_cuda, rp, ci, v, 30011, 16, two_phase=1)
+    check(oracle, dasp, torch_cuda, rp, ci, v, 30011, 16, two_phase=1, tp_col_block=8, tp_row_block=1)
+
+
+def test_two_phase_empty_accumulate_and_unaligned_x(oracle, dasp, torch_cuda):
+    torch = torch_cuda
+    # no rows / no nonzeros: nothing to launch, y = 0
+    plan = dasp.Plan(np.zeros(9, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float16), 4, precision=16, two_phase=1).upload()
+    assert (run_spmv(torch, plan, np.ones(4, np.float16), 8, 16) == 0).all()
+    plan.close()
+    rp, ci, v = util.mixed_matrix(5000, 4000, 21, values="f16")
+    v = v.astype(np.float16)
+    xh = np.random.default_rng(5).uniform(0.5, 1.5, 4000).astype(np.float16)
+    ref = oracle.csr_spmv(rp, ci, v.astype(np.float64), xh.astype(np.float64))
+    scale = np.maximum(oracle.csr_absrow(rp, ci, v.astype(np.float64), xh.astype(np.float64)), 1e-300)
+    plan = dasp.Plan(rp, ci, v, 4000, precision=16, two_phase=1, y_order=dasp.Y_NATURAL).upload()
+    # y += A x (dasp_plan_spmv_acc): one writer per position, the old value read once
+    x = torch.from_numpy(xh).cuda()
+    y = torch.full((5000,), 2.0, dtype=torch.float16, device="cuda")
+    plan.spmv(x.data_ptr(), y.data_ptr(), 0, accumulate=True)
+    torch.cuda.synchronize()
+    got = y.double().cpu().numpy()
+    assert (np.abs(got - 2.0 - ref) <= 1e-2 * np.maximum(scale, 2.0)).all()
+    # x at an address that is not 16-byte aligned: phase 1 stages its slice with scalar loads instead
+    xb = torch.zeros(4000 + 8, dtype=torch.float16, device="cuda")
+    xb[3:4003] = x
+    y2 = torch.full((5000,), float("nan"), dtype=torch.float16, device="cuda")
+    plan.spmv(xb.data_ptr() + 6, y2.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert (np.abs(y2.double().cpu().numpy() - ref) <= 1e-2 * scale).all()
+    # explicit zeros in the matrix are nonzeros of the CSR (0 * inf = nan as in the serial product); pads are not: they never touch x
+    xi = xh.copy()
+    xi[ci[rp[7]]] = np.inf
+    want = oracle.csr_spmv(rp, ci, v.astype(np.float64), xi.astype(np.float64))
+    got = run_spmv(torch, plan, xi, 5000, 16)
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+    plan.close()
+
+
+def test_two_phase_from_a_device_csr_and_a_plan_file(oracle, dasp, torch_cuda, tmp_path):
+    """dasp_plan_create_device with two_phase: the CSR's nonzeros are fetched once, packed on the host, and the plan comes back uploaded with the same
+    streams as the host-built plan; a plan file of the form loads, uploads and multiplies"""
+    torch = torch_cuda
+    rp, ci, v = util.mixed_matrix(6000, 5000, 31, values="f16")
+    v = v.astype(np.float16)
+    host = dasp.Plan(rp, ci, v, 5000, precision=16, two_phase=1)
+    d_rp, d_ci, d_v = torch.from_numpy(rp.astype(np.int32)).cuda(), torch.from_numpy(ci.astype(np.int32)).cuda(), torch.from_numpy(v).cuda()
+    dev = dasp.Plan.from_device(d_rp.data_ptr(), d_ci.data_ptr(), d_v.data_ptr(), 6000, 5000, ci.size, precision=16, two_phase=1)
+    S = host.stats["tp_segments"]
+    assert dev.stats["two_phase"] == 1 and dev.stats["tp_segments"] == S
+    for name, dt, cnt in (("tp_lcol", np.uint16, S * 64), ("tp_lrow", np.uint16, S * 64), ("tp_val", np.float16, S * 64), ("tp_dst", np.int32, S)):
+        assert np.array_equal(dev.device_array(name, cnt, dt), host.host_array(name)), name
+    xh = np.random.default_rng(6).uniform(0.5, 1.5, 5000).astype(np.float16)
+    ref = oracle.csr_spmv(rp, ci, v.astype(np.float64), xh.astype(np.float64))
+    scale = np.maximum(oracle.csr_absrow(rp, ci, v.astype(np.float64), xh.astype(np.float64)), 1e-300)
+    got = run_spmv(torch, dev, xh, 6000, 16)
+    assert (np.abs(got - ref[dev.order_rid]) <= 1e-2 * scale[dev.order_rid]).all()
+    # phase 1's stream: xs[e] = x[column of element e] for every stored element
+    xs = dev.device_array("tp_xs", S * 64, np.float16)
+    dec_cols = np.full(S * 64, -1, np.int64)
+    unit, dst, lcol = host.host_array("tp_unit").reshape(-1, 3), host.host_array("tp_dst"), host.host_array("tp_lcol")
+    cb = host.stats["tp_col_block"]
+    for c, s0, s1 in unit.tolist():
+        for s in range(s0, s1):
+            dec_cols[dst[s] * 64:(dst[s] + 1) * 64] = c * cb + lcol[s * 64:(s + 1) * 64]
+    live = host.host_array("tp_lrow") != 0xFFFF
+    assert np.array_equal(xs[live], xh[dec_cols[live]])
+    path = str(tmp_path / "tp.plan")
+    host.save(path)
+    again = dasp.Plan.load(path).upload()
+    assert np.array_equal(run_spmv(torch, again, xh, 6000, 16), got)
+    for p in (host, dev, again):
+        p.close()

@@ -479,8 +479,9 @@ def test_corrupt_plan_files_are_rejected_not_trusted(dasp, tmp_path):
     back as an error (never an exception through the C ABI, never a plan that would read out of bounds on upload)"""
     rp, ci, v = util.mixed_matrix(2500, 2000, 13)
     good = str(tmp_path / "g.plan")
-    for kw in (dict(), dict(x_window=100000, row_window=128), dict(cid16=1), dict(col_panels=3), dict(col_panels=2, row_tile_max=8)):
-        dasp.Plan(rp, ci, v, 2000, **kw).save(good)
+    for kw in (dict(), dict(x_window=100000, row_window=128), dict(cid16=1), dict(col_panels=3), dict(col_panels=2, row_tile_max=8),
+               dict(precision=16, two_phase=1, tp_col_block=256, tp_row_block=64)):
+        dasp.Plan(rp, ci, v.astype(np.float16) if kw.get("precision") == 16 else v, 2000, **kw).save(good)
         blob = bytearray(open(good, "rb").read())
         dasp.Plan.load(good).close()                                   # the undamaged file loads
         rng = np.random.default_rng(1)
@@ -502,9 +503,9 @@ def test_corrupt_plan_files_are_rejected_not_trusted(dasp, tmp_path):
                 assert e.status in (-2, -5, -11)
                 rejected += 1
         assert rejected >= 5
-    for old in (b"4", b"5"):                                           # older layouts' magics ('5': before the row tiles / 19-int header)
+    for old in (b"4", b"5", b"6"):                                     # older layouts' magics ('5': before the row tiles / 19-int header; '6': before the two-phase streams / 22-int header)
         bad = bytearray(blob)
-        assert bytes(bad[:8]) == b"DASPPLN6"
+        assert bytes(bad[:8]) == b"DASPPLN7"
         bad[7:8] = old
         open(good, "wb").write(bad)
         with pytest.raises(dasp.DaspError) as e:

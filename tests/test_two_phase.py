@@ -1,0 +1,116 @@
+"""The two-phase (gather-free) form of an f16 plan (opt.two_phase; plan.hpp struct TwoPhase, twophase.cpp) on the host: the tile streams
+decode back to the CSR -- rows in the plan's output order, every row's entries in CSR order --, the classifier counters and order_rid stay those
+of the whole matrix, block sizes / edge cases / plan files / the validator.  The GPU side (parity with the oracle) is tests/test_gpu_spmv.py."""
+import numpy as np
+import pytest
+
+import util
+
+
+def _check_decodes(plan, rp, ci, v, m, natural):
+    rows = util.decode_plan(plan)
+    order = plan.order_rid
+    lens = np.diff(rp)
+    assert sorted(rows) == sorted(int(np.flatnonzero(order == r)[0]) if not natural else r for r in range(m) if lens[r] > 0)
+    for pos, (cs, vs) in rows.items():
+        r = pos if natural else order[pos]
+        # a row's entries: the column blocks in ascending order, CSR order inside a block -- i.e. a stable sort of the row by column block
+        cb = plan.stats["tp_col_block"]
+        k = np.argsort(ci[rp[r]:rp[r + 1]] // cb, kind="stable")
+        assert cs == ci[rp[r]:rp[r + 1]][k].tolist(), (pos, r)
+        assert np.array_equal(np.asarray(vs, np.float16), v[rp[r]:rp[r + 1]][k]), (pos, r)
+
+
+@pytest.mark.parametrize("natural", [False, True])
+@pytest.mark.parametrize("m,n,seed,cb,rb", [(3000, 2500, 5, 0, 0), (3000, 2500, 6, 512, 64), (700, 70000, 7, 32768, 100), (64, 8, 8, 8, 1), (1, 5, 9, 0, 0)])
+def test_streams_decode_to_the_csr(dasp, oracle, m, n, seed, cb, rb, natural):
+    rp, ci, v = util.mixed_matrix(m, n, seed, values="f16", dtype=np.float16)
+    plan = dasp.Plan(rp, ci, v, n, precision=16, two_phase=1, tp_col_block=cb, tp_row_block=rb, y_order=dasp.Y_NATURAL if natural else dasp.Y_PERMUTED)
+    st = plan.stats
+    assert st["two_phase"] == 1 and st["n_col_panels"] == 0 and st["tp_col_block"] == (cb or 32768)
+    assert st["fill0_nnz_reg"] == st["tp_segments"] * 64 >= st["nnzA"]
+    assert abs(st["rate_fill0"] - (st["tp_segments"] * 64 - st["nnzA"]) / max(st["nnzA"], 1)) < 1e-12
+    # the whole-matrix classifier: the reference's counters and permutation do not depend on the form
+    P = oracle.Packed(16, rp, ci, v.astype(np.float64), n)
+    for f in "row_long row_block row_zero short_row_1 short_row_2 short_row_3 short_row_4 common_13".split():
+        assert st[f] == getattr(P, f), f
+    assert (plan.order_rid == P.order_rid).all()
+    row0 = plan.host_array("tp_rb_row0")
+    assert row0[0] == 0 and row0[-1] == m and (np.diff(row0) >= 1).all() and (np.diff(row0) <= (rb or 4096)).all()
+    _check_decodes(plan, rp, ci, v, m, natural)
+    plan.close()
+
+
+def test_row_blocks_balance_the_nonzeros_of_the_sorted_order(dasp):
+    """the permuted order is sorted by row length: blocks of equal row counts would give the first workgroups a hundred times the work of the last"""
+    rng = np.random.default_rng(3)
+    lens = np.minimum(rng.zipf(1.6, 60000), 3000)
+    rp, ci, v = util.csr_from_lengths(lens, 50000, 4, values="f16", dtype=np.float16)
+    plan = dasp.Plan(rp, ci, v, 50000, precision=16, two_phase=1)
+    row0, seg0 = plan.host_array("tp_rb_row0"), plan.host_array("tp_rb_seg0")
+    per_block = np.diff(seg0) * 64
+    target = max(16384, min(1 << 17, ci.size // 1024 + 1))
+    assert per_block.max() <= 2 * target + 3000 + 64 * plan.host_array("tp_unit").reshape(-1, 3)[:, 0].max()      # one row past the target + the tiles' padding
+    assert (np.diff(row0) <= 4096).all()
+    plan.close()
+
+
+def test_forced_on_what_it_cannot_do_is_an_error(dasp):
+    rp, ci, v = util.mixed_matrix(200, 300, 1)
+    with pytest.raises(dasp.DaspError):
+        dasp.Plan(rp, ci, v, 300, precision=64, two_phase=1)                     # f16 only
+    v16 = v.astype(np.float16)
+    with pytest.raises(dasp.DaspError):
+        dasp.Plan(rp, ci, v16, 300, precision=16, two_phase=1, tp_col_block=12)   # not a multiple of 8
+    with pytest.raises(dasp.DaspError):
+        dasp.Plan(rp, ci, v16, 300, precision=16, two_phase=1, tp_row_block=9000)
+    # auto never picks it for a small matrix, off is off
+    assert dasp.Plan(rp, ci, v16, 300, precision=16).stats["two_phase"] == 0
+    assert dasp.Plan(rp, ci, v16, 300, precision=16, two_phase=-1).stats["two_phase"] == 0
+
+
+def test_empty_and_degenerate_inputs(dasp):
+    for m, n in ((0, 0), (0, 7), (5, 0), (5, 7)):
+        rp = np.zeros(m + 1, np.int32)
+        plan = dasp.Plan(rp, np.zeros(0, np.int32), np.zeros(0, np.float16), n, precision=16, two_phase=1)
+        st = plan.stats
+        assert st["two_phase"] == 1 and st["tp_segments"] == 0 and st["tp_units"] == 0 and st["tp_row_blocks"] == (1 if m else 0)
+        assert util.decode_plan(plan) == {}
+        plan.close()
+
+
+def test_plan_file_round_trip_and_validator(dasp, tmp_path):
+    rp, ci, v = util.mixed_matrix(2500, 2000, 11, values="f16", dtype=np.float16)
+    plan = dasp.Plan(rp, ci, v, 2000, precision=16, two_phase=1, tp_col_block=256, tp_row_block=128)
+    path = str(tmp_path / "tp.plan")
+    plan.save(path)
+    again = dasp.Plan.load(path)
+    assert again.stats["two_phase"] == 1 and again.stats["tp_segments"] == plan.stats["tp_segments"]
+    for name in ("tp_rb_row0", "tp_rb_seg0", "tp_unit", "tp_dst", "tp_lcol", "tp_lrow", "tp_val"):
+        assert np.array_equal(again.host_array(name), plan.host_array(name)), name
+    _check_decodes(again, rp, ci, v, 2500, False)
+    again.close()
+    # a corrupted stream must be refused, not uploaded: a local row beyond its row block, a local column beyond its column block, dst not a permutation
+    raw = bytearray(open(path, "rb").read())
+    S = plan.stats["tp_segments"]
+    lrow = plan.host_array("tp_lrow")
+    k = int(np.flatnonzero(lrow != 0xFFFF)[0])
+    blob = lrow.tobytes()
+    at = bytes(raw).find(blob)
+    assert at > 0
+    bad = bytearray(raw)
+    bad[at + 2 * k: at + 2 * k + 2] = (5000).to_bytes(2, "little")
+    (tmp_path / "bad1.plan").write_bytes(bytes(bad))
+    with pytest.raises(dasp.DaspError) as e:
+        dasp.Plan.load(str(tmp_path / "bad1.plan"))
+    assert "local row" in str(e.value)
+    dst = plan.host_array("tp_dst")
+    at = bytes(raw).find(dst.tobytes())
+    assert at > 0 and S > 2
+    bad = bytearray(raw)
+    bad[at: at + 4] = int(dst[1]).to_bytes(4, "little")
+    (tmp_path / "bad2.plan").write_bytes(bytes(bad))
+    with pytest.raises(dasp.DaspError) as e:
+        dasp.Plan.load(str(tmp_path / "bad2.plan"))
+    assert "permutation" in str(e.value)
+    plan.close()

@@ -44,6 +44,43 @@ def slot_of(g, t):
     return base[p] + (u // grp[p]) * 2 * grp[p] + off[p] + u % grp[p] if grp[p] else base[p] + u
 
 
+def decode_two_phase(plan, x=None):
+    """The two-phase form (plan.hpp struct TwoPhase) from its streams alone, walked the way the two kernels walk them: phase 1 per unit
+    (column block, CB-major segments) resolves every local column and drops it at dst[segment]; phase 2 per row block reads (value, local row)
+    and what phase 1 left there.  Returns dict output position -> (cols[], vals[]) in stored order (pads removed), as decode_plan does
+    (positions of the plan's y order).  With x: also checks nothing and returns (rows, y) with y accumulated in float64."""
+    st = plan.stats
+    SEG = 64
+    cb = st["tp_col_block"]
+    S = st["tp_segments"]
+    row0, seg0 = plan.host_array("tp_rb_row0"), plan.host_array("tp_rb_seg0")
+    unit = plan.host_array("tp_unit").reshape(-1, 3)
+    dst, lcol, lrow, val = plan.host_array("tp_dst"), plan.host_array("tp_lcol"), plan.host_array("tp_lrow"), plan.host_array("tp_val")
+    assert dst.size == S and lcol.size == S * SEG and lrow.size == S * SEG and val.size == S * SEG
+    assert unit.shape[0] == st["tp_units"] and row0.size == st["tp_row_blocks"] + 1 and sorted(dst.tolist()) == list(range(S))
+    gcol = np.full(S * SEG, -1, np.int64)              # phase 1: the global column of every RB-major element
+    covered = np.zeros(S, bool)
+    for c, s0, s1 in unit.tolist():
+        assert 0 < s1 - s0 <= 1024
+        for s in range(s0, s1):
+            assert not covered[s]
+            covered[s] = True
+            gcol[dst[s] * SEG:(dst[s] + 1) * SEG] = c * cb + lcol[s * SEG:(s + 1) * SEG].astype(np.int64)
+    assert covered.all()
+    out = {}
+    for b in range(row0.size - 1):
+        rows = row0[b + 1] - row0[b]
+        for e in range(seg0[b] * SEG, seg0[b + 1] * SEG):
+            if lrow[e] == 0xFFFF:
+                assert val[e] == 0
+                continue
+            assert lrow[e] < rows
+            cs, vs = out.setdefault(int(row0[b] + lrow[e]), ([], []))
+            cs.append(int(gcol[e]))
+            vs.append(float(val[e]))
+    return out
+
+
 def decode_plan(plan):
     """Rebuild, from the native packed arrays alone, the list of (col, val) per permuted slot.
     Returns dict slot -> (cols[], vals[]) in stored order (pads removed)."""
@@ -51,6 +88,8 @@ def decode_plan(plan):
     K, CH, SR = (4, 64, 128) if prec == 64 else (16, 256, 256)
     st = plan.stats
     out = {}
+    if st.get("two_phase"):
+        return decode_two_phase(plan)
     # long rows
     lv, lc = plan.host_array("long_val"), plan.host_array("long_cid")
     pp, pd = plan.host_array("piece_ptr"), plan.host_array("piece_dst")
