@@ -62,7 +62,7 @@ __global__ __launch_bounds__(THREADS) void tp_reduce(const _Float16 *__restrict_
     float *yl = reinterpret_cast<float *>(lds_raw);
     double *yd = reinterpret_cast<double *>(lds_raw);
     const int r = blockIdx.x, r0 = r * RB, len = min(RB, m - r0);
-    if constexpr (MODE == 4) { for (int i = threadIdx.x; i < RB; i += THREADS) yd[i] = 0.0; }
+    if constexpr (MODE == 4 || MODE == 6) { for (int i = threadIdx.x; i < RB; i += THREADS) yd[i] = 0.0; }
     else for (int i = threadIdx.x; i < RB; i += THREADS) yl[i] = 0.0f;
     __syncthreads();
     const int S0 = rb_seg0[r], S1 = rb_seg0[r + 1];
@@ -84,6 +84,7 @@ __global__ __launch_bounds__(THREADS) void tp_reduce(const _Float16 *__restrict_
                 else if constexpr (MODE == 1) yl[lr[j]] += p;
                 else if constexpr (MODE == 2) __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(yl) + lr[j], __float_as_uint(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 else if constexpr (MODE == 4) { if (v[j] != (_Float16)0) __hip_atomic_fetch_add(yd + lr[j], (double)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }      // f64 accumulators: ds_add_f64 runs ~4x the rate of ds_add_f32 on gfx950
+                else if constexpr (MODE == 6) __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(yd) + lr[j], (unsigned long long)(long long)(p * 1048576.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (timing: 64-bit integer atomics)
                 else if constexpr (MODE == 5) { typedef _Float16 h2 __attribute__((ext_vector_type(2))); const h2 q = {(_Float16)p, (_Float16)0};
                                                 __builtin_amdgcn_ds_atomic_fadd_v2f16((__attribute__((address_space(3))) h2 *)(yl + lr[j]), q); }
                 else acc += p;
@@ -106,6 +107,8 @@ extern "C" int tp_set_lds(int cb_bytes, int rb_bytes)
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tp_reduce<256, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tp_reduce<256, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tp_reduce<512, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tp_reduce<512, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tp_reduce<256, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tp_reduce<512, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tp_reduce<512, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&tp_reduce<512, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -122,11 +125,11 @@ extern "C" int tp_phase1(const void *lcol, const void *dst_seg, const void *x, v
 extern "C" int tp_phase2(const void *val, const void *lrow, const void *xs, const void *rb_seg0, void *y, int RB, int m, int n_rb, int threads, void *stream)
 {
     const int mode = threads / 1000; threads %= 1000;
-#define TP_M(M) if (mode == M && threads == 512) { hipLaunchKernelGGL((tp_reduce<512, M>), dim3(n_rb), dim3(512), (size_t)RB * (M == 4 ? 8 : 4), static_cast<hipStream_t>(stream), static_cast<const _Float16 *>(val), \
+#define TP_M(M) if (mode == M && threads == 512) { hipLaunchKernelGGL((tp_reduce<512, M>), dim3(n_rb), dim3(512), (size_t)RB * (M == 4 || M == 6 ? 8 : 4), static_cast<hipStream_t>(stream), static_cast<const _Float16 *>(val), \
                            static_cast<const unsigned short *>(lrow), static_cast<const _Float16 *>(xs), static_cast<const int *>(rb_seg0), static_cast<_Float16 *>(y), RB, m); return (int)hipGetLastError(); } \
-    if (mode == M) { hipLaunchKernelGGL((tp_reduce<256, M>), dim3(n_rb), dim3(256), (size_t)RB * (M == 4 ? 8 : 4), static_cast<hipStream_t>(stream), static_cast<const _Float16 *>(val), \
+    if (mode == M) { hipLaunchKernelGGL((tp_reduce<256, M>), dim3(n_rb), dim3(256), (size_t)RB * (M == 4 || M == 6 ? 8 : 4), static_cast<hipStream_t>(stream), static_cast<const _Float16 *>(val), \
                            static_cast<const unsigned short *>(lrow), static_cast<const _Float16 *>(xs), static_cast<const int *>(rb_seg0), static_cast<_Float16 *>(y), RB, m); return (int)hipGetLastError(); }
-    TP_M(1) TP_M(2) TP_M(3) TP_M(4) TP_M(5)
+    TP_M(1) TP_M(2) TP_M(3) TP_M(4) TP_M(5) TP_M(6)
 #undef TP_M
     if (threads == 512)
         hipLaunchKernelGGL(tp_reduce<512>, dim3(n_rb), dim3(512), (size_t)RB * 4, static_cast<hipStream_t>(stream), static_cast<const _Float16 *>(val),
