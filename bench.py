@@ -311,7 +311,7 @@ def kernel_revision():
     """sha1 of the kernel + packer sources: a traffic.json entry is only attached to the build it was measured on"""
     import hashlib
     h = hashlib.sha1()
-    for f in ("kernels.hip", "spmv_device.hpp", "upload.cpp", "plan.cpp", "device.hpp", "plan.hpp"):
+    for f in ("kernels.hip", "spmv_device.hpp", "upload.cpp", "plan.cpp", "device.hpp", "plan.hpp", "twophase.cpp"):
         h.update(open(os.path.join(ROOT, "dasp_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:12]
 
@@ -325,7 +325,7 @@ def choose_y(torch, plan, x, rows, tdt, stats):
     the run's own and keep the fastest -- rowA values each, 2 + 6 launches per candidate, no sleeps, nothing hidden in the library.
     DASP_BENCH_Y_CANDIDATES (default 6; 1: off).  Returns (y, record)."""
     n = max(1, int(os.environ.get("DASP_BENCH_Y_CANDIDATES", "6")))
-    if n == 1 or stats["data_X"] < (256 << 20) or stats["n_col_panels"] or stats["x_window_on"]:
+    if n == 1 or stats["data_X"] < (256 << 20) or stats["n_col_panels"] or stats["x_window_on"] or stats.get("two_phase"):
         return torch.zeros(rows, dtype=tdt, device="cuda"), {"y_candidates": 1}
     ys = [torch.zeros(rows, dtype=tdt, device="cuda") for _ in range(n)]
     torch.cuda.synchronize()
@@ -369,7 +369,7 @@ def suite_entry(torch, D, O, name, precision, scale, budget_s=2.0):
            "frac_hbm_roofline_graph": round(b_alg / (ge * 1e6) / HBM_PEAK_GBPS, 4),
            "frac_single_y": round(b_alg / (e1 * 1e6) / HBM_PEAK_GBPS, 4),
            "rate_fill0": round(st["rate_fill0"], 4), "pre_ms": round(st["pre_ms"], 1), "verified": ok,
-           "col_panels": st["n_col_panels"], "row_long": st["row_long"], "row_block": st["row_block"],
+           "col_panels": st["n_col_panels"], "two_phase": st.get("two_phase", 0), "row_long": st["row_long"], "row_block": st["row_block"],
            "row_short": rows - st["row_long"] - st["row_block"] - st["row_zero"], "generator": generator_of(D, name),
            "x_window": {"on": st["x_window_on"], "hybrid": st["x_window_hybrid"], "lds_share_of_medium_gathers": round(st["window_nnz_frac"], 3)},
            "gather_roofline": gather_roofline(nnz, e), "placement": placement}

@@ -18,7 +18,7 @@ static int s_panels(dasp_plan_t *p) { return dasp_plan_panel_count(p); }
 
 int main(int argc, char **argv)
 {
-    if (argc < 2) { std::printf("usage: dasp_bench <workload> [scale] [precision] [iters] [warmup] [threshold] [long_piece] [x_window] [row_window] [cid16] [col_panels] [stream_policy] [slab_max_len] [piece_min_len] [x_window_hybrid] [chunk_pairs]\n"); return 0; }
+    if (argc < 2) { std::printf("usage: dasp_bench <workload> [scale] [precision] [iters] [warmup] [threshold] [long_piece] [x_window] [row_window] [cid16] [col_panels] [stream_policy] [slab_max_len] [piece_min_len] [x_window_hybrid] [chunk_pairs] [two_phase]\n"); return 0; }
     const char *name = argv[1];
     const double scale = argc > 2 ? std::atof(argv[2]) : 1.0;
     const int prec = argc > 3 ? std::atoi(argv[3]) : 64;
@@ -35,6 +35,7 @@ int main(int argc, char **argv)
     const int piece_min_len = argc > 14 ? std::atoi(argv[14]) : 0;
     const int chunk_pairs = argc > 16 ? std::atoi(argv[16]) : 0;
     const int x_window_hybrid = argc > 15 ? std::atoi(argv[15]) : 0;
+    const int two_phase = argc > 17 ? std::atoi(argv[17]) : 0;
     int rows, cols;
     CHECK(dasp_synth_dims(name, scale, &rows, &cols));
     std::vector<int> rp((size_t)rows + 1, 0);
@@ -50,7 +51,7 @@ int main(int argc, char **argv)
     else for (int i = 0; i < nnz; ++i) reinterpret_cast<uint16_t *>(val.data())[i] = 0x3C00;
     dasp_options_t opt;
     dasp_options_default(&opt);
-    opt.threshold = threshold; opt.long_piece = long_piece; opt.x_window = x_window; opt.row_window = row_window; opt.cid16 = cid16; opt.col_panels = col_panels; opt.stream_policy = stream_policy; opt.slab_max_len = slab_max_len; opt.piece_min_len = piece_min_len; opt.x_window_hybrid = x_window_hybrid; opt.chunk_pairs = chunk_pairs;
+    opt.threshold = threshold; opt.long_piece = long_piece; opt.x_window = x_window; opt.row_window = row_window; opt.cid16 = cid16; opt.col_panels = col_panels; opt.stream_policy = stream_policy; opt.slab_max_len = slab_max_len; opt.piece_min_len = piece_min_len; opt.x_window_hybrid = x_window_hybrid; opt.chunk_pairs = chunk_pairs; opt.two_phase = two_phase;
     dasp_plan_t *plan = nullptr;
     CHECK(dasp_plan_create(&plan, prec, rows, cols, nnz, rp.data(), ci.data(), val.data(), &opt));
     CHECK(dasp_plan_upload(plan));
@@ -126,8 +127,8 @@ int main(int argc, char **argv)
         if (drp) (void)hipFree(drp); if (dci) (void)hipFree(dci); if (dv) (void)hipFree(dv);
     }
     const double balg = (double)s.data_origin1;
-    std::printf("%s scale=%g f%d rows=%d nnz=%d long=%d med=%d fill0=%.4f pre=%.1fms devpre=%.1fms win=%d/%d lds=%dB c16=%d panels=%d pieces=%d | %.4f ms (event %.4f) %.1f GFLOP/s %.1f GB/s alg = %.3f of 8 TB/s | graph: %.4f ms %.3f | mismatches=%lld\n",
-                name, scale, prec, rows, nnz, s.row_long, s.row_block, s.rate_fill0, s.pre_ms, dev_pre, s.n_windows_lds, s.n_windows, s.lds_bytes, s.cid16_on, s.n_col_panels, s.med_rows_as_pieces, wall, ev, 2.0 * nnz / (wall * 1e6),
+    std::printf("%s scale=%g f%d rows=%d nnz=%d long=%d med=%d fill0=%.4f pre=%.1fms devpre=%.1fms win=%d/%d lds=%dB c16=%d panels=%d pieces=%d tp=%d | %.4f ms (event %.4f) %.1f GFLOP/s %.1f GB/s alg = %.3f of 8 TB/s | graph: %.4f ms %.3f | mismatches=%lld\n",
+                name, scale, prec, rows, nnz, s.row_long, s.row_block, s.rate_fill0, s.pre_ms, dev_pre, s.n_windows_lds, s.n_windows, s.lds_bytes, s.cid16_on, s.n_col_panels, s.med_rows_as_pieces, s.two_phase, wall, ev, 2.0 * nnz / (wall * 1e6),
                 balg / (ev * 1e6), balg / (ev * 1e6) / 8000.0, gev, balg / (gev * 1e6) / 8000.0, bad);
     (void)hipFree(dX); (void)hipFree(dY);
     dasp_plan_destroy(plan);

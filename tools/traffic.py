@@ -14,12 +14,12 @@ d = os.path.join(root, "gpurun_out", "prof_" + tag)
 
 def rev():
     h = hashlib.sha1()
-    for f in ("kernels.hip", "spmv_device.hpp", "upload.cpp", "plan.cpp", "device.hpp", "plan.hpp"):
+    for f in ("kernels.hip", "spmv_device.hpp", "upload.cpp", "plan.cpp", "device.hpp", "plan.hpp", "twophase.cpp"):      # = bench.py kernel_revision()
         h.update(open(os.path.join(root, "dasp_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:12]
 
 
-SPMV_KERNELS = ("dasp_spmv_kernel", "dasp_long_reduce_kernel", "dasp_panel_sum_kernel")   # the kernels of one SpMV (not dasp_bench's packers)
+SPMV_KERNELS = ("dasp_spmv_kernel", "dasp_long_reduce_kernel", "dasp_panel_sum_kernel", "dasp_tp_expand_kernel", "dasp_tp_reduce_kernel")   # the kernels of one SpMV (not dasp_bench's packers)
 
 
 def spmv_kernel(name):
@@ -51,14 +51,16 @@ panels = 0
 for tok in log.replace("|", " ").split():
     if tok.startswith("panels="):
         panels = int(tok.split("=")[1])
-n_spmv = fcnt["dasp_spmv_kernel"] / max(1, panels)
+two_phase = "dasp_spmv_kernel" not in fcnt and "dasp_tp_reduce_kernel" in fcnt          # a two-phase plan: one expand + one reduce launch per SpMV
+main_k = "dasp_tp_reduce_kernel" if two_phase else "dasp_spmv_kernel"
+n_spmv = fcnt[main_k] / max(1, panels)
 f_raw = sum(fetch.values()) / n_spmv
-w = sum(write.values()) / (wcnt["dasp_spmv_kernel"] / max(1, panels))
+w = sum(write.values()) / (wcnt[main_k] / max(1, panels))
 stats = list(csv.DictReader(open(max(glob.glob(d + "/trace/*/*kernel_stats.csv"), key=os.path.getmtime))))
 sys.stderr.write("## rocprofv3 --kernel-trace --stats -- dasp_bench %s %g %d (tag %s)\n\n| kernel | calls | avg ns | %% |\n|---|---|---|---|\n" % (workload, scale, prec, tag))
 for r in stats[:5]:
     sys.stderr.write("| %s | %s | %.0f | %s |\n" % (r["Name"][:90], r["Calls"], float(r["AverageNs"]), r["Percentage"]))
-g = [r for r in frows if "dasp_spmv" in r["Kernel_Name"]][0]
+g = [r for r in frows if ("dasp_tp_reduce" if two_phase else "dasp_spmv") in r["Kernel_Name"]][0]
 sys.stderr.write("\nVGPR_Count=%s SGPR_Count=%s LDS=%s scratch=%s workgroup=%s; %d column panels; %.0f SpMVs profiled\n" %
                  (g["VGPR_Count"], g["SGPR_Count"], g["LDS_Block_Size"], g["Scratch_Size"], g["Workgroup_Size"], panels, n_spmv))
 sys.stderr.write("FETCH_SIZE (own pass) = %.4f GB raw per SpMV -> x2 = %.4f GB; WRITE_SIZE (own pass) = %.2f MB; traffic = %.4f GB per SpMV\n\n" %
@@ -70,6 +72,6 @@ for r in stats:
         avg[k] = avg.get(k, 0.0) + float(r["AverageNs"]) * (max(1, panels) if k == "dasp_spmv_kernel" else 1)   # per SpMV
 print(json.dumps({"workload": workload, "precision": prec, "scale": scale, "kernel_rev": rev(), "kernels": sorted(fcnt),
                   "fetch_size_bytes_raw": round(f_raw), "write_size_bytes": round(w), "traffic_bytes": round(2 * f_raw + w),
-                  "kernel_avg_ns": avg, "column_panels": panels,
+                  "kernel_avg_ns": avg, "column_panels": panels, "two_phase": bool(two_phase),
                   "correction": "2 x FETCH_SIZE (gfx950, MI355X_MICROARCH.md HBM section; calibrated for wide coalesced streams) + WRITE_SIZE, summed over the kernels of one SpMV",
                   "source": "profiles/%s_traffic.md" % os.environ.get("ROUND", "r04")}))
