@@ -816,7 +816,10 @@ __device__ __forceinline__ void row_tile(const DevArgs &a, int t, int lane, type
     if ((a.rt_mask[t] >> lane) & 1) put_y<T>(a, t * kRowTile + lane, sum);
 }
 
-constexpr int kMinWavesPlain = 1, kMinWavesWin = 8;
+#ifndef DASP_MIN_WAVES
+#define DASP_MIN_WAVES 1
+#endif
+constexpr int kMinWavesPlain = DASP_MIN_WAVES, kMinWavesWin = 8;
 // WIN: windowed mode.  A medium workgroup owns one window of row_window rows (blocks_per_win blocks, strided over its
 // 4 waves); if the window's x span fits, it is copied once into LDS with coalesced 16-byte loads and every gather of
 // the window reads LDS; otherwise that workgroup gathers from global memory like the non-windowed kernel.
