@@ -42,7 +42,7 @@ class Stats(C.Structure):
         ("row_window", C.c_int), ("window_nnz_frac", C.c_double), ("cid16_on", C.c_int),
         ("n_col_panels", C.c_int), ("x_window_hybrid", C.c_int), ("med_rows_as_pieces", C.c_int), ("chunk_pairs", C.c_int), ("cid8_chunks", C.c_int), ("short_seg", C.c_int),
         ("row_tile_max", C.c_int), ("n_row_tiles", C.c_int), ("row_tile_nnz", C.c_longlong),
-        ("two_phase", C.c_int), ("tp_col_block", C.c_int), ("tp_row_blocks", C.c_int), ("tp_units", C.c_int), ("tp_segments", C.c_longlong),
+        ("two_phase", C.c_int), ("tp_col_block", C.c_int), ("tp_row_blocks", C.c_int), ("tp_units", C.c_int), ("tp_segments", C.c_longlong), ("tp_seg_elems", C.c_int),
         ("ref_fill0_nnz_short", C.c_longlong), ("ref_fill0_nnz_long", C.c_longlong), ("ref_fill0_nnz_reg", C.c_longlong), ("ref_data_X", C.c_longlong),
         ("ref_nnz_irreg", C.c_int), ("ref_origin_nnz_reg", C.c_int), ("ref_blocknum", C.c_int), ("ref_warp_number", C.c_int), ("ref_rate_fill0", C.c_double)]
 

@@ -144,10 +144,11 @@ __global__ __launch_bounds__(512) void dasp_tp_expand_kernel(TpDev a, const T *_
     } else for (int i = threadIdx.x; i < len; i += 512) xl[i] = x[c0 + i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane >> 3, off = (lane & 7) * 8;
+    constexpr int LPS = kTpSeg / 8, SPW = 64 / LPS;          // lanes per segment (8 elements each), segments per wave iteration
+    const int sub = lane / LPS, off = (lane % LPS) * 8;
     T *xs = static_cast<T *>(a.xs);
 #pragma unroll 2
-    for (int g = s0 + wave * 8; g < s1; g += 8 * 8) {
+    for (int g = s0 + wave * SPW; g < s1; g += 8 * SPW) {
         const int seg = g + sub;
         if (seg < s1) {
             const tp_u16x8 lc = __builtin_nontemporal_load(reinterpret_cast<const tp_u16x8 *>(a.lcol + (size_t)seg * kTpSeg + off));
@@ -176,10 +177,11 @@ __global__ __launch_bounds__(512) void dasp_tp_reduce_kernel(TpDev a, T *__restr
     __syncthreads();
     const int s0 = a.rb_seg0[r], s1 = a.rb_seg0[r + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub = lane >> 3, off = (lane & 7) * 8;
+    constexpr int LPS = kTpSeg / 8, SPW = 64 / LPS;
+    const int sub = lane / LPS, off = (lane % LPS) * 8;
     const T *val = static_cast<const T *>(a.val), *xs = static_cast<const T *>(a.xs);
 #pragma unroll 2
-    for (int g = s0 + wave * 8; g < s1; g += 8 * 8) {
+    for (int g = s0 + wave * SPW; g < s1; g += 8 * SPW) {
         const int seg = g + sub;
         if (seg < s1) {
             const size_t at = (size_t)seg * kTpSeg + off;

@@ -169,8 +169,11 @@ constexpr int kRowTileMax = 32;     // longest row a tile may take (LDS: 4 waves
 //   phase 2 (dasp_tp_reduce_kernel): one workgroup per row block: y slice in LDS as f64, streams (val, lrow, xs) -- all contiguous -- and
 //       adds val * xs to position lrow with LDS f64 atomics (ds_add_f64: ~4x the rate of ds_add_f32 on gfx950), then stores y once.
 // Pads: val 0, lrow kTpPadRow (skipped), lcol 0.
-constexpr int kTpSeg = 64;            // elements per segment: 128 bytes of f16 / u16
-constexpr int kTpUnitSegs = 1024;     // segments per phase-1 workgroup (64 Ki elements against the 64-KiB x slice it stages)
+#ifndef DASP_TP_SEG
+#define DASP_TP_SEG 64
+#endif
+constexpr int kTpSeg = DASP_TP_SEG;   // elements per segment (64: 128 bytes of f16 / u16; 32 is the other supported size): the unit a tile is padded to and phase 1 places
+constexpr int kTpUnitSegs = 65536 / kTpSeg;     // segments per phase-1 workgroup (64 Ki elements against the 64-KiB x slice it stages)
 constexpr int kTpColBlock = 32768;    // default cb: 64 KiB of LDS, two phase-1 workgroups per CU
 constexpr int kTpRowBlock = 4096;     // default rb_max: 32 KiB of f64 accumulators, five phase-2 workgroups per CU
 constexpr unsigned short kTpPadRow = 0xFFFFu;

@@ -154,7 +154,7 @@ int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val)
     s.rate_fill0 = nnz > 0 ? (double)((long long)S * kTpSeg - nnz) / (double)nnz : 0.0;
     // streamed per SpMV: local columns + xs written (phase 1), values + local rows + xs read (phase 2), the segment map, every unit's slice of x, y
     s.data_X = (long long)S * kTpSeg * (2 + vb + vb + 2 + vb) + (long long)S * 4 + (long long)t.n_units() * (long long)std::min(cb, n) * vb + (long long)m * vb;
-    s.two_phase = 1; s.tp_col_block = cb; s.tp_row_blocks = n_rb; s.tp_units = t.n_units(); s.tp_segments = (long long)S;
+    s.two_phase = 1; s.tp_col_block = cb; s.tp_row_blocks = n_rb; s.tp_units = t.n_units(); s.tp_segments = (long long)S; s.tp_seg_elems = kTpSeg;
     s.pre_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count() + s.pre_ms;
     return DASP_OK;
 }
@@ -197,7 +197,7 @@ bool validate_two_phase(const Plan &p, std::string &why)
         at = s1;
     }
     if (at != S) return fail("units do not cover the segments");
-    if (p.stats.two_phase != 1 || p.stats.tp_segments != S || p.stats.tp_row_blocks != n_rb || p.stats.tp_units != t.n_units() || p.stats.tp_col_block != t.cb) return fail("two-phase counters");
+    if (p.stats.two_phase != 1 || p.stats.tp_segments != S || p.stats.tp_row_blocks != n_rb || p.stats.tp_units != t.n_units() || p.stats.tp_col_block != t.cb || p.stats.tp_seg_elems != kTpSeg) return fail("two-phase counters");
     return true;
 }
 

@@ -221,7 +221,8 @@ typedef struct dasp_stats {
     long long row_tile_nnz;    /* nonzeros stored in row tiles */
     int two_phase;             /* 1: the plan is in the two-phase (gather-free) form (option two_phase) */
     int tp_col_block, tp_row_blocks, tp_units;   /* its columns per column block, row blocks (phase-2 workgroups) and phase-1 workgroups */
-    long long tp_segments;     /* its 64-element segments (padded nonzeros / 64) */
+    long long tp_segments;     /* its segments: stored (padded) elements / tp_seg_elems */
+    int tp_seg_elems;          /* elements per segment (64) */
     /* the REFERENCE's geometry on the same input (8-row blocks, 8x4 tiles, 32-lane warps): the padded sizes the CUDA reference computes
      * and writes into its CSV row for this matrix -- short tiles dasp_f64.h:609-629 / dasp_f16.h:1139-1156, long rows :1000-1014 /
      * :1273-1288, regular / irregular split :1044-1091 / :1317-1365, rate_fill0 and data_X :1159-1166 / dasp_f16.h:1448-1455.  Functions

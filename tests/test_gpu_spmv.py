@@ -1718,9 +1718,9 @@ def test_two_phase_from_a_device_csr_and_a_plan_file(oracle, dasp, torch_cuda, t
     host = dasp.Plan(rp, ci, v, 5000, precision=16, two_phase=1)
     d_rp, d_ci, d_v = torch.from_numpy(rp.astype(np.int32)).cuda(), torch.from_numpy(ci.astype(np.int32)).cuda(), torch.from_numpy(v).cuda()
     dev = dasp.Plan.from_device(d_rp.data_ptr(), d_ci.data_ptr(), d_v.data_ptr(), 6000, 5000, ci.size, precision=16, two_phase=1)
-    S = host.stats["tp_segments"]
+    S, SEG = host.stats["tp_segments"], host.stats["tp_seg_elems"]
     assert dev.stats["two_phase"] == 1 and dev.stats["tp_segments"] == S
-    for name, dt, cnt in (("tp_lcol", np.uint16, S * 64), ("tp_lrow", np.uint16, S * 64), ("tp_val", np.float16, S * 64), ("tp_dst", np.int32, S)):
+    for name, dt, cnt in (("tp_lcol", np.uint16, S * SEG), ("tp_lrow", np.uint16, S * SEG), ("tp_val", np.float16, S * SEG), ("tp_dst", np.int32, S)):
         assert np.array_equal(dev.device_array(name, cnt, dt), host.host_array(name)), name
     xh = np.random.default_rng(6).uniform(0.5, 1.5, 5000).astype(np.float16)
     ref = oracle.csr_spmv(rp, ci, v.astype(np.float64), xh.astype(np.float64))
@@ -1728,13 +1728,13 @@ def test_two_phase_from_a_device_csr_and_a_plan_file(oracle, dasp, torch_cuda, t
     got = run_spmv(torch, dev, xh, 6000, 16)
     assert (np.abs(got - ref[dev.order_rid]) <= 1e-2 * scale[dev.order_rid]).all()
     # phase 1's stream: xs[e] = x[column of element e] for every stored element
-    xs = dev.device_array("tp_xs", S * 64, np.float16)
-    dec_cols = np.full(S * 64, -1, np.int64)
+    xs = dev.device_array("tp_xs", S * SEG, np.float16)
+    dec_cols = np.full(S * SEG, -1, np.int64)
     unit, dst, lcol = host.host_array("tp_unit").reshape(-1, 3), host.host_array("tp_dst"), host.host_array("tp_lcol")
     cb = host.stats["tp_col_block"]
     for c, s0, s1 in unit.tolist():
         for s in range(s0, s1):
-            dec_cols[dst[s] * 64:(dst[s] + 1) * 64] = c * cb + lcol[s * 64:(s + 1) * 64]
+            dec_cols[dst[s] * SEG:(dst[s] + 1) * SEG] = c * cb + lcol[s * SEG:(s + 1) * SEG]
     live = host.host_array("tp_lrow") != 0xFFFF
     assert np.array_equal(xs[live], xh[dec_cols[live]])
     path = str(tmp_path / "tp.plan")

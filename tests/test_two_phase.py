@@ -28,8 +28,8 @@ def test_streams_decode_to_the_csr(dasp, oracle, m, n, seed, cb, rb, natural):
     plan = dasp.Plan(rp, ci, v, n, precision=16, two_phase=1, tp_col_block=cb, tp_row_block=rb, y_order=dasp.Y_NATURAL if natural else dasp.Y_PERMUTED)
     st = plan.stats
     assert st["two_phase"] == 1 and st["n_col_panels"] == 0 and st["tp_col_block"] == (cb or 32768)
-    assert st["fill0_nnz_reg"] == st["tp_segments"] * 64 >= st["nnzA"]
-    assert abs(st["rate_fill0"] - (st["tp_segments"] * 64 - st["nnzA"]) / max(st["nnzA"], 1)) < 1e-12
+    assert st["fill0_nnz_reg"] == st["tp_segments"] * st["tp_seg_elems"] >= st["nnzA"]
+    assert abs(st["rate_fill0"] - (st["tp_segments"] * st["tp_seg_elems"] - st["nnzA"]) / max(st["nnzA"], 1)) < 1e-12
     # the whole-matrix classifier: the reference's counters and permutation do not depend on the form
     P = oracle.Packed(16, rp, ci, v.astype(np.float64), n)
     for f in "row_long row_block row_zero short_row_1 short_row_2 short_row_3 short_row_4 common_13".split():
@@ -48,7 +48,7 @@ def test_row_blocks_balance_the_nonzeros_of_the_sorted_order(dasp):
     rp, ci, v = util.csr_from_lengths(lens, 50000, 4, values="f16", dtype=np.float16)
     plan = dasp.Plan(rp, ci, v, 50000, precision=16, two_phase=1)
     row0, seg0 = plan.host_array("tp_rb_row0"), plan.host_array("tp_rb_seg0")
-    per_block = np.diff(seg0) * 64
+    per_block = np.diff(seg0) * plan.stats["tp_seg_elems"]
     target = max(16384, min(1 << 17, ci.size // 1024 + 1))
     assert per_block.max() <= 2 * target + 3000 + 64 * plan.host_array("tp_unit").reshape(-1, 3)[:, 0].max()      # one row past the target + the tiles' padding
     assert (np.diff(row0) <= 4096).all()

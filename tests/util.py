@@ -50,7 +50,7 @@ def decode_two_phase(plan, x=None):
     and what phase 1 left there.  Returns dict output position -> (cols[], vals[]) in stored order (pads removed), as decode_plan does
     (positions of the plan's y order).  With x: also checks nothing and returns (rows, y) with y accumulated in float64."""
     st = plan.stats
-    SEG = 64
+    SEG = st["tp_seg_elems"]
     cb = st["tp_col_block"]
     S = st["tp_segments"]
     row0, seg0 = plan.host_array("tp_rb_row0"), plan.host_array("tp_rb_seg0")
@@ -61,7 +61,7 @@ def decode_two_phase(plan, x=None):
     gcol = np.full(S * SEG, -1, np.int64)              # phase 1: the global column of every RB-major element
     covered = np.zeros(S, bool)
     for c, s0, s1 in unit.tolist():
-        assert 0 < s1 - s0 <= 1024
+        assert 0 < s1 - s0 <= 65536 // SEG
         for s in range(s0, s1):
             assert not covered[s]
             covered[s] = True
