@@ -21,12 +21,12 @@ for g in "${groups[@]}"; do
   i=$((i+1))
 done
 python3 - "$out" <<'PY' > "$root/gpurun_out/pmc_$tag.txt"
-import csv,glob,sys,collections
+import csv,glob,sys,collections,os
 out=sys.argv[1]
 agg=collections.defaultdict(list); dur=[]
 for f in glob.glob(out+"/g*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "dasp_spmv" in r["Kernel_Name"]:
+        if any(k in r["Kernel_Name"] for k in os.environ.get("DASP_PMC_KERNELS", "dasp_spmv").split(",")):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             dur.append(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))
 print("dispatch duration under PMC: median %.1f us over %d" % (sorted(dur)[len(dur)//2]/1e3, len(dur)))

@@ -13,12 +13,13 @@ else:
     subprocess.check_call([sys.executable, "tools/traffic_collect.py"], stdout=subprocess.DEVNULL)
 rows = list(csv.DictReader(open(glob.glob("gpurun_out/round_end_prof/*/*kernel_stats.csv")[0])))
 line = [x for x in open("gpurun_out/round_end_prof.log") if x.startswith('{"metric')][-1].strip()
-d = json.loads(line)
+# r5: the stdout line is the compact driver record; the full record of the same run is the side file (bench.py emit())
+d = json.load(open("gpurun_out/round_end_prof_suite.json")) if os.path.exists("gpurun_out/round_end_prof_suite.json") else json.loads(line)
 hv = [e for e in json.load(open("profiles/traffic.json")) if e["workload"] == "HV15R"][0]
 r = d["roofline"]
 out = ["# Round " + ROUND[1:].lstrip("0") + " profile of the bench command -- HV15R stand-in (2 017 169 rows, 275 454 726 nnz, f64), MI355X\n",
        "Source: `cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-suite --no-vendor --steps 20` (kernel trace + stats only; the\n"
-       "`--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes are separate runs of `dasp_bench HV15R 1 64 20 3`, `profiles/r04_traffic.md`), kernel sources at `kernel_rev %s`\n"
+       "`--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes are separate runs of `dasp_bench HV15R 1 64 20 3`, `profiles/" + ROUND + "_traffic.md`), kernel sources at `kernel_rev %s`\n"
        "(= `profiles/traffic.json`); all of it one batch on one box (`tools/round_end.sh`, `tools/round_end_collect.py`).  The %s profiled launches include the 200 back-to-back\n"
        "launches behind `roofline.kernel_ms`, the 200 timed one by one for the spread (`launch_ms_*`), those of the random-values plan and those against the six y candidates (`config.placement`); the profiled average below (%.1f us over\n"
        "all of them) and the bench line's own `kernel_ms` of the same process (%.1f us; single launches min %.1f / p10 %.1f / median %.1f / p90 %.1f / max %.1f, each including the\n"
@@ -30,13 +31,17 @@ for q in rows[:5]:
     out.append("| %s | %s | %.0f | %s | %s | %s |" % (q["Name"][:80], q["Calls"], float(q["AverageNs"]), q["MinNs"], q["MaxNs"], q["Percentage"]))
 avg = float(rows[0]["AverageNs"])
 out.append("\nRecomputed roofline fraction from the profile: %d B algorithmic / %.0f ns / 8 TB/s = **%.3f** (bench line: %.4f); counter traffic per launch %.4f GB = %.3f x algorithmic\n"
-           "(`profiles/r04_traffic.md`: FETCH_SIZE %.4f GB raw x 2 + WRITE_SIZE %.2f MB), i.e. %.2f TB/s of real traffic.\n" %
+           "(`profiles/" + ROUND + "_traffic.md`: FETCH_SIZE %.4f GB raw x 2 + WRITE_SIZE %.2f MB), i.e. %.2f TB/s of real traffic.\n" %
            (r["algorithmic_bytes_per_launch"], avg, r["algorithmic_bytes_per_launch"] / avg / 8000, r["frac"], hv["traffic_bytes"] / 1e9,
             hv["traffic_bytes"] / r["algorithmic_bytes_per_launch"], hv["fetch_size_bytes_raw"] / 1e9, hv["write_size_bytes"] / 1e6, hv["traffic_bytes"] / avg / 1e3))
 out.append("## bench.py's JSON line of the profiled run\n\n```\n%s\n```" % line)
 open("profiles/%s_hv15r_f64.md" % ROUND, "w").write("\n".join(out) + "\n")
 full = [x for x in open("gpurun_out/round_end_bench.json.log") if x.startswith("{")][-1]
 D = json.loads(full)
+if os.path.exists("gpurun_out/round_end_bench_suite.json"):      # r5: compact line on stdout (kept as <ROUND>_bench_line.json.log), full record beside it
+    open("profiles/%s_bench_line.json.log" % ROUND, "w").write(full)
+    D = json.load(open("gpurun_out/round_end_bench_suite.json"))
+    full = json.dumps(D) + "\n"
 slow = D["roofline"]["frac"] < 0.94                      # the two box populations: ~0.90-0.91 and ~0.97-0.98 on the HV15R headline
 open("profiles/%s_bench_full.json.log" % ROUND, "w").write(full)
 print("bench record -> %s box: %.4f ms, frac %.4f, traffic/alg %s" % ("slow" if slow else "fast", D["ms_per_step"], D["roofline"]["frac"], D["roofline"].get("traffic_over_algorithmic")))
