@@ -42,7 +42,7 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPla
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const DevArgs a = load_args(c);
-    spmv_body<T, NT, C16, WIN, C8>(a, lds_raw);
+    spmv_body<T, NT, C16, WIN, C8>(a, lds_raw, blockIdx.x);
 }
 
 // a column panel with row tiles (Plan::rt_*): the non-windowed kernel + the tiles' workgroup range, dynamic LDS = 4 waves x 64 x rt_max products
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 7 : kMinWavesPlain) void dasp
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const DevArgs a = load_args(c);
-    spmv_body<T, NT, C16, false, false, true>(a, lds_raw);
+    spmv_body<T, NT, C16, false, false, true>(a, lds_raw, blockIdx.x);
 }
 
 // the windowed kernel for plans with at most one window workgroup per CU (n_windows <= CUs: cop20k_A's 212): nothing is gained by
@@ -65,7 +65,39 @@ __global__ __launch_bounds__(1024, 4) void dasp_spmv_win1_kernel(CallArgs c)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const DevArgs a = load_args(c);
-    spmv_body<T, false, C16, true, false>(a, lds_raw);
+    spmv_body<T, false, C16, true, false>(a, lds_raw, blockIdx.x);
+}
+
+// ---- all column panels of a plan in ONE launch (r5): the panels' grids back to back in one grid -- panel = a range of blockIdx.x, as the
+// row categories are inside a panel (and as the reference ranges its categories: dasp_f64.h:1194-1212) -- so that the stream carries one launch + one
+// stage 2 + the sum instead of 2 P + 1 launches with P tails.  Every panel keeps its own device-resident DevArgs; the kernel picks the pointer by range
+// (constant indices + scalar selects: a run-time index into the kernarg arrays would copy them to scratch).
+constexpr int kMaxMergedPanels = 8;
+struct PanelCall {
+    const DevArgs *plan[kMaxMergedPanels];
+    int wg_end[kMaxMergedPanels];          // end of panel k's workgroup range (spmv launch) / of its stage-2 range (long_reduce launch)
+    const void *x; char *part; size_t stride_bytes; int np;
+};
+__device__ __forceinline__ CallArgs panel_of(const PanelCall &c, int &wg)
+{
+    int k = 0, first = 0;
+    const DevArgs *p = c.plan[0];
+#pragma unroll
+    for (int i = 1; i < kMaxMergedPanels; ++i) {
+        const bool in = i < c.np && (int)blockIdx.x >= c.wg_end[i - 1];
+        k = in ? i : k; first = in ? c.wg_end[i - 1] : first; p = in ? c.plan[i] : p;
+    }
+    wg = (int)blockIdx.x - first;
+    return CallArgs{p, c.x, c.part + (size_t)k * c.stride_bytes, 0, 0};
+}
+template <class T, bool NT, bool C16>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 7 : kMinWavesPlain) void dasp_spmv_panels_kernel(PanelCall c)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    int wg;
+    const CallArgs ca = panel_of(c, wg);
+    const DevArgs a = load_args(ca);
+    spmv_body<T, NT, C16, false, false, true>(a, lds_raw, wg);
 }
 
 // stage 2 for long rows cut into several pieces (reference: longPart_sum, dasp_f64.h:53-75)
@@ -76,6 +108,23 @@ __global__ __launch_bounds__(256) void dasp_long_reduce_kernel(CallArgs c)
     using part_t = typename Tr<T>::part_t;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * kWavesPerWG + (threadIdx.x >> 6);
+    if (i >= a.n_multi) return;
+    const int q0 = a.multi_ptr[i], q1 = a.multi_ptr[i + 1];
+    const part_t *part = static_cast<const part_t *>(a.partial);
+    part_t s = 0;
+    for (int q = q0 + lane; q < q1; q += kWave) s += part[q];
+    s = wave_sum(s);
+    if (lane == 0) put_y<T>(a, a.multi_dst[i], s);
+}
+template <class T>
+__global__ __launch_bounds__(256) void dasp_long_reduce_panels_kernel(PanelCall c)
+{
+    using part_t = typename Tr<T>::part_t;
+    int wg;
+    const CallArgs ca = panel_of(c, wg);
+    const DevArgs a = load_args(ca);
+    const int lane = threadIdx.x & 63;
+    const int i = wg * kWavesPerWG + (threadIdx.x >> 6);
     if (i >= a.n_multi) return;
     const int q0 = a.multi_ptr[i], q1 = a.multi_ptr[i + 1];
     const part_t *part = static_cast<const part_t *>(a.partial);
@@ -323,6 +372,47 @@ int tp_kernels_allow_lds()
     return DASP_OK;
 }
 
+// the panels of a column-panel plan in one launch (+ one stage-2 launch when some panel cut a long row).  DASP_OK, an error, or 1 when the panels
+// cannot share one instantiation of the kernel (windows, one-byte ids, mixed id widths, more than kMaxMergedPanels) or DASP_PANELS_MERGED=0 asks for the old form
+template <class T>
+static int launch_panels_merged_typed(Plan &p, const void *dX, char *part, size_t stride_bytes, hipStream_t s)
+{
+    const int np = (int)p.panels.size();
+    PanelCall c{}, r{};
+    c.x = dX; c.part = part; c.stride_bytes = stride_bytes; c.np = np;
+    int grid = 0, grid2 = 0, rt_max = 0;
+    const Plan &p0 = p.panels[0]->impl;
+    for (int k = 0; k < np; ++k) {
+        Plan &q = p.panels[(size_t)k]->impl;
+        if (!q.dev || !q.dev->arena || q.windowed || q.two_phase || !q.panels.empty() || q.cnt_reg8 > 0 || q.cid16 != p0.cid16 || q.dev->nt != p0.dev->nt || q.dev->args.med_stride != p0.dev->args.med_stride) return 1;
+        if (int rc = sync_dev_args(q)) return rc;
+        const DevArgs &a = q.dev->args;
+        grid += a.wg_long + a.wg_med + a.wg_short + a.wg_rt;
+        grid2 += (a.n_multi + kWavesPerWG - 1) / kWavesPerWG;
+        rt_max = std::max(rt_max, a.wg_rt > 0 ? a.rt_max : 0);
+        c.plan[k] = static_cast<const DevArgs *>(q.dev->dargs); c.wg_end[k] = grid;
+        r.plan[k] = c.plan[k]; r.wg_end[k] = grid2;
+    }
+    r.x = dX; r.part = part; r.stride_bytes = stride_bytes; r.np = np;
+    const size_t lds = (size_t)kWavesPerWG * kRowTile * (size_t)rt_max * sizeof(typename Tr<T>::part_t);
+    const bool nt = p0.dev->nt, c16 = p0.cid16;
+    if (grid > 0) {
+        if (nt && c16) hipLaunchKernelGGL((dasp_spmv_panels_kernel<T, true, true>), dim3(grid), dim3(256), lds, s, c);
+        else if (nt) hipLaunchKernelGGL((dasp_spmv_panels_kernel<T, true, false>), dim3(grid), dim3(256), lds, s, c);
+        else if (c16) hipLaunchKernelGGL((dasp_spmv_panels_kernel<T, false, true>), dim3(grid), dim3(256), lds, s, c);
+        else hipLaunchKernelGGL((dasp_spmv_panels_kernel<T, false, false>), dim3(grid), dim3(256), lds, s, c);
+    }
+    if (grid2 > 0) hipLaunchKernelGGL((dasp_long_reduce_panels_kernel<T>), dim3(grid2), dim3(256), 0, s, r);
+    HIP_TRY(hipGetLastError());
+    return DASP_OK;
+}
+static int launch_panels_merged(Plan &p, const void *dX, char *part, size_t stride_bytes, hipStream_t s)
+{
+    static const bool off = [] { const char *e = std::getenv("DASP_PANELS_MERGED"); return e && std::atoi(e) == 0; }();      // A/B knob
+    if (off || p.panels.empty() || p.panels.size() > (size_t)kMaxMergedPanels) return 1;
+    return p.precision == 64 ? launch_panels_merged_typed<double>(p, dX, part, stride_bytes, s) : launch_panels_merged_typed<_Float16>(p, dX, part, stride_bytes, s);
+}
+
 int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate)
 {
     if (!p.dev || !p.dev->arena) { set_error("plan not uploaded"); return DASP_ERR_STATE; }
@@ -340,9 +430,12 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate
     if (!p.panels.empty()) {
         const size_t vb = (size_t)p.geo.vbytes, stride = p.dev->ypart_stride;
         char *part = static_cast<char *>(p.dev->arena);
-        for (size_t k = 0; k < p.panels.size(); ++k)
-            if (int rc = launch_spmv(p.panels[k]->impl, dX, part + k * stride * vb, stream, false)) return rc;
         hipStream_t s = static_cast<hipStream_t>(stream);
+        if (int rc = launch_panels_merged(p, dX, part, stride * vb, s)) {
+            if (rc != 1) return rc;          // 1: the panels do not share one kernel instantiation -- one launch (+ stage 2) per panel, as before r5
+            for (size_t k = 0; k < p.panels.size(); ++k)
+                if (int rc2 = launch_spmv(p.panels[k]->impl, dX, part + k * stride * vb, stream, false)) return rc2;
+        }
         const int np = (int)p.panels.size(), m = p.m;
         const bool wide = (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
         if (m > 0) {

@@ -824,11 +824,11 @@ constexpr int kMinWavesPlain = DASP_MIN_WAVES, kMinWavesWin = 8;
 // 4 waves); if the window's x span fits, it is copied once into LDS with coalesced 16-byte loads and every gather of
 // the window reads LDS; otherwise that workgroup gathers from global memory like the non-windowed kernel.
 template <class T, bool NT, bool C16, bool WIN, bool C8, bool RT = false>
-__device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw)
+__device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw, int wg_index)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wg = blockIdx.x;
+    const int wg = wg_index;          // blockIdx.x, or the workgroup's index inside its panel's range of a merged launch (dasp_spmv_panels_kernel)
     const int wpw = WIN ? a.wpw : kWavesPerWG;
     if (wg < a.wg_long) {
         const int p = wg * wpw + wave;

@@ -1424,21 +1424,23 @@ def test_column_panels_multi_gpu_layout_and_file(oracle, dasp, torch_cuda, tmp_p
         pl.close()
 
 
-@pytest.mark.parametrize("name,prec", [("powerlaw_1M", 64), ("ljournal-2008", 16), ("rmat_2M", 16)])
-def test_device_csr_takes_the_same_automatic_panel_decision(dasp, torch_cuda, name, prec):
+@pytest.mark.parametrize("name,prec,kw,form", [("powerlaw_1M", 64, {}, "panels"), ("ljournal-2008", 16, {}, "two_phase"), ("ljournal-2008", 16, {"two_phase": -1}, "panels"),
+                                                ("rmat_2M", 16, {}, "plain")])
+def test_device_csr_takes_the_same_automatic_panel_decision(dasp, torch_cuda, name, prec, kw, form):
     """the AUTOMATIC column-panel rule on a device-resident CSR (r3): the sampled rows' columns and the strided sample of column ids
-    are gathered by a kernel, the rule is the host's -- same number of panels, same counters, same y, at BASELINE's full size"""
+    are gathered by a kernel, the rule is the host's -- same number of panels, same counters, same y, at BASELINE's full size.  r5: where the rule fires
+    on an f16 matrix without hub rows the plan takes the two-phase form instead (ljournal-2008; two_phase = -1 keeps the panels); rmat_2M's hot columns keep it plain"""
     torch = torch_cuda
     rows, cols = dasp.synth_dims(name, 1.0)
     rp, ci = dasp.synth_csr(name, 1.0)
     dt = np.float64 if prec == 64 else np.float16
     v = np.ones(ci.size, dt)
-    host = dasp.Plan(rp, ci, v, cols, precision=prec)
+    host = dasp.Plan(rp, ci, v, cols, precision=prec, **kw)
     d_rp, d_ci, d_v = torch.from_numpy(rp).cuda(), torch.from_numpy(ci).cuda(), torch.from_numpy(v).cuda()
-    dev = dasp.Plan.from_device(d_rp.data_ptr(), d_ci.data_ptr(), d_v.data_ptr(), rows, cols, int(rp[-1]), precision=prec)
+    dev = dasp.Plan.from_device(d_rp.data_ptr(), d_ci.data_ptr(), d_v.data_ptr(), rows, cols, int(rp[-1]), precision=prec, **kw)
     hs, ds = host.stats, dev.stats
     hs.pop("pre_ms"), ds.pop("pre_ms")
-    assert hs == ds and (hs["n_col_panels"] >= 2) == (name != "rmat_2M")
+    assert hs == ds and (hs["n_col_panels"] >= 2) == (form == "panels") and hs["two_phase"] == (form == "two_phase")
     assert (host.order_rid == dev.order_rid).all()
     x = np.ones(cols, dt)
     y_d = run_spmv(torch, dev, x, rows, prec)
