@@ -18,20 +18,20 @@ d = json.load(open("gpurun_out/round_end_prof_suite.json")) if os.path.exists("g
 hv = [e for e in json.load(open("profiles/traffic.json")) if e["workload"] == "HV15R"][0]
 r = d["roofline"]
 out = ["# Round " + ROUND[1:].lstrip("0") + " profile of the bench command -- HV15R stand-in (2 017 169 rows, 275 454 726 nnz, f64), MI355X\n",
-       "Source: `cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-suite --no-vendor --steps 20` (kernel trace + stats only; the\n"
+       ("Source: `cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-suite --no-vendor --steps 20` (kernel trace + stats only; the\n"
        "`--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes are separate runs of `dasp_bench HV15R 1 64 20 3`, `profiles/" + ROUND + "_traffic.md`), kernel sources at `kernel_rev %s`\n"
-       "(= `profiles/traffic.json`); all of it one batch on one box (`tools/round_end.sh`, `tools/round_end_collect.py`).  The %s profiled launches include the 200 back-to-back\n"
+       "(= `profiles/traffic.json`); all of it one batch on one box (`tools/round_end_r5.sh`, `tools/round_end_collect.py`).  The %s profiled launches include the 200 back-to-back\n"
        "launches behind `roofline.kernel_ms`, the 200 timed one by one for the spread (`launch_ms_*`), those of the random-values plan and those against the six y candidates (`config.placement`); the profiled average below (%.1f us over\n"
        "all of them) and the bench line's own `kernel_ms` of the same process (%.1f us; single launches min %.1f / p10 %.1f / median %.1f / p90 %.1f / max %.1f, each including the\n"
-       "event between two kernels) agree.\n" % (hv["kernel_rev"], rows[0]["Calls"], float(rows[0]["AverageNs"]) / 1e3, r["kernel_ms"] * 1e3, r["launch_ms_min"] * 1e3,
+       "event between two kernels) agree.\n") % (hv["kernel_rev"], rows[0]["Calls"], float(rows[0]["AverageNs"]) / 1e3, r["kernel_ms"] * 1e3, r["launch_ms_min"] * 1e3,
                                             r["launch_ms_p10"] * 1e3, r["launch_ms_median"] * 1e3, r["launch_ms_p90"] * 1e3, r["launch_ms_max"] * 1e3),
        "## rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-suite --no-vendor --steps 20\n",
        "| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|"]
 for q in rows[:5]:
     out.append("| %s | %s | %.0f | %s | %s | %s |" % (q["Name"][:80], q["Calls"], float(q["AverageNs"]), q["MinNs"], q["MaxNs"], q["Percentage"]))
 avg = float(rows[0]["AverageNs"])
-out.append("\nRecomputed roofline fraction from the profile: %d B algorithmic / %.0f ns / 8 TB/s = **%.3f** (bench line: %.4f); counter traffic per launch %.4f GB = %.3f x algorithmic\n"
-           "(`profiles/" + ROUND + "_traffic.md`: FETCH_SIZE %.4f GB raw x 2 + WRITE_SIZE %.2f MB), i.e. %.2f TB/s of real traffic.\n" %
+out.append(("\nRecomputed roofline fraction from the profile: %d B algorithmic / %.0f ns / 8 TB/s = **%.3f** (bench line: %.4f); counter traffic per launch %.4f GB = %.3f x algorithmic\n"
+           "(`profiles/" + ROUND + "_traffic.md`: FETCH_SIZE %.4f GB raw x 2 + WRITE_SIZE %.2f MB), i.e. %.2f TB/s of real traffic.\n") %
            (r["algorithmic_bytes_per_launch"], avg, r["algorithmic_bytes_per_launch"] / avg / 8000, r["frac"], hv["traffic_bytes"] / 1e9,
             hv["traffic_bytes"] / r["algorithmic_bytes_per_launch"], hv["fetch_size_bytes_raw"] / 1e9, hv["write_size_bytes"] / 1e6, hv["traffic_bytes"] / avg / 1e3))
 out.append("## bench.py's JSON line of the profiled run\n\n```\n%s\n```" % line)
