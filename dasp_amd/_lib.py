@@ -26,7 +26,7 @@ class Options(C.Structure):
         ("x_window", C.c_int), ("row_window", C.c_int), ("cid16", C.c_int), ("stream_policy", C.c_int),
         ("col_panels", C.c_int), ("slab_max_len", C.c_int), ("x_window_hybrid", C.c_int), ("piece_min_len", C.c_int),
         ("chunk_pairs", C.c_int), ("cid8", C.c_int), ("short_seg", C.c_int), ("row_tile_max", C.c_int), ("sort_columns", C.c_int),
-        ("two_phase", C.c_int), ("tp_col_block", C.c_int), ("tp_row_block", C.c_int),
+        ("two_phase", C.c_int), ("tp_col_block", C.c_int), ("tp_row_block", C.c_int), ("long_cb", C.c_int),
     ]
 
 
@@ -43,6 +43,7 @@ class Stats(C.Structure):
         ("n_col_panels", C.c_int), ("x_window_hybrid", C.c_int), ("med_rows_as_pieces", C.c_int), ("chunk_pairs", C.c_int), ("cid8_chunks", C.c_int), ("short_seg", C.c_int),
         ("row_tile_max", C.c_int), ("n_row_tiles", C.c_int), ("row_tile_nnz", C.c_longlong),
         ("two_phase", C.c_int), ("tp_col_block", C.c_int), ("tp_row_blocks", C.c_int), ("tp_units", C.c_int), ("tp_segments", C.c_longlong), ("tp_seg_elems", C.c_int),
+        ("lcb_rows", C.c_int), ("lcb_col_block", C.c_int), ("lcb_units", C.c_int), ("lcb_elems", C.c_longlong),
         ("ref_fill0_nnz_short", C.c_longlong), ("ref_fill0_nnz_long", C.c_longlong), ("ref_fill0_nnz_reg", C.c_longlong), ("ref_data_X", C.c_longlong),
         ("ref_nnz_irreg", C.c_int), ("ref_origin_nnz_reg", C.c_int), ("ref_blocknum", C.c_int), ("ref_warp_number", C.c_int), ("ref_rate_fill0", C.c_double)]
 

@@ -87,7 +87,7 @@ class Plan:
     def __init__(self, csrRowPtr, csrColIdx, csrVal, colA, precision=64, threshold=0.75, block_longest=256,
                  y_order=Y_PERMUTED, long_piece=0, host_threads=0, part_bounds=None, part_stride=0, x_window=0, row_window=0, cid16=0, stream_policy=0,
                  col_panels=0, slab_max_len=0, x_window_hybrid=0, piece_min_len=0, chunk_pairs=0, cid8=0, short_seg=0, row_tile_max=0, sort_columns=0,
-                 two_phase=0, tp_col_block=0, tp_row_block=0):
+                 two_phase=0, tp_col_block=0, tp_row_block=0, long_cb=0):
         L = _lib.lib()
         self.precision = precision
         dt = _dtype(precision)
@@ -102,7 +102,7 @@ class Plan:
         opt.x_window, opt.row_window, opt.cid16, opt.stream_policy = x_window, row_window, cid16, stream_policy
         opt.col_panels, opt.slab_max_len, opt.x_window_hybrid, opt.piece_min_len = col_panels, slab_max_len, x_window_hybrid, piece_min_len
         opt.chunk_pairs, opt.cid8, opt.short_seg, opt.row_tile_max, opt.sort_columns = chunk_pairs, cid8, short_seg, row_tile_max, sort_columns
-        opt.two_phase, opt.tp_col_block, opt.tp_row_block = two_phase, tp_col_block, tp_row_block
+        opt.two_phase, opt.tp_col_block, opt.tp_row_block, opt.long_cb = two_phase, tp_col_block, tp_row_block, long_cb
         self._pb = None
         if part_bounds is not None:
             self._pb = np.ascontiguousarray(part_bounds, np.int32)
@@ -117,7 +117,7 @@ class Plan:
     @classmethod
     def from_device(cls, d_row_ptr, d_col_idx, d_val, rowA, colA, nnzA, precision=64, threshold=0.75, block_longest=256,
                     y_order=Y_PERMUTED, long_piece=0, part_bounds=None, part_stride=0, x_window=0, row_window=0, cid16=0, col_panels=0, slab_max_len=0,
-                    x_window_hybrid=0, piece_min_len=0, chunk_pairs=0, cid8=0, short_seg=0, row_tile_max=0, sort_columns=0, two_phase=0, tp_col_block=0, tp_row_block=0):
+                    x_window_hybrid=0, piece_min_len=0, chunk_pairs=0, cid8=0, short_seg=0, row_tile_max=0, sort_columns=0, two_phase=0, tp_col_block=0, tp_row_block=0, long_cb=0):
         """Plan from a CSR that already lives on the GPU (integer device addresses): packed by kernels, comes back uploaded."""
         L = _lib.lib()
         self = cls.__new__(cls)
@@ -128,7 +128,7 @@ class Plan:
         opt.x_window, opt.row_window, opt.cid16, opt.col_panels = x_window, row_window, cid16, col_panels
         opt.slab_max_len, opt.x_window_hybrid, opt.piece_min_len = slab_max_len, x_window_hybrid, piece_min_len
         opt.chunk_pairs, opt.cid8, opt.short_seg, opt.row_tile_max, opt.sort_columns = chunk_pairs, cid8, short_seg, row_tile_max, sort_columns
-        opt.two_phase, opt.tp_col_block, opt.tp_row_block = two_phase, tp_col_block, tp_row_block
+        opt.two_phase, opt.tp_col_block, opt.tp_row_block, opt.long_cb = two_phase, tp_col_block, tp_row_block, long_cb
         self._pb = None
         if part_bounds is not None:
             self._pb = np.ascontiguousarray(part_bounds, np.int32)
@@ -202,7 +202,7 @@ class Plan:
         n = _lib.lib().dasp_plan_host_array(self._h, name.encode(), C.byref(ptr), C.byref(eb))
         if n < 0:
             _lib.check(int(n))
-        if name in ("med_cid16", "rt_start", "tp_lrow", "tp_lcol"):
+        if name in ("med_cid16", "rt_start", "tp_lrow", "tp_lcol", "lcb_lcol"):
             dt = np.uint16
         elif name == "rt_mask":
             dt = np.uint64

@@ -223,7 +223,7 @@ static long long host_array_impl(const dasp_plan_t *plan, const char *name, cons
     // the nnz-sized arrays exist on the host only until dasp_plan_drop_host (never, for a plan packed on the device);
     // the O(rows) arrays and order_rid always do
     static const char *const kBulk[] = {"long_val", "long_cid", "med_val", "med_cid", "med_cid16", "med_cid8", "irr_val", "irr_cid", "short_val", "short_cid", "rt_val", "rt_cid",
-                                        "tp_val", "tp_lrow", "tp_lcol", "tp_dst"};
+                                        "tp_val", "tp_lrow", "tp_lcol", "tp_dst", "lcb_val", "lcb_lcol"};
     if (p.host_dropped)
         for (const char *b : kBulk)
             if (std::strcmp(name, b) == 0) { set_error("host copy of this array was dropped (use dasp_plan_download_array)"); return DASP_ERR_STATE; }
@@ -264,6 +264,12 @@ static long long host_array_impl(const dasp_plan_t *plan, const char *name, cons
     if (n == "rt_ptr") return ints(p.rt_ptr);
     if (n == "rt_start") { *ptr = p.rt_start.data(); *elem_bytes = 2; return (long long)p.rt_start.size(); }
     if (n == "rt_mask") { *ptr = p.rt_mask.data(); *elem_bytes = 8; return (long long)p.rt_mask.size(); }
+    if (n == "lcb_row_dst") return ints(p.lcb.row_dst);
+    if (n == "lcb_row_id") return ints(p.lcb.row_id);
+    if (n == "lcb_ptr") return ints(p.lcb.ptr);
+    if (n == "lcb_unit") return ints(p.lcb.unit);
+    if (n == "lcb_val") return vals(p.lcb.val);
+    if (n == "lcb_lcol") { *ptr = p.lcb.lcol.data(); *elem_bytes = 2; return (long long)p.lcb.lcol.size(); }
     if (n == "tp_rb_row0") return ints(p.tp.rb_row0);
     if (n == "tp_rb_seg0") return ints(p.tp.rb_seg0);
     if (n == "tp_unit") return ints(p.tp.unit);
@@ -308,6 +314,7 @@ int dasp_plan_drop_host(dasp_plan_t *plan)
     auto dropi = [](raw_vector<int> &v) { raw_vector<int>().swap(v); };
     dropc(p.long_val); dropi(p.long_cid); dropc(p.med_val); dropi(p.med_cid); raw_vector<uint16_t>().swap(p.med_cid16); raw_vector<uint8_t>().swap(p.med_cid8);
     dropc(p.irr_val); dropi(p.irr_cid); dropc(p.short_val); dropi(p.short_cid); dropc(p.rt_val); dropi(p.rt_cid);
+    dropc(p.lcb.val); raw_vector<uint16_t>().swap(p.lcb.lcol);
     dropc(p.tp.val); raw_vector<uint16_t>().swap(p.tp.lrow); raw_vector<uint16_t>().swap(p.tp.lcol); std::vector<int>().swap(p.tp.dst);
     p.host_dropped = true;
     for (auto &h : p.panels) if (int rc = dasp_plan_drop_host(h.get())) return rc;

@@ -66,6 +66,12 @@ struct TpDev {
     int n_units, n_rb, cb, rb_max, xlen, m;
 };
 
+// column-blocked long rows of a column-panel parent (plan.hpp struct LongCB): device pointers into the parent's arena
+struct LcbDev {
+    const void *val; const unsigned short *lcol; const int *ptr; const int *unit; const int *row_dst; void *partial;
+    int n_units, n_rows, n_cb, cb, xlen;
+};
+
 // byte offsets of the nnz-sized arrays inside the arena (devpack.hip writes them, tests download them)
 struct ArenaMap {
     size_t long_val = 0, long_cid = 0, med_val = 0, med_cid = 0, med_cid16 = 0, med_cid8 = 0, med_base = 0, irr_val = 0, irr_cid = 0,
@@ -84,6 +90,7 @@ struct DevicePlan {
     ArenaMap map{};
     DevArgs args{};
     TpDev tp{};             // Plan::two_phase: the arena holds the tile streams, `args` is unused
+    LcbDev lcb{};           // a column-panel parent with column-blocked long rows: its arrays follow the partial-result buffers in the arena
     bool nt = false;
     bool win1 = false;      // windowed plan with at most one window workgroup per CU: launch dasp_spmv_win1_kernel
     int device = -1;

@@ -247,6 +247,86 @@ __global__ __launch_bounds__(512) void dasp_tp_reduce_kernel(TpDev a, T *__restr
     else for (int i = threadIdx.x; i < rows; i += 512) y[p0 + i] = (T)(float)yl[i];
 }
 
+// ------------------------------------------------------------------ column-blocked long rows of a column-panel plan (plan.hpp struct LongCB)
+// One workgroup (1024 threads) per unit: the column block's slice of x -> LDS, then one wave per (row, block) piece: value x LDS-x, 16 bytes of values per lane
+// and step, wave sum -> partial[piece].  Pads carry local column 0xFFFF and never touch x.
+template <class T>
+__global__ __launch_bounds__(1024) void dasp_lcb_kernel(LcbDev a, const T *__restrict__ x)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    using part_t = typename Tr<T>::part_t;
+    constexpr int A = 16 / (int)sizeof(T);
+    typedef T vecA __attribute__((ext_vector_type(A)));
+    typedef unsigned short colA __attribute__((ext_vector_type(A)));
+    T *xl = reinterpret_cast<T *>(lds_raw);
+    const int u = blockIdx.x;
+    const int c = a.unit[3 * u], q0 = a.unit[3 * u + 1], q1 = a.unit[3 * u + 2];
+    const int c0 = c * a.cb, len = min(a.cb, a.xlen - c0);
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        for (int i = threadIdx.x * A; i < len; i += 1024 * A) {
+            if (i + A <= len) *reinterpret_cast<vecA *>(xl + i) = *reinterpret_cast<const vecA *>(x + c0 + i);
+            else for (int j = i; j < len; ++j) xl[j] = x[c0 + j];
+        }
+    } else for (int i = threadIdx.x; i < len; i += 1024) xl[i] = x[c0 + i];
+    __syncthreads();
+    // the unit's steps, wave-strided (f64: a wave per step of 128 elements; f16: a quarter wave per step, four steps per wave instruction): every step's loads are
+    // independent of every other's -- no per-piece chain of latencies (one wave per piece ran at 2.4 TB/s however far its loop was unrolled) -- and its sum is
+    // parked in LDS; afterwards one thread per piece adds the piece's step sums in order: no atomics, the same bits in every run
+    constexpr int G = kLcbStep / A;                       // lanes per step: 64 (f64) / 16 (f16)
+    constexpr int SPW = 64 / G;                           // steps per wave instruction
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane / G, l = lane % G;
+    part_t *stepsum = reinterpret_cast<part_t *>(lds_raw + (((size_t)a.cb * sizeof(T) + 15) & ~size_t(15)));
+    const int np = q1 - q0;
+    const T *val = static_cast<const T *>(a.val);
+    const int S0 = a.ptr[q0] / kLcbStep, S1 = a.ptr[q1] / kLcbStep;
+    constexpr int U = 4;                                  // steps in flight per lane group: all their loads are issued before the first product
+    for (int sb = S0 + wave * SPW * U; sb < S1; sb += 16 * SPW * U) {
+        vecA v[U]; colA lc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int st = min(sb + u * SPW + g, S1 - 1);          // (a step past the end re-reads the last one; its sum is dropped below)
+            const size_t e = (size_t)st * kLcbStep + (size_t)l * A;
+            v[u] = __builtin_nontemporal_load(reinterpret_cast<const vecA *>(val + e));
+            lc[u] = __builtin_nontemporal_load(reinterpret_cast<const colA *>(a.lcol + e));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            part_t s = 0;
+#pragma unroll
+            for (int j = 0; j < A; ++j) {
+                const T xv = xl[lc[u][j] == kLcbPadCol ? 0 : lc[u][j]];
+                s += lc[u][j] == kLcbPadCol ? (part_t)0 : (part_t)v[u][j] * (part_t)xv;
+            }
+            if constexpr (G == 64) s = wave_sum(s);
+            else if constexpr (sizeof(part_t) == 8) { s += dpp_mov_f64<0x128>(s); s += dpp_mov_f64<0x124>(s); s += dpp_mov_f64<0x122>(s); s += dpp_mov_f64<0x121>(s); }
+            else { s += dpp_mov_f32<0x128>(s); s += dpp_mov_f32<0x124>(s); s += dpp_mov_f32<0x122>(s); s += dpp_mov_f32<0x121>(s); }
+            if (l == 0 && sb + u * SPW + g < S1) stepsum[sb + u * SPW + g - S0] = s;
+        }
+    }
+    __syncthreads();
+    part_t *partial = static_cast<part_t *>(a.partial);
+    for (int i = threadIdx.x; i < np; i += 1024) {
+        part_t s = 0;
+        for (int st = a.ptr[q0 + i] / kLcbStep - S0, se = a.ptr[q0 + i + 1] / kLcbStep - S0; st < se; ++st) s += stepsum[st];
+        partial[q0 + i] = s;
+    }
+}
+// one wave per long row: its n_cb partial sums -> the row's slot of panel 0's partial buffer (no panel writes it: the row is empty there)
+template <class T>
+__global__ __launch_bounds__(256) void dasp_lcb_reduce_kernel(LcbDev a, T *__restrict__ part0)
+{
+    using part_t = typename Tr<T>::part_t;
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kWavesPerWG + (threadIdx.x >> 6);
+    if (i >= a.n_rows) return;
+    const part_t *partial = static_cast<const part_t *>(a.partial);
+    part_t s = 0;
+    for (int c = lane; c < a.n_cb; c += kWave) s += partial[(size_t)c * (size_t)a.n_rows + (size_t)i];
+    s = wave_sum(s);
+    if (lane == 0) part0[a.row_dst[i]] = (T)s;
+}
+
 // ------------------------------------------------------------------ MFMA lane-map self test
 __global__ void selftest_f64_kernel(double *D)
 {
@@ -369,6 +449,8 @@ int tp_kernels_allow_lds()
 {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_tp_expand_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_tp_reduce_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_lcb_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_lcb_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return DASP_OK;
 }
 
@@ -435,6 +517,16 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate
             if (rc != 1) return rc;          // 1: the panels do not share one kernel instantiation -- one launch (+ stage 2) per panel, as before r5
             for (size_t k = 0; k < p.panels.size(); ++k)
                 if (int rc2 = launch_spmv(p.panels[k]->impl, dX, part + k * stride * vb, stream, false)) return rc2;
+        }
+        if (p.lcb.n_rows() > 0) {      // the hub rows: column blocks of x staged in LDS, their result into panel 0's (otherwise unwritten) slots of the partial buffer
+            const LcbDev &q = p.dev->lcb;
+            if (p.precision == 64) {
+                hipLaunchKernelGGL((dasp_lcb_kernel<double>), dim3(q.n_units), dim3(1024), (size_t)q.cb * 8 + 16 + (size_t)(kLcbUnitElems / kLcbStep + kLcbUnitPieces) * 8, s, q, static_cast<const double *>(dX));
+                hipLaunchKernelGGL((dasp_lcb_reduce_kernel<double>), dim3((q.n_rows + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, s, q, reinterpret_cast<double *>(part));
+            } else {
+                hipLaunchKernelGGL((dasp_lcb_kernel<_Float16>), dim3(q.n_units), dim3(1024), (size_t)q.cb * 2 + 16 + (size_t)(kLcbUnitElems / kLcbStep + kLcbUnitPieces) * 8, s, q, static_cast<const _Float16 *>(dX));
+                hipLaunchKernelGGL((dasp_lcb_reduce_kernel<_Float16>), dim3((q.n_rows + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, s, q, reinterpret_cast<_Float16 *>(part));
+            }
         }
         const int np = (int)p.panels.size(), m = p.m;
         const bool wide = (reinterpret_cast<uintptr_t>(dY) & 15) == 0;

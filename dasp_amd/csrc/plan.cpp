@@ -1212,6 +1212,7 @@ static int decide_panels(const Plan &p, const int *rp, const int *ci, const Rema
 template <class T>
 static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int P, const DevCsr *dev)
 {
+    const DevCsr *const dev_in = dev;       // (a device CSR whose long rows go column-blocked is fetched and split on the host: see long_cb below)
     using clk = std::chrono::steady_clock;
     const auto t_begin = clk::now();
     const bool verbose = std::getenv("DASP_VERBOSE") != nullptr;
@@ -1242,6 +1243,23 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     std::vector<int> slot_of_row;
     if (!natural) { slot_of_row.resize((size_t)m); for (int i = 0; i < m; ++i) slot_of_row[p.order[i]] = i; }
     lap("slot table");
+    // column-blocked long rows (opt.long_cb, plan.hpp struct LongCB): the hub rows leave the panels -- in_lcb[row] -- and get their own LDS-staged kernel
+    std::vector<unsigned char> in_lcb;
+    raw_vector<int> lcb_ci;
+    raw_vector<T> lcb_val;
+    p.lcb = LongCB{};
+    if (decide_long_cb(p, rp, P, in_lcb) > 0) {
+        if (dev) {      // their cut by column block runs on the host for now: fetch the nonzeros once, then the host split below
+            lcb_ci.resize((size_t)p.nnz); lcb_val.resize((size_t)p.nnz);
+            if (int rc = devpack_fetch_csr(p, *dev, lcb_ci.data(), lcb_val.data())) return rc;
+            ci = lcb_ci.data(); val = lcb_val.data(); dev = nullptr;
+        }
+        const int rc_lcb = build_long_cb(p, rp, ci, val, in_lcb, natural ? nullptr : slot_of_row.data());
+        if (rc_lcb == 1) in_lcb.clear();          // (a piece too long for the kernel's LDS slice: the rows stay in the panels)
+        else if (rc_lcb) return rc_lcb;
+        lap("long rows by column block");
+    }
+    const bool lcb_on = !in_lcb.empty();
     // row tiles (opt.row_tile_max, Plan::rt_*): panel k keeps its rows of <= rt_max nonzeros in the parent's output order; rt[k] holds their
     // tables, rt_at[k][row] = the row's first element in the tiles' arrays (-1: the row stays with the panel's own plan)
     int rt_max = p.opt.row_tile_max == 0 ? (p.precision == 16 ? kRowTileAuto : kRowTileAuto64) : std::max(0, p.opt.row_tile_max);
@@ -1287,8 +1305,10 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     } else {
     for (auto &v : rpP) v.assign((size_t)m + 1, 0);
     parallel_for(m, threads, 1 << 12, [&](long long b, long long e) {
-        for (long long i = b; i < e; ++i)
+        for (long long i = b; i < e; ++i) {
+            if (lcb_on && in_lcb[(size_t)i]) continue;          // an empty row in every panel
             for (int j = rp[i]; j < rp[i + 1]; ++j) rpP[panel_of(remap(ci[j]))][i + 1]++;
+        }
     });
     parallel_for(P, threads, 1, [&](long long k0, long long k1) {
         for (long long k = k0; k < k1; ++k) {
@@ -1303,6 +1323,7 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
         std::vector<int> cur((size_t)P);
         std::vector<char> tiled((size_t)P);
         for (long long i = b; i < e; ++i) {
+            if (lcb_on && in_lcb[(size_t)i]) continue;
             for (int k = 0; k < P; ++k) { const int at = rt_max > 0 ? rt[(size_t)k].at[(size_t)i] : -1; tiled[k] = at >= 0; cur[k] = at >= 0 ? at : rpP[k][i]; }
             for (int j = rp[i]; j < rp[i + 1]; ++j) {
                 const int c = remap(ci[j]), k = panel_of(c), at = cur[k]++;
@@ -1404,7 +1425,16 @@ static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int
     // packed panels + x once + every panel's partial y written and read back + y
     s.data_X = dataX + xlen * vb + (long long)(2 * K + 1) * m * vb;
     s.n_col_panels = K;
-    if (dev) { if (int rc = devpack_finish_panels(p)) return rc; }      // a device-built plan comes back uploaded: the parent's partial-result buffers too
+    if (lcb_on) {
+        const LongCB &L = p.lcb;
+        s.lcb_rows = L.n_rows(); s.lcb_elems = (long long)L.elems; s.lcb_col_block = L.cb; s.lcb_units = L.n_units();
+        s.n_workgroups += L.n_units() + ceil_div(L.n_rows(), kWavesPerWG);
+        stored += (long long)L.elems;
+        s.rate_fill0 = p.nnz > 0 ? (double)(stored - p.nnz) / p.nnz : 0.0;
+        // values + local columns streamed, every unit's slice of x, the partials written and read
+        s.data_X += (long long)L.elems * (vb + 2) + (long long)L.n_units() * std::min<long long>(L.cb, xlen) * vb + 2ll * L.n_cb * L.n_rows() * 8;
+    }
+    if (dev_in) { if (int rc = devpack_finish_panels(p)) return rc; }      // a device-built plan comes back uploaded: the parent's partial-result buffers too
     lap("parent upload");
     s.pre_ms = std::chrono::duration<double, std::milli>(clk::now() - t_begin).count();
     return DASP_OK;

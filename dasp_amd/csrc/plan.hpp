@@ -191,6 +191,32 @@ struct TwoPhase {
     int n_units() const { return (int)(unit.size() / 3); }
 };
 
+// ---- column-blocked long rows of a column-panel plan (opt.long_cb, r5; the north_star's LDS-staged x gathers applied to the long rows; no reference
+// counterpart: the reference's long rows gather x from global memory, dasp_f64.h:90-144).  A hub row's nonzeros scatter over all of x; in a column panel
+// its gathers still miss the L1 once per nonzero.  Here the rows of >= lcb.h nonzeros leave the panels: their nonzeros are cut by COLUMN BLOCK of `cb`
+// columns into PIECES -- piece (c, i) = the entries of long row i inside block c, CSR order, padded to whole STEPS of kLcbStep elements -- stored CB-major.  One
+// workgroup per UNIT (a run of pieces of one column block holding ~kLcbUnitElems elements) stages the block's slice of x in LDS and streams the unit's steps --
+// every step an independent 16-byte-per-lane load of values and local columns, value x LDS-x, a wave (f64) / quarter-wave (f16) sum parked in LDS --
+// then adds every piece's step sums in order (no atomics: the result is the same in every run) and writes partial[c * n_rows + i]; a second kernel adds a row's n_cb partials and stores the result into the row's slot
+// of panel 0's partial buffer (which no panel writes: the row is empty there), so dasp_panel_sum_kernel folds it into y like any other partial result.
+// Streamed per nonzero: value + u16 local column (10 B in f64 against the 12 of B_alg), nothing gathers from global memory.
+constexpr int kLcbUnitElems = 32768;
+constexpr int kLcbStep = 128;             // elements per STEP: a piece is padded to whole steps, so that a step belongs to one piece (one wave of f64 / a quarter wave of f16 per step)
+constexpr int kLcbUnitPieces = 1024;      // most pieces per unit (the sums of a unit's steps live in LDS beside the slice of x: <= kLcbUnitElems / kLcbStep + kLcbUnitPieces of them)
+constexpr unsigned short kLcbPadCol = 0xFFFFu;
+struct LongCB {
+    int cb = 0, n_cb = 0, h = 0;      // columns per block, blocks, the shortest row taken
+    std::vector<int> row_dst;         // [n_rows] output position (the parent's slot, or the row in DASP_Y_NATURAL) of every long row
+    std::vector<int> row_id;          // [n_rows] the row itself (host only: decoding, validation)
+    std::vector<int> ptr;             // [n_cb * n_rows + 1] element offsets of the pieces, CB-major
+    std::vector<int> unit;            // [n_units * 3] column block, first piece, end piece
+    raw_vector<uint16_t> lcol;        // [elems] column - c * cb (pads: kLcbPadCol)
+    raw_vector<char> val;             // [elems * vbytes]
+    size_t elems = 0;
+    int n_rows() const { return (int)row_dst.size(); }
+    int n_units() const { return (int)(unit.size() / 3); }
+};
+
 struct DevicePlan;  // kernels.hip
 }  // namespace dasp
 struct dasp_plan;      // the C handle (defined at the end of this file): one Plan
@@ -278,6 +304,9 @@ struct Plan {
     raw_vector<int> rt_cid;
     size_t cnt_rt = 0;
 
+    // column-blocked long rows of a column-panel parent (LongCB above; empty otherwise)
+    LongCB lcb;
+
     // two-phase form (TwoPhase above): the plan then holds order / stats of the whole matrix and the tile streams, nothing else
     bool two_phase = false;
     TwoPhase tp;
@@ -339,6 +368,11 @@ int build_plan(Plan &p, const int *rp, const int *ci, const void *val, const Dev
 int decide_two_phase(const Plan &p, const int *rp, int panels_wanted);
 int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val);
 bool validate_two_phase(const Plan &p, std::string &why);
+
+// column-blocked long rows (longcb.cpp): which rows (in_lcb[row] = 1) a column-panel plan of P panels hands to them (0 rows: none), the packer, the checks
+int decide_long_cb(const Plan &p, const int *rp, int P, std::vector<unsigned char> &in_lcb);
+int build_long_cb(Plan &p, const int *rp, const int *ci, const void *val, const std::vector<unsigned char> &in_lcb, const int *slot_of_row);      // DASP_OK, an error, or 1: not representable (p.lcb left empty)
+bool validate_long_cb(const Plan &p, int n_panels, std::string &why);
 
 // loader (mmio.cpp).  val_out: malloc'd array of double or binary16.
 int load_mtx(const char *path, int precision, int *m, int *n, int *nnz, int *sym, int **rp, int **ci, void **val);

@@ -2,7 +2,7 @@
 // A plan file holds every host array of a Plan, so a later run (or every rank of a multi-GPU job)
 // skips classification and packing: load -> upload -> spmv.
 // layout: "DASPPLN7" | int32 sizeof(dasp_stats_t), kNumShortGroups, sizeof(ShortGroup) | plan, where plan = int32 precision, m, n, nnz,
-//         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows, win_hybrid, med_slot0, pair_mode, win_rel16, rt_max, two_phase, tp.cb, tp.rb_max | dasp_stats_t |
+//         y_order, windowed, row_window, lds_bytes, cid16, n_parts, part_stride, stream_policy, n_panels, n_mfma_rows, win_hybrid, med_slot0, pair_mode, win_rel16, rt_max, two_phase, tp.cb, tp.rb_max, lcb.cb, lcb.n_cb, lcb.h | dasp_stats_t |
 //         ShortGroup[kNumShortGroups] | for each array, in a fixed order: int64 byte count + bytes | the n_panels column panels, each
 //         a nested plan.
 // A file is not trusted more than a caller's CSR: after reading, every count, pointer array and column id the kernels index
@@ -18,7 +18,7 @@
 namespace dasp {
 
 namespace {
-// bumped with EVERY change of the header, the array list or the element order inside an array (5: 18-int header, one-byte ids, chunk pairs; 6: 19-int header, row tiles; 7: 22-int header, the two-phase streams)
+// bumped with EVERY change of the header, the array list or the element order inside an array (5: 18-int header, one-byte ids, chunk pairs; 6: 19-int header, row tiles; 7: 25-int header, the two-phase streams, the column-blocked long rows)
 const char kPlanMagic[8] = {'D', 'A', 'S', 'P', 'P', 'L', 'N', '7'};
 
 struct Writer {
@@ -53,6 +53,7 @@ template <class IO> void arrays(IO &io, Plan &p)
     io.vec(p.short_val); io.vec(p.short_cid);
     io.vec(p.rt_ptr); io.vec(p.rt_start); io.vec(p.rt_mask); io.vec(p.rt_val); io.vec(p.rt_cid);
     io.vec(p.tp.rb_row0); io.vec(p.tp.rb_seg0); io.vec(p.tp.unit); io.vec(p.tp.dst); io.vec(p.tp.lcol); io.vec(p.tp.lrow); io.vec(p.tp.val);
+    io.vec(p.lcb.row_dst); io.vec(p.lcb.row_id); io.vec(p.lcb.ptr); io.vec(p.lcb.unit); io.vec(p.lcb.lcol); io.vec(p.lcb.val);
 }
 }  // namespace
 
@@ -96,11 +97,12 @@ static bool validate_plan(const Plan &p, int n_panels, bool is_panel, std::strin
         return validate_two_phase(p, why);
     }
     if (!p.tp.dst.empty() || !p.tp.lcol.empty() || !p.tp.lrow.empty() || !p.tp.val.empty() || !p.tp.unit.empty() || !p.tp.rb_row0.empty() || !p.tp.rb_seg0.empty()) return fail("two-phase streams in a plan that is not two-phase");
+    if (n_panels == 0 && (p.lcb.n_rows() > 0 || !p.lcb.ptr.empty() || !p.lcb.lcol.empty() || !p.lcb.val.empty() || !p.lcb.unit.empty() || !p.lcb.row_id.empty())) return fail("column-blocked long rows outside a column-panel plan");
     if (n_panels > 0) {   // a panel parent keeps order + stats only
         if (p.cnt_long || p.cnt_reg || p.cnt_irr || p.cnt_short || !p.med_ptr.empty() || !p.irr_ptr.empty() || !p.piece_ptr.empty()) return fail("panel parent holds packed arrays");
         for (int k = 0; k < n_panels; ++k)
             if (p.panel_bounds[2 * k] < 0 || p.panel_bounds[2 * k + 1] < p.panel_bounds[2 * k] || p.panel_bounds[2 * k + 1] > xlen) return fail("panel_bounds range");
-        return true;
+        return validate_long_cb(p, n_panels, why);
     }
     auto cid_ok = [&](const raw_vector<int> &c) { for (int v : c) if (v < -1 || v >= xlen) return false; return true; };
     auto mono = [](const std::vector<int> &a) { if (a.empty() || a[0] != 0) return false; for (size_t i = 1; i < a.size(); ++i) if (a[i] < a[i - 1]) return false; return true; };
@@ -268,9 +270,9 @@ static bool validate_plan(const Plan &p, int n_panels, bool is_panel, std::strin
 
 static void write_plan(Writer &w, Plan &p)
 {
-    const int hdr[22] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
+    const int hdr[25] = {p.precision, p.m, p.n, p.nnz, p.opt.y_order, p.windowed ? 1 : 0, p.row_window, p.lds_bytes, p.cid16 ? 1 : 0,
                          p.opt.n_parts, p.opt.part_stride, p.opt.stream_policy, (int)p.panels.size(), p.n_mfma_rows, p.win_hybrid ? 1 : 0, p.med_slot0, p.pair_mode, p.win_rel16 ? 1 : 0, p.rt_max,
-                         p.two_phase ? 1 : 0, p.tp.cb, p.tp.rb_max};
+                         p.two_phase ? 1 : 0, p.tp.cb, p.tp.rb_max, p.lcb.cb, p.lcb.n_cb, p.lcb.h};
     w.raw(hdr, sizeof hdr); w.raw(&p.stats, sizeof p.stats); w.raw(p.grp, sizeof p.grp);
     arrays(w, p);
     for (auto &h : p.panels) write_plan(w, h->impl);
@@ -278,7 +280,7 @@ static void write_plan(Writer &w, Plan &p)
 
 static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
 {
-    int hdr[22];
+    int hdr[25];
     r.raw(hdr, sizeof hdr);
     if (!r.ok || (hdr[0] != 64 && hdr[0] != 16) || hdr[12] < 0 || hdr[12] > 64 || (depth > 0 && hdr[12] != 0)) return false;
     p.precision = hdr[0]; p.geo = geometry_for(p.precision);
@@ -288,11 +290,13 @@ static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
     p.opt.n_parts = hdr[9]; p.opt.part_stride = hdr[10]; p.opt.stream_policy = hdr[11]; p.n_mfma_rows = hdr[13]; p.win_hybrid = hdr[14] != 0; p.med_slot0 = hdr[15]; p.pair_mode = hdr[16]; p.win_rel16 = hdr[17] != 0; p.rt_max = hdr[18];
     if (p.pair_mode < 0 || p.pair_mode > 2 || (p.windowed && p.pair_mode)) return false;
     p.two_phase = hdr[19] != 0; p.tp.cb = hdr[20]; p.tp.rb_max = hdr[21];
+    p.lcb.cb = hdr[22]; p.lcb.n_cb = hdr[23]; p.lcb.h = hdr[24];
     if (p.two_phase && (depth > 0 || hdr[12] != 0)) return false;
     r.raw(&p.stats, sizeof p.stats); r.raw(p.grp, sizeof p.grp);
     arrays(r, p);
     if (!r.ok) return false;
     p.tp.segments = p.tp.dst.size();
+    p.lcb.elems = p.lcb.lcol.size();
     p.opt.two_phase = p.two_phase ? 1 : -1; p.opt.tp_col_block = p.tp.cb; p.opt.tp_row_block = p.tp.rb_max;
     p.opt.part_bounds = p.part_bounds.empty() ? nullptr : p.part_bounds.data();
     const size_t vb = (size_t)p.geo.vbytes;
@@ -318,6 +322,12 @@ static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
         std::unique_ptr<dasp_plan> h(new dasp_plan());
         if (!read_plan(r, h->impl, depth + 1, r_why) || h->impl.m != p.m || h->impl.precision != p.precision) return false;
         p.panels.push_back(std::move(h));
+    }
+    if (np > 0) {      // every nonzero once: in a panel, or in the column-blocked long rows
+        long long have = 0;
+        for (const auto &h : p.panels) have += (long long)h->impl.nnz + (long long)h->impl.cnt_rt;      // (a panel's row tiles are not in its nnz)
+        for (uint16_t c : p.lcb.lcol) have += c != kLcbPadCol;
+        if (have != p.nnz) { r_why = "the panels and the column-blocked long rows do not add up to nnzA"; return false; }
     }
     return true;
 }

@@ -73,9 +73,31 @@ static int upload_plan_impl(Plan &p)
     if (!p.panels.empty()) {   // column panels: every panel is a plan of its own; this one only owns their partial results
         for (auto &h : p.panels) if (int rc = upload_plan(h->impl)) return rc;
         d->ypart_stride = ((size_t)std::max(p.m, 1) + 127) & ~size_t(127);
-        d->arena_bytes = d->ypart_stride * p.panels.size() * (size_t)p.geo.vbytes;
+        const size_t part_bytes = d->ypart_stride * p.panels.size() * (size_t)p.geo.vbytes;
+        // column-blocked long rows (Plan::lcb): their streams, tables and partial sums behind the partial-result buffers
+        const LongCB &L = p.lcb;
+        const size_t vbytes = (size_t)p.geo.vbytes;
+        size_t total = (part_bytes + 255) & ~size_t(255);
+        auto place = [&](size_t bytes) { const size_t off = total; total += (std::max<size_t>(bytes, 16) + 255) & ~size_t(255); return off; };
+        const bool lcb = L.n_rows() > 0;
+        const size_t o_v = lcb ? place(L.elems * vbytes) : 0, o_c = lcb ? place(L.elems * 2) : 0, o_p = lcb ? place(L.ptr.size() * 4) : 0, o_u = lcb ? place(L.unit.size() * 4) : 0,
+                     o_d = lcb ? place(L.row_dst.size() * 4) : 0, o_s = lcb ? place((size_t)L.n_cb * (size_t)L.n_rows() * 8) : 0;
+        d->arena_bytes = total;
         HIP_TRY(hipMalloc(&d->arena, d->arena_bytes));
-        HIP_TRY(hipMemset(d->arena, 0, d->arena_bytes));      // the panels never store the rows that are empty in them (DevArgs::skip0)
+        HIP_TRY(hipMemset(d->arena, 0, d->arena_bytes));      // the panels never store the rows that are empty in them (DevArgs::skip0); empty (row, block) pieces never write their partial sum
+        if (lcb) {
+            char *base = static_cast<char *>(d->arena);
+            HIP_TRY(hipMemcpy(base + o_v, L.val.data(), L.elems * vbytes, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(base + o_c, L.lcol.data(), L.elems * 2, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(base + o_p, L.ptr.data(), L.ptr.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(base + o_u, L.unit.data(), L.unit.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(base + o_d, L.row_dst.data(), L.row_dst.size() * 4, hipMemcpyHostToDevice));
+            LcbDev &q = d->lcb;
+            q.val = base + o_v; q.lcol = (const unsigned short *)(base + o_c); q.ptr = (const int *)(base + o_p); q.unit = (const int *)(base + o_u);
+            q.row_dst = (const int *)(base + o_d); q.partial = base + o_s;
+            q.n_units = L.n_units(); q.n_rows = L.n_rows(); q.n_cb = L.n_cb; q.cb = L.cb; q.xlen = p.n;
+            if (int rc = tp_kernels_allow_lds()) return rc;
+        }
         return DASP_OK;
     }
 

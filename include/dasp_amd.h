@@ -186,6 +186,12 @@ typedef struct dasp_options {
      *   tp_col_block: columns per column block (multiple of 8, <= 65536; 0 = 32768); tp_row_block: most output positions per row block (<= 8192; 0 = 4096). */
     int two_phase;
     int tp_col_block, tp_row_block;
+    /* column-blocked long rows of a column-panel plan (no reference counterpart; the north_star's LDS-staged x gathers applied to the long rows): the rows of
+     * >= max(block_longest, 64 x column blocks) nonzeros leave the panels; their nonzeros are cut by column block (16384 columns in f64, 32768 in f16: the block's
+     * slice of x staged in LDS), one wave per (row, block) piece multiplies value x LDS-x, a second kernel adds a row's partials.  value + u16 local column are
+     * streamed, nothing gathers from global memory.  0 = auto (when those rows hold >= a quarter of the nonzeros of a plan that uses column panels), 1 = force
+     * (every row of >= block_longest nonzeros), -1 = off.  order_rid and the classifier counters are unchanged; a long row's products are added per piece. */
+    int long_cb;
 } dasp_options_t;
 
 void dasp_options_default(dasp_options_t *opt);
@@ -223,6 +229,8 @@ typedef struct dasp_stats {
     int tp_col_block, tp_row_blocks, tp_units;   /* its columns per column block, row blocks (phase-2 workgroups) and phase-1 workgroups */
     long long tp_segments;     /* its segments: stored (padded) elements / tp_seg_elems */
     int tp_seg_elems;          /* elements per segment (64) */
+    int lcb_rows, lcb_col_block, lcb_units;   /* column-blocked long rows of a column-panel plan (option long_cb): rows taken, columns per block, workgroups */
+    long long lcb_elems;       /* their stored (padded) elements */
     /* the REFERENCE's geometry on the same input (8-row blocks, 8x4 tiles, 32-lane warps): the padded sizes the CUDA reference computes
      * and writes into its CSV row for this matrix -- short tiles dasp_f64.h:609-629 / dasp_f16.h:1139-1156, long rows :1000-1014 /
      * :1273-1288, regular / irregular split :1044-1091 / :1317-1365, rate_fill0 and data_X :1159-1166 / dasp_f16.h:1448-1455.  Functions

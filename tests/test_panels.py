@@ -21,14 +21,14 @@ def rows_of(plan, m):
 
 @pytest.mark.parametrize("prec", [64, 16])
 @pytest.mark.parametrize("y_order", [0, 1])
-@pytest.mark.parametrize("P,tile", [(2, 0), (3, -1), (7, 5), (3, 32)])
-def test_panels_partition_the_matrix(dasp, prec, y_order, P, tile):
+@pytest.mark.parametrize("P,tile,lcb", [(2, 0, 0), (3, -1, -1), (7, 5, 1), (3, 32, 0)])
+def test_panels_partition_the_matrix(dasp, prec, y_order, P, tile, lcb):
     dt = np.float64 if prec == 64 else np.float16
     m, n = 1500, 5000
     lens = np.random.default_rng(3).choice([0, 1, 2, 3, 4, 9, 40, 300, 700], size=m, p=[.05, .15, .1, .15, .1, .2, .15, .07, .03])
     rp, ci, v = util.csr_from_lengths(lens, n, 5, dtype=dt)
     single = dasp.Plan(rp, ci, v, n, precision=prec, y_order=y_order, col_panels=1)
-    plan = dasp.Plan(rp, ci, v, n, precision=prec, y_order=y_order, col_panels=P, row_tile_max=tile)      # 0 = auto: 16 (f16) / 8 (f64)
+    plan = dasp.Plan(rp, ci, v, n, precision=prec, y_order=y_order, col_panels=P, row_tile_max=tile, long_cb=lcb)      # 0 = auto: 16 (f16) / 8 (f64)
     assert single.n_panels == 0 and single.stats["n_col_panels"] == 0
     assert plan.n_panels == P and plan.stats["n_col_panels"] == P
     np.testing.assert_array_equal(plan.order_rid, single.order_rid)
@@ -56,8 +56,19 @@ def test_panels_partition_the_matrix(dasp, prec, y_order, P, tile):
         assert nnz_k == sub.stats["nnzA"] + sub.stats["row_tile_nnz"]      # (the panels keep their short rows in row tiles)
         assert (sub.stats["row_tile_nnz"] > 0) == (tile >= 0) and sub.stats["row_tile_max"] == (0 if tile < 0 else tile or (16 if prec == 16 else 8)) and sub.stats["n_row_tiles"] == (-(-m // 64) if tile >= 0 else 0)
     assert prev_end == n
+    # column-blocked long rows (long_cb; auto: the rows of >= 256 hold more than a quarter of this matrix): they are in no panel, every entry once in the piece streams
+    hub = util.decode_long_cb(plan)
+    assert (len(hub) > 0) == (lcb >= 0) and set(hub) == ({r for r in range(m) if lens[r] >= 256} if lcb >= 0 else set())
+    n_hub = 0
+    for r, ent in hub.items():
+        assert got[r] == []
+        # a row's entries: column blocks in ascending order, CSR order inside a block
+        k = np.argsort(ci[rp[r]:rp[r + 1]] // plan.stats["lcb_col_block"], kind="stable")
+        assert [c for c, _ in ent] == ci[rp[r]:rp[r + 1]][k].tolist()
+        got[r] = ent
+        n_hub += len(ent)
     assert [sorted(g) for g in got] == want
-    assert sum(plan.panel(k)[0].stats["nnzA"] + plan.panel(k)[0].stats["row_tile_nnz"] for k in range(P)) == ci.size
+    assert sum(plan.panel(k)[0].stats["nnzA"] + plan.panel(k)[0].stats["row_tile_nnz"] for k in range(P)) + n_hub == ci.size
     assert plan.stats["row_tile_nnz"] == sum(plan.panel(k)[0].stats["row_tile_nnz"] for k in range(P))
 
 

@@ -89,6 +89,9 @@ def test_column_panels_partition_arbitrary_matrices(dasp, mat, opts, prec, panel
         for slot, (cs, vs) in util.decode_plan(sub).items():
             assert all(cb <= c < ce for c in cs)
             got[int(order[slot])] += list(zip(cs, [float(x) for x in vs]))
+    for r, ent in util.decode_long_cb(plan).items():          # hub rows of a panel plan live in the column-blocked piece streams (long_cb auto), in no panel
+        assert got[r] == []
+        got[r] = ent
     for r in range(m):
         assert sorted(got[r]) == sorted(zip(ci[rp[r]:rp[r + 1]].tolist(), v[rp[r]:rp[r + 1]].astype(dt).astype(np.float64).tolist()))
 

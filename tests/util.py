@@ -44,6 +44,37 @@ def slot_of(g, t):
     return base[p] + (u // grp[p]) * 2 * grp[p] + off[p] + u % grp[p] if grp[p] else base[p] + u
 
 
+def decode_long_cb(plan):
+    """the column-blocked long rows of a column-panel parent (plan.hpp struct LongCB): row -> [(col, val)] from the piece streams, walked unit by
+    unit as the kernel walks them ({} when the plan has none)"""
+    st = plan.stats
+    nL = st["lcb_rows"]
+    if nL == 0:
+        return {}
+    cb = st["lcb_col_block"]
+    rows, dst, ptr = plan.host_array("lcb_row_id"), plan.host_array("lcb_row_dst"), plan.host_array("lcb_ptr")
+    unit = plan.host_array("lcb_unit").reshape(-1, 3)
+    lcol, val = plan.host_array("lcb_lcol"), plan.host_array("lcb_val")
+    assert rows.size == nL == dst.size and lcol.size == val.size == st["lcb_elems"] == ptr[-1] and unit.shape[0] == st["lcb_units"]
+    order = plan.order_rid
+    for i in range(nL):                                   # the destination is the row's position in the plan's y order
+        assert (dst[i] == rows[i]) if getattr(plan, "y_order", 0) == 1 else (order[dst[i]] == rows[i])
+    out = {int(r): [] for r in rows}
+    seen = set()
+    for c, q0, q1 in unit.tolist():
+        for q in range(q0, q1):
+            assert q // nL == c and q not in seen
+            seen.add(q)
+            for e in range(ptr[q], ptr[q + 1]):
+                if lcol[e] == 0xFFFF:
+                    assert val[e] == 0
+                    continue
+                out[int(rows[q % nL])].append((c * cb + int(lcol[e]), float(val[e])))
+    for q in range(ptr.size - 1):                         # a piece outside every unit is empty
+        assert q in seen or ptr[q + 1] == ptr[q]
+    return out
+
+
 def decode_two_phase(plan, x=None):
     """The two-phase form (plan.hpp struct TwoPhase) from its streams alone, walked the way the two kernels walk them: phase 1 per unit
     (column block, CB-major segments) resolves every local column and drops it at dst[segment]; phase 2 per row block reads (value, local row)
