@@ -27,6 +27,7 @@ int decide_long_cb(const Plan &p, const int *rp, int P, std::vector<unsigned cha
     long long nnz_l = 0; int rows = 0;
     for (int i = 0; i < p.m; ++i) { const int len = rp[i + 1] - rp[i]; if (len >= h) { nnz_l += len; ++rows; } }
     if (rows == 0 || (long long)rows * n_cb >= (1ll << 27)) return 0;
+    if (nnz_l >= (long long)p.nnz) return 0;      // nothing would be left for the panels (every panel empty = no panel plan at all): such a matrix is the long-row kernel's
     if (p.opt.long_cb == 0 && nnz_l * 4 < (long long)p.nnz) return 0;
     in_lcb.assign((size_t)p.m, 0);
     for (int i = 0; i < p.m; ++i) if (rp[i + 1] - rp[i] >= h) in_lcb[(size_t)i] = 1;

@@ -35,10 +35,12 @@ static Csr synth(const char *name, double scale)
 
 static void plans_of(const Csr &c, const std::string &scratch, int tag)
 {
-    struct O { int x_window, row_window, cid16, col_panels, slab, hybrid, piece, pairs, cid8, natural; double thr; int longest; };
+    struct O { int x_window, row_window, cid16, col_panels, slab, hybrid, piece, pairs, cid8, natural; double thr; int longest; int two_phase = 0, long_cb = 0, tp_cb = 0, tp_rb = 0; };
     const O opts[] = {
         {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.75, 256}, {81920, 128, 1, 1, 4, -1, -1, 0, 0, 0, 0.75, 256}, {-1, 0, 1, 1, 4, -1, -1, 2, 0, 1, 0.5, 64},
         {-1, 0, -1, 3, 12, -1, 40, -1, -1, 0, 1.0, 256}, {163840, 256, 1, 1, 4, 1, -1, 0, 0, 1, 0.25, 128}, {-1, 0, 1, 1, 32, -1, 5, 1, 0, 0, 0.75, 1000000},
+        // r5: the two-phase form (f16 only: applied to the f16 plan of the pair), small blocks so that every matrix has many tiles; column panels with column-blocked long rows
+        {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.75, 256, 1, 0, 64, 16}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0.75, 256, 1, 0, 0, 0}, {-1, 0, 0, 3, 0, -1, 0, 0, 0, 0, 0.75, 64, -1, 1, 0, 0}, {-1, 0, 0, 2, 0, -1, 0, 0, 0, 1, 0.75, 256, -1, 1, 0, 0},
     };
     int k = 0;
     for (const O &o : opts) {
@@ -49,6 +51,7 @@ static void plans_of(const Csr &c, const std::string &scratch, int tag)
             opt.x_window_hybrid = o.hybrid; opt.piece_min_len = o.piece; opt.chunk_pairs = o.pairs; opt.cid8 = o.cid8; opt.y_order = o.natural;
             opt.threshold = o.thr; opt.block_longest = o.longest; opt.host_threads = 1 + (k % 5);
             opt.sort_columns = k % 3 == 0 ? 1 : 0;
+            opt.two_phase = o.two_phase > 0 && prec != 16 ? 0 : o.two_phase; opt.tp_col_block = o.tp_cb; opt.tp_row_block = o.tp_rb; opt.long_cb = o.long_cb;
             dasp_plan_t *p = nullptr;
             const void *val = prec == 64 ? (const void *)c.v64.data() : (const void *)c.v16.data();
             const int rc = dasp_plan_create(&p, prec, c.m, c.n, c.nnz, c.rp.data(), c.ci.data(), val, &opt);

@@ -31,6 +31,7 @@ int devpack_row_coherence(const Plan &, const DevCsr &, const std::vector<int> &
 int devpack_chunk_spans(const Plan &, const DevCsr &, const raw_vector<int> &, const raw_vector<int> &, const std::vector<int> &, int *, unsigned long long *) { return nodev(); }
 int devpack_all(Plan &, const DevCsr &, const PackMeta &) { return nodev(); }
 int devpack_finish_panels(Plan &) { return nodev(); }
+int devpack_fetch_csr(const Plan &, const DevCsr &, int *, void *) { return nodev(); }
 int devpack_current_device() { return -1; }
 void devpack_use_device(int) {}
 int devpack_gather_columns(const Plan &, const DevCsr &, const std::vector<long long> *, long long, long long, long long, std::vector<int> &) { return nodev(); }

@@ -122,3 +122,22 @@ def test_panel_plan_file_round_trip(dasp, prec, tmp_path):
         for name in ("dst_map", "order", "med_ptr", "med_val", "med_cid", "irr_val", "irr_cid", "long_val", "long_cid", "piece_dst",
                      "short_val", "short_cid"):
             np.testing.assert_array_equal(a[0].host_array(name), b[0].host_array(name), err_msg=name)
+
+
+def test_long_cb_leaves_something_for_the_panels(dasp, tmp_path):
+    """a matrix whose every row is a hub (found by the sanitizer driver, r5): with all rows column-blocked no panel would hold a nonzero and the parent would have no
+    panels at all -- the rule then keeps the rows in the panels; a plan with SOME hub rows saves, loads and decodes"""
+    lens = [300] * 40
+    rp, ci, v = util.csr_from_lengths(lens, 4000, 3)
+    plan = dasp.Plan(rp, ci, v, 4000, col_panels=2, long_cb=1)
+    assert plan.stats["lcb_rows"] == 0 and plan.n_panels == 2
+    lens = [300] * 40 + [7] * 100
+    rp, ci, v = util.csr_from_lengths(lens, 4000, 3)
+    plan = dasp.Plan(rp, ci, v, 4000, col_panels=2, long_cb=1)
+    assert plan.stats["lcb_rows"] == 40 and plan.n_panels == 2 and plan.stats["lcb_elems"] % 128 == 0
+    path = str(tmp_path / "lcb.plan")
+    plan.save(path)
+    again = dasp.Plan.load(path)
+    assert again.stats["lcb_rows"] == 40 and util.decode_long_cb(again) == util.decode_long_cb(plan)
+    for name in ("lcb_ptr", "lcb_unit", "lcb_row_dst", "lcb_row_id", "lcb_lcol", "lcb_val"):
+        assert np.array_equal(again.host_array(name), plan.host_array(name)), name
