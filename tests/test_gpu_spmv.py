@@ -1745,3 +1745,43 @@ def test_two_phase_from_a_device_csr_and_a_plan_file(oracle, dasp, torch_cuda, t
     assert np.array_equal(run_spmv(torch, again, xh, 6000, 16), got)
     for p in (host, dev, again):
         p.close()
+
+
+# ---- column-blocked long rows of a column-panel plan (opt.long_cb; dasp_lcb_kernel / dasp_lcb_reduce_kernel)
+@pytest.mark.parametrize("prec", [64, 16])
+@pytest.mark.parametrize("lens,n,kw", [
+    ([5000, 256, 1023, 20000, 0, 700, 2, 300, 300] + [9] * 500, 70000, dict(col_panels=3, long_cb=1)),            # every row of >= 256 column-blocked, several column blocks
+    ([300] * 64 + [1] * 200 + [0] * 30, 3000, dict(col_panels=2, long_cb=1)),                                     # one column block, pieces of one or two steps
+    ([40000, 33000] + [4] * 3000, 140000, dict(col_panels=4, long_cb=0)),                                         # auto: two hubs hold most of the nonzeros
+    ([5000, 700, 300] + [9] * 500, 70000, dict(col_panels=3, long_cb=1, block_longest=64)),
+])
+def test_column_blocked_long_rows_parity(oracle, dasp, torch_cuda, prec, lens, n, kw):
+    rp, ci, v = util.csr_from_lengths(lens, n, 17, values="f16" if prec == 16 else "uniform")
+    plan = dasp.Plan(rp, ci, v.astype(np.float64 if prec == 64 else np.float16), n, precision=prec, two_phase=-1, **kw)
+    assert plan.stats["lcb_rows"] > 0 and plan.n_panels >= 2
+    plan.close()
+    check(oracle, dasp, torch_cuda, rp, ci, v, n, prec, two_phase=-1, **kw)
+
+
+def test_column_blocked_long_rows_accumulate_device_csr_and_determinism(oracle, dasp, torch_cuda):
+    torch = torch_cuda
+    lens = [9000, 4100, 300] + [11] * 4000
+    rp, ci, v = util.csr_from_lengths(lens, 50000, 23)
+    xh = np.random.default_rng(2).uniform(-1, 1, 50000)
+    ref = oracle.csr_spmv(rp, ci, v, xh)
+    scale = np.maximum(oracle.csr_absrow(rp, ci, v, xh), 1e-300)
+    host = dasp.Plan(rp, ci, v, 50000, col_panels=2, long_cb=1, y_order=dasp.Y_NATURAL)
+    d_rp, d_ci, d_v = torch.from_numpy(rp.astype(np.int32)).cuda(), torch.from_numpy(ci.astype(np.int32)).cuda(), torch.from_numpy(v).cuda()
+    dev = dasp.Plan.from_device(d_rp.data_ptr(), d_ci.data_ptr(), d_v.data_ptr(), len(lens), 50000, ci.size, col_panels=2, long_cb=1, y_order=dasp.Y_NATURAL)
+    assert dev.stats["lcb_rows"] == host.stats["lcb_rows"] == 3 and dev.stats["lcb_elems"] == host.stats["lcb_elems"]
+    m = len(lens)
+    y_dev = run_spmv(torch, dev, xh, m, 64)
+    y_host = run_spmv(torch, host.upload(), xh, m, 64)
+    assert np.array_equal(y_dev, y_host) and (np.abs(y_host - ref) <= 1e-12 * scale).all()
+    assert np.array_equal(run_spmv(torch, host, xh, m, 64), y_host)                   # the same bits in every run: no atomics anywhere in the path
+    x = torch.from_numpy(xh).cuda()
+    y = torch.full((m,), 3.0, dtype=torch.float64, device="cuda")
+    host.spmv(x.data_ptr(), y.data_ptr(), 0, accumulate=True)                         # y += A x
+    torch.cuda.synchronize()
+    assert (np.abs(y.cpu().numpy() - 3.0 - ref) <= 1e-12 * np.maximum(scale, 3.0)).all()
+    host.close(); dev.close()
