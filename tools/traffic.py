@@ -19,7 +19,8 @@ def rev():
     return h.hexdigest()[:12]
 
 
-SPMV_KERNELS = ("dasp_spmv_kernel", "dasp_long_reduce_kernel", "dasp_panel_sum_kernel", "dasp_tp_expand_kernel", "dasp_tp_reduce_kernel")   # the kernels of one SpMV (not dasp_bench's packers)
+SPMV_KERNELS = ("dasp_spmv_panels_kernel", "dasp_long_reduce_panels_kernel", "dasp_lcb_reduce_kernel", "dasp_lcb_kernel", "dasp_spmv_kernel", "dasp_long_reduce_kernel", "dasp_panel_sum_kernel",
+                "dasp_tp_expand_kernel", "dasp_tp_reduce_kernel")   # the kernels of one SpMV (not dasp_bench's packers); longer names first: matched by substring
 
 
 def spmv_kernel(name):
@@ -52,10 +53,12 @@ for tok in log.replace("|", " ").split():
     if tok.startswith("panels="):
         panels = int(tok.split("=")[1])
 two_phase = "dasp_spmv_kernel" not in fcnt and "dasp_tp_reduce_kernel" in fcnt          # a two-phase plan: one expand + one reduce launch per SpMV
-main_k = "dasp_tp_reduce_kernel" if two_phase else "dasp_spmv_kernel"
-n_spmv = fcnt[main_k] / max(1, panels)
+merged = "dasp_spmv_panels_kernel" in fcnt                                              # r5: the panels of a column-panel plan in one launch
+main_k = "dasp_tp_reduce_kernel" if two_phase else "dasp_spmv_panels_kernel" if merged else "dasp_spmv_kernel"
+per_spmv = 1 if (two_phase or merged) else max(1, panels)
+n_spmv = fcnt[main_k] / per_spmv
 f_raw = sum(fetch.values()) / n_spmv
-w = sum(write.values()) / (wcnt[main_k] / max(1, panels))
+w = sum(write.values()) / (wcnt[main_k] / per_spmv)
 stats = list(csv.DictReader(open(max(glob.glob(d + "/trace/*/*kernel_stats.csv"), key=os.path.getmtime))))
 sys.stderr.write("## rocprofv3 --kernel-trace --stats -- dasp_bench %s %g %d (tag %s)\n\n| kernel | calls | avg ns | %% |\n|---|---|---|---|\n" % (workload, scale, prec, tag))
 for r in stats[:5]:
@@ -69,7 +72,7 @@ avg = {}
 for r in stats:
     k = spmv_kernel(r["Name"])
     if k:
-        avg[k] = avg.get(k, 0.0) + float(r["AverageNs"]) * (max(1, panels) if k == "dasp_spmv_kernel" else 1)   # per SpMV
+        avg[k] = avg.get(k, 0.0) + float(r["AverageNs"]) * (max(1, panels) if k == "dasp_spmv_kernel" and not merged else 1)   # per SpMV
 print(json.dumps({"workload": workload, "precision": prec, "scale": scale, "kernel_rev": rev(), "kernels": sorted(fcnt),
                   "fetch_size_bytes_raw": round(f_raw), "write_size_bytes": round(w), "traffic_bytes": round(2 * f_raw + w),
                   "kernel_avg_ns": avg, "column_panels": panels, "two_phase": bool(two_phase),
