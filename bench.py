@@ -663,7 +663,7 @@ def main():
     dog.kick("plans built")
     # how the ranks exchange their y slices (N > 1):
     #   "direct" : every rank stores its slice into every rank's gather buffer through hipIpc peer mappings (dasp_mg_push_connect) -- first
-    #              choice: RCCL's kernels (261-280 registers per lane on gfx950) do not start beside the product kernel
+    #              choice: RCCL's kernels (261-280 registers per lane on gfx950) do not start beside the product kernel (DESIGN_MULTIGPU.md 5.3)
     #   "RCCL"   : ncclAllGather, with the products on the plan's CU-masked stream (32 CUs kept free for RCCL's kernels) -- the fallback
     #   "host"   : test hook for ranks sharing one GPU without the direct exchange (DASP_BENCH_EXCHANGE=host)
     want = os.environ.get("DASP_BENCH_EXCHANGE", "direct")

@@ -482,7 +482,7 @@ int sticky_error(const dasp_mg_plan &g)
 void forget_exchange_events(dasp_mg_plan &g) { for (uint64_t &k : g.ev_x_step) k = 0; }
 
 // the one-launch step on stream s?  Not with RCCL between several ranks on a stream that leaves RCCL's kernels no room: they would
-// not start while workgroups wait for them -- such a call runs the two-launch form instead of timing out
+// not start while workgroups wait for them (DESIGN_MULTIGPU.md 5.3) -- such a call runs the two-launch form instead of timing out
 bool fuse_on(const dasp_mg_plan &g, hipStream_t s)
 {
     if (g.step2) return g.one_stream();

@@ -807,7 +807,7 @@ __device__ __forceinline__ void row_tile(const DevArgs &a, int t, int lane, type
     for (int i = lane; i < n; i += kWave) prod[i] = (part_t)ldg<NT>(val + e0 + i) * (part_t)x[ldg<NT>(a.rt_cid + e0 + i)];
     // this wave's LDS writes before its LDS reads (another lane's): one wave's LDS operations execute in issue order, and the compiler keeps a store before a
     // load of the same array.  NO fence and NO __builtin_amdgcn_wave_barrier() here: either makes the compiler read the row tables of the panel's blocks with
-    // vector instead of scalar loads in the f64 kernel (the cliff of DESIGN.md 5.1: 302 -> 119 s_load instructions; HV15R-unstructured in two forced panels
+    // vector instead of scalar loads in the f64 kernel (the cliff of DESIGN_MULTIGPU.md 5.1: 302 -> 119 s_load instructions; HV15R-unstructured in two forced panels
     // 0.555 -> 0.884 ms with 0.05 % of its nonzeros in tiles)
     int e = __shfl_down(s, 1);
     if (lane == kWave - 1) e = n;

@@ -417,7 +417,7 @@ int dasp_mg_set_fake_exchange(dasp_mg_plan_t *mg, int micros, int n_peers, void 
  * peer-mapped pointers (hipIpc; xGMI: one hop, all links at once) and then a sequence number into the receiver's arrived[sender] word;
  * a one-wave kernel on the receiver waits for all senders.  Why: RCCL's kernels on gfx950 need 261-280 registers per lane and do not
  * start beside a product kernel that keeps every SIMD full -- the exchange then runs AFTER the product instead of under it
- * (DESIGN.md 5.3); these kernels hold <= 32.  Single node.  Usage, after dasp_mg_upload on every rank:
+ * (DESIGN_MULTIGPU.md 5.3); these kernels hold <= 32.  Single node.  Usage, after dasp_mg_upload on every rank:
  *     dasp_mg_push_export(mg, blob)                    this rank's DASP_MG_IPC_BYTES
  *     ... all-gather the blobs among the ranks by any means (MPI_Allgather, torch.distributed.all_gather, files) ...
  *     dasp_mg_push_connect(mg, blobs)                  [n_gpus][DASP_MG_IPC_BYTES] in rank order; maps the peers and switches the plan over
