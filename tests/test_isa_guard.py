@@ -128,3 +128,21 @@ def test_row_tile_lds_ops_are_in_program_order(isa):
         assert max(writes) < min(reads), (head, writes, reads)
         seen += 1
     assert seen == 8
+
+
+def test_round_5_kernels(isa):
+    """the kernels added in r5: the merged-panel launch keeps the plain kernels' budget (<= 80 VGPRs, no scratch, scalar table loads); the two-phase and
+    column-blocked kernels stream with global (not flat) loads, use no scratch and no MFMA, and synchronise exactly where the design says (x slice staged /
+    accumulators ready)"""
+    for nt in (0, 1):
+        for c16 in (0, 1):
+            for t, cap in (("double", 80), ("half", 72)):
+                r = isa["dasp_spmv_panels_kernel<%s,%d,%d>" % (t, nt, c16)]
+                assert r["vgpr_count"] <= cap and r["private_segment_fixed_size"] == 0 and r["scratch"] == 0 and r["flat"] == 0, r
+            assert isa["dasp_spmv_panels_kernel<double,%d,%d>" % (nt, c16)]["s_load"] >= (200 if c16 else 25)
+    for k in ("dasp_tp_expand_kernel<half>", "dasp_tp_reduce_kernel<half>", "dasp_lcb_kernel<double>", "dasp_lcb_kernel<half>"):
+        r = isa[k]
+        assert r["private_segment_fixed_size"] == 0 and r["scratch"] == 0 and r["mfma"] == 0 and r["flat"] == 0 and r["ds"] > 0, (k, r)
+    assert isa["dasp_tp_expand_kernel<half>"]["s_barrier"] == 1 and isa["dasp_tp_reduce_kernel<half>"]["s_barrier"] == 2
+    assert isa["dasp_lcb_kernel<double>"]["s_barrier"] == 2 and isa["dasp_lcb_kernel<double>"]["vgpr_count"] <= 128      # 1024 threads: 4 waves per SIMD
+    assert isa["dasp_lcb_kernel<half>"]["vgpr_count"] <= 128

@@ -96,16 +96,43 @@ def test_column_panels_partition_arbitrary_matrices(dasp, mat, opts, prec, panel
         assert sorted(got[r]) == sorted(zip(ci[rp[r]:rp[r + 1]].tolist(), v[rp[r]:rp[r + 1]].astype(dt).astype(np.float64).tolist()))
 
 
+@settings(max_examples=80, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+@given(mat=matrices(), y_order=st.sampled_from([0, 1]), cb=st.sampled_from([0, 8, 64, 4096, 65536]), rb=st.sampled_from([0, 1, 7, 300, 8192]), longest=st.sampled_from([256, 16]))
+def test_two_phase_streams_decode_for_arbitrary_matrices(dasp, mat, y_order, cb, rb, longest):
+    """the two-phase form of an f16 plan (r5): whatever the matrix and the block sizes, the tile streams hold every nonzero once, at its row's output position, with
+    the whole matrix's order_rid -- and a plan file of it loads (the validator accepts what the packer wrote)"""
+    import tempfile
+    rp, ci, v, n = mat
+    m = rp.size - 1
+    plan = dasp.Plan(rp, ci, v.astype(np.float16), n, precision=16, two_phase=1, tp_col_block=cb, tp_row_block=rb, y_order=y_order, block_longest=longest)
+    single = dasp.Plan(rp, ci, v.astype(np.float16), n, precision=16, two_phase=-1, col_panels=1, y_order=y_order, block_longest=longest)
+    assert plan.stats["two_phase"] == 1 and (plan.order_rid == single.order_rid).all()
+    order = plan.order_rid
+    got = util.decode_plan(plan)
+    for pos, (cs, vs) in got.items():
+        r = pos if y_order == 1 else order[pos]
+        assert sorted(zip(cs, vs)) == sorted(zip(ci[rp[r]:rp[r + 1]].tolist(), v[rp[r]:rp[r + 1]].astype(np.float16).astype(np.float64).tolist()))
+    assert sum(len(c) for c, _ in got.values()) == ci.size
+    with tempfile.TemporaryDirectory() as d:
+        plan.save(os.path.join(d, "p.plan"))
+        assert dasp.Plan.load(os.path.join(d, "p.plan")).stats["tp_segments"] == plan.stats["tp_segments"]
+
+
 @pytest.mark.gpu
 @settings(max_examples=int(os.environ.get("DASP_HYP_EXAMPLES", "80")), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
-@given(mat=matrices(), opts=OPTS, prec=st.sampled_from([64, 16]), from_device=st.booleans(), panels=st.sampled_from([1, 1, 2, 3, 5]))
-def test_spmv_matches_csr_for_arbitrary_matrices(dasp, oracle, mat, opts, prec, from_device, panels):
+@given(mat=matrices(), opts=OPTS, prec=st.sampled_from([64, 16]), from_device=st.booleans(), panels=st.sampled_from([1, 1, 2, 3, 5]), form=st.sampled_from([0, 0, 1, 2]))
+def test_spmv_matches_csr_for_arbitrary_matrices(dasp, oracle, mat, opts, prec, from_device, panels, form):
     import torch
     rp, ci, v, n = mat
     m = rp.size - 1
     dt = np.float64 if prec == 64 else np.float16
     tdt = torch.float64 if prec == 64 else torch.float16
     xh = (np.random.default_rng(int(rp[-1]) + m).integers(1, 9, n) / 8.0).astype(dt)
+    opts = dict(opts)
+    if form == 1 and prec == 16:
+        opts.update(two_phase=1, tp_col_block=[0, 8, 512][m % 3], tp_row_block=[0, 3, 100][n % 3])       # r5: the two-phase form, odd block sizes included
+    elif form == 2:
+        opts.update(long_cb=1)                                                                               # r5: hub rows of a column-panel plan column-blocked
     if from_device and m > 0:
         d = [torch.from_numpy(a).cuda() for a in (rp, ci if ci.size else np.zeros(1, np.int32), v.astype(dt) if v.size else np.zeros(1, dt))]
         plan = dasp.Plan.from_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), m, n, int(rp[-1]), precision=prec, **opts)
