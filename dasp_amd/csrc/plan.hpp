@@ -200,7 +200,10 @@ struct TwoPhase {
 // then adds every piece's step sums in order (no atomics: the result is the same in every run) and writes partial[c * n_rows + i]; a second kernel adds a row's n_cb partials and stores the result into the row's slot
 // of panel 0's partial buffer (which no panel writes: the row is empty there), so dasp_panel_sum_kernel folds it into y like any other partial result.
 // Streamed per nonzero: value + u16 local column (10 B in f64 against the 12 of B_alg), nothing gathers from global memory.
-constexpr int kLcbUnitElems = 32768;
+#ifndef DASP_LCB_UNIT
+#define DASP_LCB_UNIT 32768
+#endif
+constexpr int kLcbUnitElems = DASP_LCB_UNIT;      // elements per phase workgroup (A/B: 65536 -- fewer slices of x, a longer tail)
 constexpr int kLcbStep = 128;             // elements per STEP: a piece is padded to whole steps, so that a step belongs to one piece (one wave of f64 / a quarter wave of f16 per step)
 constexpr int kLcbUnitPieces = 1024;      // most pieces per unit (the sums of a unit's steps live in LDS beside the slice of x: <= kLcbUnitElems / kLcbStep + kLcbUnitPieces of them)
 constexpr unsigned short kLcbPadCol = 0xFFFFu;
