@@ -175,7 +175,7 @@ constexpr int kSlabDefaultF64 = 16, kSlabDefaultF16 = 24;
 enum BuildMode { kTop = 0, kMetaOnly = 1, kPanel = 2 };   // whole plan (may choose column panels) / order+stats only / one panel
 
 template <class T> static int build_panels(Plan &p, const int *rp, const int *ci, const T *val, int P, const DevCsr *dev);
-static int decide_panels(const Plan &p, const int *rp, const int *ci, const Remap &remap, const DevCsr *dev);
+static int decide_panels(const Plan &p, const int *rp, const int *ci, const Remap &remap, const DevCsr *dev, int *scattered = nullptr);
 
 // ---- the REFERENCE's geometry on the same input (VERDICT r3 missing #5).  The native tiles are 16 x K on 64-lane waves, so the padded sizes
 // this library stores differ from the ones the CUDA reference computes (8-row blocks, 8 x 4 tiles, 32-lane warps) -- and a CSV row written
@@ -304,9 +304,10 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         lap("sort columns");
     }
     if (mode == kTop) {
-        const int P = decide_panels(p, rp, ci, remap, dev);
+        int scattered = 0;
+        const int P = decide_panels(p, rp, ci, remap, dev, &scattered);
         if (P < 0) return P;
-        if (decide_two_phase(p, rp, P)) {
+        if (decide_two_phase(p, rp, scattered)) {
             // the two-phase (gather-free) form: order_rid and the classifier counters of the whole matrix (row lengths only), then the tile streams
             if (int rc = build_impl<T>(p, rp, ci, val, nullptr, kMetaOnly)) return rc;
             lap("whole-matrix meta");
@@ -1136,16 +1137,19 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
 // ---- column panels (opt.col_panels; DESIGN.md section 4 "column panels") -------------------------------------------------
 // auto rule: only matrices whose rows scatter over more x than an XCD's L2 holds gain from cache blocking; anything with
 // locality (FEM / stencil rows touch runs of neighbouring columns, banded rows stay inside a narrow span) is left alone.
-static int decide_panels(const Plan &p, const int *rp, const int *ci, const Remap &remap, const DevCsr *dev)
+// *scattered (r5; what the two-phase rule asks): 1 when a matrix of >= 16 M nonzeros has rows whose gathers scatter -- > 50 % of a sampled row's nonzeros on distinct
+// 128-byte lines of x, a third of the entries in rows spanning > x / 4 -- whatever the size of x and however hot some of its lines are
+static int decide_panels(const Plan &p, const int *rp, const int *ci, const Remap &remap, const DevCsr *dev, int *scattered)
 {
+    if (scattered) *scattered = 0;
     const int want = p.opt.col_panels;
-    if (want == 1 || want < 0) return 1;
     if (want > 64) { set_error("col_panels must be <= 64"); return DASP_ERR_ARG; }
     if (!p.dst_map.empty()) return 1;
+    if (want == 1 || want < 0) return 1;
     if (want >= 2) return p.nnz > 0 && p.m > 0 ? want : 1;
     const long long xlen = p.opt.n_parts > 0 ? (long long)p.opt.n_parts * p.opt.part_stride : (long long)p.n;
     const long long vb = p.geo.vbytes, xbytes = xlen * vb;
-    if (xbytes <= (4ll << 20) || p.nnz < (16 << 20) || p.m <= 0) return 1;      // x fits an XCD's L2: nothing to block (A/B: 2.9 MB loses 10 %, 4.4 MB wins 11 %)
+    if (p.nnz < (16 << 20) || p.m <= 0) return 1;
     const int line_shift = vb == 8 ? 4 : 6;                       // 128-byte lines of x
     const int S = 4096;
     long long entries = 0, lines = 0, wide = 0;
@@ -1177,7 +1181,10 @@ static int decide_panels(const Plan &p, const int *rp, const int *ci, const Rema
         if ((long long)(cols[take - 1] - cols[0]) * vb > xbytes / 4) wide += take;
     }
     if (entries < 4096) return 1;
+    // the two-phase form pays from a weaker scatter on (rmat_2M f16: 0.69 lines per entry, 49 % of the entries in wide rows: 0.135 -> 0.094 ms) than cache blocking does
+    if (scattered && (double)lines > 0.5 * (double)entries && (double)wide >= 0.33 * (double)entries) *scattered = 1;
     if ((double)lines <= 0.75 * (double)entries || (double)wide < 0.5 * (double)entries) return 1;
+    if (xbytes <= (4ll << 20)) return 1;      // x fits an XCD's L2: nothing to block (A/B: 2.9 MB loses 10 %, 4.4 MB wins 11 %)
     {   // scattered is not enough: real graphs have popular columns, and if the hottest 3 MiB of x lines already take most of
         // the gathers the L2 serves them without blocking (R-MAT 2^21 f64: 92 % of the gathers on 3 MiB of lines, panels
         // -24 %; 2^23: 76 %, panels +9 %; the uniform stand-ins: 25-44 %, panels +45-55 %)

@@ -368,7 +368,7 @@ int build_plan(Plan &p, const int *rp, const int *ci, const void *val, const Dev
 
 // two-phase form (twophase.cpp): the automatic rule (1: use it), the packer (after build_impl's meta pass: p.order / p.stats are set) and the
 // checks a loaded plan file must pass
-int decide_two_phase(const Plan &p, const int *rp, int panels_wanted);
+int decide_two_phase(const Plan &p, const int *rp, int scattered);
 int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val);
 bool validate_two_phase(const Plan &p, std::string &why);
 

@@ -30,18 +30,19 @@ void for_each_block(int n, int threads, F f)
 }
 }  // namespace
 
-// the automatic rule (opt.two_phase == 0): f16, identity column map, a matrix the column-panel rule would split (its gathers scatter over more
-// x than an XCD's L2 holds and no few hot lines absorb them), and no row so long that its additions into ONE LDS word would serialise a
-// row block (R-MAT / Zipf hubs: the rmat_2M and powerlaw_1M stand-ins run 10-20x slower in this form, profiles/r05_two_phase.md)
-int decide_two_phase(const Plan &p, const int *rp, int panels_wanted)
+// the automatic rule (opt.two_phase == 0): f16, identity column map, no explicit choice of column panels, >= 16 M nonzeros in rows whose gathers scatter over x
+// (`scattered`: decide_panels' samples -- > 50 % of a row's nonzeros on distinct 128-byte lines, a third of the entries in rows spanning > x / 4).  Neither the size of x nor hot lines
+// matter to this form: powerlaw_1M f16 (x = 2 MB) 0.324 -> 0.209 ms, rmat_2M f16 (92 % of the gathers on 3 MiB of hot lines) 0.135 -> 0.094.  Hub rows are fine since
+// phase 2 combines a lane's consecutive same-row elements before the atomic (before that: rmat_2M 3.13 ms); small matrices lose (webbase-1M, 3.6 M nonzeros:
+// 0.0149 -> 0.0246 ms: two launches and a slice of x per workgroup), hence the 16 M.
+int decide_two_phase(const Plan &p, const int *rp, int scattered)
 {
+    (void)rp;
     if (p.panel || p.opt.two_phase < 0) return 0;
     if (p.opt.two_phase > 0) return 1;                              // forced: build_two_phase refuses what it cannot do
     if (p.precision != 16 || p.opt.n_parts > 0 || !p.dst_map.empty()) return 0;
-    if (panels_wanted < 2 || p.opt.col_panels >= 2) return 0;      // (an explicit panel count is the caller's choice of form)
-    int longest = 0;
-    for (int i = 0; i < p.m; ++i) longest = std::max(longest, rp[i + 1] - rp[i]);
-    return longest <= 8192 ? 1 : 0;
+    if (p.opt.col_panels >= 2 || p.opt.col_panels == 1 || p.opt.col_panels < 0) return 0;      // (an explicit choice about column panels is a choice of form)
+    return scattered ? 1 : 0;
 }
 
 int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val)

@@ -1425,11 +1425,11 @@ def test_column_panels_multi_gpu_layout_and_file(oracle, dasp, torch_cuda, tmp_p
 
 
 @pytest.mark.parametrize("name,prec,kw,form", [("powerlaw_1M", 64, {}, "panels"), ("ljournal-2008", 16, {}, "two_phase"), ("ljournal-2008", 16, {"two_phase": -1}, "panels"),
-                                                ("rmat_2M", 16, {}, "plain")])
+                                                ("rmat_2M", 16, {}, "two_phase"), ("rmat_2M", 16, {"two_phase": -1}, "plain")])
 def test_device_csr_takes_the_same_automatic_panel_decision(dasp, torch_cuda, name, prec, kw, form):
     """the AUTOMATIC column-panel rule on a device-resident CSR (r3): the sampled rows' columns and the strided sample of column ids
     are gathered by a kernel, the rule is the host's -- same number of panels, same counters, same y, at BASELINE's full size.  r5: where the rule fires
-    on an f16 matrix without hub rows the plan takes the two-phase form instead (ljournal-2008; two_phase = -1 keeps the panels); rmat_2M's hot columns keep it plain"""
+    on an f16 matrix the plan takes the two-phase form instead (ljournal-2008; two_phase = -1 keeps the panels) -- and so does rmat_2M, whose hot columns kept it out of the panels: the two-phase rule asks only for scattered rows"""
     torch = torch_cuda
     rows, cols = dasp.synth_dims(name, 1.0)
     rp, ci = dasp.synth_csr(name, 1.0)
