@@ -4,7 +4,7 @@ import os, re
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out") + "/"
 rows = [("HV15R f64 (`dasp_spmv_kernel<double,1,1,0,1>`)", "pmc_mfma_hv15r64.txt", "F64"), ("nlpkkt160 f64 (`dasp_spmv_kernel<double,1,1,0,0>`)", "pmc_mfma_nlp64.txt", "F64"),
         ("ljournal-2008 f16, DASP form (`two_phase = -1`: 4 column panels in one launch, `dasp_spmv_panels_kernel<half,..>`)", "pmc_mfma_lj16_dasp.txt", "F16"),
-        ("rmat_2M f16 (`dasp_spmv_kernel<half,..>`)", "pmc_mfma_rmat16.txt", "F16"), ("webbase-1M f16", "pmc_mfma_wb16.txt", "F16"),
+        ("rmat_2M f16, DASP form (`two_phase = -1`, `dasp_spmv_kernel<half,..>`)", "pmc_mfma_rmat16.txt", "F16"), ("webbase-1M f16", "pmc_mfma_wb16.txt", "F16"),
         ("ljournal-2008 f16, two-phase form (the product's choice; `dasp_tp_expand` + `dasp_tp_reduce`, mean of the two dispatches)", "pmc_tp_lj16.txt", "F16")]
 out = ["# r05 -- MFMA utilisation of this round's kernels at full size (north_star: \"choices evidenced by rocprof HBM GB/s and MFMA utilisation\"; VERDICT r4 next #8)\n",
        "Collected by `tools/round_end_r5.sh` (`tools/pmc.sh`: `rocprofv3 --kernel-trace --pmc <one group per pass> -- dasp_amd/bin/dasp_bench <workload> 1 <precision> ...`, the program itself after `--`); raw summaries `gpurun_out/pmc_mfma_*.txt`; this table: `tools/r5_mfma_table.py`.",

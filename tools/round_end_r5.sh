@@ -19,7 +19,7 @@ export PMC_GROUPS="SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_
 bash tools/pmc.sh mfma_hv15r64 -- $B HV15R 1 64 20 3 > /dev/null 2>&1
 bash tools/pmc.sh mfma_nlp64 -- $B nlpkkt160 1 64 20 3 > /dev/null 2>&1
 bash tools/pmc.sh mfma_lj16_dasp -- $B ljournal-2008 1 16 20 3 0.75 0 0 0 0 0 0 0 0 0 0 -1 > /dev/null 2>&1
-bash tools/pmc.sh mfma_rmat16 -- $B rmat_2M 1 16 50 3 > /dev/null 2>&1
+bash tools/pmc.sh mfma_rmat16 -- $B rmat_2M 1 16 50 3 0.75 0 0 0 0 0 0 0 0 0 0 -1 > /dev/null 2>&1      # (the DASP form: the product's choice for rmat_2M is two-phase since r5)
 bash tools/pmc.sh mfma_wb16 -- $B webbase-1M 1 16 200 3 > /dev/null 2>&1
 DASP_PMC_KERNELS="dasp_tp_" bash tools/pmc.sh tp_lj16 -- $B ljournal-2008 1 16 20 3 > /dev/null 2>&1
 ls gpurun_out/pmc_*.txt
