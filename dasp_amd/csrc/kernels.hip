@@ -239,19 +239,30 @@ __global__ __launch_bounds__(512) void dasp_tp_reduce_kernel(TpDev a, T *__restr
             const vec8 xv = __builtin_nontemporal_load(reinterpret_cast<const vec8 *>(xs + at));
             // a tile's elements are in row order: consecutive elements of one lane that share a row are added up first (in f64, exactly) and cost ONE atomic.  The long
             // rows at the head of the sorted order then collide far less on one LDS word: ljournal-2008 0.2108 -> 0.1747 ms, the uniform-column variant unchanged (0.174)
-            unsigned cur = kTpPadRow;
-            double run = 0.0;
+            unsigned cur = lr[0];
+            double run = (double)((float)v[0] * (float)xv[0]);
+            bool one_run = true;                               // all 8 elements of this lane belong to one row (the inside of a hub row's run)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 1; j < 8; ++j) {
                 const unsigned r = lr[j];
                 const double p = (double)((float)v[j] * (float)xv[j]);
                 if (r == cur) run += p;
                 else {
                     if (cur != kTpPadRow) __hip_atomic_fetch_add(yl + cur, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    cur = r; run = p;
+                    cur = r; run = p; one_run = false;
                 }
             }
-            if (cur != kTpPadRow) __hip_atomic_fetch_add(yl + cur, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // ... and ACROSS the lanes of one segment (8 lanes = one tile's 64 consecutive elements, rows ascending, so equal rows are neighbours): lanes that each hold
+            // one run of the same row -- the inside of a hub row's run -- are summed by a segmented scan (DPP row_shr 1, 2, 4) and the last lane of the run adds the
+            // total: one atomic per run instead of one per lane.  (Not across segments: two tiles of one instruction may both hold the row, with other rows between.)
+            const unsigned key = one_run && cur != kTpPadRow ? cur : 0x10000u + (unsigned)lane;
+            const int ls = lane % LPS;
+#define DASP_TP_SCAN(D, CTRL) if constexpr (D < LPS) { const unsigned k2 = (unsigned)__builtin_amdgcn_update_dpp((int)key, (int)key, CTRL, 0xf, 0xf, false); const double r2 = dpp_mov_f64<CTRL>(run); if (ls >= D && k2 == key) run += r2; }
+            DASP_TP_SCAN(1, 0x111) DASP_TP_SCAN(2, 0x112) DASP_TP_SCAN(4, 0x114)
+#undef DASP_TP_SCAN
+            const unsigned knext = (unsigned)__builtin_amdgcn_update_dpp((int)key, (int)key, 0x101, 0xf, 0xf, false);       // row_shl:1 -- the next lane's key (same segment: active whenever this lane is)
+            const bool last = ls == LPS - 1 || knext != key;
+            if (cur != kTpPadRow && last) __hip_atomic_fetch_add(yl + cur, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     __syncthreads();
