@@ -1,3 +1,4 @@
+"""tools/r5_hybrid_probe.py <workload> <H> -- r5: the rows of fewer than H nonzeros of an f16 stand-in alone, two-phase against the DASP kernels: what a hybrid plan (hub rows column-blocked, the rest two-phase) could gain (profiles/r05_long_cb.md)"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")

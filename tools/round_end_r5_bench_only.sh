@@ -1,3 +1,4 @@
+# tools/round_end_r5_bench_only.sh -- the bench + rocprof part of tools/round_end_r5.sh alone (after profiles/traffic.json was regenerated without a new PMC pass)
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/round_end_bench.json.log 2> gpurun_out/round_end_bench.err
 cp gpurun_out/bench_suite.json gpurun_out/round_end_bench_suite.json
 export TMPDIR=/tmp
