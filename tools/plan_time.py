@@ -27,5 +27,6 @@ else:      # f16 results: rounded beyond 2048, +inf beyond 65504
     ok = bool(torch.where(want > 65504.0, torch.isinf(got) | fine, fine).all().item())
 st = plan.stats
 b_alg = ci.size * (prec // 8 + 4) + (m + 1) * 4 + (n + m) * (prec // 8)
-print("%s f%d %s | %.4f ms = %.3f of the roofline | two_phase %d panels %d fill0 %.4f | %s | %s" % (name, prec, kw, e, b_alg / (e * 1e6) / 8000, st["two_phase"], st["n_col_panels"], st["rate_fill0"],
+print("%s f%d %s | %.4f ms = %.3f of the roofline | two_phase %d panels %d fill0 %.4f narrow chunks %d, %.3f B/nnz packed | %s | %s" % (name, prec, kw, e, b_alg / (e * 1e6) / 8000, st["two_phase"], st["n_col_panels"], st["rate_fill0"],
+      st["cid8_chunks"], st["data_X"] / max(1, ci.size),
       "exact" if ok else "WRONG", os.environ.get("DASP_AMD_SO", "product")))
