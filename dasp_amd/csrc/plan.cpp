@@ -787,7 +787,12 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         int longest = 0;
         for (int r : ridL) longest = std::max(longest, rp[r + 1] - rp[r]);
         const int one_piece = ab_knobs().one_piece_max;
-        if ((nnz_pieces <= 2000000 && longest <= 16384) || longest <= one_piece) piece = std::max(piece, longest);
+        // ... unless the longest row alone would outlast the rest of the launch AND the stage-2 launch it saves (~3 us): one wave walks it in batches of BATCH
+        // chunks, ~0.35 us each, against ~4 us + the matrix at ~5 TB/s for everything else (r5, tools/size_sweep.py: powerlaw_1M x0.03 -- 1.7 M nonzeros, hub rows of 15 728 -- f64 22.8 ->
+        // 10.1 us, f16 10.6 -> 7.7 us in pieces of 1024; webbase-1M's 4700-long rows stay whole: 6.4 us of chain in a 29 us launch, 3.2 in 14.6 for f16)
+        const double chain_us = 0.35 * (double)longest / (double)(geo.chunk * (f16 ? kMedBatch16 : kMedBatch64));
+        const double rest_us = 4.0 + 3.0 + (double)nnz * (double)(geo.vbytes + 4) / 5.0e6;
+        if ((nnz_pieces <= 2000000 && longest <= 16384 && chain_us <= rest_us) || longest <= one_piece) piece = std::max(piece, longest);
     }
     piece = std::max(geo.chunk, ceil_div(piece, geo.chunk) * geo.chunk);
     {
@@ -1149,7 +1154,9 @@ static int decide_panels(const Plan &p, const int *rp, const int *ci, const Rema
     if (want >= 2) return p.nnz > 0 && p.m > 0 ? want : 1;
     const long long xlen = p.opt.n_parts > 0 ? (long long)p.opt.n_parts * p.opt.part_stride : (long long)p.n;
     const long long vb = p.geo.vbytes, xbytes = xlen * vb;
-    if (p.nnz < (16 << 20) || p.m <= 0) return 1;
+    // (the two-phase form pays from ~10 M nonzeros on: rmat_2M x0.25 / x0.3 / x0.5 = 8.4 / 9.0 / 16.8 M: 0.0363 / 0.0354 / 0.0556 ms against 0.0323 / 0.0377 / 0.0609;
+    // webbase-1M x4 = 14.3 M: 0.0527 against 0.0651; cache blocking keeps its 16 M)
+    if (p.nnz < (10 << 20) || p.m <= 0) return 1;
     const int line_shift = vb == 8 ? 4 : 6;                       // 128-byte lines of x
     const int S = 4096;
     long long entries = 0, lines = 0, wide = 0;
@@ -1183,8 +1190,17 @@ static int decide_panels(const Plan &p, const int *rp, const int *ci, const Rema
     if (entries < 4096) return 1;
     // the two-phase form pays from a weaker scatter on (rmat_2M f16: 0.69 lines per entry, 49 % of the entries in wide rows: 0.135 -> 0.094 ms) than cache blocking does
     if (scattered && (double)lines > 0.5 * (double)entries && (double)wide >= 0.33 * (double)entries) *scattered = 1;
+    if (p.nnz < (16 << 20)) return 1;
     if ((double)lines <= 0.75 * (double)entries || (double)wide < 0.5 * (double)entries) return 1;
-    if (xbytes <= (4ll << 20)) return 1;      // x fits an XCD's L2: nothing to block (A/B: 2.9 MB loses 10 %, 4.4 MB wins 11 %)
+    if (xbytes <= (4ll << 20)) {      // x fits an XCD's L2: nothing to block (A/B: 2.9 MB loses 10 %, 4.4 MB wins 11 %) ...
+        // ... but hub rows that hold most of the nonzeros gain from the column-blocked form, which lives in a panel plan (longcb.cpp: x staged in LDS instead of
+        // one L1 miss per nonzero): two panels for its sake (r5: powerlaw_1M x0.3 f64, 27 M nonzeros, x = 2.5 MB: 0.141 -> 0.114 ms; 0.145 with the hubs left to the panels)
+        if (p.opt.long_cb < 0 || p.opt.n_parts > 0) return 1;
+        const long long h = std::max<long long>(p.opt.block_longest, 64ll * ((p.n + (vb == 8 ? 16384 : 32768) - 1) / (vb == 8 ? 16384 : 32768)));
+        long long hub = 0;
+        for (int i = 0; i < p.m; ++i) { const int len = rp[i + 1] - rp[i]; if (len >= h) hub += len; }
+        return hub * 2 >= (long long)p.nnz && hub < (long long)p.nnz ? 2 : 1;
+    }
     {   // scattered is not enough: real graphs have popular columns, and if the hottest 3 MiB of x lines already take most of
         // the gathers the L2 serves them without blocking (R-MAT 2^21 f64: 92 % of the gathers on 3 MiB of lines, panels
         // -24 %; 2^23: 76 %, panels +9 %; the uniform stand-ins: 25-44 %, panels +45-55 %)

@@ -472,6 +472,12 @@ def test_long_rows_stay_one_piece_when_none_is_very_long(dasp):
     m, pieces, rl = multi([5000] * 450 + [7] * 100, 8000)                         # 2.25 M long nonzeros in rows of 5000: pieces of 1024
     assert m == 450 and pieces == 450 * 5 and rl == 450
     assert multi([20000] * 3 + [7] * 100, 30000)[0] == 3                          # rows beyond 16384 are always cut
+    # r5: ... and a row is cut when walking it alone (one wave, ~0.35 us per batch of 256 f64 / 512 f16 elements) would outlast everything else of the launch
+    # plus the stage-2 launch that one piece per row saves (~7 us + the matrix at 5 TB/s)
+    assert multi([15000] * 3 + [7] * 1000, 30000) == (3, 45, 3)                   # 20 us of chain in a ~4 us launch: pieces of 1024
+    assert multi([4500] * 3 + [7] * 1000, 30000) == (0, 3, 3)                     # 6 us of chain: not worth a second launch
+    assert multi([10000] + [10] * 600000, 20000) == (0, 1, 1)                     # 13.7 us of chain beside 6 M nonzeros (~21 us): stays whole
+    assert multi([10000] + [10] * 100000, 20000) == (1, 10, 1)                    # ... beside 1 M nonzeros (~9.4 us): cut
 
 
 def test_corrupt_plan_files_are_rejected_not_trusted(dasp, tmp_path):

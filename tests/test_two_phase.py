@@ -114,3 +114,26 @@ def test_plan_file_round_trip_and_validator(dasp, tmp_path):
         dasp.Plan.load(str(tmp_path / "bad2.plan"))
     assert "permutation" in str(e.value)
     plan.close()
+
+
+def test_automatic_forms_by_size(dasp):
+    """the automatic rules' size gates (r5, tools/size_sweep.py): the two-phase form from ~10 M nonzeros on for an f16 matrix whose rows scatter; two column panels for the
+    sake of the column-blocked hub rows when those hold most of a >= 16 M-nonzero f64 matrix, even though x fits an XCD's L2"""
+    rng = np.random.default_rng(5)
+    def graph(m, per_row, hubs=0, hub_len=0):
+        lens = np.full(m, per_row, np.int64)
+        if hubs:
+            lens[rng.choice(m, hubs, replace=False)] = hub_len
+        rp = np.zeros(m + 1, np.int64); np.cumsum(lens, out=rp[1:])
+        ci = rng.integers(0, m, int(rp[-1]), dtype=np.int32)
+        return rp.astype(np.int32), ci
+    rp, ci = graph(700000, 16)                                       # 11.2 M nonzeros, uniform columns
+    assert dasp.Plan(rp, ci, np.ones(ci.size, np.float16), 700000, precision=16).stats["two_phase"] == 1
+    rp, ci = graph(700000, 13)                                       # 9.1 M: the plain kernels
+    assert dasp.Plan(rp, ci, np.ones(ci.size, np.float16), 700000, precision=16).stats["two_phase"] == 0
+    rp, ci = graph(300000, 24, hubs=2000, hub_len=5000)              # 17.2 M, 58 % of them in 2000 hub rows; x = 2.4 MB
+    st = dasp.Plan(rp, ci, np.ones(ci.size), 300000, precision=64).stats
+    assert st["n_col_panels"] == 2 and st["lcb_rows"] == 2000, st
+    rp, ci = graph(300000, 50, hubs=600, hub_len=5000)               # 18 M, 17 % in hub rows: nothing to block, nothing to stage
+    st = dasp.Plan(rp, ci, np.ones(ci.size), 300000, precision=64).stats
+    assert st["n_col_panels"] == 0 and st["lcb_rows"] == 0, st
