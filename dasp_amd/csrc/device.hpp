@@ -42,6 +42,10 @@ struct DevArgs {
     // short
     const void *short_val; const int *short_cid; const ShortDev *groups;
     int n_short_tiles;
+    // short tiles per wave: 1, or kShortTpw consecutive tiles of a wave-segmented group in plans that have such groups (spmv_device.hpp short_waves; upload_plan sizes wg_short
+    // with it).  Then wave w of the short range serves group gi = the last with grp_wave0[gi] <= w: tiles kShortTpw * (w - grp_wave0[gi]) .. of a segmented group, tile w - grp_wave0[gi] of any other
+    int short_tpw, n_short_waves;
+    int grp_wave0[kNumShortGroups];
     int grp_tile0[kNumShortGroups];   // first tile of every slab group (kernel arguments: the lookup is scalar)
     // permutation (DASP_Y_NATURAL only)
     const int *order;

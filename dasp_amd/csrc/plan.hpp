@@ -88,6 +88,10 @@ inline size_t med_elem_index(int npair, int c, int lane, int j, int vpl, int ch)
 {
     return c < npair ? (size_t)(c & ~1) * ch + (size_t)vpl * (2 * lane + (c & 1)) + j : (size_t)c * ch + (size_t)vpl * lane + j;
 }
+#ifndef DASP_SHORT_TPW
+#define DASP_SHORT_TPW 4
+#endif
+constexpr int kShortTpw = DASP_SHORT_TPW;      // wave-segmented short tiles (64 elements each) handled by one wave (device.hpp DevArgs::short_tpw)
 constexpr int kMedRows = 16;      // rows of one MFMA tile (v_mfma_*_16x16x*)
 constexpr int kLongAlign = 4;     // long rows start on a multiple of 4 elements
 constexpr int kSlabMaxLen = 32;     // longest medium row that can be stored as a uniform-length slab (opt.slab_max_len)

@@ -558,7 +558,7 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     const T *val = static_cast<const T *>(a.med_val);
     // tables through the CONSTANT address space (tab<>) wherever the compiler could not prove them unclobbered: the step kernels (YS != 0) and the windowed
     // kernels, whose blocks sit behind the barrier of the x copy (r4: cop20k_A x16, 1695 windows, 124.4 -> 111.1 us; the 212-window size is unchanged)
-    constexpr bool KT = YS != 0 || YM == 2;
+    constexpr bool KT = true;
     const int c0 = tab<KT>(a.med_ptr, b), c1 = tab<KT>(a.med_ptr, b + 1);
     acc_t acc = {0, 0, 0, 0};
     // the block's first row is its longest (rows are sorted), so its tail length bounds the number of tail steps
@@ -574,7 +574,7 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     src.nc = c1 - c0; src.npair = med_npair(c1 - c0, nt, (int)sizeof(T), YM == 2 ? 0 : a.pair_mode); src.cid16 = a.med_cid16; src.base = a.med_base; src.c0 = c0;
     src.c8 = a.med_cid8; src.w16 = a.med_cid16; src.n8 = 0;
     if constexpr (C8 && C16 && sizeof(T) == 8 && YM != 2) {
-        const int q0 = tab<YS != 0>(a.med_c8ptr, b), q1 = tab<YS != 0>(a.med_c8ptr, b + 1);
+        const int q0 = tab<true>(a.med_c8ptr, b), q1 = tab<true>(a.med_c8ptr, b + 1);
         src.n8 = q1 - q0; src.c8 = a.med_cid8 + (size_t)q0 * CH; src.w16 = a.med_cid16 - (size_t)q1 * CH;      // e16 - (e0 + n8 CH) = -(q0 + n8) CH
     }
     src.ival = static_cast<const T *>(a.irr_val); src.icid = a.irr_cid; src.t0 = t0; src.t1 = t1; src.kq = kq;
@@ -598,7 +598,7 @@ __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
     constexpr int VPL = CH / kWave;          // values per lane per MFMA: 1 (f64) / 4 (f16)
     const XGlobal<T> x{static_cast<const T *>(a.x)};
     const T *val = static_cast<const T *>(a.long_val);
-    const int p0 = tab<YS != 0>(a.piece_ptr, p), p1 = tab<YS != 0>(a.piece_ptr, p + 1);
+    const int p0 = tab<true>(a.piece_ptr, p), p1 = tab<true>(a.piece_ptr, p + 1);
     acc_t acc = {0, 0, 0, 0};
     const int full = p0 + (p1 - p0) / CH * CH;
     ChunkSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane};
@@ -621,7 +621,7 @@ __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
     const bool on_diag = diag_of(acc, lane, d);
     const part_t total = wave_sum(on_diag ? d : (part_t)0);
     if (lane == 0) {
-        const int dst = tab<YS != 0>(a.piece_dst, p);
+        const int dst = tab<true>(a.piece_dst, p);
         if (dst >= 0) put_y<T, YS>(a, dst, total);
         else static_cast<part_t *>(a.partial)[~dst] = total;
     }
@@ -705,6 +705,46 @@ __device__ __forceinline__ void short_rows_seg(const DevArgs &a, const ShortDev 
     }
 }
 
+// TPW consecutive tiles of ONE wave-segmented group in one wave (r5): every load of the TPW tiles is issued before the first gather, every gather before the first
+// DPP step.  nv (wave-uniform) = how many of the tiles exist; the others repeat the first tile's addresses and store nothing.
+template <class T, int L, bool NT, int TPW>
+__device__ __forceinline__ void short_rows_seg_multi(const DevArgs &a, const ShortDev &g, int local0, int nv, int lane)
+{
+    constexpr int PER16 = 16 / L, RPW = 4 * PER16;
+    using part_t = typename Tr<T>::part_t;
+    const T *x = static_cast<const T *>(a.x);
+    const int sub = lane & 15, rloc = sub / L, k = sub - rloc * L;
+    T av[TPW]; int c[TPW]; T xv[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const size_t e = (size_t)g.elem_off + (size_t)(local0 + (u < nv ? u : 0)) * kWave + (size_t)lane;
+        av[u] = ldg<NT>(static_cast<const T *>(a.short_val) + e);
+        c[u] = ldg<NT>(a.short_cid + e);
+    }
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) xv[u] = x[c[u] < 0 ? 0 : c[u]];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        part_t p = c[u] < 0 ? (part_t)0 : (part_t)av[u] * (part_t)xv[u];
+        if constexpr (L >= 2) {
+            part_t q;
+            if constexpr (sizeof(part_t) == 8) q = dpp_mov_f64<0x101>(p); else q = dpp_mov_f32<0x101>(p);
+            if (k + 1 < L) p += q;
+        }
+        if constexpr (L >= 3) {
+            part_t q;
+            if constexpr (sizeof(part_t) == 8) q = dpp_mov_f64<0x102>(p); else q = dpp_mov_f32<0x102>(p);
+            if (k == 0) p += q;
+        }
+        const int t = (local0 + u) * RPW + (lane >> 4) * PER16 + rloc;
+        if (u < nv && k == 0 && rloc < PER16 && t < g.count) {
+            const int slot = slot_of(g.map, t);
+            const int yi = a.order ? a.order[slot] : slot;
+            put_y<T>(a, yi, p);
+        }
+    }
+}
+
 // the same for the medium rows stored as slabs (5 <= L <= kSlabMaxLen): L is a run-time value, four steps in flight
 template <class T, bool NT, int YS = 0>
 __device__ __forceinline__ void slab_rows(const DevArgs &a, const ShortDev &g, int local_tile, int lane)
@@ -785,6 +825,27 @@ __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
         case 3: short_rows<T, 3, NT, YS>(a, g, local, lane); break;
         case 4: short_rows<T, 4, NT, YS>(a, g, local, lane); break;
         default: slab_rows<T, NT, YS>(a, g, local, lane); break;
+    }
+}
+
+// wave w of the short range of a plan with wave-segmented groups (DevArgs::grp_wave0): TPW consecutive tiles of a segmented group, one tile of any other group -- a
+// wave never straddles two groups, so there is no loop here (a store followed by another tile's loads in one function costs the f64 kernels their scalar table loads:
+// tests/test_isa_guard.py)
+template <class T, bool NT, int TPW>
+__device__ __forceinline__ void short_waves(const DevArgs &a, int w, int lane)
+{
+    int gi = 0, w0 = 0;      // (constant indices + selects: a run-time index into DevArgs would pin the whole block in scratch, load_args)
+#pragma unroll
+    for (int g = 1; g < kNumShortGroups; ++g) { const bool in = w >= a.grp_wave0[g]; gi = in ? g : gi; w0 = in ? a.grp_wave0[g] : w0; }
+    const ShortDev g = a.groups[gi];
+    const int lw = w - w0;
+    if (!g.seg) { short_tile<T, NT, 0, false>(a, g.tile0 + lw, lane); return; }
+    const int local0 = lw * TPW, nv = min(TPW, g.tiles - local0);
+    switch (g.len) {
+        case 1: short_rows_seg_multi<T, 1, NT, TPW>(a, g, local0, nv, lane); break;
+        case 2: short_rows_seg_multi<T, 2, NT, TPW>(a, g, local0, nv, lane); break;
+        case 3: short_rows_seg_multi<T, 3, NT, TPW>(a, g, local0, nv, lane); break;
+        default: short_rows_seg_multi<T, 4, NT, TPW>(a, g, local0, nv, lane); break;
     }
 }
 
@@ -915,6 +976,12 @@ __device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw, int w
         }
     } else if (!RT || wg < a.wg_long + a.wg_med + a.wg_short) {
         const int t = (wg - a.wg_long - a.wg_med) * wpw + wave;
+        if constexpr (!WIN && sizeof(T) == 8) {      // (f64 only: the f16 kernels are held to 72 registers and never segment their short rows by themselves)
+            if (a.short_tpw > 1) {      // plans with wave-segmented groups: kShortTpw tiles per wave (upload_plan)
+                if (t < a.n_short_waves) short_waves<T, NT, kShortTpw>(a, t, lane);
+                return;
+            }
+        }
         if (t < a.n_short_tiles) short_tile<T, NT, 0, !WIN>(a, t, lane);
     } else if constexpr (RT) {
         const int t = (wg - a.wg_long - a.wg_med - a.wg_short) * kWavesPerWG + wave;

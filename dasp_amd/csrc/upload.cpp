@@ -271,7 +271,12 @@ static int upload_plan_impl(Plan &p)
             a.wg_med = 8 * ((most + kWavesPerWG - 1) / kWavesPerWG);
         }
     }
-    a.wg_short = (a.n_short_tiles + a.wpw - 1) / a.wpw;
+    // wave-segmented groups hold 64 ELEMENTS per tile: one tile per wave leaves a wave's fixed cost (arguments, group tables) and one memory round trip per 768 bytes -- a matrix of
+    // short rows only ran at 0.35 of the roofline.  Such plans (f64, no windows, never the multi-GPU step's) hand kShortTpw consecutive tiles to a wave, all loads issued up front
+    a.short_tpw = p.stats.short_seg && !p.windowed && p.precision == 64 ? kShortTpw : 1;
+    a.n_short_waves = 0;
+    for (int g = 0; g < kNumShortGroups; ++g) { a.grp_wave0[g] = a.n_short_waves; a.n_short_waves += p.grp[g].seg && a.short_tpw > 1 ? (p.grp[g].tiles + a.short_tpw - 1) / a.short_tpw : p.grp[g].tiles; }
+    a.wg_short = (a.n_short_waves + a.wpw - 1) / a.wpw;
     a.rt_val = base + o_rv; a.rt_cid = (const int *)(base + o_rc); a.rt_ptr = (const int *)(base + o_rp);
     a.rt_start = (const unsigned short *)(base + o_rs); a.rt_mask = (const unsigned long long *)(base + o_rm);
     a.n_rt_tiles = (int)p.rt_mask.size(); a.wg_rt = (a.n_rt_tiles + kWavesPerWG - 1) / kWavesPerWG; a.rt_max = p.rt_max;

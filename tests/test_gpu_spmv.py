@@ -1031,6 +1031,31 @@ def test_bench_bare_multi_gpu_launch_needs_that_many_devices(torch_cuda):
     assert r.returncode == 4 and "need 2 devices" in r.stderr
 
 
+@pytest.mark.parametrize("tiles", [1, 2, 3, 4, 5, 7, 8, 9, 13])
+@pytest.mark.parametrize("natural", [0, 1])
+def test_segmented_short_tiles_go_to_a_wave_in_fours(oracle, dasp, torch_cuda, tiles, natural):
+    """r5: an f64 plan with wave-segmented short rows hands kShortTpw = 4 consecutive tiles of ONE group to a wave (DevArgs::grp_wave0), the group's last wave
+    fewer; no wave straddles two groups.  Every group here has `tiles` tiles (+ a partial last one), so the last wave holds 1..4 of them; exact against the CSR product
+    (values and x are small integers / 8)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(tiles)
+    per_tile = {1: 64, 2: 32, 3: 20, 4: 16}                      # rows of one 64-element tile (plan.hpp short_seg_rows)
+    lens = np.concatenate([np.full(per_tile[L] * (tiles - 1) + 1 + int(rng.integers(0, per_tile[L] - 1)), L) for L in (1, 2, 3, 4)] + [np.full(7, 0), np.full(33, 6)])
+    lens = lens[rng.permutation(lens.size)]
+    m, n = lens.size, 5000
+    rp = np.zeros(m + 1, np.int32); rp[1:] = np.cumsum(lens)
+    ci = rng.integers(0, n, rp[-1]).astype(np.int32)
+    v = rng.integers(1, 17, rp[-1]).astype(np.float64) / 8.0
+    x = rng.integers(1, 17, n).astype(np.float64) / 8.0
+    for kw in (dict(), dict(col_panels=2)):
+        plan = dasp.Plan(rp, ci, v, n, precision=64, short_seg=1, x_window=-1, y_order=natural, **kw)
+        assert plan.stats["short_seg"] == 1
+        got = run_spmv(torch, plan.upload(), x, m, 64)
+        ref = oracle.csr_spmv(rp, ci, v, x)
+        assert np.array_equal(got, ref if natural else ref[plan.order_rid]), kw
+        plan.close()
+
+
 @pytest.mark.parametrize("prec", [64, 16])
 @pytest.mark.parametrize("seg", [1, -1])
 @pytest.mark.parametrize("natural", [0, 1])

@@ -1,0 +1,11 @@
+# tools/r5_short_multi_ab.sh -- r5: several wave-segmented short tiles per wave (+ every per-block table through the constant address space) against the build before (tools/ab/libdasp_amd_base.so)
+export SWEEP_ONLY="short rows,circuit,empty rows,mixed" SWEEP_PREC=64
+echo "== base"; DASP_AMD_SO=tools/ab/libdasp_amd_base.so python3 tools/category_sweep.py 2>&1 | grep " us "
+echo "== new";  python3 tools/category_sweep.py 2>&1 | grep " us "
+export DASP_PLACEMENT_TRIALS=4
+for w in "HV15R 64" "nlpkkt160 64" "Queen_4147 64" "HV15R-unstructured 64" "powerlaw_1M 64" "webbase-1M 64" "cop20k_A 64" "webbase-1M 16" "rmat_2M 16"; do
+  for rep in 1 2; do
+    DASP_AMD_SO=tools/ab/libdasp_amd_base.so python3 tools/plan_time.py $w 2>&1 | tail -1
+    python3 tools/plan_time.py $w 2>&1 | tail -1
+  done
+done
