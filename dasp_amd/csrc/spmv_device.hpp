@@ -123,6 +123,24 @@ __device__ __forceinline__ DevArgs load_args(const CallArgs &c)
     return a;
 }
 
+// the arrays INSIDE DevArgs are only ever read at compile-time indices: one run-time index, and the compiler keeps the array (or the whole block) in scratch and reaches
+// it with flat loads -- which is also what a `#pragma unroll` loop turns into when a kernel grows and the unroller gives up (r5: the 36 bytes of xcd_blk in the row-tile
+// kernel).  Template recursion cannot be "not unrolled".
+// last_le: the last index i in [1, N) with w >= arr[i] (0 if none), and arr[that index] (0 for index 0)
+template <int I, int N> struct LastLE {
+    static __device__ __forceinline__ void run(const int (&arr)[N], int w, int &idx, int &val)
+    {
+        if constexpr (I < N) { const bool in = w >= arr[I]; idx = in ? I : idx; val = in ? arr[I] : val; LastLE<I + 1, N>::run(arr, w, idx, val); }
+    }
+};
+// pick: arr[k], arr[k + 1] for a run-time k in [0, N - 1)
+template <int I, int N> struct PickPair {
+    static __device__ __forceinline__ void run(const int (&arr)[N], int k, int &lo, int &hi)
+    {
+        if constexpr (I + 1 < N) { lo = k == I ? arr[I] : lo; hi = k == I ? arr[I + 1] : hi; PickPair<I + 1, N>::run(arr, k, lo, hi); }
+    }
+};
+
 __device__ __forceinline__ int slot_of(const SlotMap &m, int t)
 {
     const int p = t < m.split ? 0 : 1;
@@ -232,6 +250,33 @@ struct ChunkSrc {
     const T *val; const int *cid; size_t e0; int lane;
     template <bool PAIRED_OK = true> __device__ __forceinline__ void load(Frag<T> &f, int i) const { frag_load<NT>(f, val, cid, e0 + (size_t)i * Tr<T>::CHUNK, lane); }
     template <bool QUAD = false, class XV> __device__ __forceinline__ void gather(Frag<T> &f, int, const XV &x) const { frag_gather(f, x); }
+};
+
+// a long piece: nfull whole chunks, then (tail > 0) its last, partial chunk as one more step of the SAME stream (r5: issued beside the whole chunks instead of behind
+// their gathers -- a row of 300 is four chunks and a tail, and a wave's life was two dependent rounds of stream + gather instead of one: tools/category_sweep.py).
+// Rows are padded to kLongAlign, so a lane's group of the tail is all-in or all-out; lanes beyond it re-read the piece's first group (in bounds) and gather x[0] times 0.
+template <class T, bool NT>
+struct PieceSrc {
+    static constexpr bool kPairs = false, kQuadIds = false;
+    static constexpr int VPL = Tr<T>::CHUNK / kWave;
+    const T *val; const int *cid; size_t e0; int lane, nfull, tail;
+    template <bool PAIRED_OK = true> __device__ __forceinline__ void load(Frag<T> &f, int i) const
+    {
+        if (i < nfull) frag_load<NT>(f, val, cid, e0 + (size_t)i * Tr<T>::CHUNK, lane);
+        else frag_load_at<NT>(f, val, cid, VPL * lane < tail ? e0 + (size_t)i * Tr<T>::CHUNK + (size_t)(VPL * lane) : e0);
+    }
+    template <bool QUAD = false, class XV> __device__ __forceinline__ void gather(Frag<T> &f, int i, const XV &x) const
+    {
+        if (i >= nfull) {
+            const bool ok = VPL * lane < tail;
+            if constexpr (VPL == 1) { f.c = ok ? f.c : -1; f.a = ok ? f.a : 0.0; }      // (the value too: the re-read element may be inf / NaN)
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f.c[j] = ok ? f.c[j] : -1; f.a[j] = ok ? f.a[j] : (_Float16)0; }
+            }
+        }
+        frag_gather(f, x);
+    }
 };
 
 // a medium block: nc lane-linear chunks, then the irregular tail as extra steps in which lane (row = l&15, kq = l>>4)
@@ -589,7 +634,9 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
 }
 
 // ---- long: one wave = one piece (<= long_piece elements) of one long row (reference: dasp_f64.h:90-144)
-template <class T, bool NT, int YS = 0>
+// TAIL_IN: the partial last chunk rides in the stream (PieceSrc) -- the plain kernels; the windowed and the multi-GPU step kernels, which sit at their register caps,
+// keep it as a step of its own behind the stream
+template <class T, bool NT, int YS = 0, bool TAIL_IN = false>
 __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
 {
     using acc_t = typename Tr<T>::acc_t;
@@ -600,22 +647,28 @@ __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
     const T *val = static_cast<const T *>(a.long_val);
     const int p0 = tab<true>(a.piece_ptr, p), p1 = tab<true>(a.piece_ptr, p + 1);
     acc_t acc = {0, 0, 0, 0};
-    const int full = p0 + (p1 - p0) / CH * CH;
-    ChunkSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane};
-    run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, (full - p0) / CH, x);
-    if (full < p1) {   // last, partial chunk: rows are padded to kLongAlign, so a lane's group is all-in or all-out;
-                       // out-of-range lanes re-read the piece's first group (in bounds) and are zeroed
-        const int i = full + VPL * lane;
-        const bool ok = i < p1;
-        Frag<T> f;
-        frag_load_at<NT>(f, val, a.long_cid, (size_t)(ok ? i : p0));
-        frag_gather(f, x);
-        if constexpr (VPL == 1) { f.a = ok ? f.a : 0.0; f.b = ok ? f.b : 0.0; }
-        else {
+    const int nfull = (p1 - p0) / CH, tail = (p1 - p0) - nfull * CH;
+    if (TAIL_IN && tail > 0) {       // (pieces of whole chunks -- every piece but the last of a row cut in pieces -- keep the stream without the per-step test: rmat_2M f64 +1.3 % with it)
+        const PieceSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane, nfull, tail};
+        run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, nfull + 1, x);
+    } else {
+        const int full = p0 + nfull * CH;
+        ChunkSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane};
+        run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, nfull, x);
+        if (full < p1) {   // last, partial chunk: rows are padded to kLongAlign, so a lane's group is all-in or all-out;
+                           // out-of-range lanes re-read the piece's first group (in bounds) and are zeroed
+            const int i = full + VPL * lane;
+            const bool ok = i < p1;
+            Frag<T> f;
+            frag_load_at<NT>(f, val, a.long_cid, (size_t)(ok ? i : p0));
+            frag_gather(f, x);
+            if constexpr (VPL == 1) { f.a = ok ? f.a : 0.0; f.b = ok ? f.b : 0.0; }
+            else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { f.a[j] = ok ? f.a[j] : (_Float16)0; f.b[j] = ok ? f.b[j] : (_Float16)0; }
+                for (int j = 0; j < 4; ++j) { f.a[j] = ok ? f.a[j] : (_Float16)0; f.b[j] = ok ? f.b[j] : (_Float16)0; }
+            }
+            frag_mfma(acc, f);
         }
-        frag_mfma(acc, f);
     }
     part_t d;
     const bool on_diag = diag_of(acc, lane, d);
@@ -794,8 +847,8 @@ __device__ __forceinline__ void slab_rows(const DevArgs &a, const ShortDev &g, i
 template <class T, bool NT, int YS = 0, bool SEG = true>
 __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
 {
-    int gi = 0;
-    for (int g = 1; g < kNumShortGroups; ++g) if (tile >= a.grp_tile0[g]) gi = g;     // kernel arguments: scalar compares
+    int gi = 0, t0_unused = 0;
+    LastLE<1, kNumShortGroups>::run(a.grp_tile0, tile, gi, t0_unused);     // scalar compares
     ShortDev g;
     if constexpr (YS != 0) {      // word by word through the constant address space (see tab)
         static_assert(sizeof(ShortDev) % 4 == 0, "ShortDev is a whole number of words");
@@ -834,9 +887,8 @@ __device__ __forceinline__ void short_tile(const DevArgs &a, int tile, int lane)
 template <class T, bool NT, int TPW>
 __device__ __forceinline__ void short_waves(const DevArgs &a, int w, int lane)
 {
-    int gi = 0, w0 = 0;      // (constant indices + selects: a run-time index into DevArgs would pin the whole block in scratch, load_args)
-#pragma unroll
-    for (int g = 1; g < kNumShortGroups; ++g) { const bool in = w >= a.grp_wave0[g]; gi = in ? g : gi; w0 = in ? a.grp_wave0[g] : w0; }
+    int gi = 0, w0 = 0;
+    LastLE<1, kNumShortGroups>::run(a.grp_wave0, w, gi, w0);
     const ShortDev g = a.groups[gi];
     const int lw = w - w0;
     if (!g.seg) { short_tile<T, NT, 0, false>(a, g.tile0 + lw, lane); return; }
@@ -893,7 +945,7 @@ __device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw, int w
     const int wpw = WIN ? a.wpw : kWavesPerWG;
     if (wg < a.wg_long) {
         const int p = wg * wpw + wave;
-        if (p < a.n_pieces) long_piece<T, NT>(a, p, lane);
+        if (p < a.n_pieces) long_piece<T, NT, 0, !WIN>(a, p, lane);
     } else if (wg < a.wg_long + a.wg_med) {
         if constexpr (!WIN) {
             const int m = wg - a.wg_long;
@@ -906,8 +958,7 @@ __device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw, int w
                 // (constant indices + scalar selects instead of xcd_blk[k]: a run-time index into DevArgs would pin the whole block in scratch, load_args)
                 const int k = m & 7;
                 int lo = a.xcd_blk[0], hi = a.xcd_blk[1];
-#pragma unroll
-                for (int i = 1; i < 8; ++i) { lo = k == i ? a.xcd_blk[i] : lo; hi = k == i ? a.xcd_blk[i + 1] : hi; }
+                PickPair<1, 9>::run(a.xcd_blk, k, lo, hi);
                 const int b = lo + (m >> 3) * kWavesPerWG + wave;
                 if (b < hi) medium_block<T, NT, C16, 0, C8>(a, b, lane, x);
             } else if (sizeof(T) == 8 && !a.med_stride) {
