@@ -97,6 +97,10 @@ struct DevicePlan {
     LcbDev lcb{};           // a column-panel parent with column-blocked long rows: its arrays follow the partial-result buffers in the arena
     bool nt = false;
     bool win1 = false;      // windowed plan with at most one window workgroup per CU: launch dasp_spmv_win1_kernel
+    // f64, no windows: most of the regular chunks sit in ONE-SHOT blocks (rows of <= 32: all of a block's loads in flight at once, a wave's life is two memory round
+    // trips for 3-8 KB) -- such a plan runs the build held to 72 registers = 7 waves per SIMD (kernels.hip; r5: rows of 40 0.74 -> 0.83, rows of 17 0.65 -> 0.71 of the
+    // roofline; the pipelined blocks of long medium rows lose 4 % in that build and keep the unconstrained one)
+    bool seven_waves = false;
     int device = -1;
     // column-panel parent: arena = the panels' partial results, panel k at ypart + k * ypart_stride elements
     size_t ypart_stride = 0;

@@ -37,8 +37,9 @@
 
 namespace dasp {
 
-template <class T, bool NT, bool C16, bool WIN, bool C8 = false>
-__global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : kMinWavesPlain) void dasp_spmv_kernel(CallArgs c)
+// MW (f64, no windows): 7 = the build held to 72 registers = 7 waves per SIMD, for plans of one-shot blocks (DevicePlan::seven_waves)
+template <class T, bool NT, bool C16, bool WIN, bool C8 = false, int MW = 0>
+__global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : MW ? MW : kMinWavesPlain) void dasp_spmv_kernel(CallArgs c)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     const DevArgs a = load_args(c);
@@ -444,8 +445,17 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
             if (c16) hipLaunchKernelGGL((dasp_spmv_win1_kernel<T, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
             else hipLaunchKernelGGL((dasp_spmv_win1_kernel<T, false>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
         } else if (sizeof(T) == 8 && c16 && !p.windowed && p.cnt_reg8 > 0) {      // plans with one-byte ids: their own instantiation
-            if (nt) hipLaunchKernelGGL((dasp_spmv_kernel<double, true, true, false, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
+            if (p.dev->seven_waves) {
+                if (nt) hipLaunchKernelGGL((dasp_spmv_kernel<double, true, true, false, true, 7>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
+                else hipLaunchKernelGGL((dasp_spmv_kernel<double, false, true, false, true, 7>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
+            }
+            else if (nt) hipLaunchKernelGGL((dasp_spmv_kernel<double, true, true, false, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
             else hipLaunchKernelGGL((dasp_spmv_kernel<double, false, true, false, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
+        } else if (sizeof(T) == 8 && !p.windowed && p.dev->seven_waves) {
+            if (nt && c16) hipLaunchKernelGGL((dasp_spmv_kernel<double, true, true, false, false, 7>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
+            else if (nt) hipLaunchKernelGGL((dasp_spmv_kernel<double, true, false, false, false, 7>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
+            else if (c16) hipLaunchKernelGGL((dasp_spmv_kernel<double, false, true, false, false, 7>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
+            else hipLaunchKernelGGL((dasp_spmv_kernel<double, false, false, false, false, 7>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
         } else
         DASP_FOR_EACH(DASP_LAUNCH)
 #undef DASP_LAUNCH

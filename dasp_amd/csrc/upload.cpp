@@ -215,6 +215,20 @@ static int upload_plan_impl(Plan &p)
     a.skip0 = p.panel ? 1 : 0;
     if (const char *e = std::getenv("DASP_WIN_XCD")) a.win_xcd = std::atoi(e);      // A/B knob
     d->win1 = false;
+    d->seven_waves = false;
+    if (p.precision == 64 && !p.windowed && p.med_ptr.size() > 1 && p.irr_ptr.size() > 1) {
+        long long one = 0, all = 0;
+        const int K = p.geo.med_k, nbk = (int)p.med_ptr.size() - 1;
+        for (int b = 0; b < nbk; ++b) {
+            const int nc = p.med_ptr[(size_t)b + 1] - p.med_ptr[(size_t)b], r0 = b * kMedRows;
+            const int nt = (p.irr_ptr[(size_t)r0 + 1] - p.irr_ptr[(size_t)r0] + K - 1) / K;
+            all += nc + nt;
+            if (med_oneshot64(nc, nt)) one += nc + nt;
+        }
+        // (bandwidth-bound plans only: webbase-1M f64, 43 MB in 29 us, loses 1.7 % on the 72-register build; nlpkkt160 0.4636 -> 0.4426 ms, x0.1 = 291 MB 41.6 -> 40.7 us)
+        d->seven_waves = all > 0 && one * 10 >= all * 7 && p.stats.data_X > (64ll << 20);
+        if (const char *e = std::getenv("DASP_SEVEN_WAVES")) d->seven_waves = std::atoi(e) != 0;      // A/B knob
+    }
     if (p.windowed) {
         int cus = 256;
         hipDeviceProp_t prop;
