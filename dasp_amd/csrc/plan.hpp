@@ -44,7 +44,10 @@ constexpr int kWavesPerWG = 4;    // 256-thread workgroups
 // 8-byte one: half the tag lookups per streamed byte, profiles/r02_pairs.md).  The remaining chunks, every chunk of a one-shot f64
 // block and every chunk of an LDS-windowed plan stay lane-linear [chunk][lane][vpl].  kMedBatch / kMedShot are the kernel's Tr<T>::BATCH / SHOT (static_assert there).
 // Shared by the host packer, the device packer and the plan validator; mirrored in tests/util.py.
-constexpr int kMedBatch64 = 4, kMedShot64 = 8, kMedBatch16 = 2, kMedShot16 = 2;      // (other values measured: profiles/r02_pairs.md section 3)
+#ifndef DASP_SHOT16
+#define DASP_SHOT16 4
+#endif
+constexpr int kMedBatch64 = 4, kMedShot64 = 8, kMedBatch16 = 2, kMedShot16 = DASP_SHOT16;      // (other values measured: profiles/r02_pairs.md section 3)
 #if defined(__HIPCC__)
 __host__ __device__
 #endif

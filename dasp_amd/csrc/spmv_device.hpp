@@ -154,11 +154,11 @@ __device__ __forceinline__ int slot_of(const SlotMap &m, int t)
 template <class T> struct Tr;
 template <> struct Tr<double> {
     using acc_t = f64x4; using part_t = double;
-    static constexpr int CHUNK = 64, SHORT_ROWS = 128, BATCH = kMedBatch64, SHOT = kMedShot64;
+    static constexpr int CHUNK = 64, SHORT_ROWS = 128, BATCH = kMedBatch64, SHOT = kMedShot64, LONG_SHOT = kMedShot64;
 };
 template <> struct Tr<_Float16> {
     using acc_t = f32x4; using part_t = float;
-    static constexpr int CHUNK = 256, SHORT_ROWS = 256, BATCH = kMedBatch16, SHOT = kMedShot16;
+    static constexpr int CHUNK = 256, SHORT_ROWS = 256, BATCH = kMedBatch16, SHOT = kMedShot16, LONG_SHOT = 2;      // (long pieces of up to 4 chunks in one shot: rows of 300 0.524 -> 0.458)
 };
 static_assert(Tr<double>::BATCH == kMedBatch64 && Tr<double>::SHOT == kMedShot64 && Tr<_Float16>::BATCH == kMedBatch16 &&
               Tr<_Float16>::SHOT == kMedShot16 && kMedBatch64 % 2 == 0 && kMedBatch16 % 2 == 0, "the packers' pairing rule (plan.hpp) follows the kernel's batches");
@@ -623,7 +623,8 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
         src.n8 = q1 - q0; src.c8 = a.med_cid8 + (size_t)q0 * CH; src.w16 = a.med_cid16 - (size_t)q1 * CH;      // e16 - (e0 + n8 CH) = -(q0 + n8) CH
     }
     src.ival = static_cast<const T *>(a.irr_val); src.icid = a.irr_cid; src.t0 = t0; src.t1 = t1; src.kq = kq;
-    run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, src.nc + nt, x);
+    // (the windowed f16 kernels, held to 64 registers, keep blocks of up to 2 steps in one shot: 4 spill there; windowed plans store no pairs, so their layout does not depend on it)
+    run_stream<T, Tr<T>::BATCH, (YM == 2 && sizeof(T) == 2) ? 2 : Tr<T>::SHOT>(acc, src, src.nc + nt, x);
 
     typename Tr<T>::part_t d;
     if (diag_of(acc, lane, d) && r < a.row_block) {
@@ -650,11 +651,11 @@ __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
     const int nfull = (p1 - p0) / CH, tail = (p1 - p0) - nfull * CH;
     if (TAIL_IN && tail > 0) {       // (pieces of whole chunks -- every piece but the last of a row cut in pieces -- keep the stream without the per-step test: rmat_2M f64 +1.3 % with it)
         const PieceSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane, nfull, tail};
-        run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, nfull + 1, x);
+        run_stream<T, Tr<T>::BATCH, Tr<T>::LONG_SHOT>(acc, src, nfull + 1, x);
     } else {
         const int full = p0 + nfull * CH;
         ChunkSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane};
-        run_stream<T, Tr<T>::BATCH, Tr<T>::SHOT>(acc, src, nfull, x);
+        run_stream<T, Tr<T>::BATCH, Tr<T>::LONG_SHOT>(acc, src, nfull, x);
         if (full < p1) {   // last, partial chunk: rows are padded to kLongAlign, so a lane's group is all-in or all-out;
                            // out-of-range lanes re-read the piece's first group (in bounds) and are zeroed
             const int i = full + VPL * lane;

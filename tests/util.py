@@ -151,7 +151,7 @@ def decode_plan(plan):
     VPL = CH // 64
 
     ip_all = plan.host_array("irr_ptr")
-    batch, shot = (4, 8) if prec == 64 else (2, 2)       # the kernel's pipeline batch / one-shot limit (plan.hpp med_npair)
+    batch, shot = (4, 8) if prec == 64 else (2, 4)       # the kernel's pipeline batch / one-shot limit (plan.hpp med_npair; for f16 both branches below pair the same chunks)
 
     def npair_of(b):
         """a block long enough for the kernel's pipeline (chunks + tail steps of its first row > shot) stores its leading
