@@ -2,7 +2,7 @@
 """tools/r5_mfma_table.py -- gpurun_out/pmc_mfma_*.txt / pmc_tp_lj16.txt (written by tools/round_end_r5.sh through tools/pmc.sh) -> profiles/r05_mfma_util.md"""
 import os, re
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out") + "/"
-rows = [("HV15R f64 (`dasp_spmv_kernel<double,1,1,0,1>`)", "pmc_mfma_hv15r64.txt", "F64"), ("nlpkkt160 f64 (`dasp_spmv_kernel<double,1,1,0,0>`)", "pmc_mfma_nlp64.txt", "F64"),
+rows = [("HV15R f64 (`dasp_spmv_kernel<double,1,1,0,1,0>`)", "pmc_mfma_hv15r64.txt", "F64"), ("nlpkkt160 f64 (`dasp_spmv_kernel<double,1,1,0,0,7>`: the 7-wave build)", "pmc_mfma_nlp64.txt", "F64"),
         ("ljournal-2008 f16, DASP form (`two_phase = -1`: 4 column panels in one launch, `dasp_spmv_panels_kernel<half,..>`)", "pmc_mfma_lj16_dasp.txt", "F16"),
         ("rmat_2M f16, DASP form (`two_phase = -1`, `dasp_spmv_kernel<half,..>`)", "pmc_mfma_rmat16.txt", "F16"), ("webbase-1M f16", "pmc_mfma_wb16.txt", "F16"),
         ("ljournal-2008 f16, two-phase form (the product's choice; `dasp_tp_expand` + `dasp_tp_reduce`, mean of the two dispatches)", "pmc_tp_lj16.txt", "F16")]
