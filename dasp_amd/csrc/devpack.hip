@@ -82,14 +82,14 @@ __global__ void k_line_scatter(const int *rp, const int *ci, const int *rows, in
     atomicAdd(out + 1, (unsigned long long)(e - b));
 }
 
-// one thread per pair of equally long rows: positions whose columns lie within 16 of each other
-__global__ void k_row_coherence(const int *rp, const int *ci, const int *rows, int npairs, RemapDev remap, unsigned long long *out)
+// one thread per pair of equally long rows: positions whose columns lie within `within` of each other
+__global__ void k_row_coherence(const int *rp, const int *ci, const int *rows, int npairs, RemapDev remap, unsigned long long *out, int within)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npairs) return;
     const int a = rp[rows[2 * i]], b = rp[rows[2 * i + 1]], len = rp[rows[2 * i] + 1] - a;
     int near = 0;
-    for (int k = 0; k < len; ++k) { const int d = remap(ci[a + k]) - remap(ci[b + k]); near += d > -16 && d < 16; }
+    for (int k = 0; k < len; ++k) { const int d = remap(ci[a + k]) - remap(ci[b + k]); near += d > -within && d < within; }
     atomicAdd(out, (unsigned long long)near);
     atomicAdd(out + 1, (unsigned long long)len);
 }
@@ -309,7 +309,7 @@ int devpack_line_scatter(const Plan &p, const DevCsr &d, const std::vector<int> 
     return DASP_OK;
 }
 
-int devpack_row_coherence(const Plan &p, const DevCsr &d, const std::vector<int> &rows, long long *near, long long *entries)
+int devpack_row_coherence(const Plan &p, const DevCsr &d, const std::vector<int> &rows, int within, long long *near, long long *entries)
 {
     *near = 0; *entries = 0;
     const int npairs = (int)(rows.size() / 2);
@@ -319,7 +319,7 @@ int devpack_row_coherence(const Plan &p, const DevCsr &d, const std::vector<int>
     unsigned long long h[2] = {0, 0};
     DevBuf<unsigned long long> dout; if (int rc = dout.init(2)) return rc;
     HIP_TRYP(hipMemset(dout.d, 0, sizeof h));
-    hipLaunchKernelGGL(k_row_coherence, dim3((npairs + 255) / 256), dim3(256), 0, 0, d.rp, d.ci, dr.d, npairs, rm.r, dout.d);
+    hipLaunchKernelGGL(k_row_coherence, dim3((npairs + 255) / 256), dim3(256), 0, 0, d.rp, d.ci, dr.d, npairs, rm.r, dout.d, within);
     HIP_TRYP(hipGetLastError());
     HIP_TRYP(hipMemcpy(h, dout.d, sizeof h, hipMemcpyDeviceToHost));
     *near = (long long)h[0]; *entries = (long long)h[1];

@@ -445,11 +445,19 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         for (int i = nmf; i + 1 < nmed_all; i += step)
             if (lenM[i] == lenM[i + 1]) { pairs.push_back(ridM[i]); pairs.push_back(ridM[i + 1]); }
         long long near = 0, entries = 0;
-        if (dev) { if (int rc = devpack_row_coherence(p, *dev, pairs, &near, &entries)) return rc; }
+        // "neighbouring": within a 128-byte line of x for f64.  f16 (late r5): within 512 columns -- an f16 tile holds 16 columns of a row, so rows of fewer than 12 have NO regular
+        // chunk at all (a 16 x 16 tile is never 75 % full) and their MFMA blocks are all tail steps: 8 M local rows of 5..8 run at 0.21 of the roofline as blocks, 0.62 as slabs; a
+        // circuit-like mix 0.32 -> 0.60; rows of 17 0.41 -> 0.61 (tools/scratch/circ_probe.py, tools/category_knobs.py).  The graph stand-ins, whose equally long neighbours are far
+        // apart in the matrix, stay blocks (slabs cost webbase-1M f16 15.1 -> 18.8 us, rmat_2M 0.134 -> 0.164 ms: tools/r5_f16_slab_probe.sh)
+        // Only where those degenerate rows are most of the candidates: rows of 12..24 in a band keep their blocks and with them the LDS windows (4.2)
+        long long cand_nnz = 0, tiny_nnz = 0;
+        for (int i = nmf; i < nmed_all; ++i) { cand_nnz += lenM[i]; if (lenM[i] < 12) tiny_nnz += lenM[i]; }
+        const int within = f16 && 2 * tiny_nnz >= cand_nnz ? 512 : 16;
+        if (dev) { if (int rc = devpack_row_coherence(p, *dev, pairs, within, &near, &entries)) return rc; }
         else
             for (size_t q = 0; q + 1 < pairs.size(); q += 2) {
                 const int a = rp[pairs[q]], b = rp[pairs[q + 1]], len = rp[pairs[q] + 1] - a;
-                for (int k = 0; k < len; ++k) { const int d = remap(ci[a + k]) - remap(ci[b + k]); near += d > -16 && d < 16; }
+                for (int k = 0; k < len; ++k) { const int d = remap(ci[a + k]) - remap(ci[b + k]); near += d > -within && d < within; }
                 entries += len;
             }
         // ... and only when those rows are most of the matrix: a minority of slab waves (128 rows x up to 16 sequential steps) next

@@ -341,7 +341,7 @@ int devpack_window_spans(const Plan &p, const DevCsr &d, const raw_vector<int> &
 int devpack_line_scatter(const Plan &p, const DevCsr &d, const std::vector<int> &rows, long long *lines, long long *entries);
 // over pairs of equally long rows (rows[2i], rows[2i+1]): entries compared, and how many lie within 16 columns of the other row's
 // entry at the same position
-int devpack_row_coherence(const Plan &p, const DevCsr &d, const std::vector<int> &rows, long long *near, long long *entries);
+int devpack_row_coherence(const Plan &p, const DevCsr &d, const std::vector<int> &rows, int within, long long *near, long long *entries);
 int devpack_chunk_spans(const Plan &p, const DevCsr &d, const raw_vector<int> &ridM, const raw_vector<int> &lenM,
                         const std::vector<int> &nchunks, int *k16, unsigned long long *narrow_mask);      // narrow_mask: nullptr or [blocks] (plan.cpp)
 int devpack_all(Plan &p, const DevCsr &d, const PackMeta &m);

@@ -27,7 +27,7 @@ int time_spmv_graph(Plan &, const void *, void *, void *, int, int, int, double 
 int devpack_validate(const Plan &, const DevCsr &) { return nodev(); }
 int devpack_window_spans(const Plan &, const DevCsr &, const raw_vector<int> &, int, int *, int *, long long *) { return nodev(); }
 int devpack_line_scatter(const Plan &, const DevCsr &, const std::vector<int> &, long long *, long long *) { return nodev(); }
-int devpack_row_coherence(const Plan &, const DevCsr &, const std::vector<int> &, long long *, long long *) { return nodev(); }
+int devpack_row_coherence(const Plan &, const DevCsr &, const std::vector<int> &, int, long long *, long long *) { return nodev(); }
 int devpack_chunk_spans(const Plan &, const DevCsr &, const raw_vector<int> &, const raw_vector<int> &, const std::vector<int> &, int *, unsigned long long *) { return nodev(); }
 int devpack_all(Plan &, const DevCsr &, const PackMeta &) { return nodev(); }
 int devpack_finish_panels(Plan &) { return nodev(); }

@@ -678,3 +678,24 @@ def test_many_plans_back_to_back_on_the_worker_pool(dasp):
         st = p.stats
         assert all(st[k] == stats[k] for k in ("row_long", "row_block", "n_med_blocks", "nnz_irreg", "n_short_tiles", "data_X"))
         p.close()
+
+
+def test_f16_rows_without_a_regular_chunk_become_slabs_when_neighbours_are_close(dasp):
+    """late r5: an f16 tile holds 16 columns of a row, so rows of fewer than 12 nonzeros never fill a regular chunk to 75 % -- their MFMA blocks are all tail steps (8 M such rows:
+    0.21 of the roofline as blocks, 0.62 as slabs).  For them the automatic slab rule accepts equally long neighbours whose columns lie within 512 (f64 and rows of 12..24: within a
+    128-byte line); scattered (graph-like) rows keep their blocks either way."""
+    rng = np.random.default_rng(3)
+    m = n = 200000
+    lens = rng.integers(5, 9, m)
+    rp = np.zeros(m + 1, np.int64); np.cumsum(lens, out=rp[1:])
+    rows = np.repeat(np.arange(m), lens)
+    k = np.arange(rp[-1]) - rp[rows]
+    local = np.clip(rows + rng.integers(-256, 257, m)[rows] + k, 0, n - 1).astype(np.int32)       # a row's columns consecutive from a start within +-256 of the row
+    far = rng.integers(0, n, int(rp[-1])).astype(np.int32)
+    rp = rp.astype(np.int32)
+    as16 = lambda ci, **kw: dasp.Plan(rp, ci, np.ones(ci.size, np.float16), n, precision=16, x_window=-1, **kw).stats
+    as64 = lambda ci: dasp.Plan(rp, ci, np.ones(ci.size), n, precision=64, x_window=-1).stats
+    assert as16(local)["n_med_blocks"] == 0 and as16(local)["n_short_tiles"] > 0            # slabs
+    assert as16(local, slab_max_len=4)["n_med_blocks"] == (m + 15) // 16                    # (what they would have been)
+    assert as16(far)["n_med_blocks"] == (m + 15) // 16                                      # scattered: blocks
+    assert as64(local)["n_med_blocks"] == (m + 15) // 16                                    # f64: its tiles hold 4 columns, rows of 5..8 fill them
