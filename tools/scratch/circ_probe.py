@@ -1,7 +1,8 @@
+"""tools/scratch/circ_probe.py -- r5: rows of 5..8 (a circuit-like mix, 8 M local rows of 5..8, 8 M stencil-like rows of 7) as MFMA blocks (slab_max_len=4), as slabs (16) and under the automatic rule, f64 and f16: the f16 rows have no regular chunk at all (profiles/r05_category_sweep.md section 5)"""
 import os, sys, numpy as np, torch
-sys.path.insert(0, '/root/repo/tools'); sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import dasp_amd as D
-src = open('/root/repo/tools/category_sweep.py').read().split("FAMILIES = [")[0]
+src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'category_sweep.py')).read().split("FAMILIES = [")[0]
 exec(src[src.index("rng = "):])
 M = 1 << 20
 for desc, (rp, ci), n in (("circuit", from_lengths(np.concatenate([rng.integers(1, 9, 4 * M - 60), np.full(60, 100000)])[rng.permutation(4 * M)], 4 * M, 256), 4 * M),

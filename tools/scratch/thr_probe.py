@@ -1,8 +1,8 @@
-"""r5 probe: the regular / irregular split threshold (reference default 0.75 of a tile) on f16, whose tiles are 16 x 16: more zero fill, fewer tail steps"""
+"""tools/scratch/thr_probe.py -- r5 probe: the regular / irregular split threshold (reference default 0.75 of a tile) on f16, whose tiles are 16 x 16: more zero fill, fewer tail steps"""
 import os, sys, numpy as np, torch
-sys.path.insert(0, '/root/repo/tools'); sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import dasp_amd as D
-src = open('/root/repo/tools/category_sweep.py').read().split("FAMILIES = [")[0]
+src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'category_sweep.py')).read().split("FAMILIES = [")[0]
 exec(src[src.index("rng = "):])
 M = 1 << 20
 cases = [("len 40", from_lengths(np.full(2 * M, 40), 2 * M, 256), 2 * M), ("len 17", from_lengths(np.full(4 * M, 17), 4 * M, 256), 4 * M), ("5..255", from_lengths(rng.integers(5, 256, M), M, 512), M)]
