@@ -255,36 +255,24 @@ struct ChunkSrc {
 // a long piece: nfull whole chunks, then (tail > 0) its last, partial chunk as one more step of the SAME stream (r5: issued beside the whole chunks instead of behind
 // their gathers -- a row of 300 is four chunks and a tail, and a wave's life was two dependent rounds of stream + gather instead of one: tools/category_sweep.py).
 // Rows are padded to kLongAlign, so a lane's group of the tail is all-in or all-out; lanes beyond it re-read the piece's first group (in bounds) and gather x[0] times 0.
-template <class T, bool NT, bool HAS_TAIL>
+template <class T, bool NT>
 struct PieceSrc {
-    // f64: two whole chunks = 128 consecutive elements arrive as TWO elements per lane -- one 16-byte value load and one 8-byte id load (any assignment of a row's elements to
-    // lanes sums the same row) -- like the medium blocks' chunk pairs, without a layout of their own: long rows are stored in CSR order
-    static constexpr bool kPairs = sizeof(T) == 8, kQuadIds = false;
+    static constexpr bool kPairs = false, kQuadIds = false;
     static constexpr int VPL = Tr<T>::CHUNK / kWave;
     const T *val; const int *cid; size_t e0; int lane, nfull, tail;
-    __device__ __forceinline__ bool pairs_ok(int i0, int n) const { return i0 + n <= nfull; }
-    __device__ __forceinline__ void load2(Frag<T> &f0, Frag<T> &f1, int i) const
-    {
-        const size_t at = e0 + (size_t)i * Tr<T>::CHUNK + 2 * (size_t)lane;
-        const f64x2 v = ldg<NT>(reinterpret_cast<const f64x2 *>(val + at));
-        const i32x2 c = ldg<NT>(reinterpret_cast<const i32x2 *>(cid + at));
-        f0.a = v[0]; f1.a = v[1]; f0.c = c[0]; f1.c = c[1];
-    }
     template <bool PAIRED_OK = true> __device__ __forceinline__ void load(Frag<T> &f, int i) const
     {
-        if (!HAS_TAIL || i < nfull) frag_load<NT>(f, val, cid, e0 + (size_t)i * Tr<T>::CHUNK, lane);
+        if (i < nfull) frag_load<NT>(f, val, cid, e0 + (size_t)i * Tr<T>::CHUNK, lane);
         else frag_load_at<NT>(f, val, cid, VPL * lane < tail ? e0 + (size_t)i * Tr<T>::CHUNK + (size_t)(VPL * lane) : e0);
     }
     template <bool QUAD = false, class XV> __device__ __forceinline__ void gather(Frag<T> &f, int i, const XV &x) const
     {
-        if constexpr (HAS_TAIL) {
-            if (i >= nfull) {
-                const bool ok = VPL * lane < tail;
-                if constexpr (VPL == 1) { f.c = ok ? f.c : -1; f.a = ok ? f.a : 0.0; }      // (the value too: the re-read element may be inf / NaN)
-                else {
+        if (i >= nfull) {
+            const bool ok = VPL * lane < tail;
+            if constexpr (VPL == 1) { f.c = ok ? f.c : -1; f.a = ok ? f.a : 0.0; }      // (the value too: the re-read element may be inf / NaN)
+            else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { f.c[j] = ok ? f.c[j] : -1; f.a[j] = ok ? f.a[j] : (_Float16)0; }
-                }
+                for (int j = 0; j < 4; ++j) { f.c[j] = ok ? f.c[j] : -1; f.a[j] = ok ? f.a[j] : (_Float16)0; }
             }
         }
         frag_gather(f, x);
@@ -662,11 +650,8 @@ __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
     acc_t acc = {0, 0, 0, 0};
     const int nfull = (p1 - p0) / CH, tail = (p1 - p0) - nfull * CH;
     if (TAIL_IN && tail > 0) {       // (pieces of whole chunks -- every piece but the last of a row cut in pieces -- keep the stream without the per-step test: rmat_2M f64 +1.3 % with it)
-        const PieceSrc<T, NT, true> src{val, a.long_cid, (size_t)p0, lane, nfull, tail};
+        const PieceSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane, nfull, tail};
         run_stream<T, Tr<T>::BATCH, Tr<T>::LONG_SHOT>(acc, src, nfull + 1, x);
-    } else if (TAIL_IN) {
-        const PieceSrc<T, NT, false> src{val, a.long_cid, (size_t)p0, lane, nfull, 0};
-        run_stream<T, Tr<T>::BATCH, Tr<T>::LONG_SHOT>(acc, src, nfull, x);
     } else {
         const int full = p0 + nfull * CH;
         ChunkSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane};
