@@ -84,7 +84,9 @@ typedef struct dasp_options {
     int block_longest;     /* rows with >= this many nonzeros are "long"; reference: 256 (main_f64.cu:124) */
     int y_order;           /* dasp_y_order */
     int long_piece;        /* nonzeros of a long row given to one wave; 0 = default (1024; the longest row when the long
-                              rows hold <= 2 M nonzeros in rows of <= 16384, or when no row is longer than 4096, so that no second launch is needed) */
+                              rows hold <= 2 M nonzeros in rows of <= 16384, or when no row is longer than 4096, so that no second launch is needed --
+                              unless one wave walking the longest row would outlast the rest of the launch: ~0.35 us per 256 f64 / 512 f16 elements
+                              against ~7 us + the matrix at 5 TB/s; then pieces of 1024 again) */
     int host_threads;      /* preprocessing threads; 0 = hardware concurrency */
     /* column remap for the row-partitioned multi-GPU layout (0/NULL = identity):
      * column c owned by part g (part_bounds[g] <= c < part_bounds[g+1]) is read from
@@ -121,7 +123,8 @@ typedef struct dasp_options {
      * kernel adds the panels' partial results.  order_rid and the classifier counters stay those of the whole matrix.
      *   0 = auto (on for matrices whose rows scatter over more x than the L2 holds: x > 4 MiB, >= 16 M nonzeros,
      *       > 75 % of a row's nonzeros on distinct 128-byte lines of x, rows spanning > x/4, and < 80 % of the gathers on the
-     *       hottest 3 MiB of x lines; for a device-resident CSR the samples are gathered by a kernel and the split runs on the GPU),
+     *       hottest 3 MiB of x lines; for a device-resident CSR the samples are gathered by a kernel and the split runs on the GPU;
+     *       also 2 panels when x fits the L2 but rows long enough for long_cb hold half the nonzeros: the panel plan is where they live),
      *   1 or -1 = off,  2..64 = that many panels.
      * f16: the per-panel partial results are rounded to binary16 before they are added (in f32). */
     int col_panels;
@@ -130,7 +133,8 @@ typedef struct dasp_options {
      * overhead (8 M rows of 5 nonzeros: 0.39 of the roofline as blocks, 0.8+ as slabs).  Their slots in order_rid stay the
      * medium rows' (sorted by length).  0 = auto: up to 16 (f64) / 24 (f16) nonzeros, and only when neighbouring rows read
      * neighbouring columns (stencils: the lanes' gathers coalesce; on graph-like rows slabs lose) and those
-     * rows hold at least half of the nonzeros;
+     * rows hold at least half of the nonzeros ("neighbouring" = within a 128-byte line of x; within 512 columns for f16 candidates that are mostly rows
+     * of fewer than 12 nonzeros: an f16 tile holds 16 columns of a row, such rows never fill a regular chunk and their blocks are all tail steps);
      * 4 = off; 5..32 = that bound, unconditionally. */
     int slab_max_len;
     /* hybrid x windows (graph-like rows: most columns near the rows, a scattered remainder).  When the whole span of a window
@@ -182,7 +186,8 @@ typedef struct dasp_options {
      * streams (value, local row, xs): every byte is streamed, 10 B per nonzero against the 6 of B_alg, nothing gathers from global memory
      * (ljournal-2008 f16: 0.43 -> 0.22 ms, the uniform-column variant 0.51 -> 0.18).  All rows take this path; order_rid and the classifier counters
      * stay those of the whole matrix; products are f16 x f16 accumulated in f64 (the order of a row's additions is not fixed: LDS atomics).
-     *   0 = auto: f16, no column remap, where the column-panel rule fires (col_panels) and no row is longer than 8192; 1 = force; -1 = off.
+     *   0 = auto: f16, no column remap, no explicit col_panels, >= 10 M nonzeros whose rows scatter (> 50 % of a sampled row's nonzeros on distinct 128-byte lines of x,
+     *       a third of the entries in rows spanning > x/4; hub rows are fine: same-row elements are combined before they reach LDS); 1 = force; -1 = off.
      *   tp_col_block: columns per column block (multiple of 8, <= 65536; 0 = 32768); tp_row_block: most output positions per row block (<= 8192; 0 = 4096). */
     int two_phase;
     int tp_col_block, tp_row_block;
