@@ -59,6 +59,18 @@ int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val)
     if (cb % 8 || cb < 8 || cb > 65536) { set_error("tp_col_block must be a multiple of 8 in 8 .. 65536"); return DASP_ERR_ARG; }
     if (rbm < 1 || rbm > 8192) { set_error("tp_row_block must be in 1 .. 8192"); return DASP_ERR_ARG; }
     const int threads = resolve_threads(p.opt.host_threads);
+    if (p.opt.tp_col_block <= 0 && nnz > 0) {
+        // auto: half-size column blocks when the columns are skewed -- one block of 32768 holding several times its share of the nonzeros (R-MAT: the heaviest holds 19 %, 12 x
+        // the mean; the other stand-ins 1.0-1.3 x).  rmat_2M f16 0.0893 -> 0.0826 ms; every even family prefers 32768 (fewer tiles, less padding: ljournal-2008 0.1745 / 0.1891,
+        // webbase-1M x4 0.0529 / 0.0690: tools/scratch/tp_blocks_sweep2.sh)
+        const int nb = std::max(1, (n + kTpColBlock - 1) / kTpColBlock);
+        std::vector<long long> hist((size_t)nb, 0);
+        const long long stride = std::max<long long>(1, nnz >> 22);              // <= ~4 M samples
+        long long taken = 0;
+        for (long long j = 0; j < nnz; j += stride) { hist[(size_t)(ci[j] / kTpColBlock)]++; ++taken; }
+        const long long heaviest = *std::max_element(hist.begin(), hist.end());
+        if (nb >= 8 && heaviest * nb > 4 * taken) cb = kTpColBlock / 2;
+    }
     TwoPhase &t = p.tp;
     t = TwoPhase{};
     t.cb = cb; t.rb_max = rbm;

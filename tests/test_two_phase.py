@@ -137,3 +137,20 @@ def test_automatic_forms_by_size(dasp):
     rp, ci = graph(300000, 50, hubs=600, hub_len=5000)               # 18 M, 17 % in hub rows: nothing to block, nothing to stage
     st = dasp.Plan(rp, ci, np.ones(ci.size), 300000, precision=64).stats
     assert st["n_col_panels"] == 0 and st["lcb_rows"] == 0, st
+
+
+def test_column_block_halves_when_the_columns_are_skewed(dasp):
+    """late r5: automatic tp_col_block -- 32768, or 16384 when one block of 32768 columns holds more than four times its share of the nonzeros (R-MAT graphs: rmat_2M f16
+    0.0893 -> 0.0826 ms; the even families prefer the larger block); an explicit tp_col_block is taken as given"""
+    rng = np.random.default_rng(9)
+    m, n, per = 40000, 300000, 8
+    rp = (np.arange(m + 1) * per).astype(np.int32)
+    even = rng.integers(0, n, m * per).astype(np.int32)
+    skew = np.where(rng.random(m * per) < 0.5, rng.integers(0, 32768, m * per), rng.integers(0, n, m * per)).astype(np.int32)     # half of the nonzeros in the first block of ten
+    v = np.ones(m * per, np.float16)
+    assert dasp.Plan(rp, even, v, n, precision=16, two_phase=1).stats["tp_col_block"] == 32768
+    sk = dasp.Plan(rp, skew, v, n, precision=16, two_phase=1)
+    assert sk.stats["tp_col_block"] == 16384
+    got = util.decode_plan(sk)
+    assert sum(len(c) for c, _ in got.values()) == skew.size
+    assert dasp.Plan(rp, skew, v, n, precision=16, two_phase=1, tp_col_block=32768).stats["tp_col_block"] == 32768
