@@ -1,4 +1,5 @@
 # tools/r5_short_multi_ab.sh -- r5: several wave-segmented short tiles per wave (+ every per-block table through the constant address space) against the build before (tools/ab/libdasp_amd_base.so)
+# (tools/ab/libdasp_amd_base*.so = the library of the commit before the change under test: `bash tools/build_rev.sh <rev> base && mkdir -p tools/ab && cp dasp_amd/variants/base/libdasp_amd.so tools/ab/<name the script uses>`; git-ignored, removed after the run)
 export SWEEP_ONLY="short rows,circuit,empty rows,mixed" SWEEP_PREC=64
 echo "== base"; DASP_AMD_SO=tools/ab/libdasp_amd_base.so python3 tools/category_sweep.py 2>&1 | grep " us "
 echo "== new";  python3 tools/category_sweep.py 2>&1 | grep " us "

@@ -1,4 +1,5 @@
 # tools/r5_slot_shift_ab.sh -- r5: slot_of with shifts instead of an integer division per lane (the 1&3 pairing groups are 8 / 32) against the build before (tools/ab/libdasp_amd_base3.so)
+# (tools/ab/libdasp_amd_base*.so = the library of the commit before the change under test: `bash tools/build_rev.sh <rev> base && mkdir -p tools/ab && cp dasp_amd/variants/base/libdasp_amd.so tools/ab/<name the script uses>`; git-ignored, removed after the run)
 export SWEEP_ONLY="short rows,circuit,empty rows"
 echo "== base"; DASP_AMD_SO=tools/ab/libdasp_amd_base3.so python3 tools/category_sweep.py 2>&1 | grep " us "
 echo "== new";  python3 tools/category_sweep.py 2>&1 | grep " us "
