@@ -725,6 +725,21 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                 }
             }
             worth = entries > 0 && (double)lines >= 0.6 * (double)entries;
+            // ... or when it is the GLOBAL LENGTH SORT that scatters: rows of many different lengths whose columns are local (the strict windows fit, so they are) end up in
+            // blocks of 16 rows from all over the matrix -- 16 regions of x per chunk whatever the rows' own runs.  Windows sort inside R rows only and stage those rows' x
+            // (late r5, tools/scratch/window_order_probe.py / window_size_probe.py: 1 M local rows of 5..255 f64 0.571 -> 0.792 of the roofline, f16 0.623 -> 0.892; 4 M rows of
+            // 10..60 0.628 -> 0.722 / 0.546 -> 0.780; pays from ~8 M nonzeros on, so: >= 16 M).  Rows of one length (HV15R, Queen_4147) keep their row order in the sort and are
+            // not touched: measured as the span of row ids inside sampled blocks of the sorted order
+            if (!worth && nnz >= (16 << 20) && nmed >= 16 * 64) {
+                int far = 0, cnt = 0;
+                const int nblk = nmed / kMedRows, bstep = std::max(1, nblk / 512);
+                for (int b = 0; b < nblk; b += bstep) {
+                    int lo = 2147483647, hi = -1;
+                    for (int i = b * kMedRows; i < (b + 1) * kMedRows; ++i) { lo = std::min(lo, ridM[i]); hi = std::max(hi, ridM[i]); }
+                    far += hi - lo > 16 * kMedRows; ++cnt;       // (not neighbours: more than 16 rows apart on average -- every row of the block then reads lines of its own)
+                }
+                worth = cnt > 0 && 2 * far >= cnt;
+            }
         }
         if (!(((force || worth) && fit > 0) || order_only)) p.win_hybrid = false;
         if (((force || worth) && fit > 0) || order_only) {

@@ -699,3 +699,25 @@ def test_f16_rows_without_a_regular_chunk_become_slabs_when_neighbours_are_close
     assert as16(local, slab_max_len=4)["n_med_blocks"] == (m + 15) // 16                    # (what they would have been)
     assert as16(far)["n_med_blocks"] == (m + 15) // 16                                      # scattered: blocks
     assert as64(local)["n_med_blocks"] == (m + 15) // 16                                    # f64: its tiles hold 4 columns, rows of 5..8 fill them
+
+
+def test_windows_when_the_length_sort_scatters_local_rows(dasp):
+    """late r5: rows of many different lengths with local columns -- the global length sort puts 16 rows from anywhere into a block.  From 16 M nonzeros on such a plan gets the
+    LDS windows (sorted inside 1024 rows) although every row's own columns form runs; rows of ONE length (which keep their row order in the sort) do not"""
+    rng = np.random.default_rng(4)
+    m = n = 300000
+
+    def local(lens):
+        rp = np.zeros(m + 1, np.int64); np.cumsum(lens, out=rp[1:])
+        rows = np.repeat(np.arange(m, dtype=np.int64), lens)
+        k = np.arange(int(rp[-1]), dtype=np.int64) - rp[rows]
+        start = np.clip(rows + rng.integers(-500, 501, m)[rows] - lens[rows] // 2, 0, n - lens[rows])
+        return rp.astype(np.int32), (start + k).astype(np.int32)
+    rp, ci = local(rng.integers(20, 120, m))                       # ~21 M nonzeros
+    st = dasp.Plan(rp, ci, np.ones(ci.size), n, precision=64).stats
+    assert ci.size >= (16 << 20) and st["x_window_on"] == 1 and st["n_windows_lds"] == st["n_windows"] > 0, st
+    rp1, ci1 = local(np.full(m, 70))                               # 21 M nonzeros, one length: the sorted order is the row order
+    assert dasp.Plan(rp1, ci1, np.ones(ci1.size), n, precision=64).stats["x_window_on"] == 0
+    small = rng.integers(20, 120, m) // 4 + 5                      # the same structure under 16 M nonzeros
+    rp2, ci2 = local(small)
+    assert ci2.size < (16 << 20) and dasp.Plan(rp2, ci2, np.ones(ci2.size), n, precision=64).stats["x_window_on"] == 0
