@@ -100,7 +100,8 @@ typedef struct dasp_options {
      * once into LDS (coalesced) and every gather of the window is served from LDS.  y still goes to the slots
      * of the reference permutation (order_rid is unchanged), through a per-row destination table.
      *   x_window: 0 = auto (on when the windows of >= half of the medium nonzeros fit AND the rows' gathers are scattered:
-     *             >= 60 % of a sampled row's nonzeros lie on another 128-byte line of x than their predecessor), -1 = off,
+     *             >= 60 % of a sampled row's nonzeros lie on another 128-byte line of x than their predecessor -- or, from 16 M nonzeros on,
+     *             when it is the global length sort that scatters: sampled blocks of the sorted order hold rows more than 16 apart), -1 = off,
      *             -2 = windowed order without LDS staging (measurement knob: slower than either alternative),
      *             > 0 = force on with this many bytes of LDS per workgroup as the cap (<= 163840; auto uses 81920,
      *                   i.e. two workgroups per CU, and falls back to 163840 when the spans do not fit that)
