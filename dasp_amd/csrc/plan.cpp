@@ -931,14 +931,21 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     // one-shot f64 blocks only when the plan is far beyond the 256 MiB Infinity Cache (nlpkkt160: 2.8 GB -7 % / -1.5 % by box; at 278 MB +4-8 %)
     p.pair_mode = p.windowed || p.opt.chunk_pairs < 0 ? 0 : p.opt.chunk_pairs > 0 ? std::min(2, p.opt.chunk_pairs)
                                                                      : ((long long)nnz * (geo.vbytes + 4) > 4 * kStreamBytes ? 2 : 1);
-    // narrow chunks per block: those of its pipelined paired region, in whole pipeline batches
+    // narrow chunks per block: those of its pipelined paired region, in whole pipeline batches.  Automatic (opt.cid8 = 0, late r5): not in ONE-SHOT blocks -- their one-byte ids are
+    // 16-bit loads per lane and pair, slower per byte than the 16-bit ids they replace (27-point stencil on 160^3: 0.719 -> 0.830 of the roofline without them; nlpkkt160 with 98 % of its
+    // chunks narrow 15-19 % slower, profiles/r05_id_encoding.md 4) -- and not at all when under a tenth of the chunks qualify: a plan with ANY narrow chunk runs the one-byte-id
+    // kernel instantiation (80 registers; rows of 40 with 240 narrow chunks of 1.3 M: 0.740 against 0.764).  opt.cid8 = 1 keeps both (the r4 behaviour)
     std::vector<int> n8of((size_t)nb + 1, 0);
-    if (try8 && p.cid16 && p.pair_mode > 0)
+    if (try8 && p.cid16 && p.pair_mode > 0) {
+        long long total8 = 0, total = 0;
         for (int b = 0; b < nb; ++b) {
             const int nt = (p.irr_ptr[(size_t)b * kMedRows] + K - 1) / K, npair = med_npair(nchunks[b], nt, geo.vbytes, p.pair_mode);
             const unsigned long long in = npair >= 64 ? ~0ull : ((1ull << npair) - 1);
-            n8of[b] = med_n8(__builtin_popcountll(narrow_mask[(size_t)b] & in), nchunks[b], nt);
+            n8of[b] = p.opt.cid8 == 0 && med_oneshot64(nchunks[b], nt) ? 0 : med_n8(__builtin_popcountll(narrow_mask[(size_t)b] & in), nchunks[b], nt);
+            total8 += n8of[b]; total += nchunks[b];
         }
+        if (p.opt.cid8 == 0 && total8 * 10 < total) std::fill(n8of.begin(), n8of.end(), 0);
+    }
     lap("chunk split (+cid16 spans)");
     p.med_ptr.assign((size_t)nb + 1, 0);
     {

@@ -158,7 +158,9 @@ typedef struct dasp_options {
     int chunk_pairs;
     /* one-byte column ids (f64, inside cid16 mode, pipelined paired chunks only): a chunk whose columns span <= 254 stores its offsets from
      * the chunk's base column in one byte; such chunks are moved to the front of their block's paired region in whole pipeline batches
-     * (the order of a block's MFMA steps is free), a batch's ids being one dword per lane.  0 = auto (on wherever it applies); -1 = off. */
+     * (the order of a block's MFMA steps is free), a batch's ids being one dword per lane.  0 = auto: in pipelined blocks only, and only when at least a tenth of the plan's
+     * chunks qualify (one-shot blocks are faster with 16-bit ids, and a plan with any one-byte id runs its own, 80-register kernel build); 1 = wherever it applies, one-shot blocks
+     * included (whole pairs); -1 = off. */
     int cid8;
     /* wave-segmented short rows (BASELINE north_star; reference branches dasp_f64.h:281-483): rows of 1..4 nonzeros stored back to back, ONE
      * nonzero per lane, every 16-lane DPP row holding 16 / L whole rows; a row is summed with two DPP row_shl steps and the lane holding its

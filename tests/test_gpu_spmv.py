@@ -1197,10 +1197,11 @@ def test_one_byte_ids_in_one_shot_blocks(oracle, dasp, torch_cuda):
     rp, ci = dasp.synth_csr("nlpkkt160", 0.01)
     m, n = rp.size - 1, dasp.synth_dims("nlpkkt160", 0.01)[1]
     v = np.random.default_rng(5).uniform(0.5, 1.5, ci.size)
-    kw = dict(cid16=1, chunk_pairs=2, x_window=-1, slab_max_len=4)
+    kw = dict(cid16=1, chunk_pairs=2, x_window=-1, slab_max_len=4, cid8=1)       # cid8 = 1: late r5 the automatic rule keeps one-byte ids out of one-shot blocks (they lose there)
     host = dasp.Plan(rp, ci, v, n, **kw)
     st = host.stats
     nchunks = int(host.host_array("med_ptr")[-1])
+    assert dasp.Plan(rp, ci, v, n, cid16=1, chunk_pairs=2, x_window=-1, slab_max_len=4).stats["cid8_chunks"] == 0
     assert st["cid16_on"] == 1 and st["chunk_pairs"] == 2 and 0.3 * nchunks < st["cid8_chunks"] < nchunks
     d = [torch.from_numpy(a).cuda() for a in (rp, ci, v)]
     dev = dasp.Plan.from_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), m, n, ci.size, **kw)

@@ -300,7 +300,8 @@ def test_cid8_narrow_chunks_layout(dasp, tmp_path):
     short = dasp.Plan(rp8, ci8, np.ones(32 * 16), 1300000, x_window=-1, cid16=1, slab_max_len=4, piece_min_len=-1)
     assert short.stats["cid8_chunks"] == 0 and short.stats["chunk_pairs"] == 1
     v8 = np.arange(1, ci8.size + 1, dtype=np.float64)
-    one = dasp.Plan(rp8, ci8, v8, 1300000, x_window=-1, cid16=1, slab_max_len=4, piece_min_len=-1, chunk_pairs=2)
+    assert dasp.Plan(rp8, ci8, v8, 1300000, x_window=-1, cid16=1, slab_max_len=4, piece_min_len=-1, chunk_pairs=2).stats["cid8_chunks"] == 0      # late r5: automatic keeps one-byte ids out of one-shot blocks
+    one = dasp.Plan(rp8, ci8, v8, 1300000, x_window=-1, cid16=1, slab_max_len=4, piece_min_len=-1, chunk_pairs=2, cid8=1)
     # 7 of its 8 chunks are narrow -> three whole PAIRS in front; ids [pair][lane][2 bytes]
     assert one.stats["chunk_pairs"] == 2 and one.stats["cid8_chunks"] == 6 and one.host_array("med_c8ptr").tolist() == [0, 6]
     assert one.host_array("med_korig").tolist() == [0, 1, 2, 3, 4, 5, 6, 7] and one.host_array("med_cid8").size == 6 * CH and one.host_array("med_cid16").size == 2 * CH
