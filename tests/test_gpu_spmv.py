@@ -1218,7 +1218,7 @@ def test_one_byte_ids_in_one_shot_blocks(oracle, dasp, torch_cuda):
     ref = oracle.csr_spmv(rp, ci, v, x)[dev.order_rid]
     mag = oracle.csr_absrow(rp, ci, v, x)[dev.order_rid]
     assert (np.abs(y - ref) <= 1e-12 * np.maximum(mag, 1e-300)).all()
-    wide = dasp.Plan(rp, ci, v, n, cid8=-1, **kw).upload()
+    wide = dasp.Plan(rp, ci, v, n, **dict(kw, cid8=-1)).upload()
     assert wide.stats["cid8_chunks"] == 0
     # (the narrow chunks move to the front of their block: another order of the block's MFMA steps, so the last bits may differ)
     assert (np.abs(y - run_spmv(torch, wide, x, m, 64)) <= 1e-12 * np.maximum(mag, 1e-300)).all()
