@@ -107,15 +107,21 @@ __global__ __launch_bounds__(256) void dasp_long_reduce_kernel(CallArgs c)
 {
     const DevArgs a = load_args(c);
     using part_t = typename Tr<T>::part_t;
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * kWavesPerWG + (threadIdx.x >> 6);
-    if (i >= a.n_multi) return;
+    // one WORKGROUP per row, four loads in flight per thread (late r5): one wave walking a row's partial sums 64 at a time took as long as the main kernel on a row of 50 M nonzeros
+    // (51 200 partial sums: 354 us for 1 GB, tools/scratch/shape_probe.py).  A fixed order of additions: thread t takes t, t + 256, ...; lanes, then the four waves, are combined in order
+    __shared__ part_t wsum[kWavesPerWG];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x;
     const int q0 = a.multi_ptr[i], q1 = a.multi_ptr[i + 1];
     const part_t *part = static_cast<const part_t *>(a.partial);
-    part_t s = 0;
-    for (int q = q0 + lane; q < q1; q += kWave) s += part[q];
-    s = wave_sum(s);
-    if (lane == 0) put_y<T>(a, a.multi_dst[i], s);
+    part_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int q = q0 + (int)threadIdx.x;
+    for (; q + 768 < q1; q += 1024) { s0 += part[q]; s1 += part[q + 256]; s2 += part[q + 512]; s3 += part[q + 768]; }
+    for (; q < q1; q += 256) s0 += part[q];
+    const part_t s = wave_sum((s0 + s1) + (s2 + s3));
+    if (lane == 0) wsum[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) put_y<T>(a, a.multi_dst[i], (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
 }
 template <class T>
 __global__ __launch_bounds__(256) void dasp_long_reduce_panels_kernel(PanelCall c)
@@ -462,7 +468,7 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
 #undef DASP_FOR_EACH
     }
     if (a.n_multi > 0)
-        hipLaunchKernelGGL((dasp_long_reduce_kernel<T>), dim3((a.n_multi + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, s, c);
+        hipLaunchKernelGGL((dasp_long_reduce_kernel<T>), dim3(a.n_multi), dim3(256), 0, s, c);
     HIP_TRY(hipGetLastError());
     return DASP_OK;
 }
