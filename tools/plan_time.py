@@ -18,7 +18,7 @@ tdt = torch.float64 if prec == 64 else torch.float16
 x = torch.ones(n, dtype=tdt, device="cuda"); y = torch.zeros(m, dtype=tdt, device="cuda")
 for rep in range(2):
     w, e = plan.time(x.data_ptr(), y.data_ptr(), 0, warmup=30, iters=int(os.environ.get("ITERS", "300")))
-want = torch.from_numpy(np.diff(rp)[plan.order_rid].astype(np.float64)).cuda()
+want = torch.from_numpy((np.diff(rp) if kw.get("y_order") == 1 else np.diff(rp)[plan.order_rid]).astype(np.float64)).cuda()      # DASP_Y_NATURAL: y in row order
 got = y.double()
 if prec == 64 or int(np.diff(rp).max()) <= 2048:
     ok = bool((got == want).all().item())
