@@ -74,14 +74,14 @@ def driver_line(out):
     rec = {k: out.get(k) for k in keep}
     c = out.get("config", {})
     rec["config"] = {k: c[k] for k in ("workload", "rows", "cols", "nnz", "scale", "partition", "generator_rev", "exchange", "step_form",
-                                       "rank0_nnz_own_columns", "rank0_nnz_other_columns") if k in c}
+                                       "rank0_nnz_own_columns", "rank0_nnz_other_columns", "y_candidates") if k in c}
     for k, n in (("workload", 120), ("partition", 100), ("exchange", 80), ("step_form", 240)):
         if k in rec["config"]:
             rec["config"][k] = _short(rec["config"][k], n)
     r = out.get("roofline", {})
     rec["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "kernel", "kernel_ms",
-                                         "algorithmic_bytes_per_launch", "frac_single_y", "frac_random_values", "launch_ms_median",
-                                         "f64_share_at_or_above_0.6", "suite_frac", "suite_frac_random_values") if k in r}
+                                         "algorithmic_bytes_per_launch", "frac_best_of_n_y", "frac_separate_launches", "frac_random_values", "launch_ms_median",
+                                         "f64_share_at_or_above_0.6", "suite_frac", "suite_frac_mfma_form", "suite_frac_random_values") if k in r}
     if "traffic_reason" in r:
         rec["roofline"]["traffic_reason"] = _short(r["traffic_reason"], 120)
     cb = out.get("cpu_baseline")
@@ -112,7 +112,7 @@ def driver_line(out):
     rec["full_record"] = "bench_suite.json"
     line = json.dumps(rec, separators=(",", ":"))
     # the limit holds by construction for every run of this file; should a future key break it, shed the optional ones rather than the line
-    for k in ("suite_frac_random_values", "suite_frac"):
+    for k in ("suite_frac_mfma_form", "suite_frac_random_values", "suite_frac"):
         if len(line) <= LINE_LIMIT:
             break
         rec["roofline"].pop(k, None)
@@ -316,26 +316,24 @@ def kernel_revision():
     return h.hexdigest()[:12]
 
 
-_FIRST_Y = {}
-
-
 def choose_y(torch, plan, x, rows, tdt, stats):
-    """The written vector's placement decides between the two speeds of the HBM-bound kernels (profiles/r04_placement.md): instead of copying the
-    2.9-GB plan into fresh allocations until one is fast (r3's trials inside dasp_plan_upload), time the plan against a few y vectors of
-    the run's own and keep the fastest -- rowA values each, 2 + 6 launches per candidate, no sleeps, nothing hidden in the library.
-    DASP_BENCH_Y_CANDIDATES (default 6; 1: off).  Returns (y, record)."""
+    """The written vector's placement decides between the two speeds of the HBM-bound kernels (profiles/r04_placement.md).  The run's numbers are taken
+    against the FIRST y it allocates -- what a solver calling dasp_plan_spmv with its one y vector gets.  Beside it, for the record
+    only: the plan timed against n y vectors of the run's own (2 + 6 launches each) and the fastest of them (`frac_best_of_n_y`).
+    DASP_BENCH_Y_CANDIDATES (default 6; 1: off).  Returns (y, y_best, record): y is the first allocation, y_best the fastest (y itself when off)."""
     n = max(1, int(os.environ.get("DASP_BENCH_Y_CANDIDATES", "6")))
     if n == 1 or stats["data_X"] < (256 << 20) or stats["n_col_panels"] or stats["x_window_on"] or stats.get("two_phase"):
-        return torch.zeros(rows, dtype=tdt, device="cuda"), {"y_candidates": 1}
+        y = torch.zeros(rows, dtype=tdt, device="cuda")
+        return y, y, {"y_candidates": 1}
     ys = [torch.zeros(rows, dtype=tdt, device="cuda") for _ in range(n)]
     torch.cuda.synchronize()
     ms = [plan.time(x.data_ptr(), yk.data_ptr(), 0, 2, 6)[1] for yk in ys]
     k = int(np.argmin(ms))
-    y = ys[k]
-    _FIRST_Y["y"] = ys[0]          # what a caller with ONE y gets: timed beside the kept one (roofline.frac_single_y; ADVICE r4)
+    y, y_best = ys[0], ys[k]
     del ys
-    return y, {"y_candidates": n, "ms_each": [round(float(v), 4) for v in ms], "kept": k,
-               "note": "the plan timed against n y vectors of the run's own (2 + 6 launches each), the fastest kept; no copy of the plan, no trial inside the library"}
+    return y, y_best, {"y_candidates": n, "ms_each": [round(float(v), 4) for v in ms], "fastest": k,
+                       "note": "every number of this record is the plan against the FIRST y allocated (candidate 0); frac_best_of_n_y alone is the fastest of n "
+                               "y vectors of the run's own (2 + 6 launches each): no copy of the plan, no trial inside the library"}
 
 
 def suite_entry(torch, D, O, name, precision, scale, budget_s=2.0):
@@ -349,14 +347,13 @@ def suite_entry(torch, D, O, name, precision, scale, budget_s=2.0):
     plan.drop_host()
     tdt = torch.float64 if precision == 64 else torch.float16
     x = torch.ones(cols, dtype=tdt, device="cuda")
-    y, placement = choose_y(torch, plan, x, rows, tdt, plan.stats)      # as the headline
-    y_first = _FIRST_Y.pop("y", None)
+    y, y_best, placement = choose_y(torch, plan, x, rows, tdt, plan.stats)      # as the headline: y = the first allocation
     w, e = time_plan(torch, plan, x, y, 20, 10)
     iters = int(max(20, min(1000, budget_s * 1e3 / max(e, 1e-4))))
     w, e = time_plan(torch, plan, x, y, iters, min(100, iters))
     gw, ge = plan.time_graph(x.data_ptr(), y.data_ptr(), 0, warmup=min(100, iters), iters=iters, batch=min(50, iters))
-    e1 = e if y_first is None or y_first is y else time_plan(torch, plan, x, y_first, min(iters, 200), 10)[1]
-    del y_first
+    eb = e if y_best is y else time_plan(torch, plan, x, y_best, min(iters, 200), 10)[1]
+    del y_best
     order = torch.from_numpy(plan.order_rid.astype(np.int64)).cuda()
     want = torch.from_numpy(np.diff(rp).astype(np.float64)).cuda()[order]
     ok = bool((y.double() == want).all().item()) if precision == 64 or int(np.diff(rp).max()) <= 2048 else \
@@ -367,7 +364,7 @@ def suite_entry(torch, D, O, name, precision, scale, budget_s=2.0):
            "ms": round(w, 6), "event_ms": round(e, 6), "graph_event_ms": round(ge, 6), "iters": iters, "gflops": round(2.0 * nnz / (w * 1e6), 2),
            "achieved_GBps": round(b_alg / (e * 1e6), 1), "frac_hbm_roofline": round(b_alg / (e * 1e6) / HBM_PEAK_GBPS, 4),
            "frac_hbm_roofline_graph": round(b_alg / (ge * 1e6) / HBM_PEAK_GBPS, 4),
-           "frac_single_y": round(b_alg / (e1 * 1e6) / HBM_PEAK_GBPS, 4),
+           "frac_best_of_n_y": round(b_alg / (eb * 1e6) / HBM_PEAK_GBPS, 4),
            "rate_fill0": round(st["rate_fill0"], 4), "pre_ms": round(st["pre_ms"], 1), "verified": ok,
            "col_panels": st["n_col_panels"], "two_phase": st.get("two_phase", 0), "row_long": st["row_long"], "row_block": st["row_block"],
            "row_short": rows - st["row_long"] - st["row_block"] - st["row_zero"], "generator": generator_of(D, name),
@@ -375,6 +372,21 @@ def suite_entry(torch, D, O, name, precision, scale, budget_s=2.0):
            "gather_roofline": gather_roofline(nnz, e), "placement": placement}
     out.update(traffic_for(name, precision, scale, b_alg, kernel_revision()))
     plan.close()
+    if st.get("two_phase"):
+        # BASELINE config 4 names the f16 MFMA path: the same matrix as the plan the two-phase form replaced (two_phase = -1: DASP blocks on
+        # v_mfma_f32_16x16x16_f16, column panels where the rule asks for them), timed beside it so that the driver's record carries both
+        try:
+            mp = D.Plan(rp, ci, np.ones(nnz, np.float16), cols, precision=precision, y_order=D.Y_PERMUTED, two_phase=-1)
+            mp.upload()
+            mp.drop_host()
+            em = time_plan(torch, mp, x, y, min(iters, 200), 10)[1]
+            mst = mp.stats
+            out["mfma_form"] = {"event_ms": round(em, 6), "frac_hbm_roofline": round(b_alg / (em * 1e6) / HBM_PEAK_GBPS, 4), "col_panels": mst["n_col_panels"],
+                                "note": "two_phase = -1: the DASP / MFMA_F32_16x16x16_F16 plan of the same matrix"}
+            out["frac_mfma_form"] = out["mfma_form"]["frac_hbm_roofline"]
+            mp.close()
+        except Exception as exc:
+            out["mfma_form"] = {"error": repr(exc)}
     del x, y
     torch.cuda.empty_cache()
     out.update(device_pre_ms(torch, D, rp, ci, rows, cols, precision))
@@ -504,8 +516,7 @@ def setup_rank(torch, D, name, scale, prec, rank, world, multi=None, chain=None)
     plan.drop_host()
     tdt = torch.float64 if prec == 64 else torch.float16
     x = torch.ones(plan.x_len, dtype=tdt, device="cuda")
-    y, placement = choose_y(torch, plan, x, r1 - r0, tdt, plan.stats)
-    y_first = _FIRST_Y.pop("y", None)
+    y, y_best, placement = choose_y(torch, plan, x, r1 - r0, tdt, plan.stats)
     arena_trials = int(os.environ.get("DASP_BENCH_ARENA_TRIALS", "0"))          # r3's trials (copies of the whole plan): off unless asked for
     if arena_trials > 1:
         first, kept = plan.tune_placement(arena_trials, x.data_ptr(), y.data_ptr())
@@ -516,7 +527,7 @@ def setup_rank(torch, D, name, scale, prec, rank, world, multi=None, chain=None)
     placement["upload_ms"] = round(upload_ms, 1)
     placement["device_bytes_plan_and_vectors"] = int(free0 - torch.cuda.mem_get_info()[0])
     return dict(chain=None, mg=None, placement=placement, plan=plan, rp=rp, ci=ci, val=None, stats=plan.stats, pre_s=pre_s, rows=rows, cols=cols, nnz_total=nnz_total,
-                lengths=lengths, bounds=bounds, stride=0, r0=r0, r1=r1, x=x, y=y, y_first=y_first)
+                lengths=lengths, bounds=bounds, stride=0, r0=r0, r1=r1, x=x, y=y, y_best=y_best)
 
 
 def cpu_baseline(O, rp, ci, n_cols, budget_s=20.0):
@@ -889,14 +900,18 @@ def main():
         tdt = torch.float64 if prec == 64 else torch.float16
         kx = torch.ones(plan.x_len, dtype=tdt, device="cuda")
         ky = torch.zeros(stride, dtype=tdt, device="cuda")
-    kw, ke = plan.time(kx.data_ptr(), ky.data_ptr(), stream, warmup=5, iters=k_iters)      # one event pair around >= 200 back-to-back launches
+    kw, ke_sep = plan.time(kx.data_ptr(), ky.data_ptr(), stream, warmup=5, iters=k_iters)      # one event pair around >= 200 back-to-back launches
+    # N = 1: a step IS one launch of the plan (+ stage 2 where long rows were cut), so the kernel's average duration is taken from the driver's own timed region
+    # (HIP events on the launch stream around exactly --steps steps) -- the separate >= 200-launch figure stays beside it.
+    # N > 1: the region also holds the exchange, so the dominant kernel (the rank's own-column plan) keeps its separate timing.
+    ke = region_event_ms if mg is None else ke_sep
     # the spread inside this process: every one of >= 200 launches between its own pair of events (VERDICT r2 weak #8a); each interval
     # carries the few microseconds an event between two kernels costs, so the headline kernel_ms stays the back-to-back mean above
     each = np.sort(plan.time_each(kx.data_ptr(), ky.data_ptr(), stream, warmup=5, iters=max(200, k_iters)).astype(np.float64))
-    # the same plan against the FIRST y this run allocated (no choice among candidates): what a solver with one y vector gets
-    y1 = R.get("y_first")
-    ke1 = ke if (mg is not None or y1 is None or y1 is y) else plan.time(x.data_ptr(), y1.data_ptr(), stream, warmup=5, iters=k_iters)[1]
-    R["y_first"] = y1 = None
+    # the same plan against the FASTEST of the n y vectors this run allocated: for the record only (a solver with one y vector gets `frac`)
+    yb = R.get("y_best")
+    keb = ke_sep if (mg is not None or yb is None or yb is y) else plan.time(x.data_ptr(), yb.data_ptr(), stream, warmup=5, iters=k_iters)[1]
+    R["y_best"] = yb = None
     # partitioned: the dominant kernel is the rank's own-column plan (its x is the rank's own slice)
     nnz_local = int(rp[-1]) if mg is None else mg.nnz_local
     b_alg_local = algorithmic_bytes(r1 - r0, cols if mg is None else (stride if mg.overlap else cols), nnz_local, vb)
@@ -926,19 +941,23 @@ def main():
                                              "stream_handoff": "in-kernel flags + one-lane kernels on the communication stream" if mg.info["fused_step"] else
                                              ("hipStreamWriteValue64 / hipStreamWaitValue64" if mg.info["stream_memops"] else "events")}),
                    "row_long": st["row_long"], "row_block": st["row_block"], "rate_fill0": round(st["rate_fill0"], 4),
+                   "y_candidates": R.get("placement", {}).get("y_candidates", 0),      # N of roofline.frac_best_of_n_y; `frac` itself is against the first y
                    "placement": R.get("placement", {"y_candidates": 0})},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "kernel": "dasp_spmv_kernel<%s>" % ("double" if prec == 64 else "_Float16"),
                      "algorithmic_bytes_per_launch": b_alg_local, "kernel_ms": round(ke, 6),
-                     "frac_single_y": round(b_alg_local / (ke1 * 1e6) / HBM_PEAK_GBPS, 4), "kernel_ms_single_y": round(ke1, 6),
+                     "kernel_ms_separate_launches": round(ke_sep, 6), "frac_separate_launches": round(b_alg_local / (ke_sep * 1e6) / HBM_PEAK_GBPS, 4),
+                     "frac_best_of_n_y": round(b_alg_local / (keb * 1e6) / HBM_PEAK_GBPS, 4), "kernel_ms_best_of_n_y": round(keb, 6),
                      "launch_ms_min": round(float(each[0]), 6), "launch_ms_p10": round(float(each[len(each) // 10]), 6),
                      "launch_ms_median": round(float(np.median(each)), 6), "launch_ms_p90": round(float(each[(len(each) * 9) // 10]), 6),
                      "launch_ms_max": round(float(each[-1]), 6),
                      "frac_at_fastest_launch": round(b_alg_local / (float(each[0]) * 1e6) / HBM_PEAK_GBPS, 4),
                      "frac_at_slowest_launch": round(b_alg_local / (float(each[-1]) * 1e6) / HBM_PEAK_GBPS, 4),
-                     "method": "kernel_ms: hipEvent pair on the launch stream around %d back-to-back launches (rank 0 slice); launch_ms_*: the same "
-                               "%d launches with a hipEvent between every two (each interval includes the few us an event between two kernels costs)" % (k_iters, len(each))},
+                     "method": ("kernel_ms: hipEvent pair on the launch stream around the driver's %d timed steps (one launch each), against the run's first y; " % args.steps if mg is None else
+                                "kernel_ms: hipEvent pair on the launch stream around %d back-to-back launches of the rank's own-column plan (rank 0 slice); " % k_iters) +
+                               "kernel_ms_separate_launches: a second pair around %d back-to-back launches; launch_ms_*: %d launches with a hipEvent between every two "
+                               "(each interval includes the few us an event between two kernels costs)" % (k_iters, len(each))},
         "achieved_GBps_whole_job": round(b_alg_total / (ms_per_step * 1e6), 1),
         "frac_hbm_roofline_whole_job": round(b_alg_total / (ms_per_step * 1e6) / (HBM_PEAK_GBPS * world), 4),
         "region_event_ms_per_step": round(region_event_ms, 6), "verified": ok, "preprocess_s": round(pre_s, 3),
@@ -1088,14 +1107,18 @@ def main():
         out["gather_roofline_note"] = GATHER_NOTE
         # where the driver's record keeps it: every BASELINE configuration's fraction of the HBM roofline inside the roofline object
         sf = {"%s %s" % (name, "f64" if prec == 64 else "f16"): out["roofline"]["frac"]}
-        sfr = {}
+        sfr, sfm = {}, {}
         for e in suite:
             if "frac_hbm_roofline" in e:
                 sf["%s %s" % (e["workload"], e["dtype"])] = e["frac_hbm_roofline"]
+                if "frac_mfma_form" in e:
+                    sfm["%s %s" % (e["workload"], e["dtype"])] = e["frac_mfma_form"]
                 if "frac_hbm_roofline_random_values" in e:
                     sfr["%s %s" % (e["workload"], e["dtype"])] = e["frac_hbm_roofline_random_values"]
         out["roofline"]["suite_frac"] = sf
         out["roofline"]["suite_frac_random_values"] = sfr
+        if sfm:
+            out["roofline"]["suite_frac_mfma_form"] = sfm      # the two-phase rows of suite_frac as their DASP / MFMA plans (two_phase = -1)
         f64 = [v for k, v in sf.items() if k.endswith("f64")]
         out["roofline"]["f64_share_at_or_above_0.6"] = round(sum(v >= 0.6 for v in f64) / max(len(f64), 1), 3)
 

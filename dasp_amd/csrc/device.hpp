@@ -59,6 +59,8 @@ struct DevArgs {
     // row tiles of a column panel (Plan::rt_*): workgroups [wg_long + wg_med + wg_short, + wg_rt), one tile per wave
     const void *rt_val; const int *rt_cid; const int *rt_ptr; const unsigned short *rt_start; const unsigned long long *rt_mask;
     int n_rt_tiles, wg_rt, rt_max;
+    // (r6; last, so that every older field keeps its offset: the multi-GPU step kernels take this block by value and their code depends on its layout)
+    int win_tiles;    // short tiles folded into every window workgroup (upload_plan): workgroup w also serves tiles w, w + n_windows, ... ; 0: the short tiles keep workgroups of their own
 };
 
 // two-phase form (plan.hpp struct TwoPhase): what its two kernels read.  All device pointers into the plan's arena; xs is the stream phase 1
@@ -104,6 +106,9 @@ struct DevicePlan {
     int device = -1;
     // column-panel parent: arena = the panels' partial results, panel k at ypart + k * ypart_stride elements
     size_t ypart_stride = 0;
+    // column-panel parent with column-blocked long rows (r6): the hub rows' two kernels run on a stream of the plan's own BESIDE the panels' launch (fork / join by events on
+    // the caller's stream: capturable) -- the panels are bound by L2 gathers, the hub rows by the HBM stream.  Null: one stream, as before.
+    void *side_stream = nullptr, *ev_fork = nullptr, *ev_join = nullptr;
 };
 
 

@@ -36,14 +36,25 @@
 #include "spmv_device.hpp"
 
 namespace dasp {
+#ifdef DASP_STAMPS
+extern int g_stamp_launch;
+#endif
 
 // MW (f64, no windows): 7 = the build held to 72 registers = 7 waves per SIMD, for plans of one-shot blocks (DevicePlan::seven_waves)
 template <class T, bool NT, bool C16, bool WIN, bool C8 = false, int MW = 0>
 __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : MW ? MW : kMinWavesPlain) void dasp_spmv_kernel(CallArgs c)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+#ifdef DASP_STAMPS
+    Stamps st; st.begin(c.stamp_launch);
+#else
+    Stamps st; st.begin(0);
+#endif
     const DevArgs a = load_args(c);
-    spmv_body<T, NT, C16, WIN, C8>(a, lds_raw, blockIdx.x);
+    spmv_body<T, NT, C16, WIN, C8, false, WIN>(a, lds_raw, blockIdx.x, st);
+#ifdef DASP_STAMPS
+    st.finish(a.wpw);
+#endif
 }
 
 // a column panel with row tiles (Plan::rt_*): the non-windowed kernel + the tiles' workgroup range, dynamic LDS = 4 waves x 64 x rt_max products
@@ -52,8 +63,13 @@ template <class T, bool NT, bool C16>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 7 : kMinWavesPlain) void dasp_spmv_rt_kernel(CallArgs c)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+#ifdef DASP_STAMPS
+    Stamps st; st.begin(c.stamp_launch);
+#else
+    Stamps st; st.begin(0);
+#endif
     const DevArgs a = load_args(c);
-    spmv_body<T, NT, C16, false, false, true>(a, lds_raw, blockIdx.x);
+    spmv_body<T, NT, C16, false, false, true>(a, lds_raw, blockIdx.x, st);
 }
 
 // the windowed kernel for plans with at most one window workgroup per CU (n_windows <= CUs: cop20k_A's 212): nothing is gained by
@@ -65,8 +81,18 @@ template <class T, bool C16>
 __global__ __launch_bounds__(1024, 4) void dasp_spmv_win1_kernel(CallArgs c)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+#ifdef DASP_STAMPS
+    Stamps st; st.begin(c.stamp_launch);
+#else
+    Stamps st; st.begin(0);
+#endif
     const DevArgs a = load_args(c);
-    spmv_body<T, false, C16, true, false>(a, lds_raw, blockIdx.x);
+    // tiles, tails and ids stream with non-temporal loads although the matrix is cache-sized (r6, same box: cop20k_A 9.24 -> 8.91 us, x2 16.0 -> 15.4; every 4th window
+    // only: 9.53): what the XCD's L2 then holds is the x spans neighbouring windows share and the row tables, and nothing of the once-per-launch stream pushes them out
+    spmv_body<T, true, C16, true, false>(a, lds_raw, blockIdx.x, st);
+#ifdef DASP_STAMPS
+    st.finish(a.wpw);
+#endif
 }
 
 // ---- all column panels of a plan in ONE launch (r5): the panels' grids back to back in one grid -- panel = a range of blockIdx.x, as the
@@ -89,7 +115,11 @@ __device__ __forceinline__ CallArgs panel_of(const PanelCall &c, int &wg)
         k = in ? i : k; first = in ? c.wg_end[i - 1] : first; p = in ? c.plan[i] : p;
     }
     wg = (int)blockIdx.x - first;
+#ifdef DASP_STAMPS
+    return CallArgs{p, c.x, c.part + (size_t)k * c.stride_bytes, 0, 0, -1};
+#else
     return CallArgs{p, c.x, c.part + (size_t)k * c.stride_bytes, 0, 0};
+#endif
 }
 template <class T, bool NT, bool C16>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 7 : kMinWavesPlain) void dasp_spmv_panels_kernel(PanelCall c)
@@ -97,8 +127,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 7 : kMinWavesPlain) void dasp
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     int wg;
     const CallArgs ca = panel_of(c, wg);
+    Stamps st; st.begin(0);
     const DevArgs a = load_args(ca);
-    spmv_body<T, NT, C16, false, false, true>(a, lds_raw, wg);
+    spmv_body<T, NT, C16, false, false, true>(a, lds_raw, wg, st);
 }
 
 // stage 2 for long rows cut into several pieces (reference: longPart_sum, dasp_f64.h:53-75)
@@ -357,6 +388,19 @@ __global__ __launch_bounds__(256) void dasp_lcb_reduce_kernel(LcbDev a, T *__res
     if (lane == 0) part0[a.row_dst[i]] = (T)s;
 }
 
+#ifdef DASP_STAMPS
+int g_stamp_launch = -1;          // host: the number the next stamped launch carries (-1: stamps off)
+}  // namespace dasp
+// tools/stamp_probe.py: where the stamped kernels write (device pointer; rec = cap records of 12 words) and the first launch number
+extern "C" int dasp_debug_set_stamps(void *rec, unsigned cap)
+{
+    dasp::StampBuf b{static_cast<unsigned long long *>(rec), cap};
+    dasp::g_stamp_launch = rec ? 0 : -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(dasp::g_stamps), &b, sizeof b) == hipSuccess ? 0 : -1;
+}
+namespace dasp {
+#endif
+
 // ------------------------------------------------------------------ MFMA lane-map self test
 __global__ void selftest_f64_kernel(double *D)
 {
@@ -400,7 +444,7 @@ __global__ void selftest_f16_kernel(float *D)
 // the limit under an earlier one with wider windows
 int spmv_kernel_allow_full_lds(int precision, bool c16)
 {
-    const int bytes = 160 * 1024;
+    const int bytes = kWinLdsMax;          // + the window kernels' static LDS (the unit counter) = under the 160 KiB of a CU
     hipError_t e1, e2;
 #define DASP_ATTR(TT, NTV, CV) hipFuncSetAttribute(reinterpret_cast<const void *>(&dasp_spmv_kernel<TT, NTV, CV, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes)
     if (precision == 64) { e1 = c16 ? DASP_ATTR(double, true, true) : DASP_ATTR(double, true, false); e2 = c16 ? DASP_ATTR(double, false, true) : DASP_ATTR(double, false, false); }
@@ -431,7 +475,11 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
     const int grid = a.wg_long + a.wg_med + a.wg_short + a.wg_rt;
     const bool nt = p.dev->nt;
     if (int rc = sync_dev_args(p)) return rc;          // (a memcmp: the device copy follows DevicePlan::args)
+#ifdef DASP_STAMPS
+    const CallArgs c{static_cast<const DevArgs *>(p.dev->dargs), a.x, a.y, a.acc, a.ywt, g_stamp_launch >= 0 ? g_stamp_launch++ : -1};
+#else
     const CallArgs c{static_cast<const DevArgs *>(p.dev->dargs), a.x, a.y, a.acc, a.ywt};
+#endif
     if (a.wg_rt > 0) {      // a column panel with row tiles (never windowed, never with one-byte ids: plan.cpp build_panels)
         const size_t lds = (size_t)kWavesPerWG * kRowTile * (size_t)a.rt_max * sizeof(typename Tr<T>::part_t);
         if (nt && p.cid16) hipLaunchKernelGGL((dasp_spmv_rt_kernel<T, true, true>), dim3(grid), dim3(256), lds, s, c);
@@ -552,21 +600,33 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate
         const size_t vb = (size_t)p.geo.vbytes, stride = p.dev->ypart_stride;
         char *part = static_cast<char *>(p.dev->arena);
         hipStream_t s = static_cast<hipStream_t>(stream);
+        // hub rows on the plan's side stream, forked off the caller's stream BEFORE the panels' launch and joined before the sum (r6): x is complete where the fork event
+        // sits, the two kernels write only their own partial sums and the hub rows' slots of panel 0's buffer, which no panel writes
+        const bool side = p.lcb.n_rows() > 0 && p.dev->side_stream != nullptr;
+        hipStream_t hs = side ? static_cast<hipStream_t>(p.dev->side_stream) : s;
+        auto launch_hub = [&]() {
+            const LcbDev &q = p.dev->lcb;
+            if (p.precision == 64) {
+                hipLaunchKernelGGL((dasp_lcb_kernel<double>), dim3(q.n_units), dim3(1024), (size_t)q.cb * 8 + 16 + (size_t)(kLcbUnitElems / kLcbStep + kLcbUnitPieces) * 8, hs, q, static_cast<const double *>(dX));
+                hipLaunchKernelGGL((dasp_lcb_reduce_kernel<double>), dim3((q.n_rows + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, hs, q, reinterpret_cast<double *>(part));
+            } else {
+                hipLaunchKernelGGL((dasp_lcb_kernel<_Float16>), dim3(q.n_units), dim3(1024), (size_t)q.cb * 2 + 16 + (size_t)(kLcbUnitElems / kLcbStep + kLcbUnitPieces) * 8, hs, q, static_cast<const _Float16 *>(dX));
+                hipLaunchKernelGGL((dasp_lcb_reduce_kernel<_Float16>), dim3((q.n_rows + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, hs, q, reinterpret_cast<_Float16 *>(part));
+            }
+        };
+        if (side) {
+            HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(p.dev->ev_fork), s));
+            HIP_TRY(hipStreamWaitEvent(hs, static_cast<hipEvent_t>(p.dev->ev_fork), 0));
+            launch_hub();
+            HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(p.dev->ev_join), hs));
+        }
         if (int rc = launch_panels_merged(p, dX, part, stride * vb, s)) {
             if (rc != 1) return rc;          // 1: the panels do not share one kernel instantiation -- one launch (+ stage 2) per panel, as before r5
             for (size_t k = 0; k < p.panels.size(); ++k)
                 if (int rc2 = launch_spmv(p.panels[k]->impl, dX, part + k * stride * vb, stream, false)) return rc2;
         }
-        if (p.lcb.n_rows() > 0) {      // the hub rows: column blocks of x staged in LDS, their result into panel 0's (otherwise unwritten) slots of the partial buffer
-            const LcbDev &q = p.dev->lcb;
-            if (p.precision == 64) {
-                hipLaunchKernelGGL((dasp_lcb_kernel<double>), dim3(q.n_units), dim3(1024), (size_t)q.cb * 8 + 16 + (size_t)(kLcbUnitElems / kLcbStep + kLcbUnitPieces) * 8, s, q, static_cast<const double *>(dX));
-                hipLaunchKernelGGL((dasp_lcb_reduce_kernel<double>), dim3((q.n_rows + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, s, q, reinterpret_cast<double *>(part));
-            } else {
-                hipLaunchKernelGGL((dasp_lcb_kernel<_Float16>), dim3(q.n_units), dim3(1024), (size_t)q.cb * 2 + 16 + (size_t)(kLcbUnitElems / kLcbStep + kLcbUnitPieces) * 8, s, q, static_cast<const _Float16 *>(dX));
-                hipLaunchKernelGGL((dasp_lcb_reduce_kernel<_Float16>), dim3((q.n_rows + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, s, q, reinterpret_cast<_Float16 *>(part));
-            }
-        }
+        if (side) HIP_TRY(hipStreamWaitEvent(s, static_cast<hipEvent_t>(p.dev->ev_join), 0));
+        else if (p.lcb.n_rows() > 0) launch_hub();      // one stream: the hub rows behind the panels (column blocks of x staged in LDS, their result into panel 0's otherwise unwritten slots)
         const int np = (int)p.panels.size(), m = p.m;
         const bool wide = (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
         if (m > 0) {

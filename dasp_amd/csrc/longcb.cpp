@@ -103,7 +103,8 @@ bool validate_long_cb(const Plan &p, int n_panels, std::string &why)
     if (n_panels < 1 || p.opt.n_parts > 0) return fail("long_cb outside a column-panel plan");
     const int vb = p.geo.vbytes, A = kLcbStep;
     if (L.cb < 8 || L.cb % 8 || L.cb > 65528 || L.n_cb != std::max(1, (p.n + L.cb - 1) / L.cb)) return fail("long_cb column blocks");
-    if ((size_t)L.cb * (size_t)vb > 160 * 1024) return fail("long_cb column block beyond the LDS");
+    // the kernel's dynamic LDS: the block's slice of x + 16 + one sum per step and piece of a unit (kernels.hip launch_spmv) -- all of it inside the 160 KiB the attribute allows
+    if ((size_t)L.cb * (size_t)vb + 16 + (size_t)(kLcbUnitElems / kLcbStep + kLcbUnitPieces) * 8 > 160 * 1024) return fail("long_cb column block beyond the LDS");
     if (L.row_id.size() != (size_t)nL || L.ptr.size() != (size_t)L.n_cb * (size_t)nL + 1 || L.ptr[0] != 0) return fail("long_cb tables");
     if ((size_t)L.ptr.back() != L.elems || L.lcol.size() != L.elems || L.val.size() != L.elems * (size_t)vb) return fail("long_cb streams");
     std::vector<bool> seen((size_t)p.m, false);

@@ -311,13 +311,18 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             // the two-phase (gather-free) form: order_rid and the classifier counters of the whole matrix (row lengths only), then the tile streams
             if (int rc = build_impl<T>(p, rp, ci, val, nullptr, kMetaOnly)) return rc;
             lap("whole-matrix meta");
-            if (!dev) { const int rc = build_two_phase(p, rp, ci, val); lap("two-phase streams"); return rc; }
-            raw_vector<int> hci((size_t)nnz);
-            raw_vector<T> hval((size_t)nnz);
-            if (int rc = devpack_fetch_csr(p, *dev, hci.data(), hval.data())) return rc;
-            if (int rc = build_two_phase(p, rp, hci.data(), hval.data())) return rc;
-            lap("two-phase streams (device CSR fetched)");
-            return devpack_finish_panels(p);       // a device-built plan comes back uploaded
+            int rc2;
+            if (!dev) { rc2 = build_two_phase(p, rp, ci, val); lap("two-phase streams"); if (rc2 != kTpDeclined) return rc2; }
+            else {
+                raw_vector<int> hci((size_t)nnz);
+                raw_vector<T> hval((size_t)nnz);
+                if (int rc = devpack_fetch_csr(p, *dev, hci.data(), hval.data())) return rc;
+                rc2 = build_two_phase(p, rp, hci.data(), hval.data());
+                lap("two-phase streams (device CSR fetched)");
+                if (rc2 == DASP_OK) return devpack_finish_panels(p);       // a device-built plan comes back uploaded
+                if (rc2 != kTpDeclined) return rc2;
+            }
+            // declined by the padding guard (automatic rule only): the matrix keeps its DASP form -- column panels where the rule asked for them, else the plain plan below
         }
         if (P >= 2) return build_panels<T>(p, rp, ci, val, P, dev);
     }
@@ -515,16 +520,29 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         // CU count, not at it: sweeps on the cop20k_A stand-in put the optimum at 200-230 windows (162 k medium rows: 318 / 255 /
         // 231 / 212 / 159 windows = 17.7 / 18.6 / 14.6 / 14.6 / 16.0 us; 130 k: 255 / 226 / 170 = 15.4 / 13.2 / 13.4; 65 k:
         // 507 / 254 / 127 / 64 = 8.4 / 7.4 / 9.1 / 13.4) and at ~424 for 325 k rows (424 / 318 = 24.6 / 27.3 us).
+        // r6 (profiles/r06_small_matrix.md): with the 128-register build exactly one window workgroup resides per CU, so the fastest grid is the one that puts a
+        // workgroup on EVERY CU and none behind another: windows (rounded up to a whole number per XCD, as the kernel deals them) + long-piece workgroups + short-tile
+        // workgroups (none where the tiles fold into the windows) <= 256.  cop20k_A: 212 windows of 512 rows 10.56 us, 242 of 448 10.08, 251 of 432 WITH seven short-tile
+        // workgroups behind them 17.6 (263 workgroups: seven CUs take a second one) -- hence the count of ALL workgroups, and window heights in whole blocks (16 rows).
         int R = p.opt.row_window;
         if (R <= 0) {
-            R = ceil_div(ceil_div(nmed, 224), 64) * 64;
-            if (R > 1024) R = ceil_div(ceil_div(nmed, 448), 64) * 64;
-            R = std::max(128, R);
+            const int cus = 256, SR = geo.short_rows;
+            int est_tiles = 0;
+            for (int g = 0; g < kNumShortGroups; ++g) est_tiles += ceil_div(p.grp[g].count, SR);
+            long long est_pieces = nlong;
+            for (int i = 0; i < nlong; ++i) est_pieces += (rp[ridL[(size_t)i] + 1] - rp[ridL[(size_t)i]]) / 1024;
+            for (int r = 128; r <= 1024 && R <= 0; r += kMedRows) {
+                const int nWr = ceil_div(nmed, r), wpw_r = std::min(16, r / kMedRows);
+                const int wgs = ceil_div(nWr, 8) * 8 + (int)ceil_div(est_pieces, (long long)wpw_r) + (win_fold_tiles(nWr, est_tiles) ? 0 : ceil_div(est_tiles, wpw_r));
+                if (wgs <= cus) R = r;
+            }
+            // more rows than 256 windows of 1024 hold: two workgroups per CU (the 64-register build, 2 x 80 KiB of LDS), ~448 windows as before
+            if (R <= 0) R = std::max(128, ceil_div(ceil_div(nmed, 448), 64) * 64);
         }
-        R = std::min(1024, std::max(64, (R / 64) * 64));         // <= 16 waves per workgroup, 1-4 blocks per wave
+        R = std::min(1024, std::max(64, (R / kMedRows) * kMedRows));         // whole blocks; <= 16 waves per workgroup, 1-4 blocks per wave
         // default cap: 80 KiB = two workgroups per CU out of gfx950's 160 KiB of LDS
         const bool order_only = p.opt.x_window == -2;          // windowed order, no LDS staging (every window gathers from global memory)
-        int cap_bytes = order_only ? 0 : (p.opt.x_window > 0 ? std::min(p.opt.x_window, 160 * 1024) : 80 * 1024);
+        int cap_bytes = order_only ? 0 : (p.opt.x_window > 0 ? std::min(p.opt.x_window, kWinLdsMax) : 80 * 1024);
         const int A = 16 / geo.vbytes;                         // window base aligned for 16-byte copies
         // medium rows in row order, then a stable descending length sort inside each window
         raw_vector<int> ridW((size_t)nmed), lenW((size_t)nmed);
@@ -581,7 +599,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             long long fit_s = 0, all_s = 0;
             for (int q = 0; q < ns; ++q) {
                 all_s += snz[q];
-                if (shi[q] >= 0 && ((long long)shi[q] - (slo[q] / A) * A + 1) * geo.vbytes <= 160 * 1024) fit_s += snz[q];
+                if (shi[q] >= 0 && ((long long)shi[q] - (slo[q] / A) * A + 1) * geo.vbytes <= kWinLdsMax) fit_s += snz[q];
             }
             scan_all = 4 * fit_s >= all_s;
         }
@@ -611,7 +629,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         fit_windows();
         // auto: when the spans are too wide for two workgroups per CU (80 KiB each), one workgroup per CU with all of the LDS
         // still beats global gathers on band-scattered rows (+-30 k columns, f16: 98.8 -> 65.9 us; +-8 k, f64: 166.8 -> 115.8 us)
-        if (p.opt.x_window == 0 && window_frac < 0.5) { cap_bytes = 160 * 1024; fit_windows(); }
+        if (p.opt.x_window == 0 && window_frac < 0.5) { cap_bytes = kWinLdsMax; fit_windows(); }
         const bool force = p.opt.x_window > 0;
         // ---- hybrid windows: when the whole span of a window does not fit (graph-like rows: most columns near the rows -- the
         // pages of a host, the members of a community -- plus a scattered remainder), stage the DENSEST span of cap bytes and let
@@ -625,7 +643,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         const bool even_rows = nmed > 0 && (long long)lenM[0] * nmed <= 4 * std::max<long long>(1, all);
         if (!dev && !order_only && p.opt.x_window_hybrid >= 0 &&
             (p.opt.x_window_hybrid > 0 || (p.opt.x_window == 0 && window_frac < 0.5 && even_rows))) {
-            const int hcap = p.opt.x_window > 0 ? std::min(p.opt.x_window, 160 * 1024) : 80 * 1024;    // two workgroups per CU
+            const int hcap = p.opt.x_window > 0 ? std::min(p.opt.x_window, kWinLdsMax) : 80 * 1024;    // two workgroups per CU
             const long long cap_cols = std::max<long long>(A, (hcap / geo.vbytes / A) * A);
             const long long xl = p.opt.n_parts > 0 ? (long long)p.opt.n_parts * p.opt.part_stride : (long long)p.n;
             std::vector<int> hmin(nW), hlen(nW);
@@ -1153,7 +1171,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     for (int v : p.win_len) s.n_windows_lds += v > 0;
     s.window_nnz_frac = window_frac;
     s.x_window_hybrid = p.win_hybrid ? 1 : 0;
-    if (p.windowed) { const int wpw = std::min(16, p.row_window / kMedRows); s.n_workgroups = ceil_div(s.n_long_pieces, wpw) + s.n_windows + ceil_div(s.n_short_tiles, wpw); }
+    if (p.windowed) { const int wpw = std::min(16, p.row_window / kMedRows); s.n_workgroups = ceil_div(s.n_long_pieces, wpw) + ceil_div(s.n_windows, 8) * 8 + (win_fold_tiles(s.n_windows, s.n_short_tiles) ? 0 : ceil_div(s.n_short_tiles, wpw)); }
     if (dev && !meta_only) {   // the O(nnz) copies happen on the GPU; the plan comes back uploaded
         PackMeta meta;
         meta.ridL = &ridL; meta.startL = &startL; meta.ridM = &ridM; meta.lenM = &lenM;
@@ -1174,7 +1192,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
 // ---- column panels (opt.col_panels; DESIGN.md section 4 "column panels") -------------------------------------------------
 // auto rule: only matrices whose rows scatter over more x than an XCD's L2 holds gain from cache blocking; anything with
 // locality (FEM / stencil rows touch runs of neighbouring columns, banded rows stay inside a narrow span) is left alone.
-// *scattered (r5; what the two-phase rule asks): 1 when a matrix of >= 16 M nonzeros has rows whose gathers scatter -- > 50 % of a sampled row's nonzeros on distinct
+// *scattered (r5; what the two-phase rule asks): 1 when a matrix of >= 10 M nonzeros has rows whose gathers scatter -- > 50 % of a sampled row's nonzeros on distinct
 // 128-byte lines of x, a third of the entries in rows spanning > x / 4 -- whatever the size of x and however hot some of its lines are
 static int decide_panels(const Plan &p, const int *rp, const int *ci, const Remap &remap, const DevCsr *dev, int *scattered)
 {
@@ -1189,6 +1207,21 @@ static int decide_panels(const Plan &p, const int *rp, const int *ci, const Rema
     // (the two-phase form pays from ~10 M nonzeros on: rmat_2M x0.25 / x0.3 / x0.5 = 8.4 / 9.0 / 16.8 M: 0.0363 / 0.0354 / 0.0556 ms against 0.0323 / 0.0377 / 0.0609;
     // webbase-1M x4 = 14.3 M: 0.0527 against 0.0651; cache blocking keeps its 16 M)
     if (p.nnz < (10 << 20) || p.m <= 0) return 1;
+    // the samples below cost a pass over 4096 rows (a gather kernel + a copy for a device CSR): skipped where no outcome could use them --
+    // the two-phase rule cannot fire (f64, a column remap, a panel, or the caller chose), and either the matrix is below the panels' 16 M nonzeros or its x fits an
+    // XCD's L2 and the O(rows) hub-row test (the only way to panels then) already says no
+    const bool tp_possible = scattered && p.precision == 16 && p.opt.n_parts == 0 && p.opt.two_phase == 0 && !p.panel;
+    auto hub_panels = [&]() -> int {
+        if (p.opt.long_cb < 0 || p.opt.n_parts > 0) return 1;
+        const long long h = std::max<long long>(p.opt.block_longest, 64ll * ((p.n + (vb == 8 ? 16384 : 32768) - 1) / (vb == 8 ? 16384 : 32768)));
+        long long hub = 0;
+        for (int i = 0; i < p.m; ++i) { const int len = rp[i + 1] - rp[i]; if (len >= h) hub += len; }
+        return hub * 2 >= (long long)p.nnz && hub < (long long)p.nnz ? 2 : 1;
+    };
+    if (!tp_possible) {
+        if (p.nnz < (16 << 20)) return 1;
+        if (xbytes <= (4ll << 20) && hub_panels() == 1) return 1;
+    }
     const int line_shift = vb == 8 ? 4 : 6;                       // 128-byte lines of x
     const int S = 4096;
     long long entries = 0, lines = 0, wide = 0;
@@ -1227,11 +1260,7 @@ static int decide_panels(const Plan &p, const int *rp, const int *ci, const Rema
     if (xbytes <= (4ll << 20)) {      // x fits an XCD's L2: nothing to block (A/B: 2.9 MB loses 10 %, 4.4 MB wins 11 %) ...
         // ... but hub rows that hold most of the nonzeros gain from the column-blocked form, which lives in a panel plan (longcb.cpp: x staged in LDS instead of
         // one L1 miss per nonzero): two panels for its sake (r5: powerlaw_1M x0.3 f64, 27 M nonzeros, x = 2.5 MB: 0.141 -> 0.114 ms; 0.145 with the hubs left to the panels)
-        if (p.opt.long_cb < 0 || p.opt.n_parts > 0) return 1;
-        const long long h = std::max<long long>(p.opt.block_longest, 64ll * ((p.n + (vb == 8 ? 16384 : 32768) - 1) / (vb == 8 ? 16384 : 32768)));
-        long long hub = 0;
-        for (int i = 0; i < p.m; ++i) { const int len = rp[i + 1] - rp[i]; if (len >= h) hub += len; }
-        return hub * 2 >= (long long)p.nnz && hub < (long long)p.nnz ? 2 : 1;
+        return hub_panels();
     }
     {   // scattered is not enough: real graphs have popular columns, and if the hottest 3 MiB of x lines already take most of
         // the gathers the L2 serves them without blocking (R-MAT 2^21 f64: 92 % of the gathers on 3 MiB of lines, panels

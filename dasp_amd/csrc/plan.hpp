@@ -376,6 +376,18 @@ int build_plan(Plan &p, const int *rp, const int *ci, const void *val, const Dev
 // two-phase form (twophase.cpp): the automatic rule (1: use it), the packer (after build_impl's meta pass: p.order / p.stats are set) and the
 // checks a loaded plan file must pass
 int decide_two_phase(const Plan &p, const int *rp, int scattered);
+// windowed plans: the workgroup's dynamic LDS = the window's copy of x (Plan::lds_bytes, a multiple of 256, <= kWinLdsMax); the kernels keep a word of static LDS beside it
+// (the unit counter of the window's waves)
+constexpr int kWinLdsMax = 160 * 1024 - 256;
+// short tiles folded into the window workgroups as fillers (upload_plan, spmv_body): tiles per window, or 0 when the tiles are too many beside the windows and keep
+// workgroups of their own
+// Only while the windows are at most two per CU: there the tiles' own workgroups are the ones left over at the end (cop20k_A x1 9.3 against 10.8 us, x2 16.0 / 24.9, x4 26.8 /
+// 29.0; f16 x4 18.2 / 26.6); with several rounds of window workgroups they fill the gaps by themselves and folding costs (x16, 1695 windows: 112.7 against 107.7 us).
+inline int win_fold_tiles(int n_windows, int n_short_tiles)
+{
+    return n_windows > 0 && n_windows <= 512 && n_short_tiles > 0 && n_short_tiles <= 2 * n_windows ? (n_short_tiles + n_windows - 1) / n_windows : 0;
+}
+constexpr int kTpDeclined = 1;          // build_two_phase under the automatic rule: the padded streams would pass 1.5 x the nonzeros (or the tile table 64 M entries) -- not an error
 int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val);
 bool validate_two_phase(const Plan &p, std::string &why);
 

@@ -170,9 +170,9 @@ static bool validate_plan(const Plan &p, int n_panels, bool is_panel, std::strin
                 for (long long e = 0; e < CH; ++e) if (cid_at(b, c, e) >= xlen) return fail("16-bit column id out of range");
             }
     // ---- windows
-    if (p.lds_bytes < 0 || p.lds_bytes > 160 * 1024) return fail("lds_bytes");
+    if (p.lds_bytes < 0 || p.lds_bytes > kWinLdsMax) return fail("lds_bytes");
     if (p.windowed) {
-        if (p.row_window < 64 || p.row_window > 1024 || p.row_window % 64) return fail("row_window");
+        if (p.row_window < 64 || p.row_window > 1024 || p.row_window % kMedRows) return fail("row_window");
         const long long nW = (p.n_mfma_rows + p.row_window - 1) / p.row_window;
         if (p.win_len.size() != (size_t)nW || p.win_cmin.size() != (size_t)nW || p.med_dst.size() != (size_t)p.n_mfma_rows) return fail("window tables");
         for (int d : p.med_dst) if ((unsigned)d >= (unsigned)m) return fail("med_dst out of range");

@@ -95,7 +95,11 @@ __device__ __forceinline__ U tab(const U *p, int i)
 // The kernels' arguments: the plan's DevArgs lives on the device (DevicePlan::dargs) and is read word by word through the constant address space --
 // scalar loads the compiler sinks to their uses and drops where a field is unused, exactly as it treats a by-value kernarg block -- and the four
 // per-call values travel in the kernarg segment (device.hpp: ~0.7 us per small launch against the 528-byte by-value block).
+#ifdef DASP_STAMPS
+struct CallArgs { const DevArgs *plan; const void *x; void *y; int acc, ywt, stamp_launch; };
+#else
 struct CallArgs { const DevArgs *plan; const void *x; void *y; int acc, ywt; };
+#endif
 // a pointer field of the device-resident block, loaded AS a global pointer (address space 1) through the constant address space: a pointer that arrives in
 // the kernarg segment is known to be global, one loaded from memory as a generic pointer is flat (flat_load instead of global_load, and no scalar
 // loads through it -- the plain f64 kernels fell from 302 to 19 s_load that way)
@@ -196,16 +200,21 @@ struct XGlobal {
     const T *x;
     __device__ __forceinline__ T at(int c) const { return x[c < 0 ? 0 : c]; }       // pads read x[0], dropped below
 };
+// (the window's copy of x is held through an explicitly-LDS pointer and the global x of the hybrid through an explicitly-global one: as two generic pointers the optimiser
+// folds XHyb's two branches into ONE flat load through a select of the pointers -- every staged gather then goes through the flat path, and with some register budgets the
+// gfx950 backend of ROCm 7.2 fails on it outright ("Illegal instruction detected ... V_CMP_NE_U32_e32 0, $src_shared_base"); pointers of two address spaces cannot be merged)
+template <class T> using lds_cptr = const __attribute__((address_space(3))) T *;
+template <class T> using glb_cptr = const __attribute__((address_space(1))) T *;
 template <class T>
 struct XLds {
-    const T *xw; int cmin;
+    lds_cptr<T> xw; int cmin;
     __device__ __forceinline__ T at(int c) const { return xw[c < 0 ? 0 : c - cmin]; }
 };
 // hybrid window: the densest span of the window's columns is in LDS, everything else is gathered from global memory.
 // The two loads sit in divergent branches on purpose: a lane whose column is staged issues no global load.
 template <class T>
 struct XHyb {
-    const T *xw; const T *xg; int cmin; unsigned len;
+    lds_cptr<T> xw; glb_cptr<T> xg; int cmin; unsigned len;
     __device__ __forceinline__ T at(int c) const
     {
         const unsigned o = (unsigned)(c - cmin);
@@ -595,7 +604,9 @@ __device__ __forceinline__ bool diag_of(const f32x4 &acc, int lane, float &d)
 // ---- medium: one wave = one block of 16 sorted rows (reference: dasp_f64.h:145-279)
 // YM: where the 16 results go -- 0: the block's own slots (reference permutation), or order[slot] when the plan is
 // DASP_Y_NATURAL (a.order set); 2: med_dst[position] (windowed mode)
-template <class T, bool NT, bool C16, int YM, bool C8 = false, int YS = 0, bool REL = false, class XV>
+// WU / WS (windowed f64 only; 0 = the defaults of Tr<T>): pipeline batch and longest one-shot unit of the build held to 64 registers -- with 4 + 4 fragments in flight it
+// spilled 12-29 VGPRs; windowed plans store no pairs, so their layout does not depend on the batch
+template <class T, bool NT, bool C16, int YM, bool C8 = false, int YS = 0, bool REL = false, int WU = 0, int WS = 0, class XV>
 __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, const XV &x)
 {
     using acc_t = typename Tr<T>::acc_t;
@@ -624,7 +635,7 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     }
     src.ival = static_cast<const T *>(a.irr_val); src.icid = a.irr_cid; src.t0 = t0; src.t1 = t1; src.kq = kq;
     // (the windowed f16 kernels, held to 64 registers, keep blocks of up to 2 steps in one shot: 4 spill there; windowed plans store no pairs, so their layout does not depend on it)
-    run_stream<T, Tr<T>::BATCH, (YM == 2 && sizeof(T) == 2) ? 2 : Tr<T>::SHOT>(acc, src, src.nc + nt, x);
+    run_stream<T, (WU > 0 && sizeof(T) == 8) ? WU : Tr<T>::BATCH, (YM == 2 && sizeof(T) == 2) ? 2 : ((WS > 0 && sizeof(T) == 8) ? WS : Tr<T>::SHOT)>(acc, src, src.nc + nt, x);
 
     typename Tr<T>::part_t d;
     if (diag_of(acc, lane, d) && r < a.row_block) {
@@ -930,6 +941,44 @@ __device__ __forceinline__ void row_tile(const DevArgs &a, int t, int lane, type
     if ((a.rt_mask[t] >> lane) & 1) put_y<T>(a, t * kRowTile + lane, sum);
 }
 
+// ---- per-phase time stamps of a workgroup (tools/stamp_probe.py; the DASP_STAMPS build of tools/build_variant.sh only -- in the product every member is empty and the
+// calls vanish).  mark(i) waits for everything the wave has in flight, then reads the shader clock: phase i ends where all loads issued before it have returned.
+// finish() adds a workgroup barrier, takes a ticket (completion order; ticket / grid = the launch) and writes one 16-word record.
+#ifdef DASP_STAMPS
+struct StampBuf { unsigned long long *rec; unsigned cap; };      // cap = records (one per wave, 12 words each)
+static __device__ StampBuf g_stamps;
+struct Stamps {
+    unsigned long long wall0, clk[4];
+    int kind, launch;
+    __device__ __forceinline__ void begin(int launch_no) { wall0 = __builtin_amdgcn_s_memrealtime(); clk[0] = __builtin_readcyclecounter(); clk[1] = clk[2] = clk[3] = clk[0]; kind = 0; launch = launch_no; }
+    __device__ __forceinline__ void mark(int i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); clk[i] = __builtin_readcyclecounter(); }
+    // no barrier, no atomic (3000 workgroups taking tickets from one word serialise at the memory side: the stamped launch took 3x as long): the record's place follows from
+    // the launch number the host passes, the workgroup and the wave
+    __device__ __forceinline__ void finish(int nwaves)
+    {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const unsigned long long e = __builtin_readcyclecounter();
+        const unsigned long long wall1 = __builtin_amdgcn_s_memrealtime();
+        const size_t slot = ((size_t)launch * gridDim.x + blockIdx.x) * (size_t)nwaves + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63) == 0 && g_stamps.rec && launch >= 0 && slot < g_stamps.cap) {
+            unsigned long long *r = g_stamps.rec + slot * 12;
+            unsigned xcc, hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            r[0] = blockIdx.x | ((unsigned long long)(threadIdx.x >> 6) << 32) | ((unsigned long long)nwaves << 40) | ((unsigned long long)kind << 48) | (1ull << 63);
+            r[1] = xcc | ((unsigned long long)hw << 32); r[2] = gridDim.x; r[3] = wall0; r[4] = wall1;
+            r[5] = clk[0]; r[6] = clk[1]; r[7] = clk[2]; r[8] = clk[3]; r[9] = e; r[10] = (unsigned long long)launch; r[11] = 0;
+        }
+    }
+};
+#else
+struct Stamps {
+    int kind;
+    __device__ __forceinline__ void begin(int) {}
+    __device__ __forceinline__ void mark(int) {}
+};
+#endif
+
 #ifndef DASP_MIN_WAVES
 #define DASP_MIN_WAVES 1
 #endif
@@ -937,8 +986,13 @@ constexpr int kMinWavesPlain = DASP_MIN_WAVES, kMinWavesWin = 8;
 // WIN: windowed mode.  A medium workgroup owns one window of row_window rows (blocks_per_win blocks, strided over its
 // 4 waves); if the window's x span fits, it is copied once into LDS with coalesced 16-byte loads and every gather of
 // the window reads LDS; otherwise that workgroup gathers from global memory like the non-windowed kernel.
-template <class T, bool NT, bool C16, bool WIN, bool C8, bool RT = false>
-__device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw, int wg_index)
+#ifndef DASP_WIN64_U
+#define DASP_WIN64_U 4
+#define DASP_WIN64_S 8
+#endif
+// W64: the windowed build held to 64 registers (two window workgroups per CU)
+template <class T, bool NT, bool C16, bool WIN, bool C8, bool RT = false, bool W64 = false>
+__device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw, int wg_index, Stamps &st)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -948,6 +1002,7 @@ __device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw, int w
         const int p = wg * wpw + wave;
         if (p < a.n_pieces) long_piece<T, NT, 0, !WIN>(a, p, lane);
     } else if (wg < a.wg_long + a.wg_med) {
+        st.kind = 1;
         if constexpr (!WIN) {
             const int m = wg - a.wg_long;
             const XGlobal<T> x{static_cast<const T *>(a.x)};
@@ -973,20 +1028,30 @@ __device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw, int w
                 medium_block<T, NT, C16, 0, C8>(a, b, lane, x);
             }
         } else {
-            // one window per workgroup; its blocks_per_win blocks are dealt round-robin to the wpw waves.  Workgroups are dealt to the 8
-            // XCDs round-robin, so workgroup m of the range takes window (m % 8) * per_xcd + m / 8: every XCD works on ONE contiguous
-            // eighth of the windows -- the same eighth in every launch, whose tiles and x (an eighth of x plus the band) can stay in
+            // one window per workgroup.  Workgroups are dealt to the 8 XCDs round-robin, so workgroup m of the range takes window (m % 8) * per_xcd + m / 8: every
+            // XCD works on ONE contiguous eighth of the windows -- the same eighth in every launch, whose tiles and x (an eighth of x plus the band) can stay in
             // that XCD's 4 MiB L2 from one SpMV to the next when the matrix is small enough (cop20k_A: 3.5 MB per XCD)
             const int mw = wg - a.wg_long, per_xcd = a.wg_med >> 3;
             const int w = a.win_xcd ? (mw & 7) * per_xcd + (mw >> 3) : mw;
             if (w >= a.n_windows) return;
             const int len = a.win_len[w], cmin = a.win_cmin[w];
             const T *xg = static_cast<const T *>(a.x);
-            T *xw = reinterpret_cast<T *>(lds_raw);
+            // the workgroup's units: its blocks_per_win blocks, longest first (the window's rows are sorted by length), then the short tiles folded into it
+            // (DevArgs::win_tiles: tiles w, w + n_windows, ...).  Wave k starts with unit k and then takes the next free one from a counter in LDS: the waves end
+            // together whatever the blocks' lengths (r6, profiles/r06_small_matrix.md: dealt round-robin, a workgroup's first wave was done after 4.5 us, its last
+            // after 6.0), and the short tiles -- 16 waves of 64-line gathers per CU when they had workgroups of their own, the last waves of the launch to exit --
+            // are spread over all CUs as fillers
+            __shared__ int next_unit_word;                // (static LDS beside the dynamic window: kWinLdsMax leaves room for it)
+            int *next_unit = &next_unit_word;
+            typedef __attribute__((address_space(3))) T lds_T;
+            lds_T *xw = (lds_T *)lds_raw;                 // (lds_raw IS the kernel's dynamic LDS: the cast back folds away once spmv_body is inlined)
+            if (threadIdx.x == 0) *next_unit = wpw;
+            st.kind = 3; st.mark(1);
             if (len > 0) {
                 constexpr int A = 16 / (int)sizeof(T);
                 const i32x4 *src = reinterpret_cast<const i32x4 *>(xg + cmin);
-                i32x4 *dst = reinterpret_cast<i32x4 *>(xw);
+                typedef __attribute__((address_space(3))) i32x4 lds_i32x4;
+                lds_i32x4 *dst = (lds_i32x4 *)xw;
                 const int nvec = len / A, nth = wpw * kWave;
                 for (int i0 = threadIdx.x; i0 < nvec; i0 += 4 * nth) {       // four 16-byte loads in flight per lane
                     const int i1 = i0 + nth, i2 = i0 + 2 * nth, i3 = i0 + 3 * nth;
@@ -998,35 +1063,56 @@ __device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw, int w
                     if (i3 < nvec) dst[i3] = v3;
                 }
                 for (int i = nvec * A + threadIdx.x; i < len; i += nth) xw[i] = xg[cmin + i];
-                __syncthreads();
+                st.mark(2);
+            }
+            __syncthreads();
+            st.mark(3);
+            const int n_units = a.blocks_per_win + a.win_tiles;
+            // (one loop per gather source: the block is a different instantiation in each.  The short tiles have a loop of their own behind the blocks' -- in ONE loop with
+            // the LDS-gathering blocks the f16 64-register build does not compile: "Illegal instruction detected ... V_CMP_NE_U32_e32 0, $src_shared_base", ROCm 7.2)
+            constexpr int WU = W64 ? DASP_WIN64_U : 0, WS = W64 ? DASP_WIN64_S : 0;
+            int q = wave;
+#define DASP_NEXT_UNIT()                                                                                          \
+            {                                                                                                     \
+                int nq = 0;                                                                                       \
+                if (lane == 0) nq = atomicAdd(next_unit, 1);                                                      \
+                q = __builtin_amdgcn_readfirstlane(nq);                                                           \
+            }
+#define DASP_WINDOW_BLOCKS(BLOCK_CALL)                                                                            \
+            while (q < a.blocks_per_win) {                                                                        \
+                const int b = w * a.blocks_per_win + q;                                                           \
+                if (b < a.n_blocks) { BLOCK_CALL; }                                                               \
+                DASP_NEXT_UNIT()                                                                                  \
+            }
+            if (len > 0) {
                 if (a.win_hybrid) {
-                    const XHyb<T> x{xw, xg, cmin, (unsigned)len};
-                    for (int q = wave; q < a.blocks_per_win; q += wpw) {
-                        const int b = w * a.blocks_per_win + q;
-                        if (b < a.n_blocks) medium_block<T, NT, C16, 2>(a, b, lane, x);
-                    }
+                    const XHyb<T> x{xw, (glb_cptr<T>)xg, cmin, (unsigned)len};
+                    DASP_WINDOW_BLOCKS((medium_block<T, NT, C16, 2, false, 0, false, WU, WS>(a, b, lane, x)))
                 } else if (C16 && a.win_rel16) {
                     const XLds<T> x{xw, cmin};
-                    for (int q = wave; q < a.blocks_per_win; q += wpw) {
-                        const int b = w * a.blocks_per_win + q;
-                        if (b < a.n_blocks) medium_block<T, NT, C16, 2, false, 0, C16>(a, b, lane, x);
-                    }
+#ifdef DASP_WIN_KEEPMOD     // experiment build (tools/build_variant.sh): all windows but every DASP_WIN_KEEPMOD-th read their tiles with plain loads (could they stay in the L2 from launch to launch?)
+                    if ((w % DASP_WIN_KEEPMOD) != DASP_WIN_KEEPMOD - 1) { DASP_WINDOW_BLOCKS((medium_block<T, false, C16, 2, false, 0, C16, WU, WS>(a, b, lane, x))) }
+                    else
+#endif
+                    DASP_WINDOW_BLOCKS((medium_block<T, NT, C16, 2, false, 0, C16, WU, WS>(a, b, lane, x)))
                 } else {
                     const XLds<T> x{xw, cmin};
-                    for (int q = wave; q < a.blocks_per_win; q += wpw) {
-                        const int b = w * a.blocks_per_win + q;
-                        if (b < a.n_blocks) medium_block<T, NT, C16, 2>(a, b, lane, x);
-                    }
+                    DASP_WINDOW_BLOCKS((medium_block<T, NT, C16, 2, false, 0, false, WU, WS>(a, b, lane, x)))
                 }
             } else {
                 const XGlobal<T> x{xg};
-                for (int q = wave; q < a.blocks_per_win; q += wpw) {
-                    const int b = w * a.blocks_per_win + q;
-                    if (b < a.n_blocks) medium_block<T, NT, C16, 2>(a, b, lane, x);
-                }
+                DASP_WINDOW_BLOCKS((medium_block<T, NT, C16, 2, false, 0, false, WU, WS>(a, b, lane, x)))
             }
+            while (q < n_units) {
+                const int t = w + (q - a.blocks_per_win) * a.n_windows;
+                if (t < a.n_short_tiles) short_tile<T, NT, 0, false>(a, t, lane);
+                DASP_NEXT_UNIT()
+            }
+#undef DASP_WINDOW_BLOCKS
+#undef DASP_NEXT_UNIT
         }
     } else if (!RT || wg < a.wg_long + a.wg_med + a.wg_short) {
+        st.kind = 2;
         const int t = (wg - a.wg_long - a.wg_med) * wpw + wave;
         if constexpr (!WIN && sizeof(T) == 8) {      // (f64 only: the f16 kernels are held to 72 registers and never segment their short rows by themselves)
             if (a.short_tpw > 1) {      // plans with wave-segmented groups: kShortTpw tiles per wave (upload_plan)

@@ -30,11 +30,11 @@ void for_each_block(int n, int threads, F f)
 }
 }  // namespace
 
-// the automatic rule (opt.two_phase == 0): f16, identity column map, no explicit choice of column panels, >= 16 M nonzeros in rows whose gathers scatter over x
+// the automatic rule (opt.two_phase == 0): f16, identity column map, no explicit choice of column panels, >= 10 M nonzeros in rows whose gathers scatter over x
 // (`scattered`: decide_panels' samples -- > 50 % of a row's nonzeros on distinct 128-byte lines, a third of the entries in rows spanning > x / 4).  Neither the size of x nor hot lines
 // matter to this form: powerlaw_1M f16 (x = 2 MB) 0.324 -> 0.209 ms, rmat_2M f16 (92 % of the gathers on 3 MiB of hot lines) 0.135 -> 0.094.  Hub rows are fine since
 // phase 2 combines a lane's consecutive same-row elements before the atomic (before that: rmat_2M 3.13 ms); small matrices lose (webbase-1M, 3.6 M nonzeros:
-// 0.0149 -> 0.0246 ms: two launches and a slice of x per workgroup), hence the 16 M.
+// 0.0149 -> 0.0246 ms: two launches and a slice of x per workgroup), hence the size bound (decide_panels: 10 M nonzeros since the r5 size sweep; 16 M before it).
 int decide_two_phase(const Plan &p, const int *rp, int scattered)
 {
     (void)rp;
@@ -94,6 +94,12 @@ int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val)
         if (m > 0) t.rb_row0.push_back(m);
     }
     const int n_rb = t.n_rb();
+    // the automatic rule's last word: every non-empty (row block, column block) tile is padded to whole 64-element segments, and a row block holds at most
+    // rbm rows -- a large, very sparse matrix (50 M rows of 3 nonzeros: 1526 column blocks, ~8 nonzeros per tile) would store several times its nonzeros and keep
+    // n_rb * n_cb * 20 bytes of tables on the host.  Declined (kTpDeclined: build_impl goes on to column panels / the plain plan) when the padded streams pass 1.5 x the
+    // nonzeros or the tile table passes 64 M entries; a forced two_phase = 1 is built as asked.
+    const bool may_decline = p.opt.two_phase == 0;
+    if (may_decline && (long long)n_rb * (long long)n_cb > (1ll << 26)) { t = TwoPhase{}; return kTpDeclined; }
     // ---- nonzeros per tile
     std::vector<int> cnt((size_t)n_rb * (size_t)n_cb, 0);
     for_each_block(n_rb, threads, [&](int b) {
@@ -114,6 +120,7 @@ int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val)
         for (int c = 0; c < n_cb; ++c)
             for (int b = 0; b < n_rb; ++b) { const size_t i = (size_t)b * (size_t)n_cb + (size_t)c; off1[i] = run1; run1 += segs_of(i); }
         if (run != run1) { set_error("two_phase: internal offset mismatch"); return DASP_ERR_STATE; }
+        if (may_decline && run * kTpSeg > nnz + nnz / 2) { t = TwoPhase{}; return kTpDeclined; }
         if (run >= (1ll << 31) / 2) { set_error("two_phase: too many segments for 32-bit segment indices"); return DASP_ERR_ARG; }
         t.segments = (size_t)run;
     }

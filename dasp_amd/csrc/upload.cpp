@@ -27,9 +27,18 @@ namespace dasp {
         }                                                                                      \
     } while (0)
 
+static void release_side_stream(DevicePlan *d)
+{
+    if (d->ev_fork) (void)hipEventDestroy(static_cast<hipEvent_t>(d->ev_fork));
+    if (d->ev_join) (void)hipEventDestroy(static_cast<hipEvent_t>(d->ev_join));
+    if (d->side_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(d->side_stream));
+    d->ev_fork = d->ev_join = d->side_stream = nullptr;
+}
+
 Plan::~Plan()
 {
     if (dev) {
+        release_side_stream(dev);
         if (dev->arena) (void)hipFree(dev->arena);
         if (dev->dargs) (void)hipFree(dev->dargs);
         std::free(dev->args_sent);
@@ -66,7 +75,7 @@ static int upload_plan_impl(Plan &p)
     if (int rc = require_device()) return rc;
     if (p.host_dropped && p.dev) return DASP_OK;   // already on the device (packed there, or host copies released)
     if (p.host_dropped) { set_error("host arrays were dropped"); return DASP_ERR_STATE; }
-    if (p.dev) { if (p.dev->arena) (void)hipFree(p.dev->arena); if (p.dev->dargs) (void)hipFree(p.dev->dargs); std::free(p.dev->args_sent); delete p.dev; p.dev = nullptr; }
+    if (p.dev) { release_side_stream(p.dev); if (p.dev->arena) (void)hipFree(p.dev->arena); if (p.dev->dargs) (void)hipFree(p.dev->dargs); std::free(p.dev->args_sent); delete p.dev; p.dev = nullptr; }
     auto *d = new DevicePlan();
     p.dev = d;
     HIP_TRY(hipGetDevice(&d->device));
@@ -97,6 +106,16 @@ static int upload_plan_impl(Plan &p)
             q.row_dst = (const int *)(base + o_d); q.partial = base + o_s;
             q.n_units = L.n_units(); q.n_rows = L.n_rows(); q.n_cb = L.n_cb; q.cb = L.cb; q.xlen = p.n;
             if (int rc = tp_kernels_allow_lds()) return rc;
+            // the hub rows' own stream (a failure here leaves the plan on one stream)
+            const char *e = std::getenv("DASP_LCB_SIDE_STREAM");      // A/B knob: 0 = the hub rows behind the panels on the caller's stream, as in r5
+            if (!(e && std::atoi(e) == 0)) {
+                hipStream_t ss = nullptr; hipEvent_t ef = nullptr, ej = nullptr;
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // (hi = the numerically lowest = highest priority: the few 1024-thread workgroups get their CUs as the panels' first ones end)
+                if (hipStreamCreateWithPriority(&ss, hipStreamNonBlocking, hi) == hipSuccess && hipEventCreateWithFlags(&ef, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&ej, hipEventDisableTiming) == hipSuccess) { d->side_stream = ss; d->ev_fork = ef; d->ev_join = ej; }
+                else { if (ef) (void)hipEventDestroy(ef); if (ej) (void)hipEventDestroy(ej); if (ss) (void)hipStreamDestroy(ss); (void)hipGetLastError(); }
+            }
         }
         return DASP_OK;
     }
@@ -233,7 +252,7 @@ static int upload_plan_impl(Plan &p)
         int cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, d->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        d->win1 = a.n_windows <= cus;
+        d->win1 = a.n_windows <= cus;          // (wg_med below rounds the windows up to a multiple of 8: with 249..256 windows the grid is exactly the 256 CUs)
         if (const char *e = std::getenv("DASP_WIN1")) d->win1 = d->win1 && std::atoi(e) != 0;
     }
     a.wg_med = p.windowed ? (a.n_windows + 7) / 8 * 8 : (a.n_blocks + kWavesPerWG - 1) / kWavesPerWG;      // windows: a whole number per XCD (kernel)
@@ -291,6 +310,15 @@ static int upload_plan_impl(Plan &p)
     a.n_short_waves = 0;
     for (int g = 0; g < kNumShortGroups; ++g) { a.grp_wave0[g] = a.n_short_waves; a.n_short_waves += p.grp[g].seg && a.short_tpw > 1 ? (p.grp[g].tiles + a.short_tpw - 1) / a.short_tpw : p.grp[g].tiles; }
     a.wg_short = (a.n_short_waves + a.wpw - 1) / a.wpw;
+    // windowed plans: a short tile per wave in workgroups of 16 waves puts 16 waves of 64-line gathers on each of a few CUs -- on cop20k_A (104 tiles in 7 workgroups) they
+    // were the last waves of the launch to exit (9.9 us against 7.2 for the median window wave).  Where the tiles are few beside the windows they are folded into the window
+    // workgroups as fillers behind their blocks (spmv_body): tile t goes to window t % n_windows.  One launch-wide rule: all tiles or none.
+    a.win_tiles = 0;
+    if (p.windowed && win_fold_tiles(a.n_windows, a.n_short_tiles) > 0) {
+        a.win_tiles = win_fold_tiles(a.n_windows, a.n_short_tiles);
+        a.wg_short = 0;
+    }
+    if (const char *e = std::getenv("DASP_WIN_FOLD")) if (std::atoi(e) == 0 && a.win_tiles) { a.win_tiles = 0; a.wg_short = (a.n_short_waves + a.wpw - 1) / a.wpw; }      // A/B knob
     a.rt_val = base + o_rv; a.rt_cid = (const int *)(base + o_rc); a.rt_ptr = (const int *)(base + o_rp);
     a.rt_start = (const unsigned short *)(base + o_rs); a.rt_mask = (const unsigned long long *)(base + o_rm);
     a.n_rt_tiles = (int)p.rt_mask.size(); a.wg_rt = (a.n_rt_tiles + kWavesPerWG - 1) / kWavesPerWG; a.rt_max = p.rt_max;
@@ -395,6 +423,10 @@ int tune_placement(Plan &p, int trials, const void *dX, void *dY, double *ms_fir
         if (ok) { lo = std::min(lo, ms); hi = std::max(hi, ms); }
     }
     if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+    // the device-resident DevArgs follows the arena that was kept (a losing last trial rebased `args` back behind it): re-sent HERE, with nothing captured, so that
+    // the next launch_spmv -- possibly inside a caller's stream capture -- finds it in sync and copies nothing
+    // (column-panel parents never get here: the trials return at once for them)
+    if (int rc = sync_dev_args(p)) { cleanup(); return rc; }
     if (ms_kept) *ms_kept = best;
     // the allocations that lost go back now (the driver wipes released VRAM in the background: see the note above)
     for (void *q : losers) (void)hipFree(q);

@@ -105,7 +105,7 @@ typedef struct dasp_options {
      *             -2 = windowed order without LDS staging (measurement knob: slower than either alternative),
      *             > 0 = force on with this many bytes of LDS per workgroup as the cap (<= 163840; auto uses 81920,
      *                   i.e. two workgroups per CU, and falls back to 163840 when the spans do not fit that)
-     *   row_window: rows per window, multiple of 64 up to 1024 (16 rows per block, up to 16 waves per workgroup);
+     *   row_window: rows per window, multiple of 16 (one block) from 64 up to 1024 (up to 16 waves per workgroup, 1-4 blocks per wave);
      *               0 = by size: ~224 windows (one per CU, with slack), ~448 once a window would pass 1024 rows */
     int x_window;
     int row_window;
@@ -191,6 +191,11 @@ typedef struct dasp_options {
      * stay those of the whole matrix; products are f16 x f16 accumulated in f64 (the order of a row's additions is not fixed: LDS atomics).
      *   0 = auto: f16, no column remap, no explicit col_panels, >= 10 M nonzeros whose rows scatter (> 50 % of a sampled row's nonzeros on distinct 128-byte lines of x,
      *       a third of the entries in rows spanning > x/4; hub rows are fine: same-row elements are combined before they reach LDS); 1 = force; -1 = off.
+     *       The automatic rule also declines (the matrix keeps its DASP form) when the tiles' padding to whole 64-element segments would store > 1.5 x the nonzeros
+     *       (large, very sparse matrices: few nonzeros per tile) or the tile table would pass 64 M entries.
+     *   DETERMINISM: this is the one form whose results are not bit-reproducible from run to run -- a row's products reach its f64 LDS accumulator through relaxed
+     *   atomics, so their order of addition is not fixed (the f64 sum rounds ~2^-53; the difference shows only where the final rounding to f16 sits on a tie).  Every other
+     *   path (DASP blocks, slabs, panels, column-blocked long rows, the multi-GPU step) adds in a fixed order.  two_phase = -1 is the deterministic choice.
      *   tp_col_block: columns per column block (multiple of 8, <= 65536; 0 = 32768); tp_row_block: most output positions per row block (<= 8192; 0 = 4096). */
     int two_phase;
     int tp_col_block, tp_row_block;

@@ -117,12 +117,13 @@ def _worst_case_record(b, multi):
     out = {"metric": "SpMV GFLOP/s (f64)", "value": 1236.27, "unit": "GFLOP/s", "n_gpus": 8 if multi else 1, "steps": 20, "warmup": 5,
            "ms_per_step": 0.445621, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "HV15R synthetic stand-in " + "x" * 400, "generator": "g" * 600, "generator_rev": "26e32ff958e7", "rows": 2017169,
-                      "cols": 2017169, "nnz": 275454726, "scale": 1.0, "partition": "p" * 400, "placement": {"note": "n" * 900},
+                      "cols": 2017169, "nnz": 275454726, "scale": 1.0, "partition": "p" * 400, "placement": {"note": "n" * 900}, "y_candidates": 6,
                       "exchange": "e" * 300, "step_form": "s" * 700, "rank0_nnz_own_columns": 1, "rank0_nnz_other_columns": 2},
            "roofline": {"bound": "hbm", "achieved": 7500.7, "peak": 8000.0, "unit": "GB/s", "frac": 0.9376, "traffic": 2913962942,
                         "traffic_over_algorithmic": 0.8709, "traffic_reason": "r" * 500, "kernel": "dasp_spmv_kernel<double>", "kernel_ms": 0.446063,
-                        "algorithmic_bytes_per_launch": 3345800096, "frac_single_y": 0.91, "frac_random_values": 0.9194, "launch_ms_median": 0.447,
-                        "method": "m" * 900, "f64_share_at_or_above_0.6": 0.667, "suite_frac": sf, "suite_frac_random_values": dict(sf)},
+                        "algorithmic_bytes_per_launch": 3345800096, "frac_best_of_n_y": 0.98, "frac_separate_launches": 0.94, "frac_random_values": 0.9194, "launch_ms_median": 0.447,
+                        "method": "m" * 900, "f64_share_at_or_above_0.6": 0.667, "suite_frac": sf, "suite_frac_random_values": dict(sf),
+                        "suite_frac_mfma_form": {k: v for k, v in sf.items() if k.endswith("f16")}},
            "cpu_baseline": {"value": 5.343, "unit": "GFLOP/s", "cores": 1, "kind": "port", "sample": "c" * 500, "ms": 103.1, "host_cores_available": 256,
                             "build": "b" * 300},
            "verified": True, "region_event_ms_per_step": 0.445, "achieved_GBps_whole_job": 7508.2, "frac_hbm_roofline_whole_job": 0.9385,
@@ -155,7 +156,8 @@ def test_driver_line_is_short_and_complete(tmp_path, capsys):
         assert "model" not in rec["config"]
         r = rec["roofline"]
         assert (r["bound"], r["frac"], r["achieved"], r["peak"], r["unit"], r["traffic"]) == ("hbm", 0.9376, 7500.7, 8000.0, "GB/s", 2913962942)
-        assert r["frac_single_y"] == 0.91 and r["frac_random_values"] == 0.9194 and len(r["suite_frac"]) == 11 and len(r["suite_frac_random_values"]) == 11
+        assert r["frac_best_of_n_y"] == 0.98 and rec["config"]["y_candidates"] == 6 and r["frac_separate_launches"] == 0.94      # `frac` is the single-y figure
+        assert r["frac_random_values"] == 0.9194 and len(r["suite_frac"]) == 11 and len(r["suite_frac_random_values"]) == 11 and len(r["suite_frac_mfma_form"]) == 5
         c = rec["cpu_baseline"]
         assert (c["value"], c["cores"], c["kind"], c["unit"]) == (5.343, 1, "port", "GFLOP/s") and c["sample"]
         assert rec["suite_errors"] == ["broken"] and "suite" not in rec and rec["full_record"] == "bench_suite.json"

@@ -79,8 +79,10 @@ def test_row_tables_stay_scalar_loads(isa):
         assert isa[k]["s_load"] >= 25, (k, isa[k]["s_load"])
     # pointers of the device-resident argument block must be known to be GLOBAL (ldp in load_args): as flat pointers every table and tile load becomes
     # flat_load and none of them scalar (f64 16-bit-id kernel: 1056 global_load + 20 flat stores -> 297 + 972)
+    # (the windowed kernels hold the short-tile code twice since r6 -- as fillers of the window workgroups and for the plans whose tiles keep workgroups of their own --
+    # and with it twice its x gathers / y stores through the generic x / y pointers: 90 flat ops, none of them a table or tile load)
     for k in PLAIN64 + RT64 + PLAIN16 + RT16 + WIN + WIN1:
-        assert isa[k]["flat"] <= 80 and isa[k]["global_load"] >= 400, (k, isa[k]["flat"], isa[k]["global_load"])
+        assert isa[k]["flat"] <= (100 if k in WIN + WIN1 else 80) and isa[k]["global_load"] >= 400, (k, isa[k]["flat"], isa[k]["global_load"])
         assert isa[k]["kernarg_segment_size"] <= 64, (k, isa[k]["kernarg_segment_size"])
     # the multi-GPU step kernels wait on flags in memory; their tables go through the constant address space (tab<true>) and must stay scalar
     assert isa["dasp_mg_step_kernel<1>"]["s_load"] >= 200 and isa["dasp_mg_step2_kernel<1>"]["s_load"] >= 700, [isa[k]["s_load"] for k in STEP]

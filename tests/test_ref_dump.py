@@ -23,6 +23,20 @@ def _load(prec):
     return json.loads(txt)
 
 
+def _mtx(name, tmp):
+    """a fixture by the base name the dump recorded: tests/golden/<name>, or <name>.gz unpacked on the fly (survey_g3000.mtx travels gzipped)"""
+    path = os.path.join(GOLD, name)
+    if os.path.exists(path):
+        return path
+    if os.path.exists(path + ".gz"):
+        import gzip
+        out = os.path.join(str(tmp), name)
+        with gzip.open(path + ".gz", "rb") as f, open(out, "wb") as g:
+            g.write(f.read())
+        return out
+    pytest.fail("the reference dump names %s, which tests/golden does not hold" % name)
+
+
 def _fnv(a):
     h = 1469598103934665603
     for b in np.ascontiguousarray(a, np.int32).view(np.uint8).tolist():
@@ -34,11 +48,11 @@ CSV_INT = "rowA colA nnzA short_row_1 common_13 short_row_3 short_row_4 short_ro
 
 
 @pytest.mark.parametrize("prec", [64, 16])
-def test_counters_sizes_and_order_match_the_cuda_reference(dasp, prec):
+def test_counters_sizes_and_order_match_the_cuda_reference(dasp, prec, tmp_path):
     ref = _load(prec)
     assert ref["precision"] == prec
     for mat in ref["matrices"]:
-        path = os.path.join(GOLD, mat["file"])
+        path = _mtx(mat["file"], tmp_path)
         m, n, nnz, sym, rp, ci, v = dasp.mmio_allinone(path, precision=prec)
         assert (m, n, nnz) == (mat["rowA"], mat["colA"], mat["nnzA"])
         assert _fnv(rp) == mat["rowptr_fnv"] and _fnv(ci) == mat["colidx_fnv"], mat["file"]           # the loader's CSR, bit for bit
@@ -56,14 +70,15 @@ def test_counters_sizes_and_order_match_the_cuda_reference(dasp, prec):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("prec", [64, 16])
-def test_y_matches_the_cuda_reference(dasp, torch_cuda, prec):
+def test_y_matches_the_cuda_reference(dasp, torch_cuda, prec, tmp_path):
     """Y_val of the reference's spmv_all, slot by slot: exact in the all-ones mode, 1e-12 (f64) / 1e-2 (f16: the reference accumulates in
-    half, this build in f32) of sum |a x| otherwise."""
+    half, this build in f32) of sum |a x| otherwise.  f16: the Y_val the reference leaves behind is its bypass kernel's (dasp_spmv2, the run its "SpMV_X2" line times:
+    dasp_f16.h:1636-1705), in both value modes."""
     torch = torch_cuda
     ref = _load(prec)
     dt, tdt = (np.float64, torch.float64) if prec == 64 else (np.float16, torch.float16)
     for mat in ref["matrices"]:
-        m, n, nnz, sym, rp, ci, v = dasp.mmio_allinone(os.path.join(GOLD, mat["file"]), precision=prec)
+        m, n, nnz, sym, rp, ci, v = dasp.mmio_allinone(_mtx(mat["file"], tmp_path), precision=prec)
         for run in mat["runs"]:
             ones = run["mode"] == "ones"
             vals = np.ones(nnz, dt) if ones else v
