@@ -106,9 +106,6 @@ struct DevicePlan {
     int device = -1;
     // column-panel parent: arena = the panels' partial results, panel k at ypart + k * ypart_stride elements
     size_t ypart_stride = 0;
-    // column-panel parent with column-blocked long rows (r6): the hub rows' two kernels run on a stream of the plan's own BESIDE the panels' launch (fork / join by events on
-    // the caller's stream: capturable) -- the panels are bound by L2 gathers, the hub rows by the HBM stream.  Null: one stream, as before.
-    void *side_stream = nullptr, *ev_fork = nullptr, *ev_join = nullptr;
 };
 
 

@@ -374,8 +374,9 @@ __global__ __launch_bounds__(1024) void dasp_lcb_kernel(LcbDev a, const T *__res
     }
 }
 // one wave per long row: its n_cb partial sums -> the row's slot of panel 0's partial buffer (no panel writes it: the row is empty there)
+// acc (the two-phase hybrid, whose phase 2 has stored 0 -- or left y as it was in accumulate mode -- at the hub rows' positions): out[dst] += the row's sum
 template <class T>
-__global__ __launch_bounds__(256) void dasp_lcb_reduce_kernel(LcbDev a, T *__restrict__ part0)
+__global__ __launch_bounds__(256) void dasp_lcb_reduce_kernel(LcbDev a, T *__restrict__ part0, int acc)
 {
     using part_t = typename Tr<T>::part_t;
     const int lane = threadIdx.x & 63;
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(256) void dasp_lcb_reduce_kernel(LcbDev a, T *__res
     part_t s = 0;
     for (int c = lane; c < a.n_cb; c += kWave) s += partial[(size_t)c * (size_t)a.n_rows + (size_t)i];
     s = wave_sum(s);
-    if (lane == 0) part0[a.row_dst[i]] = (T)s;
+    if (lane == 0) { const int d = a.row_dst[i]; part0[d] = acc ? (T)((part_t)part0[d] + s) : (T)s; }
 }
 
 #ifdef DASP_STAMPS
@@ -589,10 +590,19 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate
     if (p.two_phase) {
         const TpDev &a = p.dev->tp;
         hipStream_t s = static_cast<hipStream_t>(stream);
+        // the hybrid's hub rows (Plan::lcb): their streaming kernel, then -- BEHIND phase 2, which stores 0 at their positions or leaves y alone in accumulate mode -- their
+        // per-row sums added into y
+        const bool hub = p.lcb.n_rows() > 0;
+        const LcbDev &q = p.dev->lcb;
+        if (hub)
+            hipLaunchKernelGGL((dasp_lcb_kernel<_Float16>), dim3(q.n_units), dim3(1024), (size_t)q.cb * 2 + 16 + (size_t)(kLcbUnitElems / kLcbStep + kLcbUnitPieces) * 8, s, q, static_cast<const _Float16 *>(dX));
         if (a.n_units > 0)
             hipLaunchKernelGGL((dasp_tp_expand_kernel<_Float16>), dim3(a.n_units), dim3(512), (size_t)a.cb * 2, s, a, static_cast<const _Float16 *>(dX));
         if (a.n_rb > 0)
             hipLaunchKernelGGL((dasp_tp_reduce_kernel<_Float16>), dim3(a.n_rb), dim3(512), (size_t)a.rb_max * 8, s, a, static_cast<_Float16 *>(dY), accumulate ? 1 : 0);
+        if (hub) {
+            hipLaunchKernelGGL((dasp_lcb_reduce_kernel<_Float16>), dim3((q.n_rows + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, s, q, static_cast<_Float16 *>(dY), 1);
+        }
         HIP_TRY(hipGetLastError());
         return DASP_OK;
     }
@@ -600,33 +610,26 @@ int launch_spmv(Plan &p, const void *dX, void *dY, void *stream, bool accumulate
         const size_t vb = (size_t)p.geo.vbytes, stride = p.dev->ypart_stride;
         char *part = static_cast<char *>(p.dev->arena);
         hipStream_t s = static_cast<hipStream_t>(stream);
-        // hub rows on the plan's side stream, forked off the caller's stream BEFORE the panels' launch and joined before the sum (r6): x is complete where the fork event
-        // sits, the two kernels write only their own partial sums and the hub rows' slots of panel 0's buffer, which no panel writes
-        const bool side = p.lcb.n_rows() > 0 && p.dev->side_stream != nullptr;
-        hipStream_t hs = side ? static_cast<hipStream_t>(p.dev->side_stream) : s;
+        // the hub rows (Plan::lcb): column blocks of x staged in LDS, their result into panel 0's slots of the partial buffer -- BEHIND the panels' launch on the same
+        // stream: a panel's row tiles store 0 at the positions of rows that are empty in it, the hub rows' too.  (r6, measured and not kept: the two hub kernels on a
+        // stream of the plan's own beside the panels, fork / join by events -- powerlaw_1M f64 375 -> 380 us in back-to-back launches, 369 when captured in a graph;
+        // both kernels are bound by what ONE CU keeps in flight, so CUs given to one are taken from the other: profiles/r06_hub_rows.md)
         auto launch_hub = [&]() {
             const LcbDev &q = p.dev->lcb;
             if (p.precision == 64) {
-                hipLaunchKernelGGL((dasp_lcb_kernel<double>), dim3(q.n_units), dim3(1024), (size_t)q.cb * 8 + 16 + (size_t)(kLcbUnitElems / kLcbStep + kLcbUnitPieces) * 8, hs, q, static_cast<const double *>(dX));
-                hipLaunchKernelGGL((dasp_lcb_reduce_kernel<double>), dim3((q.n_rows + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, hs, q, reinterpret_cast<double *>(part));
+                hipLaunchKernelGGL((dasp_lcb_kernel<double>), dim3(q.n_units), dim3(1024), (size_t)q.cb * 8 + 16 + (size_t)(kLcbUnitElems / kLcbStep + kLcbUnitPieces) * 8, s, q, static_cast<const double *>(dX));
+                hipLaunchKernelGGL((dasp_lcb_reduce_kernel<double>), dim3((q.n_rows + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, s, q, reinterpret_cast<double *>(part), 0);
             } else {
-                hipLaunchKernelGGL((dasp_lcb_kernel<_Float16>), dim3(q.n_units), dim3(1024), (size_t)q.cb * 2 + 16 + (size_t)(kLcbUnitElems / kLcbStep + kLcbUnitPieces) * 8, hs, q, static_cast<const _Float16 *>(dX));
-                hipLaunchKernelGGL((dasp_lcb_reduce_kernel<_Float16>), dim3((q.n_rows + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, hs, q, reinterpret_cast<_Float16 *>(part));
+                hipLaunchKernelGGL((dasp_lcb_kernel<_Float16>), dim3(q.n_units), dim3(1024), (size_t)q.cb * 2 + 16 + (size_t)(kLcbUnitElems / kLcbStep + kLcbUnitPieces) * 8, s, q, static_cast<const _Float16 *>(dX));
+                hipLaunchKernelGGL((dasp_lcb_reduce_kernel<_Float16>), dim3((q.n_rows + kWavesPerWG - 1) / kWavesPerWG), dim3(256), 0, s, q, reinterpret_cast<_Float16 *>(part), 0);
             }
         };
-        if (side) {
-            HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(p.dev->ev_fork), s));
-            HIP_TRY(hipStreamWaitEvent(hs, static_cast<hipEvent_t>(p.dev->ev_fork), 0));
-            launch_hub();
-            HIP_TRY(hipEventRecord(static_cast<hipEvent_t>(p.dev->ev_join), hs));
-        }
         if (int rc = launch_panels_merged(p, dX, part, stride * vb, s)) {
             if (rc != 1) return rc;          // 1: the panels do not share one kernel instantiation -- one launch (+ stage 2) per panel, as before r5
             for (size_t k = 0; k < p.panels.size(); ++k)
                 if (int rc2 = launch_spmv(p.panels[k]->impl, dX, part + k * stride * vb, stream, false)) return rc2;
         }
-        if (side) HIP_TRY(hipStreamWaitEvent(s, static_cast<hipEvent_t>(p.dev->ev_join), 0));
-        else if (p.lcb.n_rows() > 0) launch_hub();      // one stream: the hub rows behind the panels (column blocks of x staged in LDS, their result into panel 0's otherwise unwritten slots)
+        if (p.lcb.n_rows() > 0) launch_hub();
         const int np = (int)p.panels.size(), m = p.m;
         const bool wide = (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
         if (m > 0) {

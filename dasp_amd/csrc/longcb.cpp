@@ -18,7 +18,9 @@ int lcb_col_block(const Plan &p) { return p.precision == 64 ? 16384 : 32768; }  
 
 // rows of >= h nonzeros, h = max(block_longest, 64 per column block): a piece then averages a wave's worth of elements per step.  Auto: when those rows hold
 // at least a quarter of the nonzeros (powerlaw_1M f64: 2565 rows of >= 4096 hold 68 %); 1 forces (h = block_longest), -1 turns it off.
-int decide_long_cb(const Plan &p, const int *rp, int P, std::vector<unsigned char> &in_lcb)
+// share_den: the automatic rule asks for >= 1 / share_den of the nonzeros in those rows (column panels: a quarter; the two-phase hybrid: a sixteenth -- there a hub row is
+// not only gathers saved but thousands of additions to ONE LDS word taken out of phase 2)
+int decide_long_cb(const Plan &p, const int *rp, int P, std::vector<unsigned char> &in_lcb, int share_den)
 {
     in_lcb.clear();
     if (p.opt.long_cb < 0 || P < 2 || p.opt.n_parts > 0 || !p.dst_map.empty() || p.m <= 0) return 0;
@@ -28,7 +30,7 @@ int decide_long_cb(const Plan &p, const int *rp, int P, std::vector<unsigned cha
     for (int i = 0; i < p.m; ++i) { const int len = rp[i + 1] - rp[i]; if (len >= h) { nnz_l += len; ++rows; } }
     if (rows == 0 || (long long)rows * n_cb >= (1ll << 27)) return 0;
     if (nnz_l >= (long long)p.nnz) return 0;      // nothing would be left for the panels (every panel empty = no panel plan at all): such a matrix is the long-row kernel's
-    if (p.opt.long_cb == 0 && nnz_l * 4 < (long long)p.nnz) return 0;
+    if (p.opt.long_cb == 0 && nnz_l * share_den < (long long)p.nnz) return 0;
     in_lcb.assign((size_t)p.m, 0);
     for (int i = 0; i < p.m; ++i) if (rp[i + 1] - rp[i] >= h) in_lcb[(size_t)i] = 1;
     return rows;
@@ -100,7 +102,7 @@ bool validate_long_cb(const Plan &p, int n_panels, std::string &why)
     const LongCB &L = p.lcb;
     const int nL = L.n_rows();
     if (nL == 0) return L.ptr.empty() && L.unit.empty() && L.lcol.empty() && L.val.empty() && L.row_id.empty() ? true : fail("long_cb arrays without rows");
-    if (n_panels < 1 || p.opt.n_parts > 0) return fail("long_cb outside a column-panel plan");
+    if ((n_panels < 1 && !p.two_phase) || p.opt.n_parts > 0) return fail("long_cb outside a column-panel or two-phase plan");
     const int vb = p.geo.vbytes, A = kLcbStep;
     if (L.cb < 8 || L.cb % 8 || L.cb > 65528 || L.n_cb != std::max(1, (p.n + L.cb - 1) / L.cb)) return fail("long_cb column blocks");
     // the kernel's dynamic LDS: the block's slice of x + 16 + one sum per step and piece of a unit (kernels.hip launch_spmv) -- all of it inside the 160 KiB the attribute allows

@@ -311,13 +311,38 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             // the two-phase (gather-free) form: order_rid and the classifier counters of the whole matrix (row lengths only), then the tile streams
             if (int rc = build_impl<T>(p, rp, ci, val, nullptr, kMetaOnly)) return rc;
             lap("whole-matrix meta");
+            // the hybrid (r6): hub rows -- the rule of the column-blocked long rows, decide_long_cb -- leave the two-phase streams for
+            // Plan::lcb (x staged in LDS per column block, no atomics on one LDS word per hub row); everything else stays two-phase
+            auto hybrid_then_tp = [&](const int *hci, const T *hval) -> int {
+                std::vector<unsigned char> in_lcb;
+                p.lcb = LongCB{};
+                if (decide_long_cb(p, rp, 2, in_lcb, 16) > 0) {
+                    std::vector<int> slot_of_row;
+                    const bool natural = p.opt.y_order == DASP_Y_NATURAL;
+                    if (!natural) { slot_of_row.resize((size_t)m); for (int i = 0; i < m; ++i) slot_of_row[(size_t)p.order[(size_t)i]] = i; }
+                    const int rc_l = build_long_cb(p, rp, hci, hval, in_lcb, natural ? nullptr : slot_of_row.data());
+                    if (rc_l == 1) in_lcb.clear();
+                    else if (rc_l) return rc_l;
+                    lap("hub rows by column block");
+                }
+                const int rc_t = build_two_phase(p, rp, hci, hval, in_lcb.empty() ? nullptr : in_lcb.data());
+                if (rc_t != DASP_OK) { p.lcb = LongCB{}; return rc_t; }
+                if (!in_lcb.empty()) {
+                    const LongCB &L = p.lcb;
+                    dasp_stats_t &s = p.stats;
+                    s.lcb_rows = L.n_rows(); s.lcb_elems = (long long)L.elems; s.lcb_col_block = L.cb; s.lcb_units = L.n_units();
+                    s.n_workgroups += L.n_units() + ceil_div(L.n_rows(), kWavesPerWG);
+                    s.data_X += (long long)L.elems * (geo.vbytes + 2) + (long long)L.n_units() * (long long)std::min(L.cb, p.n) * geo.vbytes;
+                }
+                return DASP_OK;
+            };
             int rc2;
-            if (!dev) { rc2 = build_two_phase(p, rp, ci, val); lap("two-phase streams"); if (rc2 != kTpDeclined) return rc2; }
+            if (!dev) { rc2 = hybrid_then_tp(ci, val); lap("two-phase streams"); if (rc2 != kTpDeclined) return rc2; }
             else {
                 raw_vector<int> hci((size_t)nnz);
                 raw_vector<T> hval((size_t)nnz);
                 if (int rc = devpack_fetch_csr(p, *dev, hci.data(), hval.data())) return rc;
-                rc2 = build_two_phase(p, rp, hci.data(), hval.data());
+                rc2 = hybrid_then_tp(hci.data(), hval.data());
                 lap("two-phase streams (device CSR fetched)");
                 if (rc2 == DASP_OK) return devpack_finish_panels(p);       // a device-built plan comes back uploaded
                 if (rc2 != kTpDeclined) return rc2;

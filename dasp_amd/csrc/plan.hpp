@@ -388,11 +388,11 @@ inline int win_fold_tiles(int n_windows, int n_short_tiles)
     return n_windows > 0 && n_windows <= 512 && n_short_tiles > 0 && n_short_tiles <= 2 * n_windows ? (n_short_tiles + n_windows - 1) / n_windows : 0;
 }
 constexpr int kTpDeclined = 1;          // build_two_phase under the automatic rule: the padded streams would pass 1.5 x the nonzeros (or the tile table 64 M entries) -- not an error
-int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val);
+int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val, const unsigned char *skip = nullptr);
 bool validate_two_phase(const Plan &p, std::string &why);
 
 // column-blocked long rows (longcb.cpp): which rows (in_lcb[row] = 1) a column-panel plan of P panels hands to them (0 rows: none), the packer, the checks
-int decide_long_cb(const Plan &p, const int *rp, int P, std::vector<unsigned char> &in_lcb);
+int decide_long_cb(const Plan &p, const int *rp, int P, std::vector<unsigned char> &in_lcb, int share_den = 4);
 int build_long_cb(Plan &p, const int *rp, const int *ci, const void *val, const std::vector<unsigned char> &in_lcb, const int *slot_of_row);      // DASP_OK, an error, or 1: not representable (p.lcb left empty)
 bool validate_long_cb(const Plan &p, int n_panels, std::string &why);
 

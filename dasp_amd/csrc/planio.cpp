@@ -94,7 +94,13 @@ static bool validate_plan(const Plan &p, int n_panels, bool is_panel, std::strin
     if (p.two_phase) {    // order + stats + the tile streams (twophase.cpp)
         if (n_panels > 0 || is_panel) return fail("two-phase plan with column panels");
         if (p.cnt_long || p.cnt_reg || p.cnt_irr || p.cnt_short || p.cnt_rt || !p.med_ptr.empty() || !p.irr_ptr.empty() || !p.piece_ptr.empty()) return fail("two-phase plan holds packed DASP arrays");
-        return validate_two_phase(p, why);
+        if (!validate_two_phase(p, why)) return false;
+        if (!validate_long_cb(p, 0, why)) return false;          // the hybrid's hub rows (none: empty arrays)
+        long long have = 0;                                       // every nonzero once: in a tile stream or in the column-blocked hub rows
+        for (uint16_t r : p.tp.lrow) have += r != kTpPadRow;
+        for (uint16_t c : p.lcb.lcol) have += c != kLcbPadCol;
+        if (have != p.nnz) return fail("the two-phase streams and the column-blocked hub rows do not add up to nnzA");
+        return true;
     }
     if (!p.tp.dst.empty() || !p.tp.lcol.empty() || !p.tp.lrow.empty() || !p.tp.val.empty() || !p.tp.unit.empty() || !p.tp.rb_row0.empty() || !p.tp.rb_seg0.empty()) return fail("two-phase streams in a plan that is not two-phase");
     if (n_panels == 0 && (p.lcb.n_rows() > 0 || !p.lcb.ptr.empty() || !p.lcb.lcol.empty() || !p.lcb.val.empty() || !p.lcb.unit.empty() || !p.lcb.row_id.empty())) return fail("column-blocked long rows outside a column-panel plan");

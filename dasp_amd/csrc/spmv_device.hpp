@@ -986,9 +986,11 @@ constexpr int kMinWavesPlain = DASP_MIN_WAVES, kMinWavesWin = 8;
 // WIN: windowed mode.  A medium workgroup owns one window of row_window rows (blocks_per_win blocks, strided over its
 // 4 waves); if the window's x span fits, it is copied once into LDS with coalesced 16-byte loads and every gather of
 // the window reads LDS; otherwise that workgroup gathers from global memory like the non-windowed kernel.
+// the 64-register build's pipeline batch / longest one-shot unit (r6, same box, cop20k_A x4 / x16 / x64 f64): (4, 8) -- the other kernels' values, 12-29 spilled VGPRs --
+// 26.75 / 114.1 / 438.0 us; (2, 8) 26.2 / 104.7 / 416.9; (3, 6) 26.9 / 103.1 / 412.9: no scratch from (3, x) down
 #ifndef DASP_WIN64_U
-#define DASP_WIN64_U 4
-#define DASP_WIN64_S 8
+#define DASP_WIN64_U 3
+#define DASP_WIN64_S 6
 #endif
 // W64: the windowed build held to 64 registers (two window workgroups per CU)
 template <class T, bool NT, bool C16, bool WIN, bool C8, bool RT = false, bool W64 = false>

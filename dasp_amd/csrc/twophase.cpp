@@ -45,8 +45,11 @@ int decide_two_phase(const Plan &p, const int *rp, int scattered)
     return scattered ? 1 : 0;
 }
 
-int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val)
+int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val, const unsigned char *skip)
 {
+    // skip[row] != 0 (r6, the f16 hybrid): the row's nonzeros are not this form's -- the hub rows of a plan whose Plan::lcb holds them column-blocked; the row keeps its
+    // output position and gets y = 0 from phase 2 (dasp_lcb_reduce_kernel stores / adds its sum behind it)
+    auto len_of = [&](int r) { return skip && skip[r] ? 0 : rp[r + 1] - rp[r]; };
     using clk = std::chrono::steady_clock;
     const auto t_begin = clk::now();
     if (p.precision != 16) { set_error("two_phase: f16 plans only"); return DASP_ERR_ARG; }
@@ -87,7 +90,7 @@ int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val)
         long long acc = 0; int rows = 0;
         for (int pos = 0; pos < m; ++pos) {
             const int r = row_at(pos);
-            const int len = rp[r + 1] - rp[r];
+            const int len = len_of(r);
             if (rows > 0 && (rows >= rbm || acc + len > target)) { t.rb_row0.push_back(pos); acc = 0; rows = 0; }
             acc += len; ++rows;
         }
@@ -99,6 +102,8 @@ int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val)
     // n_rb * n_cb * 20 bytes of tables on the host.  Declined (kTpDeclined: build_impl goes on to column panels / the plain plan) when the padded streams pass 1.5 x the
     // nonzeros or the tile table passes 64 M entries; a forced two_phase = 1 is built as asked.
     const bool may_decline = p.opt.two_phase == 0;
+    long long nnz_here = 0;
+    for (int r = 0; r < m; ++r) nnz_here += len_of(r);
     if (may_decline && (long long)n_rb * (long long)n_cb > (1ll << 26)) { t = TwoPhase{}; return kTpDeclined; }
     // ---- nonzeros per tile
     std::vector<int> cnt((size_t)n_rb * (size_t)n_cb, 0);
@@ -106,7 +111,7 @@ int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val)
         int *c = cnt.data() + (size_t)b * (size_t)n_cb;
         for (int pos = t.rb_row0[(size_t)b]; pos < t.rb_row0[(size_t)b + 1]; ++pos) {
             const int r = row_at(pos);
-            for (int j = rp[r]; j < rp[r + 1]; ++j) c[ci[j] / cb]++;
+            for (int j = rp[r], je = rp[r] + len_of(r); j < je; ++j) c[ci[j] / cb]++;
         }
     });
     // ---- segment offsets: off2 = RB-major (row block, then column block), off1 = CB-major (column block, then row block)
@@ -120,7 +125,7 @@ int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val)
         for (int c = 0; c < n_cb; ++c)
             for (int b = 0; b < n_rb; ++b) { const size_t i = (size_t)b * (size_t)n_cb + (size_t)c; off1[i] = run1; run1 += segs_of(i); }
         if (run != run1) { set_error("two_phase: internal offset mismatch"); return DASP_ERR_STATE; }
-        if (may_decline && run * kTpSeg > nnz + nnz / 2) { t = TwoPhase{}; return kTpDeclined; }
+        if (may_decline && run * kTpSeg > nnz_here + nnz_here / 2) { t = TwoPhase{}; return kTpDeclined; }
         if (run >= (1ll << 31) / 2) { set_error("two_phase: too many segments for 32-bit segment indices"); return DASP_ERR_ARG; }
         t.segments = (size_t)run;
     }
@@ -138,7 +143,7 @@ int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val)
         const int pos0 = t.rb_row0[(size_t)b];
         for (int pos = pos0; pos < t.rb_row0[(size_t)b + 1]; ++pos) {
             const int r = row_at(pos);
-            for (int j = rp[r]; j < rp[r + 1]; ++j) {
+            for (int j = rp[r], je = rp[r] + len_of(r); j < je; ++j) {
                 const int c = ci[j] / cb, k = cur[(size_t)c]++;
                 const size_t e2 = (size_t)off2[base + (size_t)c] * kTpSeg + (size_t)k, e1 = (size_t)off1[base + (size_t)c] * kTpSeg + (size_t)k;
                 t.lrow[e2] = (uint16_t)(pos - pos0);
@@ -171,7 +176,7 @@ int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val)
     s.n_workgroups = t.n_units() + n_rb;
     s.x_window_on = s.n_windows = s.n_windows_lds = s.lds_bytes = s.row_window = s.cid16_on = s.x_window_hybrid = s.chunk_pairs = s.cid8_chunks = 0;
     s.med_rows_as_pieces = s.short_seg = s.row_tile_max = s.n_row_tiles = 0; s.row_tile_nnz = 0; s.n_col_panels = 0; s.window_nnz_frac = 0.0;
-    s.rate_fill0 = nnz > 0 ? (double)((long long)S * kTpSeg - nnz) / (double)nnz : 0.0;
+    s.rate_fill0 = nnz > 0 ? (double)((long long)S * kTpSeg + (long long)p.lcb.elems - nnz) / (double)nnz : 0.0;
     // streamed per SpMV: local columns + xs written (phase 1), values + local rows + xs read (phase 2), the segment map, every unit's slice of x, y
     s.data_X = (long long)S * kTpSeg * (2 + vb + vb + 2 + vb) + (long long)S * 4 + (long long)t.n_units() * (long long)std::min(cb, n) * vb + (long long)m * vb;
     s.two_phase = 1; s.tp_col_block = cb; s.tp_row_blocks = n_rb; s.tp_units = t.n_units(); s.tp_segments = (long long)S; s.tp_seg_elems = kTpSeg;

@@ -27,18 +27,9 @@ namespace dasp {
         }                                                                                      \
     } while (0)
 
-static void release_side_stream(DevicePlan *d)
-{
-    if (d->ev_fork) (void)hipEventDestroy(static_cast<hipEvent_t>(d->ev_fork));
-    if (d->ev_join) (void)hipEventDestroy(static_cast<hipEvent_t>(d->ev_join));
-    if (d->side_stream) (void)hipStreamDestroy(static_cast<hipStream_t>(d->side_stream));
-    d->ev_fork = d->ev_join = d->side_stream = nullptr;
-}
-
 Plan::~Plan()
 {
     if (dev) {
-        release_side_stream(dev);
         if (dev->arena) (void)hipFree(dev->arena);
         if (dev->dargs) (void)hipFree(dev->dargs);
         std::free(dev->args_sent);
@@ -69,13 +60,43 @@ int sync_dev_args(Plan &p)
     return DASP_OK;
 }
 
+// column-blocked long rows (Plan::lcb) of a column-panel parent or of a two-phase plan (the f16 hybrid): where their arrays sit in the plan's arena, the copies, the device
+// view
+struct LcbOffsets { size_t v = 0, c = 0, p = 0, u = 0, d = 0, s = 0; };
+template <class Place>
+static LcbOffsets place_long_cb(const LongCB &L, size_t vbytes, Place &&place)
+{
+    LcbOffsets o;
+    o.v = place(L.elems * vbytes); o.c = place(L.elems * 2); o.p = place(L.ptr.size() * 4); o.u = place(L.unit.size() * 4);
+    o.d = place(L.row_dst.size() * 4); o.s = place((size_t)L.n_cb * (size_t)L.n_rows() * 8);
+    return o;
+}
+static int upload_long_cb(Plan &p, DevicePlan *d, const LcbOffsets &o)
+{
+    const LongCB &L = p.lcb;
+    const size_t vbytes = (size_t)p.geo.vbytes;
+    char *base = static_cast<char *>(d->arena);
+    HIP_TRY(hipMemcpy(base + o.v, L.val.data(), L.elems * vbytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + o.c, L.lcol.data(), L.elems * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + o.p, L.ptr.data(), L.ptr.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + o.u, L.unit.data(), L.unit.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(base + o.d, L.row_dst.data(), L.row_dst.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(base + o.s, 0, std::max<size_t>((size_t)L.n_cb * (size_t)L.n_rows() * 8, 16)));      // empty (row, block) pieces never write their partial sum
+    LcbDev &q = d->lcb;
+    q.val = base + o.v; q.lcol = (const unsigned short *)(base + o.c); q.ptr = (const int *)(base + o.p); q.unit = (const int *)(base + o.u);
+    q.row_dst = (const int *)(base + o.d); q.partial = base + o.s;
+    q.n_units = L.n_units(); q.n_rows = L.n_rows(); q.n_cb = L.n_cb; q.cb = L.cb; q.xlen = p.n;
+    if (int rc = tp_kernels_allow_lds()) return rc;
+    return DASP_OK;
+}
+
 int upload_plan(Plan &p);
 static int upload_plan_impl(Plan &p)
 {
     if (int rc = require_device()) return rc;
     if (p.host_dropped && p.dev) return DASP_OK;   // already on the device (packed there, or host copies released)
     if (p.host_dropped) { set_error("host arrays were dropped"); return DASP_ERR_STATE; }
-    if (p.dev) { release_side_stream(p.dev); if (p.dev->arena) (void)hipFree(p.dev->arena); if (p.dev->dargs) (void)hipFree(p.dev->dargs); std::free(p.dev->args_sent); delete p.dev; p.dev = nullptr; }
+    if (p.dev) { if (p.dev->arena) (void)hipFree(p.dev->arena); if (p.dev->dargs) (void)hipFree(p.dev->dargs); std::free(p.dev->args_sent); delete p.dev; p.dev = nullptr; }
     auto *d = new DevicePlan();
     p.dev = d;
     HIP_TRY(hipGetDevice(&d->device));
@@ -89,34 +110,12 @@ static int upload_plan_impl(Plan &p)
         size_t total = (part_bytes + 255) & ~size_t(255);
         auto place = [&](size_t bytes) { const size_t off = total; total += (std::max<size_t>(bytes, 16) + 255) & ~size_t(255); return off; };
         const bool lcb = L.n_rows() > 0;
-        const size_t o_v = lcb ? place(L.elems * vbytes) : 0, o_c = lcb ? place(L.elems * 2) : 0, o_p = lcb ? place(L.ptr.size() * 4) : 0, o_u = lcb ? place(L.unit.size() * 4) : 0,
-                     o_d = lcb ? place(L.row_dst.size() * 4) : 0, o_s = lcb ? place((size_t)L.n_cb * (size_t)L.n_rows() * 8) : 0;
+        LcbOffsets lo;
+        if (lcb) lo = place_long_cb(L, vbytes, place);
         d->arena_bytes = total;
         HIP_TRY(hipMalloc(&d->arena, d->arena_bytes));
         HIP_TRY(hipMemset(d->arena, 0, d->arena_bytes));      // the panels never store the rows that are empty in them (DevArgs::skip0); empty (row, block) pieces never write their partial sum
-        if (lcb) {
-            char *base = static_cast<char *>(d->arena);
-            HIP_TRY(hipMemcpy(base + o_v, L.val.data(), L.elems * vbytes, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(base + o_c, L.lcol.data(), L.elems * 2, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(base + o_p, L.ptr.data(), L.ptr.size() * 4, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(base + o_u, L.unit.data(), L.unit.size() * 4, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(base + o_d, L.row_dst.data(), L.row_dst.size() * 4, hipMemcpyHostToDevice));
-            LcbDev &q = d->lcb;
-            q.val = base + o_v; q.lcol = (const unsigned short *)(base + o_c); q.ptr = (const int *)(base + o_p); q.unit = (const int *)(base + o_u);
-            q.row_dst = (const int *)(base + o_d); q.partial = base + o_s;
-            q.n_units = L.n_units(); q.n_rows = L.n_rows(); q.n_cb = L.n_cb; q.cb = L.cb; q.xlen = p.n;
-            if (int rc = tp_kernels_allow_lds()) return rc;
-            // the hub rows' own stream (a failure here leaves the plan on one stream)
-            const char *e = std::getenv("DASP_LCB_SIDE_STREAM");      // A/B knob: 0 = the hub rows behind the panels on the caller's stream, as in r5
-            if (!(e && std::atoi(e) == 0)) {
-                hipStream_t ss = nullptr; hipEvent_t ef = nullptr, ej = nullptr;
-                int lo = 0, hi = 0;
-                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // (hi = the numerically lowest = highest priority: the few 1024-thread workgroups get their CUs as the panels' first ones end)
-                if (hipStreamCreateWithPriority(&ss, hipStreamNonBlocking, hi) == hipSuccess && hipEventCreateWithFlags(&ef, hipEventDisableTiming) == hipSuccess &&
-                    hipEventCreateWithFlags(&ej, hipEventDisableTiming) == hipSuccess) { d->side_stream = ss; d->ev_fork = ef; d->ev_join = ej; }
-                else { if (ef) (void)hipEventDestroy(ef); if (ej) (void)hipEventDestroy(ej); if (ss) (void)hipStreamDestroy(ss); (void)hipGetLastError(); }
-            }
-        }
+        if (lcb) if (int rc = upload_long_cb(p, d, lo)) return rc;
         return DASP_OK;
     }
 
@@ -131,6 +130,9 @@ static int upload_plan_impl(Plan &p)
         const size_t o_lc = add(t.lcol.data(), S * kTpSeg * 2), o_dst = add(t.dst.data(), S * 4), o_un = add(t.unit.data(), t.unit.size() * 4);
         const size_t o_v = add(t.val.data(), S * kTpSeg * vbytes), o_lr = add(t.lrow.data(), S * kTpSeg * 2), o_xs = add(nullptr, S * kTpSeg * vbytes);
         const size_t o_r0 = add(t.rb_row0.data(), t.rb_row0.size() * 4), o_s0 = add(t.rb_seg0.data(), t.rb_seg0.size() * 4);
+        const bool lcb = p.lcb.n_rows() > 0;          // the hybrid: hub rows column-blocked beside the streams
+        LcbOffsets lo;
+        if (lcb) lo = place_long_cb(p.lcb, vbytes, [&](size_t bytes) { return add(nullptr, bytes); });
         HIP_TRY(hipMalloc(&d->arena, total));
         d->arena_bytes = total;
         char *base = static_cast<char *>(d->arena);
@@ -143,6 +145,7 @@ static int upload_plan_impl(Plan &p)
         q.rb_row0 = (const int *)(base + o_r0); q.rb_seg0 = (const int *)(base + o_s0);
         q.n_units = t.n_units(); q.n_rb = t.n_rb(); q.cb = t.cb; q.rb_max = t.rb_max; q.xlen = p.n; q.m = p.m;
         d->nt = true;
+        if (lcb) if (int rc = upload_long_cb(p, d, lo)) return rc;
         return tp_kernels_allow_lds();
     }
 

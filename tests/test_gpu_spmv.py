@@ -1702,6 +1702,36 @@ def test_two_phase_edges(oracle, dasp, torch_cuda, lens):
     check(oracle, dasp, torch_cuda, rp, ci, v, 30011, 16, two_phase=1, tp_col_block=8, tp_row_block=1)
 
 
+def test_two_phase_hybrid_hub_rows(oracle, dasp, torch_cuda):
+    """r6: hub rows of a two-phase plan column-blocked (dasp_lcb_kernel<half>; dasp_lcb_reduce_kernel adds their sums into y behind phase 2),
+    everything else two-phase: parity in both y orders and the all-ones mode, y += A x, replay from a graph"""
+    torch = torch_cuda
+    lens = [7] * 5000 + [40000, 33000, 9000, 300, 0, 2] + [1] * 100
+    n = 140000                                                       # five column blocks of 32768: hub rows are those of >= 320 nonzeros
+    rp, ci, v = util.csr_from_lengths(lens, n, 23, values="f16")
+    st = dasp.Plan(rp, ci, v.astype(np.float16), n, precision=16, two_phase=1).stats
+    assert st["two_phase"] == 1 and st["lcb_rows"] == 3 and st["lcb_col_block"] == 32768
+    check(oracle, dasp, torch, rp, ci, v, n, 16, two_phase=1)
+    check(oracle, dasp, torch, rp, ci, v, n, 16, two_phase=1, tp_col_block=4096, tp_row_block=64, long_cb=1)      # forced: every row of >= 256
+    v16 = v.astype(np.float16)
+    xh = np.random.default_rng(5).uniform(0.5, 1.5, n).astype(np.float16)
+    ref = oracle.csr_spmv(rp, ci, v16.astype(np.float64), xh.astype(np.float64))
+    scale = np.maximum(oracle.csr_absrow(rp, ci, v16.astype(np.float64), xh.astype(np.float64)), 1e-300)
+    m = len(lens)
+    plan = dasp.Plan(rp, ci, v16, n, precision=16, two_phase=1, y_order=dasp.Y_NATURAL).upload()
+    x = torch.from_numpy(xh).cuda()
+    y = torch.full((m,), 2.0, dtype=torch.float16, device="cuda")
+    plan.spmv(x.data_ptr(), y.data_ptr(), 0, accumulate=True)
+    torch.cuda.synchronize()
+    assert (np.abs(y.double().cpu().numpy() - 2.0 - ref) <= 1e-2 * np.maximum(scale, 2.0)).all()
+    a = run_spmv(torch, plan, xh, m, 16)
+    # captured into a graph and replayed: the hub rows' sums are deterministic (no atomics on their path)
+    wall, ev = plan.time_graph(x.data_ptr(), y.data_ptr(), 0, warmup=2, iters=6, batch=3)
+    torch.cuda.synchronize()
+    assert ev > 0 and np.array_equal(y.double().cpu().numpy()[[5000, 5001, 5002]], a[[5000, 5001, 5002]])
+    plan.close()
+
+
 def test_two_phase_empty_accumulate_and_unaligned_x(oracle, dasp, torch_cuda):
     torch = torch_cuda
     # no rows / no nonzeros: nothing to launch, y = 0
@@ -1810,4 +1840,15 @@ def test_column_blocked_long_rows_accumulate_device_csr_and_determinism(oracle, 
     host.spmv(x.data_ptr(), y.data_ptr(), 0, accumulate=True)                         # y += A x
     torch.cuda.synchronize()
     assert (np.abs(y.cpu().numpy() - 3.0 - ref) <= 1e-12 * np.maximum(scale, 3.0)).all()
+    # captured into a graph and replayed, and on another stream of the caller's: the same bits
+    wall, ev = host.time_graph(x.data_ptr(), y.data_ptr(), 0, warmup=2, iters=6, batch=3)
+    torch.cuda.synchronize()
+    assert ev > 0 and np.array_equal(y.cpu().numpy(), y_host)
+    s2 = torch.cuda.Stream()
+    y.fill_(float("nan"))
+    torch.cuda.synchronize()
+    for _ in range(3):
+        host.spmv(x.data_ptr(), y.data_ptr(), s2.cuda_stream)
+    s2.synchronize()
+    assert np.array_equal(y.cpu().numpy(), y_host)
     host.close(); dev.close()

