@@ -202,7 +202,7 @@ class Plan:
         n = _lib.lib().dasp_plan_host_array(self._h, name.encode(), C.byref(ptr), C.byref(eb))
         if n < 0:
             _lib.check(int(n))
-        if name in ("med_cid16", "rt_start", "tp_lrow", "tp_lcol", "lcb_lcol"):
+        if name in ("med_cid16", "long_cid16", "rt_start", "tp_lrow", "tp_lcol", "lcb_lcol"):
             dt = np.uint16
         elif name == "rt_mask":
             dt = np.uint64

@@ -222,7 +222,7 @@ static long long host_array_impl(const dasp_plan_t *plan, const char *name, cons
     const Plan &p = plan->impl;
     // the nnz-sized arrays exist on the host only until dasp_plan_drop_host (never, for a plan packed on the device);
     // the O(rows) arrays and order_rid always do
-    static const char *const kBulk[] = {"long_val", "long_cid", "med_val", "med_cid", "med_cid16", "med_cid8", "irr_val", "irr_cid", "short_val", "short_cid", "rt_val", "rt_cid",
+    static const char *const kBulk[] = {"long_val", "long_cid", "long_cid16", "med_val", "med_cid", "med_cid16", "med_cid8", "irr_val", "irr_cid", "short_val", "short_cid", "rt_val", "rt_cid",
                                         "tp_val", "tp_lrow", "tp_lcol", "tp_dst", "lcb_val", "lcb_lcol"};
     if (p.host_dropped)
         for (const char *b : kBulk)
@@ -236,6 +236,12 @@ static long long host_array_impl(const dasp_plan_t *plan, const char *name, cons
     if (n == "dst_map") return ints(p.dst_map);
     if (n == "long_val") return vals(p.long_val);
     if (n == "long_cid") return rints(p.long_cid);
+    if (n == "long_cid16") { *ptr = p.long_cid16.data(); *elem_bytes = 2; return (long long)p.long_cid16.size(); }
+    if (n == "long_base") {
+        if (p.long_base.empty() && p.cnt_long_chunks > 0) { set_error("long_base lives on the device only (use dasp_plan_download_array)"); return DASP_ERR_STATE; }
+        return ints(p.long_base);
+    }
+    if (n == "piece_c16") return ints(p.piece_c16);
     if (n == "piece_ptr") return ints(p.piece_ptr);
     if (n == "piece_dst") return ints(p.piece_dst);
     if (n == "multi_ptr") return ints(p.multi_ptr);
@@ -312,7 +318,7 @@ int dasp_plan_drop_host(dasp_plan_t *plan)
     if (!p.dev) { set_error("upload the plan before dropping its host arrays"); return DASP_ERR_STATE; }
     auto dropc = [](raw_vector<char> &v) { raw_vector<char>().swap(v); };
     auto dropi = [](raw_vector<int> &v) { raw_vector<int>().swap(v); };
-    dropc(p.long_val); dropi(p.long_cid); dropc(p.med_val); dropi(p.med_cid); raw_vector<uint16_t>().swap(p.med_cid16); raw_vector<uint8_t>().swap(p.med_cid8);
+    dropc(p.long_val); dropi(p.long_cid); raw_vector<uint16_t>().swap(p.long_cid16); dropc(p.med_val); dropi(p.med_cid); raw_vector<uint16_t>().swap(p.med_cid16); raw_vector<uint8_t>().swap(p.med_cid8);
     dropc(p.irr_val); dropi(p.irr_cid); dropc(p.short_val); dropi(p.short_cid); dropc(p.rt_val); dropi(p.rt_cid);
     dropc(p.lcb.val); raw_vector<uint16_t>().swap(p.lcb.lcol);
     dropc(p.tp.val); raw_vector<uint16_t>().swap(p.tp.lrow); raw_vector<uint16_t>().swap(p.tp.lcol); std::vector<int>().swap(p.tp.dst);

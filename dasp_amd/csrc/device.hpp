@@ -60,6 +60,8 @@ struct DevArgs {
     const void *rt_val; const int *rt_cid; const int *rt_ptr; const unsigned short *rt_start; const unsigned long long *rt_mask;
     int n_rt_tiles, wg_rt, rt_max;
     // (r6; last, so that every older field keeps its offset: the multi-GPU step kernels take this block by value and their code depends on its layout)
+    const unsigned short *long_cid16; const int *long_base; const int *piece_c16;      // 16-bit ids of the narrow long pieces (plan.hpp long_cid16)
+    int wg_rot;       // workgroup b of the launch serves virtual workgroup (b + wg_rot) mod grid of the [long | medium | short] ranges (upload_plan: which category is dispatched first)
     int win_tiles;    // short tiles folded into every window workgroup (upload_plan): workgroup w also serves tiles w, w + n_windows, ... ; 0: the short tiles keep workgroups of their own
 };
 
@@ -81,7 +83,7 @@ struct LcbDev {
 // byte offsets of the nnz-sized arrays inside the arena (devpack.hip writes them, tests download them)
 struct ArenaMap {
     size_t long_val = 0, long_cid = 0, med_val = 0, med_cid = 0, med_cid16 = 0, med_cid8 = 0, med_base = 0, irr_val = 0, irr_cid = 0,
-           short_val = 0, short_cid = 0, rt_val = 0, rt_cid = 0;
+           short_val = 0, short_cid = 0, rt_val = 0, rt_cid = 0, long_cid16 = 0, long_base = 0, piece_c16 = 0;
 };
 
 struct DevicePlan {

@@ -134,6 +134,28 @@ __global__ void k_pack_long(const int *rp, const int *ci, const T *val, const in
     }
 }
 
+// 16-bit ids of the long pieces (plan.hpp long_cid16; the host packer's rule, plan.cpp): one wave per piece over its chunks of CH elements -- the chunk's smallest column is
+// its base; a piece all of whose chunks span <= 65534 columns is narrow and keeps u16 offsets (0xFFFF = pad), a wide piece's u16 ids are 0
+__global__ void k_long_cid16(const int *lc, const int *piece_ptr, int *piece_c16, int np, int CH, int *lbase, unsigned short *lc16)
+{
+    const int lane = threadIdx.x & 63, q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= np) return;
+    const int e0 = piece_ptr[q], e1 = piece_ptr[q + 1], c0 = piece_c16[2 * q];
+    bool narrow = true;
+    for (int e = e0, c = c0; e < e1; e += CH, ++c) {
+        int lo = 2147483647, hi = -1;
+        for (int j = e + lane; j < min(e + CH, e1); j += 64) { const int col = lc[j]; if (col >= 0) { lo = min(lo, col); hi = max(hi, col); } }
+        for (int d = 32; d > 0; d >>= 1) { lo = min(lo, __shfl_xor(lo, d)); hi = max(hi, __shfl_xor(hi, d)); }
+        const int b = hi < 0 ? 0 : lo;
+        if (lane == 0) lbase[c] = b;
+        if (hi >= 0 && (long long)hi - lo > 65534) narrow = false;
+        for (int j = e + lane; j < min(e + CH, e1); j += 64) { const int col = lc[j]; lc16[j] = col < 0 ? kLongPad16 : (unsigned short)(col - b); }      // (garbage where the chunk is wide: zeroed below)
+    }
+    narrow = narrow && e1 - e0 >= kLong16MinChunks * CH;
+    if (lane == 0) piece_c16[2 * q + 1] = narrow ? 1 : 0;
+    if (!narrow) for (int j = e0 + lane; j < e1; j += 64) lc16[j] = 0;
+}
+
 // one wave per medium block: regular chunks in lane-linear order (+ per-chunk base and u16 offsets in cid16 mode), then tails
 template <class T, bool C16>
 __global__ void k_pack_medium(const int *rp, const int *ci, const T *val, const int *ridM, const int *lenM, const int *med_ptr,
@@ -363,6 +385,14 @@ static int pack_all_typed(Plan &p, const DevCsr &d, const PackMeta &m)
         hipLaunchKernelGGL((k_pack_long<T>), dim3(waves_grid(nlong)), dim3(256), 0, 0, d.rp, d.ci, val, dr.d, ds.d, nlong, rm.r,
                            reinterpret_cast<T *>(base + dp.map.long_val), reinterpret_cast<int *>(base + dp.map.long_cid));
         HIP_TRYP(hipGetLastError());
+        const int np = (int)p.piece_dst.size();
+        if (np > 0) {
+            int *pc16 = const_cast<int *>(dp.args.piece_c16);
+            hipLaunchKernelGGL(k_long_cid16, dim3(waves_grid(np)), dim3(256), 0, 0, reinterpret_cast<const int *>(base + dp.map.long_cid), dp.args.piece_ptr, pc16, np, p.geo.chunk,
+                               reinterpret_cast<int *>(base + dp.map.long_base), reinterpret_cast<unsigned short *>(base + dp.map.long_cid16));
+            HIP_TRYP(hipGetLastError());
+            HIP_TRYP(hipMemcpy(p.piece_c16.data(), pc16, p.piece_c16.size() * sizeof(int), hipMemcpyDeviceToHost));      // which pieces are narrow: back to the host (plan files, decoders)
+        }
         HIP_TRYP(hipDeviceSynchronize());
     }
     if (nb > 0) {
@@ -727,7 +757,7 @@ int download_array(Plan &p, const char *name, void *dst, size_t bytes)
         return DASP_ERR_ARG;
     }
     struct { const char *n; size_t off, len; } tab[] = {
-        {"long_val", mp.long_val, p.cnt_long * vb}, {"long_cid", mp.long_cid, p.cnt_long * 4},
+        {"long_val", mp.long_val, p.cnt_long * vb}, {"long_cid", mp.long_cid, p.cnt_long * 4}, {"long_cid16", mp.long_cid16, p.cnt_long * 2}, {"long_base", mp.long_base, p.cnt_long_chunks * 4},
         {"med_val", mp.med_val, p.cnt_reg * vb}, {"med_cid", mp.med_cid, p.cid16 ? 0 : p.cnt_reg * 4},
         {"med_cid16", mp.med_cid16, p.cid16 ? (p.cnt_reg - p.cnt_reg8) * 2 : 0}, {"med_cid8", mp.med_cid8, p.cnt_reg8}, {"med_base", mp.med_base, p.cid16 ? (size_t)p.med_ptr.back() * 4 : 0},
         {"irr_val", mp.irr_val, p.cnt_irr * vb}, {"irr_cid", mp.irr_cid, p.cnt_irr * 4},

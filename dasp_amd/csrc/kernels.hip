@@ -51,7 +51,7 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : MW ? MW : kM
     Stamps st; st.begin(0);
 #endif
     const DevArgs a = load_args(c);
-    spmv_body<T, NT, C16, WIN, C8, false, WIN>(a, lds_raw, blockIdx.x, st);
+    spmv_body<T, NT, C16, WIN, C8, false, WIN, !WIN && !C8 && MW == 0>(a, lds_raw, blockIdx.x, st);
 #ifdef DASP_STAMPS
     st.finish(a.wpw);
 #endif
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 7 : kMinWavesPlain) void dasp
     Stamps st; st.begin(0);
 #endif
     const DevArgs a = load_args(c);
-    spmv_body<T, NT, C16, false, false, true>(a, lds_raw, blockIdx.x, st);
+    spmv_body<T, NT, C16, false, false, true, false, true>(a, lds_raw, blockIdx.x, st);
 }
 
 // the windowed kernel for plans with at most one window workgroup per CU (n_windows <= CUs: cop20k_A's 212): nothing is gained by
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 7 : kMinWavesPlain) void dasp
     const CallArgs ca = panel_of(c, wg);
     Stamps st; st.begin(0);
     const DevArgs a = load_args(ca);
-    spmv_body<T, NT, C16, false, false, true>(a, lds_raw, wg, st);
+    spmv_body<T, NT, C16, false, false, true, false, true>(a, lds_raw, wg, st);
 }
 
 // stage 2 for long rows cut into several pieces (reference: longPart_sum, dasp_f64.h:53-75)

@@ -18,14 +18,17 @@ int lcb_col_block(const Plan &p) { return p.precision == 64 ? 16384 : 32768; }  
 
 // rows of >= h nonzeros, h = max(block_longest, 64 per column block): a piece then averages a wave's worth of elements per step.  Auto: when those rows hold
 // at least a quarter of the nonzeros (powerlaw_1M f64: 2565 rows of >= 4096 hold 68 %); 1 forces (h = block_longest), -1 turns it off.
-// share_den: the automatic rule asks for >= 1 / share_den of the nonzeros in those rows (column panels: a quarter; the two-phase hybrid: a sixteenth -- there a hub row is
-// not only gathers saved but thousands of additions to ONE LDS word taken out of phase 2)
-int decide_long_cb(const Plan &p, const int *rp, int P, std::vector<unsigned char> &in_lcb, int share_den)
+// share_den: the automatic rule asks for >= 1 / share_den of the nonzeros in those rows: a quarter, for column panels and for the two-phase hybrid alike (r6, f16: powerlaw_1M,
+// 68 % in 4375 hub rows, 198 -> 124 us as a hybrid; rmat_2M, 9 % in 232 rows, 82.0 -> 91.3 and x0.5 51.5 -> 55.7: every unit stages 64 KB of x for a few hundred elements)
+// per_block: a hub row holds >= per_block nonzeros per column block on average -- 64 for column panels (the powerlaw_1M f64 sweep, profiles/r05_long_cb.md), 128 = one
+// whole step of the hub kernel for the two-phase hybrid, whose alternative is the better one (rmat_2M x0.5 f16: 49 % of the nonzeros in rows of >= 2048 = 64 per block,
+// 51.7 -> 55.9 us as a hybrid)
+int decide_long_cb(const Plan &p, const int *rp, int P, std::vector<unsigned char> &in_lcb, int share_den, int per_block)
 {
     in_lcb.clear();
     if (p.opt.long_cb < 0 || P < 2 || p.opt.n_parts > 0 || !p.dst_map.empty() || p.m <= 0) return 0;
     const int cb = lcb_col_block(p), n_cb = std::max(1, (p.n + cb - 1) / cb);
-    const long long h = p.opt.long_cb > 0 ? (long long)std::max(6, p.opt.block_longest) : std::max<long long>(p.opt.block_longest, 64ll * n_cb);
+    const long long h = p.opt.long_cb > 0 ? (long long)std::max(6, p.opt.block_longest) : std::max<long long>(p.opt.block_longest, (long long)per_block * n_cb);
     long long nnz_l = 0; int rows = 0;
     for (int i = 0; i < p.m; ++i) { const int len = rp[i + 1] - rp[i]; if (len >= h) { nnz_l += len; ++rows; } }
     if (rows == 0 || (long long)rows * n_cb >= (1ll << 27)) return 0;

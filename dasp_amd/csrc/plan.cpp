@@ -316,7 +316,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             auto hybrid_then_tp = [&](const int *hci, const T *hval) -> int {
                 std::vector<unsigned char> in_lcb;
                 p.lcb = LongCB{};
-                if (decide_long_cb(p, rp, 2, in_lcb, 16) > 0) {
+                if (decide_long_cb(p, rp, 2, in_lcb, 4, 128) > 0) {
                     std::vector<int> slot_of_row;
                     const bool natural = p.opt.y_order == DASP_Y_NATURAL;
                     if (!natural) { slot_of_row.resize((size_t)m); for (int i = 0; i < m; ++i) slot_of_row[(size_t)p.order[(size_t)i]] = i; }
@@ -902,6 +902,37 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                 for (long long j = std::max(s0, real_end); j < s1; ++j) { lv[j] = (T)0; p.long_cid[(size_t)j] = -1; }   // pad to kLongAlign
             }
         });
+        // ---- 16-bit ids (plan.hpp long_cid16): the chunk grid is the kernel's -- CH elements from the piece's first element on
+        {
+            const int CHL = geo.chunk, np_all = (int)p.piece_dst.size();
+            p.piece_c16.assign((size_t)2 * (size_t)np_all, 0);
+            long long nchunk = 0;
+            for (int q = 0; q < np_all; ++q) { p.piece_c16[(size_t)2 * q] = (int)nchunk; nchunk += ceil_div(p.piece_ptr[(size_t)q + 1] - p.piece_ptr[(size_t)q], CHL); }
+            if (pack) {
+                p.long_base.assign((size_t)nchunk, 0);
+                p.long_cid16.resize((size_t)total);
+                parallel_for(np_all, threads, 16, [&](long long q0, long long q1) {
+                    for (long long q = q0; q < q1; ++q) {
+                        const int e0 = p.piece_ptr[(size_t)q], e1 = p.piece_ptr[(size_t)q + 1], c0 = p.piece_c16[(size_t)2 * q];
+                        bool narrow = true;
+                        for (int e = e0, c = c0; e < e1; e += CHL, ++c) {
+                            int lo = 2147483647, hi = -1;
+                            for (int j = e; j < std::min(e + CHL, e1); ++j) { const int col = p.long_cid[(size_t)j]; if (col >= 0) { lo = std::min(lo, col); hi = std::max(hi, col); } }
+                            p.long_base[(size_t)c] = hi < 0 ? 0 : lo;
+                            if (hi >= 0 && (long long)hi - lo > 65534) narrow = false;
+                        }
+                        narrow = narrow && e1 - e0 >= kLong16MinChunks * CHL;
+                        p.piece_c16[(size_t)2 * q + 1] = narrow ? 1 : 0;
+                        for (int e = e0, c = c0; e < e1; e += CHL, ++c)
+                            for (int j = e; j < std::min(e + CHL, e1); ++j) {
+                                const int col = p.long_cid[(size_t)j];
+                                p.long_cid16[(size_t)j] = !narrow ? (uint16_t)0 : col < 0 ? kLongPad16 : (uint16_t)(col - p.long_base[(size_t)c]);
+                            }
+                    }
+                });
+            } else { p.long_base.clear(); p.long_cid16.clear(); }
+            p.cnt_long_chunks = (size_t)nchunk;
+        }
     }
 
     lap("long rows");
@@ -956,10 +987,12 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         // 2 bytes per nonzero save: cop20k_A 11.6 vs 12.4 us).  From ~64 MiB of CSR on it pays on every FEM-like stand-in
         // (nlpkkt160 x0.03 16.7 -> 15.5 us, Queen x0.05 31.2 -> 27.7, x0.08 56.8 -> 42.5: the packed matrix then fits the
         // Infinity Cache); windowed plans keep the old bound.
-        const bool streams = (long long)nnz * (geo.vbytes + 4) > (p.windowed ? kStreamBytes : (64ll << 20));
+        // r6 (tests/test_zz_auto_rules.py): from 16 MiB on -- nlpkkt160 x0.01 f64 (26 MB) 5.9 -> 5.4 us, Queen_4147 x0.03 f16 (56 MB) 12.1 -> 10.2 with them
+        const bool streams = (long long)nnz * (geo.vbytes + 4) > (p.windowed ? kStreamBytes : (16ll << 20));
         // r3: plans of at most 256 LDS windows (one window workgroup per CU: the 128-register kernel) whose ids can be window-relative
         // (no per-chunk base load at all): cop20k_A 10.7 -> 10.4 us, 10.2 with the windows dealt to the XCDs in contiguous eighths
-        const bool rel1 = p.windowed && !p.win_hybrid && p.opt.x_window != -2 && p.win_len.size() <= 256 && p.lds_bytes / geo.vbytes <= 65534;
+        // (r6: any number of windows -- the 64-register build no longer spills with 16-bit ids; cop20k_A x8 f64, 848 windows, 58.6 -> 45.6 us, x4 f16 18.4 -> 16.8)
+        const bool rel1 = p.windowed && !p.win_hybrid && p.opt.x_window != -2 && p.lds_bytes / geo.vbytes <= 65534;
         p.cid16 = try16 && e32 > 0 && (p.opt.cid16 > 0 || ((streams || rel1) && (double)e16 >= 0.97 * (double)e32));
         if (p.cid16) nchunks.swap(nchunks16);
         // LDS-staged windows: offsets from the window's first staged column (every staged span is far below 65535 elements in f64;
@@ -1114,7 +1147,28 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     // spill more with the DPP path compiled in: cop20k_A 11.1 -> 12.0 us; f16 gains nothing: DESIGN.md section 3)
     {
         const int SR = geo.short_rows;
-        const bool seg = p.opt.short_seg > 0 || (p.opt.short_seg == 0 && !f16 && !p.windowed);
+        bool seg = p.opt.short_seg > 0 || (p.opt.short_seg == 0 && !f16 && !p.windowed);
+        if (seg && p.opt.short_seg == 0 && !meta_only) {
+            // r6 (tests/test_zz_auto_rules.py): in a slab a lane owns whole rows, so the 64 lanes of a step gather for 128 neighbouring rows of one length -- where neighbouring
+            // short rows read neighbouring columns (road networks, meshes' boundary rows) those gathers coalesce and the slabs win: rows of 1..4 within +-64 columns of the
+            // diagonal, 262 k / 1 M / 4 M rows, 4.9 / 15.5 / 50.2 us segmented against 3.9 / 12.3 / 46.9 as slabs; graph rows (webbase-1M f64: 30.6 -> 28.4 us segmented) keep
+            // the segmented tiles.  The measure of the slab rule above: pairs of successive rows of one length, positions whose columns differ by < 16.
+            std::vector<int> pairs;
+            for (int g = 0; g < 4; ++g) {
+                const std::vector<int> &list = *glist[g];
+                const int step = std::max(2, ((int)list.size() / 2048) & ~1);
+                for (size_t i = 0; i + 1 < list.size(); i += (size_t)step) { pairs.push_back(list[i]); pairs.push_back(list[i + 1]); }
+            }
+            long long near = 0, entries = 0;
+            if (dev) { if (int rc = devpack_row_coherence(p, *dev, pairs, 16, &near, &entries)) return rc; }
+            else
+                for (size_t q = 0; q + 1 < pairs.size(); q += 2) {
+                    const int a = rp[pairs[q]], b = rp[pairs[q + 1]], len = rp[pairs[q] + 1] - a;
+                    for (int k = 0; k < len; ++k) { const int d = remap(ci[a + k]) - remap(ci[b + k]); near += d > -16 && d < 16; }
+                    entries += len;
+                }
+            if (entries >= 256 && 2 * near >= entries) seg = false;
+        }
         long long off = 0; int tile0 = 0;
         for (int g = 0; g < kNumShortGroups; ++g) {
             ShortGroup &G = p.grp[g];
@@ -1206,7 +1260,7 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     }
     if (meta_only) {   // the panels own the packed data; this plan keeps order_rid + the whole-matrix counters
         p.cnt_long = p.cnt_reg = p.cnt_irr = p.cnt_short = 0;
-        p.piece_ptr.clear(); p.piece_dst.clear(); p.multi_ptr.clear(); p.multi_dst.clear();
+        p.piece_ptr.clear(); p.piece_dst.clear(); p.multi_ptr.clear(); p.multi_dst.clear(); p.piece_c16.clear(); p.long_base.clear(); p.long_cid16.clear(); p.cnt_long_chunks = 0;
         p.med_ptr.clear(); p.irr_ptr.clear();
         for (int g = 0; g < kNumShortGroups; ++g) { p.grp[g].tiles = 0; p.grp[g].tile0 = 0; p.grp[g].elem_off = 0; }
     }

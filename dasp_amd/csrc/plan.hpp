@@ -97,6 +97,10 @@ inline size_t med_elem_index(int npair, int c, int lane, int j, int vpl, int ch)
 constexpr int kShortTpw = DASP_SHORT_TPW;      // wave-segmented short tiles (64 elements each) handled by one wave (device.hpp DevArgs::short_tpw)
 constexpr int kMedRows = 16;      // rows of one MFMA tile (v_mfma_*_16x16x*)
 constexpr int kLongAlign = 4;     // long rows start on a multiple of 4 elements
+// ... and only pieces of at least four whole chunks take them: a row of 300 in f16 (one chunk and a tail) is two steps whose id unpacking costs more than its 600 bytes
+// save (rows of 300 f16 131 -> 150 us with 16-bit ids; rows of 2000 95.6 -> 88.7, 400 rows of 200 000 92.9 -> 83.9; f64 rows of 300, four chunks and a tail: 196 / 198)
+constexpr int kLong16MinChunks = 4;
+constexpr unsigned short kLongPad16 = 0xFFFFu;      // a pad among the 16-bit ids of a narrow long piece (Plan::long_cid16)
 constexpr int kSlabMaxLen = 32;     // longest medium row that can be stored as a uniform-length slab (opt.slab_max_len)
 // slab groups: row lengths 1,2,3,4 and 0 (zero rows only get y=0) -- the reference's short rows -- then 5..kSlabMaxLen
 constexpr int kNumShortGroups = 5 + (kSlabMaxLen - 4);
@@ -245,6 +249,13 @@ struct Plan {
     // long rows: CSR-ordered, each row padded to kLongAlign (val 0, cid -1); pieces of <= long_piece
     raw_vector<char> long_val;      // vbytes per element
     raw_vector<int> long_cid;
+    // 16-bit ids of the long pieces (r6): chunk i of piece p -- elements [piece_ptr[p] + i CH, + CH) -- has the base column long_base[piece_c16[2 p] + i]
+    // (its smallest column; 0 for a chunk of pads only); a piece all of whose chunks span <= 65534 columns is NARROW (piece_c16[2 p + 1] = 1) and its ids are also stored as
+    // u16 offsets from the chunk's base in long_cid16[element] (0xFFFF = pad): the kernel streams 10 / 4 instead of 12 / 6 bytes per nonzero.  Lane assignment and the order of
+    // a row's additions are those of the 32-bit form, which stays complete in long_cid (wide pieces, the multi-GPU step kernels, decoders); a wide piece's u16 ids are 0.
+    raw_vector<uint16_t> long_cid16;  // [cnt_long]
+    std::vector<int> long_base;       // [chunks of all pieces]
+    std::vector<int> piece_c16;       // [2 P] {first chunk, narrow}
     std::vector<int> piece_ptr;     // [P+1] element offsets
     std::vector<int> piece_dst;     // [P]   >= 0: y index ; < 0: partial sum ~dst
     std::vector<int> multi_ptr;     // [R2+1] ranges of partial sums of rows cut into several pieces
@@ -289,6 +300,7 @@ struct Plan {
 
     // element counts of the nnz-sized arrays (the host vectors are empty when the plan was packed on the device)
     size_t cnt_long = 0, cnt_reg = 0, cnt_irr = 0, cnt_short = 0;
+    size_t cnt_long_chunks = 0;      // chunks of all long pieces (entries of long_base)
 
     // column panels (opt.col_panels): this plan then holds only order / stats of the whole matrix and owns one natural-order
     // plan per column range [panel_bounds[k], panel_bounds[k+1]); panel k writes its partial result for row r to
@@ -387,12 +399,12 @@ inline int win_fold_tiles(int n_windows, int n_short_tiles)
 {
     return n_windows > 0 && n_windows <= 512 && n_short_tiles > 0 && n_short_tiles <= 2 * n_windows ? (n_short_tiles + n_windows - 1) / n_windows : 0;
 }
-constexpr int kTpDeclined = 1;          // build_two_phase under the automatic rule: the padded streams would pass 1.5 x the nonzeros (or the tile table 64 M entries) -- not an error
+constexpr int kTpDeclined = 1;          // build_two_phase under the automatic rule: the padded streams would pass 2 x the nonzeros (or the tile table 64 M entries) -- not an error
 int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val, const unsigned char *skip = nullptr);
 bool validate_two_phase(const Plan &p, std::string &why);
 
 // column-blocked long rows (longcb.cpp): which rows (in_lcb[row] = 1) a column-panel plan of P panels hands to them (0 rows: none), the packer, the checks
-int decide_long_cb(const Plan &p, const int *rp, int P, std::vector<unsigned char> &in_lcb, int share_den = 4);
+int decide_long_cb(const Plan &p, const int *rp, int P, std::vector<unsigned char> &in_lcb, int share_den = 4, int per_block = 64);
 int build_long_cb(Plan &p, const int *rp, const int *ci, const void *val, const std::vector<unsigned char> &in_lcb, const int *slot_of_row);      // DASP_OK, an error, or 1: not representable (p.lcb left empty)
 bool validate_long_cb(const Plan &p, int n_panels, std::string &why);
 

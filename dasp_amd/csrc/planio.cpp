@@ -19,7 +19,7 @@ namespace dasp {
 
 namespace {
 // bumped with EVERY change of the header, the array list or the element order inside an array (5: 18-int header, one-byte ids, chunk pairs; 6: 19-int header, row tiles; 7: 25-int header, the two-phase streams, the column-blocked long rows)
-const char kPlanMagic[8] = {'D', 'A', 'S', 'P', 'P', 'L', 'N', '7'};
+const char kPlanMagic[8] = {'D', 'A', 'S', 'P', 'P', 'L', 'N', '8'};      // v8 (r6): + long_cid16 / long_base / piece_c16
 
 struct Writer {
     FILE *f; bool ok = true;
@@ -46,7 +46,7 @@ struct Reader {
 template <class IO> void arrays(IO &io, Plan &p)
 {
     io.vec(p.part_bounds); io.vec(p.order); io.vec(p.dst_map); io.vec(p.panel_bounds);
-    io.vec(p.long_val); io.vec(p.long_cid); io.vec(p.piece_ptr); io.vec(p.piece_dst); io.vec(p.multi_ptr); io.vec(p.multi_dst);
+    io.vec(p.long_val); io.vec(p.long_cid); io.vec(p.long_cid16); io.vec(p.long_base); io.vec(p.piece_c16); io.vec(p.piece_ptr); io.vec(p.piece_dst); io.vec(p.multi_ptr); io.vec(p.multi_dst);
     io.vec(p.med_ptr); io.vec(p.med_val); io.vec(p.med_cid); io.vec(p.med_cid16); io.vec(p.med_cid8); io.vec(p.med_c8ptr); io.vec(p.med_korig); io.vec(p.med_base);
     io.vec(p.irr_ptr); io.vec(p.irr_val); io.vec(p.irr_cid);
     io.vec(p.med_dst); io.vec(p.win_cmin); io.vec(p.win_len);
@@ -121,6 +121,28 @@ static bool validate_plan(const Plan &p, int n_panels, bool is_panel, std::strin
     for (int d : p.multi_dst) if ((unsigned)d >= (unsigned)m) return fail("multi_dst out of range");
     for (size_t i = 0; i + 1 < p.piece_ptr.size(); ++i) if (p.piece_ptr[i] % kLongAlign) return fail("piece_ptr alignment");
     if (!cid_ok(p.long_cid)) return fail("long_cid out of range");
+    {   // 16-bit ids of the long pieces: the chunk prefix, and -- narrow pieces -- base + offset == the 32-bit id of every element, pads at the pads; wide pieces hold zeros
+        const size_t np = p.piece_dst.size();
+        if (p.piece_c16.size() != 2 * np || p.long_cid16.size() != p.cnt_long) return fail("long_cid16 / piece_c16 sizes");
+        long long chunks = 0;
+        for (size_t q = 0; q < np; ++q) {
+            if (p.piece_c16[2 * q] != chunks || (unsigned)p.piece_c16[2 * q + 1] > 1u) return fail("piece_c16");
+            chunks += (p.piece_ptr[q + 1] - p.piece_ptr[q] + CH - 1) / CH;
+        }
+        if ((long long)p.long_base.size() != chunks || (long long)p.cnt_long_chunks != chunks) return fail("long_base size");
+        for (size_t q = 0; q < np; ++q) {
+            const bool narrow = p.piece_c16[2 * q + 1] != 0;
+            if (narrow && p.piece_ptr[q + 1] - p.piece_ptr[q] < kLong16MinChunks * CH) return fail("narrow piece shorter than four chunks");
+            for (long long e = p.piece_ptr[q], c = p.piece_c16[2 * q]; e < p.piece_ptr[q + 1]; e += CH, ++c) {
+                const int b = p.long_base[(size_t)c];
+                if (b < 0 || b >= std::max<long long>(xlen, 1)) return fail("long_base out of range");
+                for (long long j = e; j < std::min<long long>(e + CH, p.piece_ptr[q + 1]); ++j) {
+                    const int col = p.long_cid[(size_t)j]; const unsigned o = p.long_cid16[(size_t)j];
+                    if (narrow ? (col < 0 ? o != kLongPad16 : (o == kLongPad16 || b + (int)o != col)) : o != 0) return fail("long_cid16 does not match long_cid");
+                }
+            }
+        }
+    }
     // ---- medium rows
     const long long nb = (p.n_mfma_rows + kMedRows - 1) / kMedRows;
     if (p.med_ptr.size() != (size_t)nb + 1 || !mono(p.med_ptr) || p.stats.n_med_blocks != nb) return fail("med_ptr size / n_med_blocks");
@@ -317,6 +339,7 @@ static bool read_plan(Reader &r, Plan &p, int depth, std::string &r_why)
                p.n_mfma_rows >= 0 && p.n_mfma_rows <= p.stats.row_block && (!p.windowed || p.med_dst.size() == (size_t)p.n_mfma_rows);
     if (!sane) return false;
     p.cnt_long = p.long_cid.size(); p.cnt_irr = p.irr_cid.size(); p.cnt_short = p.short_cid.size();
+    p.cnt_long_chunks = p.long_base.size();
     p.cnt_reg = p.cid16 ? p.med_cid16.size() + p.med_cid8.size() : p.med_cid.size();
     p.cnt_reg8 = p.med_cid8.size();
     p.cnt_rt = p.rt_cid.size();

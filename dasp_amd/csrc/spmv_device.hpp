@@ -117,7 +117,7 @@ __device__ __forceinline__ DevArgs load_args(const CallArgs &c)
     DevArgs a;
     __builtin_memcpy(&a, w, sizeof a);
 #define DASP_G(f) a.f = ldp(&c.plan->f)
-    DASP_G(long_val); DASP_G(long_cid); DASP_G(piece_ptr); DASP_G(piece_dst); DASP_G(partial); DASP_G(multi_ptr); DASP_G(multi_dst);
+    DASP_G(long_val); DASP_G(long_cid); DASP_G(long_cid16); DASP_G(long_base); DASP_G(piece_c16); DASP_G(piece_ptr); DASP_G(piece_dst); DASP_G(partial); DASP_G(multi_ptr); DASP_G(multi_dst);
     DASP_G(med_ptr); DASP_G(med_val); DASP_G(med_cid); DASP_G(med_cid16); DASP_G(med_base); DASP_G(med_cid8); DASP_G(med_c8ptr);
     DASP_G(irr_ptr); DASP_G(irr_val); DASP_G(irr_cid); DASP_G(med_dst); DASP_G(win_cmin); DASP_G(win_len);
     DASP_G(short_val); DASP_G(short_cid); DASP_G(groups); DASP_G(order);
@@ -269,13 +269,33 @@ struct PieceSrc {
     static constexpr bool kPairs = false, kQuadIds = false;
     static constexpr int VPL = Tr<T>::CHUNK / kWave;
     const T *val; const int *cid; size_t e0; int lane, nfull, tail;
+    // r6 (plan.hpp long_cid16): a NARROW piece (wave-uniform flag) reads its ids as u16 offsets -- 2 instead of 4 bytes per element -- from its chunks' base columns, a scalar
+    // load per step; 0xFFFF = pad.  The same elements in the same lanes as the 32-bit form, so the same bits.  base = the piece's first entry of long_base.
+    bool narrow = false; const unsigned short *cid16 = nullptr; const int *base = nullptr;
     template <bool PAIRED_OK = true> __device__ __forceinline__ void load(Frag<T> &f, int i) const
     {
-        if (i < nfull) frag_load<NT>(f, val, cid, e0 + (size_t)i * Tr<T>::CHUNK, lane);
-        else frag_load_at<NT>(f, val, cid, VPL * lane < tail ? e0 + (size_t)i * Tr<T>::CHUNK + (size_t)(VPL * lane) : e0);
+        const size_t at = i < nfull || VPL * lane < tail ? e0 + (size_t)i * Tr<T>::CHUNK + (size_t)(VPL * lane) : e0;
+        if (narrow) {
+            if constexpr (VPL == 1) { f.a = ldg<NT>(val + at); f.c = (int)ldg<NT>(cid16 + at); }
+            else {
+                f.a = ldg<NT>(reinterpret_cast<const f16x4 *>(val + at));
+                const i32x2 o = ldg<NT>(reinterpret_cast<const i32x2 *>(cid16 + at));      // raw u16 offsets, two per dword; unpacked and rebased in gather()
+                f.c[0] = o[0]; f.c[1] = o[1];
+            }
+        } else frag_load_at<NT>(f, val, cid, at);
     }
     template <bool QUAD = false, class XV> __device__ __forceinline__ void gather(Frag<T> &f, int i, const XV &x) const
     {
+        if (narrow) {
+            const int b = tab<true>(base, i);                   // wave-uniform: one scalar load per step
+            if constexpr (VPL == 1) { const unsigned o = (unsigned)f.c; f.c = o == kLongPad16 ? -1 : b + (int)o; }
+            else {
+                const unsigned lo = (unsigned)f.c[0], hi = (unsigned)f.c[1];
+                const unsigned o[4] = {lo & 0xFFFFu, lo >> 16, hi & 0xFFFFu, hi >> 16};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f.c[q] = o[q] == kLongPad16 ? -1 : b + (int)o[q];
+            }
+        }
         if (i >= nfull) {
             const bool ok = VPL * lane < tail;
             if constexpr (VPL == 1) { f.c = ok ? f.c : -1; f.a = ok ? f.a : 0.0; }      // (the value too: the re-read element may be inf / NaN)
@@ -648,7 +668,8 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
 // ---- long: one wave = one piece (<= long_piece elements) of one long row (reference: dasp_f64.h:90-144)
 // TAIL_IN: the partial last chunk rides in the stream (PieceSrc) -- the plain kernels; the windowed and the multi-GPU step kernels, which sit at their register caps,
 // keep it as a step of its own behind the stream
-template <class T, bool NT, int YS = 0, bool TAIL_IN = false>
+// L16: the build reads the 16-bit ids of narrow pieces (plan.hpp long_cid16)
+template <class T, bool NT, int YS = 0, bool TAIL_IN = false, bool L16 = false>
 __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
 {
     using acc_t = typename Tr<T>::acc_t;
@@ -660,9 +681,14 @@ __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
     const int p0 = tab<true>(a.piece_ptr, p), p1 = tab<true>(a.piece_ptr, p + 1);
     acc_t acc = {0, 0, 0, 0};
     const int nfull = (p1 - p0) / CH, tail = (p1 - p0) - nfull * CH;
-    if (TAIL_IN && tail > 0) {       // (pieces of whole chunks -- every piece but the last of a row cut in pieces -- keep the stream without the per-step test: rmat_2M f64 +1.3 % with it)
-        const PieceSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane, nfull, tail};
-        run_stream<T, Tr<T>::BATCH, Tr<T>::LONG_SHOT>(acc, src, nfull + 1, x);
+    // narrow piece: 16-bit ids (L16: the plain kernels without one-byte ids and the merged-panel kernels -- the one-byte-id and 7-wave f64 builds, the windowed and the
+    // multi-GPU step kernels sit at their register ceilings and read the 32-bit ids every piece keeps; the r6 attempt cost the one-byte-id build a 36-byte frame)
+    bool narrow = false;
+    if constexpr (L16) narrow = tab<true>(a.piece_c16, 2 * p + 1) != 0;
+    if (TAIL_IN && (tail > 0 || narrow)) {       // (wide pieces of whole chunks -- every piece but the last of a row cut in pieces -- keep the stream without the per-step tests: rmat_2M f64 +1.3 % with it)
+        PieceSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane, nfull, tail};
+        if constexpr (L16) { src.narrow = narrow; src.cid16 = a.long_cid16; src.base = a.long_base + tab<true>(a.piece_c16, 2 * p); }
+        run_stream<T, Tr<T>::BATCH, Tr<T>::LONG_SHOT>(acc, src, nfull + (tail > 0 ? 1 : 0), x);
     } else {
         const int full = p0 + nfull * CH;
         ChunkSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane};
@@ -993,16 +1019,20 @@ constexpr int kMinWavesPlain = DASP_MIN_WAVES, kMinWavesWin = 8;
 #define DASP_WIN64_S 6
 #endif
 // W64: the windowed build held to 64 registers (two window workgroups per CU)
-template <class T, bool NT, bool C16, bool WIN, bool C8, bool RT = false, bool W64 = false>
+template <class T, bool NT, bool C16, bool WIN, bool C8, bool RT = false, bool W64 = false, bool L16 = false>
 __device__ __forceinline__ void spmv_body(const DevArgs &a, char *lds_raw, int wg_index, Stamps &st)
 {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wg = wg_index;          // blockIdx.x, or the workgroup's index inside its panel's range of a merged launch (dasp_spmv_panels_kernel)
+    // blockIdx.x, or the workgroup's index inside its panel's range of a merged launch (dasp_spmv_panels_kernel) -- rotated by wg_rot (plain plans only: 0 elsewhere)
+    int wg = wg_index;
+    if constexpr (sizeof(T) == 2 && !WIN && !RT) {      // (f16 builds only: the f64 one-byte-id build, at its 104 SGPRs, pays for it with a 36-byte frame)
+        if (a.wg_rot) { const int grid = a.wg_long + a.wg_med + a.wg_short; wg += a.wg_rot; wg = wg >= grid ? wg - grid : wg; }
+    }
     const int wpw = WIN ? a.wpw : kWavesPerWG;
     if (wg < a.wg_long) {
         const int p = wg * wpw + wave;
-        if (p < a.n_pieces) long_piece<T, NT, 0, !WIN>(a, p, lane);
+        if (p < a.n_pieces) long_piece<T, NT, 0, !WIN, L16 && !WIN>(a, p, lane);
     } else if (wg < a.wg_long + a.wg_med) {
         st.kind = 1;
         if constexpr (!WIN) {

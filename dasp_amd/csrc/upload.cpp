@@ -173,6 +173,9 @@ static int upload_plan_impl(Plan &p)
     const size_t vbytes = (size_t)p.geo.vbytes;
     const size_t o_lv = add(src_of(p.long_val), p.cnt_long * vbytes);
     const size_t o_lc = add(src_of(p.long_cid), p.cnt_long * 4);
+    const size_t o_lc16 = add(src_of(p.long_cid16), p.cnt_long * 2);
+    const size_t o_lb = add(src_of(p.long_base), p.cnt_long_chunks * 4);
+    const size_t o_pc16 = add(p.piece_c16.data(), p.piece_c16.size() * 4);
     const size_t o_pp = add(p.piece_ptr.data(), p.piece_ptr.size() * 4);
     const size_t o_pd = add(p.piece_dst.data(), p.piece_dst.size() * 4);
     const size_t o_mp = add(p.multi_ptr.data(), p.multi_ptr.size() * 4);
@@ -212,9 +215,10 @@ static int upload_plan_impl(Plan &p)
 
     d->map.long_val = o_lv; d->map.long_cid = o_lc; d->map.med_val = o_mv; d->map.med_cid = o_mc; d->map.med_cid16 = o_mc16; d->map.med_cid8 = o_mc8;
     d->map.med_base = o_mb; d->map.irr_val = o_iv; d->map.irr_cid = o_ic; d->map.short_val = o_sv; d->map.short_cid = o_sc;
-    d->map.rt_val = o_rv; d->map.rt_cid = o_rc;
+    d->map.rt_val = o_rv; d->map.rt_cid = o_rc; d->map.long_cid16 = o_lc16; d->map.long_base = o_lb; d->map.piece_c16 = o_pc16;
     DevArgs &a = d->args;
     a.long_val = base + o_lv; a.long_cid = (const int *)(base + o_lc);
+    a.long_cid16 = (const unsigned short *)(base + o_lc16); a.long_base = (const int *)(base + o_lb); a.piece_c16 = (const int *)(base + o_pc16);
     a.piece_ptr = (const int *)(base + o_pp); a.piece_dst = (const int *)(base + o_pd);
     a.multi_ptr = (const int *)(base + o_mp); a.multi_dst = (const int *)(base + o_md);
     a.partial = base + o_part;
@@ -316,6 +320,17 @@ static int upload_plan_impl(Plan &p)
     // windowed plans: a short tile per wave in workgroups of 16 waves puts 16 waves of 64-line gathers on each of a few CUs -- on cop20k_A (104 tiles in 7 workgroups) they
     // were the last waves of the launch to exit (9.9 us against 7.2 for the median window wave).  Where the tiles are few beside the windows they are folded into the window
     // workgroups as fillers behind their blocks (spmv_body): tile t goes to window t % n_windows.  One launch-wide rule: all tiles or none.
+    // which category the dispatcher starts with (r6, the f16 builds): workgroups start in index order, and what is dispatched last is the launch's tail.  The f16 short tiles
+    // are the longest-lived waves of a latency-bound launch (webbase-1M f16, per-wave stamps: 4.1 us against 3.0 for a medium block) and stood at the end of the grid:
+    // short tiles first, webbase-1M f16 14.68 -> 13.7 us, x4 65.3 -> 61.6, the uniform variant 15.7 -> 15.1 (f64, measured the same way: 28.9 -> 31.2 -- its short waves
+    // hold four tiles each -- so the f64 builds do not carry the rotation at all; medium blocks first: HV15R x0.1 f64 40.9 -> 39.2, not taken up)
+    a.wg_rot = 0;
+    const bool can_rot = p.precision == 16 && !p.windowed && p.rt_mask.empty() && !p.panel;
+    if (can_rot && a.wg_short > 0 && a.wg_long + a.wg_med > 0) a.wg_rot = a.wg_long + a.wg_med;
+    if (const char *e = std::getenv("DASP_WG_ROT")) {      // A/B knob: 0 = the grid as stored [long | medium | short], 1 = short tiles first, 2 = medium blocks first
+        const int k = std::atoi(e);
+        if (can_rot) a.wg_rot = k == 1 ? a.wg_long + a.wg_med : k == 2 ? a.wg_long : 0;
+    }
     a.win_tiles = 0;
     if (p.windowed && win_fold_tiles(a.n_windows, a.n_short_tiles) > 0) {
         a.win_tiles = win_fold_tiles(a.n_windows, a.n_short_tiles);
@@ -357,7 +372,7 @@ static void rebase_args(DevArgs &a, const char *from, const char *to, size_t byt
         const char *q = reinterpret_cast<const char *>(ptr);
         if (q >= from && q < from + bytes) ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(const_cast<char *>(to + (q - from)));
     };
-    mv(a.long_val); mv(a.long_cid); mv(a.piece_ptr); mv(a.piece_dst); mv(a.partial); mv(a.multi_ptr); mv(a.multi_dst);
+    mv(a.long_val); mv(a.long_cid); mv(a.long_cid16); mv(a.long_base); mv(a.piece_c16); mv(a.piece_ptr); mv(a.piece_dst); mv(a.partial); mv(a.multi_ptr); mv(a.multi_dst);
     mv(a.med_ptr); mv(a.med_val); mv(a.med_cid); mv(a.med_cid16); mv(a.med_base); mv(a.med_cid8); mv(a.med_c8ptr);
     mv(a.irr_ptr); mv(a.irr_val); mv(a.irr_cid); mv(a.med_dst); mv(a.win_cmin); mv(a.win_len);
     mv(a.short_val); mv(a.short_cid); mv(a.groups); mv(a.order);

@@ -1089,8 +1089,8 @@ def test_wave_segmented_short_rows_against_the_oracle(oracle, dasp, torch_cuda, 
     plan.close()
 
 
-NNZ_ARRAYS = ("long_val long_cid med_val med_cid med_cid16 med_cid8 med_base irr_val irr_cid short_val short_cid rt_val rt_cid").split()
-META_ARRAYS = ("piece_ptr piece_dst multi_ptr multi_dst med_ptr med_c8ptr med_korig irr_ptr med_dst win_cmin win_len short_groups rt_ptr rt_start rt_mask").split()
+NNZ_ARRAYS = ("long_val long_cid long_cid16 long_base med_val med_cid med_cid16 med_cid8 med_base irr_val irr_cid short_val short_cid rt_val rt_cid").split()
+META_ARRAYS = ("piece_ptr piece_dst piece_c16 multi_ptr multi_dst med_ptr med_c8ptr med_korig irr_ptr med_dst win_cmin win_len short_groups rt_ptr rt_start rt_mask").split()
 
 
 @pytest.mark.parametrize("prec", [64, 16])

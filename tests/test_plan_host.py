@@ -512,7 +512,7 @@ def test_corrupt_plan_files_are_rejected_not_trusted(dasp, tmp_path):
         assert rejected >= 5
     for old in (b"4", b"5", b"6"):                                     # older layouts' magics ('5': before the row tiles / 19-int header; '6': before the two-phase streams / 22-int header)
         bad = bytearray(blob)
-        assert bytes(bad[:8]) == b"DASPPLN7"
+        assert bytes(bad[:8]) == b"DASPPLN8"
         bad[7:8] = old
         open(good, "wb").write(bad)
         with pytest.raises(dasp.DaspError) as e:
@@ -722,3 +722,52 @@ def test_windows_when_the_length_sort_scatters_local_rows(dasp):
     small = rng.integers(20, 120, m) // 4 + 5                      # the same structure under 16 M nonzeros
     rp2, ci2 = local(small)
     assert ci2.size < (16 << 20) and dasp.Plan(rp2, ci2, np.ones(ci2.size), n, precision=64).stats["x_window_on"] == 0
+
+
+@pytest.mark.parametrize("prec", [64, 16])
+def test_long_pieces_carry_16_bit_ids_where_their_chunks_are_narrow(dasp, prec, tmp_path):
+    """r6 (reference long path src/dasp_f64.h:90-144): per chunk of a long piece the smallest column is its base; a piece all of whose chunks span
+    <= 65534 columns stores u16 offsets besides the 32-bit ids (the kernel streams 10 / 4 instead of 12 / 6 bytes per nonzero), any other piece zeros.  Same lanes, same
+    order of additions: order_rid, the counters and the 32-bit arrays are exactly what they were.  util.decode_plan rebuilds the narrow pieces' columns from base + offset."""
+    rng = np.random.default_rng(3)
+    n = 400000
+    lens = [2000, 300, 5000, 257, 1500, 0, 3] + [9] * 200
+    rp = np.zeros(len(lens) + 1, np.int64); np.cumsum(lens, out=rp[1:])
+    cols = []
+    for i, L in enumerate(lens):
+        if i in (0, 3):      # local rows: consecutive columns -> narrow
+            cols.append(np.arange(L) + 1000 * i)
+        elif i == 2:         # sorted, dense enough per chunk: 5000 over 400 000 -> ~5000 columns per 64 entries -> narrow in f64, ~20 000 per 256 in f16 -> narrow too
+            cols.append(np.sort(rng.choice(n, L, replace=False)))
+        else:                # uniform, unsorted: a chunk spans most of x -> wide
+            cols.append(rng.integers(0, n, L))
+    ci = np.concatenate(cols).astype(np.int32)
+    dt = np.float64 if prec == 64 else np.float16
+    v = rng.integers(1, 9, ci.size).astype(dt)
+    plan = dasp.Plan(rp.astype(np.int32), ci, v, n, precision=prec, long_piece=1024)
+    pc = plan.host_array("piece_c16").reshape(-1, 2)
+    pp = plan.host_array("piece_ptr")
+    assert pc.shape[0] == plan.stats["n_long_pieces"] > 5 and 0 < pc[:, 1].sum() < pc.shape[0]          # both kinds present
+    rows = util.decode_plan(plan)                                                                      # (asserts base = chunk minimum, narrow <=> spans fit, offsets)
+    order = plan.order_rid
+    for slot, (cs, vs) in rows.items():
+        r = order[slot]
+        assert cs == ci[rp[r]:rp[r + 1]].tolist()
+    path = str(tmp_path / "l16.plan")
+    plan.save(path)
+    again = dasp.Plan.load(path)
+    for name in ("long_cid16", "long_base", "piece_c16", "long_cid"):
+        assert np.array_equal(again.host_array(name), plan.host_array(name)), name
+    again.close()
+    # a narrow piece whose offsets disagree with its 32-bit ids is refused
+    raw = bytearray(open(path, "rb").read())
+    l16 = plan.host_array("long_cid16")
+    k = int(pp[int(np.flatnonzero(pc[:, 1] == 1)[0])])
+    at = bytes(raw).find(l16.tobytes())
+    assert at > 0
+    raw[at + 2 * k: at + 2 * k + 2] = int((int(l16[k]) + 1) & 0x7FFF).to_bytes(2, "little")
+    (tmp_path / "bad.plan").write_bytes(bytes(raw))
+    with pytest.raises(dasp.DaspError) as e:
+        dasp.Plan.load(str(tmp_path / "bad.plan"))
+    assert "long_cid16" in str(e.value)
+    plan.close()

@@ -109,7 +109,7 @@ def test_two_phase_streams_decode_for_arbitrary_matrices(dasp, mat, y_order, cb,
     assert plan.stats["two_phase"] == 1 and (plan.order_rid == single.order_rid).all()
     order = plan.order_rid
     got = util.decode_plan(plan)
-    hub = util.decode_long_cb(plan)          # r6, the hybrid: hub rows (when they hold >= a sixteenth of the nonzeros) live column-blocked beside the streams, in no tile
+    hub = util.decode_long_cb(plan)          # r6, the hybrid: hub rows (when they hold >= a quarter of the nonzeros) live column-blocked beside the streams, in no tile
     for pos, (cs, vs) in got.items():
         r = pos if y_order == 1 else order[pos]
         assert r not in hub

@@ -50,8 +50,8 @@ def test_streams_decode_to_the_csr(dasp, oracle, m, n, seed, cb, rb, natural):
 @pytest.mark.parametrize("natural", [False, True])
 def test_hybrid_hub_rows_leave_the_streams(dasp, natural, tmp_path):
     """r6: the rows of >= max(block_longest, 64 x column blocks) nonzeros of a two-phase plan go column-blocked (Plan::lcb, the kernels of the column
-    panels' hub rows) when they hold >= a sixteenth of the nonzeros; long_cb = -1 keeps every row in the streams; fewer than that: no hybrid; the plan file round-trips"""
-    lens = [5] * 2000 + [300, 2999, 0, 256, 255, 1200] + [17] * 500 + [1] * 300
+    panels' hub rows) when they hold >= a quarter of the nonzeros; long_cb = -1 keeps every row in the streams; fewer than that: no hybrid; the plan file round-trips"""
+    lens = [5] * 700 + [300, 2999, 0, 256, 255, 1200] + [17] * 500 + [1] * 300          # 4755 of 17310 nonzeros in the four rows of >= 256
     rp, ci, v = util.csr_from_lengths(lens, 3000, 17, values="f16", dtype=np.float16)
     m = len(lens)
     kw = dict(precision=16, two_phase=1, y_order=dasp.Y_NATURAL if natural else dasp.Y_PERMUTED)

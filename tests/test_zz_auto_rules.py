@@ -1,0 +1,173 @@
+"""The automatic layout rules against each forced alternative (the r5 size sweep found three rules wrong away from the size they were tuned at).
+
+For ~20 structures -- three sizes each of a band (cop20k_A), a stencil / FEM mesh (nlpkkt160, HV15R), a power-law and an R-MAT graph, plus circuit-like, all-short and
+all-long matrices -- the plan the library builds by itself is timed against the same matrix with ONE knob forced the other way (x windows on / off, column panels 1 / 2 /
+4, the two-phase form on / off, column-blocked hub rows on / off, slabs on / off, 16-bit and one-byte ids on / off, medium rows as pieces on / off, wave-segmented short
+rows on / off).  The automatic plan may not be more than 7 % slower than the best of them.  Pairs that are known to lose more are listed in KNOWN with the measured ratio
+(an honest table, not a waiver: a KNOWN entry that no longer loses fails too, so that the list shrinks).  Last in the alphabet on purpose: with `pytest -x` a noisy box
+fails this file, not the parity tests behind it.  The table of a run goes to gpurun_out/r6_auto_rules.md (committed copy: profiles/r06_auto_rules.md).
+
+Reference heuristics these rules replace: src/dasp_f64.h:533-536 (the reference has ONE layout and one rule, the 0.75 fill threshold)."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1.07
+
+# (family, generator, dtype, scales)
+SYNTH = [
+    ("band", "cop20k_A", 64, (0.5, 2.0, 8.0)),
+    ("band f16", "cop20k_A", 16, (1.0, 4.0)),
+    ("stencil", "nlpkkt160", 64, (0.01, 0.03, 0.1)),
+    ("FEM", "HV15R", 64, (0.01, 0.03, 0.1)),
+    ("FEM f16", "Queen_4147", 16, (0.03, 0.1)),
+    ("power-law", "powerlaw_1M", 64, (0.03, 0.1, 0.3)),
+    ("power-law f16", "powerlaw_1M", 16, (0.1, 0.3)),
+    ("R-MAT f16", "rmat_2M", 16, (0.1, 0.25, 0.5)),
+    ("web f16", "webbase-1M", 16, (1.0, 4.0)),
+]
+
+# one knob at a time, relative to the automatic plan: (label, options, applies(dtype))
+KNOBS = [
+    ("x windows off", dict(x_window=-1), lambda p: True),
+    ("x windows forced (160 KiB)", dict(x_window=160 * 1024 - 256), lambda p: True),
+    ("one column panel", dict(col_panels=1), lambda p: True),
+    ("2 column panels", dict(col_panels=2), lambda p: True),
+    ("4 column panels", dict(col_panels=4), lambda p: True),
+    ("two-phase on", dict(two_phase=1), lambda p: p == 16),
+    ("two-phase off", dict(two_phase=-1), lambda p: p == 16),
+    ("hub rows column-blocked off", dict(long_cb=-1), lambda p: True),
+    ("slabs off", dict(slab_max_len=4), lambda p: True),
+    ("slabs up to 16", dict(slab_max_len=16), lambda p: True),
+    ("16-bit ids off", dict(cid16=-1), lambda p: True),
+    ("16-bit ids on", dict(cid16=1), lambda p: True),
+    ("one-byte ids off", dict(cid8=-1), lambda p: p == 64),
+    ("one-byte ids on", dict(cid8=1, cid16=1), lambda p: p == 64),
+    ("long medium rows as pieces off", dict(piece_min_len=-1), lambda p: True),
+    ("segmented short rows off", dict(short_seg=-1), lambda p: p == 64),
+    ("segmented short rows on", dict(short_seg=1), lambda p: True),
+    ("grid as stored: long | medium | short (f16 default: short first)", dict(_env=("DASP_WG_ROT", "0")), lambda p: p == 16),
+]
+
+# (case label, knob label) -> the ratio auto / forced measured when the entry was written (> TOL): what the automatic rule is known to leave on the table
+KNOWN = {}
+
+
+def _numpy_cases():
+    rng = np.random.default_rng(11)
+
+    def from_lengths(lens, n, band):
+        m = lens.size
+        rp = np.zeros(m + 1, np.int64)
+        np.cumsum(lens, out=rp[1:])
+        rows = np.repeat(np.arange(m, dtype=np.int64), lens)
+        k = np.arange(int(rp[-1]), dtype=np.int64) - rp[rows]
+        centre = rows * n // max(m, 1)
+        start = np.clip(centre + rng.integers(-band, band + 1, m)[rows] - lens[rows] // 2, 0, np.maximum(n - lens[rows], 0))
+        return rp.astype(np.int32), (start + k).astype(np.int32), n
+
+    M = 1 << 20
+    out = []
+    for sz in (M // 4, M, 4 * M, 16 * M):
+        out.append(("all-short 1..4, %d rows" % sz, lambda sz=sz: from_lengths(rng.integers(1, 5, sz), sz, 64)))
+    for rows in (2000, 16000, 64000):
+        out.append(("all-long 300, %d rows" % rows, lambda rows=rows: from_lengths(np.full(rows, 300), 16 * rows, 4096)))
+    for sz in (M // 4, M):
+        out.append(("circuit-like, %d rows of 1..8 + 16 rows of 50 000" % sz,
+                    lambda sz=sz: from_lengths(np.concatenate([rng.integers(1, 9, sz - 16), np.full(16, 50000)])[rng.permutation(sz)], sz, 256)))
+    return out
+
+
+def _time(torch, plan, x, y, nnz):
+    iters = 400 if nnz < 2e6 else 150 if nnz < 2e7 else 60
+    return min(plan.time(x.data_ptr(), y.data_ptr(), 0, warmup=max(10, iters // 10), iters=iters)[1] for _ in range(2))
+
+
+@pytest.mark.gpu
+def test_automatic_plan_is_within_7_percent_of_every_forced_form(dasp, torch_cuda):
+    torch = torch_cuda
+    D = dasp
+    t_start = time.time()
+    cases = []
+    for fam, gen, prec, scales in SYNTH:
+        for sc in scales:
+            cases.append(("%s: %s x%g f%d" % (fam, gen, sc, prec), prec, (lambda gen=gen, sc=sc: D.synth_csr(gen, sc) + (D.synth_dims(gen, sc)[1],))))
+    for label, make in _numpy_cases():
+        for prec in (64, 16):
+            cases.append(("%s f%d" % (label, prec), prec, make))
+    table, bad, stale = [], [], []
+    for label, prec, make in cases:
+        rp, ci, n = make()
+        m = rp.size - 1
+        dt, tdt = (np.float64, torch.float64) if prec == 64 else (np.float16, torch.float16)
+        v = np.ones(ci.size, dt)
+        x = torch.ones(n, dtype=tdt, device="cuda")
+        y = torch.zeros(m, dtype=tdt, device="cuda")
+        auto = D.Plan(rp, ci, v, n, precision=prec).upload()
+        st = auto.stats
+        form = "two-phase%s" % (" + hub rows" if st["lcb_rows"] else "") if st["two_phase"] else ("%d panels%s" % (st["n_col_panels"], " + hub rows" if st["lcb_rows"] else "") if st["n_col_panels"]
+                                                                                                   else ("LDS windows" if st["x_window_on"] else "plain"))
+        t_auto = _time(torch, auto, x, y, ci.size)
+        want = torch.from_numpy(np.diff(rp)[auto.order_rid].astype(np.float64)).cuda()
+        got = y.double()
+        fine = (got - want).abs() <= (0.0 if prec == 64 else 1e-2) * want.clamp(min=1)
+        assert bool((torch.where(want > 65504.0, torch.isinf(got) | fine, fine) if prec == 16 else fine).all().item()), label      # (f16: a row longer than binary16 holds is +inf)
+        alts = []
+        for klabel, kw, applies in KNOBS:
+            if not applies(prec):
+                continue
+            kw = dict(kw)
+            env = kw.pop("_env", None)
+            try:
+                plan = D.Plan(rp, ci, v, n, precision=prec, **kw)
+            except D.DaspError:
+                continue                                   # a form this matrix cannot take (two-phase of an empty matrix ...)
+            ps = plan.stats
+            same = all(ps[k] == st[k] for k in ("two_phase", "n_col_panels", "x_window_on", "cid16_on", "cid8_chunks", "short_seg", "med_rows_as_pieces", "lcb_rows", "n_short_tiles",
+                                                "n_med_blocks", "n_long_pieces", "n_windows"))
+            if same and env is None:                       # the knob changes nothing on this matrix: the automatic plan already is that form
+                plan.close()
+                continue
+            if env is not None:                            # a launch-side knob the library reads from the environment at upload
+                if st["two_phase"] or st["n_col_panels"] or st["x_window_on"] or st["n_short_tiles"] == 0:
+                    plan.close()
+                    continue
+                os.environ[env[0]] = env[1]
+            try:
+                plan.upload()
+            finally:
+                if env is not None:
+                    del os.environ[env[0]]
+            t = _time(torch, plan, x, y, ci.size)
+            if t_auto > TOL * t:                           # before calling it a loss: both once more, interleaved
+                t_auto = min(t_auto, _time(torch, auto, x, y, ci.size))
+                t = min(t, _time(torch, plan, x, y, ci.size))
+            alts.append((klabel, t))
+            plan.close()
+        best = min(alts, key=lambda a: a[1]) if alts else ("-", t_auto)
+        b_alg = ci.size * (prec // 8 + 4) + (m + 1) * 4 + (n + m) * (prec // 8)
+        table.append((label, ci.size, form, t_auto * 1e3, b_alg / (t_auto * 1e6) / 8000, best[0], best[1] * 1e3, t_auto / best[1]))
+        for klabel, t in alts:
+            ratio = t_auto / t
+            known = KNOWN.get((label, klabel))
+            if ratio > TOL and known is None:
+                bad.append("%s: automatic %.1f us, '%s' %.1f us (%.2f x)" % (label, t_auto * 1e3, klabel, t * 1e3, ratio))
+            if known is not None and ratio <= 1.02:
+                stale.append("%s / %s: listed in KNOWN at %.2f x, now %.2f x -- remove the entry" % (label, klabel, known, ratio))
+        auto.close()
+        del x, y
+        torch.cuda.empty_cache()
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "r6_auto_rules.md"), "w") as f:
+            f.write("| structure | nonzeros | automatic form | automatic us | fraction of 8 TB/s | fastest forced alternative | its us | automatic / fastest |\n|---|---|---|---|---|---|---|---|\n")
+            for r in table:
+                f.write("| %s | %d | %s | %.1f | %.3f | %s | %.1f | %s |\n" % (r[0], r[1], r[2], r[3], r[4], r[5], r[6], ("**%.2f**" if r[7] > TOL else "%.2f") % r[7]))
+            f.write("\n%d structures, %.0f s.  Bold: the automatic plan is more than 7 %% slower than one forced knob.\n" % (len(table), time.time() - t_start))
+            for b in bad:
+                f.write("* LOSS: %s\n" % b)
+    assert not bad, "\n".join(bad)
+    assert not stale, "\n".join(stale)

@@ -135,6 +135,14 @@ def decode_plan(plan):
     for i in range(md.size):
         for q in range(mp[i], mp[i + 1]):
             part_owner[q] = int(md[i])
+    # 16-bit ids of the long pieces (r6, plan.hpp long_cid16): chunk i of piece p has base long_base[piece_c16[2 p] + i]; a narrow piece's columns are also
+    # base + u16 offset (0xFFFF = pad) -- decoded from THOSE here, so that a plan whose 16-bit ids disagreed with its 32-bit ones would not decode to the CSR
+    pc16 = plan.host_array("piece_c16").reshape(-1, 2)
+    assert pc16.shape[0] == pd.size
+    have16 = pd.size > 0 and lc.size > 0
+    if have16:
+        l16, lb = plan.host_array("long_cid16"), plan.host_array("long_base")
+        assert l16.size == lc.size and lb.size == sum(-(-(int(pp[p + 1]) - int(pp[p])) // CH) for p in range(pd.size))
     for p in range(pd.size):
         dst = int(pd[p])
         slot = dst if dst >= 0 else part_owner[~dst]
@@ -142,6 +150,20 @@ def decode_plan(plan):
             slot = int(inv[slot])
         c = lc[pp[p]:pp[p + 1]]
         v = lv[pp[p]:pp[p + 1]]
+        if have16:
+            o = l16[pp[p]:pp[p + 1]].astype(np.int64)
+            bases = np.repeat(lb[pc16[p, 0]: pc16[p, 0] + -(-c.size // CH)], CH)[:c.size].astype(np.int64)
+            real = c >= 0
+            lo = np.array([c[k:k + CH][c[k:k + CH] >= 0].min() if (c[k:k + CH] >= 0).any() else 0 for k in range(0, c.size, CH)])
+            assert np.array_equal(lb[pc16[p, 0]: pc16[p, 0] + lo.size], lo)                      # the base is the chunk's smallest column
+            spans_fit = all((c[k:k + CH][c[k:k + CH] >= 0].max() - lo[k // CH] <= 65534) if (c[k:k + CH] >= 0).any() else True for k in range(0, c.size, CH))
+            assert bool(pc16[p, 1]) == (spans_fit and c.size >= 4 * CH)                             # (pieces of fewer than four whole chunks keep their 32-bit ids: plan.hpp kLong16MinChunks)
+            if pc16[p, 1]:
+                assert ((o == 0xFFFF) == ~real).all()
+                c = np.where(real, bases + o, -1).astype(c.dtype)                               # the columns as the kernel derives them
+                assert np.array_equal(c, lc[pp[p]:pp[p + 1]])
+            else:
+                assert (o == 0).all()
         keep = c >= 0
         cs, vs = out.setdefault(slot, ([], []))
         cs.extend(c[keep].tolist())
