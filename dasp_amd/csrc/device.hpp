@@ -105,6 +105,8 @@ struct DevicePlan {
     // trips for 3-8 KB) -- such a plan runs the build held to 72 registers = 7 waves per SIMD (kernels.hip; r5: rows of 40 0.74 -> 0.83, rows of 17 0.65 -> 0.71 of the
     // roofline; the pipelined blocks of long medium rows lose 4 % in that build and keep the unconstrained one)
     bool seven_waves = false;
+    // r6: >= 5 % of the plan's nonzeros sit in narrow long pieces (plan.hpp long_cid16) of a plain plan: launch the builds that read their 16-bit ids (kernels.hip L16)
+    bool long16 = false;
     int device = -1;
     // column-panel parent: arena = the panels' partial results, panel k at ypart + k * ypart_stride elements
     size_t ypart_stride = 0;
@@ -113,6 +115,7 @@ struct DevicePlan {
 
 int require_device();                  // upload.cpp: DASP_OK, or DASP_ERR_NO_DEVICE with the error text set
 int upload_plan(Plan &p);
+void choose_long16(Plan &p);           // upload.cpp
 int sync_dev_args(Plan &p);            // upload.cpp: DevicePlan::dargs = DevicePlan::args (a memcmp when nothing changed; a blocking copy otherwise -- never inside a stream capture: upload and the placement trials leave it in sync)
 int upload_plan_unpacked(Plan &p);     // for the device packers: arena + O(rows) arrays, no placement trials yet
 // kernels.hip: one SpMV of an uploaded plan (asynchronous); what upload.cpp asks the kernels

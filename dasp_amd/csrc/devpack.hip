@@ -392,6 +392,7 @@ static int pack_all_typed(Plan &p, const DevCsr &d, const PackMeta &m)
                                reinterpret_cast<int *>(base + dp.map.long_base), reinterpret_cast<unsigned short *>(base + dp.map.long_cid16));
             HIP_TRYP(hipGetLastError());
             HIP_TRYP(hipMemcpy(p.piece_c16.data(), pc16, p.piece_c16.size() * sizeof(int), hipMemcpyDeviceToHost));      // which pieces are narrow: back to the host (plan files, decoders)
+            choose_long16(p);
         }
         HIP_TRYP(hipDeviceSynchronize());
     }

@@ -41,7 +41,10 @@ extern int g_stamp_launch;
 #endif
 
 // MW (f64, no windows): 7 = the build held to 72 registers = 7 waves per SIMD, for plans of one-shot blocks (DevicePlan::seven_waves)
-template <class T, bool NT, bool C16, bool WIN, bool C8 = false, int MW = 0>
+// L16 (r6): the build that reads the 16-bit ids of narrow long pieces (plan.hpp long_cid16) -- instantiations of their own, launched for plans in which those pieces
+// matter (DevicePlan::long16): compiled into the ordinary builds, the third piece source cost every plan 1-3 % (HV15R-unstructured 507 -> 523 us, powerlaw_1M 374 -> 379,
+// webbase-1M f64 28.9 -> 29.3, same box) for code that only long-row matrices run
+template <class T, bool NT, bool C16, bool WIN, bool C8 = false, int MW = 0, bool L16 = false>
 __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : MW ? MW : kMinWavesPlain) void dasp_spmv_kernel(CallArgs c)
 {
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
@@ -51,7 +54,8 @@ __global__ __launch_bounds__(WIN ? 1024 : 256, WIN ? kMinWavesWin : MW ? MW : kM
     Stamps st; st.begin(0);
 #endif
     const DevArgs a = load_args(c);
-    spmv_body<T, NT, C16, WIN, C8, false, WIN, !WIN && !C8 && MW == 0>(a, lds_raw, blockIdx.x, st);
+    static_assert(!L16 || (!WIN && !C8 && MW == 0), "the 16-bit long ids ride in the plain build only");
+    spmv_body<T, NT, C16, WIN, C8, false, WIN, L16>(a, lds_raw, blockIdx.x, st);
 #ifdef DASP_STAMPS
     st.finish(a.wpw);
 #endif
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 7 : kMinWavesPlain) void dasp
     Stamps st; st.begin(0);
 #endif
     const DevArgs a = load_args(c);
-    spmv_body<T, NT, C16, false, false, true, false, true>(a, lds_raw, blockIdx.x, st);
+    spmv_body<T, NT, C16, false, false, true>(a, lds_raw, blockIdx.x, st);
 }
 
 // the windowed kernel for plans with at most one window workgroup per CU (n_windows <= CUs: cop20k_A's 212): nothing is gained by
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 7 : kMinWavesPlain) void dasp
     const CallArgs ca = panel_of(c, wg);
     Stamps st; st.begin(0);
     const DevArgs a = load_args(ca);
-    spmv_body<T, NT, C16, false, false, true, false, true>(a, lds_raw, wg, st);
+    spmv_body<T, NT, C16, false, false, true>(a, lds_raw, wg, st);
 }
 
 // stage 2 for long rows cut into several pieces (reference: longPart_sum, dasp_f64.h:53-75)
@@ -506,6 +510,11 @@ static int launch_typed(Plan &p, const DevArgs &a, hipStream_t s)
             }
             else if (nt) hipLaunchKernelGGL((dasp_spmv_kernel<double, true, true, false, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
             else hipLaunchKernelGGL((dasp_spmv_kernel<double, false, true, false, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
+        } else if (!p.windowed && p.dev->long16 && !(sizeof(T) == 8 && p.dev->seven_waves)) {      // narrow long pieces that matter: the builds that read their 16-bit ids
+            if (nt && c16) hipLaunchKernelGGL((dasp_spmv_kernel<T, true, true, false, false, 0, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
+            else if (nt) hipLaunchKernelGGL((dasp_spmv_kernel<T, true, false, false, false, 0, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
+            else if (c16) hipLaunchKernelGGL((dasp_spmv_kernel<T, false, true, false, false, 0, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
+            else hipLaunchKernelGGL((dasp_spmv_kernel<T, false, false, false, false, 0, true>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
         } else if (sizeof(T) == 8 && !p.windowed && p.dev->seven_waves) {
             if (nt && c16) hipLaunchKernelGGL((dasp_spmv_kernel<double, true, true, false, false, 7>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);
             else if (nt) hipLaunchKernelGGL((dasp_spmv_kernel<double, true, false, false, false, 7>), dim3(grid), dim3(kWave * a.wpw), lds, s, c);

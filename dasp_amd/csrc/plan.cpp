@@ -1023,6 +1023,9 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
             total8 += n8of[b]; total += nchunks[b];
         }
         if (p.opt.cid8 == 0 && total8 * 10 < total) std::fill(n8of.begin(), n8of.end(), 0);
+        // ... and (r6) only from 64 MiB of CSR on, where the 16-bit ids used to start and the one-byte ids were tuned: below it the launch is latency-bound and the 80-register
+        // build with its longer id decode loses (HV15R x0.01, 30 MB: 8.1 -> 9.1 us when the lower 16-bit bound of r6 brought them along: tests/test_zz_auto_rules.py)
+        if (p.opt.cid8 == 0 && p.opt.cid16 == 0 && (long long)nnz * (geo.vbytes + 4) <= (64ll << 20)) std::fill(n8of.begin(), n8of.end(), 0);      // (a caller who forces the 16-bit ids on a small matrix keeps the r5 rule)
     }
     lap("chunk split (+cid16 spans)");
     p.med_ptr.assign((size_t)nb + 1, 0);
@@ -1147,12 +1150,16 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
     // spill more with the DPP path compiled in: cop20k_A 11.1 -> 12.0 us; f16 gains nothing: DESIGN.md section 3)
     {
         const int SR = geo.short_rows;
-        bool seg = p.opt.short_seg > 0 || (p.opt.short_seg == 0 && !f16 && !p.windowed);
-        if (seg && p.opt.short_seg == 0 && !meta_only) {
-            // r6 (tests/test_zz_auto_rules.py): in a slab a lane owns whole rows, so the 64 lanes of a step gather for 128 neighbouring rows of one length -- where neighbouring
-            // short rows read neighbouring columns (road networks, meshes' boundary rows) those gathers coalesce and the slabs win: rows of 1..4 within +-64 columns of the
-            // diagonal, 262 k / 1 M / 4 M rows, 4.9 / 15.5 / 50.2 us segmented against 3.9 / 12.3 / 46.9 as slabs; graph rows (webbase-1M f64: 30.6 -> 28.4 us segmented) keep
-            // the segmented tiles.  The measure of the slab rule above: pairs of successive rows of one length, positions whose columns differ by < 16.
+        const bool seg = p.opt.short_seg > 0 || (p.opt.short_seg == 0 && !f16 && !p.windowed);
+        int seg_max_len = 4;          // the longest rows that take the segmented layout
+        if (seg && p.opt.short_seg == 0 && !meta_only && nnz_short <= (16ll << 20)) {
+            // r6 (tests/test_zz_auto_rules.py, tools/category_sweep.py): in a slab a lane owns whole rows, so the 64 lanes of a step gather for 128 neighbouring rows of one
+            // length -- where neighbouring short rows read neighbouring columns (road networks, meshes' boundary rows) those gathers coalesce, and while the launch is
+            // latency-bound the slabs win: rows of 1..4 within +-64 columns of the diagonal, 262 k / 1 M / 4 M rows: 4.9 / 15.5 / 50.2 us segmented against 3.9 / 12.3 / 46.9
+            // as slabs.  At HBM scale the segmented tiles (256 elements per wave against 128 L) are the faster stream again (16 M rows: 219 against 192 us; 24 M: 356 / 325
+            // with slabs for lengths 3 and 4 only) -- hence the bound of 16 M short nonzeros.  Graph rows (webbase-1M f64: 30.6 -> 28.4 us segmented) keep the segmented
+            // tiles at every size.  The measure of the slab rule above -- pairs of successive rows of one length -- with a wider test: positions whose columns differ by < 256
+            // (a tile's 128 rows then read a few KB of x: L1 hits, whatever the order inside)
             std::vector<int> pairs;
             for (int g = 0; g < 4; ++g) {
                 const std::vector<int> &list = *glist[g];
@@ -1160,19 +1167,19 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                 for (size_t i = 0; i + 1 < list.size(); i += (size_t)step) { pairs.push_back(list[i]); pairs.push_back(list[i + 1]); }
             }
             long long near = 0, entries = 0;
-            if (dev) { if (int rc = devpack_row_coherence(p, *dev, pairs, 16, &near, &entries)) return rc; }
+            if (dev) { if (int rc = devpack_row_coherence(p, *dev, pairs, 256, &near, &entries)) return rc; }
             else
                 for (size_t q = 0; q + 1 < pairs.size(); q += 2) {
                     const int a = rp[pairs[q]], b = rp[pairs[q + 1]], len = rp[pairs[q] + 1] - a;
-                    for (int k = 0; k < len; ++k) { const int d = remap(ci[a + k]) - remap(ci[b + k]); near += d > -16 && d < 16; }
+                    for (int k = 0; k < len; ++k) { const int d = remap(ci[a + k]) - remap(ci[b + k]); near += d > -256 && d < 256; }
                     entries += len;
                 }
-            if (entries >= 256 && 2 * near >= entries) seg = false;
+            if (entries >= 256 && 2 * near >= entries) seg_max_len = 0;
         }
         long long off = 0; int tile0 = 0;
         for (int g = 0; g < kNumShortGroups; ++g) {
             ShortGroup &G = p.grp[g];
-            G.seg = seg && !p.windowed && G.len >= 1 && G.len <= 4 && g < 5 ? 1 : 0;
+            G.seg = seg && !p.windowed && G.len >= 1 && G.len <= seg_max_len && g < 5 ? 1 : 0;
             G.rpt = G.seg ? short_seg_rows(G.len) : SR;
             G.tiles = ceil_div(G.count, G.rpt);
             G.tile0 = tile0; G.elem_off = off;

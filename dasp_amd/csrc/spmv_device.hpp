@@ -264,29 +264,33 @@ struct ChunkSrc {
 // a long piece: nfull whole chunks, then (tail > 0) its last, partial chunk as one more step of the SAME stream (r5: issued beside the whole chunks instead of behind
 // their gathers -- a row of 300 is four chunks and a tail, and a wave's life was two dependent rounds of stream + gather instead of one: tools/category_sweep.py).
 // Rows are padded to kLongAlign, so a lane's group of the tail is all-in or all-out; lanes beyond it re-read the piece's first group (in bounds) and gather x[0] times 0.
-template <class T, bool NT>
+template <class T, bool NT, bool N16 = false>
 struct PieceSrc {
     static constexpr bool kPairs = false, kQuadIds = false;
     static constexpr int VPL = Tr<T>::CHUNK / kWave;
     const T *val; const int *cid; size_t e0; int lane, nfull, tail;
-    // r6 (plan.hpp long_cid16): a NARROW piece (wave-uniform flag) reads its ids as u16 offsets -- 2 instead of 4 bytes per element -- from its chunks' base columns, a scalar
-    // load per step; 0xFFFF = pad.  The same elements in the same lanes as the 32-bit form, so the same bits.  base = the piece's first entry of long_base.
-    bool narrow = false; const unsigned short *cid16 = nullptr; const int *base = nullptr;
+    // N16 (r6, plan.hpp long_cid16): a NARROW piece reads its ids as u16 offsets -- 2 instead of 4 bytes per element -- from its chunks' base columns, a scalar load per
+    // step; 0xFFFF = pad.  The same elements in the same lanes as the 32-bit form, so the same bits.  base = the piece's first entry of long_base.  An instantiation of its
+    // own, chosen per piece: with a run-time flag inside ONE instantiation the wide pieces pay for the tests too (f16 rows of 300: 131 -> 144 us)
+    const unsigned short *cid16 = nullptr; const int *base = nullptr;
     template <bool PAIRED_OK = true> __device__ __forceinline__ void load(Frag<T> &f, int i) const
     {
-        const size_t at = i < nfull || VPL * lane < tail ? e0 + (size_t)i * Tr<T>::CHUNK + (size_t)(VPL * lane) : e0;
-        if (narrow) {
+        if constexpr (N16) {
+            const size_t at = i < nfull || VPL * lane < tail ? e0 + (size_t)i * Tr<T>::CHUNK + (size_t)(VPL * lane) : e0;
             if constexpr (VPL == 1) { f.a = ldg<NT>(val + at); f.c = (int)ldg<NT>(cid16 + at); }
             else {
                 f.a = ldg<NT>(reinterpret_cast<const f16x4 *>(val + at));
                 const i32x2 o = ldg<NT>(reinterpret_cast<const i32x2 *>(cid16 + at));      // raw u16 offsets, two per dword; unpacked and rebased in gather()
                 f.c[0] = o[0]; f.c[1] = o[1];
             }
-        } else frag_load_at<NT>(f, val, cid, at);
+        } else {
+            if (i < nfull) frag_load<NT>(f, val, cid, e0 + (size_t)i * Tr<T>::CHUNK, lane);
+            else frag_load_at<NT>(f, val, cid, VPL * lane < tail ? e0 + (size_t)i * Tr<T>::CHUNK + (size_t)(VPL * lane) : e0);
+        }
     }
     template <bool QUAD = false, class XV> __device__ __forceinline__ void gather(Frag<T> &f, int i, const XV &x) const
     {
-        if (narrow) {
+        if constexpr (N16) {
             const int b = tab<true>(base, i);                   // wave-uniform: one scalar load per step
             if constexpr (VPL == 1) { const unsigned o = (unsigned)f.c; f.c = o == kLongPad16 ? -1 : b + (int)o; }
             else {
@@ -685,10 +689,12 @@ __device__ __forceinline__ void long_piece(const DevArgs &a, int p, int lane)
     // multi-GPU step kernels sit at their register ceilings and read the 32-bit ids every piece keeps; the r6 attempt cost the one-byte-id build a 36-byte frame)
     bool narrow = false;
     if constexpr (L16) narrow = tab<true>(a.piece_c16, 2 * p + 1) != 0;
-    if (TAIL_IN && (tail > 0 || narrow)) {       // (wide pieces of whole chunks -- every piece but the last of a row cut in pieces -- keep the stream without the per-step tests: rmat_2M f64 +1.3 % with it)
-        PieceSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane, nfull, tail};
-        if constexpr (L16) { src.narrow = narrow; src.cid16 = a.long_cid16; src.base = a.long_base + tab<true>(a.piece_c16, 2 * p); }
+    if (L16 && narrow) {
+        const PieceSrc<T, NT, true> src{val, a.long_cid, (size_t)p0, lane, nfull, tail, a.long_cid16, a.long_base + tab<true>(a.piece_c16, 2 * p)};
         run_stream<T, Tr<T>::BATCH, Tr<T>::LONG_SHOT>(acc, src, nfull + (tail > 0 ? 1 : 0), x);
+    } else if (TAIL_IN && tail > 0) {       // (pieces of whole chunks -- every piece but the last of a row cut in pieces -- keep the stream without the per-step test: rmat_2M f64 +1.3 % with it)
+        const PieceSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane, nfull, tail};
+        run_stream<T, Tr<T>::BATCH, Tr<T>::LONG_SHOT>(acc, src, nfull + 1, x);
     } else {
         const int full = p0 + nfull * CH;
         ChunkSrc<T, NT> src{val, a.long_cid, (size_t)p0, lane};

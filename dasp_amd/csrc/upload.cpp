@@ -90,6 +90,20 @@ static int upload_long_cb(Plan &p, DevicePlan *d, const LcbOffsets &o)
     return DASP_OK;
 }
 
+// DevicePlan::long16 from the pieces' narrow flags (host-built plans: at upload; device-built ones: again once the device packer has sent the flags back)
+void choose_long16(Plan &p)
+{
+    DevicePlan *d = p.dev;
+    if (!d) return;
+    d->long16 = false;
+    if (!p.windowed && p.cnt_reg8 == 0 && p.piece_c16.size() == 2 * p.piece_dst.size() && !p.piece_dst.empty()) {
+        long long narrow = 0;
+        for (size_t q = 0; q < p.piece_dst.size(); ++q) if (p.piece_c16[2 * q + 1]) narrow += p.piece_ptr[q + 1] - p.piece_ptr[q];
+        d->long16 = narrow * 20 >= (long long)p.nnz && narrow > 0;
+        if (const char *e = std::getenv("DASP_LONG16")) d->long16 = std::atoi(e) != 0;      // A/B knob
+    }
+}
+
 int upload_plan(Plan &p);
 static int upload_plan_impl(Plan &p)
 {
@@ -242,6 +256,7 @@ static int upload_plan_impl(Plan &p)
     if (const char *e = std::getenv("DASP_WIN_XCD")) a.win_xcd = std::atoi(e);      // A/B knob
     d->win1 = false;
     d->seven_waves = false;
+    choose_long16(p);
     if (p.precision == 64 && !p.windowed && p.med_ptr.size() > 1 && p.irr_ptr.size() > 1) {
         long long one = 0, all = 0;
         const int K = p.geo.med_k, nbk = (int)p.med_ptr.size() - 1;

@@ -106,7 +106,8 @@ typedef struct dasp_options {
      *             > 0 = force on with this many bytes of LDS per workgroup as the cap (<= 163840; auto uses 81920,
      *                   i.e. two workgroups per CU, and falls back to 163840 when the spans do not fit that)
      *   row_window: rows per window, multiple of 16 (one block) from 64 up to 1024 (up to 16 waves per workgroup, 1-4 blocks per wave);
-     *               0 = by size: ~224 windows (one per CU, with slack), ~448 once a window would pass 1024 rows */
+     *               0 = by size: as many windows as put a workgroup on every CU and none behind another (windows rounded up to 8 + long + short workgroups <= 256; r6),
+     *               ~448 (two per CU) once a window would pass 1024 rows */
     int x_window;
     int row_window;
     /* 16-bit column ids for the regular medium tiles: u16 offsets from a per-chunk base column (10 instead of 12 bytes

@@ -24,18 +24,21 @@ def isa():
     return rows
 
 
-PLAIN64 = ["dasp_spmv_kernel<double,%d,%d,0,%d,0>" % (nt, c16, c8) for nt in (0, 1) for c16, c8 in ((0, 0), (1, 0), (1, 1))]
-SEVEN64 = [k[:-3] + ",7>" for k in PLAIN64]        # r5: the same held to 7 waves per SIMD, for plans of one-shot blocks (DevicePlan::seven_waves)
-PLAIN16 = ["dasp_spmv_kernel<half,%d,%d,0,0,0>" % (nt, c16) for nt in (0, 1) for c16 in (0, 1)]
+PLAIN64 = ["dasp_spmv_kernel<double,%d,%d,0,%d,0,0>" % (nt, c16, c8) for nt in (0, 1) for c16, c8 in ((0, 0), (1, 0), (1, 1))]
+SEVEN64 = [k[:-5] + ",7,0>" for k in PLAIN64]      # r5: the same held to 7 waves per SIMD, for plans of one-shot blocks (DevicePlan::seven_waves)
+PLAIN16 = ["dasp_spmv_kernel<half,%d,%d,0,0,0,0>" % (nt, c16) for nt in (0, 1) for c16 in (0, 1)]
+# r6: the builds that read the 16-bit ids of narrow long pieces (DevicePlan::long16): the plain kernels' budget
+LONG16_64 = ["dasp_spmv_kernel<double,%d,%d,0,0,0,1>" % (nt, c16) for nt in (0, 1) for c16 in (0, 1)]
+LONG16_16 = ["dasp_spmv_kernel<half,%d,%d,0,0,0,1>" % (nt, c16) for nt in (0, 1) for c16 in (0, 1)]
 RT64 = ["dasp_spmv_rt_kernel<double,%d,%d>" % (nt, c16) for nt in (0, 1) for c16 in (0, 1)]
 RT16 = ["dasp_spmv_rt_kernel<half,%d,%d>" % (nt, c16) for nt in (0, 1) for c16 in (0, 1)]
-WIN = ["dasp_spmv_kernel<%s,%d,%d,1,0,0>" % (t, nt, c16) for t in ("double", "half") for nt in (0, 1) for c16 in (0, 1)]
+WIN = ["dasp_spmv_kernel<%s,%d,%d,1,0,0,0>" % (t, nt, c16) for t in ("double", "half") for nt in (0, 1) for c16 in (0, 1)]
 WIN1 = ["dasp_spmv_win1_kernel<%s,%d>" % (t, c16) for t in ("double", "half") for c16 in (0, 1)]
 STEP = ["dasp_mg_step_kernel<0>", "dasp_mg_step_kernel<1>", "dasp_mg_step2_kernel<0>", "dasp_mg_step2_kernel<1>"]
 
 
 def test_every_kernel_of_the_hot_path_is_there(isa):
-    for k in PLAIN64 + SEVEN64 + PLAIN16 + RT64 + RT16 + WIN + WIN1 + STEP + ["dasp_long_reduce_kernel<double>", "dasp_long_reduce_kernel<half>",
+    for k in PLAIN64 + SEVEN64 + PLAIN16 + LONG16_64 + LONG16_16 + RT64 + RT16 + WIN + WIN1 + STEP + ["dasp_long_reduce_kernel<double>", "dasp_long_reduce_kernel<half>",
                                                                     "dasp_panel_sum_kernel<double,2>", "dasp_panel_sum_kernel<half,8>"]:
         assert k in isa, k
     # the MFMA kernels issue MFMAs, and agree on wave64 geometry: 4 waves of 64 (256) or a window workgroup (1024)
@@ -46,13 +49,13 @@ def test_every_kernel_of_the_hot_path_is_there(isa):
 def test_plain_kernels_have_no_scratch_and_keep_their_occupancy(isa):
     """DESIGN.md 4.4 / kernels.hip: the non-windowed kernels never spill; f64 <= 80 VGPRs (6 waves per SIMD), f16 <= 72 (7 waves; the row-tile
     build is held there by its launch bound)"""
-    for k in PLAIN64 + RT64:
+    for k in PLAIN64 + RT64 + LONG16_64:
         r = isa[k]
         # no scratch INSTRUCTION and no spilled VGPR.  (r5: the 32-bit-id row-tile build reports a 36-byte private segment that nothing accesses -- the frame slots of nine
         # SGPRs spilled to VGPR lanes at the 104-SGPR ceiling; the product reaches that code through dasp_spmv_panels_kernel, which has none.)
         assert r["vgpr_spill_count"] == 0 and r["scratch"] == 0 and r["private_segment_fixed_size"] <= (64 if k in RT64 else 0), (k, r)
         assert r["vgpr_count"] <= 80, (k, r["vgpr_count"])
-    for k in PLAIN16 + RT16:
+    for k in PLAIN16 + RT16 + LONG16_16:
         r = isa[k]
         assert r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0 and r["scratch"] == 0, (k, r)
         assert r["vgpr_count"] <= 72, (k, r["vgpr_count"])
@@ -73,8 +76,8 @@ def test_row_tables_stay_scalar_loads(isa):
     # the row-tile build must not lose scalar loads against the kernel without tiles (the f64 panel kernel is the one the cliff was found on)
     for nt in (0, 1):
         for c16 in (0, 1):
-            assert isa["dasp_spmv_rt_kernel<double,%d,%d>" % (nt, c16)]["s_load"] >= isa["dasp_spmv_kernel<double,%d,%d,0,0,0>" % (nt, c16)]["s_load"] - 40      # (how loads merge differs by a few dozen)
-            assert isa["dasp_spmv_rt_kernel<half,%d,%d>" % (nt, c16)]["s_load"] >= isa["dasp_spmv_kernel<half,%d,%d,0,0,0>" % (nt, c16)]["s_load"] - 8
+            assert isa["dasp_spmv_rt_kernel<double,%d,%d>" % (nt, c16)]["s_load"] >= isa["dasp_spmv_kernel<double,%d,%d,0,0,0,0>" % (nt, c16)]["s_load"] - 40      # (how loads merge differs by a few dozen)
+            assert isa["dasp_spmv_rt_kernel<half,%d,%d>" % (nt, c16)]["s_load"] >= isa["dasp_spmv_kernel<half,%d,%d,0,0,0,0>" % (nt, c16)]["s_load"] - 8
     for k in PLAIN16 + RT16:
         assert isa[k]["s_load"] >= 25, (k, isa[k]["s_load"])
     # pointers of the device-resident argument block must be known to be GLOBAL (ldp in load_args): as flat pointers every table and tile load becomes
@@ -93,7 +96,7 @@ def test_windowed_kernels_keep_their_register_cap_and_known_scratch(isa):
     costs in scratch is an accepted, recorded figure -- growth is a regression.  The one-window-per-CU build (win1) has no cap and no scratch."""
     # r6 (VERDICT r5 weak #8 / next #7): the f64 builds run their blocks in batches of 3 (one shot up to 6 steps) instead of the plain kernels' 4 / 8 and no longer spill
     # (60 / 40 bytes of scratch, 12-29 VGPRs in r5; cop20k_A x16 114.1 -> 103.1 us, x64 438 -> 413); the f16 build with 32-bit ids keeps its two spilled registers
-    accepted = {"dasp_spmv_kernel<double,0,0,1,0,0>": 0, "dasp_spmv_kernel<double,0,1,1,0,0>": 0, "dasp_spmv_kernel<half,0,0,1,0,0>": 12, "dasp_spmv_kernel<half,0,1,1,0,0>": 0}
+    accepted = {"dasp_spmv_kernel<double,0,0,1,0,0,0>": 0, "dasp_spmv_kernel<double,0,1,1,0,0,0>": 0, "dasp_spmv_kernel<half,0,0,1,0,0,0>": 12, "dasp_spmv_kernel<half,0,1,1,0,0,0>": 0}
     for k in WIN:
         r = isa[k]
         assert r["vgpr_count"] <= 64, (k, r["vgpr_count"])
