@@ -20,10 +20,10 @@ r = d["roofline"]
 out = ["# Round " + ROUND[1:].lstrip("0") + " profile of the bench command -- HV15R stand-in (2 017 169 rows, 275 454 726 nnz, f64), MI355X\n",
        ("Source: `cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-suite --no-vendor --steps 20` (kernel trace + stats only; the\n"
        "`--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes are separate runs of `dasp_bench HV15R 1 64 20 3`, `profiles/" + ROUND + "_traffic.md`), kernel sources at `kernel_rev %s`\n"
-       "(= `profiles/traffic.json`); all of it one batch on one box (`tools/round_end_" + ROUND[:1] + ROUND[2:] + ".sh`, `tools/round_end_collect.py`).  The %s profiled launches include the 200 back-to-back\n"
-       "launches behind `roofline.kernel_ms`, the 200 timed one by one for the spread (`launch_ms_*`), those of the random-values plan and those against the six y candidates (`config.placement`); the profiled average below (%.1f us over\n"
-       "all of them) and the bench line's own `kernel_ms` of the same process (%.1f us; single launches min %.1f / p10 %.1f / median %.1f / p90 %.1f / max %.1f, each including the\n"
-       "event between two kernels) agree.\n") % (hv["kernel_rev"], rows[0]["Calls"], float(rows[0]["AverageNs"]) / 1e3, r["kernel_ms"] * 1e3, r["launch_ms_min"] * 1e3,
+       "(= `profiles/traffic.json`); all of it one batch on one box (`tools/round_end_" + ROUND[:1] + ROUND[2:] + ".sh`, `tools/round_end_collect.py`).  The %s profiled launches include the timed steps behind\n"
+       "`roofline.kernel_ms` (r6: HIP events around exactly the run's --steps steps, against the first y allocated), the 200 back-to-back launches of `kernel_ms_separate_launches`, the 200 timed one by one for the spread (`launch_ms_*`), those of the\n"
+       "random-values plan and those against the six y candidates (`frac_best_of_n_y`); the profiled average below (%.1f us over all of them) and the bench line's own `kernel_ms` of the same process (%.1f us; single launches\n"
+       "min %.1f / p10 %.1f / median %.1f / p90 %.1f / max %.1f, each including the event between two kernels) agree.\n") % (hv["kernel_rev"], rows[0]["Calls"], float(rows[0]["AverageNs"]) / 1e3, r["kernel_ms"] * 1e3, r["launch_ms_min"] * 1e3,
                                             r["launch_ms_p10"] * 1e3, r["launch_ms_median"] * 1e3, r["launch_ms_p90"] * 1e3, r["launch_ms_max"] * 1e3),
        "## rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-suite --no-vendor --steps 20\n",
        "| kernel | calls | avg ns | min ns | max ns | % |\n|---|---|---|---|---|---|"]
