@@ -1,4 +1,5 @@
 #!/bin/bash
+# r6_call8 -- one gpurun batch of round 6 (its output: gpurun_out/r6/; what it measured is quoted in profiles/r06_*.md)
 out=gpurun_out/r6; mkdir -p $out
 export PYTHONPATH=$PWD
 V=$PWD/dasp_amd/variants
