@@ -61,6 +61,7 @@ struct DevArgs {
     int n_rt_tiles, wg_rt, rt_max;
     // (r6; last, so that every older field keeps its offset: the multi-GPU step kernels take this block by value and their code depends on its layout)
     const unsigned short *long_cid16; const int *long_base; const int *piece_c16;      // 16-bit ids of the narrow long pieces (plan.hpp long_cid16)
+    const int *med_nt;                                     // [blocks] tail steps of every medium block = ceil(tail entries of its first, longest row / entries per step) -- derived from irr_ptr at upload (r6)
     int wg_rot;       // workgroup b of the launch serves virtual workgroup (b + wg_rot) mod grid of the [long | medium | short] ranges (upload_plan: which category is dispatched first)
     int win_tiles;    // short tiles folded into every window workgroup (upload_plan): workgroup w also serves tiles w, w + n_windows, ... ; 0: the short tiles keep workgroups of their own
 };

@@ -119,7 +119,7 @@ __device__ __forceinline__ DevArgs load_args(const CallArgs &c)
 #define DASP_G(f) a.f = ldp(&c.plan->f)
     DASP_G(long_val); DASP_G(long_cid); DASP_G(long_cid16); DASP_G(long_base); DASP_G(piece_c16); DASP_G(piece_ptr); DASP_G(piece_dst); DASP_G(partial); DASP_G(multi_ptr); DASP_G(multi_dst);
     DASP_G(med_ptr); DASP_G(med_val); DASP_G(med_cid); DASP_G(med_cid16); DASP_G(med_base); DASP_G(med_cid8); DASP_G(med_c8ptr);
-    DASP_G(irr_ptr); DASP_G(irr_val); DASP_G(irr_cid); DASP_G(med_dst); DASP_G(win_cmin); DASP_G(win_len);
+    DASP_G(irr_ptr); DASP_G(med_nt); DASP_G(irr_val); DASP_G(irr_cid); DASP_G(med_dst); DASP_G(win_cmin); DASP_G(win_len);
     DASP_G(short_val); DASP_G(short_cid); DASP_G(groups); DASP_G(order);
     DASP_G(rt_val); DASP_G(rt_cid); DASP_G(rt_ptr); DASP_G(rt_start); DASP_G(rt_mask);
 #undef DASP_G
@@ -647,7 +647,9 @@ __device__ __forceinline__ void medium_block(const DevArgs &a, int b, int lane, 
     int t0 = 0, t1 = 0;
     if (r < a.row_block) { t0 = a.irr_ptr[r]; t1 = a.irr_ptr[r + 1]; }
     constexpr int TK = sizeof(T) == 8 ? 4 : 16;                      // tail entries of one row per MFMA step
-    const int nt = (__builtin_amdgcn_readfirstlane(t1 - t0) + TK - 1) / TK;
+    // (r6: from the per-block table, a scalar load beside med_ptr's -- the wave does not wait for the vector load of irr_ptr before it issues its tiles' loads; the multi-GPU
+    // step kernels, YS != 0, keep the form they were frozen with)
+    const int nt = YS == 0 ? tab<true>(a.med_nt, b) : (__builtin_amdgcn_readfirstlane(t1 - t0) + TK - 1) / TK;
     BlockSrc<T, NT, C16, YM != 2, C8, KT, REL> src;
     if constexpr (REL) src.relb = x.cmin; else src.relb = 0;
     src.reg.val = val; src.reg.cid = a.med_cid; src.reg.e0 = (size_t)c0 * CH; src.reg.lane = lane;

@@ -203,6 +203,17 @@ static int upload_plan_impl(Plan &p)
     const size_t o_c8p = add(p.med_c8ptr.data(), p.med_c8ptr.size() * 4);
     const size_t o_mb = add(src_of(p.med_base), p.cid16 ? (size_t)p.med_ptr.back() * 4 : 0);
     const size_t o_ip = add(p.irr_ptr.data(), p.irr_ptr.size() * 4);
+    // r6: the number of tail steps of every block, so that a wave knows its block's step count from two SCALAR loads (med_ptr, med_nt) and can issue the tiles' loads at once --
+    // it used to read it off irr_ptr with a vector load, one memory latency in front of every block's stream (the latency-bound plans: cop20k_A two blocks per wave, webbase-1M)
+    std::vector<int> med_nt((size_t)std::max(p.stats.n_med_blocks, 0), 0);
+    {
+        const int TK = p.precision == 64 ? 4 : 16;
+        for (size_t b = 0; b < med_nt.size(); ++b) {
+            const size_t r0 = b * (size_t)kMedRows;
+            if (r0 + 1 < p.irr_ptr.size()) med_nt[b] = (p.irr_ptr[r0 + 1] - p.irr_ptr[r0] + TK - 1) / TK;
+        }
+    }
+    const size_t o_mnt = add(med_nt.data(), med_nt.size() * 4);
     const size_t o_iv = add(src_of(p.irr_val), p.cnt_irr * vbytes);
     const size_t o_ic = add(src_of(p.irr_cid), p.cnt_irr * 4);
     const size_t o_mdst = add(p.med_dst.data(), p.med_dst.size() * 4);
@@ -238,7 +249,7 @@ static int upload_plan_impl(Plan &p)
     a.partial = base + o_part;
     a.n_pieces = (int)p.piece_dst.size(); a.n_multi = (int)p.multi_dst.size();
     a.med_ptr = (const int *)(base + o_mptr); a.med_val = base + o_mv; a.med_cid = (const int *)(base + o_mc);
-    a.irr_ptr = (const int *)(base + o_ip); a.irr_val = base + o_iv; a.irr_cid = (const int *)(base + o_ic);
+    a.irr_ptr = (const int *)(base + o_ip); a.med_nt = (const int *)(base + o_mnt); a.irr_val = base + o_iv; a.irr_cid = (const int *)(base + o_ic);
     a.n_blocks = p.stats.n_med_blocks; a.row_block = p.n_mfma_rows; a.row_long = p.med_slot0;
     for (int g = 0; g < kNumShortGroups; ++g) a.grp_tile0[g] = p.grp[g].tile0;
     a.short_val = base + o_sv; a.short_cid = (const int *)(base + o_sc); a.groups = (const ShortDev *)(base + o_g);
@@ -389,7 +400,7 @@ static void rebase_args(DevArgs &a, const char *from, const char *to, size_t byt
     };
     mv(a.long_val); mv(a.long_cid); mv(a.long_cid16); mv(a.long_base); mv(a.piece_c16); mv(a.piece_ptr); mv(a.piece_dst); mv(a.partial); mv(a.multi_ptr); mv(a.multi_dst);
     mv(a.med_ptr); mv(a.med_val); mv(a.med_cid); mv(a.med_cid16); mv(a.med_base); mv(a.med_cid8); mv(a.med_c8ptr);
-    mv(a.irr_ptr); mv(a.irr_val); mv(a.irr_cid); mv(a.med_dst); mv(a.win_cmin); mv(a.win_len);
+    mv(a.irr_ptr); mv(a.med_nt); mv(a.irr_val); mv(a.irr_cid); mv(a.med_dst); mv(a.win_cmin); mv(a.win_len);
     mv(a.short_val); mv(a.short_cid); mv(a.groups); mv(a.order);
 }
 

@@ -27,7 +27,7 @@ SYNTH = [
     ("power-law", "powerlaw_1M", 64, (0.03, 0.1, 0.3)),
     ("power-law f16", "powerlaw_1M", 16, (0.1, 0.3)),
     ("R-MAT f16", "rmat_2M", 16, (0.1, 0.25, 0.5)),
-    ("web f16", "webbase-1M", 16, (1.0, 4.0)),
+    ("web f16", "webbase-1M", 16, (1.0, 4.0, 16.0)),
     ("web f64", "webbase-1M", 64, (1.0, 4.0)),
 ]
 
