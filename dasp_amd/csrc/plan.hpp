@@ -399,7 +399,7 @@ inline int win_fold_tiles(int n_windows, int n_short_tiles)
 {
     return n_windows > 0 && n_windows <= 512 && n_short_tiles > 0 && n_short_tiles <= 2 * n_windows ? (n_short_tiles + n_windows - 1) / n_windows : 0;
 }
-constexpr int kTpDeclined = 1;          // build_two_phase under the automatic rule: the padded streams would pass 2.5 x the nonzeros (or the tile table 64 M entries) -- not an error
+constexpr int kTpDeclined = 1;          // build_two_phase under the automatic rule: the padded streams would pass 3 x the nonzeros (or the tile table 64 M entries) -- not an error
 int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val, const unsigned char *skip = nullptr);
 bool validate_two_phase(const Plan &p, std::string &why);
 

@@ -99,8 +99,8 @@ int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val, cons
     const int n_rb = t.n_rb();
     // the automatic rule's last word: every non-empty (row block, column block) tile is padded to whole 64-element segments, and a row block holds at most
     // rbm rows -- a large, very sparse matrix (50 M rows of 3 nonzeros: 1526 column blocks, ~8 nonzeros per tile) would store several times its nonzeros and keep
-    // n_rb * n_cb * 20 bytes of tables on the host.  Declined (kTpDeclined: build_impl goes on to column panels / the plain plan) when the padded streams pass 2.5 x the
-    // nonzeros (webbase-1M x4, 1.59 x, wins 53.0 against 61.5 us; x16, 2.1 x, 281 against 325 us; the form's time follows its padded size, so ~2.4 x is the break-even there) or the tile table passes 64 M entries; a forced two_phase = 1 is built as asked.
+    // n_rb * n_cb * 20 bytes of tables on the host.  Declined (kTpDeclined: build_impl goes on to column panels / the plain plan) when the padded streams pass 3 x the
+    // nonzeros (webbase-1M x4, 1.59 x padding, wins 53.0 against 61.5 us; x16, 2.69 x, 291.9 against 328.2 us; the form's time follows its padded size, so ~3 x is the break-even there) or the tile table passes 64 M entries; a forced two_phase = 1 is built as asked.
     const bool may_decline = p.opt.two_phase == 0;
     long long nnz_here = 0;
     for (int r = 0; r < m; ++r) nnz_here += len_of(r);
@@ -125,7 +125,7 @@ int build_two_phase(Plan &p, const int *rp, const int *ci, const void *val, cons
         for (int c = 0; c < n_cb; ++c)
             for (int b = 0; b < n_rb; ++b) { const size_t i = (size_t)b * (size_t)n_cb + (size_t)c; off1[i] = run1; run1 += segs_of(i); }
         if (run != run1) { set_error("two_phase: internal offset mismatch"); return DASP_ERR_STATE; }
-        if (may_decline && 2 * run * kTpSeg > 5 * nnz_here) { t = TwoPhase{}; return kTpDeclined; }
+        if (may_decline && run * kTpSeg > 3 * nnz_here) { t = TwoPhase{}; return kTpDeclined; }
         if (run >= (1ll << 31) / 2) { set_error("two_phase: too many segments for 32-bit segment indices"); return DASP_ERR_ARG; }
         t.segments = (size_t)run;
     }

@@ -192,7 +192,7 @@ typedef struct dasp_options {
      * stay those of the whole matrix; products are f16 x f16 accumulated in f64 (the order of a row's additions is not fixed: LDS atomics).
      *   0 = auto: f16, no column remap, no explicit col_panels, >= 10 M nonzeros whose rows scatter (> 50 % of a sampled row's nonzeros on distinct 128-byte lines of x,
      *       a third of the entries in rows spanning > x/4; hub rows are fine: same-row elements are combined before they reach LDS); 1 = force; -1 = off.
-     *       The automatic rule also declines (the matrix keeps its DASP form) when the tiles' padding to whole 64-element segments would store > 2.5 x the nonzeros
+     *       The automatic rule also declines (the matrix keeps its DASP form) when the tiles' padding to whole 64-element segments would store > 3 x the nonzeros
      *       (large, very sparse matrices: few nonzeros per tile) or the tile table would pass 64 M entries.
      *   DETERMINISM: this is the one form whose results are not bit-reproducible from run to run -- a row's products reach its f64 LDS accumulator through relaxed
      *   atomics, so their order of addition is not fixed (the f64 sum rounds ~2^-53; the difference shows only where the final rounding to f16 sits on a tie).  Every other
