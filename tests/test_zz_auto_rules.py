@@ -3,7 +3,7 @@
 For ~20 structures -- three sizes each of a band (cop20k_A), a stencil / FEM mesh (nlpkkt160, HV15R), a power-law and an R-MAT graph, plus circuit-like, all-short and
 all-long matrices -- the plan the library builds by itself is timed against the same matrix with ONE knob forced the other way (x windows on / off, column panels 1 / 2 /
 4, the two-phase form on / off, column-blocked hub rows on / off, slabs on / off, 16-bit and one-byte ids on / off, medium rows as pieces on / off, wave-segmented short
-rows on / off).  The automatic plan may not be more than 7 % slower than the best of them.  Pairs that are known to lose more are listed in KNOWN with the measured ratio
+rows on / off).  The automatic plan may not be more than 7 % slower than the best of them (10 % for launches under 10 us).  Pairs that are known to lose more are listed in KNOWN with the measured ratio
 (an honest table, not a waiver: a KNOWN entry that no longer loses fails too, so that the list shrinks).  Last in the alphabet on purpose: with `pytest -x` a noisy box
 fails this file, not the parity tests behind it.  The table of a run goes to gpurun_out/r6_auto_rules.md (committed copy: profiles/r06_auto_rules.md).
 
@@ -154,20 +154,21 @@ def test_automatic_plan_is_within_7_percent_of_every_forced_form(dasp, torch_cud
                 if env is not None:
                     del os.environ[env[0]]
             t = _time(torch, plan, x, y, ci.size)
+            tol = TOL if t_auto >= 10e-3 else TOL + 0.03     # (launches under 10 us: back-to-back means differ by 2-3 % from process to process)
             for _ in range(3):                             # before calling it a loss: both again, interleaved, the fastest of each kept
-                if t_auto <= TOL * t:
+                if t_auto <= tol * t:
                     break
                 t_auto = min(t_auto, _time(torch, auto, x, y, ci.size))
                 t = min(t, _time(torch, plan, x, y, ci.size))
-            alts.append((klabel, t))
+            alts.append((klabel, t, tol))
             plan.close()
-        best = min(alts, key=lambda a: a[1]) if alts else ("-", t_auto)
+        best = min(alts, key=lambda a: a[1]) if alts else ("-", t_auto, TOL)
         b_alg = ci.size * (prec // 8 + 4) + (m + 1) * 4 + (n + m) * (prec // 8)
         table.append((label, ci.size, form, t_auto * 1e3, b_alg / (t_auto * 1e6) / 8000, best[0], best[1] * 1e3, t_auto / best[1]))
-        for klabel, t in alts:
+        for klabel, t, tol in alts:
             ratio = t_auto / t
             known = KNOWN.get((label, klabel))
-            if ratio > TOL and known is None:
+            if ratio > tol and known is None:
                 bad.append("%s: automatic %.1f us, '%s' %.1f us (%.2f x)" % (label, t_auto * 1e3, klabel, t * 1e3, ratio))
             if known is not None and ratio <= 1.0:
                 stale.append("%s / %s: listed in KNOWN at %.2f x, now %.2f x" % (label, klabel, known, ratio))
