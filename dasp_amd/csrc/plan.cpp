@@ -482,7 +482,28 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
         // Only where those degenerate rows are most of the candidates: rows of 12..24 in a band keep their blocks and with them the LDS windows (4.2)
         long long cand_nnz = 0, tiny_nnz = 0;
         for (int i = nmf; i < nmed_all; ++i) { cand_nnz += lenM[i]; if (lenM[i] < 12) tiny_nnz += lenM[i]; }
-        const int within = f16 && 2 * tiny_nnz >= cand_nnz ? 512 : 16;
+        // r6: ... or where ONE length holds >= 80 % of the candidates' nonzeros (13- / 19-point stencils, fixed-valence meshes in f16): rows of one length keep their
+        // neighbours under the length sort, and as slabs they run half as long again (r5, profiles/r05_category_sweep.md 16: 4 M rows of 17 0.413 -> 0.615 of the roofline,
+        // 3 M rows of 24 0.445 -> 0.666), while thirteen lengths 12..24 -- whose equally long rows lie 13 rows apart -- keep the windows (0.568 against 0.484)
+        long long dom_nnz = 0;
+        for (int i = nmf; i < nmed_all; ) { int j = i; while (j < nmed_all && lenM[j] == lenM[i]) ++j; dom_nnz = std::max(dom_nnz, (long long)(j - i) * lenM[i]); i = j; }
+        // ... whose OWN columns run along lines of x (a slab lane walks its row: consecutive steps then hit the line the last one fetched): under 30 % of a sampled row's
+        // entries on another 128-byte line than their predecessor.  Rows of 12 with columns anywhere within +-500 of the diagonal pass the neighbour test too and LOSE as slabs
+        // (120 k rows, f16: 6.3 us against 4.2 as blocks, gpurun_out/r6/call21.txt)
+        bool dom_runs = false;
+        if (f16 && 5 * dom_nnz >= 4 * cand_nnz && !pairs.empty()) {
+            long long lines = 0, ent = 0;
+            if (dev) { std::vector<int> firsts; for (size_t q = 0; q < pairs.size(); q += 2) firsts.push_back(pairs[q]); if (int rc = devpack_line_scatter(p, *dev, firsts, &lines, &ent)) return rc; }
+            else
+            for (size_t q = 0; q < pairs.size(); q += 2) {
+                const int b = rp[pairs[q]], e = rp[pairs[q] + 1];
+                int prev = remap(ci[b]) >> 6; lines += 1;
+                for (int j = b + 1; j < e; ++j) { const int l = remap(ci[j]) >> 6; lines += l != prev; prev = l; }
+                ent += e - b;
+            }
+            dom_runs = ent > 0 && 10 * lines < 3 * ent;
+        }
+        const int within = f16 && (2 * tiny_nnz >= cand_nnz || dom_runs) ? 512 : 16;
         if (dev) { if (int rc = devpack_row_coherence(p, *dev, pairs, within, &near, &entries)) return rc; }
         else
             for (size_t q = 0; q + 1 < pairs.size(); q += 2) {
@@ -768,6 +789,47 @@ static int build_impl(Plan &p, const int *rp, const int *ci, const T *val, const
                 }
             }
             worth = entries > 0 && (double)lines >= 0.6 * (double)entries;
+            // r6: ... and only when a row's columns spread over more x than the L1 holds anyway.  The CORE span of a row -- 10th to 90th percentile of its columns, so that
+            // a few outliers do not count -- times the value size, median over the sampled rows: under 16 KB the 16 rows of a block gather from a few KB each and hit the
+            // L1, and the window's copy -> barrier -> blocks chain only costs (rows of 12 within +-500 columns + 10 % anywhere: 120 k rows f64 7.5 us with hybrid windows
+            // against 5.3-5.7 without, f16 6.0 / 4.2; 1 M rows f64 61.5 / 44.2; 500 k rows of 14 within +-3000 f16 25.2 / 19.6 -- while +-8000 f64 (102 KB) 181 -> 151 us,
+            // 200 k rows of 30 within +-2000 f64 (26 KB) 25.9 -> 22.7 and cop20k_A (51 KB) keep them: tools/hybrid_probe.py, gpurun_out/r6/call19.txt, call20.txt)
+            if (worth && p.opt.x_window_hybrid <= 0) {      // (a caller who forces the hybrid windows keeps them)
+                std::vector<int> fetched;
+                if (dev) {
+                    std::vector<long long> idx;
+                    for (int r : sample) for (int j = rp[r], e = std::min(rp[r + 1], rp[r] + 512); j < e; ++j) idx.push_back(j);
+                    if (int rc = devpack_gather_columns(p, *dev, &idx, 0, 0, 0, fetched)) return rc;
+                }
+                std::vector<long long> spans;
+                std::vector<int> cols;
+                size_t fpos = 0;
+                for (int r : sample) {
+                    const int b = rp[r], e = std::min(rp[r + 1], b + 512), len = e - b;
+                    cols.resize((size_t)len);
+                    if (dev) { for (int j = 0; j < len; ++j) cols[(size_t)j] = fetched[fpos + (size_t)j]; fpos += (size_t)len; }
+                    else for (int j = 0; j < len; ++j) cols[(size_t)j] = remap(ci[b + j]);
+                    if (len < 4) continue;
+                    std::sort(cols.begin(), cols.end());
+                    spans.push_back((long long)cols[(size_t)(len - 1 - len / 10)] - cols[(size_t)(len / 10)] + 1);
+                }
+                // ... provided the global length sort leaves neighbouring rows in one block (rows of one length: the block's 16 rows then share those few KB).  Rows of many
+                // lengths end up in blocks of rows from all over the matrix -- 16 such regions per chunk -- and keep their windows whatever their own span: cop20k_A in f16
+                // (12.8 KB per row) 6.9 -> 6.5 us, x4 22.0 -> 17.3 with windows.  The measure of the rule below: sampled blocks of the sorted order whose rows lie far apart.
+                int far = 0, cnt = 0;
+                {
+                    const int nblk = nmed / kMedRows, bstep = std::max(1, nblk / 512);
+                    for (int b = 0; b < nblk; b += bstep) {
+                        int lo = 2147483647, hi = -1;
+                        for (int i = b * kMedRows; i < (b + 1) * kMedRows; ++i) { lo = std::min(lo, ridM[i]); hi = std::max(hi, ridM[i]); }
+                        far += hi - lo > 16 * kMedRows; ++cnt;
+                    }
+                }
+                if (!spans.empty() && 2 * far < cnt) {
+                    std::nth_element(spans.begin(), spans.begin() + (long long)(spans.size() / 2), spans.end());
+                    if (spans[spans.size() / 2] * geo.vbytes < 16 * 1024) worth = false;
+                }
+            }
             // ... or when it is the GLOBAL LENGTH SORT that scatters: rows of many different lengths whose columns are local (the strict windows fit, so they are) end up in
             // blocks of 16 rows from all over the matrix -- 16 regions of x per chunk whatever the rows' own runs.  Windows sort inside R rows only and stage those rows' x
             // (late r5, tools/scratch/window_order_probe.py / window_size_probe.py: 1 M local rows of 5..255 f64 0.571 -> 0.792 of the roofline, f16 0.623 -> 0.892; 4 M rows of
@@ -1336,7 +1398,9 @@ static int decide_panels(const Plan &p, const int *rp, const int *ci, const Rema
         int distinct = 1;
         for (int j = 1; j < take; ++j) distinct += (cols[j] >> line_shift) != (cols[j - 1] >> line_shift);
         entries += take; lines += distinct;
-        if ((long long)(cols[take - 1] - cols[0]) * vb > xbytes / 4) wide += take;
+        // (r6: the span of the row's CORE -- 10th to 90th percentile of its columns: a banded row with a few entries anywhere is not a wide row; 1 M rows of 12 within +-500
+        // columns + 10 % anywhere in f16 took the two-phase form and ran 35.2 us against 22.6 as plain blocks, tests/test_zz_auto_rules.py)
+        if ((long long)(cols[take - 1 - take / 10] - cols[take / 10]) * vb > xbytes / 4) wide += take;
     }
     if (entries < 4096) return 1;
     // the two-phase form pays from a weaker scatter on (rmat_2M f16: 0.69 lines per entry, 49 % of the entries in wide rows: 0.135 -> 0.094 ms) than cache blocking does

@@ -350,13 +350,17 @@ def test_auto_hybrid_windows_need_even_rows_and_keep_the_format(dasp, prec):
     m = n = 120000
     dt = np.float64 if prec == 64 else np.float16
 
-    def cols(rows):
-        return np.where(rng.random(rows.size) < 0.9, np.clip(rows + rng.integers(-500, 501, rows.size), 0, n - 1), rng.integers(0, n, rows.size)).astype(np.int32)
+    def cols(rows, half=6000, near=0.95):
+        return np.where(rng.random(rows.size) < near, np.clip(rows + rng.integers(-half, half + 1, rows.size), 0, n - 1), rng.integers(0, n, rows.size)).astype(np.int32)
     rp = (np.arange(m + 1, dtype=np.int64) * 12).astype(np.int32)
+    # r6: a NARROW band (+-500 columns: a row's gathers span a few KB, and rows of one length keep their neighbours in a block) stays without windows -- the L1 serves it;
+    # measured: 120 k such rows f64 7.5 us with hybrid windows against 5.7 without, 1 M rows 61.5 / 44.2 (plan.cpp, the core-span condition)
+    narrow = cols(np.repeat(np.arange(m), 12), 500, 0.9)
+    assert dasp.Plan(rp, narrow, np.ones(narrow.size, dt), n, precision=prec, slab_max_len=4).stats["x_window_on"] == 0
     ci = cols(np.repeat(np.arange(m), 12))
     plan = dasp.Plan(rp, ci, np.ones(ci.size, dt), n, precision=prec)
     st = plan.stats
-    assert st["x_window_on"] == 1 and st["x_window_hybrid"] == 1 and 0.8 < st["window_nnz_frac"] < 0.97 and st["lds_bytes"] <= 81920
+    assert st["x_window_on"] == 1 and st["x_window_hybrid"] == 1 and 0.6 < st["window_nnz_frac"] < 0.97 and st["lds_bytes"] <= 81920, st
     rows = util.decode_plan(plan)
     order = plan.order_rid
     for slot in list(range(0, m, 997)):

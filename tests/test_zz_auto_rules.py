@@ -65,6 +65,13 @@ KNOWN = {
     ("circuit-like, 262144 rows of 1..8 + 16 rows of 50 000 f16", "slabs up to 16"): 1.12,
     ("circuit-like, 1048576 rows of 1..8 + 16 rows of 50 000 f64", "x windows forced (160 KiB)"): 1.11,
     ("circuit-like, 1048576 rows of 1..8 + 16 rows of 50 000 f64", "slabs up to 16"): 1.08,
+    # rows of one length with columns anywhere inside a band (+ a few anywhere), f16: slabs or the two-phase form would win where the band is wider than the L1 serves;
+    # the slab rule asks for runs along lines of x, the two-phase rule for rows whose core spans a quarter of x
+    ("band + outliers: 500000 rows of 14 within +-3000, 0.1 anywhere f16", "slabs up to 16"): 1.20,
+    ("band + outliers: 1000000 rows of 14 within +-8000, 0.03 anywhere f16", "slabs up to 16"): 1.23,
+    ("band + outliers: 1000000 rows of 14 within +-8000, 0.03 anywhere f16", "two-phase on"): 1.23,
+    ("rows of 17 in runs, 1048576 rows f64", "x windows forced (160 KiB)"): 1.10,          # 18 M nonzeros of local rows of one length: windows would still gain 9-10 %
+    ("rows of 24 in runs, 1048576 rows f64", "x windows forced (160 KiB)"): 1.09,
 }
 
 
@@ -87,6 +94,14 @@ def _numpy_cases():
         out.append(("all-short 1..4, %d rows" % sz, lambda sz=sz: from_lengths(rng.integers(1, 5, sz), sz, 64)))
     for rows in (2000, 16000, 64000):
         out.append(("all-long 300, %d rows" % rows, lambda rows=rows: from_lengths(np.full(rows, 300), 16 * rows, 4096)))
+    def band(m, per, half, far):          # rows of one length, columns anywhere within +-half of the diagonal, a share `far` of them anywhere (tools/hybrid_probe.py)
+        rows = np.repeat(np.arange(m, dtype=np.int64), per)
+        ci = np.where(rng.random(rows.size) < far, rng.integers(0, m, rows.size), np.clip(rows + rng.integers(-half, half + 1, rows.size), 0, m - 1))
+        return (np.arange(m + 1, dtype=np.int64) * per).astype(np.int32), ci.astype(np.int32), m
+    for m, per, half, far in ((120000, 12, 500, 0.1), (1000000, 12, 500, 0.1), (500000, 14, 3000, 0.1), (200000, 30, 2000, 0.05), (1000000, 14, 8000, 0.03)):
+        out.append(("band + outliers: %d rows of %d within +-%d, %g anywhere" % (m, per, half, far), lambda m=m, per=per, half=half, far=far: band(m, per, half, far)))
+    for rows, L in ((1 << 20, 17), (1 << 20, 24)):
+        out.append(("rows of %d in runs, %d rows" % (L, rows), lambda rows=rows, L=L: from_lengths(np.full(rows, L), rows, 256)))
     for sz in (M // 4, M):
         out.append(("circuit-like, %d rows of 1..8 + 16 rows of 50 000" % sz,
                     lambda sz=sz: from_lengths(np.concatenate([rng.integers(1, 9, sz - 16), np.full(16, 50000)])[rng.permutation(sz)], sz, 256)))
