@@ -1373,6 +1373,7 @@ static int decide_panels(const Plan &p, const int *rp, const int *ci, const Rema
     const int line_shift = vb == 8 ? 4 : 6;                       // 128-byte lines of x
     const int S = 4096;
     long long entries = 0, lines = 0, wide = 0;
+    std::vector<long long> core_spans;          // per sampled row: 10th to 90th percentile of its columns
     std::vector<int> cols;
     // device CSR (r3): the sampled rows' column ids are gathered by a kernel and copied over (<= 2 M ids), the rule itself is the same
     std::vector<int> fetched;
@@ -1398,13 +1399,25 @@ static int decide_panels(const Plan &p, const int *rp, const int *ci, const Rema
         int distinct = 1;
         for (int j = 1; j < take; ++j) distinct += (cols[j] >> line_shift) != (cols[j - 1] >> line_shift);
         entries += take; lines += distinct;
-        // (r6: the span of the row's CORE -- 10th to 90th percentile of its columns: a banded row with a few entries anywhere is not a wide row; 1 M rows of 12 within +-500
-        // columns + 10 % anywhere in f16 took the two-phase form and ran 35.2 us against 22.6 as plain blocks, tests/test_zz_auto_rules.py)
-        if ((long long)(cols[take - 1 - take / 10] - cols[take / 10]) * vb > xbytes / 4) wide += take;
+        if ((long long)(cols[take - 1] - cols[0]) * vb > xbytes / 4) wide += take;
+        core_spans.push_back((long long)cols[take - 1 - take / 10] - cols[take / 10] + 1);
     }
     if (entries < 4096) return 1;
     // the two-phase form pays from a weaker scatter on (rmat_2M f16: 0.69 lines per entry, 49 % of the entries in wide rows: 0.135 -> 0.094 ms) than cache blocking does
-    if (scattered && (double)lines > 0.5 * (double)entries && (double)wide >= 0.33 * (double)entries) *scattered = 1;
+    // r6 (tests/test_zz_auto_rules.py): not scattered where the L1 serves the gathers anyway -- rows of (nearly) one length, which keep their neighbours under the length
+    // sort, whose CORE spans under 16 KB of x however far a few of their entries reach: 1 M rows of 12 within +-500 columns + 10 % anywhere in f16 took the two-phase form
+    // and ran 35.2 us against 22.6 as plain blocks.  (webbase-like rows -- many lengths, so blocks of unrelated rows -- stay scattered: x4 51.1 against 61.8 us two-phase.)
+    bool l1_served = false;
+    if (!core_spans.empty()) {
+        std::nth_element(core_spans.begin(), core_spans.begin() + (long long)(core_spans.size() / 2), core_spans.end());
+        if (core_spans[core_spans.size() / 2] * vb < 16 * 1024) {
+            std::vector<long long> by_len(257, 0);
+            long long med_nnz = 0;
+            for (int i = 0; i < p.m; ++i) { const int len = rp[i + 1] - rp[i]; if (len >= 5 && len < p.opt.block_longest && len <= 256) { by_len[(size_t)len] += len; med_nnz += len; } }
+            l1_served = med_nnz > 0 && 5 * *std::max_element(by_len.begin(), by_len.end()) >= 4 * med_nnz && 2 * med_nnz >= (long long)p.nnz;
+        }
+    }
+    if (scattered && !l1_served && (double)lines > 0.5 * (double)entries && (double)wide >= 0.33 * (double)entries) *scattered = 1;
     if (p.nnz < (16 << 20)) return 1;
     if ((double)lines <= 0.75 * (double)entries || (double)wide < 0.5 * (double)entries) return 1;
     if (xbytes <= (4ll << 20)) {      // x fits an XCD's L2: nothing to block (A/B: 2.9 MB loses 10 %, 4.4 MB wins 11 %) ...

@@ -70,6 +70,7 @@ KNOWN = {
     ("band + outliers: 500000 rows of 14 within +-3000, 0.1 anywhere f16", "slabs up to 16"): 1.20,
     ("band + outliers: 1000000 rows of 14 within +-8000, 0.03 anywhere f16", "slabs up to 16"): 1.23,
     ("band + outliers: 1000000 rows of 14 within +-8000, 0.03 anywhere f16", "two-phase on"): 1.23,
+    ("band + outliers: 1000000 rows of 12 within +-500, 0.1 anywhere f16", "slabs up to 16"): 1.16,
     ("rows of 17 in runs, 1048576 rows f64", "x windows forced (160 KiB)"): 1.10,          # 18 M nonzeros of local rows of one length: windows would still gain 9-10 %
     ("rows of 24 in runs, 1048576 rows f64", "x windows forced (160 KiB)"): 1.09,
 }
