@@ -55,7 +55,7 @@ KNOBS = [
 ]
 
 # (case label, knob label) -> the ratio auto / forced measured when the entry was written (> TOL): what the automatic rules are known to leave on the table (r6, three runs on
-# three boxes: gpurun_out/r6/auto_rules{8,9,10}.md; DESIGN.md section 9 says why each is still there)
+# three boxes: profiles/r06_auto_rules.md is the last of them; DESIGN.md section 9 says why each is still there)
 KNOWN = {
     ("FEM: HV15R x0.01 f64", "16-bit ids off"): 1.15,                     # 30 MB: the 16-bit ids lose here and win 9 % on nlpkkt160 x0.01 (26 MB) -- the rule knows sizes, not block shapes
     ("FEM: HV15R x0.01 f64", "one-byte ids off"): 1.15,
