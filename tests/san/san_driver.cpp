@@ -41,6 +41,8 @@ static void plans_of(const Csr &c, const std::string &scratch, int tag)
         {-1, 0, -1, 3, 12, -1, 40, -1, -1, 0, 1.0, 256}, {163840, 256, 1, 1, 4, 1, -1, 0, 0, 1, 0.25, 128}, {-1, 0, 1, 1, 32, -1, 5, 1, 0, 0, 0.75, 1000000},
         // r5: the two-phase form (f16 only: applied to the f16 plan of the pair), small blocks so that every matrix has many tiles; column panels with column-blocked long rows
         {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.75, 256, 1, 0, 64, 16}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0.75, 256, 1, 0, 0, 0}, {-1, 0, 0, 3, 0, -1, 0, 0, 0, 0, 0.75, 64, -1, 1, 0, 0}, {-1, 0, 0, 2, 0, -1, 0, 0, 0, 1, 0.75, 256, -1, 1, 0, 0},
+        // r6: the f16 hybrid (hub rows of a two-phase plan column-blocked: forced, rows of >= 64), both y orders; window heights that are not a multiple of 64 (whole blocks)
+        {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.75, 64, 1, 1, 256, 64}, {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0.75, 64, 1, 1, 0, 0}, {81920, 432, 1, 1, 4, -1, -1, 0, 0, 0, 0.75, 256}, {81920, 80, 0, 1, 4, -1, -1, 0, 0, 1, 0.75, 256},
     };
     int k = 0;
     for (const O &o : opts) {
